@@ -1,0 +1,56 @@
+// Shared helpers for the gfx950 kernels of libdvis_hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/dvis_hip.h"
+
+#define DVIS_EXPORT extern "C" __attribute__((visibility("default")))
+
+void dvis_set_error(const char *fmt, ...);
+
+// Check the launch that was just enqueued; report instead of printf-and-continue.
+static inline int dvis_check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    dvis_set_error("%s: %s", what, hipGetErrorString(e));
+    return DVIS_E_LAUNCH;
+  }
+  return DVIS_OK;
+}
+
+#define DVIS_REQUIRE(cond, ...)      \
+  do {                               \
+    if (!(cond)) {                   \
+      dvis_set_error(__VA_ARGS__);   \
+      return DVIS_E_ARG;             \
+    }                                \
+  } while (0)
+
+// fp32 <-> storage type conversions used by the generic (any-dtype) kernels.
+template <typename T> struct dvis_acc { using type = float; };
+template <> struct dvis_acc<double> { using type = double; };
+
+template <typename A, typename T> __device__ __forceinline__ A dvis_load(const T *p) { return (A)(*p); }
+template <> __device__ __forceinline__ float dvis_load<float, __half>(const __half *p) { return __half2float(*p); }
+template <> __device__ __forceinline__ float dvis_load<float, __hip_bfloat16>(const __hip_bfloat16 *p) {
+  return __bfloat162float(*p);
+}
+template <typename T, typename A> __device__ __forceinline__ void dvis_store(T *p, A v) { *p = (T)v; }
+template <> __device__ __forceinline__ void dvis_store<__half, float>(__half *p, float v) { *p = __float2half(v); }
+template <> __device__ __forceinline__ void dvis_store<__hip_bfloat16, float>(__hip_bfloat16 *p, float v) {
+  *p = __float2bfloat16(v);
+}
+
+typedef unsigned dvis_v4u __attribute__((ext_vector_type(4)));
+typedef float dvis_f4 __attribute__((ext_vector_type(4)));
+typedef float dvis_f16v __attribute__((ext_vector_type(16)));
+
+// Wave-uniform buffer descriptor over [base, base + bytes): loads past the end return 0 in hardware.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dvis_make_rsrc(const void *base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}

@@ -1,0 +1,87 @@
+// Host-side linear sum assignment for the tracker's query matching (Noiser.match_embds,
+// dvis_Plus/noiser.py:43-56 calls scipy.optimize.linear_sum_assignment(C.T)[1]).
+//
+// scipy (pinned scipy==1.5.4 in the reference's requirements.txt; 1.15.3 in this image) is an un-vendored
+// third-party dependency; its solver is the shortest-augmenting-path algorithm of
+//   D. F. Crouse, "On implementing 2D rectangular assignment algorithms", IEEE TAES 52(4), 2016
+// (a Jonker-Volgenant variant with dual variables u, v).  This file restates that published algorithm.
+// To return the SAME permutation on degenerate (tied) cost matrices the scan conventions that decide
+// ties are kept: unscanned columns are visited from a list initialised in descending column order with
+// swap-with-last removal, and among equal shortest-path costs an unassigned column is preferred.
+// Index parity is pinned by tests/golden/g5_match.npz (random, permuted, duplicated-row and zero-vector cases).
+#include <cmath>
+#include <limits>
+#include <vector>
+
+#include "dvis_common.h"
+
+DVIS_EXPORT int dvis_lsap_solve(const double *cost, int nr, int nc, int64_t *col4row_out) {
+  DVIS_REQUIRE(cost && col4row_out, "lsap: null pointer");
+  DVIS_REQUIRE(nr >= 0 && nc >= 0 && nr <= nc, "lsap: need 0 <= nr <= nc (got %d x %d)", nr, nc);
+  for (long long k = 0; k < (long long)nr * nc; ++k)
+    DVIS_REQUIRE(!(std::isnan(cost[k]) || cost[k] == -std::numeric_limits<double>::infinity()),
+                 "lsap: cost matrix contains nan or -inf");
+  const double INF = std::numeric_limits<double>::infinity();
+  std::vector<double> u(nr, 0.0), v(nc, 0.0), dist(nc);
+  std::vector<int> path(nc, -1), col4row(nr, -1), row4col(nc, -1), todo(nc);
+  std::vector<char> rowSeen(nr), colSeen(nc);
+
+  for (int cur = 0; cur < nr; ++cur) {
+    // ---- shortest augmenting path from row `cur` to an unassigned column
+    std::fill(rowSeen.begin(), rowSeen.end(), 0);
+    std::fill(colSeen.begin(), colSeen.end(), 0);
+    std::fill(dist.begin(), dist.end(), INF);
+    int ntodo = nc;
+    for (int t = 0; t < nc; ++t) todo[t] = nc - 1 - t;
+    double minVal = 0.0;
+    int i = cur, sink = -1;
+    while (sink < 0) {
+      int pick = -1;
+      double lowest = INF;
+      rowSeen[i] = 1;
+      const double *ci = cost + (long long)i * nc;
+      for (int t = 0; t < ntodo; ++t) {
+        const int j = todo[t];
+        const double r = minVal + ci[j] - u[i] - v[j];
+        if (r < dist[j]) {
+          dist[j] = r;
+          path[j] = i;
+        }
+        if (dist[j] < lowest || (dist[j] == lowest && row4col[j] < 0)) {
+          lowest = dist[j];
+          pick = t;
+        }
+      }
+      minVal = lowest;
+      if (minVal == INF) {
+        dvis_set_error("lsap: cost matrix is infeasible");
+        return DVIS_E_ARG;
+      }
+      const int j = todo[pick];
+      if (row4col[j] < 0)
+        sink = j;
+      else
+        i = row4col[j];
+      colSeen[j] = 1;
+      todo[pick] = todo[--ntodo];
+    }
+    // ---- dual update
+    u[cur] += minVal;
+    for (int r = 0; r < nr; ++r)
+      if (rowSeen[r] && r != cur) u[r] += minVal - dist[col4row[r]];
+    for (int j = 0; j < nc; ++j)
+      if (colSeen[j]) v[j] -= minVal - dist[j];
+    // ---- flip the assignments along the path
+    int j = sink;
+    while (true) {
+      const int r = path[j];
+      row4col[j] = r;
+      const int prev = col4row[r];
+      col4row[r] = j;
+      j = prev;
+      if (r == cur) break;
+    }
+  }
+  for (int r = 0; r < nr; ++r) col4row_out[r] = col4row[r];
+  return DVIS_OK;
+}

@@ -1,0 +1,118 @@
+// Multi-scale deformable attention, backward — gfx950.
+//
+// Replaces ms_deformable_col2im_cuda and its 7 kernel variants
+// (ops/src/cuda/ms_deform_im2col_cuda.cuh:306-925, host :961-1331; wrapper ms_deform_attn_cuda.cu:88-158).
+// The reference picks a kernel by D (blocksize-aware / dynamic-smem / multi-block / global-atomic) because it
+// assigns one thread per channel and reduces grad_loc / grad_w through shared memory.  Here a GROUP of 32 or
+// 64 lanes (half / full wavefront) owns one (n, q, m) pair for every D: lanes stride over channels, the three
+// scalar gradients of a sample are reduced with wavefront shuffles (no LDS, no __syncthreads), and grad_value
+// gets lane-contiguous atomics (one 128-byte line per corner for D = 32).
+//   d out / d w      = sum_c go[c] * bilinear(v)[c]
+//   d out / d loc_x  = W * w * sum_c go[c] * (hh (v2 - v1) + lh (v4 - v3))      (corners outside the map = 0)
+//   d out / d loc_y  = H * w * sum_c go[c] * (hw (v3 - v1) + lw (v4 - v2))
+//   d out / d v_k[c] = go[c] * w * corner_weight_k
+#include "dvis_common.h"
+
+namespace {
+
+template <typename A, int GS>
+__device__ __forceinline__ A group_sum(A v) {
+#pragma unroll
+  for (int o = GS / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, GS);
+  return v;
+}
+
+template <typename T, int GS>
+__global__ __launch_bounds__(256) void msda_bwd_kernel(
+    const T *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
+    const T *__restrict__ loc, const T *__restrict__ w, const T *__restrict__ grad_out, size_t npairs, int S, int M,
+    int D, int L, int Lq, int P, T *__restrict__ grad_value, T *__restrict__ grad_loc, T *__restrict__ grad_w) {
+  constexpr int GPB = 256 / GS;
+  const int gl = threadIdx.x % GS;
+  const size_t pix = (size_t)M * D;
+  for (size_t pair = (size_t)blockIdx.x * GPB + threadIdx.x / GS; pair < npairs; pair += (size_t)gridDim.x * GPB) {
+    const int m = (int)(pair % M);
+    const size_t n = pair / ((size_t)Lq * M);
+    const T *go = grad_out + pair * D;
+    for (int l = 0; l < L; ++l) {
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      const size_t lbase = ((n * S + (size_t)level_start[l]) * M + m) * D;
+      for (int p = 0; p < P; ++p) {
+        const size_t s = pair * (size_t)(L * P) + (size_t)l * P + p;
+        const T x = loc[2 * s], y = loc[2 * s + 1], aw = w[s];
+        const T h_im = y * (T)H - (T)0.5, w_im = x * (T)W - (T)0.5;
+        T gw = 0, gx = 0, gy = 0;
+        if (h_im > (T)-1 && w_im > (T)-1 && h_im < (T)H && w_im < (T)W) {   // group-uniform branch
+          const T hf = floor(h_im), wf = floor(w_im);
+          const int h0 = (int)hf, w0 = (int)wf;
+          const T lh = h_im - hf, lw = w_im - wf, hh = (T)1 - lh, hw = (T)1 - lw;
+          const bool ok1 = h0 >= 0 && w0 >= 0, ok2 = h0 >= 0 && w0 + 1 <= W - 1;
+          const bool ok3 = h0 + 1 <= H - 1 && w0 >= 0, ok4 = h0 + 1 <= H - 1 && w0 + 1 <= W - 1;
+          const long long i1 = (long long)lbase + ((long long)h0 * W + w0) * (long long)pix;
+          const long long i2 = i1 + (long long)pix, i3 = i1 + (long long)W * (long long)pix, i4 = i3 + (long long)pix;
+          for (int c = gl; c < D; c += GS) {
+            const T a = ok1 ? value[i1 + c] : (T)0, b = ok2 ? value[i2 + c] : (T)0;
+            const T e = ok3 ? value[i3 + c] : (T)0, f = ok4 ? value[i4 + c] : (T)0;
+            const T g = go[c];
+            gw += g * (hh * hw * a + hh * lw * b + lh * hw * e + lh * lw * f);
+            gx += g * (hh * (b - a) + lh * (f - e));
+            gy += g * (hw * (e - a) + lw * (f - b));
+            const T ga = g * aw;
+            if (ok1) atomicAdd(grad_value + i1 + c, ga * hh * hw);
+            if (ok2) atomicAdd(grad_value + i2 + c, ga * hh * lw);
+            if (ok3) atomicAdd(grad_value + i3 + c, ga * lh * hw);
+            if (ok4) atomicAdd(grad_value + i4 + c, ga * lh * lw);
+          }
+        }
+        gw = group_sum<T, GS>(gw);
+        gx = group_sum<T, GS>(gx);
+        gy = group_sum<T, GS>(gy);
+        if (gl == 0) {
+          grad_w[s] = gw;
+          grad_loc[2 * s] = gx * aw * (T)W;
+          grad_loc[2 * s + 1] = gy * aw * (T)H;
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+int launch_bwd(const void *value, const int64_t *shapes, const int64_t *ls, const void *loc, const void *w,
+               const void *go, int N, int S, int M, int D, int L, int Lq, int P, void *gv, void *gl, void *gw,
+               hipStream_t st) {
+  const size_t npairs = (size_t)N * Lq * M;
+  if (D <= 32) {
+    const size_t blocks = (npairs + 7) / 8;
+    hipLaunchKernelGGL((msda_bwd_kernel<T, 32>), dim3((unsigned)(blocks > 262144 ? 262144 : blocks)), dim3(256), 0, st,
+                       (const T *)value, shapes, ls, (const T *)loc, (const T *)w, (const T *)go, npairs, S, M, D, L,
+                       Lq, P, (T *)gv, (T *)gl, (T *)gw);
+  } else {
+    const size_t blocks = (npairs + 3) / 4;
+    hipLaunchKernelGGL((msda_bwd_kernel<T, 64>), dim3((unsigned)(blocks > 262144 ? 262144 : blocks)), dim3(256), 0, st,
+                       (const T *)value, shapes, ls, (const T *)loc, (const T *)w, (const T *)go, npairs, S, M, D, L,
+                       Lq, P, (T *)gv, (T *)gl, (T *)gw);
+  }
+  return dvis_check_launch("msda_bwd_kernel");
+}
+
+}  // namespace
+
+DVIS_EXPORT int dvis_msda_backward(int dtype, const void *value, const int64_t *shapes, const int64_t *level_start,
+                                   const void *loc, const void *w, const void *grad_out, int N, int S, int M, int D,
+                                   int L, int Lq, int P, void *grad_value, void *grad_loc, void *grad_w,
+                                   void *stream) {
+  DVIS_REQUIRE(value && shapes && level_start && loc && w && grad_out && grad_value && grad_loc && grad_w,
+               "msda_backward: null pointer");
+  DVIS_REQUIRE(N >= 0 && S > 0 && M > 0 && D > 0 && L > 0 && Lq >= 0 && P > 0, "msda_backward: bad sizes");
+  if (N == 0 || Lq == 0) return DVIS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DVIS_F32)
+    return launch_bwd<float>(value, shapes, level_start, loc, w, grad_out, N, S, M, D, L, Lq, P, grad_value, grad_loc,
+                             grad_w, st);
+  if (dtype == DVIS_F64)
+    return launch_bwd<double>(value, shapes, level_start, loc, w, grad_out, N, S, M, D, L, Lq, P, grad_value, grad_loc,
+                              grad_w, st);
+  dvis_set_error("msda_backward: only fp32 / fp64 gradients are supported (got dtype %d)", dtype);
+  return DVIS_E_UNSUPPORTED;
+}

@@ -1,0 +1,347 @@
+// Multi-scale deformable attention, forward — gfx950 (MI355X).
+//
+// Replaces ms_deformable_im2col_gpu_kernel + host wrapper of the reference
+// (mask2former/modeling/pixel_decoder/ops/src/cuda/ms_deform_im2col_cuda.cuh:242-304,
+//  ms_deform_attn_cuda.cu:25-85).  Semantics (restated):
+//   out[n,q,m,:] = sum_{l,p} w[n,q,m,l,p] * bilinear(value[n, level l, :, m, :], (x*W_l-0.5, y*H_l-0.5))
+//   sample counted iff -1 < h_im < H and -1 < w_im < W; corners outside the map contribute 0.
+//
+// Design (not the reference's one-thread-per-output-channel decomposition):
+//   * The op is a GATHER bound by the vector-memory path, not by flops.  A workgroup owns ONE head m
+//     and 64 consecutive queries of one frame; blockIdx % M == m, so with M == 8 every XCD (block b
+//     runs on XCD b % 8) touches only its own head's 1/8 slice of `value` and that slice
+//     (2.5 MB/frame at 720p) stays resident in the XCD's private 4 MB L2.
+//   * A (query, head) pair is served by D/4 lanes, each owning 4 channels: one corner of one sample
+//     is ONE 16-byte load per lane = a whole 128-byte line per pair (D = 32), 8 pairs per
+//     wave-instruction.  The reference issues 4-byte loads and re-reads (loc, w) per channel thread.
+//   * (loc, w) of the block are staged once through LDS with coalesced 16-byte reads and then
+//     broadcast-read by the D/4 lanes of a pair (identical LDS addresses broadcast, no conflict).
+//   * Corner loads go through wave-uniform buffer descriptors, one per level, sized to the level's
+//     slice: an out-of-map corner gets an out-of-range offset and the hardware returns 0 — no
+//     per-corner branch, no clamped re-read, exact zero padding.
+//   * FUSED variant: the LDS stage also applies softmax over (L*P) and loc = ref + off / (W_l, H_l)
+//     (ops/modules/ms_deform_attn.py:101-109), so sampling_locations / attention_weights
+//     (22 MB per frame-layer at 720p) never exist in HBM.
+//   * Any dtype / D / L / P outside the tiled set falls to the generic kernel (one thread per output
+//     element, fp32 or fp64 accumulation) — correctness path for fp64, fp16/bf16 and odd D.
+#include "dvis_common.h"
+
+namespace {
+
+#ifndef DVIS_MSDA_WAVES_PER_SIMD
+#define DVIS_MSDA_WAVES_PER_SIMD 4  // register budget: 4 waves/SIMD (512/4 = 128 VGPRs) ~ 24 corner loads in flight per wave
+#endif
+
+constexpr int kQB = 64;        // queries per workgroup (tiled kernel)
+constexpr unsigned kOOB = 0x80000000u;  // buffer offset beyond every level slice (< 2 GiB, checked on host)
+
+template <int D, int L, int P, bool FUSED>
+__global__ __launch_bounds__(256, DVIS_MSDA_WAVES_PER_SIMD) void msda_fwd_tile_f32(
+    const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
+    const float *__restrict__ loc_or_off, int64_t off_stride, const float *__restrict__ w_or_logit,
+    int64_t logit_stride, const float *__restrict__ refp, int nref, int S, int M, int Lq, int nchunks,
+    float *__restrict__ out) {
+  constexpr int LP = L * P;
+  constexpr int G = D / 4;          // lanes per (query, head) pair
+  constexpr int GPW = 64 / G;       // pairs per wave-instruction
+  constexpr int LOCV = LP / 2;      // float4s of (x, y) per pair
+  constexpr int WV = LP / 4;        // float4s of weights per pair
+  constexpr int ITERS = kQB / (4 * GPW);
+  static_assert(LP % 4 == 0 && D % 4 == 0 && 64 % G == 0, "tile shape");
+
+  __shared__ float4 s_loc[kQB * LOCV];
+  __shared__ float4 s_w[kQB * WV];
+
+  const int tid = threadIdx.x;
+  const int m = blockIdx.x % M;
+  const int rest = blockIdx.x / M;
+  const int chunk = rest % nchunks;
+  const int n = rest / nchunks;
+  const int q0 = chunk * kQB;
+  const int MD = M * D;
+
+  int Hs[L], Ws[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    Hs[l] = (int)shapes[2 * l];
+    Ws[l] = (int)shapes[2 * l + 1];
+  }
+
+  // ---- stage (loc, w) [or raw (offsets, logits)] of this block's 64 queries x 1 head into LDS
+  for (int i = tid; i < kQB * LOCV; i += 256) {
+    const int ql = i / LOCV, k = i - ql * LOCV;
+    const int q = q0 + ql;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < Lq) {
+      const size_t row = (size_t)n * Lq + q;
+      const float *src = FUSED ? loc_or_off + row * off_stride + (size_t)m * (LP * 2) + 4 * k
+                               : loc_or_off + (row * M + m) * (size_t)(LP * 2) + 4 * k;
+      v = *reinterpret_cast<const float4 *>(src);
+    }
+    s_loc[i] = v;
+  }
+  for (int i = tid; i < kQB * WV; i += 256) {
+    const int ql = i / WV, k = i - ql * WV;
+    const int q = q0 + ql;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < Lq) {
+      const size_t row = (size_t)n * Lq + q;
+      const float *src = FUSED ? w_or_logit + row * logit_stride + (size_t)m * LP + 4 * k
+                               : w_or_logit + (row * M + m) * (size_t)LP + 4 * k;
+      v = *reinterpret_cast<const float4 *>(src);
+    }
+    s_w[i] = v;
+  }
+  if (FUSED) {
+    __syncthreads();
+    float *lf = reinterpret_cast<float *>(s_loc);
+    float *wf = reinterpret_cast<float *>(s_w);
+    // loc = ref + off / (W_l, H_l)
+    for (int i = tid; i < kQB * LP; i += 256) {
+      const int ql = i / LP, s = i - ql * LP;
+      const int l = s / P;
+      const int q = q0 + ql;
+      if (q < Lq) {
+        int Hl = Hs[0], Wl = Ws[0];
+#pragma unroll
+        for (int ll = 1; ll < L; ++ll)
+          if (l == ll) { Hl = Hs[ll]; Wl = Ws[ll]; }
+        const size_t rrow = ((size_t)(nref == 1 ? 0 : n) * Lq + q) * L + l;
+        const float rx = refp[rrow * 2], ry = refp[rrow * 2 + 1];
+        lf[ql * LP * 2 + 2 * s] = rx + lf[ql * LP * 2 + 2 * s] / (float)Wl;
+        lf[ql * LP * 2 + 2 * s + 1] = ry + lf[ql * LP * 2 + 2 * s + 1] / (float)Hl;
+      }
+    }
+    // softmax over the L*P logits of each (query, head)
+    if (tid < kQB) {
+      float *row = wf + tid * LP;
+      float mx = row[0];
+#pragma unroll
+      for (int s = 1; s < LP; ++s) mx = fmaxf(mx, row[s]);
+      float e[LP], sum = 0.f;
+#pragma unroll
+      for (int s = 0; s < LP; ++s) { e[s] = expf(row[s] - mx); sum += e[s]; }
+#pragma unroll
+      for (int s = 0; s < LP; ++s) row[s] = e[s] / sum;
+    }
+  }
+  __syncthreads();
+
+  // ---- per-level buffer descriptors over this (frame, head) slice
+  __amdgpu_buffer_rsrc_t rs[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const float *base = value + (((size_t)n * S + (size_t)level_start[l]) * M + m) * D;
+    const unsigned bytes = (unsigned)(((size_t)(Hs[l] * Ws[l] - 1) * MD + D) * sizeof(float));
+    rs[l] = dvis_make_rsrc(base, bytes);
+  }
+
+  const int lane = tid & 63, wv = tid >> 6;
+  const int g = lane / G, j = lane - g * G;
+  const unsigned pix_bytes = (unsigned)MD * 4u;
+  const unsigned lane_bytes = (unsigned)j * 16u;
+
+#pragma unroll 1
+  for (int it = 0; it < ITERS; ++it) {
+    const int ql = (it * 4 + wv) * GPW + g;
+    const int q = q0 + ql;
+    const bool active = q < Lq;
+
+    float lf[LP * 2], wf[LP];
+#pragma unroll
+    for (int k = 0; k < LOCV; ++k) {
+      const float4 v = s_loc[ql * LOCV + k];
+      lf[4 * k] = v.x; lf[4 * k + 1] = v.y; lf[4 * k + 2] = v.z; lf[4 * k + 3] = v.w;
+    }
+#pragma unroll
+    for (int k = 0; k < WV; ++k) {
+      const float4 v = s_w[ql * WV + k];
+      wf[4 * k] = v.x; wf[4 * k + 1] = v.y; wf[4 * k + 2] = v.z; wf[4 * k + 3] = v.w;
+    }
+
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const int H = Hs[l], W = Ws[l];
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int s = l * P + p;
+        const float h_im = lf[2 * s + 1] * (float)H - 0.5f;
+        const float w_im = lf[2 * s] * (float)W - 0.5f;
+        const bool ok = active && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+        const float hf = floorf(h_im), wf_ = floorf(w_im);
+        const int h0 = (int)hf, w0 = (int)wf_;
+        const float lh = h_im - hf, lw = w_im - wf_;
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const bool h0ok = ok && h0 >= 0, h1ok = ok && h0 + 1 <= H - 1;
+        const bool w0ok = w0 >= 0, w1ok = w0 + 1 <= W - 1;
+        const unsigned o00 = (unsigned)(h0 * W + w0) * pix_bytes + lane_bytes;
+        const unsigned o01 = o00 + pix_bytes;
+        const unsigned o10 = o00 + (unsigned)W * pix_bytes;
+        const unsigned o11 = o10 + pix_bytes;
+        const dvis_v4u r1 = __builtin_amdgcn_raw_buffer_load_b128(rs[l], (h0ok && w0ok) ? o00 : kOOB, 0, 0);
+        const dvis_v4u r2 = __builtin_amdgcn_raw_buffer_load_b128(rs[l], (h0ok && w1ok) ? o01 : kOOB, 0, 0);
+        const dvis_v4u r3 = __builtin_amdgcn_raw_buffer_load_b128(rs[l], (h1ok && w0ok) ? o10 : kOOB, 0, 0);
+        const dvis_v4u r4 = __builtin_amdgcn_raw_buffer_load_b128(rs[l], (h1ok && w1ok) ? o11 : kOOB, 0, 0);
+        const float c1 = hh * hw, c2 = hh * lw, c3 = lh * hw, c4 = lh * lw;
+        const float aw = ok ? wf[s] : 0.f;
+        const float c1v = ok ? c1 : 0.f, c2v = ok ? c2 : 0.f, c3v = ok ? c3 : 0.f, c4v = ok ? c4 : 0.f;
+        // reference order: (w1 v1 + w2 v2 + w3 v3 + w4 v4) * weight, accumulated over samples
+        a0 += (c1v * __uint_as_float(r1.x) + c2v * __uint_as_float(r2.x) + c3v * __uint_as_float(r3.x) +
+               c4v * __uint_as_float(r4.x)) * aw;
+        a1 += (c1v * __uint_as_float(r1.y) + c2v * __uint_as_float(r2.y) + c3v * __uint_as_float(r3.y) +
+               c4v * __uint_as_float(r4.y)) * aw;
+        a2 += (c1v * __uint_as_float(r1.z) + c2v * __uint_as_float(r2.z) + c3v * __uint_as_float(r3.z) +
+               c4v * __uint_as_float(r4.z)) * aw;
+        a3 += (c1v * __uint_as_float(r1.w) + c2v * __uint_as_float(r2.w) + c3v * __uint_as_float(r3.w) +
+               c4v * __uint_as_float(r4.w)) * aw;
+      }
+    }
+    if (active) {
+      float *dst = out + (((size_t)n * Lq + q) * M + m) * D + 4 * j;
+      *reinterpret_cast<float4 *>(dst) = make_float4(a0, a1, a2, a3);
+    }
+  }
+}
+
+// One thread per output element; any dtype, any D / L / P.  fp64 accumulates in fp64, the rest in fp32.
+template <typename T>
+__global__ __launch_bounds__(256) void msda_fwd_generic(
+    const T *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
+    const T *__restrict__ loc, const T *__restrict__ w, size_t total, int S, int M, int D, int L, int Lq, int P,
+    T *__restrict__ out) {
+  using A = typename dvis_acc<T>::type;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % D);
+    size_t t = idx / D;
+    const int m = (int)(t % M);
+    t /= M;
+    const int q = (int)(t % Lq);
+    const size_t n = t / Lq;
+    const size_t pair = (n * Lq + q) * M + m;
+    const T *lp = loc + pair * (size_t)(L * P * 2);
+    const T *wp = w + pair * (size_t)(L * P);
+    const size_t pix = (size_t)M * D;
+    A col = 0;
+    for (int l = 0; l < L; ++l) {
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      const T *vb = value + ((n * S + (size_t)level_start[l]) * M + m) * D + c;
+      for (int p = 0; p < P; ++p) {
+        const A x = dvis_load<A>(lp + 2 * (l * P + p));
+        const A y = dvis_load<A>(lp + 2 * (l * P + p) + 1);
+        const A aw = dvis_load<A>(wp + l * P + p);
+        const A h_im = y * (A)H - (A)0.5, w_im = x * (A)W - (A)0.5;
+        if (h_im > (A)-1 && w_im > (A)-1 && h_im < (A)H && w_im < (A)W) {
+          const A hf = floor(h_im), wf = floor(w_im);
+          const int h0 = (int)hf, w0 = (int)wf;
+          const A lh = h_im - hf, lw = w_im - wf, hh = (A)1 - lh, hw = (A)1 - lw;
+          A v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+          if (h0 >= 0 && w0 >= 0) v1 = dvis_load<A>(vb + ((size_t)h0 * W + w0) * pix);
+          if (h0 >= 0 && w0 + 1 <= W - 1) v2 = dvis_load<A>(vb + ((size_t)h0 * W + w0 + 1) * pix);
+          if (h0 + 1 <= H - 1 && w0 >= 0) v3 = dvis_load<A>(vb + ((size_t)(h0 + 1) * W + w0) * pix);
+          if (h0 + 1 <= H - 1 && w0 + 1 <= W - 1) v4 = dvis_load<A>(vb + ((size_t)(h0 + 1) * W + w0 + 1) * pix);
+          col += (hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4) * aw;
+        }
+      }
+    }
+    dvis_store<T, A>(out + idx, col);
+  }
+}
+
+template <typename T>
+int launch_generic(const void *value, const int64_t *shapes, const int64_t *ls, const void *loc, const void *w, int N,
+                   int S, int M, int D, int L, int Lq, int P, void *out, hipStream_t st) {
+  const size_t total = (size_t)N * Lq * M * D;
+  const size_t blocks = (total + 255) / 256;
+  const unsigned grid = (unsigned)(blocks > 65536 ? 65536 : blocks);
+  hipLaunchKernelGGL(msda_fwd_generic<T>, dim3(grid), dim3(256), 0, st, (const T *)value, shapes, ls, (const T *)loc,
+                     (const T *)w, total, S, M, D, L, Lq, P, (T *)out);
+  return dvis_check_launch("msda_fwd_generic");
+}
+
+template <int D, int L, int P, bool FUSED>
+int launch_tile(const float *value, const int64_t *shapes, const int64_t *ls, const float *a, int64_t a_stride,
+                const float *b, int64_t b_stride, const float *refp, int nref, int N, int S, int M, int Lq, float *out,
+                hipStream_t st) {
+  const int nchunks = (Lq + kQB - 1) / kQB;
+  const size_t grid = (size_t)N * nchunks * M;
+  if (grid > 0x7fffffffu) {
+    dvis_set_error("msda: grid too large");
+    return DVIS_E_ARG;
+  }
+  hipLaunchKernelGGL((msda_fwd_tile_f32<D, L, P, FUSED>), dim3((unsigned)grid), dim3(256), 0, st, value, shapes, ls, a,
+                     a_stride, b, b_stride, refp, nref, S, M, Lq, nchunks, out);
+  return dvis_check_launch("msda_fwd_tile_f32");
+}
+
+template <bool FUSED>
+int dispatch_tile(int D, int L, int P, const float *value, const int64_t *shapes, const int64_t *ls, const float *a,
+                  int64_t a_stride, const float *b, int64_t b_stride, const float *refp, int nref, int N, int S, int M,
+                  int Lq, float *out, hipStream_t st, bool *handled) {
+  *handled = true;
+#define DVIS_TILE_CASE(d, l, p)  \
+  if (D == d && L == l && P == p) \
+    return launch_tile<d, l, p, FUSED>(value, shapes, ls, a, a_stride, b, b_stride, refp, nref, N, S, M, Lq, out, st);
+  DVIS_TILE_CASE(32, 3, 4)
+  DVIS_TILE_CASE(32, 4, 4)
+  DVIS_TILE_CASE(32, 1, 4)
+  DVIS_TILE_CASE(64, 1, 4)
+  DVIS_TILE_CASE(64, 3, 4)
+  DVIS_TILE_CASE(64, 4, 4)
+#undef DVIS_TILE_CASE
+  *handled = false;
+  return DVIS_OK;
+}
+
+bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
+
+}  // namespace
+
+DVIS_EXPORT int dvis_msda_forward(int dtype, const void *value, const int64_t *shapes, const int64_t *level_start,
+                                  const void *loc, const void *w, int N, int S, int M, int D, int L, int Lq, int P,
+                                  void *out, void *stream) {
+  DVIS_REQUIRE(value && shapes && level_start && loc && w && out, "msda_forward: null pointer");
+  DVIS_REQUIRE(N >= 0 && S > 0 && M > 0 && D > 0 && L > 0 && Lq >= 0 && P > 0, "msda_forward: bad sizes");
+  if (N == 0 || Lq == 0) return DVIS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DVIS_F32) {
+    const bool fits = (size_t)S * M * D * sizeof(float) < 0x7fffffffu;
+    if (fits && aligned16(value) && aligned16(loc) && aligned16(w) && aligned16(out)) {
+      bool handled = false;
+      int rc = dispatch_tile<false>(D, L, P, (const float *)value, shapes, level_start, (const float *)loc, 0,
+                                    (const float *)w, 0, nullptr, 0, N, S, M, Lq, (float *)out, st, &handled);
+      if (handled) return rc;
+    }
+    return launch_generic<float>(value, shapes, level_start, loc, w, N, S, M, D, L, Lq, P, out, st);
+  }
+  if (dtype == DVIS_F64) return launch_generic<double>(value, shapes, level_start, loc, w, N, S, M, D, L, Lq, P, out, st);
+  if (dtype == DVIS_F16) return launch_generic<__half>(value, shapes, level_start, loc, w, N, S, M, D, L, Lq, P, out, st);
+  if (dtype == DVIS_BF16)
+    return launch_generic<__hip_bfloat16>(value, shapes, level_start, loc, w, N, S, M, D, L, Lq, P, out, st);
+  dvis_set_error("msda_forward: unsupported dtype %d", dtype);
+  return DVIS_E_ARG;
+}
+
+DVIS_EXPORT int dvis_msda_fused_forward(const float *value, const int64_t *shapes, const int64_t *level_start,
+                                        const float *ref, int Nref, const float *offsets, int64_t off_stride,
+                                        const float *logits, int64_t logit_stride, int N, int S, int M, int D, int L,
+                                        int Lq, int P, float *out, void *stream) {
+  DVIS_REQUIRE(value && shapes && level_start && ref && offsets && logits && out, "msda_fused_forward: null pointer");
+  DVIS_REQUIRE(N >= 0 && S > 0 && M > 0 && D > 0 && L > 0 && Lq >= 0 && P > 0, "msda_fused_forward: bad sizes");
+  DVIS_REQUIRE(Nref == 1 || Nref == N, "msda_fused_forward: Nref must be 1 or N");
+  DVIS_REQUIRE(off_stride >= (int64_t)M * L * P * 2 && logit_stride >= (int64_t)M * L * P,
+               "msda_fused_forward: row strides too small");
+  DVIS_REQUIRE(off_stride % 4 == 0 && logit_stride % 4 == 0 && aligned16(offsets) && aligned16(logits) &&
+                   aligned16(value) && aligned16(out),
+               "msda_fused_forward: 16-byte alignment required");
+  DVIS_REQUIRE((size_t)S * M * D * sizeof(float) < 0x7fffffffu, "msda_fused_forward: frame slice >= 2 GiB");
+  if (N == 0 || Lq == 0) return DVIS_OK;
+  bool handled = false;
+  int rc = dispatch_tile<true>(D, L, P, value, shapes, level_start, offsets, off_stride, logits, logit_stride, ref,
+                               Nref, N, S, M, Lq, out, (hipStream_t)stream, &handled);
+  if (handled) return rc;
+  dvis_set_error("msda_fused_forward: unsupported (D=%d, L=%d, P=%d); supported D in {32,64}, (L,P) in {(1,4),(3,4),(4,4)}",
+                 D, L, P);
+  return DVIS_E_UNSUPPORTED;
+}

@@ -1,0 +1,129 @@
+"""Op front-ends over the C ABI: the Python surface the reference's callers bind to.
+
+``ms_deform_attn_forward`` / ``ms_deform_attn_backward`` have the signature of the reference's
+pybind exports (ops/src/vision.cpp:18-21, ops/src/ms_deform_attn.h:25-66) and ``MSDeformAttnFunction``
+that of ops/functions/ms_deform_attn_func.py:32-49, so ``MSDeformAttn`` / ViT-Adapter call sites work
+unchanged.  Differences, all deliberate:
+  * any batch size (the ``N % im2col_step`` assertion of ms_deform_attn_cuda.cu:55-57 is not needed;
+    ``im2col_step`` is accepted and ignored),
+  * fp16 / bf16 tensors are accepted in forward (fp32 accumulation) besides float / double,
+  * failures raise ``RuntimeError`` — there is no torch/CPU fallback to hide them.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import native
+
+
+def _check_msda_inputs(value, spatial_shapes, level_start_index, sampling_loc, attn_weight):
+    for name, t in (("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+                    ("sampling_loc", sampling_loc), ("attn_weight", attn_weight)):
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} tensor has to be contiguous")
+        if not t.is_cuda:
+            raise RuntimeError(f"{name} must be a GPU tensor (no CPU implementation; got {t.device})")
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise RuntimeError("spatial_shapes / level_start_index must be int64")
+    if value.dim() != 4 or sampling_loc.dim() != 6 or attn_weight.dim() != 5:
+        raise RuntimeError("expected value (N,S,M,D), sampling_loc (N,Lq,M,L,P,2), attn_weight (N,Lq,M,L,P)")
+    if not (value.dtype == sampling_loc.dtype == attn_weight.dtype):
+        raise RuntimeError("value, sampling_loc and attn_weight must share one dtype")
+    N, S, M, D = value.shape
+    N2, Lq, M2, L, P, two = sampling_loc.shape
+    if (N2, M2, two) != (N, M, 2) or tuple(attn_weight.shape) != (N, Lq, M, L, P) or spatial_shapes.shape != (L, 2) \
+            or level_start_index.shape != (L,):
+        raise RuntimeError("inconsistent shapes between value / sampling_loc / attn_weight / spatial_shapes")
+    return N, S, M, D, L, Lq, P
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step=128):
+    """-> (N, Lq, M*D).  Drop-in for ``MultiScaleDeformableAttention.ms_deform_attn_forward``."""
+    N, S, M, D, L, Lq, P = _check_msda_inputs(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    with torch.cuda.device(value.device):
+        rc = native.lib().dvis_msda_forward(
+            native.dtype_code(value), native.dev_ptr(value, "value"), native.dev_ptr(spatial_shapes, "spatial_shapes"),
+            native.dev_ptr(level_start_index, "level_start_index"), native.dev_ptr(sampling_loc, "sampling_loc"),
+            native.dev_ptr(attn_weight, "attn_weight"), N, S, M, D, L, Lq, P, native.dev_ptr(out, "out"),
+            native.stream_ptr(value.device))
+    native.check(rc, "dvis_msda_forward")
+    return out
+
+
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
+                            im2col_step=128):
+    """-> [grad_value, grad_sampling_loc, grad_attn_weight] (ops/src/ms_deform_attn.h:47-66)."""
+    N, S, M, D, L, Lq, P = _check_msda_inputs(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    if not grad_output.is_cuda:
+        raise RuntimeError("grad_output must be a GPU tensor")
+    grad_output = grad_output.contiguous()
+    if grad_output.dtype != value.dtype or grad_output.numel() != N * Lq * M * D:
+        raise RuntimeError("grad_output must be (N, Lq, M*D) with value's dtype")
+    grad_value = torch.zeros_like(value)
+    grad_loc = torch.empty_like(sampling_loc)
+    grad_w = torch.empty_like(attn_weight)
+    with torch.cuda.device(value.device):
+        rc = native.lib().dvis_msda_backward(
+            native.dtype_code(value), native.dev_ptr(value, "value"), native.dev_ptr(spatial_shapes, "spatial_shapes"),
+            native.dev_ptr(level_start_index, "level_start_index"), native.dev_ptr(sampling_loc, "sampling_loc"),
+            native.dev_ptr(attn_weight, "attn_weight"), native.dev_ptr(grad_output, "grad_output"),
+            N, S, M, D, L, Lq, P, native.dev_ptr(grad_value, "grad_value"), native.dev_ptr(grad_loc, "grad_loc"),
+            native.dev_ptr(grad_w, "grad_w"), native.stream_ptr(value.device))
+    native.check(rc, "dvis_msda_backward")
+    return [grad_value, grad_loc, grad_w]
+
+
+class MSDeformAttnFunction(Function):
+    """Same contract as the reference's autograd wrapper (ops/functions/ms_deform_attn_func.py:32-49)."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
+                im2col_step):
+        ctx.im2col_step = im2col_step
+        output = ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                                        attention_weights, im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                              attention_weights)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, level_start, loc, w = ctx.saved_tensors
+        grad_value, grad_loc, grad_w = ms_deform_attn_backward(value, shapes, level_start, loc, w, grad_output,
+                                                               ctx.im2col_step)
+        return grad_value, None, None, grad_loc, grad_w, None
+
+
+def msda_fused_forward(value, spatial_shapes, level_start_index, reference_points, offsets, logits, n_levels,
+                       n_points):
+    """Inference fast path of ``MSDeformAttn.forward`` (ops/modules/ms_deform_attn.py:101-117), fp32.
+
+    value (N,S,M,D); reference_points (1|N, Lq, L, 2); ``offsets`` / ``logits`` are 2-D row views
+    (N*Lq, >= M*L*P*2) / (N*Lq, >= M*L*P) of the raw linear outputs (row stride may exceed the width, e.g.
+    both sliced out of one fused projection).  softmax + location arithmetic happen inside the kernel.
+    """
+    N, S, M, D = value.shape
+    L, P = n_levels, n_points
+    nref, Lq = reference_points.shape[0], reference_points.shape[1]
+    for name, t in (("value", value), ("reference_points", reference_points)):
+        native.dev_ptr(t, name)
+    for name, t in (("offsets", offsets), ("logits", logits)):
+        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or t.shape[0] != N * Lq:
+            raise RuntimeError(f"{name} must be a float32 GPU (N*Lq, width) row view with unit inner stride")
+    if value.dtype != torch.float32 or reference_points.dtype != torch.float32:
+        raise RuntimeError("msda_fused_forward is fp32 only")
+    if offsets.shape[1] < M * L * P * 2 or logits.shape[1] < M * L * P or reference_points.shape[2:] != (L, 2):
+        raise RuntimeError("msda_fused_forward: inconsistent shapes")
+    out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    with torch.cuda.device(value.device):
+        rc = native.lib().dvis_msda_fused_forward(
+            native.dev_ptr(value, "value"), native.dev_ptr(spatial_shapes, "spatial_shapes"),
+            native.dev_ptr(level_start_index, "level_start_index"), native.dev_ptr(reference_points, "ref"), nref,
+            ctypes.c_void_p(offsets.data_ptr()), offsets.stride(0), ctypes.c_void_p(logits.data_ptr()),
+            logits.stride(0), N, S, M, D, L, Lq, P, native.dev_ptr(out, "out"), native.stream_ptr(value.device))
+    native.check(rc, "dvis_msda_fused_forward")
+    return out

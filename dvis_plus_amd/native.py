@@ -1,0 +1,73 @@
+"""ctypes binding of libdvis_hip.so — the C ABI declared in include/dvis_hip.h.
+
+This is the ONLY way product code reaches the kernels.  There is no CPU or eager fallback: if the
+library is missing, or an entry point is called on non-GPU memory, a ``RuntimeError`` is raised
+(the reference instead swallows every failure, ops/modules/ms_deform_attn.py:116-121).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdvis_hip.so")
+
+F32, F64, F16, BF16 = 0, 1, 2, 3
+_DTYPE = {torch.float32: F32, torch.float64: F64, torch.float16: F16, torch.bfloat16: BF16}
+
+_c = ctypes
+_i, _i64, _p, _f = _c.c_int, _c.c_int64, _c.c_void_p, _c.c_float
+
+# name -> (restype, argtypes); mirrors include/dvis_hip.h one-to-one (checked by tests/test_abi.py)
+SIGNATURES = {
+    "dvis_last_error": (_c.c_char_p, []),
+    "dvis_version": (_i, []),
+    "dvis_msda_forward": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "dvis_msda_backward": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "dvis_msda_fused_forward": (_i, [_p, _p, _p, _p, _i, _p, _i64, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "dvis_lsap_solve": (_i, [_p, _i, _i, _p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built — never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -m dvis_plus_amd.build` "
+                "(__graft_entry__.build()).  dvis_plus_amd has no CPU/eager fallback.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().dvis_last_error().decode()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def dtype_code(t):
+    try:
+        return _DTYPE[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"unsupported dtype {t.dtype}") from None
+
+
+def dev_ptr(t, name):
+    """Device pointer of a contiguous GPU tensor; loud failure otherwise."""
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a GPU tensor (dvis_plus_amd has no CPU path); got device {t.device}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} tensor has to be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

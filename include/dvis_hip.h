@@ -1,0 +1,95 @@
+/*
+ * dvis_hip.h — C ABI of libdvis_hip.so: the MI355X (gfx950) hot path of DVIS++.
+ *
+ * Every entry point takes plain DEVICE pointers + sizes + a hipStream_t (passed
+ * as void*; NULL = the null stream), enqueues asynchronously on that stream,
+ * allocates nothing, keeps no reference to its arguments and is re-entrant.
+ * Return value: 0 on success, a negative DVIS_E_* code otherwise;
+ * dvis_last_error() returns a thread-local human-readable message.  Launch
+ * failures are reported (the reference only printf()s them:
+ * ops/src/cuda/ms_deform_im2col_cuda.cuh:953-957).
+ *
+ * Reference interfaces replaced (paths relative to /root/reference/DVIS_Plus):
+ *   dvis_msda_forward        <- ms_deform_attn_forward,  mask2former/modeling/pixel_decoder/ops/src/ms_deform_attn.h:25-45
+ *                               (kernel ops/src/cuda/ms_deform_im2col_cuda.cuh:242-304, host ms_deform_attn_cuda.cu:25-85)
+ *   dvis_msda_backward       <- ms_deform_attn_backward, ops/src/ms_deform_attn.h:47-66 (ms_deform_attn_cuda.cu:88-158)
+ *   dvis_msda_fused_forward  <- softmax + location arithmetic + op of MSDeformAttn.forward,
+ *                               ops/modules/ms_deform_attn.py:101-117 (no materialised loc / weights)
+ *   dvis_mask_logits         <- einsum("bqc,bchw->bqhw"), dvis_Plus/video_mask2former_transformer_decoder.py:363
+ *   dvis_attn_mask           <- einsum + F.interpolate + (sigmoid < 0.5) of forward_prediction_heads, ibid. :363-371,
+ *                               plus the "fully masked row" reset at :297
+ *   dvis_attention_forward   <- nn.MultiheadAttention core (softmax(QK^T/sqrt(d) [+mask]) V) as used by
+ *                               CrossAttentionLayer / SelfAttentionLayer (mask2former_video/.../video_mask2former_transformer_decoder.py:18-136),
+ *                               ReferringCrossAttentionLayer (dvis_Plus/tracker.py:8-92), TemporalRefiner (dvis_Plus/refiner.py:104-139)
+ *   dvis_lsap_solve          <- scipy.optimize.linear_sum_assignment as called by Noiser.match_embds, dvis_Plus/noiser.py:43-56
+ */
+#ifndef DVIS_HIP_H
+#define DVIS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* element types of floating tensors */
+enum { DVIS_F32 = 0, DVIS_F64 = 1, DVIS_F16 = 2, DVIS_BF16 = 3 };
+
+/* error codes */
+enum {
+  DVIS_OK = 0,
+  DVIS_E_ARG = -1,      /* bad argument (null pointer, non-positive size, unsupported dtype) */
+  DVIS_E_LAUNCH = -2,   /* hipLaunchKernel / hipGetLastError failed */
+  DVIS_E_UNSUPPORTED = -3
+};
+
+const char *dvis_last_error(void);
+int dvis_version(void);
+
+/*
+ * Multi-scale deformable attention, forward.
+ *   value   (N, S, M, D)          dtype
+ *   shapes  (L, 2) int64 [H_l, W_l]    DEVICE memory (reference contract, ms_deform_attn_cuda.cu:39-41)
+ *   level_start (L,) int64              DEVICE memory
+ *   loc     (N, Lq, M, L, P, 2)   dtype, normalised (x, y)
+ *   w       (N, Lq, M, L, P)      dtype
+ *   out     (N, Lq, M*D)          dtype, fully overwritten (no need to pre-zero)
+ * out[n,q,m,:] = sum_{l,p} w * bilinear(value[n, level l, :, m, :], (x*W_l - 0.5, y*H_l - 0.5)), zero padding.
+ * Any N is accepted (the reference's N % im2col_step constraint is not needed).
+ */
+int dvis_msda_forward(int dtype, const void *value, const int64_t *shapes, const int64_t *level_start,
+                      const void *loc, const void *w, int N, int S, int M, int D, int L, int Lq, int P,
+                      void *out, void *stream);
+
+/*
+ * Backward.  grad_value (N,S,M,D), grad_loc (N,Lq,M,L,P,2), grad_w (N,Lq,M,L,P): grad_value MUST be
+ * zero-filled by the caller (it is accumulated with atomics); grad_loc / grad_w are fully overwritten.
+ */
+int dvis_msda_backward(int dtype, const void *value, const int64_t *shapes, const int64_t *level_start,
+                       const void *loc, const void *w, const void *grad_out,
+                       int N, int S, int M, int D, int L, int Lq, int P,
+                       void *grad_value, void *grad_loc, void *grad_w, void *stream);
+
+/*
+ * Fused forward (fp32): takes the RAW outputs of the sampling_offsets / attention_weights linears.
+ *   offsets  rows of (M, L, P, 2) floats, row stride `off_stride` floats, one row per (n, q)
+ *   logits   rows of (M, L*P)     floats, row stride `logit_stride` floats
+ *   ref      (Nref, Lq, L, 2) reference points; Nref == 1 broadcasts over the batch
+ * loc = ref[:, :, None, :, None, :] + offsets / (W_l, H_l);  w = softmax over (L*P) — ms_deform_attn.py:101-109.
+ */
+int dvis_msda_fused_forward(const float *value, const int64_t *shapes, const int64_t *level_start,
+                            const float *ref, int Nref, const float *offsets, int64_t off_stride,
+                            const float *logits, int64_t logit_stride,
+                            int N, int S, int M, int D, int L, int Lq, int P, float *out, void *stream);
+
+/*
+ * HOST function: minimum-cost assignment of an nr x nc (nr <= nc) row-major double cost matrix,
+ * shortest-augmenting-path (Jonker-Volgenant / Crouse 2016) like scipy.optimize.linear_sum_assignment;
+ * col4row[i] = column assigned to row i.  Returns 0, or DVIS_E_ARG for nan/-inf entries or nr > nc.
+ */
+int dvis_lsap_solve(const double *cost, int nr, int nc, int64_t *col4row);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVIS_HIP_H */

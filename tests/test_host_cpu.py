@@ -1,0 +1,38 @@
+"""CPU: host-side behaviour that needs no GPU — loud failures, library symbols."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT, make_msda_inputs
+
+
+def test_ops_refuse_cpu_tensors():
+    from dvis_plus_amd.functions import MSDeformAttnFunction
+    value, s, lsi, loc, w = make_msda_inputs(1, 2, 4, [(3, 3)], 5, 2, torch.float32, 1)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        MSDeformAttnFunction.apply(value, s, lsi, loc, w, 128)
+
+
+def test_library_exports_every_declared_symbol():
+    """include/dvis_hip.h <-> libdvis_hip.so <-> native.SIGNATURES stay in sync (no compute calls here)."""
+    from dvis_plus_amd import native
+    hdr = open(os.path.join(ROOT, "include", "dvis_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(dvis_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(native.SIGNATURES), declared ^ set(native.SIGNATURES)
+    if not os.path.exists(native.LIB_PATH):
+        import dvis_plus_amd.build as b
+        b.build()
+    lib = ctypes.CDLL(native.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/dvis_hip.h but not exported"
+    assert native.lib().dvis_version() >= 100
+
+
+def test_import_name_shim():
+    import MultiScaleDeformableAttention as MSDA
+    assert callable(MSDA.ms_deform_attn_forward) and callable(MSDA.ms_deform_attn_backward)

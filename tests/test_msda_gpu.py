@@ -1,0 +1,199 @@
+"""GPU parity: the HIP MSDA kernels (through the C ABI / MSDeformAttnFunction) vs the oracle and goldens.
+
+Tolerances: fp64 1e-12 (the reference's own fp64 check is allclose defaults, ops/test.py:43);
+fp32 atol 1e-5 + rtol 1e-4 — two orders inside the reference's own fp32 acceptance (rtol 1e-2, atol 1e-3,
+ops/test.py:59) and inside the 1e-3 of BASELINE.json.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, Golden, make_msda_inputs, level_tensors
+from oracle import msda as omsda
+
+pytestmark = pytest.mark.gpu
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "g1_msda_*.npz")))
+DEV = "cuda:0"
+
+
+def _fn():
+    from dvis_plus_amd.functions import MSDeformAttnFunction
+    return MSDeformAttnFunction
+
+
+def _tol(dtype):
+    return dict(rtol=1e-9, atol=1e-12) if dtype == torch.float64 else dict(rtol=1e-4, atol=1e-5)
+
+
+def _run(value, s, lsi, loc, w):
+    return _fn().apply(value.to(DEV), s.to(DEV), lsi.to(DEV), loc.to(DEV), w.to(DEV), 128).cpu()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_vs_golden(name):
+    g = Golden(name)
+    i, o = g.ins, g.outs
+    out = _run(i["value"], i["shapes"], i["level_start"], i["loc"], i["w"])
+    torch.testing.assert_close(out, o["out"], **_tol(out.dtype))
+
+
+@pytest.mark.parametrize("name", [c for c in CASES if "reftest" not in c])
+def test_backward_vs_golden(name):
+    g = Golden(name)
+    i, o = g.ins, g.outs
+    value, loc, w = (i[k].to(DEV).requires_grad_(True) for k in ("value", "loc", "w"))
+    out = _fn().apply(value, i["shapes"].to(DEV), i["level_start"].to(DEV), loc, w, 128)
+    out.backward(i["grad_out"].to(DEV))
+    tol = _tol(value.dtype) if value.dtype == torch.float64 else dict(rtol=1e-3, atol=2e-4)
+    torch.testing.assert_close(value.grad.cpu(), o["grad_value"], **tol)
+    torch.testing.assert_close(loc.grad.cpu(), o["grad_loc"], **tol)
+    torch.testing.assert_close(w.grad.cpu(), o["grad_w"], **tol)
+
+
+# (N, M, D, shapes, Lq, P, dtype): tiled fast path (D 32/64, (L,P) in the tiled set), generic path, ragged Lq
+SHAPES = [
+    (3, 8, 32, [(5, 8), (10, 16), (20, 32)], None, 4, torch.float32),     # R50 layout, Lq = S = 1000 (ragged vs 64)
+    (2, 8, 32, [(4, 5), (8, 10), (16, 20), (32, 40)], 130, 4, torch.float32),   # 4 levels (image Mask2Former)
+    (2, 16, 64, [(20, 32)], 777, 4, torch.float32),                       # ViT-Adapter extractor layout
+    (1, 8, 32, [(5, 8), (10, 16), (20, 32)], 63, 4, torch.float32),
+    (1, 8, 32, [(5, 8), (10, 16), (20, 32)], 65, 4, torch.float32),
+    (130, 2, 32, [(2, 3)], 3, 4, torch.float32),                          # N = 130: rejected by the reference (N % 128)
+    (2, 4, 30, [(6, 4), (3, 2)], 50, 2, torch.float32),                   # generic: odd D
+    (2, 2, 71, [(6, 4), (3, 2)], 17, 3, torch.float64),
+    (1, 2, 1025, [(3, 2)], 5, 2, torch.float64),                          # the reference's large-D gradcheck sizes
+    (1, 8, 32, [(5, 8), (10, 16), (20, 32)], 200, 4, torch.float64),
+]
+
+
+@pytest.mark.parametrize("case", SHAPES, ids=lambda c: f"N{c[0]}M{c[1]}D{c[2]}L{len(c[3])}P{c[5]}q{c[4]}{str(c[6])[-2:]}")
+def test_forward_backward_vs_oracle(case):
+    N, M, D, shapes, Lq, P, dt = case
+    s0, _ = level_tensors(shapes)
+    Lq = int(s0.prod(1).sum()) if Lq is None else Lq
+    value, s, lsi, loc, w = make_msda_inputs(N, M, D, shapes, Lq, P, dt, seed=N * 7 + D)
+    ref = torch.from_numpy(omsda.msda_forward(value, s, lsi, loc, w))
+    v, l_, w_ = (t.to(DEV).requires_grad_(True) for t in (value, loc, w))
+    out = _fn().apply(v, s.to(DEV), lsi.to(DEV), l_, w_, 128)
+    torch.testing.assert_close(out.detach().cpu(), ref, **_tol(dt))
+    go = torch.randn(out.shape, generator=torch.Generator().manual_seed(1), dtype=torch.float64).to(dt)
+    out.backward(go.to(DEV))
+    gv, gl, gw = omsda.msda_backward(value, s, lsi, loc, w, go)
+    tol = _tol(dt) if dt == torch.float64 else dict(rtol=2e-3, atol=5e-4)
+    torch.testing.assert_close(v.grad.cpu(), torch.from_numpy(gv), **tol)
+    torch.testing.assert_close(l_.grad.cpu(), torch.from_numpy(gl), **tol)
+    torch.testing.assert_close(w_.grad.cpu(), torch.from_numpy(gw), **tol)
+
+
+def test_gradcheck_like_reference():
+    """ops/test.py:66-81: gradcheck in fp64 on the tiny config, one D per backward dispatch class."""
+    shapes = [(6, 4), (3, 2)]
+    for D in (30, 32, 64, 71):
+        value, s, lsi, loc, w = make_msda_inputs(1, 2, D, shapes, 2, 2, torch.float64, seed=D, spread=1.0)
+        value = (value * 0.01).to(DEV).requires_grad_(True)
+        loc, w = loc.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+        assert torch.autograd.gradcheck(_fn().apply, (value, s.to(DEV), lsi.to(DEV), loc, w, 2))
+
+
+def test_production_frame_720p_vs_oracle():
+    """BASELINE config shapes: one 736x1280 frame, S = Lq = 19320, M=8, D=32, L=3, P=4 (fp32)."""
+    shapes = [(23, 40), (46, 80), (92, 160)]
+    value, s, lsi, loc, w = make_msda_inputs(1, 8, 32, shapes, 19320, 4, torch.float32, seed=5, spread=1.1)
+    ref = torch.from_numpy(omsda.msda_forward(value, s, lsi, loc, w))
+    out = _run(value, s, lsi, loc, w)
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-5)
+
+
+def test_fused_forward_matches_unfused_module_math():
+    """softmax + (ref + off / (W,H)) inside the kernel == torch softmax / arithmetic + plain op."""
+    from dvis_plus_amd.functions import msda_fused_forward
+    shapes = [(5, 8), (10, 16), (20, 32)]
+    N, M, D, L, P = 2, 8, 32, 3, 4
+    s, lsi = level_tensors(shapes)
+    S = Lq = int(s.prod(1).sum())
+    g = torch.Generator().manual_seed(11)
+    value = torch.randn(N, S, M, D, generator=g)
+    proj = torch.randn(N * Lq, M * L * P * 3 + 4, generator=g) * 2     # one fused projection row: offsets | logits | pad
+    offsets, logits = proj[:, :M * L * P * 2], proj[:, M * L * P * 2:M * L * P * 3]
+    ref_pts = torch.rand(1, Lq, L, 2, generator=g)
+    norm = torch.stack([s[:, 1], s[:, 0]], -1).float()
+    loc = ref_pts[:, :, None, :, None, :] + offsets.reshape(N, Lq, M, L, P, 2) / norm[None, None, None, :, None, :]
+    w = torch.softmax(logits.reshape(N, Lq, M, L * P), -1).reshape(N, Lq, M, L, P)
+    ref = torch.from_numpy(omsda.msda_forward(value, s, lsi, loc.contiguous(), w.contiguous()))
+    projd = proj.to(DEV)
+    out = msda_fused_forward(value.to(DEV), s.to(DEV), lsi.to(DEV), ref_pts.to(DEV), projd[:, :M * L * P * 2],
+                             projd[:, M * L * P * 2:M * L * P * 3], L, P).cpu()
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=2e-5)
+    # per-frame reference points
+    ref_n = ref_pts.expand(N, -1, -1, -1).contiguous()
+    out2 = msda_fused_forward(value.to(DEV), s.to(DEV), lsi.to(DEV), ref_n.to(DEV), projd[:, :M * L * P * 2],
+                              projd[:, M * L * P * 2:M * L * P * 3], L, P).cpu()
+    assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_half_precision_forward(dt):
+    """fp16/bf16 storage, fp32 accumulation (the reference only dispatches float/double)."""
+    shapes = [(5, 8), (10, 16)]
+    value, s, lsi, loc, w = make_msda_inputs(2, 4, 32, shapes, 90, 4, torch.float32, seed=3, spread=1.0)
+    vq, lq, wq = value.to(dt), loc.to(dt), w.to(dt)
+    ref = torch.from_numpy(omsda.msda_forward(vq.float(), s, lsi, lq.float(), wq.float()))
+    out = _run(vq, s, lsi, lq, wq)
+    assert out.dtype == dt
+    torch.testing.assert_close(out.float(), ref, rtol=2e-2, atol=2e-2)
+
+
+def test_edge_cases():
+    shapes = [(5, 8), (10, 16), (20, 32)]
+    value, s, lsi, loc, w = make_msda_inputs(2, 8, 32, shapes, 100, 4, torch.float32, seed=9)
+    # everything outside the maps -> exact zeros (zero padding), including exactly -1 / H boundaries
+    far = loc.clone()
+    far[:] = 3.0
+    assert torch.count_nonzero(_run(value, s, lsi, far, w)) == 0
+    # NaN locations contribute nothing (comparison false), like the reference's validity test
+    nanloc = loc.clone()
+    nanloc[0, 0, 0, 0, 0] = float("nan")
+    ref = torch.from_numpy(omsda.msda_forward(value, s, lsi, nanloc, w))
+    torch.testing.assert_close(_run(value, s, lsi, nanloc, w), ref, rtol=1e-4, atol=1e-5)
+    # non-finite values next to the border must not leak into zero-padded corners
+    v2 = value.clone()
+    v2[0, 0] = float("inf")
+    edge = loc.clone()
+    edge[0, :, :, 0, :, :] = 0.999   # bottom-right corner of level 0: high corners are outside
+    ref = torch.from_numpy(omsda.msda_forward(v2, s, lsi, edge, w))
+    got = _run(v2, s, lsi, edge, w)
+    assert torch.equal(torch.isfinite(got), torch.isfinite(ref))
+    # empty batch / no queries
+    assert _run(value[:0], s, lsi, loc[:0], w[:0]).shape == (0, 100, 256)
+    assert _run(value, s, lsi, loc[:, :0], w[:, :0]).shape == (2, 0, 256)
+
+
+def test_linearity_and_weight_scaling_full_size():
+    """Size-independent properties at production size (30 frames): linear in value, linear in weights."""
+    shapes = [(23, 40), (46, 80), (92, 160)]
+    value, s, lsi, loc, w = make_msda_inputs(4, 8, 32, shapes, 19320, 4, torch.float32, seed=2, spread=1.05)
+    f = lambda v, ww: _fn().apply(v, s.to(DEV), lsi.to(DEV), loc.to(DEV), ww, 128)
+    v1, v2, wd = value.to(DEV), torch.randn_like(value).to(DEV), w.to(DEV)
+    a, b, c = f(v1, wd), f(v2, wd), f(v1 + v2, wd)
+    torch.testing.assert_close(c, a + b, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(f(v1, 2 * wd), 2 * a, rtol=1e-6, atol=1e-6)
+    # constant value map + weights summing to 1 with all samples inside -> constant output
+    ones = torch.ones_like(v1)
+    inside = (loc * 0.5 + 0.25).to(DEV)
+    out = _fn().apply(ones, s.to(DEV), lsi.to(DEV), inside, wd, 128)
+    torch.testing.assert_close(out, torch.ones_like(out), rtol=1e-5, atol=1e-5)
+
+
+def test_errors_are_loud():
+    from dvis_plus_amd.functions import ms_deform_attn_forward
+    value, s, lsi, loc, w = make_msda_inputs(1, 2, 4, [(3, 3)], 5, 2, torch.float32, 1)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        ms_deform_attn_forward(value, s, lsi, loc, w, 128)                       # CPU tensors: no fallback
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        ms_deform_attn_forward(value.to(DEV), s, lsi.to(DEV), loc.to(DEV), w.to(DEV), 128)   # shapes on host
+    with pytest.raises(RuntimeError, match="contiguous"):
+        ms_deform_attn_forward(value.to(DEV).transpose(2, 3), s.to(DEV), lsi.to(DEV), loc.to(DEV), w.to(DEV), 128)
+    with pytest.raises(RuntimeError, match="dtype"):
+        ms_deform_attn_forward(value.to(DEV), s.to(DEV), lsi.to(DEV), loc.to(DEV).double(), w.to(DEV), 128)

@@ -1,0 +1,113 @@
+"""GPU micro-sweep of the MSDA forward variants at the BASELINE shape (736x1280, N frames).
+
+    python tools/msda_sweep.py [N]
+
+Reports ms / launch and algorithmic GB/s (61.824 MB per frame-layer) for: the tiled kernel at
+several register budgets (variant .so files built by tools/build_variants.sh), the fused kernel and the generic
+(one thread per output) kernel.  Development tool; bench.py carries the judged numbers.
+"""
+import ctypes
+import glob
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dvis_plus_amd import native  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+dev = "cuda:0"
+shapes = torch.tensor([(23, 40), (46, 80), (92, 160)], dtype=torch.long, device=dev)
+lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+M, D, L, P = 8, 32, 3, 4
+S = Lq = int(shapes.prod(1).sum())
+g = torch.Generator(device=dev).manual_seed(0)
+value = torch.randn(N, S, M, D, device=dev, generator=g)
+# encoder-like sampling: reference point = own pixel centre, offsets of a few pixels
+ref = []
+for (h, w) in shapes.tolist():
+    ys, xs = torch.meshgrid(torch.linspace(0.5, h - 0.5, h, device=dev) / h,
+                            torch.linspace(0.5, w - 0.5, w, device=dev) / w, indexing="ij")
+    ref.append(torch.stack((xs.reshape(-1), ys.reshape(-1)), -1))
+ref = torch.cat(ref, 0)[None, :, None, :].expand(1, Lq, L, 2).contiguous()
+off = torch.randn(N, Lq, M, L, P, 2, device=dev, generator=g) * 2.5     # pixels
+norm = torch.stack([shapes[:, 1], shapes[:, 0]], -1).float()
+loc = (ref[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]).contiguous()
+logits = torch.randn(N, Lq, M, L * P, device=dev, generator=g)
+w = torch.softmax(logits, -1).view(N, Lq, M, L, P).contiguous()
+out = torch.empty(N, Lq, M * D, device=dev)
+alg_bytes = 4 * (S * M * D + Lq * M * L * P * 2 + Lq * M * L * P + Lq * M * D) * N
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def bind(path):
+    l = ctypes.CDLL(path)
+    for name in ("dvis_msda_forward", "dvis_msda_fused_forward"):
+        fn = getattr(l, name)
+        fn.restype, fn.argtypes = native.SIGNATURES[name]
+    return l
+
+
+def p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+libs = [("default", native.LIB_PATH)] + [(os.path.basename(f), f) for f in
+                                         sorted(glob.glob(os.path.join(ROOT, "dvis_plus_amd", "lib", "variants", "*.so")))]
+ref_out = None
+for tag, path in libs:
+    l = bind(path)
+
+    def plain():
+        rc = l.dvis_msda_forward(0, p(value), p(shapes), p(lsi), p(loc), p(w), N, S, M, D, L, Lq, P, p(out), st)
+        assert rc == 0
+    ms = timeit(plain)
+    if ref_out is None:
+        ref_out = out.clone()
+    err = (out - ref_out).abs().max().item()
+    print(f"{tag:28s} tiled  {ms:8.3f} ms  {alg_bytes / ms / 1e6:8.1f} GB/s (alg)  {ms / N * 1e3:7.1f} us/frame  maxdiff {err:.1e}")
+
+    offs2d = off.view(N * Lq, -1)
+    log2d = logits.view(N * Lq, -1)
+
+    def fused():
+        rc = l.dvis_msda_fused_forward(p(value), p(shapes), p(lsi), p(ref), 1, p(offs2d), offs2d.stride(0), p(log2d),
+                                       log2d.stride(0), N, S, M, D, L, Lq, P, p(out), st)
+        assert rc == 0
+    ms = timeit(fused)
+    err = (out - ref_out).abs().max().item()
+    print(f"{tag:28s} fused  {ms:8.3f} ms  {alg_bytes / ms / 1e6:8.1f} GB/s (alg)  {ms / N * 1e3:7.1f} us/frame  maxdiff {err:.1e}")
+
+# generic kernel: force it with an unaligned-free trick -> use fp64? no: call with D split view is not possible;
+# time it through a 4-level (L,P)=(3,2)-style shape is a different op, so just time fp16 generic for reference
+v16, l16, w16, o16 = value.half(), loc.half(), w.half(), torch.empty(N, Lq, M * D, device=dev, dtype=torch.half)
+l = bind(native.LIB_PATH)
+
+
+def gen16():
+    rc = l.dvis_msda_forward(2, p(v16), p(shapes), p(lsi), p(l16), p(w16), N, S, M, D, L, Lq, P, p(o16), st)
+    assert rc == 0
+
+
+ms = timeit(gen16, 5)
+print(f"{'generic fp16 (1 thr/output)':28s}        {ms:8.3f} ms  {ms / N * 1e3:7.1f} us/frame")
+
+# torch reference formulation on the GPU (grid_sample), what the reference falls back to under autocast
+from oracle.msda import msda_forward_torch  # noqa: E402  (dev tool only)
+ms = timeit(lambda: msda_forward_torch(value, shapes.cpu(), loc, w), 3)
+print(f"{'torch grid_sample on GPU':28s}        {ms:8.3f} ms  {ms / N * 1e3:7.1f} us/frame")
