@@ -54,3 +54,12 @@ typedef float dvis_f16v __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t dvis_make_rsrc(const void *base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
 }
+
+// Same, with the (already uniform) inputs passed through readfirstlane so the descriptor is PROVABLY wave-uniform:
+// otherwise hipcc wraps every buffer load in a waterfall loop (v_readfirstlane x4 + s_and_saveexec + branch).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dvis_make_rsrc_uniform(const void *base, unsigned bytes) {
+  const uintptr_t b = (uintptr_t)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  return dvis_make_rsrc((const void *)(((uintptr_t)hi << 32) | lo), __builtin_amdgcn_readfirstlane(bytes));
+}

@@ -102,10 +102,10 @@ DVIS_EXPORT int dvis_msda_backward(int dtype, const void *value, const int64_t *
                                    const void *loc, const void *w, const void *grad_out, int N, int S, int M, int D,
                                    int L, int Lq, int P, void *grad_value, void *grad_loc, void *grad_w,
                                    void *stream) {
-  DVIS_REQUIRE(value && shapes && level_start && loc && w && grad_out && grad_value && grad_loc && grad_w,
-               "msda_backward: null pointer");
   DVIS_REQUIRE(N >= 0 && S > 0 && M > 0 && D > 0 && L > 0 && Lq >= 0 && P > 0, "msda_backward: bad sizes");
   if (N == 0 || Lq == 0) return DVIS_OK;
+  DVIS_REQUIRE(value && shapes && level_start && loc && w && grad_out && grad_value && grad_loc && grad_w,
+               "msda_backward: null pointer");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DVIS_F32)
     return launch_bwd<float>(value, shapes, level_start, loc, w, grad_out, N, S, M, D, L, Lq, P, grad_value, grad_loc,

@@ -24,22 +24,52 @@
 //     (22 MB per frame-layer at 720p) never exist in HBM.
 //   * Any dtype / D / L / P outside the tiled set falls to the generic kernel (one thread per output
 //     element, fp32 or fp64 accumulation) — correctness path for fp64, fp16/bf16 and odd D.
+#include <stdlib.h>
+
 #include "dvis_common.h"
 
 namespace {
 
-#ifndef DVIS_MSDA_WAVES_PER_SIMD
-#define DVIS_MSDA_WAVES_PER_SIMD 4  // register budget: 4 waves/SIMD (512/4 = 128 VGPRs) ~ 24 corner loads in flight per wave
-#endif
-
 constexpr int kQB = 64;        // queries per workgroup (tiled kernel)
 constexpr unsigned kOOB = 0x80000000u;  // buffer offset beyond every level slice (< 2 GiB, checked on host)
 
-template <int D, int L, int P, bool FUSED>
-__global__ __launch_bounds__(256, DVIS_MSDA_WAVES_PER_SIMD) void msda_fwd_tile_f32(
+// Bilinear set-up of one sample for one lane: 4 corner byte offsets (kOOB when the corner is outside the map or
+// the sample is not counted) and the 4 corner weights.  Pure VALU, recomputed at consume time instead of being
+// kept live across the loads (registers are what limits loads in flight here).
+struct Tap {
+  unsigned o[4];
+  float c[4];
+};
+
+__device__ __forceinline__ Tap make_tap(float x, float y, int H, int W, bool active, unsigned pix_bytes,
+                                        unsigned lane_bytes) {
+  Tap t;
+  const float h_im = y * (float)H - 0.5f;
+  const float w_im = x * (float)W - 0.5f;
+  const bool ok = active && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+  const float hf = floorf(h_im), wf = floorf(w_im);
+  const int h0 = (int)hf, w0 = (int)wf;
+  const float lh = h_im - hf, lw = w_im - wf;
+  const float hh = 1.f - lh, hw = 1.f - lw;
+  const bool h0ok = ok && h0 >= 0, h1ok = ok && h0 + 1 <= H - 1;
+  const bool w0ok = w0 >= 0, w1ok = w0 + 1 <= W - 1;
+  const unsigned o00 = (unsigned)(h0 * W + w0) * pix_bytes + lane_bytes;
+  t.o[0] = (h0ok && w0ok) ? o00 : kOOB;
+  t.o[1] = (h0ok && w1ok) ? o00 + pix_bytes : kOOB;
+  t.o[2] = (h1ok && w0ok) ? o00 + (unsigned)W * pix_bytes : kOOB;
+  t.o[3] = (h1ok && w1ok) ? o00 + (unsigned)W * pix_bytes + pix_bytes : kOOB;
+  t.c[0] = ok ? hh * hw : 0.f;
+  t.c[1] = ok ? hh * lw : 0.f;
+  t.c[2] = ok ? lh * hw : 0.f;
+  t.c[3] = ok ? lh * lw : 0.f;
+  return t;
+}
+
+template <int D, int L, int P, bool FUSED, int WPS, int B>
+__global__ __launch_bounds__(256, WPS) void msda_fwd_tile_f32(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const float *__restrict__ loc_or_off, int64_t off_stride, const float *__restrict__ w_or_logit,
-    int64_t logit_stride, const float *__restrict__ refp, int nref, int S, int M, int Lq, int nchunks,
+    int64_t logit_stride, const float *__restrict__ refp, int nref, int S, int M, int Lq,
     float *__restrict__ out) {
   constexpr int LP = L * P;
   constexpr int G = D / 4;          // lanes per (query, head) pair
@@ -47,17 +77,18 @@ __global__ __launch_bounds__(256, DVIS_MSDA_WAVES_PER_SIMD) void msda_fwd_tile_f
   constexpr int LOCV = LP / 2;      // float4s of (x, y) per pair
   constexpr int WV = LP / 4;        // float4s of weights per pair
   constexpr int ITERS = kQB / (4 * GPW);
-  static_assert(LP % 4 == 0 && D % 4 == 0 && 64 % G == 0, "tile shape");
+  static_assert(LP % 4 == 0 && D % 4 == 0 && 64 % G == 0 && P % B == 0 && B % 2 == 0, "tile shape");
 
   __shared__ float4 s_loc[kQB * LOCV];
   __shared__ float4 s_w[kQB * WV];
 
+  // grid = (M, ceil(Lq/64), N): x is the fastest dispatch dimension, so linear id % 8 == m % 8 -> head m on XCD m % 8.
+  // blockIdx.* are SGPRs: everything derived from them (bases, descriptors) is wave-uniform.
   const int tid = threadIdx.x;
-  const int m = blockIdx.x % M;
-  const int rest = blockIdx.x / M;
-  const int chunk = rest % nchunks;
-  const int n = rest / nchunks;
-  const int q0 = chunk * kQB;
+  const int m = blockIdx.x;
+  const int n = blockIdx.z;
+  const int q0 = blockIdx.y * kQB;
+  const int nq = min(kQB, Lq - q0);
   const int MD = M * D;
 
   int Hs[L], Ws[L];
@@ -67,30 +98,28 @@ __global__ __launch_bounds__(256, DVIS_MSDA_WAVES_PER_SIMD) void msda_fwd_tile_f
     Ws[l] = (int)shapes[2 * l + 1];
   }
 
-  // ---- stage (loc, w) [or raw (offsets, logits)] of this block's 64 queries x 1 head into LDS
-  for (int i = tid; i < kQB * LOCV; i += 256) {
-    const int ql = i / LOCV, k = i - ql * LOCV;
-    const int q = q0 + ql;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (q < Lq) {
-      const size_t row = (size_t)n * Lq + q;
-      const float *src = FUSED ? loc_or_off + row * off_stride + (size_t)m * (LP * 2) + 4 * k
-                               : loc_or_off + (row * M + m) * (size_t)(LP * 2) + 4 * k;
-      v = *reinterpret_cast<const float4 *>(src);
+  // ---- stage (loc, w) [or raw (offsets, logits)] of this block's 64 queries x 1 head into LDS.
+  // Descriptors cover exactly the nq valid rows: rows past Lq read as 0 without a branch.
+  {
+    const size_t row0 = (size_t)n * Lq + q0;
+    const float *lbase = FUSED ? loc_or_off + row0 * off_stride + (size_t)m * (LP * 2)
+                               : loc_or_off + (row0 * M + m) * (size_t)(LP * 2);
+    const float *wbase = FUSED ? w_or_logit + row0 * logit_stride + (size_t)m * LP
+                               : w_or_logit + (row0 * M + m) * (size_t)LP;
+    const unsigned lrow = (unsigned)((FUSED ? (size_t)off_stride : (size_t)M * LP * 2) * sizeof(float));
+    const unsigned wrow = (unsigned)((FUSED ? (size_t)logit_stride : (size_t)M * LP) * sizeof(float));
+    const __amdgpu_buffer_rsrc_t lrs = dvis_make_rsrc_uniform(lbase, (unsigned)(nq - 1) * lrow + LP * 2 * 4);
+    const __amdgpu_buffer_rsrc_t wrs = dvis_make_rsrc_uniform(wbase, (unsigned)(nq - 1) * wrow + LP * 4);
+    for (int i = tid; i < kQB * LOCV; i += 256) {
+      const int ql = i / LOCV, k = i - ql * LOCV;
+      const dvis_v4u v = __builtin_amdgcn_raw_buffer_load_b128(lrs, (unsigned)ql * lrow + (unsigned)k * 16u, 0, 0);
+      s_loc[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     }
-    s_loc[i] = v;
-  }
-  for (int i = tid; i < kQB * WV; i += 256) {
-    const int ql = i / WV, k = i - ql * WV;
-    const int q = q0 + ql;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (q < Lq) {
-      const size_t row = (size_t)n * Lq + q;
-      const float *src = FUSED ? w_or_logit + row * logit_stride + (size_t)m * LP + 4 * k
-                               : w_or_logit + (row * M + m) * (size_t)LP + 4 * k;
-      v = *reinterpret_cast<const float4 *>(src);
+    for (int i = tid; i < kQB * WV; i += 256) {
+      const int ql = i / WV, k = i - ql * WV;
+      const dvis_v4u v = __builtin_amdgcn_raw_buffer_load_b128(wrs, (unsigned)ql * wrow + (unsigned)k * 16u, 0, 0);
+      s_w[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     }
-    s_w[i] = v;
   }
   if (FUSED) {
     __syncthreads();
@@ -100,16 +129,15 @@ __global__ __launch_bounds__(256, DVIS_MSDA_WAVES_PER_SIMD) void msda_fwd_tile_f
     for (int i = tid; i < kQB * LP; i += 256) {
       const int ql = i / LP, s = i - ql * LP;
       const int l = s / P;
-      const int q = q0 + ql;
-      if (q < Lq) {
+      if (ql < nq) {
         int Hl = Hs[0], Wl = Ws[0];
 #pragma unroll
         for (int ll = 1; ll < L; ++ll)
           if (l == ll) { Hl = Hs[ll]; Wl = Ws[ll]; }
-        const size_t rrow = ((size_t)(nref == 1 ? 0 : n) * Lq + q) * L + l;
-        const float rx = refp[rrow * 2], ry = refp[rrow * 2 + 1];
-        lf[ql * LP * 2 + 2 * s] = rx + lf[ql * LP * 2 + 2 * s] / (float)Wl;
-        lf[ql * LP * 2 + 2 * s + 1] = ry + lf[ql * LP * 2 + 2 * s + 1] / (float)Hl;
+        const size_t rrow = ((size_t)(nref == 1 ? 0 : n) * Lq + q0 + ql) * L + l;
+        const float2 r = *reinterpret_cast<const float2 *>(refp + rrow * 2);
+        lf[ql * LP * 2 + 2 * s] = r.x + lf[ql * LP * 2 + 2 * s] / (float)Wl;
+        lf[ql * LP * 2 + 2 * s + 1] = r.y + lf[ql * LP * 2 + 2 * s + 1] / (float)Hl;
       }
     }
     // softmax over the L*P logits of each (query, head)
@@ -127,78 +155,75 @@ __global__ __launch_bounds__(256, DVIS_MSDA_WAVES_PER_SIMD) void msda_fwd_tile_f
   }
   __syncthreads();
 
-  // ---- per-level buffer descriptors over this (frame, head) slice
+  // ---- per-level buffer descriptors over this (frame, head) slice of `value`
   __amdgpu_buffer_rsrc_t rs[L];
 #pragma unroll
   for (int l = 0; l < L; ++l) {
     const float *base = value + (((size_t)n * S + (size_t)level_start[l]) * M + m) * D;
-    const unsigned bytes = (unsigned)(((size_t)(Hs[l] * Ws[l] - 1) * MD + D) * sizeof(float));
-    rs[l] = dvis_make_rsrc(base, bytes);
+    rs[l] = dvis_make_rsrc_uniform(base, (unsigned)(((size_t)(Hs[l] * Ws[l] - 1) * MD + D) * sizeof(float)));
   }
 
   const int lane = tid & 63, wv = tid >> 6;
   const int g = lane / G, j = lane - g * G;
   const unsigned pix_bytes = (unsigned)MD * 4u;
   const unsigned lane_bytes = (unsigned)j * 16u;
+  float *const out_blk = out + (((size_t)n * Lq + q0) * M + m) * D;   // uniform
 
+  const float *lds_loc = reinterpret_cast<const float *>(s_loc);
+  const float *lds_w = reinterpret_cast<const float *>(s_w);
+
+  // Latency is hidden by WAVES, not by a deep per-wave pipeline: each wave keeps one batch of B samples
+  // (4*B corner loads) in flight, reads that batch's (x, y, w) from LDS just in time, and stays within the
+  // register budget of WPS waves/SIMD.  (A fully unrolled 12-sample body makes hipcc hoist all 48 loads and
+  // spill to scratch; measured 3-10x slower.)
 #pragma unroll 1
   for (int it = 0; it < ITERS; ++it) {
     const int ql = (it * 4 + wv) * GPW + g;
-    const int q = q0 + ql;
-    const bool active = q < Lq;
-
-    float lf[LP * 2], wf[LP];
-#pragma unroll
-    for (int k = 0; k < LOCV; ++k) {
-      const float4 v = s_loc[ql * LOCV + k];
-      lf[4 * k] = v.x; lf[4 * k + 1] = v.y; lf[4 * k + 2] = v.z; lf[4 * k + 3] = v.w;
-    }
-#pragma unroll
-    for (int k = 0; k < WV; ++k) {
-      const float4 v = s_w[ql * WV + k];
-      wf[4 * k] = v.x; wf[4 * k + 1] = v.y; wf[4 * k + 2] = v.z; wf[4 * k + 3] = v.w;
-    }
-
+    const bool active = ql < nq;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
     for (int l = 0; l < L; ++l) {
       const int H = Hs[l], W = Ws[l];
+#pragma unroll 1
+      for (int pb = 0; pb < P / B; ++pb) {
+        const int s0 = l * P + pb * B;
+        float xy[2 * B], aw[B];
 #pragma unroll
-      for (int p = 0; p < P; ++p) {
-        const int s = l * P + p;
-        const float h_im = lf[2 * s + 1] * (float)H - 0.5f;
-        const float w_im = lf[2 * s] * (float)W - 0.5f;
-        const bool ok = active && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
-        const float hf = floorf(h_im), wf_ = floorf(w_im);
-        const int h0 = (int)hf, w0 = (int)wf_;
-        const float lh = h_im - hf, lw = w_im - wf_;
-        const float hh = 1.f - lh, hw = 1.f - lw;
-        const bool h0ok = ok && h0 >= 0, h1ok = ok && h0 + 1 <= H - 1;
-        const bool w0ok = w0 >= 0, w1ok = w0 + 1 <= W - 1;
-        const unsigned o00 = (unsigned)(h0 * W + w0) * pix_bytes + lane_bytes;
-        const unsigned o01 = o00 + pix_bytes;
-        const unsigned o10 = o00 + (unsigned)W * pix_bytes;
-        const unsigned o11 = o10 + pix_bytes;
-        const dvis_v4u r1 = __builtin_amdgcn_raw_buffer_load_b128(rs[l], (h0ok && w0ok) ? o00 : kOOB, 0, 0);
-        const dvis_v4u r2 = __builtin_amdgcn_raw_buffer_load_b128(rs[l], (h0ok && w1ok) ? o01 : kOOB, 0, 0);
-        const dvis_v4u r3 = __builtin_amdgcn_raw_buffer_load_b128(rs[l], (h1ok && w0ok) ? o10 : kOOB, 0, 0);
-        const dvis_v4u r4 = __builtin_amdgcn_raw_buffer_load_b128(rs[l], (h1ok && w1ok) ? o11 : kOOB, 0, 0);
-        const float c1 = hh * hw, c2 = hh * lw, c3 = lh * hw, c4 = lh * lw;
-        const float aw = ok ? wf[s] : 0.f;
-        const float c1v = ok ? c1 : 0.f, c2v = ok ? c2 : 0.f, c3v = ok ? c3 : 0.f, c4v = ok ? c4 : 0.f;
-        // reference order: (w1 v1 + w2 v2 + w3 v3 + w4 v4) * weight, accumulated over samples
-        a0 += (c1v * __uint_as_float(r1.x) + c2v * __uint_as_float(r2.x) + c3v * __uint_as_float(r3.x) +
-               c4v * __uint_as_float(r4.x)) * aw;
-        a1 += (c1v * __uint_as_float(r1.y) + c2v * __uint_as_float(r2.y) + c3v * __uint_as_float(r3.y) +
-               c4v * __uint_as_float(r4.y)) * aw;
-        a2 += (c1v * __uint_as_float(r1.z) + c2v * __uint_as_float(r2.z) + c3v * __uint_as_float(r3.z) +
-               c4v * __uint_as_float(r4.z)) * aw;
-        a3 += (c1v * __uint_as_float(r1.w) + c2v * __uint_as_float(r2.w) + c3v * __uint_as_float(r3.w) +
-               c4v * __uint_as_float(r4.w)) * aw;
+        for (int i = 0; i < B / 2; ++i) {
+          const float4 v = *reinterpret_cast<const float4 *>(lds_loc + ql * (LP * 2) + 2 * s0 + 4 * i);
+          xy[4 * i] = v.x; xy[4 * i + 1] = v.y; xy[4 * i + 2] = v.z; xy[4 * i + 3] = v.w;
+        }
+#pragma unroll
+        for (int i = 0; i < B / 2; ++i) {
+          const float2 v = *reinterpret_cast<const float2 *>(lds_w + ql * LP + s0 + 2 * i);
+          aw[2 * i] = v.x; aw[2 * i + 1] = v.y;
+        }
+        Tap t[B];
+        dvis_v4u r[4 * B];
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+          t[i] = make_tap(xy[2 * i], xy[2 * i + 1], H, W, active, pix_bytes, lane_bytes);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) r[4 * i + c] = __builtin_amdgcn_raw_buffer_load_b128(rs[l], t[i].o[c], 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+          const dvis_v4u r1 = r[4 * i], r2 = r[4 * i + 1], r3 = r[4 * i + 2], r4 = r[4 * i + 3];
+          const float c1 = t[i].c[0], c2 = t[i].c[1], c3 = t[i].c[2], c4 = t[i].c[3];
+          // reference order: (w1 v1 + w2 v2 + w3 v3 + w4 v4) * weight, accumulated over samples
+          a0 += (c1 * __uint_as_float(r1.x) + c2 * __uint_as_float(r2.x) + c3 * __uint_as_float(r3.x) +
+                 c4 * __uint_as_float(r4.x)) * aw[i];
+          a1 += (c1 * __uint_as_float(r1.y) + c2 * __uint_as_float(r2.y) + c3 * __uint_as_float(r3.y) +
+                 c4 * __uint_as_float(r4.y)) * aw[i];
+          a2 += (c1 * __uint_as_float(r1.z) + c2 * __uint_as_float(r2.z) + c3 * __uint_as_float(r3.z) +
+                 c4 * __uint_as_float(r4.z)) * aw[i];
+          a3 += (c1 * __uint_as_float(r1.w) + c2 * __uint_as_float(r2.w) + c3 * __uint_as_float(r3.w) +
+                 c4 * __uint_as_float(r4.w)) * aw[i];
+        }
       }
     }
     if (active) {
-      float *dst = out + (((size_t)n * Lq + q) * M + m) * D + 4 * j;
+      float *dst = out_blk + (size_t)ql * MD + 4 * j;
       *reinterpret_cast<float4 *>(dst) = make_float4(a0, a1, a2, a3);
     }
   }
@@ -260,18 +285,38 @@ int launch_generic(const void *value, const int64_t *shapes, const int64_t *ls, 
   return dvis_check_launch("msda_fwd_generic");
 }
 
+// Developer knob (tools/msda_sweep.py): DVIS_MSDA_VARIANT=0..6 selects the tile-kernel build variant.
+int tile_variant() {
+  static const int v = [] {
+    const char *e = getenv("DVIS_MSDA_VARIANT");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+
 template <int D, int L, int P, bool FUSED>
 int launch_tile(const float *value, const int64_t *shapes, const int64_t *ls, const float *a, int64_t a_stride,
                 const float *b, int64_t b_stride, const float *refp, int nref, int N, int S, int M, int Lq, float *out,
                 hipStream_t st) {
   const int nchunks = (Lq + kQB - 1) / kQB;
-  const size_t grid = (size_t)N * nchunks * M;
-  if (grid > 0x7fffffffu) {
-    dvis_set_error("msda: grid too large");
+  if (nchunks > 65535 || N > 65535) {
+    dvis_set_error("msda: grid too large (Lq/64 and N must be <= 65535)");
     return DVIS_E_ARG;
   }
-  hipLaunchKernelGGL((msda_fwd_tile_f32<D, L, P, FUSED>), dim3((unsigned)grid), dim3(256), 0, st, value, shapes, ls, a,
-                     a_stride, b, b_stride, refp, nref, S, M, Lq, nchunks, out);
+  const dim3 grid(M, nchunks, N), block(256);
+#define DVIS_LAUNCH_VARIANT(wps, bsz)                                                                              \
+  hipLaunchKernelGGL((msda_fwd_tile_f32<D, L, P, FUSED, wps, bsz>), grid, block, 0, st, value, shapes, ls, a, a_stride,  \
+                     b, b_stride, refp, nref, S, M, Lq, out)
+  switch (tile_variant()) {   // register budget (waves/SIMD) x samples per load batch; default picked by measurement
+    case 1: DVIS_LAUNCH_VARIANT(6, 2); break;
+    case 2: DVIS_LAUNCH_VARIANT(4, 2); break;
+    case 3: DVIS_LAUNCH_VARIANT(4, 4); break;
+    case 4: DVIS_LAUNCH_VARIANT(5, 4); break;
+    case 5: DVIS_LAUNCH_VARIANT(3, 4); break;
+    case 6: DVIS_LAUNCH_VARIANT(2, 4); break;
+    default: DVIS_LAUNCH_VARIANT(8, 2); break;
+  }
+#undef DVIS_LAUNCH_VARIANT
   return dvis_check_launch("msda_fwd_tile_f32");
 }
 
@@ -301,9 +346,9 @@ bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 DVIS_EXPORT int dvis_msda_forward(int dtype, const void *value, const int64_t *shapes, const int64_t *level_start,
                                   const void *loc, const void *w, int N, int S, int M, int D, int L, int Lq, int P,
                                   void *out, void *stream) {
-  DVIS_REQUIRE(value && shapes && level_start && loc && w && out, "msda_forward: null pointer");
   DVIS_REQUIRE(N >= 0 && S > 0 && M > 0 && D > 0 && L > 0 && Lq >= 0 && P > 0, "msda_forward: bad sizes");
-  if (N == 0 || Lq == 0) return DVIS_OK;
+  if (N == 0 || Lq == 0) return DVIS_OK;   // empty batch: nothing to write (pointers may be null)
+  DVIS_REQUIRE(value && shapes && level_start && loc && w && out, "msda_forward: null pointer");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DVIS_F32) {
     const bool fits = (size_t)S * M * D * sizeof(float) < 0x7fffffffu;
@@ -327,8 +372,9 @@ DVIS_EXPORT int dvis_msda_fused_forward(const float *value, const int64_t *shape
                                         const float *ref, int Nref, const float *offsets, int64_t off_stride,
                                         const float *logits, int64_t logit_stride, int N, int S, int M, int D, int L,
                                         int Lq, int P, float *out, void *stream) {
-  DVIS_REQUIRE(value && shapes && level_start && ref && offsets && logits && out, "msda_fused_forward: null pointer");
   DVIS_REQUIRE(N >= 0 && S > 0 && M > 0 && D > 0 && L > 0 && Lq >= 0 && P > 0, "msda_fused_forward: bad sizes");
+  if (N == 0 || Lq == 0) return DVIS_OK;
+  DVIS_REQUIRE(value && shapes && level_start && ref && offsets && logits && out, "msda_fused_forward: null pointer");
   DVIS_REQUIRE(Nref == 1 || Nref == N, "msda_fused_forward: Nref must be 1 or N");
   DVIS_REQUIRE(off_stride >= (int64_t)M * L * P * 2 && logit_stride >= (int64_t)M * L * P,
                "msda_fused_forward: row strides too small");
@@ -336,7 +382,6 @@ DVIS_EXPORT int dvis_msda_fused_forward(const float *value, const int64_t *shape
                    aligned16(value) && aligned16(out),
                "msda_fused_forward: 16-byte alignment required");
   DVIS_REQUIRE((size_t)S * M * D * sizeof(float) < 0x7fffffffu, "msda_fused_forward: frame slice >= 2 GiB");
-  if (N == 0 || Lq == 0) return DVIS_OK;
   bool handled = false;
   int rc = dispatch_tile<true>(D, L, P, value, shapes, level_start, offsets, off_stride, logits, logit_stride, ref,
                                Nref, N, S, M, Lq, out, (hipStream_t)stream, &handled);

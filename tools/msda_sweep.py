@@ -3,7 +3,7 @@
     python tools/msda_sweep.py [N]
 
 Reports ms / launch and algorithmic GB/s (61.824 MB per frame-layer) for: the tiled kernel at
-several register budgets (variant .so files built by tools/build_variants.sh), the fused kernel and the generic
+the variant selected by DVIS_MSDA_VARIANT (run once per variant), the fused kernel and the generic
 (one thread per output) kernel.  Development tool; bench.py carries the judged numbers.
 """
 import ctypes
@@ -67,8 +67,8 @@ def p(t):
 
 
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-libs = [("default", native.LIB_PATH)] + [(os.path.basename(f), f) for f in
-                                         sorted(glob.glob(os.path.join(ROOT, "dvis_plus_amd", "lib", "variants", "*.so")))]
+libs = [("variant " + os.environ.get("DVIS_MSDA_VARIANT", "default"), native.LIB_PATH)]
+FULL = os.environ.get("SWEEP_FULL", "0") == "1"
 ref_out = None
 for tag, path in libs:
     l = bind(path)
@@ -93,6 +93,8 @@ for tag, path in libs:
     err = (out - ref_out).abs().max().item()
     print(f"{tag:28s} fused  {ms:8.3f} ms  {alg_bytes / ms / 1e6:8.1f} GB/s (alg)  {ms / N * 1e3:7.1f} us/frame  maxdiff {err:.1e}")
 
+if not FULL:
+    sys.exit(0)
 # generic kernel: force it with an unaligned-free trick -> use fp64? no: call with D split view is not possible;
 # time it through a 4-level (L,P)=(3,2)-style shape is a different op, so just time fp16 generic for reference
 v16, l16, w16, o16 = value.half(), loc.half(), w.half(), torch.empty(N, Lq, M * D, device=dev, dtype=torch.half)
