@@ -1,0 +1,297 @@
+// softmax(Q K^T * scale [masked]) V for small-query / long-key attention — gfx950, exact-fp32 MFMA.
+//
+// Replaces the core of nn.MultiheadAttention as the reference uses it (need_weights=True slow path that
+// materialises (B*heads, Q, HW) probabilities): masked cross-attention of the Mask2Former decoder
+// (mask2former_video/modeling/transformer_decoder/video_mask2former_transformer_decoder.py:99-111, called from
+// dvis_Plus/video_mask2former_transformer_decoder.py:299), the referring cross-attention and self-attention of
+// the tracker (dvis_Plus/tracker.py:35-53) and the time / object / cross attention of the temporal refiner
+// (dvis_Plus/refiner.py:104-139).  Projections stay library GEMMs; this kernel is the part in between.
+//
+// Shape regime: few queries (Q = 100/200, or T = 30), head dim 32 or 64, keys from 30 to 14 720.
+//   * A wave owns 16 queries; a workgroup (8 waves) 128 queries of one (batch, head) and one key range
+//     (flash-decoding style split over keys; partial (O, m, l) are merged by a second tiny kernel).
+//   * S^T = K Q^T is computed instead of S (swapped operands): the accumulator then holds, per lane, 4 keys of
+//     ONE query, which (a) makes the row max/sum a 2-shuffle reduction and (b) is already the A-operand layout
+//     of P V — probabilities never leave registers.  K index permutation as in mask_gemm.hip (lane group g sums
+//     dims [g*d/4, (g+1)*d/4)) so Q / K fragments are contiguous 16-byte reads.
+//   * K / V stages of 64 (d=32) or 32 (d=64) keys go through LDS once per workgroup (all 8 waves reuse them), next stage prefetched
+//     into registers under the current stage's MFMAs.
+//   * mask: uint8 (1 = blocked), ONE copy per frame shared by all heads (the reference repeats it 8x);
+//     a row whose allowed_count is 0 ignores the mask = the reference's "fully masked row" reset (…:297), done
+//     on the device without the torch.where host sync.
+//   * v_mfma_f32_16x16x4_f32 = fp32 fma chain, online softmax in fp32 with expf: parity well inside 1e-3.
+#include <math.h>
+
+#include "dvis_common.h"
+
+namespace {
+
+constexpr int kKT = 64;   // keys per LDS stage
+
+struct SplitPlan {
+  int nsplit, keys_per_split, qchunks;
+};
+
+SplitPlan plan_split(int BH, int Lq, int Lk) {
+  SplitPlan p;
+  p.qchunks = (Lq + 127) / 128;
+  const long long base = (long long)BH * p.qchunks;
+  int ns = (int)((2048 + base - 1) / base);
+  const int max_ns = (Lk + 4 * kKT - 1) / (4 * kKT);   // at least 256 keys per split
+  if (ns > max_ns) ns = max_ns;
+  if (ns < 1) ns = 1;
+  int kps = ((Lk + ns - 1) / ns + kKT - 1) / kKT * kKT;
+  p.nsplit = (Lk + kps - 1) / kps;
+  p.keys_per_split = kps;
+  return p;
+}
+
+template <int DH>
+__global__ __launch_bounds__(512) void attn_fwd_kernel(
+    const float *__restrict__ q, int64_t q_bs, int64_t q_rs, const float *__restrict__ k, int64_t k_bs, int64_t k_rs,
+    const float *__restrict__ v, int64_t v_bs, int64_t v_rs, float *__restrict__ out, int64_t o_bs, int64_t o_rs,
+    const uint8_t *__restrict__ mask, const int *__restrict__ allowed, int heads_per_mask, int Lq, int Lk, float scale,
+    int nsplit, int keys_per_split, float *__restrict__ ws_o, float *__restrict__ ws_ml) {
+  constexpr int DQ = DH / 4;        // dims per lane group
+  constexpr int NT = DH / 16;       // output N tiles
+  constexpr int LS = DH + 4;        // LDS row stride (floats): 16-B aligned, V rows of lane groups 0/1 split banks
+  // keys per LDS stage: 64 (d=32) / 32 (d=64) -> one float4 of K and of V per thread per stage
+  // (two per thread crashes hipcc 7.2's machine-copy-propagation pass on the d=64 instantiation)
+  constexpr int KT = DH == 64 ? 32 : 64;
+  constexpr int F4 = KT * DH / 4 / 512;   // float4 per thread per matrix per stage
+  __shared__ float k_lds[KT * LS];
+  __shared__ float v_lds[KT * LS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int split = blockIdx.x, bh = blockIdx.y;
+  const int q0 = blockIdx.z * 128 + wv * 16;
+  const bool wave_on = q0 < Lq;
+  const int myq = q0 + j;                // the query this lane's accumulator COLUMN belongs to
+  const bool q_ok = myq < Lq;
+  const int key_lo = split * keys_per_split;
+  const int key_hi = min(Lk, key_lo + keys_per_split);
+
+  // ---- B operand of S^T: Q[myq][g*DQ + kk] * scale (torch scales q before the product)
+  float qf[DQ];
+  {
+    const float *qrow = q + (size_t)bh * q_bs + (size_t)(q_ok ? myq : 0) * q_rs + g * DQ;
+#pragma unroll
+    for (int c = 0; c < DQ / 4; ++c) {
+      const float4 t = *reinterpret_cast<const float4 *>(qrow + 4 * c);
+      qf[4 * c] = q_ok ? t.x * scale : 0.f;
+      qf[4 * c + 1] = q_ok ? t.y * scale : 0.f;
+      qf[4 * c + 2] = q_ok ? t.z * scale : 0.f;
+      qf[4 * c + 3] = q_ok ? t.w * scale : 0.f;
+    }
+  }
+  const int mb = mask ? bh / heads_per_mask : 0;
+  const bool use_mask = mask != nullptr && q_ok && (allowed == nullptr || allowed[(size_t)mb * Lq + myq] != 0);
+  const uint8_t *mrow = mask ? mask + ((size_t)mb * Lq + (q_ok ? myq : 0)) * Lk : nullptr;
+  const bool lk4 = (Lk & 3) == 0;
+
+  dvis_f4 o[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) o[n] = dvis_f4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_part = 0.f;
+
+  const float *kb = k + (size_t)bh * k_bs;
+  const float *vb = v + (size_t)bh * v_bs;
+  float4 pk[F4], pv[F4];
+  auto prefetch = [&](int ks) {
+#pragma unroll
+    for (int i = 0; i < F4; ++i) {
+      const int e = tid + 512 * i;              // float4 index within the stage
+      const int row = e / (DH / 4), c4 = e - row * (DH / 4);
+      const int key = ks + row;
+      if (key < key_hi) {
+        pk[i] = *reinterpret_cast<const float4 *>(kb + (size_t)key * k_rs + 4 * c4);
+        pv[i] = *reinterpret_cast<const float4 *>(vb + (size_t)key * v_rs + 4 * c4);
+      } else {
+        pk[i] = pv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  prefetch(key_lo);
+  for (int ks = key_lo; ks < key_hi; ks += KT) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < F4; ++i) {
+      const int e = tid + 512 * i;
+      const int row = e / (DH / 4), c4 = e - row * (DH / 4);
+      *reinterpret_cast<float4 *>(&k_lds[row * LS + 4 * c4]) = pk[i];
+      *reinterpret_cast<float4 *>(&v_lds[row * LS + 4 * c4]) = pv[i];
+    }
+    __syncthreads();
+    if (ks + KT < key_hi) prefetch(ks + KT);
+    if (!wave_on) continue;
+#pragma unroll 1
+    for (int kt = 0; kt < KT / 16; ++kt) {
+      const int key0 = ks + kt * 16;
+      if (key0 >= key_hi) break;   // uniform
+      // ---- S^T tile: rows = 16 keys, cols = 16 queries
+      dvis_f4 s = dvis_f4{0.f, 0.f, 0.f, 0.f};
+      {
+        const float *krow = &k_lds[(kt * 16 + j) * LS + g * DQ];
+#pragma unroll
+        for (int c = 0; c < DQ / 4; ++c) {
+          const float4 kk = *reinterpret_cast<const float4 *>(krow + 4 * c);
+          s = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.x, qf[4 * c], s, 0, 0, 0);
+          s = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.y, qf[4 * c + 1], s, 0, 0, 0);
+          s = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.z, qf[4 * c + 2], s, 0, 0, 0);
+          s = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.w, qf[4 * c + 3], s, 0, 0, 0);
+        }
+      }
+      // lane (j, g) now holds S[query myq][key0 + 4g + r], r = 0..3
+      const int kbase = key0 + 4 * g;
+      bool dead[4];
+      if (use_mask) {
+        if (lk4 && kbase + 3 < key_hi) {
+          const unsigned mw = *reinterpret_cast<const unsigned *>(mrow + kbase);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dead[r] = ((mw >> (8 * r)) & 0xffu) != 0;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dead[r] = kbase + r >= key_hi || mrow[kbase + r] != 0;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dead[r] = kbase + r >= key_hi;
+      }
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tmax = dead[r] ? tmax : fmaxf(tmax, s[r]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = (m_new == -INFINITY) ? 1.f : expf(m_run - m_new);   // exp(-inf) = 0 on first live tile
+      float p[4], psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p[r] = dead[r] ? 0.f : expf(s[r] - m_new);
+        psum += p[r];
+      }
+      l_part = l_part * alpha + psum;
+      m_run = m_new;
+      // rescale O rows: row (4g + r) of the accumulator belongs to query q0 + 4g + r, whose alpha lives in lane 4g + r
+      if (!__all(alpha == 1.f)) {
+        const dvis_f4 av = dvis_f4{__shfl(alpha, 4 * g), __shfl(alpha, 4 * g + 1), __shfl(alpha, 4 * g + 2),
+                                   __shfl(alpha, 4 * g + 3)};
+#pragma unroll
+        for (int n = 0; n < NT; ++n) o[n] = o[n] * av;
+      }
+      // ---- O += P V : A = P (already in A layout), B = V rows key0 + 4g + r
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float *vrow = &v_lds[(kt * 16 + 4 * g + r) * LS + j];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) o[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[r], vrow[16 * n], o[n], 0, 0, 0);
+      }
+    }
+  }
+  if (!wave_on) return;
+
+  // ---- epilogue: l over the 4 lane groups; stats of query (4g + r) come from lane 4g + r
+  float l_tot = l_part + __shfl_xor(l_part, 16);
+  l_tot += __shfl_xor(l_tot, 32);
+  float lr[4], mr[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    lr[r] = __shfl(l_tot, 4 * g + r);
+    mr[r] = __shfl(m_run, 4 * g + r);
+  }
+  if (nsplit == 1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qq = q0 + 4 * g + r;
+      if (qq < Lq) {
+        const float inv = lr[r] > 0.f ? 1.f / lr[r] : 0.f;
+        float *orow = out + (size_t)bh * o_bs + (size_t)qq * o_rs;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) orow[16 * n + j] = o[n][r] * inv;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qq = q0 + 4 * g + r;
+      if (qq < Lq) {
+        const size_t row = ((size_t)bh * nsplit + split) * Lq + qq;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) ws_o[row * DH + 16 * n + j] = o[n][r];
+        if (j == 0) {
+          ws_ml[row * 2] = mr[r];
+          ws_ml[row * 2 + 1] = lr[r];
+        }
+      }
+    }
+  }
+}
+
+// Merge the per-split partials: O = sum_s O_s e^{m_s - M} / sum_s l_s e^{m_s - M}.
+__global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restrict__ ws_o, const float *__restrict__ ws_ml,
+                                                           int nsplit, int Lq, int DH, size_t total,
+                                                           float *__restrict__ out, int64_t o_bs, int64_t o_rs) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int d = (int)(idx % DH);
+  const size_t t = idx / DH;
+  const int qq = (int)(t % Lq);
+  const size_t bh = t / Lq;
+  float M = -INFINITY;
+  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, ws_ml[((bh * nsplit + s) * Lq + qq) * 2]);
+  float num = 0.f, den = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const size_t row = (bh * nsplit + s) * Lq + qq;
+    const float ms = ws_ml[row * 2];
+    const float wgt = (ms == -INFINITY) ? 0.f : expf(ms - M);
+    num += ws_o[row * DH + d] * wgt;
+    den += ws_ml[row * 2 + 1] * wgt;
+  }
+  out[bh * o_bs + (size_t)qq * o_rs + d] = den > 0.f ? num / den : 0.f;
+}
+
+}  // namespace
+
+DVIS_EXPORT int64_t dvis_attention_ws_bytes(int BH, int Lq, int Lk, int d) {
+  if (BH <= 0 || Lq <= 0 || Lk <= 0 || d <= 0) return 0;
+  const SplitPlan p = plan_split(BH, Lq, Lk);
+  if (p.nsplit == 1) return 0;
+  return (int64_t)BH * p.nsplit * Lq * (d + 2) * (int64_t)sizeof(float);
+}
+
+DVIS_EXPORT int dvis_attention_forward(const float *q, int64_t q_bs, int64_t q_rs, const float *k, int64_t k_bs,
+                                       int64_t k_rs, const float *v, int64_t v_bs, int64_t v_rs, float *out,
+                                       int64_t o_bs, int64_t o_rs, const uint8_t *mask, const int32_t *allowed_count,
+                                       int heads_per_mask, int BH, int Lq, int Lk, int d, float scale, void *ws,
+                                       void *stream) {
+  DVIS_REQUIRE(BH >= 0 && Lq >= 0 && Lk > 0, "attention: bad sizes");
+  if (BH == 0 || Lq == 0) return DVIS_OK;
+  DVIS_REQUIRE(q && k && v && out, "attention: null pointer");
+  DVIS_REQUIRE(d == 32 || d == 64, "attention: head dim must be 32 or 64 (got %d)", d);
+  DVIS_REQUIRE(BH <= 65535, "attention: batch*heads must be <= 65535");
+  DVIS_REQUIRE(mask == nullptr || heads_per_mask > 0, "attention: heads_per_mask must be > 0 with a mask");
+  const uintptr_t al = (uintptr_t)q | (uintptr_t)k | (uintptr_t)v;
+  DVIS_REQUIRE((al & 15) == 0 && ((q_bs | q_rs | k_bs | k_rs | v_bs | v_rs) & 3) == 0,
+               "attention: q/k/v must be 16-byte aligned with strides that are multiples of 4 floats");
+  DVIS_REQUIRE(mask == nullptr || ((uintptr_t)mask & 3) == 0, "attention: mask must be 4-byte aligned");
+  const SplitPlan p = plan_split(BH, Lq, Lk);
+  DVIS_REQUIRE(p.nsplit == 1 || ws, "attention: workspace required (dvis_attention_ws_bytes)");
+  hipStream_t st = (hipStream_t)stream;
+  float *ws_o = (float *)ws;
+  float *ws_ml = ws_o ? ws_o + (size_t)BH * p.nsplit * Lq * d : nullptr;
+  const dim3 grid(p.nsplit, BH, p.qchunks), block(512);
+  if (d == 32)
+    hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, block, 0, st, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, out, o_bs,
+                       o_rs, mask, allowed_count, heads_per_mask, Lq, Lk, scale, p.nsplit, p.keys_per_split, ws_o, ws_ml);
+  else
+    hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, block, 0, st, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, out, o_bs,
+                       o_rs, mask, allowed_count, heads_per_mask, Lq, Lk, scale, p.nsplit, p.keys_per_split, ws_o, ws_ml);
+  int rc = dvis_check_launch("attn_fwd_kernel");
+  if (rc != DVIS_OK || p.nsplit == 1) return rc;
+  const size_t total = (size_t)BH * Lq * d;
+  hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws_o, ws_ml, p.nsplit,
+                     Lq, d, total, out, o_bs, o_rs);
+  return dvis_check_launch("attn_combine_kernel");
+}

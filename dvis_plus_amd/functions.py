@@ -127,3 +127,92 @@ def msda_fused_forward(value, spatial_shapes, level_start_index, reference_point
             logits.stride(0), N, S, M, D, L, Lq, P, native.dev_ptr(out, "out"), native.stream_ptr(value.device))
     native.check(rc, "dvis_msda_fused_forward")
     return out
+
+
+def _f32_gpu(t, name):
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32 (got {t.dtype})")
+    return native.dev_ptr(t, name)
+
+
+def mask_logits(mask_embed, mask_features):
+    """einsum("bqc,bchw->bqhw") of forward_prediction_heads
+    (dvis_Plus/video_mask2former_transformer_decoder.py:363), exact-fp32 MFMA.  (B,Q,C) x (B,C,H,W) -> (B,Q,H,W)."""
+    B, Q, C = mask_embed.shape
+    Bf, Cf, H, W = mask_features.shape
+    if (Bf, Cf) != (B, C):
+        raise RuntimeError("mask_logits: mask_embed (B,Q,C) and mask_features (B,C,H,W) disagree")
+    pe, pf = _f32_gpu(mask_embed, "mask_embed"), _f32_gpu(mask_features, "mask_features")
+    out = torch.empty((B, Q, H, W), dtype=torch.float32, device=mask_embed.device)
+    with torch.cuda.device(mask_embed.device):
+        rc = native.lib().dvis_mask_logits(pe, pf, B, Q, C, H * W, native.dev_ptr(out, "out"),
+                                           native.stream_ptr(mask_embed.device))
+    native.check(rc, "dvis_mask_logits")
+    return out
+
+
+def attn_mask(mask_embed, mask_features, target_size):
+    """Attention mask of the next decoder layer in ONE launch: contraction + bilinear down-sizing + threshold
+    (ibid. :363-371).  Returns (mask uint8 (B,Q,h*w) with 1 = blocked — a single copy, not repeated per head —,
+    allowed_count int32 (B,Q)); a row with allowed_count == 0 must be treated as un-masked (:297), which
+    ``attention`` does on the device."""
+    B, Q, C = mask_embed.shape
+    Bf, Cf, H, W = mask_features.shape
+    h, w = int(target_size[0]), int(target_size[1])
+    if (Bf, Cf) != (B, C):
+        raise RuntimeError("attn_mask: mask_embed (B,Q,C) and mask_features (B,C,H,W) disagree")
+    pe, pf = _f32_gpu(mask_embed, "mask_embed"), _f32_gpu(mask_features, "mask_features")
+    mask = torch.empty((B, Q, h * w), dtype=torch.uint8, device=mask_embed.device)
+    allowed = torch.empty((B, Q), dtype=torch.int32, device=mask_embed.device)
+    with torch.cuda.device(mask_embed.device):
+        rc = native.lib().dvis_attn_mask(pe, pf, B, Q, C, H, W, h, w, native.dev_ptr(mask, "mask"),
+                                         native.dev_ptr(allowed, "allowed"), native.stream_ptr(mask_embed.device))
+    native.check(rc, "dvis_attn_mask")
+    return mask, allowed
+
+
+def attention(q, k, v, nheads, mask=None, allowed_count=None, out=None):
+    """Multi-head softmax(q k^T / sqrt(d)) v on projected, sequence-first tensors (what
+    nn.MultiheadAttention computes between its in- and out-projection).
+
+    q (Lq, B, C), k / v (Lk, B, C) float32 GPU tensors whose last dim is contiguous (views into a fused
+    in-projection are fine); heads are the C = nheads * d split, d in {32, 64}.
+    mask: uint8 / bool (B, Lq, Lk), 1 = blocked, shared by all heads of a batch entry; allowed_count int32 (B, Lq)
+    from ``attn_mask`` (rows with 0 ignore the mask).  Returns (Lq, B, C) ready for the out-projection.
+    """
+    Lq, B, C = q.shape
+    Lk = k.shape[0]
+    d = C // nheads
+    for name, t in (("q", q), ("k", k), ("v", v)):
+        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 3 or t.stride(2) != 1:
+            raise RuntimeError(f"attention: {name} must be a float32 GPU (L, B, C) tensor with a contiguous last dim")
+        if t.stride(1) != C and t.shape[1] != 1:
+            # (b, h) is addressed as one index bh = b * nheads + h with stride d: needs batch stride == C
+            raise RuntimeError(f"attention: {name} must have batch stride C (got {t.stride(1)} vs {C})")
+    if k.shape != v.shape or k.shape[1:] != q.shape[1:]:
+        raise RuntimeError("attention: inconsistent q / k / v shapes")
+    if out is None:
+        out = torch.empty((Lq, B, C), dtype=torch.float32, device=q.device)
+    mptr = aptr = None
+    if mask is not None:
+        if mask.dtype == torch.bool:
+            mask = mask.view(torch.uint8)
+        if mask.shape != (B, Lq, Lk) or mask.dtype != torch.uint8:
+            raise RuntimeError("attention: mask must be uint8/bool (B, Lq, Lk)")
+        mptr = native.dev_ptr(mask, "mask")
+        if allowed_count is not None:
+            if allowed_count.shape != (B, Lq) or allowed_count.dtype != torch.int32:
+                raise RuntimeError("attention: allowed_count must be int32 (B, Lq)")
+            aptr = native.dev_ptr(allowed_count, "allowed_count")
+    BH = B * nheads
+    lib = native.lib()
+    nbytes = lib.dvis_attention_ws_bytes(BH, Lq, Lk, d)
+    ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=q.device) if nbytes else None
+    with torch.cuda.device(q.device):
+        rc = lib.dvis_attention_forward(
+            ctypes.c_void_p(q.data_ptr()), d, q.stride(0), ctypes.c_void_p(k.data_ptr()), d, k.stride(0),
+            ctypes.c_void_p(v.data_ptr()), d, v.stride(0), ctypes.c_void_p(out.data_ptr()), d, out.stride(0),
+            mptr, aptr, nheads, BH, Lq, Lk, d, 1.0 / (d ** 0.5),
+            ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, native.stream_ptr(q.device))
+    native.check(rc, "dvis_attention_forward")
+    return out

@@ -83,6 +83,41 @@ int dvis_msda_fused_forward(const float *value, const int64_t *shapes, const int
                             int N, int S, int M, int D, int L, int Lq, int P, float *out, void *stream);
 
 /*
+ * Mask logits: out[b, q, p] = sum_c embed[b, q, c] * feat[b, c, p]     (fp32, exact-fp32 MFMA)
+ *   embed (B, Q, C), feat (B, C, HW), out (B, Q, HW)
+ */
+int dvis_mask_logits(const float *embed, const float *feat, int B, int Q, int C, int64_t HW,
+                     float *out, void *stream);
+
+/*
+ * Attention mask of the masked-attention decoder, one launch:
+ *   logits = embed x feat at the stride-4 map (never written to HBM), bilinear-resized
+ *   (align_corners=False) to (h, w) where H % h == 0, W % w == 0 and the factor is even
+ *   (=> the mean of the 2x2 centre pixels of every block, evaluated in torch's order),
+ *   blocked = logits < 0  (== sigmoid < 0.5).
+ *   embed (B, Q, C), feat (B, C, H, W)  ->  mask (B, Q, h*w) uint8 (1 = blocked), one copy (not per head);
+ *   allowed_count (B, Q) int32 = number of un-blocked keys per row (zeroed inside).  A row with count 0 is
+ *   "blocked everywhere": dvis_attention_forward then ignores the mask for that row, which is the reference's
+ *   reset `attn_mask[where(attn_mask.sum(-1) == HW)] = False` (:297) without its host sync.
+ */
+int dvis_attn_mask(const float *embed, const float *feat, int B, int Q, int C, int H, int W, int h, int w,
+                   uint8_t *mask, int32_t *allowed_count, void *stream);
+
+/*
+ * softmax(Q K^T * scale [masked]) V for batched heads, fp32 in/out, exact-fp32 MFMA.
+ *   q (BH, Lq, d)  k, v (BH, Lk, d)  out (BH, Lq, d), all with explicit strides in floats:
+ *   x[b, i, :] at  x + b * x_bstride + i * x_rstride   (d contiguous)
+ *   mask: NULL or uint8 (Bm, Lq, Lk), 1 = blocked; head b uses mask batch  b / heads_per_mask.
+ *   allowed_count: NULL or int32 (Bm, Lq) from dvis_attn_mask; rows with count 0 ignore the mask.
+ *   ws: workspace of dvis_attention_ws_bytes(...) bytes (split-K partials), may be NULL when that is 0.
+ */
+int64_t dvis_attention_ws_bytes(int BH, int Lq, int Lk, int d);
+int dvis_attention_forward(const float *q, int64_t q_bs, int64_t q_rs, const float *k, int64_t k_bs, int64_t k_rs,
+                           const float *v, int64_t v_bs, int64_t v_rs, float *out, int64_t o_bs, int64_t o_rs,
+                           const uint8_t *mask, const int32_t *allowed_count, int heads_per_mask,
+                           int BH, int Lq, int Lk, int d, float scale, void *ws, void *stream);
+
+/*
  * HOST function: minimum-cost assignment of an nr x nc (nr <= nc) row-major double cost matrix,
  * shortest-augmenting-path (Jonker-Volgenant / Crouse 2016) like scipy.optimize.linear_sum_assignment;
  * col4row[i] = column assigned to row i.  Returns 0, or DVIS_E_ARG for nan/-inf entries or nr > nc.

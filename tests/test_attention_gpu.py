@@ -1,0 +1,115 @@
+"""GPU parity: the fp32-MFMA attention kernel vs torch's nn.MultiheadAttention math in fp64 on the CPU
+(the op the reference calls: F.multi_head_attention_forward, need_weights=True).  Tolerance 2e-5 abs on
+O(1) outputs (BASELINE: 1e-3)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def ref_attention(q, k, v, nheads, mask=None):
+    """(L, B, C) tensors -> (Lq, B, C), fp64, explicit softmax; mask (B, Lq, Lk) True = blocked."""
+    Lq, B, C = q.shape
+    Lk, d = k.shape[0], C // nheads
+    qh = q.double().view(Lq, B, nheads, d).permute(1, 2, 0, 3)
+    kh = k.double().view(Lk, B, nheads, d).permute(1, 2, 0, 3)
+    vh = v.double().view(Lk, B, nheads, d).permute(1, 2, 0, 3)
+    s = (qh / d ** 0.5) @ kh.transpose(-1, -2)
+    if mask is not None:
+        s = s.masked_fill(mask[:, None].bool(), float("-inf"))
+    o = torch.softmax(s, -1) @ vh
+    return o.permute(2, 0, 1, 3).reshape(Lq, B, C)
+
+
+CASES = [  # (Lq, Lk, B, heads, d, masked)
+    (100, 920, 2, 8, 32, True), (100, 3680, 2, 8, 32, True), (100, 14720, 1, 8, 32, True),
+    (100, 100, 3, 8, 64, False), (30, 30, 100, 8, 64, False), (100, 100, 30, 8, 64, False),
+    (6, 24, 2, 2, 32, True), (6, 6, 1, 2, 32, False), (200, 333, 2, 8, 32, True), (17, 70, 2, 4, 64, True),
+    (5, 5, 6, 2, 32, False), (130, 257, 1, 2, 64, True),
+]
+
+
+@pytest.mark.parametrize("Lq,Lk,B,H,d,masked", CASES)
+def test_attention_vs_fp64(Lq, Lk, B, H, d, masked):
+    from dvis_plus_amd.functions import attention
+    g = torch.Generator().manual_seed(Lq * 7 + Lk)
+    C = H * d
+    q, k, v = (torch.randn(L, B, C, generator=g) for L in (Lq, Lk, Lk))
+    q = q * 2.0
+    mask = None
+    if masked:
+        mask = torch.rand(B, Lq, Lk, generator=g) < 0.7
+        mask[:, :, 0] = False                      # every row keeps at least one key
+        mask[0, 0, 1:] = True                      # a row with exactly one live key
+    ref = ref_attention(q, k, v, H, mask)
+    out = attention(q.to(DEV), k.to(DEV), v.to(DEV), H, None if mask is None else mask.to(DEV)).cpu()
+    torch.testing.assert_close(out.double(), ref, rtol=0, atol=2e-5)
+
+
+def test_attention_strided_views_of_fused_projection():
+    """q/k/v as views into one (L, B, 3C) in-projection output, output written into a given buffer."""
+    from dvis_plus_amd.functions import attention
+    g = torch.Generator().manual_seed(1)
+    L, B, H, d = 100, 4, 8, 64
+    C = H * d
+    qkv = torch.randn(L, B, 3 * C, generator=g)
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    ref = ref_attention(q, k, v, H)
+    dq = qkv.to(DEV)
+    with pytest.raises(RuntimeError, match="batch stride"):
+        attention(dq[..., :C], dq[..., C:2 * C], dq[..., 2 * C:], H)
+    qc, kc, vc = (t.contiguous() for t in (dq[..., :C], dq[..., C:2 * C], dq[..., 2 * C:]))
+    out = attention(qc, kc, vc, H).cpu()
+    torch.testing.assert_close(out.double(), ref, rtol=0, atol=2e-5)
+
+
+def test_fully_blocked_rows_follow_the_reference_reset():
+    """dvis_Plus/video_mask2former_transformer_decoder.py:297: a row blocked everywhere attends to everything."""
+    from dvis_plus_amd.functions import attention
+    g = torch.Generator().manual_seed(2)
+    Lq, Lk, B, H, d = 100, 920, 2, 8, 32
+    q, k, v = (torch.randn(L, B, H * d, generator=g) for L in (Lq, Lk, Lk))
+    mask = torch.rand(B, Lq, Lk, generator=g) < 0.5
+    mask[0, 3] = True
+    mask[1, 99] = True
+    allowed = (~mask).sum(-1).int()
+    fixed = mask.clone()
+    fixed[torch.where(fixed.sum(-1) == fixed.shape[-1])] = False
+    ref = ref_attention(q, k, v, H, fixed)
+    out = attention(q.to(DEV), k.to(DEV), v.to(DEV), H, mask.to(DEV), allowed.to(DEV)).cpu()
+    torch.testing.assert_close(out.double(), ref, rtol=0, atol=2e-5)
+
+
+def test_attention_matches_torch_mha_module():
+    """End to end against nn.MultiheadAttention itself (fp32 CPU), projections done with torch on the GPU."""
+    from dvis_plus_amd.functions import attention
+    torch.manual_seed(0)
+    C, H, Lq, Lk, B = 256, 8, 100, 920, 2
+    mha = torch.nn.MultiheadAttention(C, H).eval()
+    q, k, v = torch.randn(Lq, B, C), torch.randn(Lk, B, C), torch.randn(Lk, B, C)
+    mask = torch.rand(B, Lq, Lk) < 0.6
+    mask[:, :, 0] = False
+    with torch.no_grad():
+        ref = mha(q, k, v, attn_mask=mask.repeat_interleave(H, 0))[0]
+        W, b = mha.in_proj_weight.to(DEV), mha.in_proj_bias.to(DEV)
+        qp = F.linear(q.to(DEV), W[:C], b[:C])
+        kp = F.linear(k.to(DEV), W[C:2 * C], b[C:2 * C])
+        vp = F.linear(v.to(DEV), W[2 * C:], b[2 * C:])
+        o = attention(qp, kp, vp, H, mask.to(DEV))
+        out = F.linear(o, mha.out_proj.weight.to(DEV), mha.out_proj.bias.to(DEV)).cpu()
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=2e-5)
+
+
+def test_online_softmax_rescale_branch_is_exercised():
+    """A key far above the rest late in the sequence forces the running-max rescale path (and only there)."""
+    from dvis_plus_amd.functions import attention
+    g = torch.Generator().manual_seed(4)
+    Lq, Lk, B, H, d = 100, 512, 1, 2, 32
+    q, k, v = (torch.randn(L, B, H * d, generator=g) for L in (Lq, Lk, Lk))
+    k[400] = q[7] * 3.0            # spikes q[7]'s score at key 400
+    k[130] = q[50] * 2.0
+    ref = ref_attention(q, k, v, H)
+    out = attention(q.to(DEV), k.to(DEV), v.to(DEV), H).cpu()
+    torch.testing.assert_close(out.double(), ref, rtol=0, atol=2e-5)

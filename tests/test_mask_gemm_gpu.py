@@ -1,0 +1,84 @@
+"""GPU parity: mask-logit contraction / fused attention-mask kernels vs an fp64 oracle.
+
+The oracle is the reference's own op sequence (einsum -> F.interpolate(bilinear, align_corners=False) ->
+sigmoid < 0.5, dvis_Plus/video_mask2former_transformer_decoder.py:363-371) evaluated in fp64 on the CPU.
+Logits: <= 1e-4 abs (BASELINE: 1e-3).  Mask bits: must equal the fp64 decision wherever the down-sized logit is
+not within 1e-4 of the threshold (closer than that, fp32 summation order decides — in the reference too).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _inputs(B, Q, C, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(B, Q, C, generator=g), torch.randn(B, C, H, W, generator=g)
+
+
+@pytest.mark.parametrize("B,Q,C,H,W", [(2, 100, 256, 24, 40), (1, 6, 16, 16, 24), (3, 200, 256, 8, 136),
+                                        (1, 100, 256, 184, 320), (2, 17, 40, 5, 7), (1, 129, 64, 3, 50)])
+def test_mask_logits_vs_fp64(B, Q, C, H, W):
+    from dvis_plus_amd.functions import mask_logits
+    e, f = _inputs(B, Q, C, H, W, seed=B * 100 + Q)
+    ref = torch.einsum("bqc,bchw->bqhw", e.double(), f.double())
+    out = mask_logits(e.to(DEV), f.to(DEV)).cpu()
+    scale = (C ** 0.5)
+    torch.testing.assert_close(out.double(), ref, rtol=0, atol=2e-6 * scale * 4)
+
+
+def test_mask_logits_transpose_detecting():
+    """asymmetric operands: identity-like embed picks single channels -> catches row/col or k-permutation mix-ups."""
+    from dvis_plus_amd.functions import mask_logits
+    B, Q, C, H, W = 1, 100, 256, 4, 48
+    e = torch.zeros(B, Q, C)
+    for q in range(Q):
+        e[0, q, (q * 7 + 3) % C] = 1.0 + q
+    f = torch.arange(C * H * W, dtype=torch.float32).reshape(1, C, H, W) / 100.0
+    out = mask_logits(e.to(DEV), f.to(DEV)).cpu()
+    ref = torch.einsum("bqc,bchw->bqhw", e, f)
+    assert torch.equal(out, ref)     # one non-zero product per output: exact
+
+
+@pytest.mark.parametrize("B,Q,C,H,W,s", [(2, 100, 256, 16, 32, 2), (2, 100, 256, 16, 32, 4), (1, 100, 256, 16, 32, 8),
+                                          (1, 6, 16, 16, 24, 2), (1, 6, 16, 16, 24, 8), (2, 200, 256, 24, 40, 4),
+                                          (1, 100, 256, 184, 320, 2), (1, 100, 256, 184, 320, 8)])
+def test_attn_mask_vs_fp64(B, Q, C, H, W, s):
+    from dvis_plus_amd.functions import attn_mask
+    e, f = _inputs(B, Q, C, H, W, seed=7 + s)
+    h, w = H // s, W // s
+    logits = torch.einsum("bqc,bchw->bqhw", e.double(), f.double())
+    small = F.interpolate(logits, size=(h, w), mode="bilinear", align_corners=False).flatten(2)
+    ref = small.sigmoid() < 0.5
+    mask, allowed = attn_mask(e.to(DEV), f.to(DEV), (h, w))
+    mask, allowed = mask.cpu().bool(), allowed.cpu()
+    decided = small.abs() > 1e-4
+    assert torch.equal(mask[decided], ref[decided])
+    assert (~decided).float().mean() < 1e-3
+    assert torch.equal(allowed.long(), (~mask).sum(-1))
+
+
+def test_attn_mask_fully_blocked_rows_are_reported():
+    from dvis_plus_amd.functions import attn_mask
+    B, Q, C, H, W = 2, 100, 256, 16, 32
+    e, f = _inputs(B, Q, C, H, W, seed=3)
+    f = f.abs() + 0.1
+    e = e.abs()
+    e[0, 5] = -e[0, 5]            # every logit of row (0, 5) negative -> blocked everywhere
+    e[1, 99] = -e[1, 99]
+    mask, allowed = attn_mask(e.to(DEV), f.to(DEV), (8, 16))
+    allowed = allowed.cpu()
+    assert allowed[0, 5] == 0 and allowed[1, 99] == 0
+    assert (allowed > 0).sum() == B * Q - 2
+    assert mask.cpu()[0, 5].all()
+
+
+def test_mask_gemm_errors():
+    from dvis_plus_amd.functions import attn_mask, mask_logits
+    e, f = _inputs(1, 4, 8, 6, 6, 0)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        mask_logits(e, f)
+    with pytest.raises(RuntimeError, match="even integer"):
+        attn_mask(e.to(DEV), f.to(DEV), (2, 2))     # factor 3
