@@ -1,0 +1,110 @@
+"""ResNet-50 front-end (detectron2 ``build_resnet_backbone`` semantics: STRIDE_IN_1X1 False, FrozenBN, outputs
+res2..res5 at strides 4/8/16/32 with 256/512/1024/2048 channels — configs/…/Base-*.yaml:2-16).
+
+detectron2 is an un-vendored third-party dependency of the reference, so this module's numerics are NOT pinned by
+any reference source ("parity unpinned"); parity of the hot path is asserted from the
+backbone OUTPUTS onward.  Parameter names follow detectron2's checkpoints (stem.conv1.{weight,norm.*},
+resN.M.{conv1,conv2,conv3,shortcut}.{weight,norm.*}).  Convolutions run on MIOpen through torch — plain library
+calls; frozen batch-norm is folded into the convolution weights once at first use (inference).
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+class FrozenBatchNorm2d(nn.Module):
+    def __init__(self, num_features, eps=1e-5):
+        super().__init__()
+        self.num_features, self.eps = num_features, eps
+        self.register_buffer("weight", torch.ones(num_features))
+        self.register_buffer("bias", torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features) - eps)
+
+    def scale_shift(self):
+        scale = self.weight * (self.running_var + self.eps).rsqrt()
+        return scale, self.bias - self.running_mean * scale
+
+    def forward(self, x):
+        scale, shift = self.scale_shift()
+        return x * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)
+
+
+class ConvBN(nn.Conv2d):
+    """bias-free conv followed by FrozenBN (`.norm`), evaluated as ONE conv with folded weights."""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0):
+        super().__init__(cin, cout, k, stride=stride, padding=padding, bias=False)
+        self.norm = FrozenBatchNorm2d(cout)
+        self._folded = None
+        nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
+
+    def folded(self):
+        key = (self.weight._version, self.norm.weight._version, self.norm.running_var._version, self.weight.device,
+               self.weight.is_contiguous(memory_format=torch.channels_last))
+        if self._folded is None or self._folded[0] != key:
+            scale, shift = self.norm.scale_shift()
+            w = (self.weight.detach() * scale.reshape(-1, 1, 1, 1))
+            if key[-1]:
+                w = w.contiguous(memory_format=torch.channels_last)
+            self._folded = (key, w, shift.detach().contiguous())
+        return self._folded[1], self._folded[2]
+
+    def forward(self, x):
+        w, b = self.folded()
+        return F.conv2d(x, w, b, self.stride, self.padding)
+
+
+class BasicStem(nn.Module):
+    def __init__(self, in_channels=3, out_channels=64):
+        super().__init__()
+        self.conv1 = ConvBN(in_channels, out_channels, 7, stride=2, padding=3)
+
+    def forward(self, x):
+        return F.max_pool2d(F.relu_(self.conv1(x)), kernel_size=3, stride=2, padding=1)
+
+
+class BottleneckBlock(nn.Module):
+    def __init__(self, cin, cout, bottleneck, stride):
+        super().__init__()
+        self.shortcut = ConvBN(cin, cout, 1, stride=stride) if cin != cout else None
+        self.conv1 = ConvBN(cin, bottleneck, 1, stride=1)                       # STRIDE_IN_1X1 False:
+        self.conv2 = ConvBN(bottleneck, bottleneck, 3, stride=stride, padding=1)  # stride on the 3x3
+        self.conv3 = ConvBN(bottleneck, cout, 1)
+
+    def forward(self, x):
+        out = F.relu_(self.conv1(x))
+        out = F.relu_(self.conv2(out))
+        out = self.conv3(out)
+        out += x if self.shortcut is None else self.shortcut(x)
+        return F.relu_(out)
+
+
+class ResNet(nn.Module):
+    def __init__(self, depths=(3, 4, 6, 3), out_features=("res2", "res3", "res4", "res5")):
+        super().__init__()
+        self.stem = BasicStem()
+        cin, self._out_features = 64, list(out_features)
+        self.stage_names = []
+        for i, (n, bott, cout) in enumerate(zip(depths, (64, 128, 256, 512), (256, 512, 1024, 2048))):
+            blocks = []
+            for b in range(n):
+                blocks.append(BottleneckBlock(cin, cout, bott, stride=(1 if i == 0 or b > 0 else 2)))
+                cin = cout
+            name = f"res{i + 2}"
+            self.add_module(name, nn.Sequential(*blocks))
+            self.stage_names.append(name)
+        self.size_divisibility = 0
+
+    def forward(self, x):
+        out = {}
+        x = self.stem(x)
+        for name in self.stage_names:
+            x = getattr(self, name)(x)
+            if name in self._out_features:
+                out[name] = x
+        return out
+
+
+def build_resnet50():
+    return ResNet((3, 4, 6, 3))

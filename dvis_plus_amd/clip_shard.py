@@ -1,0 +1,49 @@
+"""Frame sharding of one clip over the GPUs of a node — SURVEY.md §8(e).
+
+The segmenter treats frames as a batch, so rank r runs backbone + pixel decoder + masked-attention decoder on a
+contiguous block of ceil(T/G) frames and keeps their mask_features locally (never communicated).  The tracker is a
+recurrence over t and the refiner attends over all T, so both need every frame's queries: ONE all-gather of the
+packed per-frame queries (pred_embds | pred_embds_without_norm | pred_logits = 4*C + K + 1 floats per query,
+459.6 KB per frame at Q=100, C=256, K=124) over RCCL/xGMI (gloo in the CPU tests); tracker + refiner then run
+replicated and deterministic on every rank, and each rank contracts masks for its own frames only.
+The reference has no intra-video parallelism at all — this is a new capability, not a port.
+"""
+import torch
+import torch.distributed as dist
+
+
+class ClipShard:
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+
+    def frames_per_rank(self, T):
+        return (T + self.world - 1) // self.world
+
+    def local_range(self, T):
+        per = self.frames_per_rank(T)
+        lo = min(T, self.rank * per)
+        return lo, min(T, lo + per)
+
+    def all_gather_frames(self, parts, T):
+        """parts: list of (t_local, Q, c_i) tensors for this rank's frames.  Returns the same list with all T frames,
+        identical on every rank.  One collective on one packed buffer."""
+        if self.world == 1:
+            return parts
+        per = self.frames_per_rank(T)
+        widths = [p.shape[-1] for p in parts]
+        Q = parts[0].shape[1]
+        packed = torch.zeros((per, Q, sum(widths)), dtype=parts[0].dtype, device=parts[0].device)
+        t_local = parts[0].shape[0]
+        if t_local:
+            packed[:t_local] = torch.cat(parts, dim=-1)
+        gathered = torch.empty((self.world * per, Q, sum(widths)), dtype=packed.dtype, device=packed.device)
+        dist.all_gather_into_tensor(gathered, packed, group=self.group)
+        gathered = gathered[:T]                      # ranks are frame-contiguous: padding only sits at the very end
+        return list(gathered.split(widths, dim=-1))
+
+    def all_reduce_sum(self, x):
+        if self.world > 1:
+            dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
+        return x

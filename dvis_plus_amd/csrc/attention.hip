@@ -28,6 +28,10 @@ namespace {
 
 constexpr int kKT = 64;   // keys per LDS stage
 
+struct dvis_strides {
+  int64_t b, h, r;   // floats between batch entries / heads / rows (last dim contiguous)
+};
+
 struct SplitPlan {
   int nsplit, keys_per_split, qchunks;
 };
@@ -48,10 +52,10 @@ SplitPlan plan_split(int BH, int Lq, int Lk) {
 
 template <int DH>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(
-    const float *__restrict__ q, int64_t q_bs, int64_t q_rs, const float *__restrict__ k, int64_t k_bs, int64_t k_rs,
-    const float *__restrict__ v, int64_t v_bs, int64_t v_rs, float *__restrict__ out, int64_t o_bs, int64_t o_rs,
-    const uint8_t *__restrict__ mask, const int *__restrict__ allowed, int heads_per_mask, int Lq, int Lk, float scale,
-    int nsplit, int keys_per_split, float *__restrict__ ws_o, float *__restrict__ ws_ml) {
+    const float *__restrict__ q, dvis_strides qs, const float *__restrict__ k, dvis_strides ks_, const float *__restrict__ v,
+    dvis_strides vs, float *__restrict__ out, dvis_strides os, const uint8_t *__restrict__ mask,
+    const int *__restrict__ allowed, int heads, int Lq, int Lk, float scale, int nsplit, int keys_per_split,
+    float *__restrict__ ws_o, float *__restrict__ ws_ml) {
   constexpr int DQ = DH / 4;        // dims per lane group
   constexpr int NT = DH / 16;       // output N tiles
   constexpr int LS = DH + 4;        // LDS row stride (floats): 16-B aligned, V rows of lane groups 0/1 split banks
@@ -66,6 +70,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(
   const int lane = tid & 63, wv = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int split = blockIdx.x, bh = blockIdx.y;
+  const int bi = bh / heads, hi = bh - bi * heads;   // (batch entry, head)
   const int q0 = blockIdx.z * 128 + wv * 16;
   const bool wave_on = q0 < Lq;
   const int myq = q0 + j;                // the query this lane's accumulator COLUMN belongs to
@@ -76,7 +81,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(
   // ---- B operand of S^T: Q[myq][g*DQ + kk] * scale (torch scales q before the product)
   float qf[DQ];
   {
-    const float *qrow = q + (size_t)bh * q_bs + (size_t)(q_ok ? myq : 0) * q_rs + g * DQ;
+    const float *qrow = q + (size_t)bi * qs.b + (size_t)hi * qs.h + (size_t)(q_ok ? myq : 0) * qs.r + g * DQ;
 #pragma unroll
     for (int c = 0; c < DQ / 4; ++c) {
       const float4 t = *reinterpret_cast<const float4 *>(qrow + 4 * c);
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(
       qf[4 * c + 3] = q_ok ? t.w * scale : 0.f;
     }
   }
-  const int mb = mask ? bh / heads_per_mask : 0;
+  const int mb = bi;
   const bool use_mask = mask != nullptr && q_ok && (allowed == nullptr || allowed[(size_t)mb * Lq + myq] != 0);
   const uint8_t *mrow = mask ? mask + ((size_t)mb * Lq + (q_ok ? myq : 0)) * Lk : nullptr;
   const bool lk4 = (Lk & 3) == 0;
@@ -96,8 +101,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(
   for (int n = 0; n < NT; ++n) o[n] = dvis_f4{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_part = 0.f;
 
-  const float *kb = k + (size_t)bh * k_bs;
-  const float *vb = v + (size_t)bh * v_bs;
+  const float *kb = k + (size_t)bi * ks_.b + (size_t)hi * ks_.h;
+  const float *vb = v + (size_t)bi * vs.b + (size_t)hi * vs.h;
   float4 pk[F4], pv[F4];
   auto prefetch = [&](int ks) {
 #pragma unroll
@@ -106,8 +111,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(
       const int row = e / (DH / 4), c4 = e - row * (DH / 4);
       const int key = ks + row;
       if (key < key_hi) {
-        pk[i] = *reinterpret_cast<const float4 *>(kb + (size_t)key * k_rs + 4 * c4);
-        pv[i] = *reinterpret_cast<const float4 *>(vb + (size_t)key * v_rs + 4 * c4);
+        pk[i] = *reinterpret_cast<const float4 *>(kb + (size_t)key * ks_.r + 4 * c4);
+        pv[i] = *reinterpret_cast<const float4 *>(vb + (size_t)key * vs.r + 4 * c4);
       } else {
         pk[i] = pv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(
       const int qq = q0 + 4 * g + r;
       if (qq < Lq) {
         const float inv = lr[r] > 0.f ? 1.f / lr[r] : 0.f;
-        float *orow = out + (size_t)bh * o_bs + (size_t)qq * o_rs;
+        float *orow = out + (size_t)bi * os.b + (size_t)hi * os.h + (size_t)qq * os.r;
 #pragma unroll
         for (int n = 0; n < NT; ++n) orow[16 * n + j] = o[n][r] * inv;
       }
@@ -231,8 +236,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(
 
 // Merge the per-split partials: O = sum_s O_s e^{m_s - M} / sum_s l_s e^{m_s - M}.
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restrict__ ws_o, const float *__restrict__ ws_ml,
-                                                           int nsplit, int Lq, int DH, size_t total,
-                                                           float *__restrict__ out, int64_t o_bs, int64_t o_rs) {
+                                                           int nsplit, int Lq, int DH, int heads, size_t total,
+                                                           float *__restrict__ out, dvis_strides os) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const int d = (int)(idx % DH);
@@ -249,7 +254,8 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restri
     num += ws_o[row * DH + d] * wgt;
     den += ws_ml[row * 2 + 1] * wgt;
   }
-  out[bh * o_bs + (size_t)qq * o_rs + d] = den > 0.f ? num / den : 0.f;
+  const size_t bi = bh / heads, hi = bh - bi * heads;
+  out[bi * os.b + hi * os.h + (size_t)qq * os.r + d] = den > 0.f ? num / den : 0.f;
 }
 
 }  // namespace
@@ -261,19 +267,20 @@ DVIS_EXPORT int64_t dvis_attention_ws_bytes(int BH, int Lq, int Lk, int d) {
   return (int64_t)BH * p.nsplit * Lq * (d + 2) * (int64_t)sizeof(float);
 }
 
-DVIS_EXPORT int dvis_attention_forward(const float *q, int64_t q_bs, int64_t q_rs, const float *k, int64_t k_bs,
-                                       int64_t k_rs, const float *v, int64_t v_bs, int64_t v_rs, float *out,
-                                       int64_t o_bs, int64_t o_rs, const uint8_t *mask, const int32_t *allowed_count,
-                                       int heads_per_mask, int BH, int Lq, int Lk, int d, float scale, void *ws,
-                                       void *stream) {
-  DVIS_REQUIRE(BH >= 0 && Lq >= 0 && Lk > 0, "attention: bad sizes");
-  if (BH == 0 || Lq == 0) return DVIS_OK;
-  DVIS_REQUIRE(q && k && v && out, "attention: null pointer");
+DVIS_EXPORT int dvis_attention_forward(const float *q, const int64_t *q_strides, const float *k, const int64_t *k_strides,
+                                       const float *v, const int64_t *v_strides, float *out, const int64_t *o_strides,
+                                       const uint8_t *mask, const int32_t *allowed_count, int B, int heads, int Lq,
+                                       int Lk, int d, float scale, void *ws, void *stream) {
+  DVIS_REQUIRE(B >= 0 && heads > 0 && Lq >= 0 && Lk > 0, "attention: bad sizes");
+  if (B == 0 || Lq == 0) return DVIS_OK;
+  DVIS_REQUIRE(q && k && v && out && q_strides && k_strides && v_strides && o_strides, "attention: null pointer");
   DVIS_REQUIRE(d == 32 || d == 64, "attention: head dim must be 32 or 64 (got %d)", d);
+  const int BH = B * heads;
   DVIS_REQUIRE(BH <= 65535, "attention: batch*heads must be <= 65535");
-  DVIS_REQUIRE(mask == nullptr || heads_per_mask > 0, "attention: heads_per_mask must be > 0 with a mask");
+  const dvis_strides qs{q_strides[0], q_strides[1], q_strides[2]}, ks{k_strides[0], k_strides[1], k_strides[2]};
+  const dvis_strides vs{v_strides[0], v_strides[1], v_strides[2]}, os{o_strides[0], o_strides[1], o_strides[2]};
   const uintptr_t al = (uintptr_t)q | (uintptr_t)k | (uintptr_t)v;
-  DVIS_REQUIRE((al & 15) == 0 && ((q_bs | q_rs | k_bs | k_rs | v_bs | v_rs) & 3) == 0,
+  DVIS_REQUIRE((al & 15) == 0 && ((qs.b | qs.h | qs.r | ks.b | ks.h | ks.r | vs.b | vs.h | vs.r) & 3) == 0,
                "attention: q/k/v must be 16-byte aligned with strides that are multiples of 4 floats");
   DVIS_REQUIRE(mask == nullptr || ((uintptr_t)mask & 3) == 0, "attention: mask must be 4-byte aligned");
   const SplitPlan p = plan_split(BH, Lq, Lk);
@@ -283,15 +290,15 @@ DVIS_EXPORT int dvis_attention_forward(const float *q, int64_t q_bs, int64_t q_r
   float *ws_ml = ws_o ? ws_o + (size_t)BH * p.nsplit * Lq * d : nullptr;
   const dim3 grid(p.nsplit, BH, p.qchunks), block(512);
   if (d == 32)
-    hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, block, 0, st, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, out, o_bs,
-                       o_rs, mask, allowed_count, heads_per_mask, Lq, Lk, scale, p.nsplit, p.keys_per_split, ws_o, ws_ml);
+    hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, block, 0, st, q, qs, k, ks, v, vs, out, os, mask, allowed_count, heads,
+                       Lq, Lk, scale, p.nsplit, p.keys_per_split, ws_o, ws_ml);
   else
-    hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, block, 0, st, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, out, o_bs,
-                       o_rs, mask, allowed_count, heads_per_mask, Lq, Lk, scale, p.nsplit, p.keys_per_split, ws_o, ws_ml);
+    hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, block, 0, st, q, qs, k, ks, v, vs, out, os, mask, allowed_count, heads,
+                       Lq, Lk, scale, p.nsplit, p.keys_per_split, ws_o, ws_ml);
   int rc = dvis_check_launch("attn_fwd_kernel");
   if (rc != DVIS_OK || p.nsplit == 1) return rc;
   const size_t total = (size_t)BH * Lq * d;
   hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws_o, ws_ml, p.nsplit,
-                     Lq, d, total, out, o_bs, o_rs);
+                     Lq, d, heads, total, out, os);
   return dvis_check_launch("attn_combine_kernel");
 }

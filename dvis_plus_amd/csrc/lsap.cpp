@@ -85,3 +85,30 @@ DVIS_EXPORT int dvis_lsap_solve(const double *cost, int nr, int nc, int64_t *col
   for (int r = 0; r < nr; ++r) col4row_out[r] = col4row[r];
   return DVIS_OK;
 }
+
+// The whole per-clip matching recurrence of the referring tracker on the host, in one call.
+//   cost (T, Q, Q) fp32: cost[i][c][r'] = 1 - cos(cur_i[c], cur_{i-1}[r'])   (frame 0: vs the carried-over reference
+//   embeddings, or vs itself at the start of a video) — computed on the GPU for all frames by ONE batched GEMM.
+// Reference (dvis_Plus/tracker.py:283-291, noiser.py:43-56): frame i is matched against the RE-ORDERED embeddings of
+// frame i-1, last_frame_embeds = cur_{i-1}[idx_{i-1}]; re-ordering rows of the reference only permutes the columns
+// of the similarity matrix, so  C_i[c][r] = cost[i][c][idx_{i-1}[r]]  and the assignment is solved on C_i^T
+// (rows = reference slots) exactly like linear_sum_assignment(C.transpose(0, 1))[1].  NaN costs become 0 (noiser.py:52).
+DVIS_EXPORT int dvis_match_chain(const float *cost, int T, int Q, int64_t *indices) {
+  DVIS_REQUIRE(cost && indices, "match_chain: null pointer");
+  DVIS_REQUIRE(T >= 0 && Q > 0, "match_chain: bad sizes");
+  std::vector<double> c((size_t)Q * Q);
+  for (int i = 0; i < T; ++i) {
+    const float *ci = cost + (size_t)i * Q * Q;
+    const int64_t *prev = i == 0 ? nullptr : indices + (size_t)(i - 1) * Q;
+    for (int r = 0; r < Q; ++r) {
+      const int64_t src = prev ? prev[r] : r;
+      for (int q = 0; q < Q; ++q) {
+        const float x = ci[(size_t)q * Q + src];
+        c[(size_t)r * Q + q] = std::isnan(x) ? 0.0 : (double)x;
+      }
+    }
+    int rc = dvis_lsap_solve(c.data(), Q, Q, indices + (size_t)i * Q);
+    if (rc != DVIS_OK) return rc;
+  }
+  return DVIS_OK;
+}

@@ -171,14 +171,20 @@ def attn_mask(mask_embed, mask_features, target_size):
     return mask, allowed
 
 
+def _strides3(t, B, C, d):
+    """(L, B, C) tensor -> {batch, head, row} strides in floats for the kernel's (B, heads, L, d) view."""
+    return (ctypes.c_int64 * 3)(t.stride(1) if B > 1 else C, d, t.stride(0))
+
+
 def attention(q, k, v, nheads, mask=None, allowed_count=None, out=None):
     """Multi-head softmax(q k^T / sqrt(d)) v on projected, sequence-first tensors (what
     nn.MultiheadAttention computes between its in- and out-projection).
 
-    q (Lq, B, C), k / v (Lk, B, C) float32 GPU tensors whose last dim is contiguous (views into a fused
-    in-projection are fine); heads are the C = nheads * d split, d in {32, 64}.
-    mask: uint8 / bool (B, Lq, Lk), 1 = blocked, shared by all heads of a batch entry; allowed_count int32 (B, Lq)
-    from ``attn_mask`` (rows with 0 ignore the mask).  Returns (Lq, B, C) ready for the out-projection.
+    q (Lq, B, C), k / v (Lk, B, C) float32 GPU tensors whose last dim is contiguous — arbitrary row / batch
+    strides, so slices of a fused in-projection work without copies; heads are the C = nheads * d split,
+    d in {32, 64}.  mask: uint8 / bool (B, Lq, Lk), 1 = blocked, shared by all heads of a batch entry;
+    allowed_count int32 (B, Lq) from ``attn_mask`` (rows with 0 ignore the mask).
+    Returns (Lq, B, C) ready for the out-projection.
     """
     Lq, B, C = q.shape
     Lk = k.shape[0]
@@ -186,9 +192,6 @@ def attention(q, k, v, nheads, mask=None, allowed_count=None, out=None):
     for name, t in (("q", q), ("k", k), ("v", v)):
         if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 3 or t.stride(2) != 1:
             raise RuntimeError(f"attention: {name} must be a float32 GPU (L, B, C) tensor with a contiguous last dim")
-        if t.stride(1) != C and t.shape[1] != 1:
-            # (b, h) is addressed as one index bh = b * nheads + h with stride d: needs batch stride == C
-            raise RuntimeError(f"attention: {name} must have batch stride C (got {t.stride(1)} vs {C})")
     if k.shape != v.shape or k.shape[1:] != q.shape[1:]:
         raise RuntimeError("attention: inconsistent q / k / v shapes")
     if out is None:
@@ -204,15 +207,14 @@ def attention(q, k, v, nheads, mask=None, allowed_count=None, out=None):
             if allowed_count.shape != (B, Lq) or allowed_count.dtype != torch.int32:
                 raise RuntimeError("attention: allowed_count must be int32 (B, Lq)")
             aptr = native.dev_ptr(allowed_count, "allowed_count")
-    BH = B * nheads
     lib = native.lib()
-    nbytes = lib.dvis_attention_ws_bytes(BH, Lq, Lk, d)
+    nbytes = lib.dvis_attention_ws_bytes(B * nheads, Lq, Lk, d)
     ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=q.device) if nbytes else None
     with torch.cuda.device(q.device):
         rc = lib.dvis_attention_forward(
-            ctypes.c_void_p(q.data_ptr()), d, q.stride(0), ctypes.c_void_p(k.data_ptr()), d, k.stride(0),
-            ctypes.c_void_p(v.data_ptr()), d, v.stride(0), ctypes.c_void_p(out.data_ptr()), d, out.stride(0),
-            mptr, aptr, nheads, BH, Lq, Lk, d, 1.0 / (d ** 0.5),
+            ctypes.c_void_p(q.data_ptr()), _strides3(q, B, C, d), ctypes.c_void_p(k.data_ptr()), _strides3(k, B, C, d),
+            ctypes.c_void_p(v.data_ptr()), _strides3(v, B, C, d), ctypes.c_void_p(out.data_ptr()),
+            _strides3(out, B, C, d), mptr, aptr, B, nheads, Lq, Lk, d, 1.0 / (d ** 0.5),
             ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, native.stream_ptr(q.device))
     native.check(rc, "dvis_attention_forward")
     return out

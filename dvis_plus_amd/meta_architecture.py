@@ -1,0 +1,191 @@
+"""DVIS++ meta-architectures (inference) — SURVEY.md §8 rows a12, a13, a15.
+
+Mirrors the registry names and the ``forward(batched_inputs)`` contract of
+  MaskFormerHead      mask2former/modeling/meta_arch/mask_former_head.py:19-152
+  DVIS_Plus_online    dvis_Plus/meta_architecture.py:404-1065  (forward :591-706, run_window_inference :774-816)
+  DVIS_Plus_offline   dvis_Plus/meta_architecture.py:1068-1580 (forward :1264-1396, run_window_inference :1446-1500)
+``batched_inputs = [{"image": [uint8/float (3,H,W)] * T, "height": h, "width": w, optional "keep": bool}]``;
+returns the task dict documented at meta_architecture.py:603-626 (tensors stay on the device).
+Checkpoint layout: backbone.*, sem_seg_head.{pixel_decoder,predictor}.*, tracker.*, refiner.*
+
+Differences by design (same results):
+  * no windowing / CPU off-loading: the whole clip's mask_features stay in HBM (1.8 GB at T=30, 720p);
+    the reference's 3-frame windows, per-window .cpu() and per-frame scipy syncs disappear;
+  * masks are only contracted for the queries post-processing keeps;
+  * optional frame sharding over the GPUs of a node (clip_shard.ClipShard), one all-gather per clip.
+"""
+import torch
+from torch import nn
+
+from . import postprocess as PP
+from .clip_shard import ClipShard
+from .registry import META_ARCH_REGISTRY, SEM_SEG_HEADS_REGISTRY
+
+
+@SEM_SEG_HEADS_REGISTRY.register()
+class MaskFormerHead(nn.Module):
+    def __init__(self, input_shape=None, *, num_classes, pixel_decoder, loss_weight=1.0, ignore_value=-1,
+                 transformer_predictor, transformer_in_feature="multi_scale_pixel_decoder"):
+        super().__init__()
+        assert transformer_in_feature == "multi_scale_pixel_decoder"
+        self.pixel_decoder, self.predictor = pixel_decoder, transformer_predictor
+        self.num_classes, self.ignore_value, self.loss_weight = num_classes, ignore_value, loss_weight
+        self.transformer_in_feature = transformer_in_feature
+
+    def forward(self, features, mask=None):
+        mask_features, _, multi_scale_features = self.pixel_decoder.forward_features(features)
+        return self.predictor(multi_scale_features, mask_features, mask)
+
+
+class _VideoBase(nn.Module):
+    def __init__(self, *, backbone, sem_seg_head, num_queries, object_mask_threshold=0.8, overlap_threshold=0.8,
+                 n_things=0, size_divisibility=32, pixel_mean=(123.675, 116.280, 103.530),
+                 pixel_std=(58.395, 57.120, 57.375), tracker=None, refiner=None, task="vis", max_num=20,
+                 window_size=3, segmenter_chunk=0):
+        super().__init__()
+        self.backbone, self.sem_seg_head, self.tracker, self.refiner = backbone, sem_seg_head, tracker, refiner
+        self.num_queries = num_queries
+        self.object_mask_threshold, self.overlap_threshold = object_mask_threshold, overlap_threshold
+        self.n_things = n_things
+        self.size_divisibility = size_divisibility
+        self.register_buffer("pixel_mean", torch.tensor(pixel_mean, dtype=torch.float32).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.tensor(pixel_std, dtype=torch.float32).view(-1, 1, 1), False)
+        assert task in ("vis", "vss", "vps")
+        self.task, self.max_num = task, max_num
+        self.window_size = window_size        # reference knob (TEST.WINDOW_SIZE); results do not depend on it
+        self.segmenter_chunk = segmenter_chunk  # frames per segmenter call, 0 = whole (local) clip at once
+        self.keep = False
+        self.clip_shard = ClipShard() if not torch.distributed.is_initialized() else ClipShard()
+        if hasattr(self.sem_seg_head.predictor, "compute_pred_masks"):
+            self.sem_seg_head.predictor.compute_pred_masks = False
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    # ---- meta_architecture.py:1306-1311: normalise, then pad bottom/right to a multiple of size_divisibility
+    def preprocess(self, frames):
+        x = frames if torch.is_tensor(frames) else torch.stack([f.to(self.device) for f in frames])
+        x = (x.to(self.device, torch.float32) - self.pixel_mean) / self.pixel_std
+        H, W = x.shape[-2:]
+        d = self.size_divisibility
+        Hp, Wp = ((H + d - 1) // d * d, (W + d - 1) // d * d) if d > 1 else (H, W)
+        if (Hp, Wp) != (H, W):
+            x = torch.nn.functional.pad(x, (0, Wp - W, 0, Hp - H))
+        return x, (H, W)
+
+    def segment(self, images):
+        """Segmenter over this rank's frames.  Returns per-frame queries (t,Q,·) and mask_features (t,Cm,h,w)."""
+        chunk = self.segmenter_chunk or len(images)
+        embds, embds_nn, logits, feats = [], [], [], []
+        for s in range(0, len(images), chunk):
+            out = self.sem_seg_head(self.backbone(images[s:s + chunk]))
+            embds.append(out["pred_embds"][0].permute(1, 2, 0))                    # (t, Q, 2C)
+            embds_nn.append(out["pred_embds_without_norm"][0].permute(1, 2, 0))
+            logits.append(out["pred_logits"][0])                                   # (t, Q, K+1)
+            feats.append(out["mask_features"])
+        cat = lambda xs: xs[0] if len(xs) == 1 else torch.cat(xs, 0)
+        return cat(embds), cat(embds_nn), cat(logits), cat(feats)
+
+    def _task_output(self, cls, aux, mask_fn, img_size, out_hw, padded_size, T_local):
+        K = self.sem_seg_head.num_classes
+        if self.task == "vis":
+            return PP.inference_video_vis(cls, mask_fn, img_size, out_hw, padded_size, K, self.max_num, aux)
+        if self.task == "vps":
+            return PP.inference_video_vps(cls, mask_fn, img_size, out_hw, padded_size, K, self.n_things,
+                                          self.object_mask_threshold, self.overlap_threshold, aux,
+                                          num_frames=T_local, reduce_fn=self.clip_shard.all_reduce_sum)
+        return PP.inference_video_vss(cls, mask_fn, img_size, out_hw, padded_size, aux)
+
+
+@META_ARCH_REGISTRY.register()
+class DVIS_Plus_online(_VideoBase):
+    """Segmenter + referring tracker; masks come from the tracker (projected mask features)."""
+
+    @torch.no_grad()
+    def forward(self, batched_inputs):
+        assert len(batched_inputs) == 1 and not self.training
+        video = batched_inputs[0]
+        self.keep = bool(video.get("keep", False))
+        images, img_size = self.preprocess(video["image"])
+        embds, embds_nn, logits, mask_features = self.segment(images)
+        to_bctq = lambda z: z.permute(2, 0, 1).unsqueeze(0)
+        track = self.tracker(to_bctq(embds), mask_features.unsqueeze(0), resume=self.keep,
+                             frame_embeds_no_norm=to_bctq(embds_nn), need_masks=False)
+        cls, _ = PP.mean_logits(track["pred_logits"])
+        dec = self.tracker.decoder_norm(track["pred_embds"][0].permute(1, 2, 0))   # (T, Q, C)
+        emb = self.tracker.mask_embed(dec)
+        proj = self.tracker.mask_feature_proj(mask_features)
+
+        def mask_fn(idx):
+            from . import functions as Fn
+            e = emb if idx is None else emb[:, idx]
+            return Fn.mask_logits(e.contiguous(), proj).permute(1, 0, 2, 3)
+        out_hw = (video.get("height", img_size[0]), video.get("width", img_size[1]))
+        return self._task_output(cls, None, mask_fn, img_size, out_hw, images.shape[-2:], len(images))
+
+
+@META_ARCH_REGISTRY.register()
+class DVIS_Plus_offline(_VideoBase):
+    """Segmenter + referring tracker + temporal refiner (the north-star path)."""
+
+    @torch.no_grad()
+    def forward(self, batched_inputs):
+        assert len(batched_inputs) == 1 and not self.training
+        video = batched_inputs[0]
+        self.keep = bool(video.get("keep", False))
+        frames = video["image"]
+        T = len(frames)
+        lo, hi = self.clip_shard.local_range(T)
+        images, img_size = self.preprocess(frames[lo:hi])                          # this rank's frames only
+        embds, embds_nn, logits, mask_features = self.segment(images)
+        embds, embds_nn, logits = self.clip_shard.all_gather_frames([embds, embds_nn, logits], T)
+        to_bctq = lambda z: z.permute(2, 0, 1).unsqueeze(0)
+        track = self.tracker(to_bctq(embds), None, resume=self.keep, frame_embeds_no_norm=to_bctq(embds_nn),
+                             need_masks=False)
+        ref = self.refiner(track["pred_embds"], to_bctq(embds_nn), None, need_masks=False)
+        cls, aux = PP.mean_logits(ref["pred_logits"], track["pred_logits"])
+        emb_local = ref["mask_embed"][:, lo:hi]                                     # (1, t_local, Q, Cm)
+        mf = mask_features.unsqueeze(0)
+
+        def mask_fn(idx):
+            return self.refiner.predict_masks(emb_local, mf, idx)[0]                # (q', t_local, h, w)
+        out_hw = (video.get("height", img_size[0]), video.get("width", img_size[1]))
+        out = self._task_output(cls, aux, mask_fn, img_size, out_hw, images.shape[-2:], hi - lo)
+        out["frame_range"] = (lo, hi)
+        return out
+
+
+def build_dvis_plus_r50(mode="offline", *, num_classes=124, num_queries=100, n_things=58, task="vps", hidden_dim=256,
+                        nheads=8, dim_feedforward=2048, dec_layers=10, enc_layers=6, tracker_layers=6,
+                        refiner_layers=6, max_num=20, object_mask_threshold=0.8, overlap_threshold=0.8, seed=0,
+                        segmenter_chunk=0):
+    """DVIS++ R50 with the sizes of configs/dvis_Plus/VIPSeg/DVIS_Plus_{Online,Offline}_R50.yaml (HIDDEN_DIM 256,
+    NHEADS 8, DIM_FEEDFORWARD 2048, DEC_LAYERS 10, 6 encoder / tracker / refiner layers, 100 queries, REID branch ->
+    512-channel tracker/refiner) and deterministic random weights following the reference's init rules."""
+    from .backbone import build_resnet50
+    from .pixel_decoder import MSDeformAttnPixelDecoder, r50_input_shape
+    from .refiner import TemporalRefiner
+    from .tracker import ReferringTracker_noiser
+    from .transformer_decoder import VideoMultiScaleMaskedTransformerDecoder_dvisPlus
+    torch.manual_seed(seed)
+    pixel_decoder = MSDeformAttnPixelDecoder(
+        r50_input_shape(), transformer_dropout=0.0, transformer_nheads=nheads, transformer_dim_feedforward=1024,
+        transformer_enc_layers=enc_layers, conv_dim=hidden_dim, mask_dim=hidden_dim, norm="GN",
+        transformer_in_features=["res3", "res4", "res5"], common_stride=4)
+    predictor = VideoMultiScaleMaskedTransformerDecoder_dvisPlus(
+        hidden_dim, True, num_classes=num_classes, hidden_dim=hidden_dim, num_queries=num_queries, nheads=nheads,
+        dim_feedforward=dim_feedforward, dec_layers=dec_layers - 1, pre_norm=False, mask_dim=hidden_dim,
+        enforce_input_project=False, num_frames=1, num_reid_head_layers=3, reid_hidden_dim=hidden_dim)
+    head = MaskFormerHead(num_classes=num_classes, pixel_decoder=pixel_decoder, transformer_predictor=predictor)
+    tracker = ReferringTracker_noiser(hidden_channel=2 * hidden_dim, feedforward_channel=dim_feedforward,
+                                      num_head=nheads, decoder_layer_num=tracker_layers, noise_mode="wa",
+                                      mask_dim=hidden_dim, class_num=num_classes)
+    kw = dict(backbone=build_resnet50(), sem_seg_head=head, num_queries=num_queries,
+              object_mask_threshold=object_mask_threshold, overlap_threshold=overlap_threshold, n_things=n_things,
+              tracker=tracker, task=task, max_num=max_num, segmenter_chunk=segmenter_chunk)
+    if mode == "online":
+        return DVIS_Plus_online(**kw).eval()
+    refiner = TemporalRefiner(hidden_channel=2 * hidden_dim, feedforward_channel=dim_feedforward, num_head=nheads,
+                              decoder_layer_num=refiner_layers, mask_dim=hidden_dim, class_num=num_classes, windows=3)
+    return DVIS_Plus_offline(refiner=refiner, **kw).eval()

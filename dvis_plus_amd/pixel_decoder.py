@@ -1,0 +1,377 @@
+"""MSDeformAttn module + MSDeformAttn pixel decoder — host side of SURVEY.md §8 rows a3, a4, a5, a14.
+
+Mirrors (same constructor arguments, attribute names and ``state_dict`` keys, so reference checkpoints load
+with ``strict=True``):
+  MSDeformAttn                         mask2former/modeling/pixel_decoder/ops/modules/ms_deform_attn.py:34-125
+  MSDeformAttnTransformerEncoderLayer  mask2former/modeling/pixel_decoder/msdeformattn.py:92-131
+  MSDeformAttnTransformerEncoder       ibid. :134-161
+  MSDeformAttnTransformerEncoderOnly   ibid. :23-89
+  MSDeformAttnPixelDecoder             ibid. :164-358
+  PositionEmbeddingSine                mask2former/modeling/transformer_decoder/position_encoding.py:12-52
+
+What is different (MI355X-first, same numbers):
+  * no silent fallback: the op raises if the HIP library is missing or tensors are not on the GPU
+    (the reference's bare ``except`` at ms_deform_attn.py:119 hides every failure);
+  * inference fast path: ONE projection produces offsets|logits (weights concatenated once), and the fused
+    kernel applies softmax + location arithmetic in LDS — sampling_locations / attention_weights are never
+    materialised; the general path (autograd, 4-d reference boxes, padding masks, fp16/bf16/fp64) goes through
+    ``MSDeformAttnFunction`` exactly like the reference;
+  * sine position embeddings and encoder reference points depend on shapes only and are cached per shape.
+"""
+import math
+import warnings
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn.init import constant_, normal_, xavier_uniform_
+
+from . import functions as Fn
+from .registry import SEM_SEG_HEADS_REGISTRY, ShapeSpec
+
+
+def _is_power_of_2(n):
+    if (not isinstance(n, int)) or (n < 0):
+        raise ValueError("invalid input for _is_power_of_2: {} (type: {})".format(n, type(n)))
+    return (n & (n - 1) == 0) and n != 0
+
+
+class PositionEmbeddingSine(nn.Module):
+    """2-D sine embedding; output depends on (N, H, W) only (mask is always all-False on this path) → cached."""
+
+    def __init__(self, num_pos_feats=64, temperature=10000, normalize=False, scale=None):
+        super().__init__()
+        if scale is not None and normalize is False:
+            raise ValueError("normalize should be True if scale is passed")
+        self.num_pos_feats, self.temperature, self.normalize = num_pos_feats, temperature, normalize
+        self.scale = 2 * math.pi if scale is None else scale
+        self._cache = {}
+
+    def compute(self, h, w, device):
+        """(1, 2*num_pos_feats, h, w) — identical for every batch entry."""
+        key = (h, w, str(device))
+        if key not in self._cache:
+            y_embed = torch.arange(1, h + 1, dtype=torch.float32, device=device)[None, :, None].expand(1, h, w)
+            x_embed = torch.arange(1, w + 1, dtype=torch.float32, device=device)[None, None, :].expand(1, h, w)
+            if self.normalize:
+                eps = 1e-6
+                y_embed = y_embed / (y_embed[:, -1:, :] + eps) * self.scale
+                x_embed = x_embed / (x_embed[:, :, -1:] + eps) * self.scale
+            dim_t = torch.arange(self.num_pos_feats, dtype=torch.float32, device=device)
+            dim_t = self.temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / self.num_pos_feats)
+            pos_x = x_embed[:, :, :, None] / dim_t
+            pos_y = y_embed[:, :, :, None] / dim_t
+            pos_x = torch.stack((pos_x[:, :, :, 0::2].sin(), pos_x[:, :, :, 1::2].cos()), dim=4).flatten(3)
+            pos_y = torch.stack((pos_y[:, :, :, 0::2].sin(), pos_y[:, :, :, 1::2].cos()), dim=4).flatten(3)
+            self._cache[key] = torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2).contiguous()
+        return self._cache[key]
+
+    def forward(self, x, mask=None):
+        if mask is not None:
+            raise NotImplementedError("padding masks are not used on the DVIS++ inference path")
+        return self.compute(x.shape[-2], x.shape[-1], x.device).expand(x.shape[0], -1, -1, -1)
+
+
+class MSDeformAttn(nn.Module):
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4, ratio=1.0):
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise ValueError("d_model must be divisible by n_heads, but got {} and {}".format(d_model, n_heads))
+        if not _is_power_of_2(d_model // n_heads):
+            warnings.warn("MSDeformAttn: a power-of-2 head dimension (32 / 64) takes the tiled gfx950 kernel; "
+                          "other sizes run the generic kernel.")
+        self.im2col_step = 128          # accepted for API compatibility, not needed by the HIP op
+        self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+        self._fused = None               # (version key, W_cat, b_cat) for the inference fast path
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        constant_(self.sampling_offsets.weight.data, 0.)
+        thetas = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
+        grid_init = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid_init = (grid_init / grid_init.abs().max(-1, keepdim=True)[0]).view(self.n_heads, 1, 1, 2).repeat(
+            1, self.n_levels, self.n_points, 1)
+        for i in range(self.n_points):
+            grid_init[:, :, i, :] *= i + 1
+        with torch.no_grad():
+            self.sampling_offsets.bias = nn.Parameter(grid_init.view(-1))
+        constant_(self.attention_weights.weight.data, 0.)
+        constant_(self.attention_weights.bias.data, 0.)
+        xavier_uniform_(self.value_proj.weight.data)
+        constant_(self.value_proj.bias.data, 0.)
+        xavier_uniform_(self.output_proj.weight.data)
+        constant_(self.output_proj.bias.data, 0.)
+
+    def _fused_projection(self):
+        so, aw = self.sampling_offsets, self.attention_weights
+        key = (so.weight._version, so.bias._version, aw.weight._version, aw.bias._version, so.weight.device)
+        if self._fused is None or self._fused[0] != key:
+            w = torch.cat([so.weight.detach(), aw.weight.detach()], 0).contiguous()
+            b = torch.cat([so.bias.detach(), aw.bias.detach()], 0).contiguous()
+            self._fused = (key, w, b)
+        return self._fused[1], self._fused[2]
+
+    def _fast_path_ok(self, query, reference_points, input_padding_mask):
+        d = self.d_model // self.n_heads
+        return (not torch.is_grad_enabled() and query.is_cuda and query.dtype == torch.float32
+                and input_padding_mask is None and reference_points.shape[-1] == 2 and d in (32, 64)
+                and (self.n_levels, self.n_points) in ((1, 4), (3, 4), (4, 4)))
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                input_padding_mask=None):
+        N, Len_q, _ = query.shape
+        N, Len_in, _ = input_flatten.shape
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+        value = self.value_proj(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], float(0))
+        value = value.view(N, Len_in, M, self.d_model // M)
+        if self._fast_path_ok(query, reference_points, input_padding_mask):
+            w, b = self._fused_projection()
+            proj = F.linear(query.reshape(N * Len_q, self.d_model), w, b)          # offsets | logits in one GEMM
+            n_off = M * L * P * 2
+            ref = reference_points if reference_points.is_contiguous() else reference_points.contiguous()
+            output = Fn.msda_fused_forward(value, input_spatial_shapes, input_level_start_index, ref,
+                                           proj[:, :n_off], proj[:, n_off:], L, P)
+            return self.output_proj(output)
+        sampling_offsets = self.sampling_offsets(query).view(N, Len_q, M, L, P, 2)
+        attention_weights = self.attention_weights(query).view(N, Len_q, M, L * P)
+        attention_weights = F.softmax(attention_weights, -1).view(N, Len_q, M, L, P)
+        if reference_points.shape[-1] == 2:
+            offset_normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
+            sampling_locations = reference_points[:, :, None, :, None, :] \
+                + sampling_offsets / offset_normalizer[None, None, None, :, None, :]
+        elif reference_points.shape[-1] == 4:
+            sampling_locations = reference_points[:, :, None, :, None, :2] \
+                + sampling_offsets / P * reference_points[:, :, None, :, None, 2:] * 0.5
+        else:
+            raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
+                reference_points.shape[-1]))
+        output = Fn.MSDeformAttnFunction.apply(value.contiguous(), input_spatial_shapes, input_level_start_index,
+                                               sampling_locations.contiguous(), attention_weights.contiguous(),
+                                               self.im2col_step)
+        return self.output_proj(output)
+
+
+class MSDeformAttnTransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        if activation != "relu":
+            raise NotImplementedError("only relu is used by the DVIS++ configs")
+        self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.dropout_p = dropout     # inference path: dropout is the identity
+
+    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
+        q = src if pos is None else src + pos
+        src2 = self.self_attn(q, reference_points, src, spatial_shapes, level_start_index, padding_mask)
+        src = self.norm1(src + src2)
+        src2 = self.linear2(F.relu(self.linear1(src)))
+        return self.norm2(src + src2)
+
+
+class MSDeformAttnTransformerEncoder(nn.Module):
+    def __init__(self, encoder_layer_factory, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([encoder_layer_factory() for _ in range(num_layers)])
+        self.num_layers = num_layers
+        self._ref_cache = {}
+
+    @staticmethod
+    def get_reference_points(spatial_shapes, valid_ratios, device):
+        pts = []
+        for lvl, (H_, W_) in enumerate(spatial_shapes):
+            H_, W_ = int(H_), int(W_)
+            ref_y, ref_x = torch.meshgrid(torch.linspace(0.5, H_ - 0.5, H_, dtype=torch.float32, device=device),
+                                          torch.linspace(0.5, W_ - 0.5, W_, dtype=torch.float32, device=device),
+                                          indexing="ij")
+            ref_y = ref_y.reshape(-1)[None] / (valid_ratios[:, None, lvl, 1] * H_)
+            ref_x = ref_x.reshape(-1)[None] / (valid_ratios[:, None, lvl, 0] * W_)
+            pts.append(torch.stack((ref_x, ref_y), -1))
+        reference_points = torch.cat(pts, 1)
+        return reference_points[:, :, None] * valid_ratios[:, None]
+
+    def reference_points_unpadded(self, shapes_py, device):
+        """valid_ratios == 1 (no padding masks on this path): shape-only, batch-independent, cached. (1, S, L, 2)"""
+        key = (tuple(shapes_py), str(device))
+        if key not in self._ref_cache:
+            vr = torch.ones(1, len(shapes_py), 2, device=device)
+            self._ref_cache[key] = self.get_reference_points(shapes_py, vr, device).contiguous()
+        return self._ref_cache[key]
+
+    def forward(self, src, spatial_shapes, level_start_index, valid_ratios=None, pos=None, padding_mask=None,
+                shapes_py=None):
+        if valid_ratios is None:
+            reference_points = self.reference_points_unpadded(shapes_py, src.device)
+        else:
+            reference_points = self.get_reference_points(spatial_shapes.tolist(), valid_ratios, src.device)
+        output = src
+        for layer in self.layers:
+            output = layer(output, pos, reference_points, spatial_shapes, level_start_index, padding_mask)
+        return output
+
+
+class MSDeformAttnTransformerEncoderOnly(nn.Module):
+    def __init__(self, d_model=256, nhead=8, num_encoder_layers=6, dim_feedforward=1024, dropout=0.1,
+                 activation="relu", num_feature_levels=4, enc_n_points=4):
+        super().__init__()
+        self.d_model, self.nhead = d_model, nhead
+        self.encoder = MSDeformAttnTransformerEncoder(
+            lambda: MSDeformAttnTransformerEncoderLayer(d_model, dim_feedforward, dropout, activation,
+                                                        num_feature_levels, nhead, enc_n_points),
+            num_encoder_layers)
+        self.level_embed = nn.Parameter(torch.Tensor(num_feature_levels, d_model))
+        self._shape_cache = {}
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, MSDeformAttn):
+                m._reset_parameters()
+        normal_(self.level_embed)
+
+    def _shape_tensors(self, shapes_py, device):
+        key = (tuple(shapes_py), str(device))
+        if key not in self._shape_cache:
+            s = torch.as_tensor(shapes_py, dtype=torch.long, device=device)
+            lsi = torch.cat((s.new_zeros((1,)), s.prod(1).cumsum(0)[:-1]))
+            self._shape_cache[key] = (s, lsi)
+        return self._shape_cache[key]
+
+    def forward(self, srcs, pos_embeds):
+        """srcs: per level (N, C, H, W); pos_embeds: per level (1|N, C, H, W).  No padding (masks all False)."""
+        shapes_py = [(int(s.shape[2]), int(s.shape[3])) for s in srcs]
+        src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
+        lvl_pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1)
+                             for lvl, p in enumerate(pos_embeds)], 1)
+        spatial_shapes, level_start_index = self._shape_tensors(shapes_py, src_flatten.device)
+        memory = self.encoder(src_flatten, spatial_shapes, level_start_index, None, lvl_pos, None, shapes_py=shapes_py)
+        return memory, spatial_shapes, level_start_index, shapes_py
+
+
+class ConvNorm(nn.Conv2d):
+    """Conv2d -> norm -> activation with detectron2.layers.Conv2d's parameter names (weight, bias, norm.*)."""
+
+    def __init__(self, *args, norm=None, activation=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.norm, self.activation = norm, activation
+
+    def forward(self, x):
+        x = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        if self.norm is not None:
+            x = self.norm(x)
+        if self.activation is not None:
+            x = self.activation(x)
+        return x
+
+
+def get_norm(norm, out_channels):
+    if norm is None or norm == "":
+        return None
+    if norm != "GN":
+        raise NotImplementedError(f"norm {norm!r}: the DVIS++ configs use GN")
+    return nn.GroupNorm(32, out_channels)
+
+
+def c2_xavier_fill(module):
+    nn.init.kaiming_uniform_(module.weight, a=1)
+    if module.bias is not None:
+        nn.init.constant_(module.bias, 0)
+
+
+@SEM_SEG_HEADS_REGISTRY.register()
+class MSDeformAttnPixelDecoder(nn.Module):
+    def __init__(self, input_shape, *, transformer_dropout, transformer_nheads, transformer_dim_feedforward,
+                 transformer_enc_layers, conv_dim, mask_dim, norm=None, transformer_in_features, common_stride):
+        super().__init__()
+        transformer_input_shape = {k: v for k, v in input_shape.items() if k in transformer_in_features}
+        input_shape = sorted(input_shape.items(), key=lambda x: x[1].stride)
+        self.in_features = [k for k, v in input_shape]
+        self.feature_strides = [v.stride for k, v in input_shape]
+        self.feature_channels = [v.channels for k, v in input_shape]
+        transformer_input_shape = sorted(transformer_input_shape.items(), key=lambda x: x[1].stride)
+        self.transformer_in_features = [k for k, v in transformer_input_shape]
+        transformer_in_channels = [v.channels for k, v in transformer_input_shape]
+        self.transformer_feature_strides = [v.stride for k, v in transformer_input_shape]
+        self.transformer_num_feature_levels = len(self.transformer_in_features)
+        chans = transformer_in_channels[::-1] if self.transformer_num_feature_levels > 1 \
+            else [transformer_in_channels[-1]]
+        self.input_proj = nn.ModuleList([
+            nn.Sequential(nn.Conv2d(c, conv_dim, kernel_size=1), nn.GroupNorm(32, conv_dim)) for c in chans])
+        for proj in self.input_proj:
+            nn.init.xavier_uniform_(proj[0].weight, gain=1)
+            nn.init.constant_(proj[0].bias, 0)
+        self.transformer = MSDeformAttnTransformerEncoderOnly(
+            d_model=conv_dim, dropout=transformer_dropout, nhead=transformer_nheads,
+            dim_feedforward=transformer_dim_feedforward, num_encoder_layers=transformer_enc_layers,
+            num_feature_levels=self.transformer_num_feature_levels)
+        self.pe_layer = PositionEmbeddingSine(conv_dim // 2, normalize=True)
+        self.mask_dim = mask_dim
+        self.mask_features = ConvNorm(conv_dim, mask_dim, kernel_size=1, stride=1, padding=0)
+        c2_xavier_fill(self.mask_features)
+        self.maskformer_num_feature_levels = 3
+        self.common_stride = common_stride
+        stride = min(self.transformer_feature_strides)
+        self.num_fpn_levels = int(math.log2(stride) - math.log2(self.common_stride))
+        lateral_convs, output_convs = [], []
+        use_bias = norm == ""
+        for idx, in_channels in enumerate(self.feature_channels[:self.num_fpn_levels]):
+            lateral_conv = ConvNorm(in_channels, conv_dim, kernel_size=1, bias=use_bias, norm=get_norm(norm, conv_dim))
+            output_conv = ConvNorm(conv_dim, conv_dim, kernel_size=3, stride=1, padding=1, bias=use_bias,
+                                   norm=get_norm(norm, conv_dim), activation=F.relu)
+            c2_xavier_fill(lateral_conv)
+            c2_xavier_fill(output_conv)
+            self.add_module("adapter_{}".format(idx + 1), lateral_conv)
+            self.add_module("layer_{}".format(idx + 1), output_conv)
+            lateral_convs.append(lateral_conv)
+            output_convs.append(output_conv)
+        self.lateral_convs = lateral_convs[::-1]
+        self.output_convs = output_convs[::-1]
+
+    @classmethod
+    def from_config(cls, cfg, input_shape):
+        hd = cfg.MODEL.SEM_SEG_HEAD
+        return dict(
+            input_shape={k: v for k, v in input_shape.items() if k in hd.IN_FEATURES},
+            conv_dim=hd.CONVS_DIM, mask_dim=hd.MASK_DIM, norm=hd.NORM,
+            transformer_dropout=cfg.MODEL.MASK_FORMER.DROPOUT, transformer_nheads=cfg.MODEL.MASK_FORMER.NHEADS,
+            transformer_dim_feedforward=1024, transformer_enc_layers=hd.TRANSFORMER_ENC_LAYERS,
+            transformer_in_features=hd.DEFORMABLE_TRANSFORMER_ENCODER_IN_FEATURES, common_stride=hd.COMMON_STRIDE)
+
+    def forward_features(self, features):
+        """features: dict name -> (N, C, H, W).  fp32 island like the reference (msdeformattn.py:314-320).
+        Returns (mask_features, out[0], multi_scale_features[:3])."""
+        with torch.autocast(device_type="cuda", enabled=False):
+            srcs, pos = [], []
+            for idx, f in enumerate(self.transformer_in_features[::-1]):
+                x = features[f].float()
+                srcs.append(self.input_proj[idx](x))
+                pos.append(self.pe_layer.compute(x.shape[2], x.shape[3], x.device))
+            y, _, _, shapes_py = self.transformer(srcs, pos)
+            bs = y.shape[0]
+            out, start = [], 0
+            for (h, w) in shapes_py:
+                out.append(y[:, start:start + h * w].transpose(1, 2).reshape(bs, -1, h, w))
+                start += h * w
+            for idx, f in enumerate(self.in_features[:self.num_fpn_levels][::-1]):
+                x = features[f].float()
+                cur_fpn = self.lateral_convs[idx](x)
+                y = cur_fpn + F.interpolate(out[-1], size=cur_fpn.shape[-2:], mode="bilinear", align_corners=False)
+                out.append(self.output_convs[idx](y))
+            multi_scale_features = out[:self.maskformer_num_feature_levels]
+            return self.mask_features(out[-1]), out[0], multi_scale_features
+
+
+def r50_input_shape():
+    return {"res2": ShapeSpec(channels=256, stride=4), "res3": ShapeSpec(channels=512, stride=8),
+            "res4": ShapeSpec(channels=1024, stride=16), "res5": ShapeSpec(channels=2048, stride=32)}

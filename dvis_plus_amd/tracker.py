@@ -1,0 +1,193 @@
+"""Referring tracker — host side of SURVEY.md §8 rows a9, a10.
+
+Mirrors ``ReferringCrossAttentionLayer`` / ``ReferringTracker_noiser`` (dvis_Plus/tracker.py:8-380) and the eval
+branch of ``Noiser`` (dvis_Plus/noiser.py:43-77): same constructor arguments, ``state_dict`` keys, call signature,
+returned dict and cross-call state (``resume`` continues a video).
+
+The reference walks the clip frame by frame and, per frame, syncs the device for a scipy assignment, recomputes
+six K/V projections and (offline) a mask einsum whose result is thrown away.  Here:
+  * the assignment chain depends only on the segmenter's embeddings, so ALL cosine-cost matrices of a clip are one
+    batched GEMM; one D2H copy feeds the host solver (libdvis_hip's Jonker-Volgenant, bit-identical to scipy on the
+    golden vectors) which runs the T-step recurrence in C++ and returns every frame's permutation: one sync per
+    clip instead of one per frame;
+  * K / V projections of the 6 cross-attention layers for all T frames are one GEMM;
+  * the recurrence itself (what genuinely is sequential) runs on the fp32-MFMA attention kernel;
+  * masks are only contracted when asked for (online mode); offline mode never needs them
+    (dvis_Plus/meta_architecture.py:1486 deletes them).
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import functions as Fn
+from . import native
+from .pixel_decoder import c2_xavier_fill
+from .transformer_decoder import MLP, FFNLayer, SelfAttentionLayer, _xavier_
+
+
+class ReferringCrossAttentionLayer(nn.Module):
+    """Cross-attention whose residual comes from `indentify` instead of the query (tracker.py:35-53)."""
+
+    def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False):
+        super().__init__()
+        if normalize_before:
+            raise NotImplementedError("normalize_before=True is not used by DVIS++")
+        self.multihead_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.norm = nn.LayerNorm(d_model)
+        self.nhead = nhead
+        _xavier_(self)
+
+    def attend(self, indentify, tgt, k_proj, v_proj):
+        C = tgt.shape[-1]
+        q = F.linear(tgt, self.multihead_attn.in_proj_weight[:C], self.multihead_attn.in_proj_bias[:C])
+        att = Fn.attention(q, k_proj, v_proj, self.nhead)
+        return self.norm(indentify + self.multihead_attn.out_proj(att))
+
+    def forward(self, indentify, tgt, key, memory, memory_mask=None, memory_key_padding_mask=None, pos=None,
+                query_pos=None):
+        assert memory_mask is None and memory_key_padding_mask is None and pos is None and query_pos is None
+        C = tgt.shape[-1]
+        W, b = self.multihead_attn.in_proj_weight, self.multihead_attn.in_proj_bias
+        return self.attend(indentify, tgt, F.linear(key, W[C:2 * C], b[C:2 * C]), F.linear(memory, W[2 * C:], b[2 * C:]))
+
+
+def match_chain(cost):
+    """cost (T, Q, Q) fp32 GPU/CPU tensor (see dvis_match_chain) -> int64 numpy (T, Q).  ONE device->host copy."""
+    c = cost.detach().to("cpu", torch.float32).contiguous().numpy()
+    T, Q, _ = c.shape
+    out = np.empty((T, Q), dtype=np.int64)
+    rc = native.lib().dvis_match_chain(c.ctypes.data_as(ctypes.c_void_p), T, Q, out.ctypes.data_as(ctypes.c_void_p))
+    native.check(rc, "dvis_match_chain")
+    return out
+
+
+def cosine_costs(cur, ref_first):
+    """cur (T, Q, C) embeddings of the clip, ref_first (Q, C) what frame 0 is matched against.
+    -> (T, Q, Q) with cost[i] = 1 - norm(cur_i) @ norm(ref_i)^T, ref_i = cur_{i-1} (un-permuted) for i > 0.
+    Normalisation as Noiser.match_embds: x / (||x|| + 1e-6)."""
+    nrm = cur / (cur.norm(dim=-1, keepdim=True) + 1e-6)
+    r0 = ref_first / (ref_first.norm(dim=-1, keepdim=True) + 1e-6)
+    ref = torch.cat([r0[None], nrm[:-1]], 0)
+    return 1 - torch.bmm(nrm, ref.transpose(1, 2))
+
+
+class ReferringTracker_noiser(nn.Module):
+    def __init__(self, hidden_channel=256, feedforward_channel=2048, num_head=8, decoder_layer_num=6, mask_dim=256,
+                 class_num=25, noise_mode="hard", noise_ratio=0.5):
+        super().__init__()
+        self.num_heads, self.num_layers = num_head, decoder_layer_num
+        self.transformer_self_attention_layers = nn.ModuleList()
+        self.transformer_cross_attention_layers = nn.ModuleList()
+        self.transformer_ffn_layers = nn.ModuleList()
+        for _ in range(self.num_layers):
+            self.transformer_self_attention_layers.append(
+                SelfAttentionLayer(d_model=hidden_channel, nhead=num_head, dropout=0.0, normalize_before=False))
+            self.transformer_cross_attention_layers.append(
+                ReferringCrossAttentionLayer(d_model=hidden_channel, nhead=num_head, dropout=0.0,
+                                             normalize_before=False))
+            self.transformer_ffn_layers.append(
+                FFNLayer(d_model=hidden_channel, dim_feedforward=feedforward_channel, dropout=0.0,
+                         normalize_before=False))
+        self.use_memory = False
+        self.decoder_norm = nn.LayerNorm(hidden_channel)
+        self.class_embed = nn.Linear(2 * hidden_channel, class_num + 1)
+        self.mask_embed = MLP(hidden_channel, hidden_channel, mask_dim, 3)
+        self.ref_proj = MLP(hidden_channel, hidden_channel, hidden_channel, 3)
+        for layer in self.ref_proj.layers:
+            c2_xavier_fill(layer)
+        self.mask_feature_proj = nn.Conv2d(mask_dim, mask_dim, kernel_size=1, stride=1, padding=0)
+        self.last_outputs = None         # (1 + layers, q, b, c) in the reference; only [-1] is ever read -> (q, b, c)
+        self.last_frame_embeds = None
+        self.last_reference = None
+        self.noise_mode, self.noise_ratio = noise_mode, noise_ratio   # training-only knobs (kept for the ctor surface)
+        self._kv_cache = None
+
+    def _clear_memory(self):
+        self.last_outputs = None
+        self.last_reference = None
+
+    def _kv_weights(self):
+        C = self.decoder_norm.weight.shape[0]
+        ver = tuple(l.multihead_attn.in_proj_weight._version for l in self.transformer_cross_attention_layers)
+        dev = self.decoder_norm.weight.device
+        if self._kv_cache is None or self._kv_cache[0] != (ver, dev):
+            W = torch.cat([l.multihead_attn.in_proj_weight[C:].detach() for l in self.transformer_cross_attention_layers], 0)
+            b = torch.cat([l.multihead_attn.in_proj_bias[C:].detach() for l in self.transformer_cross_attention_layers], 0)
+            self._kv_cache = ((ver, dev), W.contiguous(), b.contiguous())
+        return self._kv_cache[1], self._kv_cache[2]
+
+    def forward(self, frame_embeds, mask_features, resume=False, return_indices=False, frame_classes=None,
+                frame_embeds_no_norm=None, need_masks=True):
+        """frame_embeds (b, c, t, q); mask_features (b, t, c, h, w) [may be None when need_masks=False].
+        Same outputs as the reference (eval): pred_logits (b,t,q,K+1), pred_masks (b,q,t,h,w) | None,
+        pred_embds (b,c,t,q), pred_references (b,c,t,q), aux_outputs []."""
+        if self.training:
+            raise NotImplementedError("dvis_plus_amd implements the tracker's inference path")
+        fe = frame_embeds.permute(2, 3, 0, 1)                                  # (t, q, b, c)
+        fe_nn = fe if frame_embeds_no_norm is None else frame_embeds_no_norm.permute(2, 3, 0, 1)
+        T, Q, B, C = fe.shape
+        assert B == 1, "inference runs one video at a time (the reference matches on batch entry 0 only)"
+        first_is_start = not resume
+        if first_is_start:
+            self._clear_memory()
+
+        # ---- 1. every frame's assignment: batched cosine costs on the GPU, ONE sync, chain solved on the host
+        cur = fe[:, :, 0, :]
+        ref0 = cur[0] if first_is_start else self.last_frame_embeds[:, 0, :]
+        indices = match_chain(cosine_costs(cur, ref0))                         # (T, Q) int64, host
+        idx_dev = torch.from_numpy(indices).to(fe.device)
+
+        # ---- 2. K / V of all layers for all frames: one GEMM.  (T, Q, 1, layers * 2C)
+        W, b = self._kv_weights()
+        kv = F.linear(fe_nn, W, b)
+
+        # ---- 3. the recurrence
+        outputs, refs = [], []
+        for i in range(T):
+            single_nn = fe_nn[i]                                               # (q, b, c)
+            ident = single_nn[idx_dev[i]]
+            first = i == 0 and first_is_start
+            if not first:
+                reference = self.ref_proj(self.last_outputs)
+                self.last_reference = reference
+            out = ident
+            for j in range(self.num_layers):
+                if first:
+                    ref_j = self.ref_proj(single_nn if j == 0 else out)
+                else:
+                    ref_j = reference
+                kj = kv[i, :, :, (2 * j) * C:(2 * j + 1) * C]
+                vj = kv[i, :, :, (2 * j + 1) * C:(2 * j + 2) * C]
+                out = self.transformer_cross_attention_layers[j].attend(out, ref_j, kj, vj)
+                out = self.transformer_self_attention_layers[j](out)
+                out = self.transformer_ffn_layers[j](out)
+            if first:
+                self.last_reference = self.ref_proj(single_nn)
+            refs.append(self.last_reference)
+            self.last_outputs = out
+            outputs.append(out)
+        self.last_frame_embeds = fe[T - 1][idx_dev[T - 1]]
+        outputs = torch.stack(outputs, 0)                                      # (t, q, b, c), last layer (eval)
+        refs = torch.stack(refs, 0)
+
+        # ---- 4. heads
+        dec = self.decoder_norm(outputs)
+        logits = self.class_embed(torch.cat([refs, dec], dim=-1))             # (t, q, b, K+1)
+        out = {
+            "pred_logits": logits.permute(2, 0, 1, 3),
+            "pred_masks": None,
+            "aux_outputs": [],
+            "pred_embds": outputs.permute(2, 3, 0, 1),
+            "pred_references": refs.permute(2, 3, 0, 1),
+        }
+        if need_masks:
+            b_, t_, cm, h, w = mask_features.shape
+            mf = self.mask_feature_proj(mask_features.flatten(0, 1))           # (t, cm, h, w)
+            emb = self.mask_embed(dec[:, :, 0, :])                             # (t, q, cm)
+            out["pred_masks"] = Fn.mask_logits(emb.contiguous(), mf).permute(1, 0, 2, 3).unsqueeze(0)
+        if return_indices:
+            return out, [indices[i] for i in range(T)]
+        return out

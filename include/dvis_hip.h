@@ -22,6 +22,7 @@
  *                               CrossAttentionLayer / SelfAttentionLayer (mask2former_video/.../video_mask2former_transformer_decoder.py:18-136),
  *                               ReferringCrossAttentionLayer (dvis_Plus/tracker.py:8-92), TemporalRefiner (dvis_Plus/refiner.py:104-139)
  *   dvis_lsap_solve          <- scipy.optimize.linear_sum_assignment as called by Noiser.match_embds, dvis_Plus/noiser.py:43-56
+ *   dvis_match_chain         <- the frame-by-frame matching loop of ReferringTracker_noiser.forward, dvis_Plus/tracker.py:210-291
  */
 #ifndef DVIS_HIP_H
 #define DVIS_HIP_H
@@ -104,18 +105,19 @@ int dvis_attn_mask(const float *embed, const float *feat, int B, int Q, int C, i
                    uint8_t *mask, int32_t *allowed_count, void *stream);
 
 /*
- * softmax(Q K^T * scale [masked]) V for batched heads, fp32 in/out, exact-fp32 MFMA.
- *   q (BH, Lq, d)  k, v (BH, Lk, d)  out (BH, Lq, d), all with explicit strides in floats:
- *   x[b, i, :] at  x + b * x_bstride + i * x_rstride   (d contiguous)
- *   mask: NULL or uint8 (Bm, Lq, Lk), 1 = blocked; head b uses mask batch  b / heads_per_mask.
- *   allowed_count: NULL or int32 (Bm, Lq) from dvis_attn_mask; rows with count 0 ignore the mask.
- *   ws: workspace of dvis_attention_ws_bytes(...) bytes (split-K partials), may be NULL when that is 0.
+ * softmax(Q K^T * scale [masked]) V for B batch entries x `heads` heads, fp32 in/out, exact-fp32 MFMA.
+ *   q (B, heads, Lq, d), k / v (B, heads, Lk, d), out (B, heads, Lq, d) as STRIDED views: x_strides[3] =
+ *   {batch, head, row} strides in floats, d contiguous, d in {32, 64}.  (Lets q/k/v be slices of fused
+ *   projections and out be the (Lq, B, heads*d) buffer the out-projection reads.)
+ *   mask: NULL or uint8 (B, Lq, Lk), 1 = blocked, shared by the heads of a batch entry (4-byte aligned).
+ *   allowed_count: NULL or int32 (B, Lq) from dvis_attn_mask; rows with count 0 ignore the mask.
+ *   ws: workspace of dvis_attention_ws_bytes(B*heads, Lq, Lk, d) bytes (split-K partials); may be NULL when 0.
  */
 int64_t dvis_attention_ws_bytes(int BH, int Lq, int Lk, int d);
-int dvis_attention_forward(const float *q, int64_t q_bs, int64_t q_rs, const float *k, int64_t k_bs, int64_t k_rs,
-                           const float *v, int64_t v_bs, int64_t v_rs, float *out, int64_t o_bs, int64_t o_rs,
-                           const uint8_t *mask, const int32_t *allowed_count, int heads_per_mask,
-                           int BH, int Lq, int Lk, int d, float scale, void *ws, void *stream);
+int dvis_attention_forward(const float *q, const int64_t *q_strides, const float *k, const int64_t *k_strides,
+                           const float *v, const int64_t *v_strides, float *out, const int64_t *o_strides,
+                           const uint8_t *mask, const int32_t *allowed_count, int B, int heads, int Lq, int Lk,
+                           int d, float scale, void *ws, void *stream);
 
 /*
  * HOST function: minimum-cost assignment of an nr x nc (nr <= nc) row-major double cost matrix,
@@ -123,6 +125,14 @@ int dvis_attention_forward(const float *q, int64_t q_bs, int64_t q_rs, const flo
  * col4row[i] = column assigned to row i.  Returns 0, or DVIS_E_ARG for nan/-inf entries or nr > nc.
  */
 int dvis_lsap_solve(const double *cost, int nr, int nc, int64_t *col4row);
+
+/*
+ * HOST function: the tracker's per-clip matching recurrence (ReferringTracker_noiser.forward, dvis_Plus/tracker.py:283-291
+ * + Noiser.match_embds) in one call.  cost (T, Q, Q) fp32 HOST memory, cost[i][c][r] = 1 - cos(cur_i[c], ref_i[r]) with
+ * ref_i = the UN-permuted embeddings of frame i-1 (frame 0: the carried-over / own embeddings); the column
+ * permutation by the previous frame's assignment is applied inside.  indices (T, Q) int64 out.
+ */
+int dvis_match_chain(const float *cost, int T, int Q, int64_t *indices);
 
 #ifdef __cplusplus
 }

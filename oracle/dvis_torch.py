@@ -404,3 +404,66 @@ def inference_video_vss(pred_cls, pred_masks, img_size, out_hw, first_resize_siz
         mask_cls = torch.maximum(mask_cls, F.softmax(aux_pred_cls, dim=-1)[..., :-1])
     cur_masks = _resize2(pred_masks, first_resize_size, img_size, out_hw, sigmoid=True)
     return torch.einsum("qc,qthw->cthw", mask_cls, cur_masks).max(0)[1]
+
+
+# ----------------------------------------------------------------------------- whole offline / online path (a12)
+def _sub(sd, prefix):
+    return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+def preprocess(frames, pixel_mean, pixel_std, size_divisibility=32):
+    """(x - mean) / std, then zero-pad bottom/right to a multiple of 32 (meta_architecture.py:1306-1311;
+    ImageList.from_tensors semantics, un-vendored detectron2 — SURVEY.md App. B)."""
+    x = torch.stack([f.float() for f in frames])
+    x = (x - pixel_mean.view(-1, 1, 1)) / pixel_std.view(-1, 1, 1)
+    H, W = x.shape[-2:]
+    d = size_divisibility
+    Hp, Wp = (H + d - 1) // d * d, (W + d - 1) // d * d
+    return F.pad(x, (0, Wp - W, 0, Hp - H)), (H, W)
+
+
+def dvis_plus_forward(sd, backbone, frames, *, offline=True, nheads=8, enc_layers=6, dec_layers=9, tracker_layers=6,
+                      refiner_layers=6, window_size=3, num_classes=124, n_things=58, task="vps", max_num=20,
+                      object_mask_threshold=0.8, overlap_threshold=0.8, out_hw=None, stages=None):
+    """DVIS_Plus_offline.forward (eval) = run_window_inference (meta_architecture.py:1446-1500) + post_processing
+    (:758-772) + inference_video_{vis,vps,vss}; offline=False: DVIS_Plus_online (:774-816).  `sd` uses the product's /
+    reference's checkpoint names (sem_seg_head.pixel_decoder.*, sem_seg_head.predictor.*, tracker.*, refiner.*);
+    `backbone` is any callable images -> {res2..res5} (un-pinned third-party part, shared with the product).
+    `stages`: optional dict that receives intermediate tensors (for parity tests)."""
+    images, img_size = preprocess(frames, sd["pixel_mean"].flatten(), sd["pixel_std"].flatten())
+    pd, pr = _sub(sd, "sem_seg_head.pixel_decoder."), _sub(sd, "sem_seg_head.predictor.")
+    trk = Tracker(_sub(sd, "tracker."), nheads, tracker_layers)
+    T = len(images)
+    all_mf, all_fe_nn, all_inst, online_logits, online_masks = [], [], [], [], []
+    for s in range(0, T, window_size):                                      # the reference's window loop
+        feats = backbone(images[s:s + window_size])
+        mf, _, ms = pixel_decoder_forward(pd, feats, nheads, enc_layers)
+        out = decoder_forward(pr, ms, mf, nheads, dec_layers)
+        t_out = trk.forward(out["pred_embds"], mf.unsqueeze(0), resume=(s != 0),
+                            frame_embeds_no_norm=out["pred_embds_without_norm"], with_masks=not offline)
+        all_mf.append(mf)
+        all_fe_nn.append(out["pred_embds_without_norm"])
+        all_inst.append(t_out["pred_embds"])
+        online_logits.append(t_out["pred_logits"])
+        if not offline:
+            online_masks.append(t_out["pred_masks"])
+    mask_features = torch.cat(all_mf, 0).unsqueeze(0)
+    online_logits = torch.cat(online_logits, 1)
+    if offline:
+        ref = refiner_forward(_sub(sd, "refiner."), torch.cat(all_inst, 2), torch.cat(all_fe_nn, 2), mask_features,
+                              nheads, refiner_layers)
+        cls, aux = post_processing(ref["pred_logits"], online_logits)
+        masks = ref["pred_masks"][0]
+    else:
+        cls, aux = post_processing(online_logits)
+        masks = torch.cat(online_masks, 2)[0]
+    if stages is not None:
+        stages.update(mask_features=mask_features, cls=cls, aux=aux, masks=masks, online_logits=online_logits)
+    first = tuple(images.shape[-2:])
+    out_hw = img_size if out_hw is None else out_hw
+    if task == "vis":
+        return inference_video_vis(cls, masks, img_size, out_hw, first, num_classes, max_num, aux)
+    if task == "vps":
+        return inference_video_vps(cls, masks, img_size, out_hw, first, num_classes, n_things,
+                                   object_mask_threshold, overlap_threshold, aux)
+    return inference_video_vss(cls, masks, img_size, out_hw, first, aux)

@@ -79,3 +79,69 @@ def make_msda_inputs(N, M, D, shapes, Lq, P, dtype=torch.float32, seed=0, spread
     w = torch.rand(N, Lq, M, L, P, generator=g, dtype=torch.float64)
     w = (w / w.flatten(-2).sum(-1)[..., None, None]).to(dtype)
     return value, s, lsi, loc, w
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU stand-ins for the HIP ops, built from the ORACLE — test infrastructure only.  They let the `-m "not gpu"`
+# tests exercise the product's HOST logic (module wiring, state_dict keys, batching, clip sharding) on CPU
+# tensors.  The product itself has no such path: without this fixture the ops raise on CPU tensors.
+# ---------------------------------------------------------------------------------------------------------------
+def _o_attention(q, k, v, nheads, mask=None, allowed_count=None, out=None):
+    Lq, B, C = q.shape
+    Lk, d = k.shape[0], C // nheads
+    qh = q.reshape(Lq, B, nheads, d).permute(1, 2, 0, 3)
+    kh = k.reshape(Lk, B, nheads, d).permute(1, 2, 0, 3)
+    vh = v.reshape(Lk, B, nheads, d).permute(1, 2, 0, 3)
+    s = (qh * (1.0 / d ** 0.5)) @ kh.transpose(-1, -2)
+    if mask is not None:
+        m = mask.bool().clone()
+        if allowed_count is not None:
+            m[allowed_count == 0] = False
+        s = s.masked_fill(m[:, None], float("-inf"))
+    o = (torch.softmax(s, -1) @ vh).permute(2, 0, 1, 3).reshape(Lq, B, C)
+    if out is not None:
+        out.copy_(o)
+        return out
+    return o
+
+
+def _o_attn_mask(mask_embed, mask_features, target_size):
+    import torch.nn.functional as F
+    logits = torch.einsum("bqc,bchw->bqhw", mask_embed, mask_features)
+    small = F.interpolate(logits, size=tuple(target_size), mode="bilinear", align_corners=False)
+    mask = (small.sigmoid().flatten(2) < 0.5)
+    return mask.to(torch.uint8), (~mask).sum(-1).to(torch.int32)
+
+
+def _o_mask_logits(mask_embed, mask_features):
+    return torch.einsum("bqc,bchw->bqhw", mask_embed, mask_features)
+
+
+def _o_msda_fused(value, spatial_shapes, level_start_index, reference_points, offsets, logits, n_levels, n_points):
+    from oracle.msda import msda_forward_torch
+    N, S, M, D = value.shape
+    Lq = reference_points.shape[1]
+    L, P = n_levels, n_points
+    off = offsets[:, :M * L * P * 2].reshape(N, Lq, M, L, P, 2)
+    w = torch.softmax(logits[:, :M * L * P].reshape(N, Lq, M, L * P), -1).reshape(N, Lq, M, L, P)
+    norm = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
+    loc = reference_points[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    return msda_forward_torch(value, spatial_shapes, loc.expand(N, -1, -1, -1, -1, -1), w)
+
+
+class _OMSDAFunction:
+    @staticmethod
+    def apply(value, shapes, level_start, loc, w, im2col_step):
+        from oracle.msda import msda_forward_torch
+        return msda_forward_torch(value, shapes, loc, w)
+
+
+@pytest.fixture
+def oracle_ops(monkeypatch):
+    from dvis_plus_amd import functions as Fn
+    monkeypatch.setattr(Fn, "attention", _o_attention)
+    monkeypatch.setattr(Fn, "attn_mask", _o_attn_mask)
+    monkeypatch.setattr(Fn, "mask_logits", _o_mask_logits)
+    monkeypatch.setattr(Fn, "msda_fused_forward", _o_msda_fused)
+    monkeypatch.setattr(Fn, "MSDeformAttnFunction", _OMSDAFunction)
+    return Fn

@@ -273,6 +273,13 @@ def g6_postprocess():
     pred_logits[0, :, 5, K] += 9  # void
     aux_logits = torch.randn(1, T, Q, K + 1, generator=g) * 2
     masks = torch.randn(1, Q, T, 10, 14, generator=g) * 3
+    # structured masks for the confident queries so VPS keeps real segments (thing, thing, merged stuff)
+    masks[0, :4] = -6 + torch.randn(4, T, 10, 14, generator=g)
+    masks[0, 0, :, 0:5, 0:7] += 12          # thing, class 1
+    masks[0, 1, :, 0:5, 7:14] += 12         # stuff class 4
+    masks[0, 2, :, 5:10, 0:6] += 12         # stuff class 4 again -> merged into the same segment id
+    masks[0, 3, :, 5:10, 6:14] += 12        # thing, class 0
+    masks[0, 3, 1, 0:3, 0:3] += 12          # overlaps query 0 in frame 1
     outputs = dict(pred_logits=pred_logits.clone(), pred_masks=masks.clone())
     outputs, aux = cls.post_processing(stub, outputs, aux_logits=aux_logits.clone())
     mask_cls, mask_pred, pid = outputs["pred_logits"][0], outputs["pred_masks"][0], outputs["ids"][0]
@@ -306,9 +313,7 @@ if __name__ == "__main__":
     import warnings
     warnings.filterwarnings("ignore")
     torch.set_num_threads(1)  # deterministic reduction order in the generating run
-    g1_msda()
-    g2_pixel_decoder()
-    g3_decoder()
-    g4_tracker_refiner()
-    g5_match()
-    g6_postprocess()
+    only = sys.argv[1:]
+    for fn in (g1_msda, g2_pixel_decoder, g3_decoder, g4_tracker_refiner, g5_match, g6_postprocess):
+        if not only or fn.__name__.split("_")[0] in only:
+            fn()

@@ -58,11 +58,11 @@ def test_attention_strided_views_of_fused_projection():
     q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
     ref = ref_attention(q, k, v, H)
     dq = qkv.to(DEV)
-    with pytest.raises(RuntimeError, match="batch stride"):
-        attention(dq[..., :C], dq[..., C:2 * C], dq[..., 2 * C:], H)
-    qc, kc, vc = (t.contiguous() for t in (dq[..., :C], dq[..., C:2 * C], dq[..., 2 * C:]))
-    out = attention(qc, kc, vc, H).cpu()
-    torch.testing.assert_close(out.double(), ref, rtol=0, atol=2e-5)
+    buf = torch.zeros(L, B, C + 64, device=DEV)                  # output into a strided buffer as well
+    out = attention(dq[..., :C], dq[..., C:2 * C], dq[..., 2 * C:], H, out=buf[..., :C])
+    assert out.data_ptr() == buf.data_ptr()
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=0, atol=2e-5)
+    assert torch.count_nonzero(buf[..., C:]) == 0
 
 
 def test_fully_blocked_rows_follow_the_reference_reset():

@@ -1,0 +1,281 @@
+"""CPU: host logic of the product modules (wiring, state_dict compatibility, batching tricks, post-processing,
+clip sharding) against the reference goldens, with the HIP ops replaced by oracle stand-ins (`oracle_ops`)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import Golden, ROOT
+
+TOL = dict(rtol=1e-4, atol=1e-5)
+
+
+def test_pixel_decoder_loads_reference_state_dict_and_matches(oracle_ops):
+    from dvis_plus_amd.pixel_decoder import MSDeformAttnPixelDecoder
+    from dvis_plus_amd.registry import ShapeSpec
+    g = Golden("g2_pixel_decoder")
+    chans = g.meta["cfg"]["chans"]
+    strides = dict(res2=4, res3=8, res4=16, res5=32)
+    pd = MSDeformAttnPixelDecoder({k: ShapeSpec(channels=chans[k], stride=strides[k]) for k in chans},
+                                  transformer_dropout=0.0, transformer_nheads=2, transformer_dim_feedforward=64,
+                                  transformer_enc_layers=2, conv_dim=32, mask_dim=16, norm="GN",
+                                  transformer_in_features=["res3", "res4", "res5"], common_stride=4).eval()
+    pd.load_state_dict(g.sd, strict=True)                       # checkpoint surface: identical keys
+    feats = {k[5:]: v for k, v in g.ins.items() if k.startswith("feat_")}
+    with torch.no_grad():
+        mf, out0, ms = pd.forward_features(feats)
+        attn = pd.transformer.encoder.layers[0].self_attn
+        shapes = torch.tensor([(2, 3), (4, 6), (8, 12)])
+        lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+        a = attn(g.ins["attn_query"], g.ins["attn_ref"], g.ins["attn_src"], shapes, lsi, None)
+    torch.testing.assert_close(mf, g.outs["mask_features"], **TOL)
+    torch.testing.assert_close(out0, g.outs["out0"], **TOL)
+    for x, k in zip(ms, ("ms0", "ms1", "ms2")):
+        torch.testing.assert_close(x, g.outs[k], **TOL)
+    torch.testing.assert_close(a, g.outs["attn_out"], **TOL)
+
+
+def test_msdeformattn_module_has_no_silent_fallback():
+    """Without the fixture the module must raise on CPU tensors (the reference silently runs grid_sample)."""
+    from dvis_plus_amd.pixel_decoder import MSDeformAttn
+    m = MSDeformAttn(32, 3, 2, 4).eval()
+    shapes = torch.tensor([(2, 3), (4, 6), (8, 12)])
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    with pytest.raises(RuntimeError, match="GPU tensor"), torch.no_grad():
+        m(torch.randn(1, S, 32), torch.rand(1, S, 3, 2), torch.randn(1, S, 32), shapes, lsi)
+
+
+def test_decoders_match_goldens(oracle_ops):
+    from dvis_plus_amd.transformer_decoder import (MultiScaleMaskedTransformerDecoder,
+                                                   VideoMultiScaleMaskedTransformerDecoder_dvisPlus)
+    g = Golden("g3_decoder_dvisplus")
+    dec = VideoMultiScaleMaskedTransformerDecoder_dvisPlus(
+        32, True, num_classes=7, hidden_dim=32, num_queries=6, nheads=2, dim_feedforward=64, dec_layers=3,
+        pre_norm=False, mask_dim=16, enforce_input_project=False, num_frames=2, num_reid_head_layers=3,
+        reid_hidden_dim=32).eval()
+    dec.load_state_dict(g.sd, strict=True)
+    i, o = g.ins, g.outs
+    with torch.no_grad():
+        out = dec([i["x0"], i["x1"], i["x2"]], i["mask_features"])
+    for k in ("pred_logits", "pred_masks", "pred_embds", "pred_embds_without_norm", "pred_reid_embed"):
+        torch.testing.assert_close(out[k], o[k], **TOL)
+    g = Golden("g3_decoder_image")
+    dec = MultiScaleMaskedTransformerDecoder(32, True, num_classes=7, hidden_dim=32, num_queries=6, nheads=2,
+                                             dim_feedforward=64, dec_layers=3, pre_norm=False, mask_dim=16,
+                                             enforce_input_project=False).eval()
+    dec.load_state_dict(g.sd, strict=True)
+    with torch.no_grad():
+        out = dec([g.ins["x0"], g.ins["x1"], g.ins["x2"]], g.ins["mask_features"])
+    torch.testing.assert_close(out["pred_logits"], g.outs["pred_logits"], **TOL)
+    torch.testing.assert_close(out["pred_masks"], g.outs["pred_masks"], **TOL)
+
+
+def test_static_query_version_shim(oracle_ops):
+    """state-dict shim of the reference (video_mask2former_transformer_decoder.py:213-234)."""
+    from dvis_plus_amd.transformer_decoder import MultiScaleMaskedTransformerDecoder
+    g = Golden("g3_decoder_image")
+    sd = {k.replace("query_feat", "static_query"): v for k, v in g.sd.items()}
+    dec = MultiScaleMaskedTransformerDecoder(32, True, num_classes=7, hidden_dim=32, num_queries=6, nheads=2,
+                                             dim_feedforward=64, dec_layers=3, pre_norm=False, mask_dim=16,
+                                             enforce_input_project=False)
+    missing, unexpected = dec.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected
+
+
+def test_tracker_with_resume_matches_golden_indices_bit_exact(oracle_ops):
+    from dvis_plus_amd.tracker import ReferringTracker_noiser
+    g = Golden("g4_tracker")
+    cfg, i, o = g.meta["cfg"], g.ins, g.outs
+    trk = ReferringTracker_noiser(hidden_channel=cfg["C"], feedforward_channel=cfg["ffn"], num_head=cfg["heads"],
+                                  decoder_layer_num=cfg["layers"], noise_mode="wa", mask_dim=cfg["mask_dim"],
+                                  class_num=cfg["K"]).eval()
+    trk.load_state_dict(g.sd, strict=True)
+    T1 = cfg["T1"]
+    fe, fn, mf = i["frame_embeds"], i["frame_embeds_no_norm"], i["mask_features"]
+    with torch.no_grad():
+        a, ia = trk(fe[:, :, :T1], mf[:, :T1], resume=False, return_indices=True, frame_embeds_no_norm=fn[:, :, :T1])
+        b, ib = trk(fe[:, :, T1:], mf[:, T1:], resume=True, return_indices=True, frame_embeds_no_norm=fn[:, :, T1:])
+    for tag, r, idx in (("a", a, ia), ("b", b, ib)):
+        assert np.array_equal(np.stack(idx), o[f"{tag}_indices"].numpy())
+        for k in ("pred_logits", "pred_masks", "pred_embds", "pred_references"):
+            torch.testing.assert_close(r[k], o[f"{tag}_{k}"], **TOL)
+
+
+def test_refiner_matches_golden(oracle_ops):
+    from dvis_plus_amd.refiner import TemporalRefiner
+    g = Golden("g4_refiner")
+    cfg, i, o = g.meta["cfg"], g.ins, g.outs
+    ref = TemporalRefiner(hidden_channel=cfg["C"], feedforward_channel=cfg["ffn"], num_head=cfg["heads"],
+                          decoder_layer_num=cfg["layers"], mask_dim=cfg["mask_dim"], class_num=cfg["K"],
+                          windows=2).eval()
+    ref.load_state_dict(g.sd, strict=True)
+    with torch.no_grad():
+        r = ref(i["instance_embeds"], i["frame_embeds"], i["mask_features"])
+        sub = ref(i["instance_embeds"], i["frame_embeds"], i["mask_features"], query_index=torch.tensor([4, 1]))
+    for k in ("pred_logits", "pred_masks", "pred_embds"):
+        torch.testing.assert_close(r[k], o[k], **TOL)
+    torch.testing.assert_close(sub["pred_masks"], o["pred_masks"][:, [4, 1]], **TOL)
+
+
+def test_match_chain_equals_framewise_reference_matching():
+    """The one-call clip recurrence == Noiser.match_embds applied frame by frame on re-ordered embeddings."""
+    from dvis_plus_amd.tracker import cosine_costs, match_chain
+    from oracle.dvis_torch import match_embds
+    g = torch.Generator().manual_seed(0)
+    T, Q, C = 7, 20, 32
+    base = torch.randn(Q, C, generator=g)
+    cur = torch.stack([base[torch.randperm(Q, generator=g)] + 0.4 * torch.randn(Q, C, generator=g) for _ in range(T)])
+    idx = match_chain(cosine_costs(cur, cur[0]))
+    last = None
+    for i in range(T):
+        ref = cur[i] if last is None else last
+        want = match_embds(ref[:, None], cur[i][:, None])
+        assert np.array_equal(idx[i], want), i
+        last = cur[i][want]
+
+
+def test_lsap_matches_golden_and_scipy():
+    import ctypes
+    from scipy.optimize import linear_sum_assignment
+    from dvis_plus_amd import native
+    g = Golden("g5_match")
+
+    def solve(C):
+        C = np.ascontiguousarray(C, dtype=np.float64)
+        out = np.empty(C.shape[0], dtype=np.int64)
+        rc = native.lib().dvis_lsap_solve(C.ctypes.data_as(ctypes.c_void_p), C.shape[0], C.shape[1],
+                                          out.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0
+        return out
+    for n in range(g.meta["ncases"]):
+        ref, cur = g.ins[f"ref{n}"][:, 0], g.ins[f"cur{n}"][:, 0]
+        ref = ref / (ref.norm(dim=1)[:, None] + 1e-6)
+        cur = cur / (cur.norm(dim=1)[:, None] + 1e-6)
+        C = 1 - torch.mm(cur, ref.t())
+        C = torch.where(torch.isnan(C), torch.zeros_like(C), C)
+        assert np.array_equal(solve(C.t().numpy()), g.outs[f"idx{n}"].numpy()), n
+    rng = np.random.default_rng(0)
+    for t in range(200):                       # half of these are heavily tied integer matrices
+        nr = int(rng.integers(1, 30))
+        nc = nr + int(rng.integers(0, 5))
+        C = rng.integers(0, 4, size=(nr, nc)).astype(np.float64) if t % 2 else rng.random((nr, nc))
+        assert np.array_equal(solve(C), linear_sum_assignment(C)[1])
+    bad = np.array([[0.0, np.nan], [1.0, 2.0]])
+    out = np.empty(2, dtype=np.int64)
+    assert native.lib().dvis_lsap_solve(bad.ctypes.data_as(ctypes.c_void_p), 2, 2, out.ctypes.data_as(ctypes.c_void_p)) < 0
+
+
+def test_postprocess_matches_golden_bit_exact():
+    from dvis_plus_amd import postprocess as P
+    g = Golden("g6_postprocess")
+    i, o, cfg = g.ins, g.outs, g.meta["cfg"]
+    logits, aux = P.mean_logits(i["pred_logits"], i["aux_logits"])
+    masks = i["pred_masks"][0]
+    fn = lambda idx: masks if idx is None else masks[idx]
+    img, out_hw, first = cfg["img_size"], cfg["out_hw"], cfg["first_resize"]
+    v = P.inference_video_vis(logits, fn, img, out_hw, first, cfg["K"], cfg["max_num"], aux)
+    assert torch.equal(v["pred_scores"], o["vis_scores"]) and torch.equal(v["pred_labels"], o["vis_labels"])
+    assert torch.equal(v["pred_ids"], o["vis_ids"]) and torch.equal(v["pred_masks"], o["vis_masks"])
+    p = P.inference_video_vps(logits.clone(), fn, img, out_hw, first, cfg["K"], cfg["n_things"],
+                              cfg["object_mask_threshold"], cfg["overlap_threshold"], aux, num_frames=cfg["T"])
+    assert torch.equal(p["pred_masks"], o["vps_masks"])
+    assert [s["id"] for s in p["segments_infos"]] == o["vps_seg_id"].tolist()
+    assert [s["category_id"] for s in p["segments_infos"]] == o["vps_seg_cat"].tolist()
+    assert p["pred_ids"] == o["vps_ids"].tolist()
+    s = P.inference_video_vss(logits, fn, img, out_hw, first, aux, frame_chunk=2)
+    assert torch.equal(s["pred_masks"], o["vss_masks"])
+    assert torch.equal(P.get_instance_labels(i["pred_logits"]), o["instance_labels"])
+
+
+TINY = dict(num_classes=10, num_queries=8, n_things=5, hidden_dim=64, nheads=2, dim_feedforward=64, dec_layers=4,
+            enc_layers=1, tracker_layers=2, refiner_layers=1, object_mask_threshold=0.05)
+
+
+def _tiny_model(mode="offline", task="vps"):
+    from dvis_plus_amd.meta_architecture import build_dvis_plus_r50
+    m = build_dvis_plus_r50(mode, task=task, **TINY)
+    with torch.no_grad():
+        for l in m.sem_seg_head.pixel_decoder.transformer.encoder.layers:
+            l.self_attn.sampling_offsets.weight.normal_(0, 0.05)
+            l.self_attn.attention_weights.weight.normal_(0, 0.3)
+    return m
+
+
+def _tiny_clip(T=5, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randint(0, 256, (3, 70, 100), dtype=torch.uint8, generator=g) for _ in range(T)]
+
+
+@pytest.mark.parametrize("mode,task", [("offline", "vps"), ("offline", "vis"), ("offline", "vss"), ("online", "vps")])
+def test_whole_pipeline_equals_oracle_pipeline(oracle_ops, mode, task):
+    """Whole-clip batched product pipeline == the reference's windowed, frame-by-frame pipeline (oracle)."""
+    from oracle import dvis_torch as O
+    m = _tiny_model(mode, task)
+    frames = _tiny_clip()
+    out = m([{"image": frames, "height": 70, "width": 100}])
+    sd = dict(m.state_dict())
+    sd["pixel_mean"], sd["pixel_std"] = m.pixel_mean, m.pixel_std
+    with torch.no_grad():
+        ref = O.dvis_plus_forward(sd, m.backbone, frames, offline=(mode == "offline"), nheads=2, enc_layers=1,
+                                  dec_layers=3, tracker_layers=2, refiner_layers=1, num_classes=10, n_things=5,
+                                  task=task, object_mask_threshold=0.05, max_num=20)
+    if task == "vps":
+        pan, segs, ids = ref
+        assert torch.equal(out["pred_masks"], pan) and out["segments_infos"] == segs and out["pred_ids"] == ids
+        assert len(segs) > 0
+    elif task == "vis":
+        scores, labels, qidx, masks = ref
+        torch.testing.assert_close(out["pred_scores"], scores, rtol=1e-5, atol=1e-6)
+        assert torch.equal(out["pred_labels"], labels) and torch.equal(out["pred_masks"], masks)
+    else:
+        assert torch.equal(out["pred_masks"], ref)
+
+
+def test_keep_flag_resumes_tracker_across_calls(oracle_ops):
+    """demo_long_video semantics (meta_architecture.py:629-632,793): two half clips with keep == one clip (online)."""
+    m = _tiny_model("online", "vis")
+    frames = _tiny_clip(6)
+    whole = m([{"image": frames, "height": 70, "width": 100}])
+    m([{"image": frames[:3], "height": 70, "width": 100}])
+    second = m([{"image": frames[3:], "height": 70, "width": 100, "keep": True}])
+    # tracker state carried over: the second half's instance order follows the first half's
+    last_whole = m.tracker.last_frame_embeds.clone()
+    m([{"image": frames, "height": 70, "width": 100}])
+    torch.testing.assert_close(m.tracker.last_frame_embeds, last_whole, rtol=1e-5, atol=1e-6)
+    assert second["pred_masks"].shape[1] == 3 and whole["pred_masks"].shape[1] == 6
+
+
+def _shard_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import conftest as c
+    from dvis_plus_amd import functions as Fn
+    Fn.attention, Fn.attn_mask, Fn.mask_logits = c._o_attention, c._o_attn_mask, c._o_mask_logits
+    Fn.msda_fused_forward, Fn.MSDeformAttnFunction = c._o_msda_fused, c._OMSDAFunction
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _tiny_model("offline", "vps")
+    out = m([{"image": _tiny_clip(5), "height": 70, "width": 100}])
+    torch.save({"masks": out["pred_masks"], "segs": out["segments_infos"], "ids": out["pred_ids"],
+                "range": out["frame_range"]}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_clip_sharding_world_size_2_gloo(oracle_ops, tmp_path):
+    """Frames sharded over 2 ranks + ONE all-gather of the per-frame queries == the single-process result
+    (uneven split: 5 frames -> 3 + 2)."""
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_shard_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    single = _tiny_model("offline", "vps")([{"image": _tiny_clip(5), "height": 70, "width": 100}])
+    parts = [torch.load(tmp_path / f"r{r}.pt") for r in range(2)]
+    assert [p["range"] for p in parts] == [(0, 3), (3, 5)]
+    assert torch.equal(torch.cat([p["masks"] for p in parts], 0), single["pred_masks"])
+    for p in parts:
+        assert p["segs"] == single["segments_infos"] and p["ids"] == single["pred_ids"]
+    assert len(single["segments_infos"]) > 0
