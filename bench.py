@@ -1,0 +1,196 @@
+"""bench.py — frames/s of DVIS++ R50 offline inference on synthetic 720p clips (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames T]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the whole hot path over one synthetic clip of T=30 uint8 720x1280 frames that is already
+resident in HBM: normalise/pad -> R50 backbone -> MSDeformAttn pixel decoder -> masked-attention decoder ->
+(all-gather of per-frame queries when N > 1) -> referring tracker (incl. host assignment) -> temporal refiner ->
+mask contraction -> panoptic post-processing to integer masks on the device.  With N GPUs the SAME clip is sharded by
+frame (strong scaling); value = T * K / max-over-ranks(wall time).  Weights: deterministic random init with the
+reference's init rules (no checkpoints offline).  fp32 throughout (the parity target is the fp32 path).
+
+Also reported on the one JSON line:
+  roofline      the dominant hand-written kernel of the path, MSDeformAttn forward: algorithmic bytes (61 824 000 B
+                per frame-layer) / its mean launch time (HIP events on the launch stream) vs 8 TB/s.
+  cpu_baseline  the oracle's C port of that kernel (OpenMP, all host cores) on a bounded sample, frames-layers/s
+                converted to the same unit, plus the oracle's torch pipeline on a small clip (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MSDA_BYTES_PER_FRAME_LAYER = 4 * (19320 * 8 * 32 + 19320 * 8 * 3 * 4 * 2 + 19320 * 8 * 3 * 4 + 19320 * 8 * 32)  # 61 824 000
+HBM_PEAK_GBS = 8000.0
+
+
+def synthetic_clip(T, device, seed=1234):
+    """T uint8 (3, 720, 1280) frames: uniform noise blended with a low-frequency pattern (non-degenerate masks)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    noise = torch.randint(0, 256, (T, 3, 720, 1280), generator=g, dtype=torch.uint8)
+    yy, xx = torch.meshgrid(torch.linspace(0, 6.28, 720), torch.linspace(0, 6.28, 1280), indexing="ij")
+    frames = []
+    for t in range(T):
+        pat = (127 + 100 * torch.sin(xx * (1 + t % 3) + 0.2 * t) * torch.cos(yy * 2 + 0.1 * t)).clamp(0, 255)
+        frames.append(((noise[t].float() * 0.3 + pat[None] * 0.7)).to(torch.uint8))
+    return torch.stack(frames).to(device)
+
+
+class MsdaTimer:
+    """Times every MSDeformAttn launch of the timed region with HIP events recorded on the launch stream
+    (torch's current stream IS the stream the C ABI launches on).  Wraps the product op, does not replace it."""
+
+    def __init__(self):
+        from dvis_plus_amd import functions as Fn
+        self.Fn, self.orig, self.events, self.frames = Fn, Fn.msda_fused_forward, [], 0
+
+    def __enter__(self):
+        def timed(value, *a, **k):
+            st = torch.cuda.current_stream(value.device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            out = self.orig(value, *a, **k)
+            e1.record(st)
+            self.events.append((e0, e1, value.shape[0]))
+            return out
+        self.Fn.msda_fused_forward = timed
+        return self
+
+    def __exit__(self, *exc):
+        self.Fn.msda_fused_forward = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        secs = [e0.elapsed_time(e1) / 1e3 for e0, e1, _ in self.events]
+        frames = [n for _, _, n in self.events]
+        return sum(secs) / max(1, len(secs)), sum(frames) / max(1, len(frames)), len(secs)
+
+
+def cpu_baseline(budget_s=20.0):
+    """Oracle (C port, OpenMP) of the MSDA forward on a bounded sample: one 720p frame-layer per call."""
+    from oracle import msda as omsda
+    import numpy as np
+    torch.manual_seed(0)
+    shapes = torch.tensor([(23, 40), (46, 80), (92, 160)], dtype=torch.long)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = 19320
+    value = torch.randn(1, S, 8, 32)
+    loc = torch.rand(1, S, 8, 3, 4, 2)
+    w = torch.softmax(torch.randn(1, S, 8, 12), -1).view(1, S, 8, 3, 4)
+    omsda.msda_forward(value, shapes, lsi, loc, w)
+    n, t0 = 0, time.time()
+    while time.time() - t0 < budget_s and n < 200:
+        omsda.msda_forward(value, shapes, lsi, loc, w)
+        n += 1
+    dt = (time.time() - t0) / n
+    return {"value": round(1.0 / dt, 3), "unit": "frame-layers/s (MSDeformAttn fwd, 720p)", "cores": os.cpu_count(),
+            "kind": "port", "sample": f"{n} calls of one 736x1280 frame-layer (S=Lq=19320, M=8, D=32, L=3, P=4), "
+                                      f"C/OpenMP oracle, {dt * 1e3:.1f} ms each; x6 layers/frame => "
+                                      f"{1.0 / dt / 6:.2f} frames/s for this op alone"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=30)
+    ap.add_argument("--task", default="vps")
+    ap.add_argument("--candidates", type=int, default=20, help="queries sent to the panoptic stage (see main)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=device)     # RCCL over xGMI
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from dvis_plus_amd.meta_architecture import build_dvis_plus_r50
+    # Random-init class logits are near-uniform (max prob ~ 1/125), so the reference's 0.8 score threshold would
+    # keep no query and post-processing would be skipped; the threshold is calibrated below so that --candidates
+    # (20) queries reach the panoptic stage (representative work).  Everything else follows
+    # VIPSeg/DVIS_Plus_Offline_R50.yaml.
+    model = build_dvis_plus_r50("offline", task=args.task, object_mask_threshold=0.0).to(device)
+    T = args.frames
+    clip = synthetic_clip(T, device)
+    inputs = [{"image": clip, "height": 720, "width": 1280}]
+
+    def step():
+        return model(inputs)
+
+    # calibration (untimed): pick the score threshold that sends args.candidates queries to the panoptic stage
+    if args.task == "vps":
+        from dvis_plus_amd import postprocess as PP
+        PP_scores = {}
+        orig_sel = PP.vps_select
+
+        def spy(pred_cls, num_classes, thr, aux=None):
+            scores, labels, keep = orig_sel(pred_cls, num_classes, thr, aux)
+            PP_scores["s"] = scores[labels.ne(num_classes)].sort(descending=True)[0]
+            return scores, labels, keep
+        PP.vps_select = spy
+        model.object_mask_threshold = 2.0          # keep nothing: cheap calibration pass
+        step()
+        PP.vps_select = orig_sel
+        s = PP_scores["s"]
+        k = min(args.candidates, s.numel() - 1)
+        model.object_mask_threshold = float((s[k - 1] + s[k]) / 2) if k > 0 else 2.0
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    timer = MsdaTimer()
+    t0 = time.perf_counter()
+    with timer:
+        for _ in range(args.steps):
+            out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = tt.item()
+
+    if rank == 0:
+        fps = T * args.steps / dt
+        sec, nfr, nlaunch = timer.summary()
+        achieved = MSDA_BYTES_PER_FRAME_LAYER * nfr / sec / 1e9
+        res = {
+            "metric": "frames/sec DVIS++ R50 offline, 720p T=30 synthetic", "value": round(fps, 3), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"DVIS++ offline R50, T={T} 720p synthetic clip (padded 736x1280), 100 queries, "
+                                   f"temporal refiner on, task={args.task}, frames sharded {world}-way",
+                       "panoptic_candidates": out.get("num_candidates"), "segments": len(out.get("segments_infos", []))},
+            "roofline": {"bound": "hbm", "kernel": "msda_fwd_tile_f32 (fused MSDeformAttn forward)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "us_per_launch": round(sec * 1e6, 1), "frames_per_launch": nfr, "launches_timed": nlaunch,
+                         "alg_bytes_per_frame_layer": MSDA_BYTES_PER_FRAME_LAYER},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

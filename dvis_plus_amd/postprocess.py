@@ -68,7 +68,7 @@ def inference_video_vps(pred_cls, mask_fn, img_size, out_hw, first_resize_size, 
     if ids.numel() == 0:
         T = num_frames if num_frames is not None else 0
         return {"image_size": tuple(out_hw), "pred_masks": torch.zeros((T, *out_hw), dtype=torch.int32, device=dev),
-                "segments_infos": [], "pred_ids": [], "task": "vps"}
+                "segments_infos": [], "pred_ids": [], "task": "vps", "num_candidates": 0}
     cur_scores, cur_classes = scores[ids], labels[ids]
     cur_masks = _resize2(mask_fn(ids), first_resize_size, img_size, out_hw, sigmoid=True)     # (K', T, H, W)
     cur_mask_ids = (cur_scores.view(-1, 1, 1, 1) * cur_masks).argmax(0)                       # (T, H, W)
@@ -102,7 +102,7 @@ def inference_video_vps(pred_cls, mask_fn, img_size, out_hw, first_resize_size, 
             out_ids.append(int(stats[4, k]))
     panoptic = torch.where(conf, lut.to(dev)[cur_mask_ids], torch.zeros((), dtype=torch.int32, device=dev))
     return {"image_size": tuple(out_hw), "pred_masks": panoptic, "segments_infos": segments, "pred_ids": out_ids,
-            "task": "vps"}
+            "task": "vps", "num_candidates": K}
 
 
 def inference_video_vss(pred_cls, mask_fn, img_size, out_hw, first_resize_size, aux_pred_cls=None, frame_chunk=8):

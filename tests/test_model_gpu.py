@@ -1,0 +1,134 @@
+"""GPU parity of the product modules (HIP kernels + library GEMMs) against the fp32 CPU oracle, at the real layer
+widths (hidden 256, 8 heads -> head dim 32; tracker/refiner 512 -> head dim 64) on small inputs.
+Tolerance: 1e-3 abs on logits / embeddings (BASELINE.json), integer outputs exact up to near-tie pixels."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cpu_sd(m):
+    return {k: v.detach().cpu() for k, v in m.state_dict().items()}
+
+
+def _perturb_msda(pd):
+    with torch.no_grad():
+        for l in pd.transformer.encoder.layers:
+            l.self_attn.sampling_offsets.weight.normal_(0, 0.02)
+            l.self_attn.attention_weights.weight.normal_(0, 0.1)
+
+
+def test_pixel_decoder_gpu_vs_oracle():
+    from dvis_plus_amd.pixel_decoder import MSDeformAttnPixelDecoder, r50_input_shape
+    from oracle import dvis_torch as O
+    torch.manual_seed(0)
+    pd = MSDeformAttnPixelDecoder(r50_input_shape(), transformer_dropout=0.0, transformer_nheads=8,
+                                  transformer_dim_feedforward=1024, transformer_enc_layers=3, conv_dim=256,
+                                  mask_dim=256, norm="GN", transformer_in_features=["res3", "res4", "res5"],
+                                  common_stride=4).eval()
+    _perturb_msda(pd)
+    H, W = 160, 224
+    feats = {k: torch.randn(2, c, H // s, W // s) for k, c, s in
+             (("res2", 256, 4), ("res3", 512, 8), ("res4", 1024, 16), ("res5", 2048, 32))}
+    with torch.no_grad():
+        ref_mf, ref_o0, ref_ms = O.pixel_decoder_forward(_cpu_sd(pd), feats, 8, 3)
+        pd = pd.to(DEV)
+        mf, o0, ms = pd.forward_features({k: v.to(DEV) for k, v in feats.items()})
+    torch.testing.assert_close(mf.cpu(), ref_mf, rtol=1e-3, atol=1e-3)
+    for a, b in zip(ms, ref_ms):
+        torch.testing.assert_close(a.cpu(), b, rtol=1e-3, atol=1e-3)
+
+
+def test_decoder_gpu_vs_oracle():
+    from dvis_plus_amd.transformer_decoder import VideoMultiScaleMaskedTransformerDecoder_dvisPlus
+    from oracle import dvis_torch as O
+    torch.manual_seed(1)
+    dec = VideoMultiScaleMaskedTransformerDecoder_dvisPlus(
+        256, True, num_classes=124, hidden_dim=256, num_queries=100, nheads=8, dim_feedforward=2048, dec_layers=9,
+        pre_norm=False, mask_dim=256, enforce_input_project=False, num_frames=1, num_reid_head_layers=3,
+        reid_hidden_dim=256).eval()
+    x = [torch.randn(3, 256, 5, 7), torch.randn(3, 256, 10, 14), torch.randn(3, 256, 20, 28)]
+    mf = torch.randn(3, 256, 40, 56)
+    with torch.no_grad():
+        ref = O.decoder_forward(_cpu_sd(dec), x, mf, 8, 9)
+        dec = dec.to(DEV)
+        out = dec([t.to(DEV) for t in x], mf.to(DEV))
+    for k in ("pred_logits", "pred_masks", "pred_embds", "pred_embds_without_norm", "pred_reid_embed"):
+        torch.testing.assert_close(out[k].cpu(), ref[k], rtol=1e-3, atol=1e-3)
+
+
+def test_tracker_and_refiner_gpu_vs_oracle():
+    from dvis_plus_amd.refiner import TemporalRefiner
+    from dvis_plus_amd.tracker import ReferringTracker_noiser
+    from oracle import dvis_torch as O
+    torch.manual_seed(2)
+    T, Q, C, K = 6, 100, 512, 124
+    trk = ReferringTracker_noiser(hidden_channel=C, feedforward_channel=2048, num_head=8, decoder_layer_num=6,
+                                  noise_mode="wa", mask_dim=256, class_num=K).eval()
+    rfn = TemporalRefiner(hidden_channel=C, feedforward_channel=2048, num_head=8, decoder_layer_num=6, mask_dim=256,
+                          class_num=K, windows=3).eval()
+    base = torch.randn(C, Q)
+    fe = torch.stack([base[:, torch.randperm(Q)] + 0.3 * torch.randn(C, Q) for _ in range(T)], 1)[None]  # (1,C,T,Q)
+    fe_nn = fe * 1.5 + 0.1 * torch.randn_like(fe)
+    mf = torch.randn(1, T, 256, 12, 20)
+    with torch.no_grad():
+        ot = O.Tracker(_cpu_sd(trk), 8, 6)
+        ra = ot.forward(fe[:, :, :4], mf[:, :4], resume=False, frame_embeds_no_norm=fe_nn[:, :, :4])
+        rb = ot.forward(fe[:, :, 4:], mf[:, 4:], resume=True, frame_embeds_no_norm=fe_nn[:, :, 4:])
+        inst = torch.cat([ra["pred_embds"], rb["pred_embds"]], 2)
+        rr = O.refiner_forward(_cpu_sd(rfn), inst, fe_nn, mf, 8, 6)
+        trk, rfn = trk.to(DEV), rfn.to(DEV)
+        a, ia = trk(fe[:, :, :4].to(DEV), mf[:, :4].to(DEV), resume=False, return_indices=True,
+                    frame_embeds_no_norm=fe_nn[:, :, :4].to(DEV))
+        b, ib = trk(fe[:, :, 4:].to(DEV), mf[:, 4:].to(DEV), resume=True, return_indices=True,
+                    frame_embeds_no_norm=fe_nn[:, :, 4:].to(DEV))
+        r = rfn(inst.to(DEV), fe_nn.to(DEV), mf.to(DEV))
+    assert np.array_equal(np.stack(ia), ra["indices"]) and np.array_equal(np.stack(ib), rb["indices"])   # bit-exact
+    for got, want in ((a, ra), (b, rb)):
+        for k in ("pred_logits", "pred_masks", "pred_embds", "pred_references"):
+            torch.testing.assert_close(got[k].cpu(), want[k], rtol=1e-3, atol=1e-3)
+    for k in ("pred_logits", "pred_masks", "pred_embds"):
+        torch.testing.assert_close(r[k].cpu(), rr[k], rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("task", ["vps", "vis"])
+def test_offline_pipeline_gpu_vs_oracle(task):
+    from dvis_plus_amd.meta_architecture import build_dvis_plus_r50
+    from oracle import dvis_torch as O
+    m = build_dvis_plus_r50("offline", task=task, num_classes=20, num_queries=100, n_things=10, enc_layers=2,
+                            dec_layers=4, tracker_layers=2, refiner_layers=2, object_mask_threshold=0.06)
+    _perturb_msda(m.sem_seg_head.pixel_decoder)
+    g = torch.Generator().manual_seed(3)
+    frames = [torch.randint(0, 256, (3, 120, 200), dtype=torch.uint8, generator=g) for _ in range(4)]
+    sd = _cpu_sd(m)
+    sd["pixel_mean"], sd["pixel_std"] = m.pixel_mean.clone(), m.pixel_std.clone()
+    m = m.to(DEV)
+    out = m([{"image": [f.to(DEV) for f in frames], "height": 120, "width": 200}])
+
+    # Parity is asserted from the backbone OUTPUTS onward (the R50 is un-vendored third-party code, "parity
+    # unpinned"; a 50-layer random-init conv net also amplifies MIOpen-vs-CPU rounding): the oracle's windows get
+    # the features the GPU backbone produced for the same frames.
+    def backbone_from_gpu(images_cpu):
+        with torch.no_grad():
+            return {k: v.cpu() for k, v in m.backbone(images_cpu.to(DEV)).items()}
+    stages = {}
+    with torch.no_grad():
+        ref = O.dvis_plus_forward(sd, backbone_from_gpu, frames, offline=True, nheads=8, enc_layers=2, dec_layers=3,
+                                  tracker_layers=2, refiner_layers=2, num_classes=20, n_things=10, task=task,
+                                  object_mask_threshold=0.06, stages=stages)
+    if task == "vps":
+        pan, segs, ids = ref
+        assert out["segments_infos"] == segs and out["pred_ids"] == ids and len(segs) > 0
+        agree = (out["pred_masks"].cpu() == pan).float().mean().item()
+        assert agree > 0.999, agree
+    else:
+        scores, labels, qidx, masks = ref
+        # topk(sorted=False) returns the same SET in a device-dependent order: align on (query, label)
+        key_ref = qidx * 1000 + labels
+        key_out = out["pred_ids"].cpu() * 1000 + out["pred_labels"].cpu()
+        o_ref, o_out = key_ref.argsort(), key_out.argsort()
+        assert torch.equal(key_ref[o_ref], key_out[o_out])                       # same (query, class) pairs
+        torch.testing.assert_close(out["pred_scores"].cpu()[o_out], scores[o_ref], rtol=1e-3, atol=1e-4)
+        assert (out["pred_masks"].cpu()[o_out] == masks[o_ref]).float().mean().item() > 0.999
