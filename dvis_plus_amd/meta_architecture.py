@@ -55,13 +55,21 @@ class _VideoBase(nn.Module):
         self.window_size = window_size        # reference knob (TEST.WINDOW_SIZE); results do not depend on it
         self.segmenter_chunk = segmenter_chunk  # frames per segmenter call, 0 = whole (local) clip at once
         self.keep = False
-        self.clip_shard = ClipShard() if not torch.distributed.is_initialized() else ClipShard()
+        self._clip_shard = None
         if hasattr(self.sem_seg_head.predictor, "compute_pred_masks"):
             self.sem_seg_head.predictor.compute_pred_masks = False
 
     @property
     def device(self):
         return self.pixel_mean.device
+
+    @property
+    def clip_shard(self):
+        """Frame sharding follows the default process group of the moment (none -> single GPU)."""
+        world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        if self._clip_shard is None or self._clip_shard.world != world:
+            self._clip_shard = ClipShard()
+        return self._clip_shard
 
     # ---- meta_architecture.py:1306-1311: normalise, then pad bottom/right to a multiple of size_divisibility
     def preprocess(self, frames):

@@ -15,6 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import functions as Fn
+from .graphs import GraphRunner
 from .transformer_decoder import MLP, CrossAttentionLayer, FFNLayer, SelfAttentionLayer
 
 
@@ -52,6 +53,8 @@ class TemporalRefiner(nn.Module):
         self.mask_embed = MLP(hidden_channel, hidden_channel, mask_dim, 3)
         self.activation_proj = nn.Linear(hidden_channel, 1)
         self._kv_cache = None
+        self.use_graphs = True
+        self._graph = GraphRunner(self.refine)
 
     def _kv_weights(self):
         C = self.decoder_norm.weight.shape[0]
@@ -98,7 +101,9 @@ class TemporalRefiner(nn.Module):
         pred_embds (b,c,t,q), mask_embed (b,t,q,Cm)."""
         if self.training:
             raise NotImplementedError("dvis_plus_amd implements the refiner's inference path")
-        last = self.refine(instance_embeds, frame_embeds)                          # (t, q, b, c)
+        self._kv_weights()
+        self._graph.enabled = self.use_graphs
+        last = self._graph("refine", instance_embeds.contiguous(), frame_embeds.contiguous()).clone()   # (t, q, b, c)
         dec = self.decoder_norm(last)
         dec_b = dec.permute(2, 0, 1, 3)                                            # (b, t, q, c)
         emb = self.mask_embed(dec_b)                                               # (b, t, q, Cm)

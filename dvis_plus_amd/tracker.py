@@ -24,6 +24,7 @@ from torch import nn
 
 from . import functions as Fn
 from . import native
+from .graphs import GraphRunner
 from .pixel_decoder import c2_xavier_fill
 from .transformer_decoder import MLP, FFNLayer, SelfAttentionLayer, _xavier_
 
@@ -104,6 +105,8 @@ class ReferringTracker_noiser(nn.Module):
         self.last_reference = None
         self.noise_mode, self.noise_ratio = noise_mode, noise_ratio   # training-only knobs (kept for the ctor surface)
         self._kv_cache = None
+        self.use_graphs = True
+        self._graph = GraphRunner(self._recurrence_entry)
 
     def _clear_memory(self):
         self.last_outputs = None
@@ -118,6 +121,35 @@ class ReferringTracker_noiser(nn.Module):
             b = torch.cat([l.multihead_attn.in_proj_bias[C:].detach() for l in self.transformer_cross_attention_layers], 0)
             self._kv_cache = ((ver, dev), W.contiguous(), b.contiguous())
         return self._kv_cache[1], self._kv_cache[2]
+
+    def _recurrence_entry(self, fe_nn, idx_dev, last_outputs):
+        return self._recurrence(fe_nn, idx_dev, last_outputs, self._rec_first)
+
+    def _recurrence(self, fe_nn, idx_dev, last_outputs, first_is_start):
+        """The genuinely sequential part.  fe_nn (T,Q,1,C) un-normed frame queries, idx_dev (T,Q) assignments,
+        last_outputs (Q,1,C) carried state (ignored when the clip starts a video).
+        Returns (outputs (T,Q,1,C), references (T,Q,1,C), new last_outputs)."""
+        T, Q, B, C = fe_nn.shape
+        W, b = self._kv_weights()
+        kv = F.linear(fe_nn, W, b)                                             # (T, Q, 1, layers * 2C): one GEMM
+        outputs, refs = [], []
+        for i in range(T):
+            single_nn = fe_nn[i]                                               # (q, b, c)
+            out = single_nn[idx_dev[i]]
+            first = i == 0 and first_is_start
+            if not first:
+                reference = self.ref_proj(last_outputs)
+            for j in range(self.num_layers):
+                ref_j = self.ref_proj(single_nn if j == 0 else out) if first else reference
+                kj = kv[i, :, :, (2 * j) * C:(2 * j + 1) * C]
+                vj = kv[i, :, :, (2 * j + 1) * C:(2 * j + 2) * C]
+                out = self.transformer_cross_attention_layers[j].attend(out, ref_j, kj, vj)
+                out = self.transformer_self_attention_layers[j](out)
+                out = self.transformer_ffn_layers[j](out)
+            refs.append(self.ref_proj(single_nn) if first else reference)
+            last_outputs = out
+            outputs.append(out)
+        return torch.stack(outputs, 0), torch.stack(refs, 0), last_outputs
 
     def forward(self, frame_embeds, mask_features, resume=False, return_indices=False, frame_classes=None,
                 frame_embeds_no_norm=None, need_masks=True):
@@ -140,38 +172,16 @@ class ReferringTracker_noiser(nn.Module):
         indices = match_chain(cosine_costs(cur, ref0))                         # (T, Q) int64, host
         idx_dev = torch.from_numpy(indices).to(fe.device)
 
-        # ---- 2. K / V of all layers for all frames: one GEMM.  (T, Q, 1, layers * 2C)
-        W, b = self._kv_weights()
-        kv = F.linear(fe_nn, W, b)
-
-        # ---- 3. the recurrence
-        outputs, refs = [], []
-        for i in range(T):
-            single_nn = fe_nn[i]                                               # (q, b, c)
-            ident = single_nn[idx_dev[i]]
-            first = i == 0 and first_is_start
-            if not first:
-                reference = self.ref_proj(self.last_outputs)
-                self.last_reference = reference
-            out = ident
-            for j in range(self.num_layers):
-                if first:
-                    ref_j = self.ref_proj(single_nn if j == 0 else out)
-                else:
-                    ref_j = reference
-                kj = kv[i, :, :, (2 * j) * C:(2 * j + 1) * C]
-                vj = kv[i, :, :, (2 * j + 1) * C:(2 * j + 2) * C]
-                out = self.transformer_cross_attention_layers[j].attend(out, ref_j, kj, vj)
-                out = self.transformer_self_attention_layers[j](out)
-                out = self.transformer_ffn_layers[j](out)
-            if first:
-                self.last_reference = self.ref_proj(single_nn)
-            refs.append(self.last_reference)
-            self.last_outputs = out
-            outputs.append(out)
+        # ---- 2 + 3. K / V of all layers for all frames (one GEMM) and the recurrence, replayed from a hipGraph
+        self._kv_weights()                                                     # build the cached weights outside capture
+        state = self.last_outputs if not first_is_start else torch.zeros_like(fe_nn[0])
+        self._rec_first = first_is_start                                       # part of the graph key: fixes control flow
+        self._graph.enabled = self.use_graphs
+        outputs, refs, last = self._graph((T, first_is_start), fe_nn.contiguous(), idx_dev, state)
+        self.last_outputs = last.clone()
+        self.last_reference = refs[T - 1].clone()
         self.last_frame_embeds = fe[T - 1][idx_dev[T - 1]]
-        outputs = torch.stack(outputs, 0)                                      # (t, q, b, c), last layer (eval)
-        refs = torch.stack(refs, 0)
+        outputs, refs = outputs.clone(), refs.clone()                          # static graph buffers -> owned tensors
 
         # ---- 4. heads
         dec = self.decoder_norm(outputs)
