@@ -33,6 +33,13 @@ namespace {
 constexpr int kQB = 64;        // queries per workgroup (tiled kernel)
 constexpr unsigned kOOB = 0x80000000u;  // buffer offset beyond every level slice (< 2 GiB, checked on host)
 
+// How the blocks of a launch map to queries (passed by value, wave-uniform).
+struct QueryTiling {
+  int enabled;        // 0: blockIdx.y * 64 consecutive queries;  1: 8x8 pixel tiles per level
+  int tiles_cum[5];   // first block index of each level's tiles (+ total)
+  int tiles_x[4];     // tiles per row of each level
+};
+
 // Bilinear set-up of one sample for one lane: 4 corner byte offsets (kOOB when the corner is outside the map or
 // the sample is not counted) and the 4 corner weights.  Pure VALU, recomputed at consume time instead of being
 // kept live across the loads (registers are what limits loads in flight here).
@@ -69,7 +76,7 @@ template <int D, int L, int P, bool FUSED, int WPS, int B>
 __global__ __launch_bounds__(256, WPS) void msda_fwd_tile_f32(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const float *__restrict__ loc_or_off, int64_t off_stride, const float *__restrict__ w_or_logit,
-    int64_t logit_stride, const float *__restrict__ refp, int nref, int S, int M, int Lq,
+    int64_t logit_stride, const float *__restrict__ refp, int nref, int S, int M, int Lq, QueryTiling tiling,
     float *__restrict__ out) {
   constexpr int LP = L * P;
   constexpr int G = D / 4;          // lanes per (query, head) pair
@@ -87,8 +94,6 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile_f32(
   const int tid = threadIdx.x;
   const int m = blockIdx.x;
   const int n = blockIdx.z;
-  const int q0 = blockIdx.y * kQB;
-  const int nq = min(kQB, Lq - q0);
   const int MD = M * D;
 
   int Hs[L], Ws[L];
@@ -98,26 +103,57 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile_f32(
     Ws[l] = (int)shapes[2 * l + 1];
   }
 
+  // ---- which 64 queries does this block own?  (all scalar / wave-uniform)
+  //  linear : 64 consecutive query indices.
+  //  2-D    : (encoder self-attention: the queries ARE the pixels of the L maps) one 8x8 pixel tile of one level, so
+  //           the block's sampling footprints overlap in BOTH directions: ~2.5x fewer distinct value lines per block
+  //           than a 64-pixel row segment -> higher L1 hit rate, less L2->L1 traffic (the measured bound).
+  int tl_base = 0, tl_w = 0, tl_h = 0, tl_y0 = 0, tl_x0 = 0, q0 = blockIdx.y * kQB;
+  if (tiling.enabled) {
+    int l = 0;
+#pragma unroll
+    for (int ll = 1; ll < L; ++ll)
+      if ((int)blockIdx.y >= tiling.tiles_cum[ll]) l = ll;
+    const int t = blockIdx.y - tiling.tiles_cum[l];
+    tl_y0 = (t / tiling.tiles_x[l]) * 8;
+    tl_x0 = (t % tiling.tiles_x[l]) * 8;
+#pragma unroll
+    for (int ll = 0; ll < L; ++ll)
+      if (l == ll) { tl_h = Hs[ll]; tl_w = Ws[ll]; tl_base = (int)level_start[ll]; }
+  }
+  // local slot (0..63) -> global query index, or -1 when the slot is empty
+  auto slot_query = [&](int ql) -> int {
+    if (tiling.enabled) {
+      const int y = tl_y0 + (ql >> 3), x = tl_x0 + (ql & 7);
+      return (y < tl_h && x < tl_w) ? tl_base + y * tl_w + x : -1;
+    }
+    return q0 + ql < Lq ? q0 + ql : -1;
+  };
+
   // ---- stage (loc, w) [or raw (offsets, logits)] of this block's 64 queries x 1 head into LDS.
-  // Descriptors cover exactly the nq valid rows: rows past Lq read as 0 without a branch.
+  // Descriptors cover this frame's rows; empty slots get an out-of-range offset and read as 0 without a branch.
   {
-    const size_t row0 = (size_t)n * Lq + q0;
+    const size_t row0 = (size_t)n * Lq;
     const float *lbase = FUSED ? loc_or_off + row0 * off_stride + (size_t)m * (LP * 2)
                                : loc_or_off + (row0 * M + m) * (size_t)(LP * 2);
     const float *wbase = FUSED ? w_or_logit + row0 * logit_stride + (size_t)m * LP
                                : w_or_logit + (row0 * M + m) * (size_t)LP;
     const unsigned lrow = (unsigned)((FUSED ? (size_t)off_stride : (size_t)M * LP * 2) * sizeof(float));
     const unsigned wrow = (unsigned)((FUSED ? (size_t)logit_stride : (size_t)M * LP) * sizeof(float));
-    const __amdgpu_buffer_rsrc_t lrs = dvis_make_rsrc_uniform(lbase, (unsigned)(nq - 1) * lrow + LP * 2 * 4);
-    const __amdgpu_buffer_rsrc_t wrs = dvis_make_rsrc_uniform(wbase, (unsigned)(nq - 1) * wrow + LP * 4);
+    const __amdgpu_buffer_rsrc_t lrs = dvis_make_rsrc_uniform(lbase, (unsigned)(Lq - 1) * lrow + LP * 2 * 4);
+    const __amdgpu_buffer_rsrc_t wrs = dvis_make_rsrc_uniform(wbase, (unsigned)(Lq - 1) * wrow + LP * 4);
     for (int i = tid; i < kQB * LOCV; i += 256) {
       const int ql = i / LOCV, k = i - ql * LOCV;
-      const dvis_v4u v = __builtin_amdgcn_raw_buffer_load_b128(lrs, (unsigned)ql * lrow + (unsigned)k * 16u, 0, 0);
+      const int q = slot_query(ql);
+      const dvis_v4u v = __builtin_amdgcn_raw_buffer_load_b128(
+          lrs, q >= 0 ? (unsigned)q * lrow + (unsigned)k * 16u : kOOB, 0, 0);
       s_loc[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     }
     for (int i = tid; i < kQB * WV; i += 256) {
       const int ql = i / WV, k = i - ql * WV;
-      const dvis_v4u v = __builtin_amdgcn_raw_buffer_load_b128(wrs, (unsigned)ql * wrow + (unsigned)k * 16u, 0, 0);
+      const int q = slot_query(ql);
+      const dvis_v4u v = __builtin_amdgcn_raw_buffer_load_b128(
+          wrs, q >= 0 ? (unsigned)q * wrow + (unsigned)k * 16u : kOOB, 0, 0);
       s_w[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     }
   }
@@ -129,12 +165,13 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile_f32(
     for (int i = tid; i < kQB * LP; i += 256) {
       const int ql = i / LP, s = i - ql * LP;
       const int l = s / P;
-      if (ql < nq) {
+      const int q = slot_query(ql);
+      if (q >= 0) {
         int Hl = Hs[0], Wl = Ws[0];
 #pragma unroll
         for (int ll = 1; ll < L; ++ll)
           if (l == ll) { Hl = Hs[ll]; Wl = Ws[ll]; }
-        const size_t rrow = ((size_t)(nref == 1 ? 0 : n) * Lq + q0 + ql) * L + l;
+        const size_t rrow = ((size_t)(nref == 1 ? 0 : n) * Lq + q) * L + l;
         const float2 r = *reinterpret_cast<const float2 *>(refp + rrow * 2);
         lf[ql * LP * 2 + 2 * s] = r.x + lf[ql * LP * 2 + 2 * s] / (float)Wl;
         lf[ql * LP * 2 + 2 * s + 1] = r.y + lf[ql * LP * 2 + 2 * s + 1] / (float)Hl;
@@ -167,7 +204,7 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile_f32(
   const int g = lane / G, j = lane - g * G;
   const unsigned pix_bytes = (unsigned)MD * 4u;
   const unsigned lane_bytes = (unsigned)j * 16u;
-  float *const out_blk = out + (((size_t)n * Lq + q0) * M + m) * D;   // uniform
+  float *const out_frame = out + ((size_t)n * Lq * M + m) * D;   // uniform
 
   const float *lds_loc = reinterpret_cast<const float *>(s_loc);
   const float *lds_w = reinterpret_cast<const float *>(s_w);
@@ -179,7 +216,8 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile_f32(
 #pragma unroll 1
   for (int it = 0; it < ITERS; ++it) {
     const int ql = (it * 4 + wv) * GPW + g;
-    const bool active = ql < nq;
+    const int q = slot_query(ql);
+    const bool active = q >= 0;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
     for (int l = 0; l < L; ++l) {
@@ -223,7 +261,7 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile_f32(
       }
     }
     if (active) {
-      float *dst = out_blk + (size_t)ql * MD + 4 * j;
+      float *dst = out_frame + (size_t)q * MD + 4 * j;
       *reinterpret_cast<float4 *>(dst) = make_float4(a0, a1, a2, a3);
     }
   }
@@ -286,6 +324,17 @@ int launch_generic(const void *value, const int64_t *shapes, const int64_t *ls, 
 }
 
 // Developer knob (tools/msda_sweep.py): DVIS_MSDA_VARIANT=0..6 selects the tile-kernel build variant.
+// 8x8 query tiling is OFF by default: measured neutral on MI355X (49.0 vs 49.2 us/frame-layer) — the kernel is bound by
+// the 64 B/clk/CU L1 data path (1 KB per wave-instruction, ~21 clk each = 75 % of that limit), not by L1 misses.
+// DVIS_MSDA_TILE2D=1 enables it for experiments.
+bool tile2d_enabled() {
+  static const bool v = [] {
+    const char *e = getenv("DVIS_MSDA_TILE2D");
+    return e != nullptr && atoi(e) != 0;
+  }();
+  return v;
+}
+
 int tile_variant() {
   static const int v = [] {
     const char *e = getenv("DVIS_MSDA_VARIANT");
@@ -297,8 +346,25 @@ int tile_variant() {
 template <int D, int L, int P, bool FUSED>
 int launch_tile(const float *value, const int64_t *shapes, const int64_t *ls, const float *a, int64_t a_stride,
                 const float *b, int64_t b_stride, const float *refp, int nref, int N, int S, int M, int Lq, float *out,
-                hipStream_t st) {
-  const int nchunks = (Lq + kQB - 1) / kQB;
+                hipStream_t st, const int64_t *shapes_host) {
+  QueryTiling tiling = {};
+  int nchunks = (Lq + kQB - 1) / kQB;
+  if (shapes_host != nullptr && L <= 4 && tile2d_enabled()) {
+    long long total = 0;
+    int cum = 0;
+    for (int l = 0; l < L; ++l) {
+      const int H = (int)shapes_host[2 * l], W = (int)shapes_host[2 * l + 1];
+      total += (long long)H * W;
+      tiling.tiles_cum[l] = cum;
+      tiling.tiles_x[l] = (W + 7) / 8;
+      cum += ((H + 7) / 8) * ((W + 7) / 8);
+    }
+    tiling.tiles_cum[L] = cum;
+    if (total == Lq && total == S) {   // the queries are exactly the pixels of the maps (encoder self-attention)
+      tiling.enabled = 1;
+      nchunks = cum;
+    }
+  }
   if (nchunks > 65535 || N > 65535) {
     dvis_set_error("msda: grid too large (Lq/64 and N must be <= 65535)");
     return DVIS_E_ARG;
@@ -306,7 +372,7 @@ int launch_tile(const float *value, const int64_t *shapes, const int64_t *ls, co
   const dim3 grid(M, nchunks, N), block(256);
 #define DVIS_LAUNCH_VARIANT(wps, bsz)                                                                              \
   hipLaunchKernelGGL((msda_fwd_tile_f32<D, L, P, FUSED, wps, bsz>), grid, block, 0, st, value, shapes, ls, a, a_stride,  \
-                     b, b_stride, refp, nref, S, M, Lq, out)
+                     b, b_stride, refp, nref, S, M, Lq, tiling, out)
   switch (tile_variant()) {   // register budget (waves/SIMD) x samples per load batch; default picked by measurement
     case 1: DVIS_LAUNCH_VARIANT(6, 2); break;
     case 2: DVIS_LAUNCH_VARIANT(4, 2); break;
@@ -323,11 +389,12 @@ int launch_tile(const float *value, const int64_t *shapes, const int64_t *ls, co
 template <bool FUSED>
 int dispatch_tile(int D, int L, int P, const float *value, const int64_t *shapes, const int64_t *ls, const float *a,
                   int64_t a_stride, const float *b, int64_t b_stride, const float *refp, int nref, int N, int S, int M,
-                  int Lq, float *out, hipStream_t st, bool *handled) {
+                  int Lq, float *out, hipStream_t st, bool *handled, const int64_t *shapes_host = nullptr) {
   *handled = true;
 #define DVIS_TILE_CASE(d, l, p)  \
   if (D == d && L == l && P == p) \
-    return launch_tile<d, l, p, FUSED>(value, shapes, ls, a, a_stride, b, b_stride, refp, nref, N, S, M, Lq, out, st);
+    return launch_tile<d, l, p, FUSED>(value, shapes, ls, a, a_stride, b, b_stride, refp, nref, N, S, M, Lq, out, st, \
+                                       shapes_host);
   DVIS_TILE_CASE(32, 3, 4)
   DVIS_TILE_CASE(32, 4, 4)
   DVIS_TILE_CASE(32, 1, 4)
@@ -351,7 +418,8 @@ DVIS_EXPORT int dvis_msda_forward(int dtype, const void *value, const int64_t *s
   DVIS_REQUIRE(value && shapes && level_start && loc && w && out, "msda_forward: null pointer");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DVIS_F32) {
-    const bool fits = (size_t)S * M * D * sizeof(float) < 0x7fffffffu;
+    const bool fits = (size_t)S * M * D * sizeof(float) < 0x7fffffffu &&
+                      (size_t)Lq * M * L * P * 2 * sizeof(float) < 0x7fffffffu;
     if (fits && aligned16(value) && aligned16(loc) && aligned16(w) && aligned16(out)) {
       bool handled = false;
       int rc = dispatch_tile<false>(D, L, P, (const float *)value, shapes, level_start, (const float *)loc, 0,
@@ -371,7 +439,7 @@ DVIS_EXPORT int dvis_msda_forward(int dtype, const void *value, const int64_t *s
 DVIS_EXPORT int dvis_msda_fused_forward(const float *value, const int64_t *shapes, const int64_t *level_start,
                                         const float *ref, int Nref, const float *offsets, int64_t off_stride,
                                         const float *logits, int64_t logit_stride, int N, int S, int M, int D, int L,
-                                        int Lq, int P, float *out, void *stream) {
+                                        int Lq, int P, float *out, const int64_t *shapes_host, void *stream) {
   DVIS_REQUIRE(N >= 0 && S > 0 && M > 0 && D > 0 && L > 0 && Lq >= 0 && P > 0, "msda_fused_forward: bad sizes");
   if (N == 0 || Lq == 0) return DVIS_OK;
   DVIS_REQUIRE(value && shapes && level_start && ref && offsets && logits && out, "msda_fused_forward: null pointer");
@@ -383,8 +451,10 @@ DVIS_EXPORT int dvis_msda_fused_forward(const float *value, const int64_t *shape
                "msda_fused_forward: 16-byte alignment required");
   DVIS_REQUIRE((size_t)S * M * D * sizeof(float) < 0x7fffffffu, "msda_fused_forward: frame slice >= 2 GiB");
   bool handled = false;
+  DVIS_REQUIRE((size_t)Lq * (size_t)(off_stride > logit_stride ? off_stride : logit_stride) * sizeof(float) < 0x7fffffffu,
+               "msda_fused_forward: one frame of offsets/logits must stay below 2 GiB");
   int rc = dispatch_tile<true>(D, L, P, value, shapes, level_start, offsets, off_stride, logits, logit_stride, ref,
-                               Nref, N, S, M, Lq, out, (hipStream_t)stream, &handled);
+                               Nref, N, S, M, Lq, out, (hipStream_t)stream, &handled, shapes_host);
   if (handled) return rc;
   dvis_set_error("msda_fused_forward: unsupported (D=%d, L=%d, P=%d); supported D in {32,64}, (L,P) in {(1,4),(3,4),(4,4)}",
                  D, L, P);

@@ -99,12 +99,13 @@ class MSDeformAttnFunction(Function):
 
 
 def msda_fused_forward(value, spatial_shapes, level_start_index, reference_points, offsets, logits, n_levels,
-                       n_points):
+                       n_points, shapes_host=None):
     """Inference fast path of ``MSDeformAttn.forward`` (ops/modules/ms_deform_attn.py:101-117), fp32.
 
     value (N,S,M,D); reference_points (1|N, Lq, L, 2); ``offsets`` / ``logits`` are 2-D row views
     (N*Lq, >= M*L*P*2) / (N*Lq, >= M*L*P) of the raw linear outputs (row stride may exceed the width, e.g.
     both sliced out of one fused projection).  softmax + location arithmetic happen inside the kernel.
+    shapes_host: optional [(H, W), ...] python copy of spatial_shapes (enables 8x8 query tiling for self-attention).
     """
     N, S, M, D = value.shape
     L, P = n_levels, n_points
@@ -119,12 +120,15 @@ def msda_fused_forward(value, spatial_shapes, level_start_index, reference_point
     if offsets.shape[1] < M * L * P * 2 or logits.shape[1] < M * L * P or reference_points.shape[2:] != (L, 2):
         raise RuntimeError("msda_fused_forward: inconsistent shapes")
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    hs = None
+    if shapes_host is not None:
+        hs = (ctypes.c_int64 * (2 * L))(*[int(v) for hw in shapes_host for v in hw])
     with torch.cuda.device(value.device):
         rc = native.lib().dvis_msda_fused_forward(
             native.dev_ptr(value, "value"), native.dev_ptr(spatial_shapes, "spatial_shapes"),
             native.dev_ptr(level_start_index, "level_start_index"), native.dev_ptr(reference_points, "ref"), nref,
             ctypes.c_void_p(offsets.data_ptr()), offsets.stride(0), ctypes.c_void_p(logits.data_ptr()),
-            logits.stride(0), N, S, M, D, L, Lq, P, native.dev_ptr(out, "out"), native.stream_ptr(value.device))
+            logits.stride(0), N, S, M, D, L, Lq, P, native.dev_ptr(out, "out"), hs, native.stream_ptr(value.device))
     native.check(rc, "dvis_msda_fused_forward")
     return out
 
@@ -218,3 +222,25 @@ def attention(q, k, v, nheads, mask=None, allowed_count=None, out=None):
             ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, native.stream_ptr(q.device))
     native.check(rc, "dvis_attention_forward")
     return out
+
+
+def vps_argmax(mask_logits_kthw, scores, first_resize_size, img_size, out_hw):
+    """Fused panoptic arg-max (see dvis_vps_argmax).  mask_logits_kthw: float32 GPU (K, T, h, w) view whose last two
+    dims are contiguous; scores float32 (K,).  Returns ids int32 (T,H,W), conf bool (T,H,W), areas int32 (3, K)."""
+    K, T, h, w = mask_logits_kthw.shape
+    m = mask_logits_kthw
+    if not m.is_cuda or m.dtype != torch.float32 or m.stride(3) != 1 or m.stride(2) != w:
+        raise RuntimeError("vps_argmax: logits must be a float32 GPU (K, T, h, w) view with contiguous (h, w) maps")
+    scores = scores.to(torch.float32).contiguous()
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    ids = torch.empty((T, oh, ow), dtype=torch.int32, device=m.device)
+    conf = torch.empty((T, oh, ow), dtype=torch.uint8, device=m.device)
+    areas = torch.empty((3, K), dtype=torch.int32, device=m.device)
+    with torch.cuda.device(m.device):
+        rc = native.lib().dvis_vps_argmax(
+            ctypes.c_void_p(m.data_ptr()), m.stride(0), m.stride(1), native.dev_ptr(scores, "scores"), K, T, h, w,
+            int(first_resize_size[0]), int(first_resize_size[1]), int(img_size[0]), int(img_size[1]), oh, ow,
+            native.dev_ptr(ids, "ids"), native.dev_ptr(conf, "conf"), native.dev_ptr(areas, "areas"),
+            native.stream_ptr(m.device))
+    native.check(rc, "dvis_vps_argmax")
+    return ids, conf.bool(), areas

@@ -122,7 +122,10 @@ class MSDeformAttn(nn.Module):
                 and (self.n_levels, self.n_points) in ((1, 4), (3, 4), (4, 4)))
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
-                input_padding_mask=None):
+                input_padding_mask=None, spatial_shapes_py=None):
+        """Reference signature + one optional extra: `spatial_shapes_py`, a python copy of the shapes.  When the
+        queries are the pixels themselves (encoder self-attention) it lets the kernel give each block an 8x8 pixel
+        tile (cache locality); results do not depend on it."""
         N, Len_q, _ = query.shape
         N, Len_in, _ = input_flatten.shape
         M, L, P = self.n_heads, self.n_levels, self.n_points
@@ -136,7 +139,7 @@ class MSDeformAttn(nn.Module):
             n_off = M * L * P * 2
             ref = reference_points if reference_points.is_contiguous() else reference_points.contiguous()
             output = Fn.msda_fused_forward(value, input_spatial_shapes, input_level_start_index, ref,
-                                           proj[:, :n_off], proj[:, n_off:], L, P)
+                                           proj[:, :n_off], proj[:, n_off:], L, P, shapes_host=spatial_shapes_py)
             return self.output_proj(output)
         sampling_offsets = self.sampling_offsets(query).view(N, Len_q, M, L, P, 2)
         attention_weights = self.attention_weights(query).view(N, Len_q, M, L * P)
@@ -169,9 +172,11 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         self.norm2 = nn.LayerNorm(d_model)
         self.dropout_p = dropout     # inference path: dropout is the identity
 
-    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
+    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None,
+                shapes_py=None):
         q = src if pos is None else src + pos
-        src2 = self.self_attn(q, reference_points, src, spatial_shapes, level_start_index, padding_mask)
+        src2 = self.self_attn(q, reference_points, src, spatial_shapes, level_start_index, padding_mask,
+                              spatial_shapes_py=shapes_py)
         src = self.norm1(src + src2)
         src2 = self.linear2(F.relu(self.linear1(src)))
         return self.norm2(src + src2)
@@ -214,7 +219,8 @@ class MSDeformAttnTransformerEncoder(nn.Module):
             reference_points = self.get_reference_points(spatial_shapes.tolist(), valid_ratios, src.device)
         output = src
         for layer in self.layers:
-            output = layer(output, pos, reference_points, spatial_shapes, level_start_index, padding_mask)
+            output = layer(output, pos, reference_points, spatial_shapes, level_start_index, padding_mask,
+                           shapes_py=shapes_py)
         return output
 
 

@@ -70,15 +70,23 @@ def inference_video_vps(pred_cls, mask_fn, img_size, out_hw, first_resize_size, 
         return {"image_size": tuple(out_hw), "pred_masks": torch.zeros((T, *out_hw), dtype=torch.int32, device=dev),
                 "segments_infos": [], "pred_ids": [], "task": "vps", "num_candidates": 0}
     cur_scores, cur_classes = scores[ids], labels[ids]
-    cur_masks = _resize2(mask_fn(ids), first_resize_size, img_size, out_hw, sigmoid=True)     # (K', T, H, W)
-    cur_mask_ids = (cur_scores.view(-1, 1, 1, 1) * cur_masks).argmax(0)                       # (T, H, W)
-    conf = cur_masks.gather(0, cur_mask_ids.unsqueeze(0))[0] >= 0.5                           # winner's own prob >= .5
     K = ids.numel()
-    flat_ids = cur_mask_ids.flatten()
-    mask_area = torch.bincount(flat_ids, minlength=K)
-    inter = torch.bincount(flat_ids, weights=conf.flatten().to(torch.float32), minlength=K)
-    original_area = (cur_masks >= 0.5).flatten(1).sum(1)
-    areas = torch.stack([mask_area.double(), original_area.double(), inter.double()])
+    logits = mask_fn(ids)                                                                     # (K', T, h, w)
+    if logits.is_cuda and K <= 256:
+        # one fused pass over the stride-4 logits (two-stage resize + sigmoid + weighted arg-max + areas)
+        from . import functions as Fn
+        cur_mask_ids, conf, areas = Fn.vps_argmax(logits, cur_scores, first_resize_size, img_size, out_hw)
+        cur_mask_ids = cur_mask_ids.long()
+        areas = areas.double()
+    else:
+        cur_masks = _resize2(logits, first_resize_size, img_size, out_hw, sigmoid=True)       # (K', T, H, W)
+        cur_mask_ids = (cur_scores.view(-1, 1, 1, 1) * cur_masks).argmax(0)                   # (T, H, W)
+        conf = cur_masks.gather(0, cur_mask_ids.unsqueeze(0))[0] >= 0.5                       # winner's own prob >= .5
+        flat_ids = cur_mask_ids.flatten()
+        mask_area = torch.bincount(flat_ids, minlength=K)
+        inter = torch.bincount(flat_ids, weights=conf.flatten().to(torch.float32), minlength=K)
+        original_area = (cur_masks >= 0.5).flatten(1).sum(1)
+        areas = torch.stack([mask_area.double(), original_area.double(), inter.double()])
     if reduce_fn is not None:
         areas = reduce_fn(areas)
     stats = torch.cat([areas, cur_classes.double()[None], ids.double()[None]]).cpu()         # sync #2: one copy

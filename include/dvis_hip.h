@@ -21,6 +21,8 @@
  *   dvis_attention_forward   <- nn.MultiheadAttention core (softmax(QK^T/sqrt(d) [+mask]) V) as used by
  *                               CrossAttentionLayer / SelfAttentionLayer (mask2former_video/.../video_mask2former_transformer_decoder.py:18-136),
  *                               ReferringCrossAttentionLayer (dvis_Plus/tracker.py:8-92), TemporalRefiner (dvis_Plus/refiner.py:104-139)
+ *   dvis_vps_argmax          <- two-stage resize + sigmoid + score-weighted argmax + segment areas of inference_video_vps,
+ *                               dvis_Plus/meta_architecture.py:890-925
  *   dvis_lsap_solve          <- scipy.optimize.linear_sum_assignment as called by Noiser.match_embds, dvis_Plus/noiser.py:43-56
  *   dvis_match_chain         <- the frame-by-frame matching loop of ReferringTracker_noiser.forward, dvis_Plus/tracker.py:210-291
  */
@@ -77,11 +79,15 @@ int dvis_msda_backward(int dtype, const void *value, const int64_t *shapes, cons
  *   logits   rows of (M, L*P)     floats, row stride `logit_stride` floats
  *   ref      (Nref, Lq, L, 2) reference points; Nref == 1 broadcasts over the batch
  * loc = ref[:, :, None, :, None, :] + offsets / (W_l, H_l);  w = softmax over (L*P) — ms_deform_attn.py:101-109.
+ *   shapes_host: NULL, or a HOST copy of `shapes`; when given and sum(H_l*W_l) == Lq == S (encoder self-attention:
+ *   the queries are the pixels) blocks own 8x8 pixel tiles instead of 64 consecutive queries (cache locality only;
+ *   results are identical).
  */
 int dvis_msda_fused_forward(const float *value, const int64_t *shapes, const int64_t *level_start,
                             const float *ref, int Nref, const float *offsets, int64_t off_stride,
                             const float *logits, int64_t logit_stride,
-                            int N, int S, int M, int D, int L, int Lq, int P, float *out, void *stream);
+                            int N, int S, int M, int D, int L, int Lq, int P, float *out,
+                            const int64_t *shapes_host, void *stream);
 
 /*
  * Mask logits: out[b, q, p] = sum_c embed[b, q, c] * feat[b, c, p]     (fp32, exact-fp32 MFMA)
@@ -118,6 +124,19 @@ int dvis_attention_forward(const float *q, const int64_t *q_strides, const float
                            const float *v, const int64_t *v_strides, float *out, const int64_t *o_strides,
                            const uint8_t *mask, const int32_t *allowed_count, int B, int heads, int Lq, int Lk,
                            int d, float scale, void *ws, void *stream);
+
+/*
+ * Panoptic arg-max of a clip in one pass (inference_video_vps, dvis_Plus/meta_architecture.py:890-925):
+ *   prob_k = resize2(sigmoid(resize1(logits_k)[:img_h, :img_w])), both resizes bilinear align_corners=False
+ *   (stride-4 map (h,w) -> padded input (first_h, first_w) -> crop (img_h, img_w) -> output (out_h, out_w));
+ *   ids = argmax_k scores[k] * prob_k (first maximum wins), conf = prob_ids >= 0.5,
+ *   areas (3, K) int32 = [ (ids == k).sum(), (prob_k >= 0.5).sum(), ((ids == k) & conf).sum() ]   (zeroed inside).
+ *   logits: K x T maps of h*w floats, logits[k][t] at logits + k*stride_k + t*stride_t; 1 <= K <= 256.
+ *   ids (T, out_h, out_w) int32, conf (T, out_h, out_w) uint8.
+ */
+int dvis_vps_argmax(const float *logits, int64_t stride_k, int64_t stride_t, const float *scores, int K, int T,
+                    int h, int w, int first_h, int first_w, int img_h, int img_w, int out_h, int out_w,
+                    int32_t *ids, uint8_t *conf, int32_t *areas, void *stream);
 
 /*
  * HOST function: minimum-cost assignment of an nr x nc (nr <= nc) row-major double cost matrix,

@@ -117,7 +117,8 @@ def _o_mask_logits(mask_embed, mask_features):
     return torch.einsum("bqc,bchw->bqhw", mask_embed, mask_features)
 
 
-def _o_msda_fused(value, spatial_shapes, level_start_index, reference_points, offsets, logits, n_levels, n_points):
+def _o_msda_fused(value, spatial_shapes, level_start_index, reference_points, offsets, logits, n_levels, n_points,
+                  shapes_host=None):
     from oracle.msda import msda_forward_torch
     N, S, M, D = value.shape
     Lq = reference_points.shape[1]

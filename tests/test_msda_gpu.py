@@ -197,3 +197,25 @@ def test_errors_are_loud():
         ms_deform_attn_forward(value.to(DEV).transpose(2, 3), s.to(DEV), lsi.to(DEV), loc.to(DEV), w.to(DEV), 128)
     with pytest.raises(RuntimeError, match="dtype"):
         ms_deform_attn_forward(value.to(DEV), s.to(DEV), lsi.to(DEV), loc.to(DEV).double(), w.to(DEV), 128)
+
+
+def test_fused_forward_2d_query_tiling_is_only_a_schedule():
+    """8x8 pixel-tile blocks (self-attention geometry, ragged map edges) give the same numbers as linear blocks."""
+    from dvis_plus_amd.functions import msda_fused_forward
+    for shapes in ([(23, 40), (46, 80), (92, 160)], [(5, 7), (9, 13), (17, 30)]):
+        N, M, D, L, P = 2, 8, 32, 3, 4
+        s, lsi = level_tensors(shapes)
+        S = Lq = int(s.prod(1).sum())
+        g = torch.Generator().manual_seed(12)
+        value = torch.randn(N, S, M, D, generator=g).to(DEV)
+        proj = (torch.randn(N * Lq, M * L * P * 3, generator=g) * 2).to(DEV)
+        ref_pts = torch.rand(1, Lq, L, 2, generator=g).to(DEV)
+        n_off = M * L * P * 2
+        a = msda_fused_forward(value, s.to(DEV), lsi.to(DEV), ref_pts, proj[:, :n_off], proj[:, n_off:], L, P)
+        b = msda_fused_forward(value, s.to(DEV), lsi.to(DEV), ref_pts, proj[:, :n_off], proj[:, n_off:], L, P,
+                               shapes_host=shapes)
+        assert torch.equal(a, b)
+        # queries that are NOT the pixels: the hint is ignored (linear blocks)
+        c = msda_fused_forward(value, s.to(DEV), lsi.to(DEV), ref_pts[:, :100].contiguous(), proj[:2 * 100, :n_off],
+                               proj[:2 * 100, n_off:], L, P, shapes_host=shapes)
+        assert c.shape == (N, 100, M * D)

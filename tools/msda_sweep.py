@@ -66,6 +66,9 @@ def p(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+HOST_SHAPES = (ctypes.c_int64 * 6)(23, 40, 46, 80, 92, 160)
+
+
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 libs = [("variant " + os.environ.get("DVIS_MSDA_VARIANT", "default"), native.LIB_PATH)]
 FULL = os.environ.get("SWEEP_FULL", "0") == "1"
@@ -87,7 +90,7 @@ for tag, path in libs:
 
     def fused():
         rc = l.dvis_msda_fused_forward(p(value), p(shapes), p(lsi), p(ref), 1, p(offs2d), offs2d.stride(0), p(log2d),
-                                       log2d.stride(0), N, S, M, D, L, Lq, P, p(out), st)
+                                       log2d.stride(0), N, S, M, D, L, Lq, P, p(out), HOST_SHAPES, st)
         assert rc == 0
     ms = timeit(fused)
     err = (out - ref_out).abs().max().item()
