@@ -1,0 +1,139 @@
+// Small fused memory-bound passes around the library GEMMs / convolutions — gfx950.
+//
+//   dvis_add_layernorm   out = LayerNorm(x + res) * gamma + beta      (post-norm residual blocks of every transformer
+//                        layer on the path: msdeformattn.py:125-131, video_mask2former_transformer_decoder.py:47-50,
+//                        108-111, 166-170, tracker.py:51-53).  torch runs add and layer_norm as two kernels (3 + 2
+//                        passes over the tensor); this is one pass (2 reads, 1 write) with the row kept in registers.
+//   dvis_upsample_add    out = lateral + bilinear_upsample(top)        (FPN top-down step, msdeformattn.py:347;
+//                        F.interpolate(align_corners=False) to the lateral's size + add: 2 kernels and a 1.8 GB
+//                        intermediate per clip in torch).
+// Both are HBM-bound; float4 accesses, one wave per row (layernorm) / one thread per 4 output pixels (upsample).
+#include <math.h>
+
+#include "dvis_common.h"
+
+namespace {
+
+// One wave per row, C = 4 * 64 * V floats held in registers; two-pass (mean, then centred variance) like torch.
+template <int V>
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restrict__ x, const float *__restrict__ res,
+                                                            int64_t res_row_stride, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, float *__restrict__ out,
+                                                            size_t rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float4 *xr = reinterpret_cast<const float4 *>(x + row * C);
+  const float4 *rr = res ? reinterpret_cast<const float4 *>(res + row * res_row_stride) : nullptr;
+  float4 v[V];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int c4 = lane + 64 * i;
+    if (c4 * 4 < C) {
+      v[i] = xr[c4];
+      if (rr) {
+        const float4 r = rr[c4];
+        v[i].x += r.x; v[i].y += r.y; v[i].z += r.z; v[i].w += r.w;
+      }
+      sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    } else {
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float mean = sum / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int c4 = lane + 64 * i;
+    if (c4 * 4 < C) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      sq += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+  const float rstd = rsqrtf(sq / (float)C + eps);
+  float4 *orow = reinterpret_cast<float4 *>(out + row * C);
+  const float4 *g4 = reinterpret_cast<const float4 *>(gamma);
+  const float4 *b4 = reinterpret_cast<const float4 *>(beta);
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int c4 = lane + 64 * i;
+    if (c4 * 4 < C) {
+      const float4 g = g4[c4], b = b4[c4];
+      orow[c4] = make_float4((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
+                             (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
+    }
+  }
+}
+
+// torch upsample_bilinear2d (align_corners=False) taps:  src = max(scale * (dst + .5) - .5, 0)
+__global__ __launch_bounds__(256) void upsample_add_kernel(const float *__restrict__ lateral, const float *__restrict__ top,
+                                                           float *__restrict__ out, int planes, int H, int W, int h, int w) {
+  const size_t total = (size_t)planes * H * (W / 4);
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int xq = (int)(idx % (W / 4));
+    const size_t r = idx / (W / 4);
+    const int y = (int)(r % H);
+    const size_t pl = r / H;
+    float fy = sy * ((float)y + 0.5f) - 0.5f;
+    fy = fy < 0.f ? 0.f : fy;
+    const int y0 = min((int)fy, h - 1), y1 = y0 + (y0 < h - 1 ? 1 : 0);
+    const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
+    const float *t0 = top + (pl * h + y0) * (size_t)w, *t1 = top + (pl * h + y1) * (size_t)w;
+    const size_t o = (pl * H + y) * (size_t)W + 4 * xq;
+    const float4 lat = *reinterpret_cast<const float4 *>(lateral + o);
+    float res[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float fx = sx * ((float)(4 * xq + k) + 0.5f) - 0.5f;
+      fx = fx < 0.f ? 0.f : fx;
+      const int x0 = min((int)fx, w - 1), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+      const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+      res[k] = ly0 * (lx0 * t0[x0] + lx1 * t0[x1]) + ly1 * (lx0 * t1[x0] + lx1 * t1[x1]);
+    }
+    *reinterpret_cast<float4 *>(out + o) = make_float4(lat.x + res[0], lat.y + res[1], lat.z + res[2], lat.w + res[3]);
+  }
+}
+
+}  // namespace
+
+DVIS_EXPORT int dvis_add_layernorm(const float *x, const float *res, int64_t res_row_stride, const float *gamma,
+                                   const float *beta, float *out, int64_t rows, int C, float eps, void *stream) {
+  DVIS_REQUIRE(rows >= 0 && C > 0, "add_layernorm: bad sizes");
+  if (rows == 0) return DVIS_OK;
+  DVIS_REQUIRE(x && gamma && beta && out, "add_layernorm: null pointer");
+  DVIS_REQUIRE(C % 4 == 0 && C <= 1024, "add_layernorm: C must be a multiple of 4 and <= 1024 (got %d)", C);
+  DVIS_REQUIRE(res == nullptr || res_row_stride % 4 == 0, "add_layernorm: residual row stride must be a multiple of 4");
+  const uintptr_t al = (uintptr_t)x | (uintptr_t)res | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out;
+  DVIS_REQUIRE((al & 15) == 0, "add_layernorm: pointers must be 16-byte aligned");
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (C <= 256)
+    hipLaunchKernelGGL((add_layernorm_kernel<1>), grid, block, 0, st, x, res, res_row_stride, gamma, beta, out, (size_t)rows, C, eps);
+  else if (C <= 512)
+    hipLaunchKernelGGL((add_layernorm_kernel<2>), grid, block, 0, st, x, res, res_row_stride, gamma, beta, out, (size_t)rows, C, eps);
+  else
+    hipLaunchKernelGGL((add_layernorm_kernel<4>), grid, block, 0, st, x, res, res_row_stride, gamma, beta, out, (size_t)rows, C, eps);
+  return dvis_check_launch("add_layernorm_kernel");
+}
+
+DVIS_EXPORT int dvis_upsample_add(const float *lateral, const float *top, float *out, int64_t planes, int H, int W, int h,
+                                  int w, void *stream) {
+  DVIS_REQUIRE(planes >= 0 && H > 0 && W > 0 && h > 0 && w > 0, "upsample_add: bad sizes");
+  if (planes == 0) return DVIS_OK;
+  DVIS_REQUIRE(lateral && top && out, "upsample_add: null pointer");
+  DVIS_REQUIRE(W % 4 == 0 && (((uintptr_t)lateral | (uintptr_t)out) & 15) == 0,
+               "upsample_add: W must be a multiple of 4 and lateral/out 16-byte aligned");
+  DVIS_REQUIRE(planes < (1ll << 31), "upsample_add: too many planes");
+  const size_t total = (size_t)planes * H * (W / 4);
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(upsample_add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, lateral, top, out,
+                     (int)planes, H, W, h, w);
+  return dvis_check_launch("upsample_add_kernel");
+}

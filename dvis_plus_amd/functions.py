@@ -244,3 +244,52 @@ def vps_argmax(mask_logits_kthw, scores, first_resize_size, img_size, out_hw):
             native.stream_ptr(m.device))
     native.check(rc, "dvis_vps_argmax")
     return ids, conf.bool(), areas
+
+
+def add_layer_norm(x, res, norm):
+    """``norm(x + res)`` for an ``nn.LayerNorm`` `norm` in ONE pass.  x contiguous float32 GPU (..., C); res: None or a
+    tensor broadcast-free of x's shape whose rows (last dim) are contiguous.  CPU tensors / other dtypes use torch ops
+    (library code, not one of the named hot ops)."""
+    C = x.shape[-1]
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and C % 4 == 0 and C <= 1024
+            and norm.weight is not None and not torch.is_grad_enabled()):
+        return norm(x if res is None else x + res)
+    rp, rs = None, 0
+    if res is not None:
+        if res.shape != x.shape or res.dtype != torch.float32 or not res.is_cuda:
+            return norm(x + res)
+        if not res.is_contiguous():
+            res = res.contiguous()
+        rp, rs = ctypes.c_void_p(res.data_ptr()), C
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = native.lib().dvis_add_layernorm(ctypes.c_void_p(x.data_ptr()), rp, rs, native.dev_ptr(norm.weight, "gamma"),
+                                             native.dev_ptr(norm.bias, "beta"), ctypes.c_void_p(out.data_ptr()),
+                                             x.numel() // C, C, float(norm.eps), native.stream_ptr(x.device))
+    native.check(rc, "dvis_add_layernorm")
+    return out
+
+
+def upsample_add(lateral, top):
+    """``lateral + F.interpolate(top, size=lateral.shape[-2:], mode="bilinear", align_corners=False)`` in one pass."""
+    N, C, H, W = lateral.shape
+    if not (lateral.is_cuda and lateral.dtype == torch.float32 and top.dtype == torch.float32 and W % 4 == 0
+            and lateral.is_contiguous() and not torch.is_grad_enabled()):
+        import torch.nn.functional as F
+        return lateral + F.interpolate(top, size=(H, W), mode="bilinear", align_corners=False)
+    top = top.contiguous()
+    out = torch.empty_like(lateral)
+    with torch.cuda.device(lateral.device):
+        rc = native.lib().dvis_upsample_add(native.dev_ptr(lateral, "lateral"), native.dev_ptr(top, "top"),
+                                            native.dev_ptr(out, "out"), N * C, H, W, top.shape[-2], top.shape[-1],
+                                            native.stream_ptr(lateral.device))
+    native.check(rc, "dvis_upsample_add")
+    return out
+
+
+def linear_relu(x, linear):
+    """relu(linear(x)) with the bias + ReLU epilogue inside the GEMM (hipBLASLt through torch._addmm_activation)."""
+    if x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled():
+        y = torch._addmm_activation(linear.bias, x.reshape(-1, x.shape[-1]), linear.weight.t(), use_gelu=False)
+        return y.view(*x.shape[:-1], -1)
+    return torch.relu(linear(x))

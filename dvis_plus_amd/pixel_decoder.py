@@ -177,9 +177,9 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         q = src if pos is None else src + pos
         src2 = self.self_attn(q, reference_points, src, spatial_shapes, level_start_index, padding_mask,
                               spatial_shapes_py=shapes_py)
-        src = self.norm1(src + src2)
-        src2 = self.linear2(F.relu(self.linear1(src)))
-        return self.norm2(src + src2)
+        src = Fn.add_layer_norm(src2, src, self.norm1)
+        src2 = self.linear2(Fn.linear_relu(src, self.linear1))
+        return Fn.add_layer_norm(src2, src, self.norm2)
 
 
 class MSDeformAttnTransformerEncoder(nn.Module):
@@ -372,8 +372,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
             for idx, f in enumerate(self.in_features[:self.num_fpn_levels][::-1]):
                 x = features[f].float()
                 cur_fpn = self.lateral_convs[idx](x)
-                y = cur_fpn + F.interpolate(out[-1], size=cur_fpn.shape[-2:], mode="bilinear", align_corners=False)
-                out.append(self.output_convs[idx](y))
+                out.append(self.output_convs[idx](Fn.upsample_add(cur_fpn, out[-1])))
             multi_scale_features = out[:self.maskformer_num_feature_levels]
             return self.mask_features(out[-1]), out[0], multi_scale_features
 

@@ -55,7 +55,7 @@ class SelfAttentionLayer(nn.Module):
             q, k = qk[..., :C], qk[..., C:]
             v = F.linear(tgt, W[2 * C:], b[2 * C:])
         att = Fn.attention(q, k, v, self.nhead)
-        return self.norm(tgt + self.self_attn.out_proj(att))
+        return Fn.add_layer_norm(self.self_attn.out_proj(att), tgt, self.norm)
 
 
 class CrossAttentionLayer(nn.Module):
@@ -81,7 +81,7 @@ class CrossAttentionLayer(nn.Module):
         """k_proj / v_proj are already projected (Lk, B, C) views."""
         att = Fn.attention(self.project_q(q_in), k_proj, v_proj, self.nhead, mask, allowed)
         res = tgt if identity is None else identity
-        return self.norm(res + self.multihead_attn.out_proj(att))
+        return Fn.add_layer_norm(self.multihead_attn.out_proj(att), res, self.norm)
 
     def forward(self, tgt, memory, memory_mask=None, memory_key_padding_mask=None, pos=None, query_pos=None):
         assert memory_key_padding_mask is None
@@ -103,7 +103,7 @@ class FFNLayer(nn.Module):
         _xavier_(self)
 
     def forward(self, tgt):
-        return self.norm(tgt + self.linear2(F.relu(self.linear1(tgt))))
+        return Fn.add_layer_norm(self.linear2(Fn.linear_relu(tgt, self.linear1)), tgt, self.norm)
 
 
 class MLP(nn.Module):
@@ -115,7 +115,7 @@ class MLP(nn.Module):
 
     def forward(self, x):
         for i, layer in enumerate(self.layers):
-            x = F.relu(layer(x)) if i < self.num_layers - 1 else layer(x)
+            x = Fn.linear_relu(x, layer) if i < self.num_layers - 1 else layer(x)
         return x
 
 

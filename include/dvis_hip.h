@@ -21,6 +21,9 @@
  *   dvis_attention_forward   <- nn.MultiheadAttention core (softmax(QK^T/sqrt(d) [+mask]) V) as used by
  *                               CrossAttentionLayer / SelfAttentionLayer (mask2former_video/.../video_mask2former_transformer_decoder.py:18-136),
  *                               ReferringCrossAttentionLayer (dvis_Plus/tracker.py:8-92), TemporalRefiner (dvis_Plus/refiner.py:104-139)
+ *   dvis_add_layernorm       <- `norm(tgt + tgt2)` of every post-norm residual block (msdeformattn.py:125-131,
+ *                               video_mask2former_transformer_decoder.py:47-50,108-111,166-170, tracker.py:51-53)
+ *   dvis_upsample_add        <- `cur_fpn + F.interpolate(out[-1], size=..., mode="bilinear")`, msdeformattn.py:347
  *   dvis_vps_argmax          <- two-stage resize + sigmoid + score-weighted argmax + segment areas of inference_video_vps,
  *                               dvis_Plus/meta_architecture.py:890-925
  *   dvis_lsap_solve          <- scipy.optimize.linear_sum_assignment as called by Noiser.match_embds, dvis_Plus/noiser.py:43-56
@@ -124,6 +127,20 @@ int dvis_attention_forward(const float *q, const int64_t *q_strides, const float
                            const float *v, const int64_t *v_strides, float *out, const int64_t *o_strides,
                            const uint8_t *mask, const int32_t *allowed_count, int B, int heads, int Lq, int Lk,
                            int d, float scale, void *ws, void *stream);
+
+/*
+ * out[r, :] = LayerNorm(x[r, :] + res[r, :]) * gamma + beta, rows x C fp32 (C % 4 == 0, C <= 1024); `res` may be NULL
+ * and may have its own row stride (floats).  One pass: 2 reads + 1 write (torch: add kernel + layer_norm kernel).
+ */
+int dvis_add_layernorm(const float *x, const float *res, int64_t res_row_stride, const float *gamma, const float *beta,
+                       float *out, int64_t rows, int C, float eps, void *stream);
+
+/*
+ * out = lateral + F.interpolate(top, size=(H, W), mode="bilinear", align_corners=False) for `planes` = N*C planes;
+ * lateral / out (planes, H, W), top (planes, h, w); W % 4 == 0.  (FPN top-down step, msdeformattn.py:347.)
+ */
+int dvis_upsample_add(const float *lateral, const float *top, float *out, int64_t planes, int H, int W, int h, int w,
+                      void *stream);
 
 /*
  * Panoptic arg-max of a clip in one pass (inference_video_vps, dvis_Plus/meta_architecture.py:890-925):

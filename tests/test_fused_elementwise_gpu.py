@@ -1,0 +1,58 @@
+"""GPU parity of the small fused passes (add+LayerNorm, upsample+add, GEMM+ReLU epilogue) vs the torch ops they replace."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 256), (100, 512), (3, 1024), (5, 32), (4097, 256)])
+def test_add_layernorm(rows, C):
+    from dvis_plus_amd.functions import add_layer_norm
+    g = torch.Generator().manual_seed(rows + C)
+    x, r = torch.randn(rows, C, generator=g) * 3, torch.randn(rows, C, generator=g)
+    ln = torch.nn.LayerNorm(C)
+    with torch.no_grad():
+        ln.weight.normal_(1, 0.2, generator=g)
+        ln.bias.normal_(0, 0.2, generator=g)
+        ref = ln((x + r).double().float())
+        ref64 = F.layer_norm((x.double() + r.double()), (C,), ln.weight.double(), ln.bias.double(), ln.eps)
+        lnd = ln.to(DEV)
+        out = add_layer_norm(x.to(DEV), r.to(DEV), lnd).cpu()
+        out_nores = add_layer_norm(x.to(DEV), None, lnd).cpu()
+    torch.testing.assert_close(out.double(), ref64, rtol=0, atol=5e-6)
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=5e-6)
+    torch.testing.assert_close(out_nores, ln.cpu()(x), rtol=1e-5, atol=5e-6)
+
+
+def test_add_layernorm_3d_shapes_like_the_decoder():
+    from dvis_plus_amd.functions import add_layer_norm
+    x, r = torch.randn(100, 30, 256), torch.randn(100, 30, 256)
+    ln = torch.nn.LayerNorm(256)
+    with torch.no_grad():
+        ref = ln(x + r)
+        out = add_layer_norm(x.to(DEV), r.to(DEV), ln.to(DEV)).cpu()
+    assert out.shape == ref.shape
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=5e-6)
+
+
+@pytest.mark.parametrize("N,C,h,w,H,W", [(2, 8, 5, 8, 10, 16), (1, 3, 7, 10, 23, 40), (2, 4, 46, 80, 92, 160)])
+def test_upsample_add(N, C, h, w, H, W):
+    from dvis_plus_amd.functions import upsample_add
+    g = torch.Generator().manual_seed(h * w)
+    lat, top = torch.randn(N, C, H, W, generator=g), torch.randn(N, C, h, w, generator=g)
+    with torch.no_grad():
+        ref = lat + F.interpolate(top, size=(H, W), mode="bilinear", align_corners=False)
+        out = upsample_add(lat.to(DEV), top.to(DEV)).cpu()
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_linear_relu_epilogue():
+    from dvis_plus_amd.functions import linear_relu
+    lin = torch.nn.Linear(256, 1024)
+    x = torch.randn(7, 100, 256)
+    with torch.no_grad():
+        ref = F.relu(lin(x))
+        out = linear_relu(x.to(DEV), lin.to(DEV)).cpu()
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
