@@ -172,6 +172,11 @@ def main():
         fps = T * args.steps / dt
         sec, nfr, nlaunch = timer.summary()
         achieved = MSDA_BYTES_PER_FRAME_LAYER * nfr / sec / 1e9
+        traffic = None     # HBM bytes per launch from the committed rocprofv3 PMC passes (bench.py cannot read PMCs itself)
+        tj = os.path.join(ROOT, "profiles", "r01_msda_traffic.json")
+        if os.path.exists(tj):
+            t = json.load(open(tj))
+            traffic = round(t["hbm_bytes_per_launch"] * nfr / t["frames_per_launch"])
         res = {
             "metric": "frames/sec DVIS++ R50 offline, 720p T=30 synthetic", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
@@ -181,7 +186,9 @@ def main():
                        "panoptic_candidates": out.get("num_candidates"), "segments": len(out.get("segments_infos", []))},
             "roofline": {"bound": "hbm", "kernel": "msda_fwd_tile_f32 (fused MSDeformAttn forward)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": "profiles/r01_msda_traffic.json (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE)",
+                         "alg_bytes_per_launch": int(MSDA_BYTES_PER_FRAME_LAYER * nfr),
                          "us_per_launch": round(sec * 1e6, 1), "frames_per_launch": nfr, "launches_timed": nlaunch,
                          "alg_bytes_per_frame_layer": MSDA_BYTES_PER_FRAME_LAYER},
         }
