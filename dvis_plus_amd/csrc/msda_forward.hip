@@ -29,11 +29,20 @@
 #include <algorithm>
 
 #include "dvis_common.h"
+#include "msda_tap.h"
+
+int dvis_msda_l0lds_launch(const float *value, const int64_t *shapes, const int64_t *level_start, const float *ref, int nref,
+                           const float *offsets, int64_t off_stride, const float *logits, int64_t logit_stride, int N, int S,
+                           int M, int D, int L, int Lq, int P, float *out, const int64_t *shapes_host, hipStream_t st,
+                           bool *handled);
 
 namespace {
 
+using dvis_msda::kOOB;
+using dvis_msda::make_tap;
+using dvis_msda::Tap;
+
 constexpr int kQB = 64;        // queries per workgroup (tiled kernel)
-constexpr unsigned kOOB = 0x80000000u;  // buffer offset beyond every level slice (< 2 GiB, checked on host)
 
 constexpr int kMaxOrder = 640;   // chunks of 64 queries that an order table can describe (kernel-argument space)
 
@@ -45,38 +54,6 @@ struct QueryTiling {
   int use_order;      // 1: linear 64-query chunks, but issued in the order given below
   unsigned short order[kMaxOrder];   // chunk processed by block y (band-interleaved over the levels)
 };
-
-// Bilinear set-up of one sample for one lane: 4 corner byte offsets (kOOB when the corner is outside the map or
-// the sample is not counted) and the 4 corner weights.  Pure VALU, recomputed at consume time instead of being
-// kept live across the loads (registers are what limits loads in flight here).
-struct Tap {
-  unsigned o[4];
-  float c[4];
-};
-
-__device__ __forceinline__ Tap make_tap(float x, float y, int H, int W, bool active, unsigned pix_bytes,
-                                        unsigned lane_bytes) {
-  Tap t;
-  const float h_im = y * (float)H - 0.5f;
-  const float w_im = x * (float)W - 0.5f;
-  const bool ok = active && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
-  const float hf = floorf(h_im), wf = floorf(w_im);
-  const int h0 = (int)hf, w0 = (int)wf;
-  const float lh = h_im - hf, lw = w_im - wf;
-  const float hh = 1.f - lh, hw = 1.f - lw;
-  const bool h0ok = ok && h0 >= 0, h1ok = ok && h0 + 1 <= H - 1;
-  const bool w0ok = w0 >= 0, w1ok = w0 + 1 <= W - 1;
-  const unsigned o00 = (unsigned)(h0 * W + w0) * pix_bytes + lane_bytes;
-  t.o[0] = (h0ok && w0ok) ? o00 : kOOB;
-  t.o[1] = (h0ok && w1ok) ? o00 + pix_bytes : kOOB;
-  t.o[2] = (h1ok && w0ok) ? o00 + (unsigned)W * pix_bytes : kOOB;
-  t.o[3] = (h1ok && w1ok) ? o00 + (unsigned)W * pix_bytes + pix_bytes : kOOB;
-  t.c[0] = ok ? hh * hw : 0.f;
-  t.c[1] = ok ? hh * lw : 0.f;
-  t.c[2] = ok ? lh * hw : 0.f;
-  t.c[3] = ok ? lh * lw : 0.f;
-  return t;
-}
 
 template <int D, int L, int P, bool FUSED, int WPS, int B>
 __global__ __launch_bounds__(256, WPS) void msda_fwd_tile_f32(
@@ -497,8 +474,12 @@ DVIS_EXPORT int dvis_msda_fused_forward(const float *value, const int64_t *shape
   bool handled = false;
   DVIS_REQUIRE((size_t)Lq * (size_t)(off_stride > logit_stride ? off_stride : logit_stride) * sizeof(float) < 0x7fffffffu,
                "msda_fused_forward: one frame of offsets/logits must stay below 2 GiB");
-  int rc = dispatch_tile<true>(D, L, P, value, shapes, level_start, offsets, off_stride, logits, logit_stride, ref,
-                               Nref, N, S, M, Lq, out, (hipStream_t)stream, &handled, shapes_host);
+  // preferred: persistent kernel with the coarsest value map LDS-resident (msda_forward_lds.hip)
+  int rc = dvis_msda_l0lds_launch(value, shapes, level_start, ref, Nref, offsets, off_stride, logits, logit_stride, N, S, M,
+                                  D, L, Lq, P, out, shapes_host, (hipStream_t)stream, &handled);
+  if (handled) return rc;
+  rc = dispatch_tile<true>(D, L, P, value, shapes, level_start, offsets, off_stride, logits, logit_stride, ref,
+                           Nref, N, S, M, Lq, out, (hipStream_t)stream, &handled, shapes_host);
   if (handled) return rc;
   dvis_set_error("msda_fused_forward: unsupported (D=%d, L=%d, P=%d); supported D in {32,64}, (L,P) in {(1,4),(3,4),(4,4)}",
                  D, L, P);

@@ -219,3 +219,37 @@ def test_fused_forward_2d_query_tiling_is_only_a_schedule():
         c = msda_fused_forward(value, s.to(DEV), lsi.to(DEV), ref_pts[:, :100].contiguous(), proj[:2 * 100, :n_off],
                                proj[:2 * 100, n_off:], L, P, shapes_host=shapes)
         assert c.shape == (N, 100, M * D)
+
+
+def test_lds_resident_variant_is_bit_identical(monkeypatch):
+    """The experimental persistent kernel (coarsest map in LDS, DVIS_MSDA_L0LDS=1) must give the tiled kernel's bits.
+    The knob is read once per process, so run it in a subprocess."""
+    import subprocess
+    import sys
+    code = """
+import sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from conftest import level_tensors
+from dvis_plus_amd.functions import msda_fused_forward
+shapes = [(23, 40), (46, 80), (92, 160)]
+N, M, D, L, P = 2, 8, 32, 3, 4
+s, lsi = level_tensors(shapes)
+S = Lq = int(s.prod(1).sum())
+g = torch.Generator().manual_seed(5)
+value = torch.randn(N, S, M, D, generator=g).cuda()
+proj = (torch.randn(N * Lq, M * L * P * 3, generator=g) * 2).cuda()
+ref = torch.rand(1, Lq, L, 2, generator=g).cuda()
+n_off = M * L * P * 2
+out = msda_fused_forward(value, s.cuda(), lsi.cuda(), ref, proj[:, :n_off], proj[:, n_off:], L, P, shapes_host=shapes)
+torch.save(out.cpu(), sys.argv[1])
+"""
+    import os
+    import tempfile
+    from conftest import ROOT
+    outs = []
+    for knob in ("0", "1"):
+        with tempfile.NamedTemporaryFile(suffix=".pt") as f:
+            env = dict(os.environ, DVIS_MSDA_L0LDS=knob)
+            subprocess.check_call([sys.executable, "-c", code % (ROOT, os.path.join(ROOT, "tests")), f.name], env=env)
+            outs.append(torch.load(f.name))
+    assert torch.equal(outs[0], outs[1])
