@@ -11,6 +11,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import functions as Fn
+
 
 class FrozenBatchNorm2d(nn.Module):
     def __init__(self, num_features, eps=1e-5):
@@ -50,9 +52,10 @@ class ConvBN(nn.Conv2d):
             self._folded = (key, w, shift.detach().contiguous())
         return self._folded[1], self._folded[2]
 
-    def forward(self, x):
+    def forward(self, x, res=None, relu=False):
+        """conv (MIOpen, no bias) then ONE fused pass: + folded-BN shift (+ residual) (+ ReLU)."""
         w, b = self.folded()
-        return F.conv2d(x, w, b, self.stride, self.padding)
+        return Fn.bias_act_(F.conv2d(x, w, None, self.stride, self.padding), b, res, relu)
 
 
 class BasicStem(nn.Module):
@@ -61,7 +64,7 @@ class BasicStem(nn.Module):
         self.conv1 = ConvBN(in_channels, out_channels, 7, stride=2, padding=3)
 
     def forward(self, x):
-        return F.max_pool2d(F.relu_(self.conv1(x)), kernel_size=3, stride=2, padding=1)
+        return F.max_pool2d(self.conv1(x, relu=True), kernel_size=3, stride=2, padding=1)
 
 
 class BottleneckBlock(nn.Module):
@@ -73,11 +76,10 @@ class BottleneckBlock(nn.Module):
         self.conv3 = ConvBN(bottleneck, cout, 1)
 
     def forward(self, x):
-        out = F.relu_(self.conv1(x))
-        out = F.relu_(self.conv2(out))
-        out = self.conv3(out)
-        out += x if self.shortcut is None else self.shortcut(x)
-        return F.relu_(out)
+        out = self.conv1(x, relu=True)
+        out = self.conv2(out, relu=True)
+        shortcut = x if self.shortcut is None else self.shortcut(x)
+        return self.conv3(out, res=shortcut, relu=True)
 
 
 class ResNet(nn.Module):

@@ -47,3 +47,14 @@ class ClipShard:
         if self.world > 1:
             dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
         return x
+
+    def broadcast_from_rank0(self, tensors):
+        """Make small decision inputs (class logits) bit-identical on every rank.  Tracker + refiner are replicated and
+        deterministic, but library heuristics (MIOpen find) may pick different conv algorithms per rank; post-processing
+        takes keep/merge decisions and sizes a collective from these values, so they must agree exactly."""
+        if self.world > 1:
+            for t in tensors:
+                if t is not None:
+                    dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                                   group=self.group)
+        return tensors

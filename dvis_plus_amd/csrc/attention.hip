@@ -50,7 +50,7 @@ SplitPlan plan_split(int BH, int Lq, int Lk) {
   return p;
 }
 
-template <int DH>
+template <int DH, bool SHORT>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(
     const float *__restrict__ q, dvis_strides qs, const float *__restrict__ k, dvis_strides ks_, const float *__restrict__ v,
     dvis_strides vs, float *__restrict__ out, dvis_strides os, const uint8_t *__restrict__ mask,
@@ -59,10 +59,12 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(
   constexpr int DQ = DH / 4;        // dims per lane group
   constexpr int NT = DH / 16;       // output N tiles
   constexpr int LS = DH + 4;        // LDS row stride (floats): 16-B aligned, V rows of lane groups 0/1 split banks
-  // keys per LDS stage: 64 (d=32) / 32 (d=64) -> one float4 of K and of V per thread per stage
-  // (two per thread crashes hipcc 7.2's machine-copy-propagation pass on the d=64 instantiation)
-  constexpr int KT = DH == 64 ? 32 : 64;
-  constexpr int F4 = KT * DH / 4 / 512;   // float4 per thread per matrix per stage
+  // keys per LDS stage.  Long key sequences: 64 (d=32) / 32 (d=64) with a register prefetch of the next stage — one
+  // float4 of K and of V per thread per stage (two per thread crashes hipcc 7.2's machine-copy-propagation pass on the
+  // d=64 instantiation).  SHORT (Lk <= 128: tracker / refiner / decoder self-attention): ONE 128-key stage written
+  // straight to LDS, so the whole call pays a single global-load latency instead of one per 32-key stage.
+  constexpr int KT = SHORT ? 128 : (DH == 64 ? 32 : 64);
+  constexpr int F4 = SHORT ? 1 : KT * DH / 4 / 512;   // float4 per thread per matrix per stage (prefetch registers)
   __shared__ float k_lds[KT * LS];
   __shared__ float v_lds[KT * LS];
 
@@ -118,18 +120,32 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(
       }
     }
   };
-  prefetch(key_lo);
+  if (!SHORT) prefetch(key_lo);
   for (int ks = key_lo; ks < key_hi; ks += KT) {
     __syncthreads();
+    if (SHORT) {
+      for (int e = tid; e < KT * DH / 4; e += 512) {
+        const int row = e / (DH / 4), c4 = e - row * (DH / 4);
+        const int key = ks + row;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (key < key_hi) {
+          a = *reinterpret_cast<const float4 *>(kb + (size_t)key * ks_.r + 4 * c4);
+          b = *reinterpret_cast<const float4 *>(vb + (size_t)key * vs.r + 4 * c4);
+        }
+        *reinterpret_cast<float4 *>(&k_lds[row * LS + 4 * c4]) = a;
+        *reinterpret_cast<float4 *>(&v_lds[row * LS + 4 * c4]) = b;
+      }
+    } else {
 #pragma unroll
-    for (int i = 0; i < F4; ++i) {
-      const int e = tid + 512 * i;
-      const int row = e / (DH / 4), c4 = e - row * (DH / 4);
-      *reinterpret_cast<float4 *>(&k_lds[row * LS + 4 * c4]) = pk[i];
-      *reinterpret_cast<float4 *>(&v_lds[row * LS + 4 * c4]) = pv[i];
+      for (int i = 0; i < F4; ++i) {
+        const int e = tid + 512 * i;
+        const int row = e / (DH / 4), c4 = e - row * (DH / 4);
+        *reinterpret_cast<float4 *>(&k_lds[row * LS + 4 * c4]) = pk[i];
+        *reinterpret_cast<float4 *>(&v_lds[row * LS + 4 * c4]) = pv[i];
+      }
     }
     __syncthreads();
-    if (ks + KT < key_hi) prefetch(ks + KT);
+    if (!SHORT && ks + KT < key_hi) prefetch(ks + KT);
     if (!wave_on) continue;
 #pragma unroll 1
     for (int kt = 0; kt < KT / 16; ++kt) {
@@ -289,12 +305,15 @@ DVIS_EXPORT int dvis_attention_forward(const float *q, const int64_t *q_strides,
   float *ws_o = (float *)ws;
   float *ws_ml = ws_o ? ws_o + (size_t)BH * p.nsplit * Lq * d : nullptr;
   const dim3 grid(p.nsplit, BH, p.qchunks), block(512);
-  if (d == 32)
-    hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, block, 0, st, q, qs, k, ks, v, vs, out, os, mask, allowed_count, heads,
-                       Lq, Lk, scale, p.nsplit, p.keys_per_split, ws_o, ws_ml);
-  else
-    hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, block, 0, st, q, qs, k, ks, v, vs, out, os, mask, allowed_count, heads,
-                       Lq, Lk, scale, p.nsplit, p.keys_per_split, ws_o, ws_ml);
+#define DVIS_ATTN(DH_, SHORT_)                                                                                     \
+  hipLaunchKernelGGL((attn_fwd_kernel<DH_, SHORT_>), grid, block, 0, st, q, qs, k, ks, v, vs, out, os, mask, allowed_count, \
+                     heads, Lq, Lk, scale, p.nsplit, p.keys_per_split, ws_o, ws_ml)
+  const bool shrt = Lk <= 128 && p.nsplit == 1;
+  if (d == 32 && shrt) DVIS_ATTN(32, true);
+  else if (d == 32) DVIS_ATTN(32, false);
+  else if (shrt) DVIS_ATTN(64, true);
+  else DVIS_ATTN(64, false);
+#undef DVIS_ATTN
   int rc = dvis_check_launch("attn_fwd_kernel");
   if (rc != DVIS_OK || p.nsplit == 1) return rc;
   const size_t total = (size_t)BH * Lq * d;

@@ -7,7 +7,9 @@
 //   dvis_upsample_add    out = lateral + bilinear_upsample(top)        (FPN top-down step, msdeformattn.py:347;
 //                        F.interpolate(align_corners=False) to the lateral's size + add: 2 kernels and a 1.8 GB
 //                        intermediate per clip in torch).
-// Both are HBM-bound; float4 accesses, one wave per row (layernorm) / one thread per 4 output pixels (upsample).
+//   dvis_bias_act        x = act(x + bias[c] (+ residual)) in place on NCHW planes: the folded-FrozenBN bias, the bottleneck
+//                        shortcut add and the ReLU after a MIOpen convolution (3 torch kernels -> 1 pass).
+// All are HBM-bound; float4 accesses, one wave per row (layernorm) / one thread per 4 output pixels (upsample).
 #include <math.h>
 
 #include "dvis_common.h"
@@ -100,7 +102,46 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const float *__restri
   }
 }
 
+// x[(n*C + c)*HW + i] = relu?(x + bias[c] + res); grid.x = planes * chunks_per_plane
+__global__ __launch_bounds__(256) void bias_act_kernel(float *__restrict__ x, const float *__restrict__ bias,
+                                                       const float *__restrict__ res, int C, int HW4, int chunks,
+                                                       int relu) {
+  const unsigned plane = blockIdx.x / chunks;     // n * C + c
+  const int chunk = blockIdx.x - plane * chunks;
+  const float b = bias ? bias[plane % C] : 0.f;
+  float4 *xp = reinterpret_cast<float4 *>(x) + (size_t)plane * HW4;
+  const float4 *rp = res ? reinterpret_cast<const float4 *>(res) + (size_t)plane * HW4 : nullptr;
+  for (int i = chunk * 256 + threadIdx.x; i < HW4; i += chunks * 256) {
+    float4 v = xp[i];
+    v.x += b; v.y += b; v.z += b; v.w += b;
+    if (rp) {
+      const float4 r = rp[i];
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (relu) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    xp[i] = v;
+  }
+}
+
 }  // namespace
+
+DVIS_EXPORT int dvis_bias_act(float *x, const float *bias, const float *res, int64_t planes, int C, int64_t HW, int relu,
+                              void *stream) {
+  DVIS_REQUIRE(planes >= 0 && C > 0 && HW > 0, "bias_act: bad sizes");
+  if (planes == 0) return DVIS_OK;
+  DVIS_REQUIRE(x, "bias_act: null pointer");
+  DVIS_REQUIRE(HW % 4 == 0 && (((uintptr_t)x | (uintptr_t)res) & 15) == 0,
+               "bias_act: HW must be a multiple of 4 and x / res 16-byte aligned");
+  const int HW4 = (int)(HW / 4);
+  int chunks = (HW4 + 1023) / 1024;           // ~4 float4 per thread
+  if (chunks < 1) chunks = 1;
+  DVIS_REQUIRE(planes * chunks < (1ll << 31), "bias_act: too many planes");
+  hipLaunchKernelGGL(bias_act_kernel, dim3((unsigned)(planes * chunks)), dim3(256), 0, (hipStream_t)stream, x, bias, res, C,
+                     HW4, chunks, relu);
+  return dvis_check_launch("bias_act_kernel");
+}
 
 DVIS_EXPORT int dvis_add_layernorm(const float *x, const float *res, int64_t res_row_stride, const float *gamma,
                                    const float *beta, float *out, int64_t rows, int C, float eps, void *stream) {

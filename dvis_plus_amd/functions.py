@@ -293,3 +293,23 @@ def linear_relu(x, linear):
         y = torch._addmm_activation(linear.bias, x.reshape(-1, x.shape[-1]), linear.weight.t(), use_gelu=False)
         return y.view(*x.shape[:-1], -1)
     return torch.relu(linear(x))
+
+
+def bias_act_(x, bias=None, res=None, relu=True):
+    """In place: x = relu?(x + bias[c] + res) on an NCHW float32 tensor — one pass instead of torch's three kernels
+    (conv bias add, residual add, ReLU).  Non-GPU / odd shapes use the torch ops."""
+    N, C, H, W = x.shape
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and (H * W) % 4 == 0
+            and (res is None or (res.is_contiguous() and res.shape == x.shape and res.dtype == torch.float32))
+            and not torch.is_grad_enabled()):
+        if bias is not None:
+            x = x + bias.view(1, -1, 1, 1)
+        if res is not None:
+            x = x + res
+        return torch.relu_(x) if relu else x
+    with torch.cuda.device(x.device):
+        rc = native.lib().dvis_bias_act(native.dev_ptr(x, "x"), None if bias is None else native.dev_ptr(bias, "bias"),
+                                        None if res is None else native.dev_ptr(res, "res"), N * C, C, H * W,
+                                        1 if relu else 0, native.stream_ptr(x.device))
+    native.check(rc, "dvis_bias_act")
+    return x

@@ -33,7 +33,8 @@ class GraphRunner:
                     self.fn(*static_in)
             cur.wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: other threads (e.g. the RCCL watchdog) may keep querying events while we capture
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 static_out = self.fn(*static_in)
             entry = (graph, static_in, static_out)
             self._cache[key] = entry

@@ -153,6 +153,7 @@ class DVIS_Plus_offline(_VideoBase):
                              need_masks=False)
         ref = self.refiner(track["pred_embds"], to_bctq(embds_nn), None, need_masks=False)
         cls, aux = PP.mean_logits(ref["pred_logits"], track["pred_logits"])
+        cls, aux = self.clip_shard.broadcast_from_rank0([cls.contiguous(), aux.contiguous()])
         emb_local = ref["mask_embed"][:, lo:hi]                                     # (1, t_local, Q, Cm)
         mf = mask_features.unsqueeze(0)
 

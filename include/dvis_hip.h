@@ -23,6 +23,7 @@
  *                               ReferringCrossAttentionLayer (dvis_Plus/tracker.py:8-92), TemporalRefiner (dvis_Plus/refiner.py:104-139)
  *   dvis_add_layernorm       <- `norm(tgt + tgt2)` of every post-norm residual block (msdeformattn.py:125-131,
  *                               video_mask2former_transformer_decoder.py:47-50,108-111,166-170, tracker.py:51-53)
+ *   dvis_bias_act            <- FrozenBN shift + shortcut add + ReLU after each backbone convolution (detectron2 BottleneckBlock)
  *   dvis_upsample_add        <- `cur_fpn + F.interpolate(out[-1], size=..., mode="bilinear")`, msdeformattn.py:347
  *   dvis_vps_argmax          <- two-stage resize + sigmoid + score-weighted argmax + segment areas of inference_video_vps,
  *                               dvis_Plus/meta_architecture.py:890-925
@@ -141,6 +142,14 @@ int dvis_add_layernorm(const float *x, const float *res, int64_t res_row_stride,
  */
 int dvis_upsample_add(const float *lateral, const float *top, float *out, int64_t planes, int H, int W, int h, int w,
                       void *stream);
+
+/*
+ * In place on `planes` = N*C contiguous planes of HW floats (NCHW): x = relu?(x + bias[c] + res).  bias (C,) or NULL,
+ * res same shape as x or NULL.  The folded-FrozenBN bias, bottleneck shortcut add and ReLU after a library convolution
+ * in one pass.  HW % 4 == 0.
+ */
+int dvis_bias_act(float *x, const float *bias, const float *res, int64_t planes, int C, int64_t HW, int relu,
+                  void *stream);
 
 /*
  * Panoptic arg-max of a clip in one pass (inference_video_vps, dvis_Plus/meta_architecture.py:890-925):

@@ -56,3 +56,20 @@ def test_linear_relu_epilogue():
         ref = F.relu(lin(x))
         out = linear_relu(x.to(DEV), lin.to(DEV)).cpu()
     torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 64, 8, 12), (3, 256, 23, 40), (1, 7, 5, 4)])
+def test_bias_act_inplace(N, C, H, W):
+    from dvis_plus_amd.functions import bias_act_
+    g = torch.Generator().manual_seed(C)
+    x, r, b = torch.randn(N, C, H, W, generator=g), torch.randn(N, C, H, W, generator=g), torch.randn(C, generator=g)
+    for res, relu in ((None, True), (r, True), (r, False), (None, False)):
+        ref = x + b.view(1, -1, 1, 1)
+        if res is not None:
+            ref = ref + res
+        if relu:
+            ref = ref.relu()
+        xd = x.clone().to(DEV)
+        out = bias_act_(xd, b.to(DEV), None if res is None else res.to(DEV), relu)
+        assert out.data_ptr() == xd.data_ptr()
+        torch.testing.assert_close(out.cpu(), ref, rtol=1e-6, atol=1e-6)
