@@ -1,0 +1,125 @@
+"""Minimal yacs-style config for running without detectron2: yaml files with ``_BASE_`` inheritance, attribute access,
+``KEY VALUE`` overrides, and the defaults of the keys that size the hot path (what the reference adds through
+``add_maskformer2_config`` — mask2former/config.py:6-123 —, ``add_maskformer2_video_config`` —
+mask2former_video/config.py:6 — and ``add_minvis_config / add_dvis_config`` — dvis_Plus/config.py:12-78).
+Only keys read by ``dvis_plus_amd`` are defaulted; unknown keys in a yaml are kept as they are, so the reference's own
+config files (e.g. configs/dvis_Plus/VIPSeg/DVIS_Plus_Offline_R50.yaml and its _BASE_ chain) load unchanged.
+With detectron2 installed, its CfgNode works as well: every ``from_config`` here only uses attribute access.
+"""
+import copy
+import os
+
+import yaml
+
+
+class CfgNode(dict):
+    def __init__(self, d=None):
+        super().__init__()
+        for k, v in (d or {}).items():
+            self[k] = CfgNode(v) if isinstance(v, dict) else v
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k) from None
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def merge(self, other):
+        for k, v in other.items():
+            if isinstance(v, dict) and isinstance(self.get(k), dict):
+                self[k].merge(v)
+            else:
+                self[k] = CfgNode(v) if isinstance(v, dict) else copy.deepcopy(v)
+        return self
+
+    def merge_from_file(self, path):
+        return self.merge(load_yaml_with_base(path))
+
+    def merge_from_list(self, opts):
+        assert len(opts) % 2 == 0, "overrides come as KEY VALUE pairs"
+        for key, val in zip(opts[0::2], opts[1::2]):
+            node = self
+            parts = key.split(".")
+            for p in parts[:-1]:
+                node = node.setdefault(p, CfgNode())
+            node[parts[-1]] = yaml.safe_load(val) if isinstance(val, str) else val
+        return self
+
+
+def load_yaml_with_base(path):
+    with open(path) as f:
+        cfg = yaml.safe_load(f) or {}
+    base = cfg.pop("_BASE_", None)
+    if base is None:
+        return cfg
+    if not os.path.isabs(base):
+        base = os.path.join(os.path.dirname(path), base)
+    merged = CfgNode(load_yaml_with_base(base))
+    return merged.merge(cfg)
+
+
+def get_default_cfg():
+    """Defaults of the keys the hot path reads (values as in the reference's add_*_config functions)."""
+    return CfgNode({
+        "MODEL": {
+            "META_ARCHITECTURE": "DVIS_Plus_offline",
+            "PIXEL_MEAN": [123.675, 116.280, 103.530],
+            "PIXEL_STD": [58.395, 57.120, 57.375],
+            "SEM_SEG_HEAD": {
+                "NAME": "MaskFormerHead", "IN_FEATURES": ["res2", "res3", "res4", "res5"], "NUM_CLASSES": 124,
+                "CONVS_DIM": 256, "MASK_DIM": 256, "NORM": "GN", "COMMON_STRIDE": 4,
+                "PIXEL_DECODER_NAME": "MSDeformAttnPixelDecoder", "TRANSFORMER_ENC_LAYERS": 6,
+                "DEFORMABLE_TRANSFORMER_ENCODER_IN_FEATURES": ["res3", "res4", "res5"],
+            },
+            "MASK_FORMER": {
+                "TRANSFORMER_DECODER_NAME": "VideoMultiScaleMaskedTransformerDecoder_dvisPlus",
+                "TRANSFORMER_IN_FEATURE": "multi_scale_pixel_decoder", "HIDDEN_DIM": 256, "NHEADS": 8,
+                "DIM_FEEDFORWARD": 2048, "DEC_LAYERS": 10, "PRE_NORM": False, "ENFORCE_INPUT_PROJ": False,
+                "NUM_OBJECT_QUERIES": 100, "DROPOUT": 0.0, "SIZE_DIVISIBILITY": 32, "REID_BRANCH": True,
+                "REID_HIDDEN_DIM": 256, "NUM_REID_HEAD_LAYERS": 3,
+                "TEST": {"OBJECT_MASK_THRESHOLD": 0.8, "OVERLAP_THRESHOLD": 0.8, "WINDOW_INFERENCE": True,
+                         "WINDOW_SIZE": 3, "TASK": "vis", "MAX_NUM": 20},
+            },
+            "TRACKER": {"DECODER_LAYERS": 6, "NOISE_MODE": "none", "NOISE_RATIO": 0.5},
+            "REFINER": {"DECODER_LAYERS": 6},
+        },
+        "INPUT": {"SAMPLING_FRAME_NUM": 1},
+    })
+
+
+def build_model(cfg, n_things=0):
+    """cfg -> DVIS_Plus_{online,offline} with an R50 backbone, resolved through the registries by the yaml names
+    (MODEL.META_ARCHITECTURE / SEM_SEG_HEAD.PIXEL_DECODER_NAME / MASK_FORMER.TRANSFORMER_DECODER_NAME), like
+    detectron2's build_model does for the reference."""
+    from . import meta_architecture as MA
+    from .backbone import build_resnet50
+    from .pixel_decoder import r50_input_shape
+    from .refiner import TemporalRefiner
+    from .registry import META_ARCH_REGISTRY, SEM_SEG_HEADS_REGISTRY, TRANSFORMER_DECODER_REGISTRY
+    from .tracker import ReferringTracker_noiser
+    mf, hd = cfg.MODEL.MASK_FORMER, cfg.MODEL.SEM_SEG_HEAD
+    pd_cls = SEM_SEG_HEADS_REGISTRY.get(hd.PIXEL_DECODER_NAME)
+    pixel_decoder = pd_cls(**pd_cls.from_config(cfg, r50_input_shape()))
+    dec_cls = TRANSFORMER_DECODER_REGISTRY.get(mf.TRANSFORMER_DECODER_NAME)
+    predictor = dec_cls(**dec_cls.from_config(cfg, hd.CONVS_DIM, True))
+    head = SEM_SEG_HEADS_REGISTRY.get(hd.NAME)(num_classes=hd.NUM_CLASSES, pixel_decoder=pixel_decoder,
+                                               transformer_predictor=predictor)
+    hidden = mf.HIDDEN_DIM * (2 if mf.get("REID_BRANCH", True) else 1)       # meta_architecture.py:550-551
+    tracker = ReferringTracker_noiser(hidden_channel=hidden, feedforward_channel=mf.DIM_FEEDFORWARD,
+                                      num_head=mf.NHEADS, decoder_layer_num=cfg.MODEL.TRACKER.DECODER_LAYERS,
+                                      noise_mode=cfg.MODEL.TRACKER.NOISE_MODE, mask_dim=hd.MASK_DIM,
+                                      class_num=hd.NUM_CLASSES)
+    kw = dict(backbone=build_resnet50(), sem_seg_head=head, num_queries=mf.NUM_OBJECT_QUERIES,
+              object_mask_threshold=mf.TEST.OBJECT_MASK_THRESHOLD, overlap_threshold=mf.TEST.OVERLAP_THRESHOLD,
+              n_things=n_things, size_divisibility=mf.SIZE_DIVISIBILITY, pixel_mean=cfg.MODEL.PIXEL_MEAN,
+              pixel_std=cfg.MODEL.PIXEL_STD, tracker=tracker, task=mf.TEST.TASK, max_num=mf.TEST.MAX_NUM,
+              window_size=mf.TEST.WINDOW_SIZE)
+    arch = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)
+    if arch is MA.DVIS_Plus_offline:
+        kw["refiner"] = TemporalRefiner(hidden_channel=hidden, feedforward_channel=mf.DIM_FEEDFORWARD,
+                                        num_head=mf.NHEADS, decoder_layer_num=cfg.MODEL.REFINER.DECODER_LAYERS,
+                                        mask_dim=hd.MASK_DIM, class_num=hd.NUM_CLASSES, windows=mf.TEST.WINDOW_SIZE)
+    return arch(**kw).eval()

@@ -70,6 +70,7 @@ def test_bias_act_inplace(N, C, H, W):
         if relu:
             ref = ref.relu()
         xd = x.clone().to(DEV)
-        out = bias_act_(xd, b.to(DEV), None if res is None else res.to(DEV), relu)
+        with torch.no_grad():
+            out = bias_act_(xd, b.to(DEV), None if res is None else res.to(DEV), relu)
         assert out.data_ptr() == xd.data_ptr()
         torch.testing.assert_close(out.cpu(), ref, rtol=1e-6, atol=1e-6)
