@@ -287,12 +287,22 @@ def upsample_add(lateral, top):
     return out
 
 
-def linear_relu(x, linear):
-    """relu(linear(x)) with the bias + ReLU epilogue inside the GEMM (hipBLASLt through torch._addmm_activation)."""
-    if x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled():
-        y = torch._addmm_activation(linear.bias, x.reshape(-1, x.shape[-1]), linear.weight.t(), use_gelu=False)
-        return y.view(*x.shape[:-1], -1)
-    return torch.relu(linear(x))
+def linear(x, weight, bias=None, relu=False):
+    """``F.linear`` (+ optional ReLU) on the library GEMM; with a bias the ReLU runs as the GEMM's epilogue (hipBLASLt
+    via torch._addmm_activation) instead of a second pass.  (A hand-written latency-optimised MFMA kernel for the
+    tracker's 100-row GEMMs was measured and dropped: 5.8-22 us vs the library's 6.0-7.6 us — it is L2-bandwidth
+    bound without the library's macro-tile reuse.)"""
+    if relu and bias is not None and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled():
+        K = x.shape[-1]
+        y = torch._addmm_activation(bias, x.reshape(-1, K), weight.t(), use_gelu=False)
+        return y.view(*x.shape[:-1], weight.shape[0])
+    y = torch.nn.functional.linear(x, weight, bias)
+    return torch.relu(y) if relu else y
+
+
+def linear_relu(x, lin):
+    """relu(lin(x)) for an ``nn.Linear``."""
+    return linear(x, lin.weight, lin.bias, relu=True)
 
 
 def bias_act_(x, bias=None, res=None, relu=True):

@@ -43,9 +43,10 @@ class ReferringCrossAttentionLayer(nn.Module):
 
     def attend(self, indentify, tgt, k_proj, v_proj):
         C = tgt.shape[-1]
-        q = F.linear(tgt, self.multihead_attn.in_proj_weight[:C], self.multihead_attn.in_proj_bias[:C])
+        q = Fn.linear(tgt, self.multihead_attn.in_proj_weight[:C], self.multihead_attn.in_proj_bias[:C])
         att = Fn.attention(q, k_proj, v_proj, self.nhead)
-        return Fn.add_layer_norm(self.multihead_attn.out_proj(att), indentify, self.norm)
+        op = self.multihead_attn.out_proj
+        return Fn.add_layer_norm(Fn.linear(att, op.weight, op.bias), indentify, self.norm)
 
     def forward(self, indentify, tgt, key, memory, memory_mask=None, memory_key_padding_mask=None, pos=None,
                 query_pos=None):

@@ -48,14 +48,14 @@ class SelfAttentionLayer(nn.Module):
         C = tgt.shape[-1]
         W, b = self.self_attn.in_proj_weight, self.self_attn.in_proj_bias
         if query_pos is None:
-            qkv = F.linear(tgt, W, b)
+            qkv = Fn.linear(tgt, W, b)
             q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
         else:
-            qk = F.linear(tgt + query_pos, W[:2 * C], b[:2 * C])
+            qk = Fn.linear(tgt + query_pos, W[:2 * C], b[:2 * C])
             q, k = qk[..., :C], qk[..., C:]
-            v = F.linear(tgt, W[2 * C:], b[2 * C:])
+            v = Fn.linear(tgt, W[2 * C:], b[2 * C:])
         att = Fn.attention(q, k, v, self.nhead)
-        return Fn.add_layer_norm(self.self_attn.out_proj(att), tgt, self.norm)
+        return Fn.add_layer_norm(Fn.linear(att, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias), tgt, self.norm)
 
 
 class CrossAttentionLayer(nn.Module):
@@ -70,7 +70,7 @@ class CrossAttentionLayer(nn.Module):
 
     def project_q(self, x):
         C = x.shape[-1]
-        return F.linear(x, self.multihead_attn.in_proj_weight[:C], self.multihead_attn.in_proj_bias[:C])
+        return Fn.linear(x, self.multihead_attn.in_proj_weight[:C], self.multihead_attn.in_proj_bias[:C])
 
     def kv_weights(self):
         C = self.multihead_attn.embed_dim
@@ -81,7 +81,8 @@ class CrossAttentionLayer(nn.Module):
         """k_proj / v_proj are already projected (Lk, B, C) views."""
         att = Fn.attention(self.project_q(q_in), k_proj, v_proj, self.nhead, mask, allowed)
         res = tgt if identity is None else identity
-        return Fn.add_layer_norm(self.multihead_attn.out_proj(att), res, self.norm)
+        op = self.multihead_attn.out_proj
+        return Fn.add_layer_norm(Fn.linear(att, op.weight, op.bias), res, self.norm)
 
     def forward(self, tgt, memory, memory_mask=None, memory_key_padding_mask=None, pos=None, query_pos=None):
         assert memory_key_padding_mask is None
@@ -103,7 +104,8 @@ class FFNLayer(nn.Module):
         _xavier_(self)
 
     def forward(self, tgt):
-        return Fn.add_layer_norm(self.linear2(Fn.linear_relu(tgt, self.linear1)), tgt, self.norm)
+        h = Fn.linear_relu(tgt, self.linear1)
+        return Fn.add_layer_norm(Fn.linear(h, self.linear2.weight, self.linear2.bias), tgt, self.norm)
 
 
 class MLP(nn.Module):
@@ -115,7 +117,7 @@ class MLP(nn.Module):
 
     def forward(self, x):
         for i, layer in enumerate(self.layers):
-            x = Fn.linear_relu(x, layer) if i < self.num_layers - 1 else layer(x)
+            x = Fn.linear(x, layer.weight, layer.bias, relu=i < self.num_layers - 1)
         return x
 
 
