@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=30)
     ap.add_argument("--task", default="vps")
+    ap.add_argument("--mode", default="offline", choices=["offline", "online"],
+                    help="offline = BASELINE headline config (T=30, refiner on); online = config #2 (use --frames 5)")
     ap.add_argument("--candidates", type=int, default=20, help="queries sent to the panoptic stage (see main)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -111,11 +113,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # DVIS_BENCH_ONE_DEVICE=1 + DVIS_DIST_BACKEND=gloo: development aid to exercise the sharded pipeline with several
+    # ranks on a single-GPU box (all ranks on cuda:0, collectives through gloo).  Never used for reported numbers.
+    one_device = os.environ.get("DVIS_BENCH_ONE_DEVICE") == "1"
+    dev_index = 0 if one_device else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=device)     # RCCL over xGMI
+        backend = os.environ.get("DVIS_DIST_BACKEND", "nccl")               # "nccl" = RCCL over xGMI
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=device)
+        else:
+            torch.distributed.init_process_group(backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from dvis_plus_amd.meta_architecture import build_dvis_plus_r50
@@ -123,7 +133,7 @@ def main():
     # keep no query and post-processing would be skipped; the threshold is calibrated below so that --candidates
     # (20) queries reach the panoptic stage (representative work).  Everything else follows
     # VIPSeg/DVIS_Plus_Offline_R50.yaml.
-    model = build_dvis_plus_r50("offline", task=args.task, object_mask_threshold=0.0).to(device)
+    model = build_dvis_plus_r50(args.mode, task=args.task, object_mask_threshold=0.0).to(device)
     T = args.frames
     clip = synthetic_clip(T, device)
     inputs = [{"image": clip, "height": 720, "width": 1280}]
@@ -167,6 +177,8 @@ def main():
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = tt.item()
+        ncand = torch.tensor([float(out.get("num_candidates") or 0)], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(ncand, op=torch.distributed.ReduceOp.MAX)
 
     if rank == 0:
         fps = T * args.steps / dt
@@ -178,11 +190,12 @@ def main():
             t = json.load(open(tj))
             traffic = round(t["hbm_bytes_per_launch"] * nfr / t["frames_per_launch"])
         res = {
-            "metric": "frames/sec DVIS++ R50 offline, 720p T=30 synthetic", "value": round(fps, 3), "unit": "frames/s",
+            "metric": f"frames/sec DVIS++ R50 {args.mode}, 720p T={T} synthetic", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"DVIS++ offline R50, T={T} 720p synthetic clip (padded 736x1280), 100 queries, "
-                                   f"temporal refiner on, task={args.task}, frames sharded {world}-way",
+            "config": {"workload": f"DVIS++ {args.mode} R50, T={T} 720p synthetic clip (padded 736x1280), 100 queries, "
+                                   f"temporal refiner {'on' if args.mode == 'offline' else 'off'}, task={args.task}, "
+                                   f"frames sharded {world}-way",
                        "panoptic_candidates": out.get("num_candidates"), "segments": len(out.get("segments_infos", []))},
             "roofline": {"bound": "hbm", "kernel": "msda_fwd_tile_f32 (fused MSDeformAttn forward)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

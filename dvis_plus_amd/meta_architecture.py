@@ -198,3 +198,143 @@ def build_dvis_plus_r50(mode="offline", *, num_classes=124, num_queries=100, n_t
     refiner = TemporalRefiner(hidden_channel=2 * hidden_dim, feedforward_channel=dim_feedforward, num_head=nheads,
                               decoder_layer_num=refiner_layers, mask_dim=hidden_dim, class_num=num_classes, windows=3)
     return DVIS_Plus_offline(refiner=refiner, **kw).eval()
+
+
+@META_ARCH_REGISTRY.register()
+class MaskFormer(nn.Module):
+    """Image Mask2Former (BASELINE config #1) — inference half of mask2former/maskformer_model.py:167-380.
+    ``forward([{"image": (3,H,W), "height", "width"}, ...])`` -> list of dicts with "sem_seg" (K,H,W),
+    "panoptic_seg" (map int32, segments_info) and/or "instances" ({"pred_masks","scores","pred_classes"})."""
+
+    def __init__(self, *, backbone, sem_seg_head, num_queries, object_mask_threshold=0.8, overlap_threshold=0.8,
+                 thing_ids=(), size_divisibility=32, sem_seg_postprocess_before_inference=True,
+                 pixel_mean=(123.675, 116.280, 103.530), pixel_std=(58.395, 57.120, 57.375), semantic_on=True,
+                 panoptic_on=False, instance_on=False, test_topk_per_image=100):
+        super().__init__()
+        self.backbone, self.sem_seg_head, self.num_queries = backbone, sem_seg_head, num_queries
+        self.object_mask_threshold, self.overlap_threshold = object_mask_threshold, overlap_threshold
+        self.thing_ids = set(int(t) for t in thing_ids)
+        self.size_divisibility = size_divisibility
+        self.sem_seg_postprocess_before_inference = sem_seg_postprocess_before_inference
+        self.register_buffer("pixel_mean", torch.tensor(pixel_mean, dtype=torch.float32).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.tensor(pixel_std, dtype=torch.float32).view(-1, 1, 1), False)
+        self.semantic_on, self.panoptic_on, self.instance_on = semantic_on, panoptic_on, instance_on
+        self.test_topk_per_image = test_topk_per_image
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    @staticmethod
+    def sem_seg_postprocess(result, img_size, output_height, output_width):
+        """detectron2.modeling.postprocessing.sem_seg_postprocess (un-vendored): crop the padding, resize."""
+        result = result[:, :img_size[0], :img_size[1]].expand(1, -1, -1, -1)
+        return torch.nn.functional.interpolate(result, size=(output_height, output_width), mode="bilinear",
+                                               align_corners=False)[0]
+
+    def semantic_inference(self, mask_cls, mask_pred):
+        mask_cls = torch.softmax(mask_cls, dim=-1)[..., :-1]
+        return torch.einsum("qc,qhw->chw", mask_cls, mask_pred.sigmoid())
+
+    def panoptic_inference(self, mask_cls, mask_pred):
+        scores, labels = torch.softmax(mask_cls, dim=-1).max(-1)
+        mask_pred = mask_pred.sigmoid()
+        keep = labels.ne(self.sem_seg_head.num_classes) & (scores > self.object_mask_threshold)
+        cur_scores, cur_classes, cur_masks = scores[keep], labels[keep], mask_pred[keep]
+        h, w = cur_masks.shape[-2:]
+        panoptic_seg = torch.zeros((h, w), dtype=torch.int32, device=cur_masks.device)
+        segments_info = []
+        if cur_masks.shape[0] == 0:
+            return panoptic_seg, segments_info
+        cur_mask_ids = (cur_scores.view(-1, 1, 1) * cur_masks).argmax(0)
+        K = cur_classes.shape[0]
+        conf = cur_masks.gather(0, cur_mask_ids[None])[0] >= 0.5
+        flat = cur_mask_ids.flatten()
+        stats = torch.stack([torch.bincount(flat, minlength=K).double(), (cur_masks >= 0.5).flatten(1).sum(1).double(),
+                             torch.bincount(flat, weights=conf.flatten().float(), minlength=K).double(),
+                             cur_classes.double()]).cpu()                    # one device->host copy
+        lut = torch.zeros(K, dtype=torch.int32)
+        seg_id, stuff = 0, {}
+        for k in range(K):
+            area, orig, inter, cls_k = int(stats[0, k]), int(stats[1, k]), int(stats[2, k]), int(stats[3, k])
+            isthing = cls_k in self.thing_ids
+            if area > 0 and orig > 0 and inter > 0:
+                if area / orig < self.overlap_threshold:
+                    continue
+                if not isthing:
+                    if cls_k in stuff:
+                        lut[k] = stuff[cls_k]
+                        continue
+                    stuff[cls_k] = seg_id + 1
+                seg_id += 1
+                lut[k] = seg_id
+                segments_info.append({"id": seg_id, "isthing": bool(isthing), "category_id": cls_k})
+        panoptic_seg = torch.where(conf, lut.to(conf.device)[cur_mask_ids], panoptic_seg)
+        return panoptic_seg, segments_info
+
+    def instance_inference(self, mask_cls, mask_pred):
+        K = self.sem_seg_head.num_classes
+        scores = torch.softmax(mask_cls, dim=-1)[:, :-1]
+        labels = torch.arange(K, device=mask_cls.device).unsqueeze(0).repeat(self.num_queries, 1).flatten(0, 1)
+        scores_per_image, topk = scores.flatten(0, 1).topk(self.test_topk_per_image, sorted=False)
+        labels_per_image = labels[topk]
+        mask_pred = mask_pred[topk // K]
+        if self.panoptic_on:
+            keep = torch.tensor([int(l) in self.thing_ids for l in labels_per_image.tolist()], dtype=torch.bool,
+                                device=mask_pred.device)
+            scores_per_image, labels_per_image, mask_pred = scores_per_image[keep], labels_per_image[keep], mask_pred[keep]
+        pred_masks = (mask_pred > 0).float()
+        mask_scores = (mask_pred.sigmoid().flatten(1) * pred_masks.flatten(1)).sum(1) / (pred_masks.flatten(1).sum(1) + 1e-6)
+        return {"pred_masks": pred_masks, "scores": scores_per_image * mask_scores, "pred_classes": labels_per_image}
+
+    @torch.no_grad()
+    def forward(self, batched_inputs):
+        assert not self.training, "dvis_plus_amd implements the inference path"
+        sizes = [tuple(x["image"].shape[-2:]) for x in batched_inputs]
+        d = self.size_divisibility
+        Hm, Wm = max(s[0] for s in sizes), max(s[1] for s in sizes)
+        Hp, Wp = ((Hm + d - 1) // d * d, (Wm + d - 1) // d * d) if d > 1 else (Hm, Wm)
+        batch = torch.zeros((len(sizes), 3, Hp, Wp), dtype=torch.float32, device=self.device)
+        for i, x in enumerate(batched_inputs):
+            img = (x["image"].to(self.device, torch.float32) - self.pixel_mean) / self.pixel_std
+            batch[i, :, :sizes[i][0], :sizes[i][1]] = img
+        outputs = self.sem_seg_head(self.backbone(batch))
+        mask_cls_results = outputs["pred_logits"]
+        mask_pred_results = torch.nn.functional.interpolate(outputs["pred_masks"], size=(Hp, Wp), mode="bilinear",
+                                                            align_corners=False)
+        results = []
+        for mask_cls, mask_pred, inp, image_size in zip(mask_cls_results, mask_pred_results, batched_inputs, sizes):
+            height, width = inp.get("height", image_size[0]), inp.get("width", image_size[1])
+            r = {}
+            if self.sem_seg_postprocess_before_inference:
+                mask_pred = self.sem_seg_postprocess(mask_pred, image_size, height, width)
+            if self.semantic_on:
+                sem = self.semantic_inference(mask_cls, mask_pred)
+                if not self.sem_seg_postprocess_before_inference:
+                    sem = self.sem_seg_postprocess(sem, image_size, height, width)
+                r["sem_seg"] = sem
+            if self.panoptic_on:
+                r["panoptic_seg"] = self.panoptic_inference(mask_cls, mask_pred)
+            if self.instance_on:
+                r["instances"] = self.instance_inference(mask_cls, mask_pred)
+            results.append(r)
+        return results
+
+
+def build_mask2former_r50(*, num_classes=133, num_queries=100, hidden_dim=256, nheads=8, dim_feedforward=2048,
+                          dec_layers=10, enc_layers=6, seed=0, **kw):
+    """Image Mask2Former R50 (BASELINE config #1 sizes) with deterministic random weights."""
+    from .backbone import build_resnet50
+    from .pixel_decoder import MSDeformAttnPixelDecoder, r50_input_shape
+    from .transformer_decoder import MultiScaleMaskedTransformerDecoder
+    torch.manual_seed(seed)
+    pixel_decoder = MSDeformAttnPixelDecoder(
+        r50_input_shape(), transformer_dropout=0.0, transformer_nheads=nheads, transformer_dim_feedforward=1024,
+        transformer_enc_layers=enc_layers, conv_dim=hidden_dim, mask_dim=hidden_dim, norm="GN",
+        transformer_in_features=["res3", "res4", "res5"], common_stride=4)
+    predictor = MultiScaleMaskedTransformerDecoder(
+        hidden_dim, True, num_classes=num_classes, hidden_dim=hidden_dim, num_queries=num_queries, nheads=nheads,
+        dim_feedforward=dim_feedforward, dec_layers=dec_layers - 1, pre_norm=False, mask_dim=hidden_dim,
+        enforce_input_project=False)
+    head = MaskFormerHead(num_classes=num_classes, pixel_decoder=pixel_decoder, transformer_predictor=predictor)
+    return MaskFormer(backbone=build_resnet50(), sem_seg_head=head, num_queries=num_queries, **kw).eval()

@@ -467,3 +467,22 @@ def dvis_plus_forward(sd, backbone, frames, *, offline=True, nheads=8, enc_layer
         return inference_video_vps(cls, masks, img_size, out_hw, first, num_classes, n_things,
                                    object_mask_threshold, overlap_threshold, aux)
     return inference_video_vss(cls, masks, img_size, out_hw, first, aux)
+
+
+# ----------------------------------------------------------------------------- image Mask2Former (BASELINE config #1)
+def maskformer_image_forward(sd, backbone, image, *, nheads=8, enc_layers=6, dec_layers=9, num_classes=133,
+                             out_hw=None):
+    """MaskFormer.forward eval (mask2former/maskformer_model.py:194-262) for one image with semantic inference
+    (:280-284): backbone -> pixel decoder -> image decoder -> upsample to the padded size -> crop + resize
+    (sem_seg_postprocess, un-vendored detectron2: "parity unpinned") -> einsum(softmax(cls)[:-1], sigmoid(mask)).
+    Returns (sem_seg (K,H,W), pred_logits, pred_masks at stride 4)."""
+    images, img_size = preprocess([image], sd["pixel_mean"].flatten(), sd["pixel_std"].flatten())
+    feats = backbone(images)
+    mf, _, ms = pixel_decoder_forward(_sub(sd, "sem_seg_head.pixel_decoder."), feats, nheads, enc_layers)
+    out = decoder_forward(_sub(sd, "sem_seg_head.predictor."), ms, mf, nheads, dec_layers, dvis_plus=False)
+    masks = F.interpolate(out["pred_masks"], size=tuple(images.shape[-2:]), mode="bilinear", align_corners=False)[0]
+    out_hw = img_size if out_hw is None else out_hw
+    masks = F.interpolate(masks[:, :img_size[0], :img_size[1]][None], size=tuple(out_hw), mode="bilinear",
+                          align_corners=False)[0]
+    cls = F.softmax(out["pred_logits"][0], dim=-1)[..., :-1]
+    return torch.einsum("qc,qhw->chw", cls, masks.sigmoid()), out["pred_logits"], out["pred_masks"]

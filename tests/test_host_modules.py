@@ -279,3 +279,24 @@ def test_clip_sharding_world_size_2_gloo(oracle_ops, tmp_path):
     for p in parts:
         assert p["segs"] == single["segments_infos"] and p["ids"] == single["pred_ids"]
     assert len(single["segments_infos"]) > 0
+
+
+def test_image_maskformer_config1_plumbing(oracle_ops):
+    """BASELINE config #1: image Mask2Former through the op's torch formulation on the CPU (plumbing check)."""
+    from dvis_plus_amd.meta_architecture import build_mask2former_r50
+    from oracle import dvis_torch as O
+    m = build_mask2former_r50(num_classes=9, num_queries=7, hidden_dim=64, nheads=2, dim_feedforward=64, dec_layers=3,
+                              enc_layers=1, semantic_on=True, panoptic_on=True, instance_on=True, thing_ids=(0, 1, 2),
+                              object_mask_threshold=0.05, test_topk_per_image=5)
+    img = torch.randint(0, 256, (3, 60, 90), dtype=torch.uint8, generator=torch.Generator().manual_seed(0))
+    out = m([{"image": img, "height": 48, "width": 72}])[0]
+    sd = dict(m.state_dict())
+    sd["pixel_mean"], sd["pixel_std"] = m.pixel_mean, m.pixel_std
+    with torch.no_grad():
+        sem, logits, masks = O.maskformer_image_forward(sd, m.backbone, img, nheads=2, enc_layers=1, dec_layers=2,
+                                                        num_classes=9, out_hw=(48, 72))
+    torch.testing.assert_close(out["sem_seg"], sem, rtol=1e-5, atol=1e-6)
+    pan, segs = out["panoptic_seg"]
+    assert pan.shape == (48, 72) and pan.dtype == torch.int32 and int(pan.max()) == len(segs)
+    inst = out["instances"]
+    assert inst["pred_masks"].shape[1:] == (48, 72) and inst["scores"].shape == inst["pred_classes"].shape

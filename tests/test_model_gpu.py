@@ -132,3 +132,24 @@ def test_offline_pipeline_gpu_vs_oracle(task):
         assert torch.equal(key_ref[o_ref], key_out[o_out])                       # same (query, class) pairs
         torch.testing.assert_close(out["pred_scores"].cpu()[o_out], scores[o_ref], rtol=1e-3, atol=1e-4)
         assert (out["pred_masks"].cpu()[o_out] == masks[o_ref]).float().mean().item() > 0.999
+
+
+def test_image_mask2former_gpu_vs_oracle():
+    """BASELINE config #1 on the GPU: image Mask2Former semantic output vs the CPU oracle (from backbone outputs on)."""
+    from dvis_plus_amd.meta_architecture import build_mask2former_r50
+    from oracle import dvis_torch as O
+    m = build_mask2former_r50(num_classes=19, num_queries=100, enc_layers=2, dec_layers=4, semantic_on=True)
+    _perturb_msda(m.sem_seg_head.pixel_decoder)
+    img = torch.randint(0, 256, (3, 120, 160), dtype=torch.uint8, generator=torch.Generator().manual_seed(5))
+    sd = _cpu_sd(m)
+    sd["pixel_mean"], sd["pixel_std"] = m.pixel_mean.clone(), m.pixel_std.clone()
+    m = m.to(DEV)
+    out = m([{"image": img.to(DEV), "height": 120, "width": 160}])[0]
+
+    def backbone_from_gpu(images_cpu):
+        with torch.no_grad():
+            return {k: v.cpu() for k, v in m.backbone(images_cpu.to(DEV)).items()}
+    with torch.no_grad():
+        sem, _, _ = O.maskformer_image_forward(sd, backbone_from_gpu, img, nheads=8, enc_layers=2, dec_layers=3,
+                                               num_classes=19)
+    torch.testing.assert_close(out["sem_seg"].cpu(), sem, rtol=1e-3, atol=1e-3)
