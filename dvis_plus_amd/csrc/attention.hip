@@ -250,6 +250,172 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(
   }
 }
 
+// Latency kernel for short key sequences with few (batch, head) pairs — the tracker's 100x100 attentions at batch 1,
+// which are strictly sequential, so latency is what counts.  With the mapping above one (batch, head) sits on ONE CU and
+// its 7 query tiles x 224 fp32 MFMAs (32 clk each) take ~6 us of pure MFMA issue; only 8 CUs are busy.  Here a workgroup is one 16-query tile of one head and its 4 waves (one per SIMD) split
+// the key tiles; all keys are resident in LDS, so there is no online softmax: each wave does S^T for its tiles, one
+// max / exp / sum pass, P V, and the four partial (m, l, O) are merged once through LDS.
+template <int DH>
+__global__ __launch_bounds__(256) void attn_short_kernel(
+    const float *__restrict__ q, dvis_strides qs, const float *__restrict__ k, dvis_strides ks_, const float *__restrict__ v,
+    dvis_strides vs, float *__restrict__ out, dvis_strides os, const uint8_t *__restrict__ mask,
+    const int *__restrict__ allowed, int heads, int Lq, int Lk, float scale) {
+  constexpr int DQ = DH / 4, NT = DH / 16, LS = DH + 4, NKT = 2;   // Lk <= 128: at most 2 key tiles per wave
+  // dynamic LDS sized to the padded key count (a 30-key refiner call should not pin 69 KB and halve the occupancy):
+  // [K rows | V rows | (m, l) merge]; the K region is at least 4*16*DH floats because it is reused for the O merge.
+  extern __shared__ float short_lds[];
+  const int nrows = (Lk + 15) / 16 * 16;
+  const int kregion = max(nrows * LS, 64 * DH);
+  float *k_lds = short_lds;
+  float *v_lds = short_lds + kregion;
+  float *ml_lds = v_lds + nrows * LS;
+  float *o_lds = k_lds;                  // K is dead once every wave has its S tiles
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y;
+  const int bi = bh / heads, hi = bh - bi * heads;
+  const int q0 = blockIdx.x * 16;
+  const int myq = q0 + j;
+  const bool q_ok = myq < Lq;
+
+  float qf[DQ];
+  {
+    const float *qrow = q + (size_t)bi * qs.b + (size_t)hi * qs.h + (size_t)(q_ok ? myq : 0) * qs.r + g * DQ;
+#pragma unroll
+    for (int c = 0; c < DQ / 4; ++c) {
+      const float4 t = *reinterpret_cast<const float4 *>(qrow + 4 * c);
+      qf[4 * c] = q_ok ? t.x * scale : 0.f;
+      qf[4 * c + 1] = q_ok ? t.y * scale : 0.f;
+      qf[4 * c + 2] = q_ok ? t.z * scale : 0.f;
+      qf[4 * c + 3] = q_ok ? t.w * scale : 0.f;
+    }
+  }
+  const float *kb = k + (size_t)bi * ks_.b + (size_t)hi * ks_.h;
+  const float *vb = v + (size_t)bi * vs.b + (size_t)hi * vs.h;
+  for (int e = tid; e < nrows * (DH / 4); e += 256) {
+    const int row = e / (DH / 4), c4 = e - row * (DH / 4);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (row < Lk) {
+      a = *reinterpret_cast<const float4 *>(kb + (size_t)row * ks_.r + 4 * c4);
+      b = *reinterpret_cast<const float4 *>(vb + (size_t)row * vs.r + 4 * c4);
+    }
+    *reinterpret_cast<float4 *>(&k_lds[row * LS + 4 * c4]) = a;
+    *reinterpret_cast<float4 *>(&v_lds[row * LS + 4 * c4]) = b;
+  }
+  const bool use_mask = mask != nullptr && q_ok && (allowed == nullptr || allowed[(size_t)bi * Lq + myq] != 0);
+  const uint8_t *mrow = mask ? mask + ((size_t)bi * Lq + (q_ok ? myq : 0)) * Lk : nullptr;
+  __syncthreads();
+
+  const int ntiles = nrows / 16;
+  // this wave's key tiles: wv, wv + 4
+  dvis_f4 sa[NKT];
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) sa[t] = dvis_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < DQ / 4; ++c) {
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+      const int kt = wv + 4 * t;
+      if (kt < ntiles) {   // wave-uniform
+        const float4 kk = *reinterpret_cast<const float4 *>(&k_lds[(kt * 16 + j) * LS + g * DQ + 4 * c]);
+        sa[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.x, qf[4 * c], sa[t], 0, 0, 0);
+        sa[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.y, qf[4 * c + 1], sa[t], 0, 0, 0);
+        sa[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.z, qf[4 * c + 2], sa[t], 0, 0, 0);
+        sa[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.w, qf[4 * c + 3], sa[t], 0, 0, 0);
+      }
+    }
+  }
+  // lane (j, g): sa[t][r] = S[query myq][key 16 * (wv + 4 t) + 4 g + r]
+  float tmax = -INFINITY;
+  bool dead[NKT][4];
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    const int kbase = (wv + 4 * t) * 16 + 4 * g;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      bool d = kbase + r >= Lk;
+      if (use_mask && !d) d = mrow[kbase + r] != 0;
+      dead[t][r] = d;
+      if (!d) tmax = fmaxf(tmax, sa[t][r]);
+    }
+  }
+  tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+  tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+  float lsum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NKT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float pr = dead[t][r] ? 0.f : expf(sa[t][r] - tmax);
+      sa[t][r] = pr;
+      lsum += pr;
+    }
+  lsum += __shfl_xor(lsum, 16);
+  lsum += __shfl_xor(lsum, 32);
+  dvis_f4 o[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) o[n] = dvis_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    const int kt = wv + 4 * t;
+    if (kt < ntiles) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float *vrow = &v_lds[(kt * 16 + 4 * g + r) * LS + j];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) o[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[t][r], vrow[16 * n], o[n], 0, 0, 0);
+      }
+    }
+  }
+  // ---- merge the 4 waves' partials.  (m, l) of query jq live in lanes with (lane & 15) == jq.
+  if (g == 0) {
+    ml_lds[(wv * 16 + j) * 2] = tmax;
+    ml_lds[(wv * 16 + j) * 2 + 1] = lsum;
+  }
+  __syncthreads();           // every wave is past its K reads: k_lds may be overwritten
+  // accumulator rows are queries 4 g + r
+  float inv[4], wgt[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int jq = 4 * g + r;
+    float M = -INFINITY;
+#pragma unroll
+    for (int w2 = 0; w2 < 4; ++w2) M = fmaxf(M, ml_lds[(w2 * 16 + jq) * 2]);
+    float L = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < 4; ++w2) {
+      const float mw = ml_lds[(w2 * 16 + jq) * 2];
+      L += (mw == -INFINITY) ? 0.f : ml_lds[(w2 * 16 + jq) * 2 + 1] * expf(mw - M);
+    }
+    const float mine = ml_lds[(wv * 16 + jq) * 2];
+    wgt[r] = (mine == -INFINITY) ? 0.f : expf(mine - M);
+    inv[r] = L > 0.f ? 1.f / L : 0.f;
+  }
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o_lds[(wv * 16 + 4 * g + r) * DH + 16 * n + j] = o[n][r] * wgt[r];
+  __syncthreads();
+  if (wv == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qq = q0 + 4 * g + r;
+      if (qq < Lq) {
+        float *orow = out + (size_t)bi * os.b + (size_t)hi * os.h + (size_t)qq * os.r;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          float acc = 0.f;
+#pragma unroll
+          for (int w2 = 0; w2 < 4; ++w2) acc += o_lds[(w2 * 16 + 4 * g + r) * DH + 16 * n + j];
+          orow[16 * n + j] = acc * inv[r];
+        }
+      }
+    }
+  }
+}
+
 // Merge the per-split partials: O = sum_s O_s e^{m_s - M} / sum_s l_s e^{m_s - M}.
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restrict__ ws_o, const float *__restrict__ ws_ml,
                                                            int nsplit, int Lq, int DH, int heads, size_t total,
@@ -305,7 +471,21 @@ DVIS_EXPORT int dvis_attention_forward(const float *q, const int64_t *q_strides,
   float *ws_o = (float *)ws;
   float *ws_ml = ws_o ? ws_o + (size_t)BH * p.nsplit * Lq * d : nullptr;
   const dim3 grid(p.nsplit, BH, p.qchunks), block(512);
-#define DVIS_ATTN(DH_, SHORT_)                                                                                     \
+// few workgroups: one per (batch, head, 16-query tile) with the keys split over 4 waves (8.0 vs 14.8 us for the tracker's
+  // batch-1 call); with many (batch, head) pairs the per-tile K/V restaging costs more than it saves (17 vs 11 us at B=30).
+  if (Lk <= 128 && p.nsplit == 1 && (long long)BH * ((Lq + 15) / 16) <= 256) {
+    const dim3 sgrid((Lq + 15) / 16, BH);
+    const int nrows = (Lk + 15) / 16 * 16, ls = d + 4;
+    const size_t lds = sizeof(float) * ((size_t)std::max(nrows * ls, 64 * d) + (size_t)nrows * ls + 128);
+    if (d == 32)
+      hipLaunchKernelGGL((attn_short_kernel<32>), sgrid, dim3(256), lds, st, q, qs, k, ks, v, vs, out, os, mask, allowed_count,
+                         heads, Lq, Lk, scale);
+    else
+      hipLaunchKernelGGL((attn_short_kernel<64>), sgrid, dim3(256), lds, st, q, qs, k, ks, v, vs, out, os, mask, allowed_count,
+                         heads, Lq, Lk, scale);
+    return dvis_check_launch("attn_short_kernel");
+  }
+  #define DVIS_ATTN(DH_, SHORT_)                                                                                     \
   hipLaunchKernelGGL((attn_fwd_kernel<DH_, SHORT_>), grid, block, 0, st, q, qs, k, ks, v, vs, out, os, mask, allowed_count, \
                      heads, Lq, Lk, scale, p.nsplit, p.keys_per_split, ws_o, ws_ml)
   const bool shrt = Lk <= 128 && p.nsplit == 1;

@@ -28,6 +28,9 @@ CASES = [  # (Lq, Lk, B, heads, d, masked)
     (100, 100, 3, 8, 64, False), (30, 30, 100, 8, 64, False), (100, 100, 30, 8, 64, False),
     (6, 24, 2, 2, 32, True), (6, 6, 1, 2, 32, False), (200, 333, 2, 8, 32, True), (17, 70, 2, 4, 64, True),
     (5, 5, 6, 2, 32, False), (130, 257, 1, 2, 64, True),
+    # few (batch, head, query-tile) workgroups and Lk <= 128: the key-split latency kernel (tracker shapes)
+    (100, 100, 1, 8, 64, True), (100, 100, 1, 8, 32, True), (100, 128, 1, 8, 64, True), (33, 113, 2, 4, 32, True),
+    (100, 1, 1, 8, 64, False), (1, 100, 1, 8, 64, False),
 ]
 
 
@@ -80,6 +83,25 @@ def test_fully_blocked_rows_follow_the_reference_reset():
     ref = ref_attention(q, k, v, H, fixed)
     out = attention(q.to(DEV), k.to(DEV), v.to(DEV), H, mask.to(DEV), allowed.to(DEV)).cpu()
     torch.testing.assert_close(out.double(), ref, rtol=0, atol=2e-5)
+
+
+def test_fully_blocked_rows_short_sequences():
+    """Same reset on the key-split latency kernel (Lk <= 128, few workgroups) and on the batched short path."""
+    from dvis_plus_amd.functions import attention
+    for B in (1, 40):
+        g = torch.Generator().manual_seed(3 + B)
+        Lq, Lk, H, d = 100, 100, 8, 64
+        q, k, v = (torch.randn(L, B, H * d, generator=g) for L in (Lq, Lk, Lk))
+        mask = torch.rand(B, Lq, Lk, generator=g) < 0.5
+        mask[0, 3] = True
+        mask[B - 1, 99] = True
+        mask[0, 17, :96] = True            # only the last key tile (one wave's share) is live
+        allowed = (~mask).sum(-1).int()
+        fixed = mask.clone()
+        fixed[torch.where(fixed.sum(-1) == fixed.shape[-1])] = False
+        ref = ref_attention(q, k, v, H, fixed)
+        out = attention(q.to(DEV), k.to(DEV), v.to(DEV), H, mask.to(DEV), allowed.to(DEV)).cpu()
+        torch.testing.assert_close(out.double(), ref, rtol=0, atol=2e-5)
 
 
 def test_attention_matches_torch_mha_module():
