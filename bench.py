@@ -107,6 +107,8 @@ def main():
                     help="offline = BASELINE headline config (T=30, refiner on); online = config #2 (use --frames 5)")
     ap.add_argument("--candidates", type=int, default=20, help="queries sent to the panoptic stage (see main)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rounds", type=int, default=0,
+                    help="offline mode: spans handed to the tracker while the segmenter runs the next span (0 = default)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -134,6 +136,8 @@ def main():
     # (20) queries reach the panoptic stage (representative work).  Everything else follows
     # VIPSeg/DVIS_Plus_Offline_R50.yaml.
     model = build_dvis_plus_r50(args.mode, task=args.task, object_mask_threshold=0.0).to(device)
+    if args.rounds:
+        model.pipeline_rounds = args.rounds
     T = args.frames
     clip = synthetic_clip(T, device)
     inputs = [{"image": clip, "height": 720, "width": 1280}]
@@ -196,7 +200,8 @@ def main():
             "config": {"workload": f"DVIS++ {args.mode} R50, T={T} 720p synthetic clip (padded 736x1280), 100 queries, "
                                    f"temporal refiner {'on' if args.mode == 'offline' else 'off'}, task={args.task}, "
                                    f"frames sharded {world}-way",
-                       "panoptic_candidates": out.get("num_candidates"), "segments": len(out.get("segments_infos", []))},
+                       "panoptic_candidates": out.get("num_candidates"), "segments": len(out.get("segments_infos", [])),
+                       "tracker_spans": len(model.clip_shard.round_plan(T, getattr(model, "pipeline_rounds", 1))[0])},
             "roofline": {"bound": "hbm", "kernel": "msda_fwd_tile_f32 (fused MSDeformAttn forward)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -26,12 +26,28 @@ class ClipShard:
         lo = min(T, self.rank * per)
         return lo, min(T, lo + per)
 
-    def all_gather_frames(self, parts, T):
+    def round_plan(self, T, rounds=1):
+        """Pipelined schedule: the clip is cut into `rounds` consecutive spans of world*k frames; inside a span rank r
+        owns the k frames [start + r*k, start + (r+1)*k).  After round c every rank holds frames [0, end_c) in order, so
+        the (sequential) tracker can consume round c while the segmenter is busy with round c+1.  rounds=1 is the
+        plain contiguous sharding.  Returns [(start, end, lo, hi)] with [lo, hi) this rank's frames of the span."""
+        rounds = max(1, min(int(rounds), (T + self.world - 1) // self.world)) if T else 1
+        k = max(1, (T + self.world * rounds - 1) // (self.world * rounds))
+        plan = []
+        for start in range(0, max(T, 1), self.world * k):
+            end = min(T, start + self.world * k)
+            lo = min(end, start + self.rank * k)
+            plan.append((start, end, lo, min(end, lo + k)))
+        return plan, k
+
+    def all_gather_frames(self, parts, T, per=None, async_op=False):
         """parts: list of (t_local, Q, c_i) tensors for this rank's frames.  Returns the same list with all T frames,
-        identical on every rank.  One collective on one packed buffer."""
+        identical on every rank.  One collective on one packed buffer.  `per` = slot size per rank (default
+        ceil(T / world)); with async_op the result is (tensors, work) and the caller waits on `work` in the stream that
+        consumes the tensors."""
         if self.world == 1:
-            return parts
-        per = self.frames_per_rank(T)
+            return (parts, None) if async_op else parts
+        per = per or self.frames_per_rank(T)
         widths = [p.shape[-1] for p in parts]
         Q = parts[0].shape[1]
         packed = torch.zeros((per, Q, sum(widths)), dtype=parts[0].dtype, device=parts[0].device)
@@ -39,9 +55,10 @@ class ClipShard:
         if t_local:
             packed[:t_local] = torch.cat(parts, dim=-1)
         gathered = torch.empty((self.world * per, Q, sum(widths)), dtype=packed.dtype, device=packed.device)
-        dist.all_gather_into_tensor(gathered, packed, group=self.group)
+        work = dist.all_gather_into_tensor(gathered, packed, group=self.group, async_op=async_op)
         gathered = gathered[:T]                      # ranks are frame-contiguous: padding only sits at the very end
-        return list(gathered.split(widths, dim=-1))
+        out = list(gathered.split(widths, dim=-1))
+        return (out, work) if async_op else out
 
     def all_reduce_sum(self, x):
         if self.world > 1:

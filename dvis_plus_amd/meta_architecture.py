@@ -14,6 +14,8 @@ Differences by design (same results):
   * masks are only contracted for the queries post-processing keeps;
   * optional frame sharding over the GPUs of a node (clip_shard.ClipShard), one all-gather per clip.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -56,6 +58,9 @@ class _VideoBase(nn.Module):
         self.segmenter_chunk = segmenter_chunk  # frames per segmenter call, 0 = whole (local) clip at once
         self.keep = False
         self._clip_shard = None
+        # offline mode: spans of the clip handed to the tracker while the segmenter works on the next span
+        self.pipeline_rounds = int(os.environ.get("DVIS_PIPELINE_ROUNDS", "1"))
+        self._tracker_stream = None
         if hasattr(self.sem_seg_head.predictor, "compute_pred_masks"):
             self.sem_seg_head.predictor.compute_pred_masks = False
 
@@ -82,18 +87,33 @@ class _VideoBase(nn.Module):
             x = torch.nn.functional.pad(x, (0, Wp - W, 0, Hp - H))
         return x, (H, W)
 
+    def encode(self, images):
+        """Backbone + pixel decoder over this rank's frames: (multi_scale_features, mask_features (t,Cm,h,w))."""
+        chunk = self.segmenter_chunk or max(1, len(images))
+        ms, mf = [], []
+        for s in range(0, len(images), chunk):
+            f, _, m = self.sem_seg_head.pixel_decoder.forward_features(self.backbone(images[s:s + chunk]))
+            mf.append(f)
+            ms.append(m)
+        if len(mf) == 1:
+            return ms[0], mf[0]
+        return [torch.cat(level, 0) for level in zip(*ms)], torch.cat(mf, 0)
+
+    def decode(self, multi_scale, mask_features):
+        """Masked-attention decoder over a batch of frames: per-frame queries (t,Q,2C) normed / un-normed, logits."""
+        if len(mask_features) == 0:                # a rank without frames in this span (T < world * k)
+            pred = self.sem_seg_head.predictor
+            C2, Q = self.tracker.decoder_norm.weight.shape[0], self.num_queries
+            z = lambda *shape: mask_features.new_zeros(shape)
+            return z(0, Q, C2), z(0, Q, C2), z(0, Q, pred.class_embed.out_features)
+        out = self.sem_seg_head.predictor(multi_scale, mask_features, None)
+        return (out["pred_embds"][0].permute(1, 2, 0), out["pred_embds_without_norm"][0].permute(1, 2, 0),
+                out["pred_logits"][0])
+
     def segment(self, images):
         """Segmenter over this rank's frames.  Returns per-frame queries (t,Q,·) and mask_features (t,Cm,h,w)."""
-        chunk = self.segmenter_chunk or len(images)
-        embds, embds_nn, logits, feats = [], [], [], []
-        for s in range(0, len(images), chunk):
-            out = self.sem_seg_head(self.backbone(images[s:s + chunk]))
-            embds.append(out["pred_embds"][0].permute(1, 2, 0))                    # (t, Q, 2C)
-            embds_nn.append(out["pred_embds_without_norm"][0].permute(1, 2, 0))
-            logits.append(out["pred_logits"][0])                                   # (t, Q, K+1)
-            feats.append(out["mask_features"])
-        cat = lambda xs: xs[0] if len(xs) == 1 else torch.cat(xs, 0)
-        return cat(embds), cat(embds_nn), cat(logits), cat(feats)
+        ms, mf = self.encode(images)
+        return (*self.decode(ms, mf), mf)
 
     def _task_output(self, cls, aux, mask_fn, img_size, out_hw, padded_size, T_local):
         K = self.sem_seg_head.num_classes
@@ -144,24 +164,94 @@ class DVIS_Plus_offline(_VideoBase):
         self.keep = bool(video.get("keep", False))
         frames = video["image"]
         T = len(frames)
-        lo, hi = self.clip_shard.local_range(T)
-        images, img_size = self.preprocess(frames[lo:hi])                          # this rank's frames only
-        embds, embds_nn, logits, mask_features = self.segment(images)
-        embds, embds_nn, logits = self.clip_shard.all_gather_frames([embds, embds_nn, logits], T)
+        shard = self.clip_shard
+        plan, k = shard.round_plan(T, self.pipeline_rounds)
         to_bctq = lambda z: z.permute(2, 0, 1).unsqueeze(0)
-        track = self.tracker(to_bctq(embds), None, resume=self.keep, frame_embeds_no_norm=to_bctq(embds_nn),
-                             need_masks=False)
+        overlap = len(plan) > 1 and self.device.type == "cuda"
+        main = torch.cuda.current_stream() if overlap else None
+        if overlap and self._tracker_stream is None:
+            self._tracker_stream = torch.cuda.Stream()
+
+        # backbone + pixel decoder once over all of this rank's frames (span-major order), at full batch efficiency;
+        # only the decoder (cheap, batch-insensitive) is cut into spans
+        local_ids = [i for (_, _, lo, hi) in plan for i in range(lo, hi)]
+        contiguous = local_ids == list(range(local_ids[0], local_ids[0] + len(local_ids))) if local_ids else True
+        if not local_ids:
+            mine = frames[:0] if torch.is_tensor(frames) else []
+        elif contiguous:
+            mine = frames[local_ids[0]:local_ids[0] + len(local_ids)]
+        else:
+            mine = frames[torch.as_tensor(local_ids, device=frames.device)] if torch.is_tensor(frames) \
+                else [frames[i] for i in local_ids]
+        images, img_size = self.preprocess(mine if local_ids else frames[:1])
+        if not local_ids:
+            images = images[:0]
+            pred = self.sem_seg_head.predictor
+            multi_scale = None
+            mask_features = images.new_zeros((0, pred.mask_embed.layers[-1].out_features, images.shape[-2] // 4,
+                                              images.shape[-1] // 4))
+        else:
+            multi_scale, mask_features = self.encode(images)
+        padded = images.shape[-2:]
+        offsets, o = [], 0
+        for (_, _, lo, hi) in plan:
+            offsets.append((o, o + hi - lo))
+            o += hi - lo
+
+        def run_segmenter(c):
+            """Span c's decoder on the main stream, then the (asynchronous) all-gather of its per-frame queries."""
+            start, end, lo, hi = plan[c]
+            a, b = offsets[c]
+            whole = a == 0 and b == len(local_ids)
+            ms = None if multi_scale is None else (multi_scale if whole else [m[a:b] for m in multi_scale])
+            e, e_nn, lg = self.decode(ms, mask_features[a:b])
+            (e, e_nn, lg), work = shard.all_gather_frames([e, e_nn, lg], end - start, per=k, async_op=True)
+            done = torch.cuda.Event() if overlap else None
+            if overlap:
+                done.record(main)
+            return dict(embds=e, embds_nn=e_nn, logits=lg, work=work, done=done)
+
+        def run_tracker(c, seg):
+            """Round c of the recurrence; under `overlap` on the side stream, behind the span's gather."""
+            if seg["work"] is not None:
+                seg["work"].wait()
+            return self.tracker(to_bctq(seg["embds"]), None, resume=self.keep or c > 0,
+                                frame_embeds_no_norm=to_bctq(seg["embds_nn"]), need_masks=False)
+
+        segs, tracks = [run_segmenter(0)], []
+        if overlap:
+            self._tracker_stream.wait_stream(main)
+        for c in range(len(plan)):
+            if c + 1 < len(plan):
+                segs.append(run_segmenter(c + 1))       # enqueue the next span BEFORE blocking on this span's matching
+            if overlap:
+                with torch.cuda.stream(self._tracker_stream):
+                    self._tracker_stream.wait_event(segs[c]["done"])
+                    tracks.append(run_tracker(c, segs[c]))
+            else:
+                tracks.append(run_tracker(c, segs[c]))
+        if overlap:
+            main.wait_stream(self._tracker_stream)
+        cat = lambda xs, d: xs[0] if len(xs) == 1 else torch.cat(xs, d)
+        embds_nn = cat([s_["embds_nn"] for s_ in segs], 0)
+        track = {"pred_embds": cat([t["pred_embds"] for t in tracks], 2),
+                 "pred_logits": cat([t["pred_logits"] for t in tracks], 1)}
         ref = self.refiner(track["pred_embds"], to_bctq(embds_nn), None, need_masks=False)
         cls, aux = PP.mean_logits(ref["pred_logits"], track["pred_logits"])
         cls, aux = self.clip_shard.broadcast_from_rank0([cls.contiguous(), aux.contiguous()])
-        emb_local = ref["mask_embed"][:, lo:hi]                                     # (1, t_local, Q, Cm)
+        if contiguous:
+            emb_local = ref["mask_embed"][:, local_ids[0]:local_ids[0] + len(local_ids)] if local_ids \
+                else ref["mask_embed"][:, :0]                                       # (1, t_local, Q, Cm)
+        else:
+            emb_local = ref["mask_embed"][:, torch.as_tensor(local_ids, device=self.device)]
         mf = mask_features.unsqueeze(0)
 
         def mask_fn(idx):
             return self.refiner.predict_masks(emb_local, mf, idx)[0]                # (q', t_local, h, w)
         out_hw = (video.get("height", img_size[0]), video.get("width", img_size[1]))
-        out = self._task_output(cls, aux, mask_fn, img_size, out_hw, images.shape[-2:], hi - lo)
-        out["frame_range"] = (lo, hi)
+        out = self._task_output(cls, aux, mask_fn, img_size, out_hw, padded, len(local_ids))
+        out["frame_ids"] = local_ids                                                # which frames of the clip the masks are
+        out["frame_range"] = (local_ids[0], local_ids[-1] + 1) if local_ids and contiguous else None
         return out
 
 

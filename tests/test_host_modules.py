@@ -248,7 +248,7 @@ def test_keep_flag_resumes_tracker_across_calls(oracle_ops):
     assert second["pred_masks"].shape[1] == 3 and whole["pred_masks"].shape[1] == 6
 
 
-def _shard_worker(rank, world, port, out_dir):
+def _shard_worker(rank, world, port, out_dir, rounds=1, T=5):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -260,9 +260,10 @@ def _shard_worker(rank, world, port, out_dir):
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     m = _tiny_model("offline", "vps")
-    out = m([{"image": _tiny_clip(5), "height": 70, "width": 100}])
+    m.pipeline_rounds = rounds
+    out = m([{"image": _tiny_clip(T), "height": 70, "width": 100}])
     torch.save({"masks": out["pred_masks"], "segs": out["segments_infos"], "ids": out["pred_ids"],
-                "range": out["frame_range"]}, os.path.join(out_dir, f"r{rank}.pt"))
+                "range": out["frame_range"], "frame_ids": out["frame_ids"]}, os.path.join(out_dir, f"r{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -279,6 +280,53 @@ def test_clip_sharding_world_size_2_gloo(oracle_ops, tmp_path):
     for p in parts:
         assert p["segs"] == single["segments_infos"] and p["ids"] == single["pred_ids"]
     assert len(single["segments_infos"]) > 0
+
+
+def test_round_plan_covers_every_frame_once_in_order():
+    from dvis_plus_amd.clip_shard import ClipShard
+    for world in (1, 2, 3, 8):
+        for T in (1, 2, 5, 30, 64):
+            for rounds in (1, 2, 3, 4, 7):
+                seen = []
+                plans = []
+                for rank in range(world):
+                    sh = ClipShard.__new__(ClipShard)
+                    sh.group, sh.world, sh.rank = None, world, rank
+                    plans.append(sh.round_plan(T, rounds))
+                k = plans[0][1]
+                for c in range(len(plans[0][0])):
+                    start, end = plans[0][0][c][:2]
+                    for rank in range(world):
+                        s2, e2, lo, hi = plans[rank][0][c]
+                        assert (s2, e2) == (start, end) and hi - lo <= k and lo == min(end, start + rank * k)
+                        seen += list(range(lo, hi))
+                assert seen == list(range(T)), (world, T, rounds)
+
+
+def test_pipelined_rounds_equal_single_pass(oracle_ops):
+    """Tracker fed span by span (resume between spans) == tracker over the whole clip; same integer outputs."""
+    frames = _tiny_clip(7)
+    ref = _tiny_model("offline", "vps")([{"image": frames, "height": 70, "width": 100}])
+    for rounds in (2, 3, 7):
+        m = _tiny_model("offline", "vps")
+        m.pipeline_rounds = rounds
+        out = m([{"image": frames, "height": 70, "width": 100}])
+        assert torch.equal(out["pred_masks"], ref["pred_masks"]) and out["segments_infos"] == ref["segments_infos"]
+        assert out["frame_ids"] == list(range(7))
+    assert len(ref["segments_infos"]) > 0
+
+
+def test_pipelined_sharding_world_size_2_gloo(oracle_ops, tmp_path):
+    """2 ranks x 2 rounds (interleaved spans, one gather per span) == single process; 7 frames -> spans of 4 + 3."""
+    import torch.multiprocessing as mp
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_shard_worker, args=(2, port, str(tmp_path), 2, 7), nprocs=2, join=True)
+    single = _tiny_model("offline", "vps")([{"image": _tiny_clip(7), "height": 70, "width": 100}])
+    parts = [torch.load(tmp_path / f"r{r}.pt") for r in range(2)]
+    assert [p["frame_ids"] for p in parts] == [[0, 1, 4, 5], [2, 3, 6]]
+    for p in parts:
+        assert torch.equal(p["masks"], single["pred_masks"][p["frame_ids"]])
+        assert p["segs"] == single["segments_infos"] and p["ids"] == single["pred_ids"]
 
 
 def test_image_maskformer_config1_plumbing(oracle_ops):

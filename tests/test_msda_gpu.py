@@ -253,3 +253,46 @@ torch.save(out.cpu(), sys.argv[1])
             subprocess.check_call([sys.executable, "-c", code % (ROOT, os.path.join(ROOT, "tests")), f.name], env=env)
             outs.append(torch.load(f.name))
     assert torch.equal(outs[0], outs[1])
+
+
+def test_box_staged_variant_matches_tiled_kernel():
+    """The experimental LDS-box kernel (DVIS_MSDA_BOX=1: per-level bounding boxes of an 8x8 query tile staged in LDS,
+    global fallback where a box does not fit) computes the same sums as the tiled kernel.  Self-attention geometry:
+    reference points = pixel centres, offsets of a few pixels (boxes fit) and of many pixels (fallback), ragged maps."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    from conftest import ROOT
+    code = """
+import sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from conftest import level_tensors
+from dvis_plus_amd.functions import msda_fused_forward
+res = []
+for shapes, spread in (([(23, 40), (46, 80), (92, 160)], 3.0), ([(5, 7), (9, 13), (17, 30)], 2.0),
+                       ([(23, 40), (46, 80), (92, 160)], 40.0)):
+    N, M, D, L, P = 2, 8, 32, 3, 4
+    s, lsi = level_tensors(shapes)
+    S = Lq = int(s.prod(1).sum())
+    g = torch.Generator().manual_seed(7)
+    value = torch.randn(N, S, M, D, generator=g).cuda()
+    proj = torch.randn(N * Lq, M * L * P * 3, generator=g)
+    proj[:, :M * L * P * 2] *= spread
+    cen = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w,
+                                                indexing="ij"), -1).flip(-1).reshape(-1, 2) for h, w in shapes])
+    ref = cen[None, :, None, :].expand(1, Lq, L, 2).contiguous().cuda()
+    n_off = M * L * P * 2
+    pr = proj.cuda()
+    res.append(msda_fused_forward(value, s.cuda(), lsi.cuda(), ref, pr[:, :n_off], pr[:, n_off:], L, P,
+                                  shapes_host=shapes).cpu())
+torch.save(res, sys.argv[1])
+"""
+    outs = []
+    for knob in ("0", "1"):
+        with tempfile.NamedTemporaryFile(suffix=".pt") as f:
+            env = dict(os.environ, DVIS_MSDA_BOX=knob)
+            subprocess.check_call([sys.executable, "-c", code % (ROOT, os.path.join(ROOT, "tests")), f.name], env=env)
+            outs.append(torch.load(f.name))
+    for a, b in zip(*outs):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
