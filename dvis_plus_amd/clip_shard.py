@@ -8,6 +8,8 @@ packed per-frame queries (pred_embds | pred_embds_without_norm | pred_logits = 4
 replicated and deterministic on every rank, and each rank contracts masks for its own frames only.
 The reference has no intra-video parallelism at all — this is a new capability, not a port.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -17,6 +19,9 @@ class ClipShard:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
+        # development aid: run every collective even on a single rank (exercises RCCL calls, streams and the interplay
+        # with hipGraph capture on a 1-GPU box)
+        self.force = os.environ.get("DVIS_FORCE_COLLECTIVES") == "1" and dist.is_available() and dist.is_initialized()
 
     def frames_per_rank(self, T):
         return (T + self.world - 1) // self.world
@@ -45,7 +50,7 @@ class ClipShard:
         identical on every rank.  One collective on one packed buffer.  `per` = slot size per rank (default
         ceil(T / world)); with async_op the result is (tensors, work) and the caller waits on `work` in the stream that
         consumes the tensors."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return (parts, None) if async_op else parts
         per = per or self.frames_per_rank(T)
         widths = [p.shape[-1] for p in parts]
@@ -61,7 +66,7 @@ class ClipShard:
         return (out, work) if async_op else out
 
     def all_reduce_sum(self, x):
-        if self.world > 1:
+        if self.world > 1 or self.force:
             dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
         return x
 
@@ -69,7 +74,7 @@ class ClipShard:
         """Make small decision inputs (class logits) bit-identical on every rank.  Tracker + refiner are replicated and
         deterministic, but library heuristics (MIOpen find) may pick different conv algorithms per rank; post-processing
         takes keep/merge decisions and sizes a collective from these values, so they must agree exactly."""
-        if self.world > 1:
+        if self.world > 1 or self.force:
             for t in tensors:
                 if t is not None:
                     dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
