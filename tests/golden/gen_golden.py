@@ -110,16 +110,16 @@ def g1_msda():
 
 
 # --------------------------------------------------------------------------- G2
-def g2_pixel_decoder():
+def g2_pixel_decoder(conv_dim=32, name="g2_pixel_decoder", seed=20):
     m = R.ref("mask2former.modeling.pixel_decoder.msdeformattn")
     SS = sys.modules["detectron2.layers"].ShapeSpec
-    torch.manual_seed(20)
+    torch.manual_seed(seed)
     chans = dict(res2=8, res3=12, res4=16, res5=20)
     strides = dict(res2=4, res3=8, res4=16, res5=32)
     inp = {k: SS(channels=chans[k], stride=strides[k]) for k in chans}
     pd = m.MSDeformAttnPixelDecoder(
         inp, transformer_dropout=0.0, transformer_nheads=2, transformer_dim_feedforward=64,
-        transformer_enc_layers=2, conv_dim=32, mask_dim=16, norm="GN",
+        transformer_enc_layers=2, conv_dim=conv_dim, mask_dim=16, norm="GN",
         transformer_in_features=["res3", "res4", "res5"], common_stride=4).eval()
     # non-trivial offsets/weights (the reference initialises their weights to 0)
     with torch.no_grad():
@@ -135,28 +135,28 @@ def g2_pixel_decoder():
         attn = pd.transformer.encoder.layers[0].self_attn
         shapes, lsi = level_tensors([(2, 3), (4, 6), (8, 12)])
         S = int(shapes.prod(1).sum())
-        q = torch.randn(2, S, 32)
-        src = torch.randn(2, S, 32)
+        q = torch.randn(2, S, conv_dim)
+        src = torch.randn(2, S, conv_dim)
         vr = torch.ones(2, 3, 2)
         refp = m.MSDeformAttnTransformerEncoder.get_reference_points(shapes, vr, "cpu")
         attn_out = attn(q, refp, src, shapes, lsi, None)
-    save("g2_pixel_decoder",
+    save(name,
          ins=dict(**{f"feat_{k}": v for k, v in feats.items()}, attn_query=q, attn_src=src, attn_ref=refp),
          outs=dict(mask_features=mf, out0=out0, ms0=ms[0], ms1=ms[1], ms2=ms[2], attn_out=attn_out),
-         sd=pd.state_dict(), seed=20,
-         cfg=dict(conv_dim=32, mask_dim=16, nheads=2, ffn=64, enc_layers=2, chans=chans))
+         sd=pd.state_dict(), seed=seed,
+         cfg=dict(conv_dim=conv_dim, mask_dim=16, nheads=2, ffn=64, enc_layers=2, chans=chans))
 
 
 # --------------------------------------------------------------------------- G3
-def g3_decoder():
+def g3_decoder(hid=32, suffix="", seed=30):
     d = R.ref("dvis_Plus.video_mask2former_transformer_decoder")
-    torch.manual_seed(30)
+    torch.manual_seed(seed)
     K = 7
     dec = d.VideoMultiScaleMaskedTransformerDecoder_dvisPlus(
-        32, True, num_classes=K, hidden_dim=32, num_queries=6, nheads=2, dim_feedforward=64,
+        hid, True, num_classes=K, hidden_dim=hid, num_queries=6, nheads=2, dim_feedforward=64,
         dec_layers=3, pre_norm=False, mask_dim=16, enforce_input_project=False, num_frames=2,
-        num_reid_head_layers=3, reid_hidden_dim=32).eval()
-    x = [torch.randn(2, 32, 2, 3), torch.randn(2, 32, 4, 6), torch.randn(2, 32, 8, 12)]
+        num_reid_head_layers=3, reid_hidden_dim=hid).eval()
+    x = [torch.randn(2, hid, 2, 3), torch.randn(2, hid, 4, 6), torch.randn(2, hid, 8, 12)]
     mf = torch.randn(2, 16, 16, 24)
     with torch.no_grad():
         out = dec(x, mf)
@@ -165,21 +165,21 @@ def g3_decoder():
     for i, a in enumerate(out["aux_outputs"]):
         outs[f"aux{i}_logits"] = a["pred_logits"]
         outs[f"aux{i}_masks"] = a["pred_masks"]
-    save("g3_decoder_dvisplus", ins=dict(x0=x[0], x1=x[1], x2=x[2], mask_features=mf), outs=outs,
-         sd=dec.state_dict(), seed=30,
-         cfg=dict(num_classes=K, hidden=32, Q=6, nheads=2, ffn=64, dec_layers=3, mask_dim=16))
+    save("g3_decoder_dvisplus" + suffix, ins=dict(x0=x[0], x1=x[1], x2=x[2], mask_features=mf), outs=outs,
+         sd=dec.state_dict(), seed=seed,
+         cfg=dict(num_classes=K, hidden=hid, Q=6, nheads=2, ffn=64, dec_layers=3, mask_dim=16))
 
     # image decoder of BASELINE config #1 (mask2former_transformer_decoder.py:363-448)
     im = R.ref("mask2former.modeling.transformer_decoder.mask2former_transformer_decoder")
-    torch.manual_seed(31)
+    torch.manual_seed(seed + 1)
     dec2 = im.MultiScaleMaskedTransformerDecoder(
-        32, True, num_classes=K, hidden_dim=32, num_queries=6, nheads=2, dim_feedforward=64,
+        hid, True, num_classes=K, hidden_dim=hid, num_queries=6, nheads=2, dim_feedforward=64,
         dec_layers=3, pre_norm=False, mask_dim=16, enforce_input_project=False).eval()
     with torch.no_grad():
         out2 = dec2(x, mf)
-    save("g3_decoder_image", ins=dict(x0=x[0], x1=x[1], x2=x[2], mask_features=mf),
+    save("g3_decoder_image" + suffix, ins=dict(x0=x[0], x1=x[1], x2=x[2], mask_features=mf),
          outs=dict(pred_logits=out2["pred_logits"], pred_masks=out2["pred_masks"]),
-         sd=dec2.state_dict(), seed=31)
+         sd=dec2.state_dict(), seed=seed + 1, cfg=dict(num_classes=K, hidden=hid, Q=6, nheads=2, ffn=64, dec_layers=3))
 
 
 # --------------------------------------------------------------------------- G4
@@ -309,11 +309,18 @@ def g6_postprocess():
                   img_size=img_size, out_hw=out_hw, first_resize=first))
 
 
+def g7_head_dim_32():
+    """g2 / g3 at conv_dim = hidden = 64 with 2 heads (head dim 32): the narrowest width the HIP kernels serve, so the
+    GPU tests can compare the product against the reference's outputs directly (g4 already has head dim 32)."""
+    g2_pixel_decoder(conv_dim=64, name="g7_pixel_decoder_d32", seed=70)
+    g3_decoder(hid=64, suffix="_d32", seed=71)
+
+
 if __name__ == "__main__":
     import warnings
     warnings.filterwarnings("ignore")
     torch.set_num_threads(1)  # deterministic reduction order in the generating run
     only = sys.argv[1:]
-    for fn in (g1_msda, g2_pixel_decoder, g3_decoder, g4_tracker_refiner, g5_match, g6_postprocess):
+    for fn in (g1_msda, g2_pixel_decoder, g3_decoder, g4_tracker_refiner, g5_match, g6_postprocess, g7_head_dim_32):
         if not only or fn.__name__.split("_")[0] in only:
             fn()

@@ -10,8 +10,9 @@ from oracle import dvis_torch as O
 TOL = dict(rtol=1e-5, atol=2e-6)
 
 
-def test_pixel_decoder_and_msdeformattn_module():
-    g = Golden("g2_pixel_decoder")
+@pytest.mark.parametrize("name", ["g2_pixel_decoder", "g7_pixel_decoder_d32"])
+def test_pixel_decoder_and_msdeformattn_module(name):
+    g = Golden(name)
     sd, i, o = g.sd, g.ins, g.outs
     feats = {k[5:]: v for k, v in i.items() if k.startswith("feat_")}
     mf, out0, ms = O.pixel_decoder_forward(sd, feats, nheads=2, enc_layers=2)
@@ -24,8 +25,9 @@ def test_pixel_decoder_and_msdeformattn_module():
     torch.testing.assert_close(attn, o["attn_out"], **TOL)
 
 
-def test_decoder_dvisplus():
-    g = Golden("g3_decoder_dvisplus")
+@pytest.mark.parametrize("name", ["g3_decoder_dvisplus", "g3_decoder_dvisplus_d32"])
+def test_decoder_dvisplus(name):
+    g = Golden(name)
     sd, i, o = g.sd, g.ins, g.outs
     out = O.decoder_forward(sd, [i["x0"], i["x1"], i["x2"]], i["mask_features"], nheads=2, dec_layers=3)
     for k in ("pred_logits", "pred_masks", "pred_embds", "pred_embds_without_norm", "pred_reid_embed"):
@@ -35,8 +37,9 @@ def test_decoder_dvisplus():
         torch.testing.assert_close(out["aux_masks"][n], o[f"aux{n}_masks"], **TOL)
 
 
-def test_decoder_image_config1():
-    g = Golden("g3_decoder_image")
+@pytest.mark.parametrize("name", ["g3_decoder_image", "g3_decoder_image_d32"])
+def test_decoder_image_config1(name):
+    g = Golden(name)
     sd, i, o = g.sd, g.ins, g.outs
     out = O.decoder_forward(sd, [i["x0"], i["x1"], i["x2"]], i["mask_features"], nheads=2, dec_layers=3,
                             dvis_plus=False)
