@@ -55,6 +55,8 @@ class ConvBN(nn.Conv2d):
     def forward(self, x, res=None, relu=False):
         """conv (MIOpen, no bias) then ONE fused pass: + folded-BN shift (+ residual) (+ ReLU)."""
         w, b = self.folded()
+        if self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0):
+            return Fn.bias_act_(Fn.conv1x1(x, w), b, res, relu)
         return Fn.bias_act_(F.conv2d(x, w, None, self.stride, self.padding), b, res, relu)
 
 

@@ -273,7 +273,10 @@ class ConvNorm(nn.Conv2d):
         self.norm, self.activation = norm, activation
 
     def forward(self, x):
-        x = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        if self.kernel_size == (1, 1) and self.stride == (1, 1) and self.groups == 1 and self.padding == (0, 0):
+            x = Fn.conv1x1(x, self.weight, self.bias)
+        else:
+            x = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
         if self.norm is not None:
             x = self.norm(x)
         if self.activation is not None:
