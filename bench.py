@@ -198,8 +198,11 @@ def main():
         torch.distributed.barrier()
     timer = MsdaTimer()
     t0 = time.perf_counter()
+    mark = os.environ.get("DVIS_BENCH_MARK") == "1"     # tools/steady_stats.py: marker kernel at each timed step start
     with timer:
         for _ in range(args.steps):
+            if mark:
+                torch.empty(64, device=device).uniform_()
             out = step()
     torch.cuda.synchronize()
     if dist_on:
