@@ -157,6 +157,35 @@ def ref(name):
     return importlib.import_module(name)
 
 
+def ref_vit_adapter():
+    """Import the reference's vendored ViT-Adapter (mask2former/modeling/backbones_vitAdapter/adapter.py).
+    Extra stubs: timm.models.layers.{trunc_normal_, DropPath} and detectron2.modeling.{BACKBONE_REGISTRY, Backbone}
+    (un-vendored third-party names; DropPath is the identity in eval mode, the only mode used here)."""
+    install()
+
+    class _DropPath(nn.Module):
+        def __init__(self, drop_prob=0.0):
+            super().__init__()
+            self.drop_prob = drop_prob
+
+        def forward(self, x):
+            assert not self.training or self.drop_prob == 0.0
+            return x
+
+    tl = _mod("timm.models.layers", trunc_normal_=nn.init.trunc_normal_, DropPath=_DropPath)
+    tm = _mod("timm.models", layers=tl)
+    _mod("timm", models=tm)
+    d2m = sys.modules["detectron2.modeling"]
+    d2m.BACKBONE_REGISTRY = _Registry("BACKBONE")
+    d2m.Backbone = nn.Module
+    d2m.ShapeSpec = _ShapeSpec
+    if "mask2former.modeling.backbones_vitAdapter" not in sys.modules:
+        m = types.ModuleType("mask2former.modeling.backbones_vitAdapter")
+        m.__path__ = [f"{REF}/mask2former/modeling/backbones_vitAdapter"]
+        sys.modules["mask2former.modeling.backbones_vitAdapter"] = m
+    return importlib.import_module("mask2former.modeling.backbones_vitAdapter.adapter")
+
+
 def ref_meta():
     """Import dvis_Plus.meta_architecture for its *inference* methods only.
 

@@ -18,6 +18,7 @@ import types
 import numpy as np
 import scipy
 import torch
+from torch import nn
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import _ref_import as R  # noqa: E402
@@ -316,11 +317,54 @@ def g7_head_dim_32():
     g3_decoder(hid=64, suffix="_d32", seed=71)
 
 
+def g8_vit_adapter():
+    """DINOv2 ViT + ViT-Adapter (backbones_vitAdapter/adapter.py:422-586, backbones.py:36-260) at a tiny width with head
+    dim 32: embed 64, 2 heads, depth 4 (one block per interaction stage), deformable heads 2 (D = 32), input 64x96."""
+    from functools import partial
+    A = R.ref_vit_adapter()
+    B = sys.modules["mask2former.modeling.backbones_vitAdapter.backbones"]
+    L = sys.modules["mask2former.modeling.backbones_vitAdapter.layers"]
+    torch.manual_seed(80)
+    vit = B.DinoVisionTransformer(img_size=64, patch_size=16, embed_dim=64, depth=4, num_heads=2, mlp_ratio=4,
+                                  block_fn=partial(L.NestedTensorBlock, attn_class=L.MemEffAttention),
+                                  init_values=0.5, ffn_layer="mlp", block_chunks=0, qkv_bias=True, proj_bias=True,
+                                  ffn_bias=True)
+    ad = A.DinoV2ViTAdapter(vit_module=vit, pretrain_size=64, conv_inplane=8, n_points=4, deform_num_heads=2,
+                            init_values=1e-6, interaction_indexes=[[0, 0], [1, 1], [2, 2], [3, 3]], with_cffn=True,
+                            cffn_ratio=0.25, deform_ratio=0.5, add_vit_feature=True, use_extra_extractor=True).eval()
+    with torch.no_grad():
+        for m in ad.modules():
+            if isinstance(m, (nn.BatchNorm2d, nn.SyncBatchNorm)):
+                m.running_mean.normal_(0, 0.3)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.normal_(1, 0.2)
+                m.bias.normal_(0, 0.2)
+            if type(m).__name__ == "LayerScale":
+                m.gamma.normal_(0.5, 0.2)
+            if type(m).__name__ == "MSDeformAttn":
+                m.sampling_offsets.weight.normal_(0, 0.3)
+                m.attention_weights.weight.normal_(0, 0.5)
+                m.attention_weights.bias.normal_(0, 0.5)
+            if isinstance(m, nn.Linear) and m.bias is not None:
+                m.bias.normal_(0, 0.1)
+        vit.cls_token.normal_(0, 0.5)
+        vit.pos_embed.normal_(0, 0.5)
+    x = torch.randn(2, 3, 64, 96)
+    with torch.no_grad():
+        f1, f2, f3, f4 = ad(x)
+        tok, H, W = vit.prepare_tokens_with_masks(x, masks=None, return_HW=True)
+        blk0 = vit.blocks[0](tok)
+    save("g8_vit_adapter", ins=dict(x=x), outs=dict(f1=f1, f2=f2, f3=f3, f4=f4, tokens=tok, block0=blk0),
+         sd=ad.state_dict(), seed=80,
+         cfg=dict(embed=64, heads=2, depth=4, patch=16, img_size=64, conv_inplane=8, deform_heads=2, n_points=4,
+                  interaction_indexes=[[0, 0], [1, 1], [2, 2], [3, 3]], cffn_ratio=0.25, HW=[int(H), int(W)]))
+
+
 if __name__ == "__main__":
     import warnings
     warnings.filterwarnings("ignore")
     torch.set_num_threads(1)  # deterministic reduction order in the generating run
     only = sys.argv[1:]
-    for fn in (g1_msda, g2_pixel_decoder, g3_decoder, g4_tracker_refiner, g5_match, g6_postprocess, g7_head_dim_32):
+    for fn in (g1_msda, g2_pixel_decoder, g3_decoder, g4_tracker_refiner, g5_match, g6_postprocess, g7_head_dim_32, g8_vit_adapter):
         if not only or fn.__name__.split("_")[0] in only:
             fn()
