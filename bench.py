@@ -120,6 +120,9 @@ def cpu_baseline(model, clip, frames=3):
             "msda_op": cpu_baseline_msda()}
 
 
+BB_NAME = {"r50": "R50", "vitl": "ViT-Adapter-L", "vitb": "ViT-Adapter-B"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,6 +134,10 @@ def main():
                     help="offline = BASELINE headline config (T=30, refiner on); online = config #2 (use --frames 5)")
     ap.add_argument("--candidates", type=int, default=20, help="queries sent to the panoptic stage (see main)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backbone", default="r50", choices=["r50", "vitl", "vitb"],
+                    help="r50 = the headline config; vitl = BASELINE config #5 (ViT-Adapter-L, use --queries 200)")
+    ap.add_argument("--queries", type=int, default=100)
+    ap.add_argument("--segmenter-chunk", type=int, default=0, help="frames per segmenter call (0 = all local frames)")
     ap.add_argument("--rounds", type=int, default=0,
                     help="offline mode: spans handed to the tracker while the segmenter runs the next span (0 = default)")
     args = ap.parse_args()
@@ -163,7 +170,8 @@ def main():
     # keep no query and post-processing would be skipped; the threshold is calibrated below so that --candidates
     # (20) queries reach the panoptic stage (representative work).  Everything else follows
     # VIPSeg/DVIS_Plus_Offline_R50.yaml.
-    model = build_dvis_plus_r50(args.mode, task=args.task, object_mask_threshold=0.0).to(device)
+    model = build_dvis_plus_r50(args.mode, task=args.task, object_mask_threshold=0.0, backbone=args.backbone,
+                                num_queries=args.queries, segmenter_chunk=args.segmenter_chunk).to(device)
     if args.rounds:
         model.pipeline_rounds = args.rounds
     T = args.frames
@@ -225,10 +233,11 @@ def main():
             t = json.load(open(tj))
             traffic = round(t["hbm_bytes_per_launch"] * nfr / t["frames_per_launch"])
         res = {
-            "metric": f"frames/sec DVIS++ R50 {args.mode}, 720p T={T} synthetic", "value": round(fps, 3), "unit": "frames/s",
+            "metric": f"frames/sec DVIS++ {BB_NAME[args.backbone]} {args.mode}, 720p T={T} synthetic", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"DVIS++ {args.mode} R50, T={T} 720p synthetic clip (padded 736x1280), 100 queries, "
+            "config": {"workload": f"DVIS++ {args.mode} {BB_NAME[args.backbone]}, T={T} 720p synthetic clip (padded 736x1280), "
+                                   f"{args.queries} queries, "
                                    f"temporal refiner {'on' if args.mode == 'offline' else 'off'}, task={args.task}, "
                                    f"frames sharded {world}-way",
                        "panoptic_candidates": out.get("num_candidates"), "segments": len(out.get("segments_infos", [])),

@@ -66,6 +66,9 @@ def get_default_cfg():
     return CfgNode({
         "MODEL": {
             "META_ARCHITECTURE": "DVIS_Plus_offline",
+            "BACKBONE": {"NAME": "build_resnet_backbone"},
+            "VIT_ADAPTER": {"NAME": "vitl", "VIT_WEIGHT": None, "FREEZE_VIT": True, "FINETUNE": False,
+                            "FINETUNE_INDEXES": [0], "WITH_CP": False},
             "PIXEL_MEAN": [123.675, 116.280, 103.530],
             "PIXEL_STD": [58.395, 57.120, 57.375],
             "SEM_SEG_HEAD": {
@@ -101,8 +104,14 @@ def build_model(cfg, n_things=0):
     from .registry import META_ARCH_REGISTRY, SEM_SEG_HEADS_REGISTRY, TRANSFORMER_DECODER_REGISTRY
     from .tracker import ReferringTracker_noiser
     mf, hd = cfg.MODEL.MASK_FORMER, cfg.MODEL.SEM_SEG_HEAD
+    if cfg.MODEL.BACKBONE.get("NAME", "build_resnet_backbone") == "D2VitAdapterDinoV2":   # vit_adapter/*.yaml
+        from .vit_adapter import D2VitAdapterDinoV2
+        backbone = D2VitAdapterDinoV2(cfg.MODEL.VIT_ADAPTER.NAME)
+        in_shape = backbone.output_shape()
+    else:
+        backbone, in_shape = build_resnet50(), r50_input_shape()
     pd_cls = SEM_SEG_HEADS_REGISTRY.get(hd.PIXEL_DECODER_NAME)
-    pixel_decoder = pd_cls(**pd_cls.from_config(cfg, r50_input_shape()))
+    pixel_decoder = pd_cls(**pd_cls.from_config(cfg, in_shape))
     dec_cls = TRANSFORMER_DECODER_REGISTRY.get(mf.TRANSFORMER_DECODER_NAME)
     predictor = dec_cls(**dec_cls.from_config(cfg, hd.CONVS_DIM, True))
     head = SEM_SEG_HEADS_REGISTRY.get(hd.NAME)(num_classes=hd.NUM_CLASSES, pixel_decoder=pixel_decoder,
@@ -112,7 +121,7 @@ def build_model(cfg, n_things=0):
                                       num_head=mf.NHEADS, decoder_layer_num=cfg.MODEL.TRACKER.DECODER_LAYERS,
                                       noise_mode=cfg.MODEL.TRACKER.NOISE_MODE, mask_dim=hd.MASK_DIM,
                                       class_num=hd.NUM_CLASSES)
-    kw = dict(backbone=build_resnet50(), sem_seg_head=head, num_queries=mf.NUM_OBJECT_QUERIES,
+    kw = dict(backbone=backbone, sem_seg_head=head, num_queries=mf.NUM_OBJECT_QUERIES,
               object_mask_threshold=mf.TEST.OBJECT_MASK_THRESHOLD, overlap_threshold=mf.TEST.OVERLAP_THRESHOLD,
               n_things=n_things, size_divisibility=mf.SIZE_DIVISIBILITY, pixel_mean=cfg.MODEL.PIXEL_MEAN,
               pixel_std=cfg.MODEL.PIXEL_STD, tracker=tracker, task=mf.TEST.TASK, max_num=mf.TEST.MAX_NUM,

@@ -258,18 +258,26 @@ class DVIS_Plus_offline(_VideoBase):
 def build_dvis_plus_r50(mode="offline", *, num_classes=124, num_queries=100, n_things=58, task="vps", hidden_dim=256,
                         nheads=8, dim_feedforward=2048, dec_layers=10, enc_layers=6, tracker_layers=6,
                         refiner_layers=6, max_num=20, object_mask_threshold=0.8, overlap_threshold=0.8, seed=0,
-                        segmenter_chunk=0):
+                        segmenter_chunk=0, backbone="r50"):
     """DVIS++ R50 with the sizes of configs/dvis_Plus/VIPSeg/DVIS_Plus_{Online,Offline}_R50.yaml (HIDDEN_DIM 256,
     NHEADS 8, DIM_FEEDFORWARD 2048, DEC_LAYERS 10, 6 encoder / tracker / refiner layers, 100 queries, REID branch ->
-    512-channel tracker/refiner) and deterministic random weights following the reference's init rules."""
+    512-channel tracker/refiner) and deterministic random weights following the reference's init rules.
+    backbone="vitl" / "vitb": the ViT-Adapter variants (configs/dvis_Plus/VIPSeg/vit_adapter/*.yaml swap the backbone
+    and use 200 queries — pass num_queries=200)."""
     from .backbone import build_resnet50
     from .pixel_decoder import MSDeformAttnPixelDecoder, r50_input_shape
     from .refiner import TemporalRefiner
     from .tracker import ReferringTracker_noiser
     from .transformer_decoder import VideoMultiScaleMaskedTransformerDecoder_dvisPlus
     torch.manual_seed(seed)
+    if backbone == "r50":
+        bb, in_shape = build_resnet50(), r50_input_shape()
+    else:
+        from .vit_adapter import D2VitAdapterDinoV2
+        bb = D2VitAdapterDinoV2(backbone)
+        in_shape = bb.output_shape()
     pixel_decoder = MSDeformAttnPixelDecoder(
-        r50_input_shape(), transformer_dropout=0.0, transformer_nheads=nheads, transformer_dim_feedforward=1024,
+        in_shape, transformer_dropout=0.0, transformer_nheads=nheads, transformer_dim_feedforward=1024,
         transformer_enc_layers=enc_layers, conv_dim=hidden_dim, mask_dim=hidden_dim, norm="GN",
         transformer_in_features=["res3", "res4", "res5"], common_stride=4)
     predictor = VideoMultiScaleMaskedTransformerDecoder_dvisPlus(
@@ -280,7 +288,7 @@ def build_dvis_plus_r50(mode="offline", *, num_classes=124, num_queries=100, n_t
     tracker = ReferringTracker_noiser(hidden_channel=2 * hidden_dim, feedforward_channel=dim_feedforward,
                                       num_head=nheads, decoder_layer_num=tracker_layers, noise_mode="wa",
                                       mask_dim=hidden_dim, class_num=num_classes)
-    kw = dict(backbone=build_resnet50(), sem_seg_head=head, num_queries=num_queries,
+    kw = dict(backbone=bb, sem_seg_head=head, num_queries=num_queries,
               object_mask_threshold=object_mask_threshold, overlap_threshold=overlap_threshold, n_things=n_things,
               tracker=tracker, task=task, max_num=max_num, segmenter_chunk=segmenter_chunk)
     if mode == "online":
@@ -288,6 +296,9 @@ def build_dvis_plus_r50(mode="offline", *, num_classes=124, num_queries=100, n_t
     refiner = TemporalRefiner(hidden_channel=2 * hidden_dim, feedforward_channel=dim_feedforward, num_head=nheads,
                               decoder_layer_num=refiner_layers, mask_dim=hidden_dim, class_num=num_classes, windows=3)
     return DVIS_Plus_offline(refiner=refiner, **kw).eval()
+
+
+build_dvis_plus = build_dvis_plus_r50     # backbone-agnostic name (backbone="r50" | "vitl" | "vitb")
 
 
 @META_ARCH_REGISTRY.register()
@@ -418,8 +429,14 @@ def build_mask2former_r50(*, num_classes=133, num_queries=100, hidden_dim=256, n
     from .pixel_decoder import MSDeformAttnPixelDecoder, r50_input_shape
     from .transformer_decoder import MultiScaleMaskedTransformerDecoder
     torch.manual_seed(seed)
+    if backbone == "r50":
+        bb, in_shape = build_resnet50(), r50_input_shape()
+    else:
+        from .vit_adapter import D2VitAdapterDinoV2
+        bb = D2VitAdapterDinoV2(backbone)
+        in_shape = bb.output_shape()
     pixel_decoder = MSDeformAttnPixelDecoder(
-        r50_input_shape(), transformer_dropout=0.0, transformer_nheads=nheads, transformer_dim_feedforward=1024,
+        in_shape, transformer_dropout=0.0, transformer_nheads=nheads, transformer_dim_feedforward=1024,
         transformer_enc_layers=enc_layers, conv_dim=hidden_dim, mask_dim=hidden_dim, norm="GN",
         transformer_in_features=["res3", "res4", "res5"], common_stride=4)
     predictor = MultiScaleMaskedTransformerDecoder(
