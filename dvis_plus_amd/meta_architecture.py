@@ -423,7 +423,7 @@ class MaskFormer(nn.Module):
 
 
 def build_mask2former_r50(*, num_classes=133, num_queries=100, hidden_dim=256, nheads=8, dim_feedforward=2048,
-                          dec_layers=10, enc_layers=6, seed=0, **kw):
+                          dec_layers=10, enc_layers=6, seed=0, backbone="r50", **kw):
     """Image Mask2Former R50 (BASELINE config #1 sizes) with deterministic random weights."""
     from .backbone import build_resnet50
     from .pixel_decoder import MSDeformAttnPixelDecoder, r50_input_shape
@@ -444,4 +444,4 @@ def build_mask2former_r50(*, num_classes=133, num_queries=100, hidden_dim=256, n
         dim_feedforward=dim_feedforward, dec_layers=dec_layers - 1, pre_norm=False, mask_dim=hidden_dim,
         enforce_input_project=False)
     head = MaskFormerHead(num_classes=num_classes, pixel_decoder=pixel_decoder, transformer_predictor=predictor)
-    return MaskFormer(backbone=build_resnet50(), sem_seg_head=head, num_queries=num_queries, **kw).eval()
+    return MaskFormer(backbone=bb, sem_seg_head=head, num_queries=num_queries, **kw).eval()
