@@ -255,6 +255,16 @@ class DVIS_Plus_offline(_VideoBase):
         return out
 
 
+def _make_backbone(backbone):
+    """Built LAST by the builders so that the head / tracker / refiner weights of a given seed do not depend on the
+    backbone choice."""
+    if backbone == "r50":
+        from .backbone import build_resnet50
+        return build_resnet50()
+    from .vit_adapter import D2VitAdapterDinoV2
+    return D2VitAdapterDinoV2(backbone)
+
+
 def build_dvis_plus_r50(mode="offline", *, num_classes=124, num_queries=100, n_things=58, task="vps", hidden_dim=256,
                         nheads=8, dim_feedforward=2048, dec_layers=10, enc_layers=6, tracker_layers=6,
                         refiner_layers=6, max_num=20, object_mask_threshold=0.8, overlap_threshold=0.8, seed=0,
@@ -271,11 +281,11 @@ def build_dvis_plus_r50(mode="offline", *, num_classes=124, num_queries=100, n_t
     from .transformer_decoder import VideoMultiScaleMaskedTransformerDecoder_dvisPlus
     torch.manual_seed(seed)
     if backbone == "r50":
-        bb, in_shape = build_resnet50(), r50_input_shape()
+        in_shape = r50_input_shape()
     else:
-        from .vit_adapter import D2VitAdapterDinoV2
-        bb = D2VitAdapterDinoV2(backbone)
-        in_shape = bb.output_shape()
+        from .registry import ShapeSpec
+        dim = {"vitl": 1024, "vitb": 768}[backbone]
+        in_shape = {k: ShapeSpec(channels=dim, stride=s) for k, s in (("res2", 4), ("res3", 8), ("res4", 16), ("res5", 32))}
     pixel_decoder = MSDeformAttnPixelDecoder(
         in_shape, transformer_dropout=0.0, transformer_nheads=nheads, transformer_dim_feedforward=1024,
         transformer_enc_layers=enc_layers, conv_dim=hidden_dim, mask_dim=hidden_dim, norm="GN",
@@ -288,7 +298,7 @@ def build_dvis_plus_r50(mode="offline", *, num_classes=124, num_queries=100, n_t
     tracker = ReferringTracker_noiser(hidden_channel=2 * hidden_dim, feedforward_channel=dim_feedforward,
                                       num_head=nheads, decoder_layer_num=tracker_layers, noise_mode="wa",
                                       mask_dim=hidden_dim, class_num=num_classes)
-    kw = dict(backbone=bb, sem_seg_head=head, num_queries=num_queries,
+    kw = dict(backbone=_make_backbone(backbone), sem_seg_head=head, num_queries=num_queries,
               object_mask_threshold=object_mask_threshold, overlap_threshold=overlap_threshold, n_things=n_things,
               tracker=tracker, task=task, max_num=max_num, segmenter_chunk=segmenter_chunk)
     if mode == "online":
@@ -430,11 +440,11 @@ def build_mask2former_r50(*, num_classes=133, num_queries=100, hidden_dim=256, n
     from .transformer_decoder import MultiScaleMaskedTransformerDecoder
     torch.manual_seed(seed)
     if backbone == "r50":
-        bb, in_shape = build_resnet50(), r50_input_shape()
+        in_shape = r50_input_shape()
     else:
-        from .vit_adapter import D2VitAdapterDinoV2
-        bb = D2VitAdapterDinoV2(backbone)
-        in_shape = bb.output_shape()
+        from .registry import ShapeSpec
+        dim = {"vitl": 1024, "vitb": 768}[backbone]
+        in_shape = {k: ShapeSpec(channels=dim, stride=s) for k, s in (("res2", 4), ("res3", 8), ("res4", 16), ("res5", 32))}
     pixel_decoder = MSDeformAttnPixelDecoder(
         in_shape, transformer_dropout=0.0, transformer_nheads=nheads, transformer_dim_feedforward=1024,
         transformer_enc_layers=enc_layers, conv_dim=hidden_dim, mask_dim=hidden_dim, norm="GN",
@@ -444,4 +454,4 @@ def build_mask2former_r50(*, num_classes=133, num_queries=100, hidden_dim=256, n
         dim_feedforward=dim_feedforward, dec_layers=dec_layers - 1, pre_norm=False, mask_dim=hidden_dim,
         enforce_input_project=False)
     head = MaskFormerHead(num_classes=num_classes, pixel_decoder=pixel_decoder, transformer_predictor=predictor)
-    return MaskFormer(backbone=bb, sem_seg_head=head, num_queries=num_queries, **kw).eval()
+    return MaskFormer(backbone=_make_backbone(backbone), sem_seg_head=head, num_queries=num_queries, **kw).eval()
