@@ -59,9 +59,10 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(
   constexpr int DQ = DH / 4;        // dims per lane group
   constexpr int NT = DH / 16;       // output N tiles
   constexpr int LS = DH + 4;        // LDS row stride (floats): 16-B aligned, V rows of lane groups 0/1 split banks
-  // keys per LDS stage.  Long key sequences: 64 (d=32) / 32 (d=64) with a register prefetch of the next stage — one
-  // float4 of K and of V per thread per stage (two per thread crashes hipcc 7.2's machine-copy-propagation pass on the
-  // d=64 instantiation).  SHORT (Lk <= 128: tracker / refiner / decoder self-attention): ONE 128-key stage written
+  // keys per LDS stage.  Long key sequences: 64 (d=32) / 32 (d=64) with a register prefetch of the next stage.
+  // (64 keys at d=64 was measured on the ViT-L shape — 3681 tokens, 16 heads: 17.83 ms either way, 93 TFLOP/s — so
+  // the smaller stage is kept for its 17 KB of LDS.  An earlier form of the prefetch — float4 arrays with a zero-fill
+  // branch — crashed hipcc 7.2's machine-copy-propagation pass at F4 = 2; the scalar form below compiles.)  SHORT (Lk <= 128: tracker / refiner / decoder self-attention): ONE 128-key stage written
   // straight to LDS, so the whole call pays a single global-load latency instead of one per 32-key stage.
   constexpr int KT = SHORT ? 128 : (DH == 64 ? 32 : 64);
   constexpr int F4 = SHORT ? 1 : KT * DH / 4 / 512;   // float4 per thread per matrix per stage (prefetch registers)
@@ -105,19 +106,28 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(
 
   const float *kb = k + (size_t)bi * ks_.b + (size_t)hi * ks_.h;
   const float *vb = v + (size_t)bi * vs.b + (size_t)hi * vs.h;
-  float4 pk[F4], pv[F4];
+  // prefetch registers as scalars (F4 <= 2): as arrays captured by a lambda hipcc keeps them in scratch
+  static_assert(F4 == 1 || F4 == 2, "stage size");
+  float4 pk0, pv0, pk1, pv1;
+  pk0 = pv0 = pk1 = pv1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto stage_addr = [&](int i, int &row, int &c4) {
+    const int e = tid + 512 * i;                // float4 index within the stage
+    row = e / (DH / 4);
+    c4 = e - row * (DH / 4);
+  };
   auto prefetch = [&](int ks) {
-#pragma unroll
-    for (int i = 0; i < F4; ++i) {
-      const int e = tid + 512 * i;              // float4 index within the stage
-      const int row = e / (DH / 4), c4 = e - row * (DH / 4);
-      const int key = ks + row;
-      if (key < key_hi) {
-        pk[i] = *reinterpret_cast<const float4 *>(kb + (size_t)key * ks_.r + 4 * c4);
-        pv[i] = *reinterpret_cast<const float4 *>(vb + (size_t)key * vs.r + 4 * c4);
-      } else {
-        pk[i] = pv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+    // rows past the split's last key re-read that last key: they are masked out of the softmax below (p = 0 exactly)
+    // and real rows are finite, so no zero fill / branch is needed
+    int row, c4;
+    stage_addr(0, row, c4);
+    int key = min(ks + row, key_hi - 1);
+    pk0 = *reinterpret_cast<const float4 *>(kb + (size_t)key * ks_.r + 4 * c4);
+    pv0 = *reinterpret_cast<const float4 *>(vb + (size_t)key * vs.r + 4 * c4);
+    if (F4 > 1) {
+      stage_addr(1, row, c4);
+      key = min(ks + row, key_hi - 1);
+      pk1 = *reinterpret_cast<const float4 *>(kb + (size_t)key * ks_.r + 4 * c4);
+      pv1 = *reinterpret_cast<const float4 *>(vb + (size_t)key * vs.r + 4 * c4);
     }
   };
   if (!SHORT) prefetch(key_lo);
@@ -136,12 +146,14 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(
         *reinterpret_cast<float4 *>(&v_lds[row * LS + 4 * c4]) = b;
       }
     } else {
-#pragma unroll
-      for (int i = 0; i < F4; ++i) {
-        const int e = tid + 512 * i;
-        const int row = e / (DH / 4), c4 = e - row * (DH / 4);
-        *reinterpret_cast<float4 *>(&k_lds[row * LS + 4 * c4]) = pk[i];
-        *reinterpret_cast<float4 *>(&v_lds[row * LS + 4 * c4]) = pv[i];
+      int row, c4;
+      stage_addr(0, row, c4);
+      *reinterpret_cast<float4 *>(&k_lds[row * LS + 4 * c4]) = pk0;
+      *reinterpret_cast<float4 *>(&v_lds[row * LS + 4 * c4]) = pv0;
+      if (F4 > 1) {
+        stage_addr(1, row, c4);
+        *reinterpret_cast<float4 *>(&k_lds[row * LS + 4 * c4]) = pk1;
+        *reinterpret_cast<float4 *>(&v_lds[row * LS + 4 * c4]) = pv1;
       }
     }
     __syncthreads();
