@@ -165,6 +165,8 @@ def main():
             torch.distributed.init_process_group(backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
+    if os.environ.get("DVIS_MIOPEN_FIND", "0") == "1":
+        torch.backends.cudnn.benchmark = True      # MIOpen exhaustive find per conv shape (first call of a shape is slow)
     from dvis_plus_amd.meta_architecture import build_dvis_plus_r50
     # Random-init class logits are near-uniform (max prob ~ 1/125), so the reference's 0.8 score threshold would
     # keep no query and post-processing would be skipped; the threshold is calibrated below so that --candidates

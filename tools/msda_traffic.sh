@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 export PYTHONPATH=$R
 cd /tmp && export TMPDIR=/tmp
-for knob in "DVIS_MSDA_BAND_ORDER=1" "DVIS_MSDA_BAND_ORDER=0"; do
+for knob in "${KNOBS[@]:-DVIS_MSDA_VARIANT=0}"; do   # e.g. KNOBS=("DVIS_MSDA_VARIANT=0" "DVIS_MSDA_BOX=1") tools/msda_traffic.sh
   echo "== $knob"
   env $knob python $R/tools/msda_real.py 2>&1 | grep -v ids
   for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
