@@ -34,6 +34,10 @@ int dvis_msda_l0lds_launch(const float *value, const int64_t *shapes, const int6
                            int M, int D, int L, int Lq, int P, float *out, const int64_t *shapes_host, hipStream_t st,
                            bool *handled);
 
+int dvis_msda_pipe_launch(const float *value, const int64_t *shapes, const int64_t *level_start, const float *ref, int nref,
+                          const float *offsets, int64_t off_stride, const float *logits, int64_t logit_stride, int N, int S,
+                          int M, int D, int L, int Lq, int P, float *out, const int64_t *shapes_host, hipStream_t st,
+                          bool *handled);
 int dvis_msda_box_launch(const float *value, const int64_t *shapes, const int64_t *level_start, const float *ref, int nref,
                          const float *offsets, int64_t off_stride, const float *logits, int64_t logit_stride, int N, int S,
                          int M, int D, int L, int Lq, int P, float *out, const int64_t *shapes_host, hipStream_t st,
@@ -384,8 +388,12 @@ DVIS_EXPORT int dvis_msda_fused_forward(const float *value, const int64_t *shape
   bool handled = false;
   DVIS_REQUIRE((size_t)Lq * (size_t)(off_stride > logit_stride ? off_stride : logit_stride) * sizeof(float) < 0x7fffffffu,
                "msda_fused_forward: one frame of offsets/logits must stay below 2 GiB");
-  // encoder self-attention: corners served from LDS-staged per-level boxes (msda_forward_box.hip)
-  int rc = dvis_msda_box_launch(value, shapes, level_start, ref, Nref, offsets, off_stride, logits, logit_stride, N, S, M,
+  // encoder self-attention, persistent software-pipelined LDS kernel (msda_forward_pipe.hip; env-gated)
+  int rc = dvis_msda_pipe_launch(value, shapes, level_start, ref, Nref, offsets, off_stride, logits, logit_stride, N, S, M,
+                                 D, L, Lq, P, out, shapes_host, (hipStream_t)stream, &handled);
+  if (handled) return rc;
+  // experiment (off by default): corners served from LDS-staged per-level boxes (msda_forward_box.hip)
+  rc = dvis_msda_box_launch(value, shapes, level_start, ref, Nref, offsets, off_stride, logits, logit_stride, N, S, M,
                                 D, L, Lq, P, out, shapes_host, (hipStream_t)stream, &handled);
   if (handled) return rc;
   // experiment (off by default): persistent kernel with the coarsest value map LDS-resident (msda_forward_lds.hip)

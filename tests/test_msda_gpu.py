@@ -255,9 +255,11 @@ torch.save(out.cpu(), sys.argv[1])
     assert torch.equal(outs[0], outs[1])
 
 
-def test_box_staged_variant_matches_tiled_kernel():
-    """The experimental LDS-box kernel (DVIS_MSDA_BOX=1: per-level bounding boxes of an 8x8 query tile staged in LDS,
-    global fallback where a box does not fit) computes the same sums as the tiled kernel.  Self-attention geometry:
+@pytest.mark.parametrize("knob", ["DVIS_MSDA_BOX", "DVIS_MSDA_PIPE"])
+def test_lds_staged_variants_match_tiled_kernel(knob):
+    """The experimental LDS kernels (DVIS_MSDA_BOX=1: per-level bounding boxes of an 8x8 query tile staged in LDS, global
+    fallback where a box does not fit; DVIS_MSDA_PIPE=1: the persistent software-pipelined form of the same idea) compute
+    the same sums as the tiled kernel.  Self-attention geometry:
     reference points = pixel centres, offsets of a few pixels (boxes fit) and of many pixels (fallback), ragged maps."""
     import os
     import subprocess
@@ -289,9 +291,9 @@ for shapes, spread in (([(23, 40), (46, 80), (92, 160)], 3.0), ([(5, 7), (9, 13)
 torch.save(res, sys.argv[1])
 """
     outs = []
-    for knob in ("0", "1"):
+    for val in ("0", "1"):
         with tempfile.NamedTemporaryFile(suffix=".pt") as f:
-            env = dict(os.environ, DVIS_MSDA_BOX=knob)
+            env = dict(os.environ, **{knob: val})
             subprocess.check_call([sys.executable, "-c", code % (ROOT, os.path.join(ROOT, "tests")), f.name], env=env)
             outs.append(torch.load(f.name))
     for a, b in zip(*outs):
