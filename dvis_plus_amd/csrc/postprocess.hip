@@ -106,6 +106,174 @@ __global__ __launch_bounds__(256) void vps_argmax_kernel(
     if (s_area[i]) atomicAdd(&areas[i], s_area[i]);
 }
 
+// Semantic arg-max of a clip in one pass (inference_video_vss, dvis_Plus/meta_architecture.py:954-979):
+//   prob_q = resize2(sigmoid(resize1(logits_q)[:img_h, :img_w]));  sem[c] = sum_q cls[q][c] * prob_q;  out = argmax_c sem
+// The reference materialises (Q, T, H, W) twice and (C, T, H, W) once (14 GB at Q=100, C=124, T=30, 720p).  One thread
+// owns one output pixel and keeps the C class sums in registers (C <= 4*K4); the class scores of query q are the same
+// for every lane, so they are wave-uniform loads (scalar cache -> SGPR operands of the FMAs): no LDS traffic and no
+// vector registers spent on them.  `cls` is (Q, 4*K4), zero padded by the caller.
+template <int K4>
+__global__ __launch_bounds__(256) void vss_argmax_kernel(
+    const float *__restrict__ logits, int64_t stride_q, int64_t stride_t, const float *__restrict__ cls, int Q, int C, int T,
+    int h, int w, int first_h, int first_w, int img_h, int img_w, int out_h, int out_w, int64_t *__restrict__ out) {
+  const size_t npix = (size_t)T * out_h * out_w;
+  const float s1y = (float)h / (float)first_h, s1x = (float)w / (float)first_w;
+  const float s2y = (float)img_h / (float)out_h, s2x = (float)img_w / (float)out_w;
+  const bool identity2 = img_h == out_h && img_w == out_w;
+  for (size_t base = (size_t)blockIdx.x * 256; base < npix; base += (size_t)gridDim.x * 256) {
+    const size_t p = base + threadIdx.x;
+    const bool valid = p < npix;
+    const size_t pc = valid ? p : npix - 1;
+    const int X = (int)(pc % out_w);
+    const size_t r = pc / out_w;
+    const int Y = (int)(r % out_h);
+    const int t = (int)(r / out_h);
+    const Tap ty = make_tap(Y, s2y, img_h), tx = make_tap(X, s2x, img_w);
+    float4 acc[K4];
+#pragma unroll
+    for (int k = 0; k < K4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto accumulate = [&](int q, float prob) {
+      const float4 *row = reinterpret_cast<const float4 *>(cls + (size_t)q * 4 * K4);    // uniform address
+#pragma unroll
+      for (int k = 0; k < K4; ++k) {
+        const float4 cv = row[k];
+        acc[k].x += cv.x * prob; acc[k].y += cv.y * prob; acc[k].z += cv.z * prob; acc[k].w += cv.w * prob;
+      }
+    };
+    if (identity2) {
+      // same size: the second resize is the identity.  The 4 first-stage taps do not depend on q: indices once, and the
+      // 4 logits of query q+1 are loaded while query q's class sums are accumulated (the loop is latency-bound otherwise:
+      // 128 accumulators leave 2 waves per SIMD).
+      const Tap sy = make_tap(Y, s1y, h), sx = make_tap(X, s1x, w);
+      const int o00 = sy.i0 * w + sx.i0, o01 = sy.i0 * w + sx.i1, o10 = sy.i1 * w + sx.i0, o11 = sy.i1 * w + sx.i1;
+      const float *lg = logits + (size_t)t * stride_t;
+      float a = lg[o00], b = lg[o01], c = lg[o10], d = lg[o11];
+#pragma unroll 1
+      for (int q = 0; q < Q; ++q) {
+        const float v = sy.l0 * (sx.l0 * a + sx.l1 * b) + sy.l1 * (sx.l0 * c + sx.l1 * d);
+        if (q + 1 < Q) {
+          const float *nx = lg + (size_t)(q + 1) * stride_q;
+          a = nx[o00]; b = nx[o01]; c = nx[o10]; d = nx[o11];
+        }
+        accumulate(q, 1.f / (1.f + expf(-v)));
+      }
+    } else {
+#pragma unroll 1
+      for (int q = 0; q < Q; ++q) {
+        const float *lg = logits + (size_t)q * stride_q + (size_t)t * stride_t;
+        const float a = stage1_sigmoid(lg, h, w, s1y, s1x, ty.i0, tx.i0), b = stage1_sigmoid(lg, h, w, s1y, s1x, ty.i0, tx.i1);
+        const float c = stage1_sigmoid(lg, h, w, s1y, s1x, ty.i1, tx.i0), d = stage1_sigmoid(lg, h, w, s1y, s1x, ty.i1, tx.i1);
+        accumulate(q, ty.l0 * (tx.l0 * a + tx.l1 * b) + ty.l1 * (tx.l0 * c + tx.l1 * d));
+      }
+    }
+    float best = -INFINITY;
+    int best_c = 0;
+#pragma unroll
+    for (int k = 0; k < K4; ++k) {      // ascending, strict: the first maximum wins, like torch.max(0)
+      if (4 * k < C && acc[k].x > best) { best = acc[k].x; best_c = 4 * k; }
+      if (4 * k + 1 < C && acc[k].y > best) { best = acc[k].y; best_c = 4 * k + 1; }
+      if (4 * k + 2 < C && acc[k].z > best) { best = acc[k].z; best_c = 4 * k + 2; }
+      if (4 * k + 3 < C && acc[k].w > best) { best = acc[k].w; best_c = 4 * k + 3; }
+    }
+    if (valid) out[p] = best_c;
+  }
+}
+
+// MFMA form of the semantic arg-max for the common case (second resize = identity, C <= 128): the class sums are a
+// GEMM  sem[c][px] = sum_q cls[q][c] * prob[q][px]  (C x Q) x (Q x pixels).  A wave owns 64 consecutive output pixels
+// (4 tiles of 16) x 128 classes (8 tiles of 16) = 32 accumulator tiles of v_mfma_f32_16x16x4_f32; per k-step of 4
+// queries every lane evaluates the 4 probabilities it contributes as B operand (pixel = lane & 15 of each tile, query =
+// 4*ks + (lane >> 4)) and reads its A operand (class = lane & 15, same query) from the zero-padded class matrix in LDS.
+// 124 classes x 100 queries at 720p: 0.69 TFLOP per clip = 4.4 ms at the fp32-MFMA peak, vs 12 ms of VALU work for the
+// one-pixel-per-thread form above (measured 16.7 ms).
+__global__ __launch_bounds__(256) void vss_argmax_mfma_kernel(
+    const float *__restrict__ logits, int64_t stride_q, int64_t stride_t, const float *__restrict__ cls /* (Qp, 128) */,
+    int Q, int Qp, int C, int T, int h, int w, int first_h, int first_w, int out_h, int out_w, int64_t *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float s_cls[];      // [Qp][128 + 4]: +4 spreads the 4 query rows of an A read over banks
+  constexpr int LSC = 132;
+  constexpr int NT = 2;                                              // 16-pixel tiles per wave: 8 x NT accumulator tiles
+  for (int i = threadIdx.x; i < Qp * 128; i += 256) s_cls[(i >> 7) * LSC + (i & 127)] = cls[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const size_t npix = (size_t)T * out_h * out_w;
+  const float s1y = (float)h / (float)first_h, s1x = (float)w / (float)first_w;
+  const size_t nchunks = (npix + 16 * NT - 1) / (16 * NT);
+  for (size_t chunk = (size_t)blockIdx.x * 4 + wv; chunk < nchunks; chunk += (size_t)gridDim.x * 4) {
+    // this lane's NT pixels (one per 16-pixel tile) and their first-stage taps
+    const float *l00[NT], *l01[NT], *l10[NT], *l11[NT];
+    float wy0[NT], wy1[NT], wx0[NT], wx1[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const size_t p = min(chunk * (16 * NT) + (size_t)n * 16 + j, npix - 1);
+      const int X = (int)(p % out_w);
+      const size_t r = p / out_w;
+      const int Y = (int)(r % out_h);
+      const Tap sy = make_tap(Y, s1y, h), sx = make_tap(X, s1x, w);
+      const float *base = logits + (size_t)(r / out_h) * stride_t + (size_t)g * stride_q;   // query g of k-step 0
+      l00[n] = base + sy.i0 * w + sx.i0; l01[n] = base + sy.i0 * w + sx.i1;
+      l10[n] = base + sy.i1 * w + sx.i0; l11[n] = base + sy.i1 * w + sx.i1;
+      wy0[n] = sy.l0; wy1[n] = sy.l1; wx0[n] = sx.l0; wx1[n] = sx.l1;
+    }
+    dvis_f4 acc[8][NT];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[mt][n] = dvis_f4{0.f, 0.f, 0.f, 0.f};
+    // logits of the lane's query of the NEXT k-step are loaded while this k-step's MFMAs run (Qp % 4 == 0, Qp <= Q + 3:
+    // the caller guarantees Qp == Q, so every (ks + g) row exists)
+    float va[NT], vb[NT], vc[NT], vd[NT];
+    const size_t step = (size_t)4 * stride_q;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) { va[n] = *l00[n]; vb[n] = *l01[n]; vc[n] = *l10[n]; vd[n] = *l11[n]; }
+#pragma unroll 1
+    for (int ks = 0; ks < Qp; ks += 4) {
+      float pb[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const float v = wy0[n] * (wx0[n] * va[n] + wx1[n] * vb[n]) + wy1[n] * (wx0[n] * vc[n] + wx1[n] * vd[n]);
+        pb[n] = 1.f / (1.f + expf(-v));
+      }
+      if (ks + 4 < Qp) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          l00[n] += step; l01[n] += step; l10[n] += step; l11[n] += step;
+          va[n] = *l00[n]; vb[n] = *l01[n]; vc[n] = *l10[n]; vd[n] = *l11[n];
+        }
+      }
+      const float *arow = s_cls + (size_t)(ks + g) * LSC + j;
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) {
+        const float a = arow[16 * mt];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[mt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, pb[n], acc[mt][n], 0, 0, 0);
+      }
+    }
+    // acc[mt][n][r] = sem[class 16*mt + 4*g + r][pixel tile n, column j]: arg-max over classes, first maximum wins
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      float best = -INFINITY;
+      int best_c = 0x7fffffff;
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * mt + 4 * g + r;
+          const float v = acc[mt][n][r];
+          if (c < C && v > best) { best = v; best_c = c; }      // ascending within the lane
+        }
+#pragma unroll
+      for (int o = 16; o <= 32; o <<= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oc = __shfl_xor(best_c, o);
+        if (ov > best || (ov == best && oc < best_c)) { best = ov; best_c = oc; }
+      }
+      const size_t p = chunk * (16 * NT) + (size_t)n * 16 + j;
+      if (g == 0 && p < npix) out[p] = best_c;
+    }
+  }
+}
+
 }  // namespace
 
 DVIS_EXPORT int dvis_vps_argmax(const float *logits, int64_t stride_k, int64_t stride_t, const float *scores, int K, int T,
@@ -130,4 +298,42 @@ DVIS_EXPORT int dvis_vps_argmax(const float *logits, int64_t stride_k, int64_t s
   hipLaunchKernelGGL(vps_argmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, logits, stride_k, stride_t, scores, K, T,
                      h, w, first_h, first_w, img_h, img_w, out_h, out_w, ids, conf, areas);
   return dvis_check_launch("vps_argmax_kernel");
+}
+
+DVIS_EXPORT int dvis_vss_argmax(const float *logits, int64_t stride_q, int64_t stride_t, const float *cls,
+                                int cls_row_stride, int Q, int C, int T, int h, int w, int first_h, int first_w, int img_h, int img_w, int out_h, int out_w,
+                                int64_t *out, void *stream) {
+  DVIS_REQUIRE(Q > 0 && C > 0 && C <= 128 && T >= 0 && h > 0 && w > 0 && first_h > 0 && first_w > 0 && img_h > 0 &&
+                   img_w > 0 && out_h > 0 && out_w > 0,
+               "vss_argmax: bad sizes (C must be 1..128)");
+  DVIS_REQUIRE(img_h <= first_h && img_w <= first_w, "vss_argmax: image size exceeds the padded size");
+  DVIS_REQUIRE(logits && cls && out, "vss_argmax: null pointer");
+  if (T == 0) return DVIS_OK;
+  DVIS_REQUIRE(cls_row_stride >= C && cls_row_stride % 32 == 0 && cls_row_stride <= 128 && (((uintptr_t)cls) & 15) == 0,
+               "vss_argmax: cls rows must be zero padded to a multiple of 32 floats (<= 128), 16-byte aligned");
+  const int k4 = cls_row_stride / 4;              // 8, 16, 24 or 32 float4 of class sums per thread
+  hipStream_t st = (hipStream_t)stream;
+  const size_t npix = (size_t)T * out_h * out_w;
+  size_t blocks = (npix + 255) / 256;
+  if (img_h == out_h && img_w == out_w && cls_row_stride == 128 && Q % 4 == 0) {
+    // GEMM form on the matrix cores (cls is padded to 128 columns; Q % 4 == 0 so that no row past the matrix is read)
+    const size_t lds = (size_t)Q * 132 * sizeof(float);
+    if (lds <= 64 * 1024) {
+      size_t nb = ((npix + 31) / 32 + 3) / 4;
+      if (nb > 256 * 9) nb = 256 * 9;
+      hipLaunchKernelGGL(vss_argmax_mfma_kernel, dim3((unsigned)nb), dim3(256), lds, st, logits, stride_q, stride_t, cls, Q, Q,
+                         C, T, h, w, first_h, first_w, out_h, out_w, out);
+      return dvis_check_launch("vss_argmax_mfma_kernel");
+    }
+  }
+  if (blocks > 256 * 16) blocks = 256 * 16;
+#define DVIS_VSS(K4_)                                                                                                   \
+  hipLaunchKernelGGL((vss_argmax_kernel<K4_>), dim3((unsigned)blocks), dim3(256), 0, st, logits, stride_q, stride_t, cls, \
+                     Q, C, T, h, w, first_h, first_w, img_h, img_w, out_h, out_w, out)
+  if (k4 == 8) DVIS_VSS(8);
+  else if (k4 == 16) DVIS_VSS(16);
+  else if (k4 == 24) DVIS_VSS(24);
+  else DVIS_VSS(32);
+#undef DVIS_VSS
+  return dvis_check_launch("vss_argmax_kernel");
 }

@@ -246,6 +246,27 @@ def vps_argmax(mask_logits_kthw, scores, first_resize_size, img_size, out_hw):
     return ids, conf.bool(), areas
 
 
+def vss_argmax(mask_logits_qthw, mask_cls, first_resize_size, img_size, out_hw):
+    """Fused semantic arg-max (see dvis_vss_argmax).  mask_logits_qthw: float32 GPU (Q, T, h, w) view whose last two dims
+    are contiguous; mask_cls float32 (Q, C), C <= 128.  Returns int64 (T, H, W) class indices."""
+    Q, T, h, w = mask_logits_qthw.shape
+    m = mask_logits_qthw
+    if not m.is_cuda or m.dtype != torch.float32 or m.stride(3) != 1 or m.stride(2) != w:
+        raise RuntimeError("vss_argmax: logits must be a float32 GPU (Q, T, h, w) view with contiguous (h, w) maps")
+    C = mask_cls.shape[1]
+    Cp = (C + 31) // 32 * 32
+    cls = torch.nn.functional.pad(mask_cls.to(torch.float32), (0, Cp - C)).contiguous()     # zero columns: never the max
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    out = torch.empty((T, oh, ow), dtype=torch.int64, device=m.device)
+    with torch.cuda.device(m.device):
+        rc = native.lib().dvis_vss_argmax(
+            ctypes.c_void_p(m.data_ptr()), m.stride(0), m.stride(1), native.dev_ptr(cls, "mask_cls"), Cp, Q, C, T,
+            h, w, int(first_resize_size[0]), int(first_resize_size[1]), int(img_size[0]), int(img_size[1]), oh, ow,
+            native.dev_ptr(out, "out"), native.stream_ptr(m.device))
+    native.check(rc, "dvis_vss_argmax")
+    return out
+
+
 def add_layer_norm(x, res, norm):
     """``norm(x + res)`` for an ``nn.LayerNorm`` `norm` in ONE pass.  x contiguous float32 GPU (..., C); res: None or a
     tensor broadcast-free of x's shape whose rows (last dim) are contiguous.  CPU tensors / other dtypes use torch ops

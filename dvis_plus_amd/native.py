@@ -33,6 +33,7 @@ SIGNATURES = {
     "dvis_bias_act": (_i, [_p, _p, _p, _i64, _i, _i64, _i, _p]),
     "dvis_upsample_add": (_i, [_p, _p, _p, _i64, _i, _i, _i, _i, _p]),
     "dvis_vps_argmax": (_i, [_p, _i64, _i64, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "dvis_vss_argmax": (_i, [_p, _i64, _i64, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "dvis_lsap_solve": (_i, [_p, _i, _i, _p]),
     "dvis_match_chain": (_i, [_p, _i, _i, _p]),
 }

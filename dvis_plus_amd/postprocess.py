@@ -118,6 +118,12 @@ def inference_video_vss(pred_cls, mask_fn, img_size, out_hw, first_resize_size, 
     if aux_pred_cls is not None:
         mask_cls = torch.maximum(mask_cls, F.softmax(aux_pred_cls, dim=-1)[..., :-1].to(mask_cls))
     masks = mask_fn(None)                                                                     # (Q, T, h, w)
+    if masks.is_cuda and mask_cls.shape[1] <= 128:
+        from . import functions as Fn
+        if masks.stride(3) != 1 or masks.stride(2) != masks.shape[3]:
+            masks = masks.contiguous()
+        sem = Fn.vss_argmax(masks, mask_cls, first_resize_size, img_size, out_hw)             # one pass, no (C,T,H,W)
+        return {"image_size": tuple(out_hw), "pred_masks": sem, "task": "vss"}
     outs = []
     for s in range(0, masks.shape[1], frame_chunk):                                           # bound the 720p blow-up
         cur = _resize2(masks[:, s:s + frame_chunk], first_resize_size, img_size, out_hw, sigmoid=True)

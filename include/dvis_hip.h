@@ -27,6 +27,8 @@
  *   dvis_upsample_add        <- `cur_fpn + F.interpolate(out[-1], size=..., mode="bilinear")`, msdeformattn.py:347
  *   dvis_vps_argmax          <- two-stage resize + sigmoid + score-weighted argmax + segment areas of inference_video_vps,
  *                               dvis_Plus/meta_architecture.py:890-925
+ *   dvis_vss_argmax          <- two-stage resize + sigmoid + einsum("qc,qthw->cthw") + max(0) of inference_video_vss,
+ *                               dvis_Plus/meta_architecture.py:954-979
  *   dvis_lsap_solve          <- scipy.optimize.linear_sum_assignment as called by Noiser.match_embds, dvis_Plus/noiser.py:43-56
  *   dvis_match_chain         <- the frame-by-frame matching loop of ReferringTracker_noiser.forward, dvis_Plus/tracker.py:210-291
  */
@@ -163,6 +165,17 @@ int dvis_bias_act(float *x, const float *bias, const float *res, int64_t planes,
 int dvis_vps_argmax(const float *logits, int64_t stride_k, int64_t stride_t, const float *scores, int K, int T,
                     int h, int w, int first_h, int first_w, int img_h, int img_w, int out_h, int out_w,
                     int32_t *ids, uint8_t *conf, int32_t *areas, void *stream);
+
+/*
+ * Semantic arg-max of a clip in one pass (inference_video_vss, dvis_Plus/meta_architecture.py:954-979):
+ *   prob_q as in dvis_vps_argmax; out[t][y][x] = argmax_c sum_q cls[q][c] * prob_q[t][y][x]   (first maximum wins).
+ *   logits: Q x T maps of h*w floats at logits + q*stride_q + t*stride_t; cls: Q rows of cls_row_stride floats, the
+ *   first C valid and the rest ZERO (cls_row_stride = C rounded up to a multiple of 32, <= 128), 16-byte aligned.
+ *   out (T, out_h, out_w) int64 class indices.
+ */
+int dvis_vss_argmax(const float *logits, int64_t stride_q, int64_t stride_t, const float *cls, int cls_row_stride, int Q,
+                    int C, int T, int h, int w, int first_h, int first_w, int img_h, int img_w, int out_h, int out_w,
+                    int64_t *out, void *stream);
 
 /*
  * HOST function: minimum-cost assignment of an nr x nc (nr <= nc) row-major double cost matrix,

@@ -63,3 +63,37 @@ def test_vps_fused_path_reproduces_golden_fixture():
     assert [s["category_id"] for s in p["segments_infos"]] == o["vps_seg_cat"].tolist()
     assert p["pred_ids"] == o["vps_ids"].tolist()
     assert (p["pred_masks"].cpu() == o["vps_masks"]).float().mean().item() > 0.999
+
+
+@pytest.mark.parametrize("Q,C,T,h,w,first,img,out", [
+    (100, 124, 2, 46, 80, (184, 320), (180, 320), (180, 320)),    # VIPSeg class count, identity second stage
+    (13, 7, 2, 10, 14, (40, 56), (37, 53), (30, 45)),             # both stages non-trivial
+    (40, 33, 1, 12, 20, (48, 80), (45, 77), (90, 160)),
+    (5, 128, 1, 6, 8, (24, 32), (24, 32), (24, 32)),              # largest supported class count
+])
+def test_vss_argmax_vs_torch_sequence(Q, C, T, h, w, first, img, out):
+    """dvis_vss_argmax == interpolate -> crop -> sigmoid -> interpolate -> einsum("qc,qthw->cthw") -> max(0)."""
+    from dvis_plus_amd.functions import vss_argmax
+    g = torch.Generator().manual_seed(Q + C)
+    logits = (torch.randn(T, Q, h, w, generator=g) * 3).to(DEV).permute(1, 0, 2, 3)     # (Q,T,h,w) strided like mask_fn
+    cls = torch.softmax(torch.randn(Q, C + 1, generator=g) * 2, -1)[:, :-1].to(DEV)
+    got = vss_argmax(logits, cls, first, img, out)
+    m = F.interpolate(logits.contiguous(), size=first, mode="bilinear", align_corners=False)[:, :, :img[0], :img[1]]
+    m = F.interpolate(m.sigmoid(), size=out, mode="bilinear", align_corners=False)
+    sem = torch.einsum("qc,qthw->cthw", cls.double(), m.double())
+    want = sem.max(0)[1]
+    top2 = sem.topk(min(2, C), dim=0)[0]
+    clear = (top2[0] - top2[-1]) > 1e-5 if C > 1 else torch.ones_like(want, dtype=torch.bool)
+    assert got.dtype == torch.int64 and got.shape == want.shape
+    assert torch.equal(got[clear], want[clear])
+    assert (~clear).float().mean() < 1e-3
+
+
+def test_vss_fused_path_reproduces_golden_fixture():
+    from dvis_plus_amd import postprocess as P
+    g = Golden("g6_postprocess")
+    i, o, cfg = g.ins, g.outs, g.meta["cfg"]
+    logits, aux = P.mean_logits(i["pred_logits"].to(DEV), i["aux_logits"].to(DEV))
+    masks = i["pred_masks"][0].to(DEV)
+    s = P.inference_video_vss(logits, lambda idx: masks, cfg["img_size"], cfg["out_hw"], cfg["first_resize"], aux)
+    assert (s["pred_masks"].cpu() == o["vss_masks"]).float().mean().item() > 0.999
