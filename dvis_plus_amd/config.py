@@ -116,6 +116,11 @@ def build_model(cfg, n_things=0):
     predictor = dec_cls(**dec_cls.from_config(cfg, hd.CONVS_DIM, True))
     head = SEM_SEG_HEADS_REGISTRY.get(hd.NAME)(num_classes=hd.NUM_CLASSES, pixel_decoder=pixel_decoder,
                                                transformer_predictor=predictor)
+    arch = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)
+    if arch is MA.MinVIS:                                                     # no tracker / refiner
+        return arch(backbone=backbone, sem_seg_head=head, num_queries=mf.NUM_OBJECT_QUERIES,
+                    size_divisibility=mf.SIZE_DIVISIBILITY, pixel_mean=cfg.MODEL.PIXEL_MEAN,
+                    pixel_std=cfg.MODEL.PIXEL_STD, task="vis").eval()
     hidden = mf.HIDDEN_DIM * (2 if mf.get("REID_BRANCH", True) else 1)       # meta_architecture.py:550-551
     tracker = ReferringTracker_noiser(hidden_channel=hidden, feedforward_channel=mf.DIM_FEEDFORWARD,
                                       num_head=mf.NHEADS, decoder_layer_num=cfg.MODEL.TRACKER.DECODER_LAYERS,

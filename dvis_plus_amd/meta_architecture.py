@@ -127,6 +127,46 @@ class _VideoBase(nn.Module):
 
 
 @META_ARCH_REGISTRY.register()
+class MinVIS(_VideoBase):
+    """MinVIS (dvis_Plus/meta_architecture.py:23-407, eval): per-frame segmenter, frame-by-frame Hungarian alignment of
+    the decoder embeddings (match_from_embds :255-264 — cosine WITHOUT the tracker's 1e-6), logits averaged over the
+    aligned frames, top-10 (query, class) pairs.  Takes the `_minvis` decoder.
+
+    Same results, different schedule: every frame's cost matrix against its predecessor comes from one batched GEMM and
+    the alignment recurrence runs in one host call (dvis_match_chain — permuting the previous frame only permutes the
+    columns of the cost matrix); masks are contracted for the 10 selected query slots only."""
+    TOPK = 10      # hard-coded in the reference (:371)
+
+    @torch.no_grad()
+    def forward(self, batched_inputs):
+        assert len(batched_inputs) == 1 and not self.training
+        from . import functions as Fn
+        from .tracker import match_chain
+        video = batched_inputs[0]
+        images, img_size = self.preprocess(video["image"])
+        pred = self.sem_seg_head.predictor
+        ms, mask_features = self.encode(images)
+        dec, logits, _ = pred._final_heads(pred._run_layers(ms, mask_features), mask_features, False)   # (T,Q,C), (T,Q,K+1)
+        T, Q, _ = dec.shape
+        # ---- alignment chain: frame 0 keeps its order, frame t is matched to the ALIGNED frame t-1
+        idx = torch.arange(Q, device=dec.device).unsqueeze(0).repeat(T, 1)
+        if T > 1:
+            nrm = dec / dec.norm(dim=-1, keepdim=True)
+            cost = 1 - torch.bmm(nrm[1:], nrm[:-1].transpose(1, 2))                    # (T-1, Q, Q): cur x previous
+            idx[1:] = torch.from_numpy(match_chain(cost)).to(dec.device)
+        ar = torch.arange(T, device=dec.device)[:, None]
+        cls = logits[ar, idx].mean(0)                                                   # (Q, K+1), aligned
+        K = self.sem_seg_head.num_classes
+        scores, labels, slot = PP.vis_select(cls, K, self.TOPK)
+        emb = pred.mask_embed(dec[ar, idx[:, slot]])                                    # (T, k, Cm): the slots' queries
+        masks = Fn.mask_logits(emb.contiguous(), mask_features).permute(1, 0, 2, 3)     # (k, T, h, w)
+        out_hw = (video.get("height", img_size[0]), video.get("width", img_size[1]))
+        masks = PP._resize2(masks, images.shape[-2:], img_size, out_hw, sigmoid=False) > 0.
+        return {"image_size": tuple(out_hw), "pred_scores": scores.tolist(), "pred_labels": labels.tolist(),
+                "pred_masks": [m for m in masks], "pred_ids": slot.tolist(), "aligned_indices": idx}
+
+
+@META_ARCH_REGISTRY.register()
 class DVIS_Plus_online(_VideoBase):
     """Segmenter + referring tracker; masks come from the tracker (projected mask features)."""
 
@@ -278,7 +318,8 @@ def build_dvis_plus_r50(mode="offline", *, num_classes=124, num_queries=100, n_t
     from .pixel_decoder import MSDeformAttnPixelDecoder, r50_input_shape
     from .refiner import TemporalRefiner
     from .tracker import ReferringTracker_noiser
-    from .transformer_decoder import VideoMultiScaleMaskedTransformerDecoder_dvisPlus
+    from .transformer_decoder import (VideoMultiScaleMaskedTransformerDecoder_dvisPlus,
+                                      VideoMultiScaleMaskedTransformerDecoder_minvis)
     torch.manual_seed(seed)
     if backbone == "r50":
         in_shape = r50_input_shape()
@@ -294,6 +335,14 @@ def build_dvis_plus_r50(mode="offline", *, num_classes=124, num_queries=100, n_t
         hidden_dim, True, num_classes=num_classes, hidden_dim=hidden_dim, num_queries=num_queries, nheads=nheads,
         dim_feedforward=dim_feedforward, dec_layers=dec_layers - 1, pre_norm=False, mask_dim=hidden_dim,
         enforce_input_project=False, num_frames=1, num_reid_head_layers=3, reid_hidden_dim=hidden_dim)
+    if mode == "minvis":     # configs/dvis_Plus/*/MinVIS_*.yaml: the per-frame decoder without the re-id branch, no tracker
+        predictor = VideoMultiScaleMaskedTransformerDecoder_minvis(
+            hidden_dim, True, num_classes=num_classes, hidden_dim=hidden_dim, num_queries=num_queries, nheads=nheads,
+            dim_feedforward=dim_feedforward, dec_layers=dec_layers - 1, pre_norm=False, mask_dim=hidden_dim,
+            enforce_input_project=False, num_frames=1)
+        head = MaskFormerHead(num_classes=num_classes, pixel_decoder=pixel_decoder, transformer_predictor=predictor)
+        return MinVIS(backbone=_make_backbone(backbone), sem_seg_head=head, num_queries=num_queries, task="vis",
+                      segmenter_chunk=segmenter_chunk).eval()
     head = MaskFormerHead(num_classes=num_classes, pixel_decoder=pixel_decoder, transformer_predictor=predictor)
     tracker = ReferringTracker_noiser(hidden_channel=2 * hidden_dim, feedforward_channel=dim_feedforward,
                                       num_head=nheads, decoder_layer_num=tracker_layers, noise_mode="wa",

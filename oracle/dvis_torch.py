@@ -486,3 +486,42 @@ def maskformer_image_forward(sd, backbone, image, *, nheads=8, enc_layers=6, dec
                           align_corners=False)[0]
     cls = F.softmax(out["pred_logits"][0], dim=-1)[..., :-1]
     return torch.einsum("qc,qhw->chw", cls, masks.sigmoid()), out["pred_logits"], out["pred_masks"]
+
+
+# --------------------------------------------------------------------------- MinVIS (meta_architecture.py:23-407)
+def minvis_match(tgt_embds, cur_embds):
+    """MinVIS.match_from_embds, meta_architecture.py:255-264: cosine cost WITHOUT the 1e-6 of Noiser.match_embds."""
+    from scipy.optimize import linear_sum_assignment
+    cur = cur_embds / cur_embds.norm(dim=1)[:, None]
+    tgt = tgt_embds / tgt_embds.norm(dim=1)[:, None]
+    C = (1 - torch.mm(cur, tgt.transpose(0, 1))).cpu()
+    return linear_sum_assignment(C.transpose(0, 1))[1]
+
+
+def minvis_post_processing(pred_logits, pred_masks, pred_embds):
+    """MinVIS.post_processing, meta_architecture.py:266-301.  (1,T,Q,K+1), (1,Q,T,h,w), (1,C,T,Q) ->
+    logits (1,Q,K+1) averaged over the aligned frames, masks (1,Q,T,h,w) aligned, per-frame permutations."""
+    logits = list(torch.unbind(pred_logits[0]))
+    masks = list(torch.unbind(pred_masks[0].permute(1, 0, 2, 3)))
+    embds = list(torch.unbind(pred_embds[0].permute(1, 2, 0)))
+    out_logits, out_masks, out_embds, perms = [logits[0]], [masks[0]], [embds[0]], [np.arange(logits[0].shape[0])]
+    for i in range(1, len(logits)):
+        idx = minvis_match(out_embds[-1], embds[i])
+        perms.append(np.asarray(idx))
+        out_logits.append(logits[i][idx, :])
+        out_masks.append(masks[i][idx, :, :])
+        out_embds.append(embds[i][idx, :])
+    return (sum(out_logits) / len(out_logits)).unsqueeze(0), torch.stack(out_masks, dim=1).unsqueeze(0), np.stack(perms)
+
+
+def minvis_inference_video(pred_cls, pred_masks, img_size, out_hw, first_resize_size, num_classes, topk=10):
+    """MinVIS.inference_video, meta_architecture.py:362-407 -> (scores, labels, masks bool (k,T,H,W), query index)."""
+    Q = pred_cls.shape[0]
+    scores = F.softmax(pred_cls, dim=-1)[:, :-1]
+    labels = torch.arange(num_classes).unsqueeze(0).repeat(Q, 1).flatten(0, 1)
+    s, idx = scores.flatten(0, 1).topk(topk, sorted=False)
+    q = idx // num_classes
+    m = F.interpolate(pred_masks[q], size=tuple(first_resize_size), mode="bilinear", align_corners=False)
+    m = m[:, :, :img_size[0], :img_size[1]]
+    m = F.interpolate(m, size=tuple(out_hw), mode="bilinear", align_corners=False)
+    return s, labels[idx], m > 0., q

@@ -310,6 +310,30 @@ def g6_postprocess():
                   img_size=img_size, out_hw=out_hw, first_resize=first))
 
 
+def g9_minvis():
+    """MinVIS.post_processing (frame-by-frame Hungarian alignment, meta_architecture.py:255-301) + inference_video
+    (top-10, :362-407) on random decoder outputs with permuted, noisy embeddings."""
+    ma = R.ref_meta()
+    cls = ma.MinVIS
+    K, Q, T, C = 6, 14, 5, 16
+    g = torch.Generator().manual_seed(90)
+    stub = types.SimpleNamespace(sem_seg_head=types.SimpleNamespace(num_classes=K), num_queries=Q, device="cpu")
+    stub.match_from_embds = types.MethodType(cls.match_from_embds, stub)
+    base = torch.randn(C, Q, generator=g)
+    embds = torch.stack([base[:, torch.randperm(Q, generator=g)] + 0.25 * torch.randn(C, Q, generator=g)
+                         for _ in range(T)], 1)[None]                                   # (1, C, T, Q)
+    logits = torch.randn(1, T, Q, K + 1, generator=g) * 2
+    masks = torch.randn(1, Q, T, 10, 14, generator=g) * 3
+    out = cls.post_processing(stub, dict(pred_logits=logits.clone(), pred_masks=masks.clone(), pred_embds=embds.clone()))
+    img_size, out_hw, first = (37, 53), (30, 45), (40, 56)
+    vid = cls.inference_video(stub, out["pred_logits"][0].clone(), out["pred_masks"][0].clone(), img_size, *out_hw, first)
+    save("g9_minvis", ins=dict(pred_logits=logits, pred_masks=masks, pred_embds=embds),
+         outs=dict(pp_logits=out["pred_logits"], pp_masks=out["pred_masks"],
+                   scores=np.array(vid["pred_scores"], dtype=np.float32),
+                   labels=np.array(vid["pred_labels"], dtype=np.int64), masks=torch.stack(vid["pred_masks"])),
+         seed=90, cfg=dict(K=K, Q=Q, T=T, C=C, img_size=img_size, out_hw=out_hw, first_resize=first, topk=10))
+
+
 def g7_head_dim_32():
     """g2 / g3 at conv_dim = hidden = 64 with 2 heads (head dim 32): the narrowest width the HIP kernels serve, so the
     GPU tests can compare the product against the reference's outputs directly (g4 already has head dim 32)."""
@@ -365,6 +389,6 @@ if __name__ == "__main__":
     warnings.filterwarnings("ignore")
     torch.set_num_threads(1)  # deterministic reduction order in the generating run
     only = sys.argv[1:]
-    for fn in (g1_msda, g2_pixel_decoder, g3_decoder, g4_tracker_refiner, g5_match, g6_postprocess, g7_head_dim_32, g8_vit_adapter):
+    for fn in (g1_msda, g2_pixel_decoder, g3_decoder, g4_tracker_refiner, g5_match, g6_postprocess, g7_head_dim_32, g8_vit_adapter, g9_minvis):
         if not only or fn.__name__.split("_")[0] in only:
             fn()

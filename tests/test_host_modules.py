@@ -348,3 +348,26 @@ def test_image_maskformer_config1_plumbing(oracle_ops):
     assert pan.shape == (48, 72) and pan.dtype == torch.int32 and int(pan.max()) == len(segs)
     inst = out["instances"]
     assert inst["pred_masks"].shape[1:] == (48, 72) and inst["scores"].shape == inst["pred_classes"].shape
+
+
+def test_minvis_meta_architecture_matches_reference_post_processing(oracle_ops):
+    """MinVIS (registry name, `_minvis` decoder): the one-call alignment chain + top-10 selection + masks for the selected
+    slots only == the reference's frame-by-frame post_processing + inference_video applied to the same decoder outputs."""
+    from dvis_plus_amd.meta_architecture import build_dvis_plus_r50
+    from oracle import dvis_torch as O
+    m = build_dvis_plus_r50("minvis", num_classes=6, num_queries=14, hidden_dim=64, nheads=2, dim_feedforward=64,
+                            dec_layers=3, enc_layers=1)
+    frames = _tiny_clip(4)
+    out = m([{"image": frames, "height": 60, "width": 90}])
+    with torch.no_grad():
+        images, img_size = m.preprocess(frames)
+        ref_dec = m.sem_seg_head(m.backbone(images))                       # the `_minvis` decoder's own outputs
+        logits, masks, perms = O.minvis_post_processing(ref_dec["pred_logits"], ref_dec["pred_masks"], ref_dec["pred_embds"])
+        s, l, mk, q = O.minvis_inference_video(logits[0], masks[0], img_size, (60, 90), images.shape[-2:], 6, 10)
+    assert np.array_equal(out["aligned_indices"].numpy(), perms)           # Hungarian chain: bit-exact
+    key_ref, key_out = (q * 100 + l).numpy(), np.array(out["pred_ids"]) * 100 + np.array(out["pred_labels"])
+    o_ref, o_out = np.argsort(key_ref), np.argsort(key_out)
+    assert np.array_equal(key_ref[o_ref], key_out[o_out])
+    np.testing.assert_allclose(np.array(out["pred_scores"])[o_out], s.numpy()[o_ref], rtol=1e-5)
+    got = torch.stack(out["pred_masks"])[torch.as_tensor(o_out)]
+    assert (got == mk[torch.as_tensor(o_ref)]).float().mean().item() > 0.999

@@ -153,3 +153,28 @@ def test_image_mask2former_gpu_vs_oracle():
         sem, _, _ = O.maskformer_image_forward(sd, backbone_from_gpu, img, nheads=8, enc_layers=2, dec_layers=3,
                                                num_classes=19)
     torch.testing.assert_close(out["sem_seg"].cpu(), sem, rtol=1e-3, atol=1e-3)
+
+
+def test_minvis_gpu_vs_oracle():
+    """MinVIS on the GPU: bit-exact alignment chain, same top-10 (query, class) pairs, masks equal away from 0."""
+    from dvis_plus_amd.meta_architecture import build_dvis_plus_r50
+    from oracle import dvis_torch as O
+    m = build_dvis_plus_r50("minvis", num_classes=20, num_queries=100, enc_layers=2, dec_layers=4)
+    _perturb_msda(m.sem_seg_head.pixel_decoder)
+    g = torch.Generator().manual_seed(5)
+    frames = [torch.randint(0, 256, (3, 120, 200), dtype=torch.uint8, generator=g) for _ in range(4)]
+    m = m.to(DEV)
+    out = m([{"image": [f.to(DEV) for f in frames], "height": 120, "width": 200}])
+    with torch.no_grad():
+        images, img_size = m.preprocess([f.to(DEV) for f in frames])
+        dec = m.sem_seg_head(m.backbone(images))                           # product decoder outputs (parity-tested above)
+        lg, mk, em = dec["pred_logits"].cpu(), dec["pred_masks"].cpu(), dec["pred_embds"].cpu()
+        logits, masks, perms = O.minvis_post_processing(lg, mk, em)
+        s, l, ref_m, q = O.minvis_inference_video(logits[0], masks[0], img_size, (120, 200), images.shape[-2:], 20, 10)
+    assert np.array_equal(out["aligned_indices"].cpu().numpy(), perms)
+    key_ref, key_out = (q * 1000 + l).numpy(), np.array(out["pred_ids"]) * 1000 + np.array(out["pred_labels"])
+    o_ref, o_out = np.argsort(key_ref), np.argsort(key_out)
+    assert np.array_equal(key_ref[o_ref], key_out[o_out])
+    np.testing.assert_allclose(np.array(out["pred_scores"])[o_out], s.numpy()[o_ref], rtol=1e-3, atol=1e-5)
+    got = torch.stack(out["pred_masks"]).cpu()[torch.as_tensor(o_out)]
+    assert (got == ref_m[torch.as_tensor(o_ref)]).float().mean().item() > 0.999

@@ -99,3 +99,18 @@ def test_postprocessing_integer_outputs_bit_exact():
     sem = O.inference_video_vss(logits, masks, img, out_hw, first, aux)
     assert torch.equal(sem, o["vss_masks"])
     assert torch.equal(O.get_instance_labels(i["pred_logits"]), o["instance_labels"])
+
+
+def test_minvis_alignment_and_top10():
+    g = Golden("g9_minvis")
+    i, o, cfg = g.ins, g.outs, g.meta["cfg"]
+    logits, masks, perms = O.minvis_post_processing(i["pred_logits"], i["pred_masks"], i["pred_embds"])
+    torch.testing.assert_close(logits, o["pp_logits"], **TOL)
+    assert torch.equal(masks, o["pp_masks"])                                    # pure re-ordering: bit-exact
+    assert sorted(perms[-1].tolist()) == list(range(cfg["Q"]))
+    s, l, m, _ = O.minvis_inference_video(logits[0], masks[0], cfg["img_size"], cfg["out_hw"], cfg["first_resize"],
+                                          cfg["K"], cfg["topk"])
+    order_ref, order = np.argsort(-o["scores"].numpy(), kind="stable"), np.argsort(-s.numpy(), kind="stable")
+    np.testing.assert_allclose(s.numpy()[order], o["scores"].numpy()[order_ref], rtol=1e-6)
+    assert np.array_equal(l.numpy()[order], o["labels"].numpy()[order_ref])
+    assert torch.equal(m[order], o["masks"][order_ref])
