@@ -300,8 +300,8 @@ class VideoMultiScaleMaskedTransformerDecoder_dvisPlus(_MaskedDecoderBase):
 
 
 @TRANSFORMER_DECODER_REGISTRY.register()
-class VideoMultiScaleMaskedTransformerDecoder_minvis(_MaskedDecoderBase):
-    """MinVIS / DVIS per-frame decoder: same layers, single-branch embeddings (dvis_Plus/…decoder.py:11-171)."""
+class VideoMultiScaleMaskedTransformerDecoder_dvis(_MaskedDecoderBase):
+    """DVIS (v1) per-frame decoder: single-branch embeddings, no re-id head (dvis_Plus/…decoder.py:11-145)."""
 
     def __init__(self, in_channels, mask_classification=True, *, num_classes, hidden_dim, num_queries, nheads,
                  dim_feedforward, dec_layers, pre_norm, mask_dim, enforce_input_project, num_frames):
@@ -318,7 +318,20 @@ class VideoMultiScaleMaskedTransformerDecoder_minvis(_MaskedDecoderBase):
         return ret
 
     def forward(self, x, mask_features, mask=None):
+        if self.training:
+            raise NotImplementedError("dvis_plus_amd decoders implement the inference path")
         output = self._run_layers(x, mask_features)
         dec, logits, masks = self._final_heads(output, mask_features, True)
         return {"pred_logits": logits.unsqueeze(0), "pred_masks": masks.permute(1, 0, 2, 3).unsqueeze(0),
-                "aux_outputs": [], "pred_embds": dec.permute(2, 0, 1).unsqueeze(0)}
+                "aux_outputs": [], "pred_embds": dec.permute(2, 0, 1).unsqueeze(0),
+                "pred_embds_without_norm": output.permute(2, 1, 0).unsqueeze(0), "mask_features": mask_features}
+
+
+@TRANSFORMER_DECODER_REGISTRY.register()
+class VideoMultiScaleMaskedTransformerDecoder_minvis(VideoMultiScaleMaskedTransformerDecoder_dvis):
+    """MinVIS: the `_dvis` decoder without `mask_features` in its outputs (…decoder.py:164-171)."""
+
+    def forward(self, x, mask_features, mask=None):
+        out = super().forward(x, mask_features, mask=mask)
+        del out["mask_features"]
+        return out
