@@ -1,23 +1,25 @@
-// MSDeformAttn forward for encoder self-attention, corners served from LDS — gfx950.
+// MSDeformAttn forward for encoder self-attention, corners served from LDS-staged boxes — gfx950.
 //
-// Why: the tiled kernel (msda_forward.hip) pulls every corner of every sample through the per-CU vector L1 — one
-// 128-byte line per (sample, head, corner), 949 MB per 720p frame-layer — and that 64 B/clk/CU path is its bound
-// (24 us per frame-layer at best, 37 us measured).  In encoder self-attention the queries ARE the pixels of the L
-// maps and the sampling offsets are a few pixels around the query's own position, so the samples of an 8x8 tile of
-// queries fall into a small box of every level.  This kernel makes that explicit WITHOUT assuming it:
-//   1. a workgroup owns one head and one 8x8 query tile of one level; it stages the tile's offsets / logits in LDS,
-//      applies softmax and loc = ref + off / (W_l, H_l) there (ops/modules/ms_deform_attn.py:101-109);
-//   2. it reduces, per level, the bounding box of all corners its samples touch (wave min/max + 4 LDS atomics);
-//   3. level by level: if the box has at most CAP pixels, the box is copied once into LDS with coalesced 16-byte
-//      buffer loads (one 128-byte line per pixel, each fetched ONCE instead of once per sample that touches it) and
-//      the 4 corners of every sample are ds_read_b128 from LDS (128 B/clk/CU, no TA/L1 involvement); corners outside
-//      the map read a zero row.  If the box does not fit (large learned offsets, coarse-level query tiles whose
-//      footprint on the fine maps is big) that level falls back to the tiled kernel's global gather with hardware
-//      zero padding — same arithmetic, so the result does not depend on which source served a corner.
-// L1 traffic per 8x8 level-2 tile at the initial offsets (+-4 px): 17x17 + 13x13 + 11x11 = 579 lines staged instead
-// of 64 x 12 x 4 = 3072 gathered.  Grid (M, tiles, N): head fastest => block b on XCD b % 8 == head.
-//
-// Fused interface only (raw offsets / logits + reference points), fp32, D = 32.
+// Why: the tiled kernel (msda_forward.hip) pulls every corner of every sample through the per-CU texture-address / L1
+// pipe — one 128-byte line = two 64-byte accesses per (sample, head, corner), 14.8 M accesses per 720p frame-layer —
+// and that pipe is its bound (TA busy 93 %).  In encoder self-attention the queries ARE the pixels of the L maps and
+// the sampling offsets are a few pixels around the query's own position, so the samples of a small tile of queries
+// fall into a small box of every level.  This kernel makes that explicit WITHOUT assuming it:
+//   1. a workgroup owns one head and one 8x4 query tile of one level; 128 of its threads read the raw offsets / logits
+//      of "their" (query, point) straight into registers, apply softmax and loc = ref + off / (W_l, H_l)
+//      (ops/modules/ms_deform_attn.py:101-109) and set up the bilinear taps of the 3 levels ONCE per (query, sample);
+//   2. the per-level bounding boxes of all touched corners are reduced (wave min/max + 4 LDS atomics per level);
+//   3. the boxes are packed into one LDS region, level 0 first, as long as they fit (kCap pixels); they are copied
+//      with coalesced 16-byte buffer loads — every line fetched ONCE instead of once per sample that touches it —
+//      while the tap threads rewrite their taps into final form: 4 byte offsets into the LDS region (corners outside
+//      the map point at a zero row) or, for a level whose box did not fit, 4 byte offsets into the level's value slice
+//      (out-of-range offset = hardware zero), exactly as the tiled kernel;
+//   4. every lane gathers its 12 samples x 4 corners with ds_read_b128 (or buffer loads for an unstaged level) and
+//      accumulates in the reference's order.
+// Two global round trips and two barriers per tile, ~45 KB of LDS: three workgroups per CU overlap each other.
+// (First form of this kernel: per-lane tap set-up and one stage + barrier pair per level — 55.3 us per frame-layer, VALU
+// 61 % busy, five serialised round trips; history in git.)
+// Fused interface only (raw offsets / logits + reference points), fp32, D = 32, (L, P) = (3, 4), queries = pixels.
 #include <limits.h>
 #include <stdlib.h>
 
@@ -28,41 +30,13 @@ namespace {
 
 using dvis_msda::kOOB;
 
-constexpr int kTile = 64;     // 8x8 queries
-constexpr int kCap = 320;     // pixels of one level box that fit the LDS stage (x 128 B = 40 KB)
+constexpr int kTW = 8, kTH = 4, kTile = kTW * kTH;   // 8x4 queries
+constexpr int kCap = 240;                            // staged pixels of all levels together (x 128 B = 30 KB)
 
 struct BoxTiling {
   int tiles_cum[5];   // first tile index of each level (+ total)
   int tiles_x[4];     // tiles per row of each level
 };
-
-// Bilinear set-up shared by the LDS and the global source.  Identical arithmetic to dvis_msda::make_tap.
-struct Corner {
-  int h0, w0;
-  bool ok, h0ok, h1ok, w0ok, w1ok;
-  float c[4];
-};
-
-__device__ __forceinline__ Corner make_corner(float x, float y, int H, int W, bool active) {
-  Corner t;
-  const float h_im = y * (float)H - 0.5f;
-  const float w_im = x * (float)W - 0.5f;
-  t.ok = active && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
-  const float hf = floorf(h_im), wf = floorf(w_im);
-  t.h0 = (int)hf;
-  t.w0 = (int)wf;
-  const float lh = h_im - hf, lw = w_im - wf;
-  const float hh = 1.f - lh, hw = 1.f - lw;
-  t.h0ok = t.ok && t.h0 >= 0;
-  t.h1ok = t.ok && t.h0 + 1 <= H - 1;
-  t.w0ok = t.w0 >= 0;
-  t.w1ok = t.w0 + 1 <= W - 1;
-  t.c[0] = t.ok ? hh * hw : 0.f;
-  t.c[1] = t.ok ? hh * lw : 0.f;
-  t.c[2] = t.ok ? lh * hw : 0.f;
-  t.c[3] = t.ok ? lh * lw : 0.f;
-  return t;
-}
 
 __device__ __forceinline__ int wave_min(int v) {
 #pragma unroll
@@ -79,21 +53,24 @@ template <int L, int P>
 __global__ __launch_bounds__(256, 3) void msda_fwd_box_f32(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const float *__restrict__ off, int64_t off_stride, const float *__restrict__ logit, int64_t logit_stride,
-    const float *__restrict__ refp, int nref, int S, int M, int Lq, BoxTiling tiling, float *__restrict__ out) {
-  constexpr int D = 32, LP = L * P, G = 8, GPW = 8, LOCV = LP / 2, WV = LP / 4;
-  constexpr int ITERS = kTile / (4 * GPW);   // query groups per wave
-  constexpr int B = 2;                       // samples per batch of corner reads
-  static_assert(LP % 4 == 0 && P == 4, "tile shape");
+    const float *__restrict__ refp, int nref, int S, int M, int Lq, int N, BoxTiling tiling, float *__restrict__ out) {
+  constexpr int D = 32, LP = L * P, G = 8;
+  constexpr int NST = (kCap * G + 255) / 256;        // float4 per thread to stage the whole region
+  static_assert(L == 3 && P == 4 && kTile * G == 256, "shape");
 
-  __shared__ float4 s_loc[kTile * LOCV];
-  __shared__ float4 s_w[kTile * WV];
-  __shared__ float4 s_val[(kCap + 1) * G];   // staged box, pixel-major; pixel kCap is the zero row
-  __shared__ int s_box[L * 4];               // per level: min x, max x, min y, max y of the touched corners
+  __shared__ float4 s_val[(kCap + 1) * G];           // staged boxes, pixel-major; pixel kCap is the zero row
+  __shared__ uint4 s_tap_o[kTile * LP];              // 4 corner byte offsets (LDS or global, see `staged`)
+  __shared__ float4 s_tap_c[kTile * LP];             // 4 corner weights
+  __shared__ float s_aw[kTile * LP];                 // attention weights (softmax over the L*P logits)
+  __shared__ int s_box[L * 4];                       // per level: min x, max x, min y, max y of the touched corners
 
   const int tid = threadIdx.x;
+  const int lane = tid & 63;
   const int m = blockIdx.x;
-  const int n = blockIdx.z;
   const int MD = M * D;
+  const unsigned pix_bytes = (unsigned)MD * 4u;
+  const int ntiles = tiling.tiles_cum[L];
+  const int nitems = N * ntiles;
 
   int Hs[L], Ws[L];
 #pragma unroll
@@ -102,107 +79,125 @@ __global__ __launch_bounds__(256, 3) void msda_fwd_box_f32(
     Ws[l] = (int)shapes[2 * l + 1];
   }
 
-  // ---- this block's 8x8 query tile (all wave-uniform)
-  int ql_lvl = 0;
+  if (threadIdx.x < G) s_val[kCap * G + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // Persistent: gridDim.y workers per head (3 per CU) walk the (frame, tile) items.  With one workgroup per tile the
+  // launch is dispatch-bound: 151 k four-wave workgroups of ~9 us each left 2.9 waves resident per CU on average (PMC).
+  struct Geo { int n, y0, x0, h, w, base; };
+  auto decode = [&](int item) -> Geo {
+    Geo r;
+    r.n = item / ntiles;
+    const int tile = item - r.n * ntiles;
+    int lv = 0;
 #pragma unroll
-  for (int ll = 1; ll < L; ++ll)
-    if ((int)blockIdx.y >= tiling.tiles_cum[ll]) ql_lvl = ll;
-  const int t_idx = blockIdx.y - tiling.tiles_cum[ql_lvl];
-  const int tl_y0 = (t_idx / tiling.tiles_x[ql_lvl]) * 8;
-  const int tl_x0 = (t_idx % tiling.tiles_x[ql_lvl]) * 8;
-  int tl_h = Hs[0], tl_w = Ws[0], tl_base = (int)level_start[0];
+    for (int ll = 1; ll < L; ++ll)
+      if (tile >= tiling.tiles_cum[ll]) lv = ll;
+    const int ti = tile - tiling.tiles_cum[lv];
+    r.y0 = (ti / tiling.tiles_x[lv]) * kTH;
+    r.x0 = (ti % tiling.tiles_x[lv]) * kTW;
+    r.h = Hs[0]; r.w = Ws[0]; r.base = (int)level_start[0];
 #pragma unroll
-  for (int ll = 1; ll < L; ++ll)
-    if (ql_lvl == ll) { tl_h = Hs[ll]; tl_w = Ws[ll]; tl_base = (int)level_start[ll]; }
-  auto slot_query = [&](int ql) -> int {
-    const int y = tl_y0 + (ql >> 3), x = tl_x0 + (ql & 7);
-    return (y < tl_h && x < tl_w) ? tl_base + y * tl_w + x : -1;
+    for (int ll = 1; ll < L; ++ll)
+      if (lv == ll) { r.h = Hs[ll]; r.w = Ws[ll]; r.base = (int)level_start[ll]; }
+    return r;
   };
+  auto geo_query = [&](const Geo &gq, int ql) -> int {
+    const int y = gq.y0 + ql / kTW, x = gq.x0 + ql % kTW;
+    return (y < gq.h && x < gq.w) ? gq.base + y * gq.w + x : -1;
+  };
+  // raw parameters of an item for the tap threads ((query tid >> 2, point tid & 3)); loaded one item AHEAD, under the
+  // previous item's gather, so that only the box staging is an exposed global round trip
+  const bool tap_thread = threadIdx.x < kTile * P;
+  float2 ro[L], rr[L];
+  float4 rl[LP / 4];
+  auto load_params = [&](const Geo &gq) {
+    if (tap_thread) {
+      const int q = geo_query(gq, threadIdx.x >> 2);
+      const int p = threadIdx.x & 3;
+      const size_t row = (size_t)gq.n * Lq + (q >= 0 ? q : 0);
+      const float *orow = off + row * off_stride + (size_t)m * (LP * 2);
+      const float *lrow = logit + row * logit_stride + (size_t)m * LP;
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        ro[l] = *reinterpret_cast<const float2 *>(orow + 2 * (l * P + p));
+        rr[l] = *reinterpret_cast<const float2 *>(refp + (((size_t)(nref == 1 ? 0 : gq.n) * Lq + (q >= 0 ? q : 0)) * L + l) * 2);
+      }
+#pragma unroll
+      for (int k = 0; k < LP / 4; ++k) rl[k] = *reinterpret_cast<const float4 *>(lrow + 4 * k);
+    }
+  };
+  Geo cur = decode((int)blockIdx.y < nitems ? blockIdx.y : 0);
+  if ((int)blockIdx.y < nitems) load_params(cur);
+#pragma unroll 1
+  for (int item = blockIdx.y; item < nitems; item += gridDim.y) {
+  const int n = cur.n;
+  auto slot_query = [&](int ql) -> int { return geo_query(cur, ql); };
 
-  // ---- stage raw offsets / logits of the tile (one head) into LDS; empty slots read 0 through the descriptor
-  {
-    const size_t row0 = (size_t)n * Lq;
-    const unsigned lrow = (unsigned)((size_t)off_stride * sizeof(float));
-    const unsigned wrow = (unsigned)((size_t)logit_stride * sizeof(float));
-    const __amdgpu_buffer_rsrc_t lrs =
-        dvis_make_rsrc_uniform(off + row0 * off_stride + (size_t)m * (LP * 2), (unsigned)(Lq - 1) * lrow + LP * 2 * 4);
-    const __amdgpu_buffer_rsrc_t wrs =
-        dvis_make_rsrc_uniform(logit + row0 * logit_stride + (size_t)m * LP, (unsigned)(Lq - 1) * wrow + LP * 4);
-    for (int i = tid; i < kTile * LOCV; i += 256) {
-      const int ql = i / LOCV, k = i - ql * LOCV;
-      const int q = slot_query(ql);
-      const dvis_v4u v =
-          __builtin_amdgcn_raw_buffer_load_b128(lrs, q >= 0 ? (unsigned)q * lrow + (unsigned)k * 16u : kOOB, 0, 0);
-      s_loc[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-    }
-    for (int i = tid; i < kTile * WV; i += 256) {
-      const int ql = i / WV, k = i - ql * WV;
-      const int q = slot_query(ql);
-      const dvis_v4u v =
-          __builtin_amdgcn_raw_buffer_load_b128(wrs, q >= 0 ? (unsigned)q * wrow + (unsigned)k * 16u : kOOB, 0, 0);
-      s_w[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-    }
-    if (tid < L * 4) s_box[tid] = (tid & 1) ? INT_MIN : INT_MAX;
-    if (tid < G) s_val[kCap * G + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  __syncthreads();
-  float *lf = reinterpret_cast<float *>(s_loc);
-  float *wf = reinterpret_cast<float *>(s_w);
-  // loc = ref + off / (W_l, H_l)
-  for (int i = tid; i < kTile * LP; i += 256) {
-    const int ql = i / LP, s = i - ql * LP;
-    const int l = s / P;
+  if (tid < L * 4) s_box[tid] = (tid & 1) ? INT_MIN : INT_MAX;
+  __syncthreads();      // also: every wave is done gathering the previous item (taps / boxes / values are reused)
+
+  // ---- phase 1 (tap threads): parameters (already in registers) -> taps of the 3 levels in registers
+  int t_h0[L], t_w0[L];
+  unsigned t_fl[L];
+  float t_c[L][4];
+  if (tap_thread) {
+    const int ql = tid >> 2, p = tid & 3;
     const int q = slot_query(ql);
-    if (q >= 0) {
-      int Hl = Hs[0], Wl = Ws[0];
+    const bool active = q >= 0;
+    float lg[LP];
 #pragma unroll
-      for (int ll = 1; ll < L; ++ll)
-        if (l == ll) { Hl = Hs[ll]; Wl = Ws[ll]; }
-      const size_t rrow = ((size_t)(nref == 1 ? 0 : n) * Lq + q) * L + l;
-      const float2 r = *reinterpret_cast<const float2 *>(refp + rrow * 2);
-      lf[ql * LP * 2 + 2 * s] = r.x + lf[ql * LP * 2 + 2 * s] / (float)Wl;
-      lf[ql * LP * 2 + 2 * s + 1] = r.y + lf[ql * LP * 2 + 2 * s + 1] / (float)Hl;
-    }
-  }
-  // softmax over the L*P logits of each (query, head)
-  if (tid < kTile) {
-    float *row = wf + tid * LP;
-    float mx = row[0];
+    for (int k = 0; k < LP / 4; ++k) { lg[4 * k] = rl[k].x; lg[4 * k + 1] = rl[k].y; lg[4 * k + 2] = rl[k].z; lg[4 * k + 3] = rl[k].w; }
+    float mx = lg[0];
 #pragma unroll
-    for (int s = 1; s < LP; ++s) mx = fmaxf(mx, row[s]);
+    for (int s = 1; s < LP; ++s) mx = fmaxf(mx, lg[s]);
     float e[LP], sum = 0.f;
 #pragma unroll
-    for (int s = 0; s < LP; ++s) { e[s] = expf(row[s] - mx); sum += e[s]; }
-#pragma unroll
-    for (int s = 0; s < LP; ++s) row[s] = e[s] / sum;
-  }
-  __syncthreads();
-
-  // ---- per level: bounding box of the corners the tile's samples touch.  Thread = (query tid>>2, point tid&3).
-  {
-    const int ql = tid >> 2, p = tid & 3;
-    const bool active = slot_query(ql) >= 0;
+    for (int s = 0; s < LP; ++s) { e[s] = expf(lg[s] - mx); sum += e[s]; }
 #pragma unroll
     for (int l = 0; l < L; ++l) {
-      const float2 xy = *reinterpret_cast<const float2 *>(lf + ql * (LP * 2) + 2 * (l * P + p));
-      const Corner t = make_corner(xy.x, xy.y, Hs[l], Ws[l], active);
-      int x0 = INT_MAX, x1 = INT_MIN, y0 = INT_MAX, y1 = INT_MIN;
-      if (t.ok) {
-        x0 = max(t.w0, 0); x1 = min(t.w0 + 1, Ws[l] - 1);
-        y0 = max(t.h0, 0); y1 = min(t.h0 + 1, Hs[l] - 1);
+      const int H = Hs[l], W = Ws[l];
+      const float x = rr[l].x + ro[l].x / (float)W, y = rr[l].y + ro[l].y / (float)H;
+      const float h_im = y * (float)H - 0.5f, w_im = x * (float)W - 0.5f;
+      const bool ok = active && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+      const float hf = floorf(h_im), wf = floorf(w_im);
+      const int h0 = ok ? (int)hf : 0, w0 = ok ? (int)wf : 0;
+      const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+      const bool h0ok = ok && h0 >= 0, h1ok = ok && h0 + 1 <= H - 1, w0ok = w0 >= 0, w1ok = w0 + 1 <= W - 1;
+      t_h0[l] = h0; t_w0[l] = w0;
+      t_fl[l] = (h0ok && w0ok ? 1u : 0u) | (h0ok && w1ok ? 2u : 0u) | (h1ok && w0ok ? 4u : 0u) | (h1ok && w1ok ? 8u : 0u);
+      t_c[l][0] = ok ? hh * hw : 0.f; t_c[l][1] = ok ? hh * lw : 0.f; t_c[l][2] = ok ? lh * hw : 0.f; t_c[l][3] = ok ? lh * lw : 0.f;
+      s_aw[ql * LP + l * P + p] = e[l * P + p] / sum;
+      int bx0 = INT_MAX, bx1 = INT_MIN, by0 = INT_MAX, by1 = INT_MIN;
+      if (ok) {
+        bx0 = max(w0, 0); bx1 = min(w0 + 1, W - 1);
+        by0 = max(h0, 0); by1 = min(h0 + 1, H - 1);
       }
-      x0 = wave_min(x0); x1 = wave_max(x1); y0 = wave_min(y0); y1 = wave_max(y1);
-      if ((tid & 63) == 0) {
-        atomicMin(&s_box[4 * l], x0);
-        atomicMax(&s_box[4 * l + 1], x1);
-        atomicMin(&s_box[4 * l + 2], y0);
-        atomicMax(&s_box[4 * l + 3], y1);
+      bx0 = wave_min(bx0); bx1 = wave_max(bx1); by0 = wave_min(by0); by1 = wave_max(by1);
+      if (lane == 0) {
+        atomicMin(&s_box[4 * l], bx0); atomicMax(&s_box[4 * l + 1], bx1);
+        atomicMin(&s_box[4 * l + 2], by0); atomicMax(&s_box[4 * l + 3], by1);
       }
     }
   }
   __syncthreads();
 
-  // ---- per-level descriptors over this (frame, head) slice of `value`
+  // ---- boxes -> packing of the LDS region (wave-uniform): level l occupies pixels [pbase[l], pbase[l] + npx[l])
+  int bx0[L], by0[L], bw[L], npx[L], pbase[L];
+  bool staged[L];
+  {
+    int used = 0;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const int x0 = __builtin_amdgcn_readfirstlane(s_box[4 * l]), x1 = __builtin_amdgcn_readfirstlane(s_box[4 * l + 1]);
+      const int y0 = __builtin_amdgcn_readfirstlane(s_box[4 * l + 2]), y1 = __builtin_amdgcn_readfirstlane(s_box[4 * l + 3]);
+      const bool any = x1 >= x0 && y1 >= y0;
+      bx0[l] = any ? x0 : 0; by0[l] = any ? y0 : 0;
+      bw[l] = any ? x1 - x0 + 1 : 1;
+      npx[l] = any ? bw[l] * (y1 - y0 + 1) : 0;
+      staged[l] = used + npx[l] <= kCap;
+      pbase[l] = used;
+      if (staged[l]) used += npx[l];
+    }
+  }
   __amdgpu_buffer_rsrc_t rs[L];
 #pragma unroll
   for (int l = 0; l < L; ++l) {
@@ -210,133 +205,136 @@ __global__ __launch_bounds__(256, 3) void msda_fwd_box_f32(
     rs[l] = dvis_make_rsrc_uniform(base, (unsigned)(((size_t)(Hs[l] * Ws[l] - 1) * MD + D) * sizeof(float)));
   }
 
-  const int lane = tid & 63, wv = tid >> 6;
-  const int g = lane / G, j = lane - g * G;
-  const unsigned pix_bytes = (unsigned)MD * 4u;
-  const unsigned lane_bytes = (unsigned)j * 16u;
-  const char *val_bytes = reinterpret_cast<const char *>(s_val);
-
-  float acc[ITERS][4];
-#pragma unroll
-  for (int it = 0; it < ITERS; ++it) acc[it][0] = acc[it][1] = acc[it][2] = acc[it][3] = 0.f;
-
+  // ---- phase 2a: issue the loads of every staged box (all threads), ONE global round trip.  The region is walked as
+  // one index space [0, used * G): thread-slot i belongs to the level whose pixel range contains i / G.
+  const int used_px = (staged[0] ? npx[0] : 0) + (staged[1] ? npx[1] : 0) + (staged[2] ? npx[2] : 0);
+  unsigned magic[L], org[L];
 #pragma unroll
   for (int l = 0; l < L; ++l) {
-    const int H = Hs[l], W = Ws[l];
-    const int bx0 = __builtin_amdgcn_readfirstlane(s_box[4 * l]);
-    const int bx1 = __builtin_amdgcn_readfirstlane(s_box[4 * l + 1]);
-    const int by0 = __builtin_amdgcn_readfirstlane(s_box[4 * l + 2]);
-    const int by1 = __builtin_amdgcn_readfirstlane(s_box[4 * l + 3]);
-    const bool any = bx1 >= bx0 && by1 >= by0;
-    const int bw = any ? bx1 - bx0 + 1 : 1;
-    const int npx = any ? bw * (by1 - by0 + 1) : 0;
-    const bool in_lds = npx <= kCap;          // wave-uniform (and block-uniform)
-
-    if (in_lds) {
-      if (l > 0) __syncthreads();             // everyone is done reading the previous level's box
-      // pi / bw by multiply-shift: exact for pi * bw < 2^20 (pi < kCap <= 320, bw <= 320)
-      const unsigned magic = ((1u << 20) + (unsigned)bw - 1u) / (unsigned)bw;
-      const unsigned org = (unsigned)(by0 * W + bx0) * pix_bytes;
-      // every load of the box is issued before the first LDS store: ONE global round trip per level, not one per
-      // 256 x 16 B (slots past the box get an out-of-range offset: the hardware returns 0 and nothing is stored)
-      constexpr int NST = (kCap * G + 255) / 256;
-      dvis_v4u st[NST];
+    magic[l] = ((1u << 20) + (unsigned)bw[l] - 1u) / (unsigned)bw[l];
+    org[l] = (unsigned)(by0[l] * Ws[l] + bx0[l]) * pix_bytes;
+  }
+  dvis_v4u st[NST];
 #pragma unroll
-      for (int k = 0; k < NST; ++k) {
-        const int i = tid + 256 * k;
-        const unsigned pi = (unsigned)i >> 3, jj = (unsigned)i & 7u;
-        const unsigned py = (pi * magic) >> 20;
-        const unsigned px = pi - py * (unsigned)bw;
-        st[k] = __builtin_amdgcn_raw_buffer_load_b128(
-            rs[l], i < npx * G ? org + (py * (unsigned)W + px) * pix_bytes + jj * 16u : kOOB, 0, 0);
-      }
+  for (int k = 0; k < NST; ++k) {
+    const int i = tid + 256 * k;
+    const int pi = i >> 3;
+    const unsigned jj = (unsigned)i & 7u;
+    st[k] = dvis_v4u{0u, 0u, 0u, 0u};
 #pragma unroll
-      for (int k = 0; k < NST; ++k) {
-        const int i = tid + 256 * k;
-        if (i < npx * G)
-          s_val[i] = make_float4(__uint_as_float(st[k].x), __uint_as_float(st[k].y), __uint_as_float(st[k].z),
-                                 __uint_as_float(st[k].w));
+    for (int l = 0; l < L; ++l) {
+      if (staged[l] && pi >= pbase[l] && pi < pbase[l] + npx[l]) {
+        const unsigned rel = (unsigned)(pi - pbase[l]);
+        const unsigned py = (rel * magic[l]) >> 20, px = rel - py * (unsigned)bw[l];
+        st[k] = __builtin_amdgcn_raw_buffer_load_b128(rs[l], org[l] + (py * (unsigned)Ws[l] + px) * pix_bytes + jj * 16u, 0, 0);
       }
-      __syncthreads();
     }
+  }
+  // ---- phase 2b (tap threads, under the loads): final tap offsets
+  if (tap_thread) {
+    const int ql = tid >> 2, p = tid & 3;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      uint4 o;
+      if (staged[l]) {
+        const unsigned zero = (unsigned)kCap * 128u;
+        const unsigned o00 = (unsigned)(pbase[l] + (t_h0[l] - by0[l]) * bw[l] + (t_w0[l] - bx0[l])) * 128u;
+        const unsigned rowb = (unsigned)bw[l] * 128u;
+        o.x = (t_fl[l] & 1u) ? o00 : zero;
+        o.y = (t_fl[l] & 2u) ? o00 + 128u : zero;
+        o.z = (t_fl[l] & 4u) ? o00 + rowb : zero;
+        o.w = (t_fl[l] & 8u) ? o00 + rowb + 128u : zero;
+      } else {
+        const unsigned o00 = (unsigned)(t_h0[l] * Ws[l] + t_w0[l]) * pix_bytes;
+        const unsigned rowb = (unsigned)Ws[l] * pix_bytes;
+        o.x = (t_fl[l] & 1u) ? o00 : kOOB;
+        o.y = (t_fl[l] & 2u) ? o00 + pix_bytes : kOOB;
+        o.z = (t_fl[l] & 4u) ? o00 + rowb : kOOB;
+        o.w = (t_fl[l] & 8u) ? o00 + rowb + pix_bytes : kOOB;
+      }
+      const int si = ql * LP + l * P + p;
+      s_tap_o[si] = o;
+      s_tap_c[si] = make_float4(t_c[l][0], t_c[l][1], t_c[l][2], t_c[l][3]);
+    }
+  }
+  // ---- phase 2c: staged registers -> LDS
+#pragma unroll
+  for (int k = 0; k < NST; ++k) {
+    const int i = tid + 256 * k;
+    if (i < used_px * G)
+      s_val[i] = make_float4(__uint_as_float(st[k].x), __uint_as_float(st[k].y), __uint_as_float(st[k].z),
+                             __uint_as_float(st[k].w));
+  }
+  __syncthreads();
 
+  // ---- next item's parameters: in flight during the gather
+  Geo nxt = cur;
+  if (item + (int)gridDim.y < nitems) {
+    nxt = decode(item + gridDim.y);
+    load_params(nxt);
+  }
+  // ---- phase 3: gather.  Lane group g of wave wv = query wv*8 + g; lane j owns channels 4j..4j+3.
+  const int wv = tid >> 6, g = lane >> 3, j = lane & 7;
+  const int ql = wv * 8 + g;
+  const int q = slot_query(ql);
+  const unsigned lane_bytes = (unsigned)j * 16u;
+  const char *vb = reinterpret_cast<const char *>(s_val);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-      const int ql = (it * 4 + wv) * GPW + g;
-      const bool active = slot_query(ql) >= 0;
-      // batches of B samples = 4*B corner reads in flight; rolled so that hipcc does not hoist every load of the level
+  for (int l = 0; l < L; ++l) {
+    constexpr int B = 2;                       // points per batch: 4*B corner reads in flight (register budget)
 #pragma unroll 1
-      for (int pb = 0; pb < P / B; ++pb) {
-        const int s0 = l * P + pb * B;
-        float xy[2 * B], aw[B];
+    for (int pb = 0; pb < P / B; ++pb) {
+      float4 r[4 * B];
+      float4 cw[B];
+      float aw[B];
 #pragma unroll
-        for (int i = 0; i < B / 2; ++i) {
-          const float4 v = *reinterpret_cast<const float4 *>(lf + ql * (LP * 2) + 2 * s0 + 4 * i);
-          xy[4 * i] = v.x; xy[4 * i + 1] = v.y; xy[4 * i + 2] = v.z; xy[4 * i + 3] = v.w;
-        }
+      for (int pp = 0; pp < B; ++pp) {
+        const int si = ql * LP + l * P + pb * B + pp;
+        const uint4 o = s_tap_o[si];
+        cw[pp] = s_tap_c[si];
+        aw[pp] = s_aw[si];
+        if (staged[l]) {
+          r[4 * pp] = *reinterpret_cast<const float4 *>(vb + o.x + lane_bytes);
+          r[4 * pp + 1] = *reinterpret_cast<const float4 *>(vb + o.y + lane_bytes);
+          r[4 * pp + 2] = *reinterpret_cast<const float4 *>(vb + o.z + lane_bytes);
+          r[4 * pp + 3] = *reinterpret_cast<const float4 *>(vb + o.w + lane_bytes);
+        } else {
+          const unsigned oo[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
-        for (int i = 0; i < B / 2; ++i) {
-          const float2 v = *reinterpret_cast<const float2 *>(wf + ql * LP + s0 + 2 * i);
-          aw[2 * i] = v.x; aw[2 * i + 1] = v.y;
-        }
-        float4 r[4 * B];
-        float cw[4 * B];
-#pragma unroll
-        for (int p = 0; p < B; ++p) {
-          const Corner t = make_corner(xy[2 * p], xy[2 * p + 1], H, W, active);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) cw[4 * p + c] = t.c[c];
-          const bool k00 = t.h0ok && t.w0ok, k01 = t.h0ok && t.w1ok, k10 = t.h1ok && t.w0ok, k11 = t.h1ok && t.w1ok;
-          if (in_lds) {
-            const unsigned zero = (unsigned)kCap * 128u + lane_bytes;
-            const unsigned o00 = (unsigned)((t.h0 - by0) * bw + (t.w0 - bx0)) * 128u + lane_bytes;
-            const unsigned row = (unsigned)bw * 128u;
-            r[4 * p] = *reinterpret_cast<const float4 *>(val_bytes + (k00 ? o00 : zero));
-            r[4 * p + 1] = *reinterpret_cast<const float4 *>(val_bytes + (k01 ? o00 + 128u : zero));
-            r[4 * p + 2] = *reinterpret_cast<const float4 *>(val_bytes + (k10 ? o00 + row : zero));
-            r[4 * p + 3] = *reinterpret_cast<const float4 *>(val_bytes + (k11 ? o00 + row + 128u : zero));
-          } else {
-            const unsigned o00 = (unsigned)(t.h0 * W + t.w0) * pix_bytes + lane_bytes;
-            const unsigned o[4] = {k00 ? o00 : kOOB, k01 ? o00 + pix_bytes : kOOB,
-                                   k10 ? o00 + (unsigned)W * pix_bytes : kOOB,
-                                   k11 ? o00 + (unsigned)W * pix_bytes + pix_bytes : kOOB};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const dvis_v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs[l], o[c], 0, 0);
-              r[4 * p + c] =
-                  make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-            }
+          for (int c = 0; c < 4; ++c) {
+            const dvis_v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs[l], oo[c] + lane_bytes, 0, 0);
+            r[4 * pp + c] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
           }
         }
+      }
 #pragma unroll
-        for (int p = 0; p < B; ++p) {
-          const float4 r1 = r[4 * p], r2 = r[4 * p + 1], r3 = r[4 * p + 2], r4 = r[4 * p + 3];
-          const float c1 = cw[4 * p], c2 = cw[4 * p + 1], c3 = cw[4 * p + 2], c4 = cw[4 * p + 3];
-          // reference order: (w1 v1 + w2 v2 + w3 v3 + w4 v4) * weight, accumulated over samples
-          acc[it][0] += (c1 * r1.x + c2 * r2.x + c3 * r3.x + c4 * r4.x) * aw[p];
-          acc[it][1] += (c1 * r1.y + c2 * r2.y + c3 * r3.y + c4 * r4.y) * aw[p];
-          acc[it][2] += (c1 * r1.z + c2 * r2.z + c3 * r3.z + c4 * r4.z) * aw[p];
-          acc[it][3] += (c1 * r1.w + c2 * r2.w + c3 * r3.w + c4 * r4.w) * aw[p];
-        }
+      for (int pp = 0; pp < B; ++pp) {
+        const float4 r1 = r[4 * pp], r2 = r[4 * pp + 1], r3 = r[4 * pp + 2], r4 = r[4 * pp + 3];
+        const float c1 = cw[pp].x, c2 = cw[pp].y, c3 = cw[pp].z, c4 = cw[pp].w;
+        // reference order: (w1 v1 + w2 v2 + w3 v3 + w4 v4) * weight, accumulated over samples
+        a0 += (c1 * r1.x + c2 * r2.x + c3 * r3.x + c4 * r4.x) * aw[pp];
+        a1 += (c1 * r1.y + c2 * r2.y + c3 * r3.y + c4 * r4.y) * aw[pp];
+        a2 += (c1 * r1.z + c2 * r2.z + c3 * r3.z + c4 * r4.z) * aw[pp];
+        a3 += (c1 * r1.w + c2 * r2.w + c3 * r3.w + c4 * r4.w) * aw[pp];
       }
     }
   }
-
-  float *const out_frame = out + ((size_t)n * Lq * M + m) * D;
-#pragma unroll
-  for (int it = 0; it < ITERS; ++it) {
-    const int q = slot_query((it * 4 + wv) * GPW + g);
-    if (q >= 0)
-      *reinterpret_cast<float4 *>(out_frame + (size_t)q * MD + 4 * j) =
-          make_float4(acc[it][0], acc[it][1], acc[it][2], acc[it][3]);
-  }
+  if (q >= 0)
+    *reinterpret_cast<float4 *>(out + (((size_t)n * Lq + q) * M + m) * D + 4 * j) = make_float4(a0, a1, a2, a3);
+  cur = nxt;
+  }   // items
 }
 
-// OFF by default: measured on MI355X (30 frames / launch, init-rule offsets, every level-2 tile's boxes fit):
-// 55.3 us per frame-layer vs 35.2 us for the tiled kernel.  PMC: LDS only 11 % busy, but 6.3e8 VALU instructions per
-// launch (61 % VALU utilisation: box reduction, staging addresses, per-lane taps) and — the real limit — five
-// serialised global round trips per workgroup (offsets, reference points, three box stages) with only 3 workgroups
-// per CU (50 KB of LDS each) to overlap them.  DVIS_MSDA_BOX=1 enables it for experiments.
+// OFF by default (DVIS_MSDA_BOX=1 enables it; parity-tested against the tiled kernel).  Measured on MI355X, 30 frames
+// per launch, init-rule offsets (every level-2 tile's boxes fit): 61.5 us per frame-layer vs 35.2 us for the tiled kernel,
+// although the L1 accesses drop 3.4x (TCP_TOTAL_CACHE_ACCESSES 1.3e8 vs 4.5e8, TA busy 19 %) and LDS is 11 % busy.
+// Switching phases off (results invalid, timing only): without the gather 49.5 us, without the staging loads 56.4 us,
+// without both 41.9 us — parameter loads, tap set-up, box reduction, tap rewrite and three barriers per 32-query tile
+// cost more than the whole tiled kernel.  One workgroup per tile vs a persistent grid: 61.5 vs 60.8 us (not dispatch-
+// bound); prefetching the next tile's parameters under the gather: no change.  With 128 bytes per (pixel, head) the
+// boxes leave 12 waves per CU, too few to cover two dependent global round trips per tile; the tiled kernel's 16-32
+// independent waves per CU hide latency without any barrier after its prologue.
 bool box_enabled() {
   static const bool v = [] {
     const char *e = getenv("DVIS_MSDA_BOX");
@@ -361,14 +359,23 @@ int dvis_msda_box_launch(const float *value, const int64_t *shapes, const int64_
     const int H = (int)shapes_host[2 * l], W = (int)shapes_host[2 * l + 1];
     total += (long long)H * W;
     tiling.tiles_cum[l] = cum;
-    tiling.tiles_x[l] = (W + 7) / 8;
-    cum += ((H + 7) / 8) * ((W + 7) / 8);
+    tiling.tiles_x[l] = (W + kTW - 1) / kTW;
+    cum += ((H + kTH - 1) / kTH) * ((W + kTW - 1) / kTW);
   }
   tiling.tiles_cum[L] = cum;
   // only when the queries are exactly the pixels of the maps (encoder self-attention)
-  if (total != Lq || total != S || cum > 65535 || N > 65535) return DVIS_OK;
+  if (total != Lq || total != S || (long long)N * cum > 0x7fffffffll) return DVIS_OK;
+  static int ncu = [] {
+    hipDeviceProp_t p;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
+    return p.multiProcessorCount;
+  }();
+  long long workers = (3ll * ncu + M - 1) / M;              // 3 resident workgroups per CU (45 KB of LDS each)
+  if (workers > (long long)N * cum) workers = (long long)N * cum;
+  if (workers > 65535) workers = 65535;
   *handled = true;
-  hipLaunchKernelGGL((msda_fwd_box_f32<3, 4>), dim3(M, cum, N), dim3(256), 0, st, value, shapes, level_start, offsets,
-                     off_stride, logits, logit_stride, ref, nref, S, M, Lq, tiling, out);
+  hipLaunchKernelGGL((msda_fwd_box_f32<3, 4>), dim3(M, (unsigned)workers, 1), dim3(256), 0, st, value, shapes, level_start,
+                     offsets, off_stride, logits, logit_stride, ref, nref, S, M, Lq, N, tiling, out);
   return dvis_check_launch("msda_fwd_box_f32");
 }
