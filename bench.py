@@ -138,9 +138,16 @@ def main():
                     help="r50 = the headline config; vitl = BASELINE config #5 (ViT-Adapter-L, use --queries 200)")
     ap.add_argument("--queries", type=int, default=100)
     ap.add_argument("--segmenter-chunk", type=int, default=0, help="frames per segmenter call (0 = all local frames)")
+    ap.add_argument("--clip-stream", type=int, default=1, choices=[0, 1],
+                    help="offline mode: 1 (default) = the K timed clips go through model.stream(): the segmenter of clip "
+                         "i+1 is enqueued before the tracker / refiner / post-processing of clip i, which run on a second "
+                         "stream (all K clips complete inside the timed region); 0 = one forward() per clip, back to back")
     ap.add_argument("--rounds", type=int, default=0,
                     help="offline mode: spans handed to the tracker while the segmenter runs the next span (0 = default)")
     args = ap.parse_args()
+    # a hung collective must not hang the box: dump every thread's Python stack and exit after this many seconds
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("DVIS_BENCH_WATCHDOG", "1500")), exit=True)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist_on = world > 1 or os.environ.get("DVIS_FORCE_COLLECTIVES") == "1"   # dev aid: RCCL calls on a single rank
@@ -210,10 +217,14 @@ def main():
     t0 = time.perf_counter()
     mark = os.environ.get("DVIS_BENCH_MARK") == "1"     # tools/steady_stats.py: marker kernel at each timed step start
     with timer:
-        for _ in range(args.steps):
-            if mark:
-                torch.empty(64, device=device).uniform_()
-            out = step()
+        if args.clip_stream and args.mode == "offline":
+            for out in model.stream(inputs * args.steps):
+                pass
+        else:
+            for _ in range(args.steps):
+                if mark:
+                    torch.empty(64, device=device).uniform_()
+                out = step()
     torch.cuda.synchronize()
     if dist_on:
         torch.distributed.barrier()
@@ -243,7 +254,8 @@ def main():
                                    f"temporal refiner {'on' if args.mode == 'offline' else 'off'}, task={args.task}, "
                                    f"frames sharded {world}-way",
                        "panoptic_candidates": out.get("num_candidates"), "segments": len(out.get("segments_infos", [])),
-                       "tracker_spans": len(model.clip_shard.round_plan(T, getattr(model, "pipeline_rounds", 1))[0])},
+                       "tracker_spans": len(model.clip_shard.round_plan(T, getattr(model, "pipeline_rounds", 1))[0]),
+                       "clip_stream": bool(args.clip_stream and args.mode == "offline")},
             "roofline": {"bound": "hbm", "kernel": "msda_fwd_tile_f32 (fused MSDeformAttn forward)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

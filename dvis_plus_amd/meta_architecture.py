@@ -197,10 +197,92 @@ class DVIS_Plus_online(_VideoBase):
 class DVIS_Plus_offline(_VideoBase):
     """Segmenter + referring tracker + temporal refiner (the north-star path)."""
 
+    # ---- the clip as two phases: everything up to the per-frame queries is asynchronous and rank-local (phase A);
+    # everything after needs the other ranks' queries, host-side assignment and the VPS statistics (phase B).
+    @torch.no_grad()
+    def _segment_phase(self, video):
+        """Phase A on the current stream: this rank's frames through backbone, pixel decoder and decoder.  No host sync,
+        no collective."""
+        frames = video["image"]
+        T = len(frames)
+        lo, hi = self.clip_shard.local_range(T)
+        images, img_size = self.preprocess(frames[lo:hi] if hi > lo else frames[:1])
+        if hi > lo:
+            e, e_nn, lg, mf = self.segment(images)
+        else:
+            ms, mf = None, images.new_zeros((0, self.sem_seg_head.predictor.mask_embed.layers[-1].out_features,
+                                             images.shape[-2] // 4, images.shape[-1] // 4))
+            e, e_nn, lg = self.decode(ms, mf)
+        return dict(video=video, T=T, lo=lo, hi=hi, embds=e, embds_nn=e_nn, logits=lg, mf=mf, img_size=img_size,
+                    padded=tuple(images.shape[-2:]))
+
+    @torch.no_grad()
+    def _track_phase(self, st):
+        """Phase B on the current stream: all-gather of the per-frame queries, tracker, refiner, masks of this rank's
+        frames, post-processing."""
+        video, T, lo, hi = st["video"], st["T"], st["lo"], st["hi"]
+        self.keep = bool(video.get("keep", False))
+        to_bctq = lambda z: z.permute(2, 0, 1).unsqueeze(0)
+        embds, embds_nn, _ = self.clip_shard.all_gather_frames([st["embds"], st["embds_nn"], st["logits"]], T)
+        track = self.tracker(to_bctq(embds), None, resume=self.keep, frame_embeds_no_norm=to_bctq(embds_nn),
+                             need_masks=False)
+        ref = self.refiner(track["pred_embds"], to_bctq(embds_nn), None, need_masks=False)
+        cls, aux = PP.mean_logits(ref["pred_logits"], track["pred_logits"])
+        cls, aux = self.clip_shard.broadcast_from_rank0([cls.contiguous(), aux.contiguous()])
+        emb_local = ref["mask_embed"][:, lo:hi]                                     # (1, t_local, Q, Cm)
+        mf = st["mf"].unsqueeze(0)
+
+        def mask_fn(idx):
+            return self.refiner.predict_masks(emb_local, mf, idx)[0]                # (q', t_local, h, w)
+        img_size = st["img_size"]
+        out_hw = (video.get("height", img_size[0]), video.get("width", img_size[1]))
+        out = self._task_output(cls, aux, mask_fn, img_size, out_hw, st["padded"], hi - lo)
+        out["frame_ids"] = list(range(lo, hi))
+        out["frame_range"] = (lo, hi)
+        return out
+
+    @torch.no_grad()
+    def stream(self, videos):
+        """Throughput mode for a sequence of clips: yields forward([v]) for every v in order, with phase A of clip i+1
+        enqueued BEFORE phase B of clip i blocks on its host-side steps (assignment chain, VPS statistics).  On the GPU
+        phase B runs on a second stream, so the tracker's small, strictly sequential kernels fill in next to the next
+        clip's backbone instead of owning the device.  Same results as calling forward clip by clip (same kernels,
+        same order per clip); per-clip latency is one phase A longer."""
+        overlap = self.device.type == "cuda"
+        main = torch.cuda.current_stream() if overlap else None
+        if overlap and self._tracker_stream is None:
+            self._tracker_stream = torch.cuda.Stream()
+        side = self._tracker_stream if overlap else None
+
+        def phase_b(st):
+            if not overlap:
+                return self._track_phase(st)
+            with torch.cuda.stream(side):
+                side.wait_event(st["done"])
+                for t in (st["embds"], st["embds_nn"], st["logits"], st["mf"]):
+                    t.record_stream(side)                                           # allocated on the main stream
+                return self._track_phase(st)
+
+        prev = None
+        for v in videos:
+            st = self._segment_phase(v)
+            if overlap:
+                st["done"] = torch.cuda.Event()
+                st["done"].record(main)
+            if prev is not None:
+                yield phase_b(prev)
+            prev = st
+        if prev is not None:
+            yield phase_b(prev)
+        if overlap:
+            main.wait_stream(side)
+
     @torch.no_grad()
     def forward(self, batched_inputs):
         assert len(batched_inputs) == 1 and not self.training
         video = batched_inputs[0]
+        if self.pipeline_rounds <= 1:
+            return self._track_phase(self._segment_phase(video))
         self.keep = bool(video.get("keep", False))
         frames = video["image"]
         T = len(frames)

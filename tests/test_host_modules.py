@@ -248,6 +248,38 @@ def test_keep_flag_resumes_tracker_across_calls(oracle_ops):
     assert second["pred_masks"].shape[1] == 3 and whole["pred_masks"].shape[1] == 6
 
 
+def _stream_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import conftest as c
+    from dvis_plus_amd import functions as Fn
+    Fn.attention, Fn.attn_mask, Fn.mask_logits = c._o_attention, c._o_attn_mask, c._o_mask_logits
+    Fn.msda_fused_forward, Fn.MSDeformAttnFunction = c._o_msda_fused, c._OMSDAFunction
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _tiny_model("offline", "vps")
+    clips = [{"image": _tiny_clip(5, seed=s), "height": 70, "width": 100} for s in (3, 4)]
+    outs = [{"masks": o["pred_masks"], "segs": o["segments_infos"], "frame_ids": o["frame_ids"]} for o in m.stream(clips)]
+    torch.save(outs, os.path.join(out_dir, f"s{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_clip_stream_world_size_2_gloo(oracle_ops, tmp_path):
+    """stream() under frame sharding: phase A has no collective, phase B issues them in clip order on every rank."""
+    import torch.multiprocessing as mp
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_stream_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    m = _tiny_model("offline", "vps")
+    parts = [torch.load(tmp_path / f"s{r}.pt") for r in range(2)]
+    for ci, seed in enumerate((3, 4)):
+        single = m([{"image": _tiny_clip(5, seed=seed), "height": 70, "width": 100}])
+        assert torch.equal(torch.cat([p[ci]["masks"] for p in parts], 0), single["pred_masks"])
+        assert all(p[ci]["segs"] == single["segments_infos"] for p in parts)
+        assert [p[ci]["frame_ids"] for p in parts] == [[0, 1, 2], [3, 4]]
+
+
 def _shard_worker(rank, world, port, out_dir, rounds=1, T=5):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
@@ -371,3 +403,16 @@ def test_minvis_meta_architecture_matches_reference_post_processing(oracle_ops):
     np.testing.assert_allclose(np.array(out["pred_scores"])[o_out], s.numpy()[o_ref], rtol=1e-5)
     got = torch.stack(out["pred_masks"])[torch.as_tensor(o_out)]
     assert (got == mk[torch.as_tensor(o_ref)]).float().mean().item() > 0.999
+
+
+def test_clip_stream_equals_clip_by_clip_forward(oracle_ops):
+    """stream(): phase A of clip i+1 is issued before phase B of clip i — same outputs as forward, clip by clip."""
+    m = _tiny_model("offline", "vps")
+    clips = [{"image": _tiny_clip(4, seed=s), "height": 70, "width": 100} for s in (0, 1, 2)]
+    want = [m([c]) for c in clips]
+    got = list(m.stream(clips))
+    assert len(got) == 3
+    for a, b in zip(got, want):
+        assert torch.equal(a["pred_masks"], b["pred_masks"]) and a["segments_infos"] == b["segments_infos"]
+        assert a["pred_ids"] == b["pred_ids"] and a["frame_ids"] == b["frame_ids"]
+    assert list(m.stream([])) == []
