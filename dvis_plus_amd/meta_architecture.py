@@ -12,7 +12,10 @@ Differences by design (same results):
   * no windowing / CPU off-loading: the whole clip's mask_features stay in HBM (1.8 GB at T=30, 720p);
     the reference's 3-frame windows, per-window .cpu() and per-frame scipy syncs disappear;
   * masks are only contracted for the queries post-processing keeps;
-  * optional frame sharding over the GPUs of a node (clip_shard.ClipShard), one all-gather per clip.
+  * optional frame sharding over the GPUs of a node (clip_shard.ClipShard), one all-gather per clip;
+  * DVIS_Plus_offline.stream(videos): throughput mode, the next clip's segmenter overlaps the previous clip's
+    tracker / refiner / post-processing on a second stream (same results as forward, clip by clip).
+Also here: MinVIS (meta_architecture.py:23-407) and the image MaskFormer (mask2former/maskformer_model.py).
 """
 import os
 

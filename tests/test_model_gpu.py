@@ -178,3 +178,23 @@ def test_minvis_gpu_vs_oracle():
     np.testing.assert_allclose(np.array(out["pred_scores"])[o_out], s.numpy()[o_ref], rtol=1e-3, atol=1e-5)
     got = torch.stack(out["pred_masks"]).cpu()[torch.as_tensor(o_out)]
     assert (got == ref_m[torch.as_tensor(o_ref)]).float().mean().item() > 0.999
+
+
+def test_clip_stream_gpu_equals_clip_by_clip():
+    """stream(): phase B of clip i on a second HIP stream under phase A of clip i+1 — identical outputs (same kernels,
+    same per-clip order; only the interleaving on the device changes)."""
+    from dvis_plus_amd.meta_architecture import build_dvis_plus_r50
+    m = build_dvis_plus_r50("offline", task="vps", num_classes=20, num_queries=100, n_things=10, enc_layers=2,
+                            dec_layers=4, tracker_layers=2, refiner_layers=2, object_mask_threshold=0.06).to(DEV)
+    _perturb_msda(m.sem_seg_head.pixel_decoder)
+    clips = []
+    for s in (3, 4, 5):
+        g = torch.Generator().manual_seed(s)
+        clips.append({"image": [torch.randint(0, 256, (3, 120, 200), dtype=torch.uint8, generator=g).to(DEV)
+                                for _ in range(4)], "height": 120, "width": 200})
+    want = [m([c]) for c in clips]
+    got = list(m.stream(clips))
+    torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert torch.equal(a["pred_masks"], b["pred_masks"])
+        assert a["segments_infos"] == b["segments_infos"] and a["pred_ids"] == b["pred_ids"]
