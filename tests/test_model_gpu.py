@@ -198,3 +198,36 @@ def test_clip_stream_gpu_equals_clip_by_clip():
     for a, b in zip(got, want):
         assert torch.equal(a["pred_masks"], b["pred_masks"])
         assert a["segments_infos"] == b["segments_infos"] and a["pred_ids"] == b["pred_ids"]
+
+
+def test_full_size_720p_clip_vs_oracle():
+    """BASELINE shapes end to end: 3 frames of 720p (padded 736x1280), R50 widths (hidden 256, 100 queries, 6 encoder /
+    tracker / refiner layers, 9 decoder layers), product on the GPU vs the oracle's windowed frame-by-frame pipeline on
+    the CPU (from the backbone outputs onward).  Instance task: same top-k (query, class) pairs, scores within 1e-3,
+    masks identical except near-zero logits."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import synthetic_clip
+    from dvis_plus_amd.meta_architecture import build_dvis_plus_r50
+    from oracle import dvis_torch as O
+    m = build_dvis_plus_r50("offline", task="vis", max_num=10)
+    _perturb_msda(m.sem_seg_head.pixel_decoder)
+    sd = _cpu_sd(m)
+    sd["pixel_mean"], sd["pixel_std"] = m.pixel_mean.clone(), m.pixel_std.clone()
+    m = m.to(DEV)
+    clip = synthetic_clip(3, torch.device(DEV))
+    out = m([{"image": clip, "height": 720, "width": 1280}])
+
+    def backbone_from_gpu(images_cpu):
+        with torch.no_grad():
+            return {k: v.cpu() for k, v in m.backbone(images_cpu.to(DEV)).items()}
+    with torch.no_grad():
+        scores, labels, qidx, masks = O.dvis_plus_forward(sd, backbone_from_gpu, [f for f in clip.cpu()], offline=True,
+                                                          task="vis", max_num=10, out_hw=(720, 1280))
+    key_ref, key_out = qidx * 1000 + labels, out["pred_ids"].cpu() * 1000 + out["pred_labels"].cpu()
+    o_ref, o_out = key_ref.argsort(), key_out.argsort()
+    assert torch.equal(key_ref[o_ref], key_out[o_out])
+    torch.testing.assert_close(out["pred_scores"].cpu()[o_out], scores[o_ref], rtol=1e-3, atol=1e-4)
+    assert out["pred_masks"].shape == (10, 3, 720, 1280)
+    assert (out["pred_masks"].cpu()[o_out] == masks[o_ref]).float().mean().item() > 0.999
