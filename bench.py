@@ -126,7 +126,7 @@ BB_NAME = {"r50": "R50", "vitl": "ViT-Adapter-L", "vitb": "ViT-Adapter-B"}
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=30)
     ap.add_argument("--task", default="vps")
