@@ -54,7 +54,8 @@ template <int D, int L, int P, bool FUSED, int WPS, int B, int QB>
 __global__ __launch_bounds__(256, WPS) void msda_fwd_tile_f32(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const float *__restrict__ loc_or_off, int64_t off_stride, const float *__restrict__ w_or_logit,
-    int64_t logit_stride, const float *__restrict__ refp, int nref, int S, int M, int Lq, float *__restrict__ out) {
+    int64_t logit_stride, const float *__restrict__ refp, int nref, int S, int M, int Lq, float *__restrict__ out,
+    const float *__restrict__ pos_off, const float *__restrict__ pos_logit, int64_t pos_stride) {
   constexpr int LP = L * P;
   constexpr int G = D / 4;          // lanes per (query, head) pair
   constexpr int GPW = 64 / G;       // pairs per wave-instruction
@@ -105,14 +106,24 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile_f32(
       const int q = slot_query(ql);
       const dvis_v4u v = __builtin_amdgcn_raw_buffer_load_b128(
           lrs, q >= 0 ? (unsigned)q * lrow + (unsigned)k * 16u : kOOB, 0, 0);
-      s_loc[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+      float4 f = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+      if (FUSED && pos_off != nullptr && q >= 0) {     // + projection of the query's position embedding (same for all n)
+        const float4 pv = *reinterpret_cast<const float4 *>(pos_off + (size_t)q * pos_stride + (size_t)m * (LP * 2) + 4 * k);
+        f.x += pv.x; f.y += pv.y; f.z += pv.z; f.w += pv.w;
+      }
+      s_loc[i] = f;
     }
     for (int i = tid; i < QB * WV; i += 256) {
       const int ql = i / WV, k = i - ql * WV;
       const int q = slot_query(ql);
       const dvis_v4u v = __builtin_amdgcn_raw_buffer_load_b128(
           wrs, q >= 0 ? (unsigned)q * wrow + (unsigned)k * 16u : kOOB, 0, 0);
-      s_w[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+      float4 f = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+      if (FUSED && pos_logit != nullptr && q >= 0) {
+        const float4 pv = *reinterpret_cast<const float4 *>(pos_logit + (size_t)q * pos_stride + (size_t)m * LP + 4 * k);
+        f.x += pv.x; f.y += pv.y; f.z += pv.z; f.w += pv.w;
+      }
+      s_w[i] = f;
     }
   }
   __syncthreads();
@@ -292,24 +303,24 @@ int tile_variant() {
 template <int D, int L, int P, bool FUSED, int WPS, int B, int QB>
 int launch_variant(const float *value, const int64_t *shapes, const int64_t *ls, const float *a, int64_t a_stride,
                    const float *b, int64_t b_stride, const float *refp, int nref, int N, int S, int M, int Lq, float *out,
-                   hipStream_t st) {
+                   hipStream_t st, const float *pos_off, const float *pos_logit, int64_t pos_stride) {
   const int nchunks = (Lq + QB - 1) / QB;
   if (nchunks > 65535 || N > 65535) {
     dvis_set_error("msda: grid too large (Lq/%d and N must be <= 65535)", QB);
     return DVIS_E_ARG;
   }
   hipLaunchKernelGGL((msda_fwd_tile_f32<D, L, P, FUSED, WPS, B, QB>), dim3(M, nchunks, N), dim3(256), 0, st, value, shapes,
-                     ls, a, a_stride, b, b_stride, refp, nref, S, M, Lq, out);
+                     ls, a, a_stride, b, b_stride, refp, nref, S, M, Lq, out, pos_off, pos_logit, pos_stride);
   return dvis_check_launch("msda_fwd_tile_f32");
 }
 
 template <int D, int L, int P, bool FUSED>
 int launch_tile(const float *value, const int64_t *shapes, const int64_t *ls, const float *a, int64_t a_stride,
                 const float *b, int64_t b_stride, const float *refp, int nref, int N, int S, int M, int Lq, float *out,
-                hipStream_t st) {
+                hipStream_t st, const float *pos_off, const float *pos_logit, int64_t pos_stride) {
 #define DVIS_LAUNCH_VARIANT(wps, bsz, qb) \
   return launch_variant<D, L, P, FUSED, wps, bsz, qb>(value, shapes, ls, a, a_stride, b, b_stride, refp, nref, N, S, M, Lq, \
-                                                      out, st)
+                                                      out, st, pos_off, pos_logit, pos_stride)
   constexpr int QMIN = 4 * (64 / (D / 4));   // queries covered by one pass of the 4 waves
   // (min waves/SIMD the register allocator must allow) x (samples per load batch) x (queries per block).  Measured on
   // MI355X, 720p, 30 frames: 35.2 / 35.2 / 37.0 us per frame-layer — occupancy-insensitive (4 vs 8 waves/SIMD), the
@@ -325,11 +336,13 @@ int launch_tile(const float *value, const int64_t *shapes, const int64_t *ls, co
 template <bool FUSED>
 int dispatch_tile(int D, int L, int P, const float *value, const int64_t *shapes, const int64_t *ls, const float *a,
                   int64_t a_stride, const float *b, int64_t b_stride, const float *refp, int nref, int N, int S, int M,
-                  int Lq, float *out, hipStream_t st, bool *handled) {
+                  int Lq, float *out, hipStream_t st, bool *handled, const float *pos_off = nullptr,
+                  const float *pos_logit = nullptr, int64_t pos_stride = 0) {
   *handled = true;
 #define DVIS_TILE_CASE(d, l, p)  \
   if (D == d && L == l && P == p) \
-    return launch_tile<d, l, p, FUSED>(value, shapes, ls, a, a_stride, b, b_stride, refp, nref, N, S, M, Lq, out, st);
+    return launch_tile<d, l, p, FUSED>(value, shapes, ls, a, a_stride, b, b_stride, refp, nref, N, S, M, Lq, out, st, \
+                                       pos_off, pos_logit, pos_stride);
   DVIS_TILE_CASE(32, 3, 4)
   DVIS_TILE_CASE(32, 4, 4)
   DVIS_TILE_CASE(32, 1, 4)
@@ -371,10 +384,11 @@ DVIS_EXPORT int dvis_msda_forward(int dtype, const void *value, const int64_t *s
   return DVIS_E_ARG;
 }
 
-DVIS_EXPORT int dvis_msda_fused_forward(const float *value, const int64_t *shapes, const int64_t *level_start,
-                                        const float *ref, int Nref, const float *offsets, int64_t off_stride,
-                                        const float *logits, int64_t logit_stride, int N, int S, int M, int D, int L,
-                                        int Lq, int P, float *out, const int64_t *shapes_host, void *stream) {
+DVIS_EXPORT int dvis_msda_fused_forward_pos(const float *value, const int64_t *shapes, const int64_t *level_start,
+                                            const float *ref, int Nref, const float *offsets, int64_t off_stride,
+                                            const float *logits, int64_t logit_stride, const float *pos_offsets,
+                                            const float *pos_logits, int64_t pos_stride, int N, int S, int M, int D,
+                                            int L, int Lq, int P, float *out, const int64_t *shapes_host, void *stream) {
   DVIS_REQUIRE(N >= 0 && S > 0 && M > 0 && D > 0 && L > 0 && Lq >= 0 && P > 0, "msda_fused_forward: bad sizes");
   if (N == 0 || Lq == 0) return DVIS_OK;
   DVIS_REQUIRE(value && shapes && level_start && ref && offsets && logits && out, "msda_fused_forward: null pointer");
@@ -388,6 +402,17 @@ DVIS_EXPORT int dvis_msda_fused_forward(const float *value, const int64_t *shape
   bool handled = false;
   DVIS_REQUIRE((size_t)Lq * (size_t)(off_stride > logit_stride ? off_stride : logit_stride) * sizeof(float) < 0x7fffffffu,
                "msda_fused_forward: one frame of offsets/logits must stay below 2 GiB");
+  const bool has_pos = pos_offsets != nullptr || pos_logits != nullptr;
+  if (has_pos) {
+    DVIS_REQUIRE(pos_offsets && pos_logits && pos_stride >= (int64_t)M * L * P * 2 && pos_stride % 4 == 0 &&
+                     aligned16(pos_offsets) && aligned16(pos_logits),
+                 "msda_fused_forward: position rows need both pointers, 16-byte alignment and a row stride multiple of 4");
+    int rc2 = dispatch_tile<true>(D, L, P, value, shapes, level_start, offsets, off_stride, logits, logit_stride, ref, Nref,
+                                  N, S, M, Lq, out, (hipStream_t)stream, &handled, pos_offsets, pos_logits, pos_stride);
+    if (handled) return rc2;
+    dvis_set_error("msda_fused_forward: unsupported (D=%d, L=%d, P=%d)", D, L, P);
+    return DVIS_E_UNSUPPORTED;
+  }
   // encoder self-attention, persistent software-pipelined LDS kernel (msda_forward_pipe.hip; env-gated)
   int rc = dvis_msda_pipe_launch(value, shapes, level_start, ref, Nref, offsets, off_stride, logits, logit_stride, N, S, M,
                                  D, L, Lq, P, out, shapes_host, (hipStream_t)stream, &handled);
@@ -406,4 +431,12 @@ DVIS_EXPORT int dvis_msda_fused_forward(const float *value, const int64_t *shape
   dvis_set_error("msda_fused_forward: unsupported (D=%d, L=%d, P=%d); supported D in {32,64}, (L,P) in {(1,4),(3,4),(4,4)}",
                  D, L, P);
   return DVIS_E_UNSUPPORTED;
+}
+
+DVIS_EXPORT int dvis_msda_fused_forward(const float *value, const int64_t *shapes, const int64_t *level_start,
+                                        const float *ref, int Nref, const float *offsets, int64_t off_stride,
+                                        const float *logits, int64_t logit_stride, int N, int S, int M, int D, int L,
+                                        int Lq, int P, float *out, const int64_t *shapes_host, void *stream) {
+  return dvis_msda_fused_forward_pos(value, shapes, level_start, ref, Nref, offsets, off_stride, logits, logit_stride,
+                                     nullptr, nullptr, 0, N, S, M, D, L, Lq, P, out, shapes_host, stream);
 }

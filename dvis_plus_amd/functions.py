@@ -99,13 +99,16 @@ class MSDeformAttnFunction(Function):
 
 
 def msda_fused_forward(value, spatial_shapes, level_start_index, reference_points, offsets, logits, n_levels,
-                       n_points, shapes_host=None):
+                       n_points, shapes_host=None, pos_offsets=None, pos_logits=None):
     """Inference fast path of ``MSDeformAttn.forward`` (ops/modules/ms_deform_attn.py:101-117), fp32.
 
     value (N,S,M,D); reference_points (1|N, Lq, L, 2); ``offsets`` / ``logits`` are 2-D row views
     (N*Lq, >= M*L*P*2) / (N*Lq, >= M*L*P) of the raw linear outputs (row stride may exceed the width, e.g.
     both sliced out of one fused projection).  softmax + location arithmetic happen inside the kernel.
     shapes_host: optional [(H, W), ...] python copy of spatial_shapes (enables 8x8 query tiling for self-attention).
+    pos_offsets / pos_logits: optional (Lq, >= M*L*P*2) / (Lq, >= M*L*P) row views with the SAME row stride: the
+    bias-free projections of the queries' position embedding, added to the raw rows inside the kernel
+    (linear(src + pos) = linear(src) + pos W^T), so the caller projects `src` and never forms `src + pos`.
     """
     N, S, M, D = value.shape
     L, P = n_levels, n_points
@@ -123,12 +126,23 @@ def msda_fused_forward(value, spatial_shapes, level_start_index, reference_point
     hs = None
     if shapes_host is not None:
         hs = (ctypes.c_int64 * (2 * L))(*[int(v) for hw in shapes_host for v in hw])
+    po = pl = None
+    pstride = 0
+    if pos_offsets is not None or pos_logits is not None:
+        for name, t, width in (("pos_offsets", pos_offsets, M * L * P * 2), ("pos_logits", pos_logits, M * L * P)):
+            if t is None or not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 \
+                    or t.shape[0] != Lq or t.shape[1] < width:
+                raise RuntimeError(f"{name} must be a float32 GPU (Lq, >= {width}) row view with unit inner stride")
+        if pos_offsets.stride(0) != pos_logits.stride(0):
+            raise RuntimeError("pos_offsets / pos_logits must share their row stride (slices of one projection)")
+        po, pl, pstride = ctypes.c_void_p(pos_offsets.data_ptr()), ctypes.c_void_p(pos_logits.data_ptr()), pos_offsets.stride(0)
     with torch.cuda.device(value.device):
-        rc = native.lib().dvis_msda_fused_forward(
+        rc = native.lib().dvis_msda_fused_forward_pos(
             native.dev_ptr(value, "value"), native.dev_ptr(spatial_shapes, "spatial_shapes"),
             native.dev_ptr(level_start_index, "level_start_index"), native.dev_ptr(reference_points, "ref"), nref,
             ctypes.c_void_p(offsets.data_ptr()), offsets.stride(0), ctypes.c_void_p(logits.data_ptr()),
-            logits.stride(0), N, S, M, D, L, Lq, P, native.dev_ptr(out, "out"), hs, native.stream_ptr(value.device))
+            logits.stride(0), po, pl, pstride, N, S, M, D, L, Lq, P, native.dev_ptr(out, "out"), hs,
+            native.stream_ptr(value.device))
     native.check(rc, "dvis_msda_fused_forward")
     return out
 

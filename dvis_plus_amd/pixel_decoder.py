@@ -122,10 +122,13 @@ class MSDeformAttn(nn.Module):
                 and (self.n_levels, self.n_points) in ((1, 4), (3, 4), (4, 4)))
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
-                input_padding_mask=None, spatial_shapes_py=None):
+                input_padding_mask=None, spatial_shapes_py=None, query_pos=None):
         """Reference signature + one optional extra: `spatial_shapes_py`, a python copy of the shapes.  When the
         queries are the pixels themselves (encoder self-attention) it lets the kernel give each block an 8x8 pixel
-        tile (cache locality); results do not depend on it."""
+        tile (cache locality); results do not depend on it.
+        `query_pos` (second extra): when given, `query` is the query WITHOUT its position embedding ((1, Lq, C), shared by
+        the batch); the fast path projects it once (bias-free) and the kernel adds it to the projected rows, so the
+        (N, Lq, C) sum `query + query_pos` is never formed.  Other paths add it up front."""
         N, Len_q, _ = query.shape
         N, Len_in, _ = input_flatten.shape
         M, L, P = self.n_heads, self.n_levels, self.n_points
@@ -135,12 +138,21 @@ class MSDeformAttn(nn.Module):
         value = value.view(N, Len_in, M, self.d_model // M)
         if self._fast_path_ok(query, reference_points, input_padding_mask):
             w, b = self._fused_projection()
-            proj = F.linear(query.reshape(N * Len_q, self.d_model), w, b)          # offsets | logits in one GEMM
             n_off = M * L * P * 2
+            po = pl = None
+            if query_pos is not None and query_pos.shape[0] == 1:
+                pp = F.linear(query_pos[0], w)                                     # (Lq, 3*M*L*P): tiny, once per call
+                po, pl = pp[:, :n_off], pp[:, n_off:]
+            elif query_pos is not None:
+                query = query + query_pos
+            proj = F.linear(query.reshape(N * Len_q, self.d_model), w, b)          # offsets | logits in one GEMM
             ref = reference_points if reference_points.is_contiguous() else reference_points.contiguous()
             output = Fn.msda_fused_forward(value, input_spatial_shapes, input_level_start_index, ref,
-                                           proj[:, :n_off], proj[:, n_off:], L, P, shapes_host=spatial_shapes_py)
+                                           proj[:, :n_off], proj[:, n_off:], L, P, shapes_host=spatial_shapes_py,
+                                           pos_offsets=po, pos_logits=pl)
             return self.output_proj(output)
+        if query_pos is not None:
+            query = query + query_pos
         sampling_offsets = self.sampling_offsets(query).view(N, Len_q, M, L, P, 2)
         attention_weights = self.attention_weights(query).view(N, Len_q, M, L * P)
         attention_weights = F.softmax(attention_weights, -1).view(N, Len_q, M, L, P)
@@ -174,9 +186,8 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None,
                 shapes_py=None):
-        q = src if pos is None else src + pos
-        src2 = self.self_attn(q, reference_points, src, spatial_shapes, level_start_index, padding_mask,
-                              spatial_shapes_py=shapes_py)
+        src2 = self.self_attn(src, reference_points, src, spatial_shapes, level_start_index, padding_mask,
+                              spatial_shapes_py=shapes_py, query_pos=pos)
         src = Fn.add_layer_norm(src2, src, self.norm1)
         src2 = self.linear2(Fn.linear_relu(src, self.linear1))
         return Fn.add_layer_norm(src2, src, self.norm2)

@@ -96,6 +96,19 @@ int dvis_msda_fused_forward(const float *value, const int64_t *shapes, const int
                             const int64_t *shapes_host, void *stream);
 
 /*
+ * Same, plus the projection of the queries' POSITION embedding: MSDeformAttn is called with query = src + pos
+ * (pixel_decoder/msdeformattn.py:124-126) and only the two linears above read the query, so
+ * linear(src + pos) = linear(src) + (pos W^T).  pos_offsets / pos_logits: one row per QUERY (shared by all N frames,
+ * row stride `pos_stride` floats) of (pos W_off^T) / (pos W_logit^T) WITHOUT bias; added to the raw rows inside the
+ * kernel — the (N, Lq, C) `src + pos` tensor is never formed.  Both NULL = dvis_msda_fused_forward.
+ */
+int dvis_msda_fused_forward_pos(const float *value, const int64_t *shapes, const int64_t *level_start,
+                                const float *ref, int Nref, const float *offsets, int64_t off_stride,
+                                const float *logits, int64_t logit_stride, const float *pos_offsets,
+                                const float *pos_logits, int64_t pos_stride, int N, int S, int M, int D, int L, int Lq,
+                                int P, float *out, const int64_t *shapes_host, void *stream);
+
+/*
  * Mask logits: out[b, q, p] = sum_c embed[b, q, c] * feat[b, c, p]     (fp32, exact-fp32 MFMA)
  *   embed (B, Q, C), feat (B, C, HW), out (B, Q, HW)
  */

@@ -118,13 +118,17 @@ def _o_mask_logits(mask_embed, mask_features):
 
 
 def _o_msda_fused(value, spatial_shapes, level_start_index, reference_points, offsets, logits, n_levels, n_points,
-                  shapes_host=None):
+                  shapes_host=None, pos_offsets=None, pos_logits=None):
     from oracle.msda import msda_forward_torch
     N, S, M, D = value.shape
     Lq = reference_points.shape[1]
     L, P = n_levels, n_points
     off = offsets[:, :M * L * P * 2].reshape(N, Lq, M, L, P, 2)
-    w = torch.softmax(logits[:, :M * L * P].reshape(N, Lq, M, L * P), -1).reshape(N, Lq, M, L, P)
+    lg = logits[:, :M * L * P].reshape(N, Lq, M, L * P)
+    if pos_offsets is not None:
+        off = off + pos_offsets[:, :M * L * P * 2].reshape(1, Lq, M, L, P, 2)
+        lg = lg + pos_logits[:, :M * L * P].reshape(1, Lq, M, L * P)
+    w = torch.softmax(lg, -1).reshape(N, Lq, M, L, P)
     norm = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
     loc = reference_points[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
     return msda_forward_torch(value, spatial_shapes, loc.expand(N, -1, -1, -1, -1, -1), w)

@@ -133,6 +133,29 @@ def test_fused_forward_matches_unfused_module_math():
     assert torch.equal(out, out2)
 
 
+def test_fused_forward_position_rows_equal_preadded_query():
+    """linear(src + pos) = linear(src) + pos W^T: the kernel adds the per-query position rows to the raw rows."""
+    from dvis_plus_amd.functions import msda_fused_forward
+    shapes = [(5, 8), (10, 16), (20, 32)]
+    N, M, D, L, P = 3, 8, 32, 3, 4
+    s, lsi = level_tensors(shapes)
+    S = Lq = int(s.prod(1).sum())
+    g = torch.Generator().manual_seed(13)
+    value = torch.randn(N, S, M, D, generator=g).to(DEV)
+    n_off, n_all = M * L * P * 2, M * L * P * 3
+    proj = (torch.randn(N * Lq, n_all, generator=g) * 2).to(DEV)
+    pos = (torch.randn(Lq, n_all + 4, generator=g)).to(DEV)                   # row stride != width
+    ref_pts = torch.rand(1, Lq, L, 2, generator=g).to(DEV)
+    a = msda_fused_forward(value, s.to(DEV), lsi.to(DEV), ref_pts, proj[:, :n_off], proj[:, n_off:], L, P,
+                           pos_offsets=pos[:, :n_off], pos_logits=pos[:, n_off:n_all])
+    summed = (proj.view(N, Lq, n_all) + pos[None, :, :n_all]).view(N * Lq, n_all)
+    b = msda_fused_forward(value, s.to(DEV), lsi.to(DEV), ref_pts, summed[:, :n_off], summed[:, n_off:], L, P)
+    assert torch.equal(a, b)                                                  # same fp32 additions, same kernel
+    with pytest.raises(RuntimeError):
+        msda_fused_forward(value, s.to(DEV), lsi.to(DEV), ref_pts, proj[:, :n_off], proj[:, n_off:], L, P,
+                           pos_offsets=pos[:, :n_off])
+
+
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_half_precision_forward(dt):
     """fp16/bf16 storage, fp32 accumulation (the reference only dispatches float/double)."""
