@@ -24,7 +24,7 @@ t0, t1 = int(sel[0][s_k]), max(int(r[e_k]) for r in sel)
 agg = defaultdict(lambda: [0, 0])
 for r in sel:
     n = r[name_k].replace("void ", "").replace("(anonymous namespace)::", "")
-    n = re.sub(r"\(.*", "", n)[:100]
+    n = re.sub(r"\(.*", "", n)[:int(__import__("os").environ.get("KNAME", "100"))]
     agg[n][0] += int(r[e_k]) - int(r[s_k])
     agg[n][1] += 1
 busy = sum(v[0] for v in agg.values())
