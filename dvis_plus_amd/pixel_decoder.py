@@ -19,6 +19,7 @@ What is different (MI355X-first, same numbers):
   * sine position embeddings and encoder reference points depend on shapes only and are cached per shape.
 """
 import math
+import os
 import warnings
 
 import torch
@@ -28,6 +29,11 @@ from torch.nn.init import constant_, normal_, xavier_uniform_
 
 from . import functions as Fn
 from .registry import SEM_SEG_HEADS_REGISTRY, ShapeSpec
+
+# DVIS_MSDA_POS=1: add the position embedding's projection inside the MSDA kernel instead of forming src + pos.  Measured
+# on MI355X (T=30, 720p): end to end 180.5 vs 179.1 frames/s (+0.8 %), but the MSDA launch itself 1168 vs 1059 us (its
+# set-up phase reads 22 MB more through scattered 16-byte loads) — a wash, so the plain form stays the default.
+_POS_IN_KERNEL = os.environ.get("DVIS_MSDA_POS", "0") == "1"
 
 
 def _is_power_of_2(n):
@@ -140,7 +146,7 @@ class MSDeformAttn(nn.Module):
             w, b = self._fused_projection()
             n_off = M * L * P * 2
             po = pl = None
-            if query_pos is not None and query_pos.shape[0] == 1:
+            if query_pos is not None and query_pos.shape[0] == 1 and _POS_IN_KERNEL:
                 pp = F.linear(query_pos[0], w)                                     # (Lq, 3*M*L*P): tiny, once per call
                 po, pl = pp[:, :n_off], pp[:, n_off:]
             elif query_pos is not None:
