@@ -328,7 +328,7 @@ class DVIS_Plus_offline(_VideoBase):
             start, end, lo, hi = plan[c]
             a, b = offsets[c]
             whole = a == 0 and b == len(local_ids)
-            ms = None if multi_scale is None else (multi_scale if whole else [m[a:b] for m in multi_scale])
+            ms = None if multi_scale is None else (multi_scale if whole else _slice_maps(multi_scale, a, b))
             e, e_nn, lg = self.decode(ms, mask_features[a:b])
             (e, e_nn, lg), work = shard.all_gather_frames([e, e_nn, lg], end - start, per=k, async_op=True)
             done = torch.cuda.Event() if overlap else None
@@ -378,6 +378,14 @@ class DVIS_Plus_offline(_VideoBase):
         out["frame_ids"] = local_ids                                                # which frames of the clip the masks are
         out["frame_range"] = (local_ids[0], local_ids[-1] + 1) if local_ids and contiguous else None
         return out
+
+
+def _slice_maps(maps, a, b):
+    """Frames [a, b) of a list of (N, C, h, w) maps, keeping the token views of pixel_decoder.TokenMaps."""
+    out = type(maps)(m[a:b] for m in maps)
+    if getattr(maps, "tokens", None) is not None:
+        out.tokens = [t[a:b] for t in maps.tokens]
+    return out
 
 
 def _make_backbone(backbone):

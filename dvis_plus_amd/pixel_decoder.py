@@ -385,16 +385,26 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 pos.append(self.pe_layer.compute(x.shape[2], x.shape[3], x.device))
             y, _, _, shapes_py = self.transformer(srcs, pos)
             bs = y.shape[0]
-            out, start = [], 0
+            out, tokens, start = [], [], 0
             for (h, w) in shapes_py:
-                out.append(y[:, start:start + h * w].transpose(1, 2).reshape(bs, -1, h, w))
+                tokens.append(y[:, start:start + h * w])
+                out.append(tokens[-1].transpose(1, 2).reshape(bs, -1, h, w))      # a strided view, no copy
                 start += h * w
             for idx, f in enumerate(self.in_features[:self.num_fpn_levels][::-1]):
                 x = features[f].float()
                 cur_fpn = self.lateral_convs[idx](x)
                 out.append(self.output_convs[idx](Fn.upsample_add(cur_fpn, out[-1])))
-            multi_scale_features = out[:self.maskformer_num_feature_levels]
+            multi_scale_features = TokenMaps(out[:self.maskformer_num_feature_levels])
+            multi_scale_features.tokens = tokens[:self.maskformer_num_feature_levels]
             return self.mask_features(out[-1]), out[0], multi_scale_features
+
+
+class TokenMaps(list):
+    """The multi-scale feature maps as the reference returns them — a list of (N, C, h, w) tensors — plus `.tokens`:
+    the same data as (N, h*w, C) row-major views of the encoder's output memory.  The masked-attention decoder flattens
+    and transposes every map again (video_mask2former_transformer_decoder.py:267-275); with the tokens at hand it
+    projects K / V straight from the encoder's layout (no NCHW round trip)."""
+    tokens = None
 
 
 def r50_input_shape():
