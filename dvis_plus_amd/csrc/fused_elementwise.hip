@@ -125,7 +125,41 @@ __global__ __launch_bounds__(256) void bias_act_kernel(float *__restrict__ x, co
   }
 }
 
+// out[n][row0 + p][c] = x[n][c][p]: an (N, C, HW) map laid down as HW token rows of a wider (N, S, C) token matrix —
+// the flatten(2).transpose(1, 2) + cat of MSDeformAttnTransformerEncoderOnly.forward (msdeformattn.py:64-79) without
+// torch's strided-copy kernel (0.6 TB/s).  64 x 64 tiles through LDS: reads run along p, writes along c.
+__global__ __launch_bounds__(256) void nchw_to_tokens_kernel(const float *__restrict__ x, float *__restrict__ out, int C,
+                                                             int HW, int64_t S, int64_t row0) {
+  __shared__ float tile[64][65];
+  const int n = blockIdx.z, c0 = blockIdx.y * 64, p0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const float *xb = x + (size_t)n * C * HW;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty + 4 * i, p = p0 + tx;
+    tile[ty + 4 * i][tx] = (c < C && p < HW) ? xb[(size_t)c * HW + p] : 0.f;
+  }
+  __syncthreads();
+  float *ob = out + ((size_t)n * S + row0) * C;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int p = p0 + ty + 4 * i, c = c0 + tx;
+    if (p < HW && c < C) ob[(size_t)p * C + c] = tile[tx][ty + 4 * i];
+  }
+}
+
 }  // namespace
+
+DVIS_EXPORT int dvis_nchw_to_tokens(const float *x, float *out, int64_t N, int C, int64_t HW, int64_t S, int64_t row0,
+                                    void *stream) {
+  DVIS_REQUIRE(N >= 0 && C > 0 && HW > 0 && S >= HW && row0 >= 0 && row0 + HW <= S, "nchw_to_tokens: bad sizes");
+  if (N == 0) return DVIS_OK;
+  DVIS_REQUIRE(x && out, "nchw_to_tokens: null pointer");
+  DVIS_REQUIRE(N <= 65535 && (C + 63) / 64 <= 65535 && HW < (1ll << 31), "nchw_to_tokens: grid too large");
+  hipLaunchKernelGGL(nchw_to_tokens_kernel, dim3((unsigned)((HW + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)N), dim3(256),
+                     0, (hipStream_t)stream, x, out, C, (int)HW, S, row0);
+  return dvis_check_launch("nchw_to_tokens_kernel");
+}
 
 DVIS_EXPORT int dvis_bias_act(float *x, const float *bias, const float *res, int64_t planes, int C, int64_t HW, int relu,
                               void *stream) {

@@ -340,6 +340,25 @@ def linear_relu(x, lin):
     return linear(x, lin.weight, lin.bias, relu=True)
 
 
+def maps_to_tokens(maps):
+    """[(N, C, h_l, w_l)] -> (N, sum h_l*w_l, C): ``torch.cat([m.flatten(2).transpose(1, 2) for m in maps], 1)`` with one
+    tiled transpose per level instead of torch's strided copy.  CPU / non-fp32 / non-contiguous inputs use the torch ops."""
+    if not all(m.is_cuda and m.dtype == torch.float32 and m.is_contiguous() for m in maps) or torch.is_grad_enabled():
+        return torch.cat([m.flatten(2).transpose(1, 2) for m in maps], 1)
+    N, C = maps[0].shape[:2]
+    S = sum(m.shape[2] * m.shape[3] for m in maps)
+    out = torch.empty((N, S, C), dtype=torch.float32, device=maps[0].device)
+    row0 = 0
+    with torch.cuda.device(out.device):
+        for m in maps:
+            HW = m.shape[2] * m.shape[3]
+            rc = native.lib().dvis_nchw_to_tokens(ctypes.c_void_p(m.data_ptr()), ctypes.c_void_p(out.data_ptr()), N, C, HW, S,
+                                                  row0, native.stream_ptr(out.device))
+            native.check(rc, "dvis_nchw_to_tokens")
+            row0 += HW
+    return out
+
+
 def conv1x1(x, weight, bias=None):
     """1x1 stride-1 convolution on NCHW.  On the GPU a channel-REDUCING 1x1 conv (Ci >= Co) is issued as the batched
     library GEMM W (Co,Ci) @ X (N,Ci,HW) instead of a MIOpen convolution: same contraction, same layout, measured on

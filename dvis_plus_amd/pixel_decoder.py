@@ -274,7 +274,7 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
     def forward(self, srcs, pos_embeds):
         """srcs: per level (N, C, H, W); pos_embeds: per level (1|N, C, H, W).  No padding (masks all False)."""
         shapes_py = [(int(s.shape[2]), int(s.shape[3])) for s in srcs]
-        src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
+        src_flatten = Fn.maps_to_tokens(srcs)
         lvl_pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1)
                              for lvl, p in enumerate(pos_embeds)], 1)
         spatial_shapes, level_start_index = self._shape_tensors(shapes_py, src_flatten.device)

@@ -23,6 +23,7 @@
  *                               ReferringCrossAttentionLayer (dvis_Plus/tracker.py:8-92), TemporalRefiner (dvis_Plus/refiner.py:104-139)
  *   dvis_add_layernorm       <- `norm(tgt + tgt2)` of every post-norm residual block (msdeformattn.py:125-131,
  *                               video_mask2former_transformer_decoder.py:47-50,108-111,166-170, tracker.py:51-53)
+ *   dvis_nchw_to_tokens      <- src.flatten(2).transpose(1, 2) + torch.cat over levels, msdeformattn.py:64-79
  *   dvis_bias_act            <- FrozenBN shift + shortcut add + ReLU after each backbone convolution (detectron2 BottleneckBlock)
  *   dvis_upsample_add        <- `cur_fpn + F.interpolate(out[-1], size=..., mode="bilinear")`, msdeformattn.py:347
  *   dvis_vps_argmax          <- two-stage resize + sigmoid + score-weighted argmax + segment areas of inference_video_vps,
@@ -157,6 +158,13 @@ int dvis_add_layernorm(const float *x, const float *res, int64_t res_row_stride,
  */
 int dvis_upsample_add(const float *lateral, const float *top, float *out, int64_t planes, int H, int W, int h, int w,
                       void *stream);
+
+/*
+ * out[n][row0 + p][c] = x[n][c][p]: lays an (N, C, HW) map down as HW rows of an (N, S, C) token matrix — the
+ * flatten(2).transpose(1, 2) + torch.cat over levels of MSDeformAttnTransformerEncoderOnly.forward
+ * (mask2former/modeling/pixel_decoder/msdeformattn.py:64-79).  x contiguous (N, C, HW), out contiguous (N, S, C).
+ */
+int dvis_nchw_to_tokens(const float *x, float *out, int64_t N, int C, int64_t HW, int64_t S, int64_t row0, void *stream);
 
 /*
  * In place on `planes` = N*C contiguous planes of HW floats (NCHW): x = relu?(x + bias[c] + res).  bias (C,) or NULL,

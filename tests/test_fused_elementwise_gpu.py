@@ -74,3 +74,13 @@ def test_bias_act_inplace(N, C, H, W):
             out = bias_act_(xd, b.to(DEV), None if res is None else res.to(DEV), relu)
         assert out.data_ptr() == xd.data_ptr()
         torch.testing.assert_close(out.cpu(), ref, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("N,C,sizes", [(2, 256, [(5, 7), (9, 13), (17, 30)]), (3, 64, [(23, 40)]), (1, 100, [(3, 3), (64, 65)])])
+def test_maps_to_tokens(N, C, sizes):
+    """tiled transpose into the token matrix == flatten(2).transpose(1, 2) + cat (bit-exact: pure data movement)."""
+    from dvis_plus_amd.functions import maps_to_tokens
+    g = torch.Generator().manual_seed(C)
+    maps = [torch.randn(N, C, h, w, generator=g).to("cuda:0") for h, w in sizes]
+    want = torch.cat([m.flatten(2).transpose(1, 2) for m in maps], 1)
+    assert torch.equal(maps_to_tokens(maps), want)
