@@ -321,3 +321,35 @@ torch.save(res, sys.argv[1])
             outs.append(torch.load(f.name))
     for a, b in zip(*outs):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+
+
+def test_fp16_value_experiment_error_bound():
+    """dvis_msda_fused_forward_h16 (experiment): only the sampled values are rounded to fp16, so the output differs from
+    the fp32 kernel by at most 2^-11 * max|value| (convex combination of rounded values) — inside BASELINE's 1e-3."""
+    import ctypes
+    from dvis_plus_amd import native
+    from dvis_plus_amd.functions import msda_fused_forward
+    shapes = [(23, 40), (46, 80), (92, 160)]
+    N, M, D, L, P = 2, 8, 32, 3, 4
+    s, lsi = level_tensors(shapes)
+    S = Lq = int(s.prod(1).sum())
+    g = torch.Generator().manual_seed(21)
+    value = torch.randn(N, S, M, D, generator=g).to(DEV)
+    proj = (torch.randn(N * Lq, M * L * P * 3, generator=g) * 2).to(DEV)
+    ref = torch.rand(1, Lq, L, 2, generator=g).to(DEV)
+    n_off = M * L * P * 2
+    sd, ld = s.to(DEV), lsi.to(DEV)
+    want = msda_fused_forward(value, sd, ld, ref, proj[:, :n_off], proj[:, n_off:], L, P)
+    v16 = value.half().contiguous()
+    out = torch.empty_like(want)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    offs, lgs = proj[:, :n_off], proj[:, n_off:]
+    rc = native.lib().dvis_msda_fused_forward_h16(p(v16), p(sd), p(ld), p(ref), 1, p(offs), offs.stride(0), p(lgs),
+                                                  lgs.stride(0), N, S, M, D, L, Lq, P, p(out),
+                                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    bound = 2.0 ** -11 * value.abs().max().item()
+    assert (out - want).abs().max().item() <= bound * 1.01
+    # and exactly the fp32 kernel on the rounded values
+    exact = msda_fused_forward(v16.float(), sd, ld, ref, offs, lgs, L, P)
+    torch.testing.assert_close(out, exact, rtol=1e-5, atol=1e-6)
