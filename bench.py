@@ -255,7 +255,9 @@ def main():
                                    f"frames sharded {world}-way",
                        "panoptic_candidates": out.get("num_candidates"), "segments": len(out.get("segments_infos", [])),
                        "tracker_spans": len(model.clip_shard.round_plan(T, getattr(model, "pipeline_rounds", 1))[0]),
-                       "clip_stream": bool(args.clip_stream and args.mode == "offline")},
+                       "clip_stream": bool(args.clip_stream and args.mode == "offline"),
+                       "tracker_owner_rounds": bool(args.clip_stream and args.mode == "offline" and world > 1
+                                                    and model.owner_rounds)},
             "roofline": {"bound": "hbm", "kernel": "msda_fwd_tile_f32 (fused MSDeformAttn forward)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

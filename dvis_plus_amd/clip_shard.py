@@ -65,6 +65,14 @@ class ClipShard:
         out = list(gathered.split(widths, dim=-1))
         return (out, work) if async_op else out
 
+    def all_gather_rows(self, row):
+        """row: flat tensor of the same length on every rank -> (world, len), row r from rank r."""
+        if self.world == 1 and not self.force:
+            return row.unsqueeze(0)
+        out = torch.empty(self.world * row.numel(), dtype=row.dtype, device=row.device)
+        dist.all_gather_into_tensor(out, row.contiguous(), group=self.group)
+        return out.view(self.world, row.numel())
+
     def all_reduce_sum(self, x):
         if self.world > 1 or self.force:
             dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)

@@ -64,13 +64,12 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile_f32(
   constexpr int ITERS = QB / (4 * GPW);
   static_assert(LP % 4 == 0 && D % 4 == 0 && 64 % G == 0 && P % B == 0 && QB % (4 * GPW) == 0, "tile shape");
 
-  __shared__ float4 s_loc[QB * LOCV];
-  __shared__ float4 s_w[QB * WV];
   // Bilinear set-up of every (query, sample) of the block, computed ONCE by one thread.  The D/4 lanes of a pair used
   // to redo the same ~50 VALU instructions per sample each: PMC showed 4.1e8 VALU instructions per 30-frame launch =
   // 60 % VALU utilisation, contending with the L1 path for issue slots.
   __shared__ uint4 s_tap_o[QB * LP];    // 4 corner byte offsets (kOOB = outside the map / sample not counted)
   __shared__ float4 s_tap_c[QB * LP];   // 4 corner weights
+  __shared__ float s_aw[QB * LP];       // attention weights
 
   // grid = (M, ceil(Lq/QB), N): x is the fastest dispatch dimension, so linear id % 8 == m % 8 -> head m on XCD m % 8.
   // blockIdx.* are SGPRs: everything derived from them (bases, descriptors) is wave-uniform.
@@ -89,82 +88,85 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile_f32(
   // local slot -> global query index, or -1 when the slot is past the end
   auto slot_query = [&](int ql) -> int { return q0 + ql < Lq ? q0 + ql : -1; };
 
-  // ---- stage (loc, w) [or raw (offsets, logits)] of this block's queries x 1 head into LDS.
-  // Descriptors cover this frame's rows; empty slots get an out-of-range offset and read as 0 without a branch.
-  {
-    const size_t row0 = (size_t)n * Lq;
-    const float *lbase = FUSED ? loc_or_off + row0 * off_stride + (size_t)m * (LP * 2)
-                               : loc_or_off + (row0 * M + m) * (size_t)(LP * 2);
-    const float *wbase = FUSED ? w_or_logit + row0 * logit_stride + (size_t)m * LP
-                               : w_or_logit + (row0 * M + m) * (size_t)LP;
-    const unsigned lrow = (unsigned)((FUSED ? (size_t)off_stride : (size_t)M * LP * 2) * sizeof(float));
-    const unsigned wrow = (unsigned)((FUSED ? (size_t)logit_stride : (size_t)M * LP) * sizeof(float));
-    const __amdgpu_buffer_rsrc_t lrs = dvis_make_rsrc_uniform(lbase, (unsigned)(Lq - 1) * lrow + LP * 2 * 4);
-    const __amdgpu_buffer_rsrc_t wrs = dvis_make_rsrc_uniform(wbase, (unsigned)(Lq - 1) * wrow + LP * 4);
-    for (int i = tid; i < QB * LOCV; i += 256) {
-      const int ql = i / LOCV, k = i - ql * LOCV;
-      const int q = slot_query(ql);
-      const dvis_v4u v = __builtin_amdgcn_raw_buffer_load_b128(
-          lrs, q >= 0 ? (unsigned)q * lrow + (unsigned)k * 16u : kOOB, 0, 0);
-      float4 f = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-      if (FUSED && pos_off != nullptr && q >= 0) {     // + projection of the query's position embedding (same for all n)
-        const float4 pv = *reinterpret_cast<const float4 *>(pos_off + (size_t)q * pos_stride + (size_t)m * (LP * 2) + 4 * k);
-        f.x += pv.x; f.y += pv.y; f.z += pv.z; f.w += pv.w;
-      }
-      s_loc[i] = f;
-    }
-    for (int i = tid; i < QB * WV; i += 256) {
-      const int ql = i / WV, k = i - ql * WV;
-      const int q = slot_query(ql);
-      const dvis_v4u v = __builtin_amdgcn_raw_buffer_load_b128(
-          wrs, q >= 0 ? (unsigned)q * wrow + (unsigned)k * 16u : kOOB, 0, 0);
-      float4 f = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-      if (FUSED && pos_logit != nullptr && q >= 0) {
-        const float4 pv = *reinterpret_cast<const float4 *>(pos_logit + (size_t)q * pos_stride + (size_t)m * LP + 4 * k);
-        f.x += pv.x; f.y += pv.y; f.z += pv.z; f.w += pv.w;
-      }
-      s_w[i] = f;
-    }
-  }
-  __syncthreads();
-  float *lf = reinterpret_cast<float *>(s_loc);
-  float *wf = reinterpret_cast<float *>(s_w);
+  // ---- set-up: thread (query tid / P, point tid % P) reads ITS parameters of all L levels straight into registers —
+  // raw offsets, reference points and the pair's L*P logits (fused) or locations and weights — in ONE global round trip,
+  // then softmax, loc = ref + off / (W_l, H_l) and the taps, and ONE barrier.  (The first form staged the rows in LDS,
+  // synchronised, loaded the reference points, computed, synchronised again: with the gather switched off that set-up
+  // alone took 12.7-15.5 us per 720p frame-layer, and with the loads switched off the kernel still took 23.5 of 35 us.)
   const unsigned pix_bytes = (unsigned)MD * 4u;
-  // ---- one thread per (query, sample): loc = ref + off / (W_l, H_l) if FUSED, then the tap
-  for (int i = tid; i < QB * LP; i += 256) {
-    const int ql = i / LP, s = i - ql * LP;
-    const int l = s / P;
+  static_assert(QB * P <= 256, "one set-up thread per (query, point)");
+  if (tid < QB * P) {
+    const int ql = tid / P, p = tid - ql * P;
     const int q = slot_query(ql);
-    int Hl = Hs[0], Wl = Ws[0];
+    const bool active = q >= 0;
+    const size_t qq = active ? q : 0;
+    float2 xy[L];
+    float aw[L];
+    if (FUSED) {
+      const float *orow = loc_or_off + ((size_t)n * Lq + qq) * off_stride + (size_t)m * (LP * 2);
+      const float *lrow = w_or_logit + ((size_t)n * Lq + qq) * logit_stride + (size_t)m * LP;
+      float2 ro[L], rr[L];
+      float4 rl[LP / 4];
 #pragma unroll
-    for (int ll = 1; ll < L; ++ll)
-      if (l == ll) { Hl = Hs[ll]; Wl = Ws[ll]; }
-    float x = lf[ql * LP * 2 + 2 * s], y = lf[ql * LP * 2 + 2 * s + 1];
-    if (FUSED && q >= 0) {
-      const size_t rrow = ((size_t)(nref == 1 ? 0 : n) * Lq + q) * L + l;
-      const float2 r = *reinterpret_cast<const float2 *>(refp + rrow * 2);
-      x = r.x + x / (float)Wl;
-      y = r.y + y / (float)Hl;
-    }
-    const Tap t = make_tap(x, y, Hl, Wl, q >= 0, pix_bytes, 0u);
-    s_tap_o[i] = make_uint4(t.o[0], t.o[1], t.o[2], t.o[3]);
-    s_tap_c[i] = make_float4(t.c[0], t.c[1], t.c[2], t.c[3]);
-  }
-  if (FUSED) {
-    // softmax over the L*P logits of each (query, head)
-    if (tid < QB) {
-      float *row = wf + tid * LP;
-      float mx = row[0];
+      for (int l = 0; l < L; ++l) {
+        ro[l] = *reinterpret_cast<const float2 *>(orow + 2 * (l * P + p));
+        rr[l] = *reinterpret_cast<const float2 *>(refp + (((size_t)(nref == 1 ? 0 : n) * Lq + qq) * L + l) * 2);
+      }
 #pragma unroll
-      for (int s = 1; s < LP; ++s) mx = fmaxf(mx, row[s]);
+      for (int k = 0; k < LP / 4; ++k) rl[k] = *reinterpret_cast<const float4 *>(lrow + 4 * k);
+      if (pos_off != nullptr) {     // + projection of the query's position embedding (same for all n)
+        const float *prow = pos_off + qq * pos_stride + (size_t)m * (LP * 2);
+        const float *plrow = pos_logit + qq * pos_stride + (size_t)m * LP;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+          const float2 pv = *reinterpret_cast<const float2 *>(prow + 2 * (l * P + p));
+          ro[l].x += pv.x; ro[l].y += pv.y;
+        }
+#pragma unroll
+        for (int k = 0; k < LP / 4; ++k) {
+          const float4 pv = *reinterpret_cast<const float4 *>(plrow + 4 * k);
+          rl[k].x += pv.x; rl[k].y += pv.y; rl[k].z += pv.z; rl[k].w += pv.w;
+        }
+      }
+      float lg[LP];
+#pragma unroll
+      for (int k = 0; k < LP / 4; ++k) { lg[4 * k] = rl[k].x; lg[4 * k + 1] = rl[k].y; lg[4 * k + 2] = rl[k].z; lg[4 * k + 3] = rl[k].w; }
+      float mx = lg[0];
+#pragma unroll
+      for (int s = 1; s < LP; ++s) mx = fmaxf(mx, lg[s]);
       float e[LP], sum = 0.f;
 #pragma unroll
-      for (int s = 0; s < LP; ++s) { e[s] = expf(row[s] - mx); sum += e[s]; }
+      for (int s = 0; s < LP; ++s) { e[s] = expf(lg[s] - mx); sum += e[s]; }
 #pragma unroll
-      for (int s = 0; s < LP; ++s) row[s] = e[s] / sum;
+      for (int l = 0; l < L; ++l) {
+        xy[l].x = rr[l].x + ro[l].x / (float)Ws[l];
+        xy[l].y = rr[l].y + ro[l].y / (float)Hs[l];
+        // e[] is indexed with a compile-time l and a run-time p: select instead of indexing registers dynamically
+        float ev = e[l * P];
+#pragma unroll
+        for (int pp = 1; pp < P; ++pp) ev = (p == pp) ? e[l * P + pp] : ev;
+        aw[l] = ev / sum;
+      }
+    } else {
+      const float *lrow = loc_or_off + (((size_t)n * Lq + qq) * M + m) * (size_t)(LP * 2);
+      const float *wrow = w_or_logit + (((size_t)n * Lq + qq) * M + m) * (size_t)LP;
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        xy[l] = *reinterpret_cast<const float2 *>(lrow + 2 * (l * P + p));
+        aw[l] = wrow[l * P + p];
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const Tap t = make_tap(xy[l].x, xy[l].y, Hs[l], Ws[l], active, pix_bytes, 0u);
+      const int si = ql * LP + l * P + p;
+      s_tap_o[si] = make_uint4(t.o[0], t.o[1], t.o[2], t.o[3]);
+      s_tap_c[si] = make_float4(t.c[0], t.c[1], t.c[2], t.c[3]);
+      s_aw[si] = aw[l];
     }
   }
   __syncthreads();
+  const float *wf = s_aw;
 
   // ---- per-level buffer descriptors over this (frame, head) slice of `value`
   __amdgpu_buffer_rsrc_t rs[L];

@@ -64,6 +64,9 @@ class _VideoBase(nn.Module):
         # offline mode: spans of the clip handed to the tracker while the segmenter works on the next span
         self.pipeline_rounds = int(os.environ.get("DVIS_PIPELINE_ROUNDS", "1"))
         self._tracker_stream = None
+        # stream(): clips go in rounds of `world`, each clip's tracker + refiner on its own rank (DVIS_OWNER_ROUNDS=0:
+        # one clip per round, tracker replicated on every rank)
+        self.owner_rounds = os.environ.get("DVIS_OWNER_ROUNDS", "1") != "0"
         if hasattr(self.sem_seg_head.predictor, "compute_pred_masks"):
             self.sem_seg_head.predictor.compute_pred_masks = False
 
@@ -219,20 +222,19 @@ class DVIS_Plus_offline(_VideoBase):
         return dict(video=video, T=T, lo=lo, hi=hi, embds=e, embds_nn=e_nn, logits=lg, mf=mf, img_size=img_size,
                     padded=tuple(images.shape[-2:]))
 
-    @torch.no_grad()
-    def _track_phase(self, st):
-        """Phase B on the current stream: all-gather of the per-frame queries, tracker, refiner, masks of this rank's
-        frames, post-processing."""
-        video, T, lo, hi = st["video"], st["T"], st["lo"], st["hi"]
-        self.keep = bool(video.get("keep", False))
+    def _track_core(self, embds, embds_nn):
+        """Tracker + refiner over the T gathered frames of one clip: (mask_embed (1,T,Q,Cm), cls (Q,K+1), aux (Q,K+1))."""
         to_bctq = lambda z: z.permute(2, 0, 1).unsqueeze(0)
-        embds, embds_nn, _ = self.clip_shard.all_gather_frames([st["embds"], st["embds_nn"], st["logits"]], T)
         track = self.tracker(to_bctq(embds), None, resume=self.keep, frame_embeds_no_norm=to_bctq(embds_nn),
                              need_masks=False)
         ref = self.refiner(track["pred_embds"], to_bctq(embds_nn), None, need_masks=False)
         cls, aux = PP.mean_logits(ref["pred_logits"], track["pred_logits"])
-        cls, aux = self.clip_shard.broadcast_from_rank0([cls.contiguous(), aux.contiguous()])
-        emb_local = ref["mask_embed"][:, lo:hi]                                     # (1, t_local, Q, Cm)
+        return ref["mask_embed"], cls, aux
+
+    def _finish_phase(self, st, mask_embed, cls, aux):
+        """Masks of this rank's frames + post-processing (VPS segment areas are summed over the ranks)."""
+        video, lo, hi = st["video"], st["lo"], st["hi"]
+        emb_local = mask_embed[:, lo:hi]                                            # (1, t_local, Q, Cm)
         mf = st["mf"].unsqueeze(0)
 
         def mask_fn(idx):
@@ -245,38 +247,94 @@ class DVIS_Plus_offline(_VideoBase):
         return out
 
     @torch.no_grad()
+    def _track_phase(self, st):
+        """Phase B on the current stream: all-gather of the per-frame queries, tracker, refiner (replicated on every
+        rank), masks of this rank's frames, post-processing."""
+        self.keep = bool(st["video"].get("keep", False))
+        embds, embds_nn, _ = self.clip_shard.all_gather_frames([st["embds"], st["embds_nn"], st["logits"]], st["T"])
+        mask_embed, cls, aux = self._track_core(embds, embds_nn)
+        cls, aux = self.clip_shard.broadcast_from_rank0([cls.contiguous(), aux.contiguous()])
+        return self._finish_phase(st, mask_embed, cls, aux)
+
+    @torch.no_grad()
+    def _track_round(self, sts):
+        """Phase B of a round of up to `world` clips with ONE OWNER per clip: the tracker's recurrence and the refiner
+        are strictly sequential small kernels + host-side assignment (23 ms per 30-frame clip on MI355X) that frame
+        sharding cannot split, so replicated on every rank they cap the strong-scaling speed-up at T_clip / 23 ms.  Here
+        clip j of the round is tracked and refined by rank j alone — in parallel with the other ranks' clips — and one
+        more all-gather hands every rank the refined mask embeddings + class logits of all clips of the round (3 MB per
+        clip); masks and post-processing stay sharded by frame.  Collectives per round, same order on every rank: one
+        all-gather per clip (per-frame queries), one all-gather of the results, then the post-processing reductions.
+        The results come from a single rank, so they are bit-identical everywhere without the broadcast of
+        _track_phase.  Clips that resume the tracker state of a previous call (`keep`) take the replicated path."""
+        shard = self.clip_shard
+        m = len(sts)
+        if not self.owner_rounds or (shard.world == 1 and not shard.force) \
+                or any(bool(st["video"].get("keep", False)) for st in sts):
+            return [self._track_phase(st) for st in sts]
+        assert m <= shard.world
+        gathered = [shard.all_gather_frames([st["embds"], st["embds_nn"], st["logits"]], st["T"]) for st in sts]
+        Q, K1 = self.num_queries, sts[0]["logits"].shape[-1]
+        Cm = self.refiner.mask_embed.layers[-1].out_features
+        Tmax = max(st["T"] for st in sts)
+        n_emb, n_cls = Tmax * Q * Cm, Q * K1
+        pack = sts[0]["mf"].new_zeros(n_emb + 2 * n_cls)
+        if shard.rank < m:
+            self.keep = False
+            mask_embed, cls, aux = self._track_core(gathered[shard.rank][0], gathered[shard.rank][1])
+            pack[:mask_embed.numel()] = mask_embed.reshape(-1)
+            pack[n_emb:n_emb + n_cls] = cls.reshape(-1)
+            pack[n_emb + n_cls:] = aux.reshape(-1)
+        rows = shard.all_gather_rows(pack)                                           # (world, n_emb + 2 n_cls)
+        outs = []
+        for j, st in enumerate(sts):
+            T = st["T"]
+            outs.append(self._finish_phase(st, rows[j, :T * Q * Cm].view(1, T, Q, Cm),
+                                           rows[j, n_emb:n_emb + n_cls].view(Q, K1).clone(),
+                                           rows[j, n_emb + n_cls:].view(Q, K1).clone()))
+        return outs
+
+    @torch.no_grad()
     def stream(self, videos):
-        """Throughput mode for a sequence of clips: yields forward([v]) for every v in order, with phase A of clip i+1
-        enqueued BEFORE phase B of clip i blocks on its host-side steps (assignment chain, VPS statistics).  On the GPU
-        phase B runs on a second stream, so the tracker's small, strictly sequential kernels fill in next to the next
-        clip's backbone instead of owning the device.  Same results as calling forward clip by clip (same kernels,
-        same order per clip); per-clip latency is one phase A longer."""
+        """Throughput mode for a sequence of clips: yields forward([v]) for every v in order.  Clips are taken in rounds
+        of `world` (one clip per round on a single GPU); phase A of round i+1 is enqueued BEFORE phase B of round i
+        blocks on its host-side steps (assignment chain, VPS statistics).  On the GPU phase B runs on a second stream,
+        so the tracker's small, strictly sequential kernels fill in next to the next clips' backbone instead of owning
+        the device, and with several ranks every clip of the round has its own tracker rank (_track_round).  Same
+        results as calling forward clip by clip (same kernels, same order per clip); per-clip latency is one round's
+        phase A longer."""
+        import itertools
         overlap = self.device.type == "cuda"
         main = torch.cuda.current_stream() if overlap else None
         if overlap and self._tracker_stream is None:
             self._tracker_stream = torch.cuda.Stream()
         side = self._tracker_stream if overlap else None
+        per_round = self.clip_shard.world if self.owner_rounds else 1
 
-        def phase_b(st):
+        def phase_b(sts):
             if not overlap:
-                return self._track_phase(st)
+                return self._track_round(sts)
             with torch.cuda.stream(side):
-                side.wait_event(st["done"])
-                for t in (st["embds"], st["embds_nn"], st["logits"], st["mf"]):
-                    t.record_stream(side)                                           # allocated on the main stream
-                return self._track_phase(st)
+                for st in sts:
+                    side.wait_event(st["done"])
+                    for t in (st["embds"], st["embds_nn"], st["logits"], st["mf"]):
+                        t.record_stream(side)                                       # allocated on the main stream
+                return self._track_round(sts)
 
-        prev = None
-        for v in videos:
-            st = self._segment_phase(v)
-            if overlap:
-                st["done"] = torch.cuda.Event()
-                st["done"].record(main)
+        it, prev = iter(videos), None
+        while True:
+            sts = []
+            for v in itertools.islice(it, per_round):
+                st = self._segment_phase(v)
+                if overlap:
+                    st["done"] = torch.cuda.Event()
+                    st["done"].record(main)
+                sts.append(st)
             if prev is not None:
-                yield phase_b(prev)
-            prev = st
-        if prev is not None:
-            yield phase_b(prev)
+                yield from phase_b(prev)
+            prev = sts or None
+            if not sts:
+                break
         if overlap:
             main.wait_stream(side)
 

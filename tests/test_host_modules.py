@@ -248,8 +248,12 @@ def test_keep_flag_resumes_tracker_across_calls(oracle_ops):
     assert second["pred_masks"].shape[1] == 3 and whole["pred_masks"].shape[1] == 6
 
 
-def _stream_worker(rank, world, port, out_dir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+STREAM_CLIPS = [(5, 3), (4, 4), (5, 6)]          # (T, seed): ragged rounds — with 2 ranks the last round holds one clip
+
+
+def _stream_worker(rank, world, port, out_dir, owner_rounds):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      DVIS_OWNER_ROUNDS=str(owner_rounds))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -260,24 +264,32 @@ def _stream_worker(rank, world, port, out_dir):
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     m = _tiny_model("offline", "vps")
-    clips = [{"image": _tiny_clip(5, seed=s), "height": 70, "width": 100} for s in (3, 4)]
+    calls = []
+    core = m._track_core
+    m._track_core = lambda *a: (calls.append(1), core(*a))[1]
+    clips = [{"image": _tiny_clip(T, seed=s), "height": 70, "width": 100} for T, s in STREAM_CLIPS]
     outs = [{"masks": o["pred_masks"], "segs": o["segments_infos"], "frame_ids": o["frame_ids"]} for o in m.stream(clips)]
-    torch.save(outs, os.path.join(out_dir, f"s{rank}.pt"))
+    torch.save({"outs": outs, "tracked": len(calls)}, os.path.join(out_dir, f"s{rank}.pt"))
     dist.destroy_process_group()
 
 
-def test_clip_stream_world_size_2_gloo(oracle_ops, tmp_path):
-    """stream() under frame sharding: phase A has no collective, phase B issues them in clip order on every rank."""
+@pytest.mark.parametrize("owner_rounds", [1, 0])
+def test_clip_stream_world_size_2_gloo(oracle_ops, tmp_path, owner_rounds):
+    """stream() under frame sharding: phase A has no collective, phase B issues them in the same order on every rank.
+    owner_rounds=1: clips go in rounds of 2, clip j of a round is tracked + refined by rank j only (3 clips -> rank 0
+    tracks two, rank 1 one) and the results are all-gathered; owner_rounds=0: every rank tracks every clip."""
     import torch.multiprocessing as mp
-    port = 33500 + (os.getpid() % 2000)
-    mp.spawn(_stream_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    port = 33500 + (os.getpid() % 2000) + owner_rounds
+    mp.spawn(_stream_worker, args=(2, port, str(tmp_path), owner_rounds), nprocs=2, join=True)
     m = _tiny_model("offline", "vps")
     parts = [torch.load(tmp_path / f"s{r}.pt") for r in range(2)]
-    for ci, seed in enumerate((3, 4)):
-        single = m([{"image": _tiny_clip(5, seed=seed), "height": 70, "width": 100}])
-        assert torch.equal(torch.cat([p[ci]["masks"] for p in parts], 0), single["pred_masks"])
-        assert all(p[ci]["segs"] == single["segments_infos"] for p in parts)
-        assert [p[ci]["frame_ids"] for p in parts] == [[0, 1, 2], [3, 4]]
+    assert [p["tracked"] for p in parts] == ([2, 1] if owner_rounds else [3, 3])
+    for ci, (T, seed) in enumerate(STREAM_CLIPS):
+        single = m([{"image": _tiny_clip(T, seed=seed), "height": 70, "width": 100}])
+        assert torch.equal(torch.cat([p["outs"][ci]["masks"] for p in parts], 0), single["pred_masks"])
+        assert all(p["outs"][ci]["segs"] == single["segments_infos"] for p in parts)
+        per = (T + 1) // 2
+        assert [p["outs"][ci]["frame_ids"] for p in parts] == [list(range(per)), list(range(per, T))]
 
 
 def _shard_worker(rank, world, port, out_dir, rounds=1, T=5):
