@@ -26,9 +26,12 @@ class ClipShard:
     def frames_per_rank(self, T):
         return (T + self.world - 1) // self.world
 
-    def local_range(self, T):
+    def local_range(self, T, shift=0):
+        """Frames [lo, hi) of this rank: block (rank - shift) mod world of ceil(T/world) frames.  `shift` rotates which
+        rank gets which block — stream() advances it clip by clip so that the short (or empty) last blocks of a ragged
+        split (T=30 over 8 ranks: 4,4,4,4,4,4,4,2) do not always land on the same rank."""
         per = self.frames_per_rank(T)
-        lo = min(T, self.rank * per)
+        lo = min(T, ((self.rank - shift) % self.world) * per)
         return lo, min(T, lo + per)
 
     def round_plan(self, T, rounds=1):
@@ -45,7 +48,7 @@ class ClipShard:
             plan.append((start, end, lo, min(end, lo + k)))
         return plan, k
 
-    def all_gather_frames(self, parts, T, per=None, async_op=False):
+    def all_gather_frames(self, parts, T, per=None, async_op=False, shift=0):
         """parts: list of (t_local, Q, c_i) tensors for this rank's frames.  Returns the same list with all T frames,
         identical on every rank.  One collective on one packed buffer.  `per` = slot size per rank (default
         ceil(T / world)); with async_op the result is (tensors, work) and the caller waits on `work` in the stream that
@@ -61,7 +64,10 @@ class ClipShard:
             packed[:t_local] = torch.cat(parts, dim=-1)
         gathered = torch.empty((self.world * per, Q, sum(widths)), dtype=packed.dtype, device=packed.device)
         work = dist.all_gather_into_tensor(gathered, packed, group=self.group, async_op=async_op)
-        gathered = gathered[:T]                      # ranks are frame-contiguous: padding only sits at the very end
+        if shift % self.world:                       # block b came from rank (b + shift) mod world: back to frame order
+            assert not async_op, "the rotation reads the gathered buffer"
+            gathered = gathered.view(self.world, per, Q, -1).roll(-(shift % self.world), 0).reshape(self.world * per, Q, -1)
+        gathered = gathered[:T]                      # blocks are frame-contiguous: padding only sits at the very end
         out = list(gathered.split(widths, dim=-1))
         return (out, work) if async_op else out
 

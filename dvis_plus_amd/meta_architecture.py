@@ -206,12 +206,12 @@ class DVIS_Plus_offline(_VideoBase):
     # ---- the clip as two phases: everything up to the per-frame queries is asynchronous and rank-local (phase A);
     # everything after needs the other ranks' queries, host-side assignment and the VPS statistics (phase B).
     @torch.no_grad()
-    def _segment_phase(self, video):
+    def _segment_phase(self, video, shift=0):
         """Phase A on the current stream: this rank's frames through backbone, pixel decoder and decoder.  No host sync,
-        no collective."""
+        no collective.  `shift` rotates the block -> rank assignment (ClipShard.local_range)."""
         frames = video["image"]
         T = len(frames)
-        lo, hi = self.clip_shard.local_range(T)
+        lo, hi = self.clip_shard.local_range(T, shift)
         images, img_size = self.preprocess(frames[lo:hi] if hi > lo else frames[:1])
         if hi > lo:
             e, e_nn, lg, mf = self.segment(images)
@@ -219,7 +219,7 @@ class DVIS_Plus_offline(_VideoBase):
             ms, mf = None, images.new_zeros((0, self.sem_seg_head.predictor.mask_embed.layers[-1].out_features,
                                              images.shape[-2] // 4, images.shape[-1] // 4))
             e, e_nn, lg = self.decode(ms, mf)
-        return dict(video=video, T=T, lo=lo, hi=hi, embds=e, embds_nn=e_nn, logits=lg, mf=mf, img_size=img_size,
+        return dict(video=video, T=T, lo=lo, hi=hi, shift=shift, embds=e, embds_nn=e_nn, logits=lg, mf=mf, img_size=img_size,
                     padded=tuple(images.shape[-2:]))
 
     def _track_core(self, embds, embds_nn):
@@ -251,7 +251,8 @@ class DVIS_Plus_offline(_VideoBase):
         """Phase B on the current stream: all-gather of the per-frame queries, tracker, refiner (replicated on every
         rank), masks of this rank's frames, post-processing."""
         self.keep = bool(st["video"].get("keep", False))
-        embds, embds_nn, _ = self.clip_shard.all_gather_frames([st["embds"], st["embds_nn"], st["logits"]], st["T"])
+        embds, embds_nn, _ = self.clip_shard.all_gather_frames([st["embds"], st["embds_nn"], st["logits"]], st["T"],
+                                                               shift=st["shift"])
         mask_embed, cls, aux = self._track_core(embds, embds_nn)
         cls, aux = self.clip_shard.broadcast_from_rank0([cls.contiguous(), aux.contiguous()])
         return self._finish_phase(st, mask_embed, cls, aux)
@@ -273,7 +274,8 @@ class DVIS_Plus_offline(_VideoBase):
                 or any(bool(st["video"].get("keep", False)) for st in sts):
             return [self._track_phase(st) for st in sts]
         assert m <= shard.world
-        gathered = [shard.all_gather_frames([st["embds"], st["embds_nn"], st["logits"]], st["T"]) for st in sts]
+        gathered = [shard.all_gather_frames([st["embds"], st["embds_nn"], st["logits"]], st["T"], shift=st["shift"])
+                    for st in sts]
         Q, K1 = self.num_queries, sts[0]["logits"].shape[-1]
         Cm = self.refiner.mask_embed.layers[-1].out_features
         Tmax = max(st["T"] for st in sts)
@@ -321,11 +323,12 @@ class DVIS_Plus_offline(_VideoBase):
                         t.record_stream(side)                                       # allocated on the main stream
                 return self._track_round(sts)
 
-        it, prev = iter(videos), None
+        it, prev, n = iter(videos), None, 0
         while True:
             sts = []
             for v in itertools.islice(it, per_round):
-                st = self._segment_phase(v)
+                st = self._segment_phase(v, shift=n)      # rotate the ragged split: every rank gets the short blocks in turn
+                n += 1
                 if overlap:
                     st["done"] = torch.cuda.Event()
                     st["done"].record(main)

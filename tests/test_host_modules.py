@@ -286,10 +286,14 @@ def test_clip_stream_world_size_2_gloo(oracle_ops, tmp_path, owner_rounds):
     assert [p["tracked"] for p in parts] == ([2, 1] if owner_rounds else [3, 3])
     for ci, (T, seed) in enumerate(STREAM_CLIPS):
         single = m([{"image": _tiny_clip(T, seed=seed), "height": 70, "width": 100}])
-        assert torch.equal(torch.cat([p["outs"][ci]["masks"] for p in parts], 0), single["pred_masks"])
-        assert all(p["outs"][ci]["segs"] == single["segments_infos"] for p in parts)
+        # clip ci shards with the block -> rank assignment rotated by ci (the short block changes rank every clip)
+        order = [(r - ci) % 2 for r in range(2)]                       # block held by rank r
         per = (T + 1) // 2
-        assert [p["outs"][ci]["frame_ids"] for p in parts] == [list(range(per)), list(range(per, T))]
+        blocks = [list(range(per)), list(range(per, T))]
+        assert [p["outs"][ci]["frame_ids"] for p in parts] == [blocks[b] for b in order]
+        by_block = sorted(range(2), key=lambda r: order[r])
+        assert torch.equal(torch.cat([parts[r]["outs"][ci]["masks"] for r in by_block], 0), single["pred_masks"])
+        assert all(p["outs"][ci]["segs"] == single["segments_infos"] for p in parts)
 
 
 def _shard_worker(rank, world, port, out_dir, rounds=1, T=5):
@@ -428,3 +432,21 @@ def test_clip_stream_equals_clip_by_clip_forward(oracle_ops):
         assert torch.equal(a["pred_masks"], b["pred_masks"]) and a["segments_infos"] == b["segments_infos"]
         assert a["pred_ids"] == b["pred_ids"] and a["frame_ids"] == b["frame_ids"]
     assert list(m.stream([])) == []
+
+
+def test_rotated_blocks_cover_every_frame_once():
+    """ClipShard.local_range(T, shift): for every shift the ranks' blocks tile [0, T) exactly once, and over a round of
+    `world` clips every rank holds the same number of frames (T=30 over 8: 30 each instead of 32 on seven ranks)."""
+    from dvis_plus_amd.clip_shard import ClipShard
+    for world, T in [(8, 30), (4, 30), (3, 5), (2, 1), (8, 3)]:
+        total = [0] * world
+        for shift in range(world):
+            seen = []
+            for r in range(world):
+                sh = ClipShard()
+                sh.world, sh.rank = world, r
+                lo, hi = sh.local_range(T, shift)
+                seen += list(range(lo, hi))
+                total[r] += hi - lo
+            assert sorted(seen) == list(range(T))
+        assert len(set(total)) == 1 and total[0] == T

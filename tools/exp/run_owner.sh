@@ -4,3 +4,5 @@ for n in 2 3; do
 done
 DVIS_DIST_BACKEND=nccl DVIS_FORCE_COLLECTIVES=1 timeout 280 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29539 tools/stream_shard_check.py --clips 3 --frames 6 2>&1 | grep -E "clip |SHARD_CHECK|rror|rank " | head -12
 DVIS_FORCE_COLLECTIVES=1 timeout 280 python bench.py --steps 6 --warmup 1 --no-cpu-baseline 2>&1 | grep metric | cut -c1-200
+python bench.py --no-cpu-baseline --segmenter-chunk 4 2>&1 | grep metric | cut -c1-200
+python bench.py --no-cpu-baseline --segmenter-chunk 15 2>&1 | grep metric | cut -c1-200

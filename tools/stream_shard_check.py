@@ -66,6 +66,10 @@ def main():
     d1, p1, s1 = compare(own2, repl)
     print(f"rank {rank}: owner rounds run-to-run: max|d|={d0:.2e} pixels={p0:.2e} segments_equal={s0}; "
           f"owner vs replicated tracker: max|d|={d1:.2e} pixels={p1:.2e} segments_equal={s1}", flush=True)
+    for ci in range(len(clips)):
+        f = lambda x, y: float((x[0][ci]["masks"] != y[0][ci]["masks"]).float().mean()) if x[0][ci]["masks"].numel() else 0.
+        print(f"  rank {rank} clip {ci} frames {own2[0][ci]['fr']}: pixels run-to-run {f(own1, own2):.2e}, "
+              f"owner vs replicated {f(own2, repl):.2e}, ids {own2[0][ci]['ids']} / {repl[0][ci]['ids']}", flush=True)
     same = s1 and d1 <= 1e-3      # run-to-run noise (library kernels with atomics) is 3e-6 .. 1e-4
     flag = torch.tensor([0 if same else 1], device=dev if dist.get_backend() == 'nccl' else 'cpu')
     dist.all_reduce(flag)
@@ -78,7 +82,7 @@ def main():
         bad = int(flag.item())
         for ci, clip in enumerate(clips):
             single = model([clip])
-            masks = torch.cat([p[ci]["masks"] for p in parts], 0)
+            masks = torch.cat([p[ci]["masks"] for p in sorted(parts, key=lambda p: (p[ci]["fr"] or [1 << 30])[0])], 0)
             same = torch.equal(masks, single["pred_masks"].cpu())
             diff = (masks != single["pred_masks"].cpu()).float().mean().item()
             segs = all(p[ci]["segs"] == single["segments_infos"] and p[ci]["ids"] == single["pred_ids"] for p in parts)
