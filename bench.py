@@ -208,8 +208,21 @@ def main():
         k = min(args.candidates, s.numel() - 1)
         model.object_mask_threshold = float((s[k - 1] + s[k]) / 2) if k > 0 else 2.0
 
-    for _ in range(args.warmup):
-        out = step()
+    # Warm-up must see every convolution shape of the timed region: MIOpen searches its solvers (naive kernels
+    # included, seconds per shape) the first time a shape appears.  One clip per step on a single GPU; with several
+    # ranks stream() batches this rank's frames of a whole round of `world` clips into one segmenter call, so the
+    # shapes are those of a full round and of the last, partial round (K mod world clips, same rotation of the ragged
+    # split as in the timed pass) — warm up with exactly that sequence.
+    streamed = bool(args.clip_stream and args.mode == "offline")
+    warm_clips = args.warmup
+    if streamed and world > 1 and model.owner_rounds:
+        warm_clips = max(args.warmup, args.steps if args.steps < world else world + args.steps % world)
+    if streamed:
+        for out in model.stream(inputs * warm_clips):
+            pass
+    else:
+        for _ in range(args.warmup):
+            out = step()
     torch.cuda.synchronize()
     if dist_on:
         torch.distributed.barrier()
@@ -217,7 +230,7 @@ def main():
     t0 = time.perf_counter()
     mark = os.environ.get("DVIS_BENCH_MARK") == "1"     # tools/steady_stats.py: marker kernel at each timed step start
     with timer:
-        if args.clip_stream and args.mode == "offline":
+        if streamed:
             for out in model.stream(inputs * args.steps):
                 pass
         else:
@@ -255,9 +268,9 @@ def main():
                                    f"frames sharded {world}-way",
                        "panoptic_candidates": out.get("num_candidates"), "segments": len(out.get("segments_infos", [])),
                        "tracker_spans": len(model.clip_shard.round_plan(T, getattr(model, "pipeline_rounds", 1))[0]),
-                       "clip_stream": bool(args.clip_stream and args.mode == "offline"),
-                       "tracker_owner_rounds": bool(args.clip_stream and args.mode == "offline" and world > 1
-                                                    and model.owner_rounds)},
+                       "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                       "clip_stream": streamed, "warmup_clips_run": warm_clips,
+                       "tracker_owner_rounds": bool(streamed and world > 1 and model.owner_rounds)},
             "roofline": {"bound": "hbm", "kernel": "msda_fwd_tile_f32 (fused MSDeformAttn forward)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

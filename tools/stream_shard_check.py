@@ -77,6 +77,7 @@ def main():
     torch.save(outs, os.path.join(args.out, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
+    model._clip_shard = None                       # forget the (forced) collectives of the destroyed group
     if rank == 0:
         parts = [torch.load(os.path.join(args.out, f"rank{r}.pt")) for r in range(world)]
         bad = int(flag.item())
