@@ -73,22 +73,34 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restr
 }
 
 // torch upsample_bilinear2d (align_corners=False) taps:  src = max(scale * (dst + .5) - .5, 0)
+// X2 (H == 2h, W == 2w — every FPN step of the pixel decoder): the 4 outputs of a thread read only the 4 columns
+// 2xq-1 .. 2xq+2 of two source rows, fetched as one float2 + two scalars per row (6 loads instead of 16; the kernel was
+// load-issue bound at 2.8 TB/s).  Weights and tap order are the generic formula's, so both paths give the same bits.
+template <bool X2>
 __global__ __launch_bounds__(256) void upsample_add_kernel(const float *__restrict__ lateral, const float *__restrict__ top,
                                                            float *__restrict__ out, int planes, int H, int W, int h, int w) {
-  const size_t total = (size_t)planes * H * (W / 4);
+  const unsigned W4 = (unsigned)W / 4u;
+  const unsigned total = (unsigned)planes * (unsigned)H * W4;   // < 2^32 (host check)
   const float sy = (float)h / (float)H, sx = (float)w / (float)W;
-  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-    const int xq = (int)(idx % (W / 4));
-    const size_t r = idx / (W / 4);
-    const int y = (int)(r % H);
-    const size_t pl = r / H;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+    const unsigned r = idx / W4;
+    const int xq = (int)(idx - r * W4);
+    const unsigned pl = r / (unsigned)H;
+    const int y = (int)(r - pl * (unsigned)H);
     float fy = sy * ((float)y + 0.5f) - 0.5f;
     fy = fy < 0.f ? 0.f : fy;
     const int y0 = min((int)fy, h - 1), y1 = y0 + (y0 < h - 1 ? 1 : 0);
     const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
-    const float *t0 = top + (pl * h + y0) * (size_t)w, *t1 = top + (pl * h + y1) * (size_t)w;
-    const size_t o = (pl * H + y) * (size_t)W + 4 * xq;
+    const float *t0 = top + ((size_t)pl * h + y0) * (size_t)w, *t1 = top + ((size_t)pl * h + y1) * (size_t)w;
+    const size_t o = ((size_t)pl * H + y) * (size_t)W + 4 * xq;
     const float4 lat = *reinterpret_cast<const float4 *>(lateral + o);
+    float c0[4], c1[4];     // X2: source columns 2xq-1 (clamped), 2xq, 2xq+1, 2xq+2 (clamped) of rows y0 / y1
+    if (X2) {
+      const int xm = max(2 * xq - 1, 0), xp = min(2 * xq + 2, w - 1);
+      const float2 m0 = *reinterpret_cast<const float2 *>(t0 + 2 * xq), m1 = *reinterpret_cast<const float2 *>(t1 + 2 * xq);
+      c0[0] = t0[xm]; c0[1] = m0.x; c0[2] = m0.y; c0[3] = t0[xp];
+      c1[0] = t1[xm]; c1[1] = m1.x; c1[2] = m1.y; c1[3] = t1[xp];
+    }
     float res[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -96,7 +108,13 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const float *__restri
       fx = fx < 0.f ? 0.f : fx;
       const int x0 = min((int)fx, w - 1), x1 = x0 + (x0 < w - 1 ? 1 : 0);
       const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
-      res[k] = ly0 * (lx0 * t0[x0] + lx1 * t0[x1]) + ly1 * (lx0 * t1[x0] + lx1 * t1[x1]);
+      if (X2) {
+        // x0 = 2xq-1, 2xq, 2xq, 2xq+1 for k = 0..3 (x0 = 0 with lx1 = 0 at the left border: column 0 either way)
+        const int i0 = (k + 1) / 2, i1 = i0 + 1;
+        res[k] = ly0 * (lx0 * c0[i0] + lx1 * c0[i1]) + ly1 * (lx0 * c1[i0] + lx1 * c1[i1]);
+      } else {
+        res[k] = ly0 * (lx0 * t0[x0] + lx1 * t0[x1]) + ly1 * (lx0 * t1[x0] + lx1 * t1[x1]);
+      }
     }
     *reinterpret_cast<float4 *>(out + o) = make_float4(lat.x + res[0], lat.y + res[1], lat.z + res[2], lat.w + res[3]);
   }
@@ -208,7 +226,13 @@ DVIS_EXPORT int dvis_upsample_add(const float *lateral, const float *top, float 
   const size_t total = (size_t)planes * H * (W / 4);
   size_t blocks = (total + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;
-  hipLaunchKernelGGL(upsample_add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, lateral, top, out,
-                     (int)planes, H, W, h, w);
+  DVIS_REQUIRE(total < (1ull << 32), "upsample_add: more than 2^32 output quads");
+  const bool x2 = H == 2 * h && W == 2 * w && (w & 1) == 0 && ((uintptr_t)top & 7) == 0;
+  if (x2)
+    hipLaunchKernelGGL(upsample_add_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, lateral, top,
+                       out, (int)planes, H, W, h, w);
+  else
+    hipLaunchKernelGGL(upsample_add_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, lateral, top,
+                       out, (int)planes, H, W, h, w);
   return dvis_check_launch("upsample_add_kernel");
 }
