@@ -66,7 +66,10 @@ class BasicStem(nn.Module):
         self.conv1 = ConvBN(in_channels, out_channels, 7, stride=2, padding=3)
 
     def forward(self, x):
-        return F.max_pool2d(self.conv1(x, relu=True), kernel_size=3, stride=2, padding=1)
+        """conv (MIOpen) then ONE pass: folded-BN shift + ReLU + 3x3/2 max-pool (the 1.8 GB stem output is read once)."""
+        c = self.conv1
+        w, b = c.folded()
+        return Fn.bias_relu_maxpool(F.conv2d(x, w, None, c.stride, c.padding), b)
 
 
 class BottleneckBlock(nn.Module):

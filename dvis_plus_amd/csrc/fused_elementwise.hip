@@ -120,6 +120,44 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const float *__restri
   }
 }
 
+// out = relu(max_pool2d(x, 3, stride 2, padding 1) + bias[c]) — the ResNet stem after its convolution.  x -> relu(x + b)
+// is monotonic in fp32, so this equals max_pool2d(relu(x + bias)) bit for bit; the stem output (the largest activation
+// of the model) is read once and never written back.  A thread makes 4 outputs of one row from 9 input columns x 3 rows.
+__global__ __launch_bounds__(256) void bias_relu_maxpool_kernel(const float *__restrict__ x, const float *__restrict__ bias,
+                                                                float *__restrict__ out, int planes, int C, int H, int W) {
+  const int Ho = H / 2, Wo = W / 2;
+  const unsigned Wq = (unsigned)Wo / 4u;
+  const unsigned total = (unsigned)planes * (unsigned)Ho * Wq;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+    const unsigned r = idx / Wq;
+    const int xq = (int)(idx - r * Wq);
+    const unsigned pl = r / (unsigned)Ho;
+    const int oy = (int)(r - pl * (unsigned)Ho);
+    const float *xp = x + (size_t)pl * H * W;
+    float m[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) m[i] = -INFINITY;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int y = 2 * oy + dy;
+      if (y < 0) continue;                          // padding row (y <= H - 1 always: H is even)
+      const float *row = xp + (size_t)y * W + 8 * xq;
+      const float4 a = *reinterpret_cast<const float4 *>(row), b = *reinterpret_cast<const float4 *>(row + 4);
+      const float l = xq > 0 ? row[-1] : -INFINITY;   // padding column
+      m[0] = fmaxf(m[0], l);
+      m[1] = fmaxf(m[1], a.x); m[2] = fmaxf(m[2], a.y); m[3] = fmaxf(m[3], a.z); m[4] = fmaxf(m[4], a.w);
+      m[5] = fmaxf(m[5], b.x); m[6] = fmaxf(m[6], b.y); m[7] = fmaxf(m[7], b.z); m[8] = fmaxf(m[8], b.w);
+    }
+    const float bb = bias ? bias[pl % (unsigned)C] : 0.f;
+    float4 o;
+    o.x = fmaxf(fmaxf(fmaxf(m[0], m[1]), m[2]) + bb, 0.f);
+    o.y = fmaxf(fmaxf(fmaxf(m[2], m[3]), m[4]) + bb, 0.f);
+    o.z = fmaxf(fmaxf(fmaxf(m[4], m[5]), m[6]) + bb, 0.f);
+    o.w = fmaxf(fmaxf(fmaxf(m[6], m[7]), m[8]) + bb, 0.f);
+    *reinterpret_cast<float4 *>(out + ((size_t)pl * Ho + oy) * Wo + 4 * xq) = o;
+  }
+}
+
 // x[(n*C + c)*HW + i] = relu?(x + bias[c] + res); grid.x = planes * chunks_per_plane
 __global__ __launch_bounds__(256) void bias_act_kernel(float *__restrict__ x, const float *__restrict__ bias,
                                                        const float *__restrict__ res, int C, int HW4, int chunks,
@@ -235,4 +273,20 @@ DVIS_EXPORT int dvis_upsample_add(const float *lateral, const float *top, float 
     hipLaunchKernelGGL(upsample_add_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, lateral, top,
                        out, (int)planes, H, W, h, w);
   return dvis_check_launch("upsample_add_kernel");
+}
+
+DVIS_EXPORT int dvis_bias_relu_maxpool(const float *x, const float *bias, float *out, int64_t planes, int C, int H, int W,
+                                       void *stream) {
+  DVIS_REQUIRE(planes >= 0 && C > 0 && H > 0 && W > 0, "bias_relu_maxpool: bad sizes");
+  if (planes == 0) return DVIS_OK;
+  DVIS_REQUIRE(x && out, "bias_relu_maxpool: null pointer");
+  DVIS_REQUIRE(H % 2 == 0 && W % 8 == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0,
+               "bias_relu_maxpool: needs even H, W %% 8 == 0 and 16-byte aligned x / out (H=%d W=%d)", H, W);
+  const size_t total = (size_t)planes * (H / 2) * (W / 8);
+  DVIS_REQUIRE(planes < (1ll << 31) && total < (1ull << 32), "bias_relu_maxpool: too many planes / outputs");
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(bias_relu_maxpool_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, bias, out,
+                     (int)planes, C, H, W);
+  return dvis_check_launch("bias_relu_maxpool_kernel");
 }

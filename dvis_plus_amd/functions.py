@@ -305,6 +305,25 @@ def add_layer_norm(x, res, norm):
     return out
 
 
+def bias_relu_maxpool(x, bias=None):
+    """``F.max_pool2d(relu(x + bias[c]), 3, stride=2, padding=1)`` in one pass (the ResNet stem after its convolution):
+    relu(max(x) + b), bit-identical because fp32 add and ReLU are monotonic.  Non-GPU / odd shapes use the torch ops."""
+    N, C, H, W = x.shape
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and H % 2 == 0 and W % 8 == 0
+            and not torch.is_grad_enabled()):
+        import torch.nn.functional as F
+        if bias is not None:
+            x = x + bias.view(1, -1, 1, 1)
+        return F.max_pool2d(torch.relu(x), kernel_size=3, stride=2, padding=1)
+    out = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = native.lib().dvis_bias_relu_maxpool(native.dev_ptr(x, "x"),
+                                                 None if bias is None else native.dev_ptr(bias, "bias"),
+                                                 native.dev_ptr(out, "out"), N * C, C, H, W, native.stream_ptr(x.device))
+    native.check(rc, "dvis_bias_relu_maxpool")
+    return out
+
+
 def upsample_add(lateral, top):
     """``lateral + F.interpolate(top, size=lateral.shape[-2:], mode="bilinear", align_corners=False)`` in one pass."""
     N, C, H, W = lateral.shape

@@ -25,6 +25,7 @@
  *                               video_mask2former_transformer_decoder.py:47-50,108-111,166-170, tracker.py:51-53)
  *   dvis_nchw_to_tokens      <- src.flatten(2).transpose(1, 2) + torch.cat over levels, msdeformattn.py:64-79
  *   dvis_bias_act            <- FrozenBN shift + shortcut add + ReLU after each backbone convolution (detectron2 BottleneckBlock)
+ *   dvis_bias_relu_maxpool   <- FrozenBN shift + ReLU + max_pool2d(3, stride 2, padding 1) of the ResNet stem (detectron2 BasicStem)
  *   dvis_upsample_add        <- `cur_fpn + F.interpolate(out[-1], size=..., mode="bilinear")`, msdeformattn.py:347
  *   dvis_vps_argmax          <- two-stage resize + sigmoid + score-weighted argmax + segment areas of inference_video_vps,
  *                               dvis_Plus/meta_architecture.py:890-925
@@ -183,6 +184,14 @@ int dvis_nchw_to_tokens(const float *x, float *out, int64_t N, int C, int64_t HW
  */
 int dvis_bias_act(float *x, const float *bias, const float *res, int64_t planes, int C, int64_t HW, int relu,
                   void *stream);
+
+/*
+ * out (planes, H/2, W/2) = relu(max_pool2d(x (planes, H, W), kernel 3, stride 2, padding 1) + bias[plane % C]) — equal, bit
+ * for bit, to max_pool2d(relu(x + bias)) (fp32 add and ReLU are monotonic): the stem's folded-FrozenBN shift, ReLU and
+ * pooling in one pass over the stem convolution's output.  bias (C,) or NULL.  H even, W % 8 == 0, x / out 16-byte aligned.
+ */
+int dvis_bias_relu_maxpool(const float *x, const float *bias, float *out, int64_t planes, int C, int H, int W,
+                           void *stream);
 
 /*
  * Panoptic arg-max of a clip in one pass (inference_video_vps, dvis_Plus/meta_architecture.py:890-925):

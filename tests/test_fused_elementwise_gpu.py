@@ -84,3 +84,16 @@ def test_maps_to_tokens(N, C, sizes):
     maps = [torch.randn(N, C, h, w, generator=g).to("cuda:0") for h, w in sizes]
     want = torch.cat([m.flatten(2).transpose(1, 2) for m in maps], 1)
     assert torch.equal(maps_to_tokens(maps), want)
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 5, 8, 16), (1, 3, 46, 80), (2, 64, 92, 160)])
+def test_bias_relu_maxpool_is_bit_identical_to_the_three_torch_ops(N, C, H, W):
+    from dvis_plus_amd.functions import bias_relu_maxpool
+    g = torch.Generator().manual_seed(H)
+    x, b = torch.randn(N, C, H, W, generator=g), torch.randn(C, generator=g)
+    with torch.no_grad():
+        ref = F.max_pool2d(torch.relu(x + b.view(1, -1, 1, 1)), kernel_size=3, stride=2, padding=1)
+        out = bias_relu_maxpool(x.to(DEV), b.to(DEV)).cpu()
+        out_nob = bias_relu_maxpool(x.to(DEV)).cpu()
+    assert torch.equal(out, ref)
+    assert torch.equal(out_nob, F.max_pool2d(torch.relu(x), kernel_size=3, stride=2, padding=1))
