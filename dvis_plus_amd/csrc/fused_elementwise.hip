@@ -76,9 +76,13 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restr
 // X2 (H == 2h, W == 2w — every FPN step of the pixel decoder): the 4 outputs of a thread read only the 4 columns
 // 2xq-1 .. 2xq+2 of two source rows, fetched as one float2 + two scalars per row (6 loads instead of 16; the kernel was
 // load-issue bound at 2.8 TB/s).  Weights and tap order are the generic formula's, so both paths give the same bits.
+// lat_scale / lat_shift (per plane, may be null): the lateral operand is read as lateral * scale + shift — the
+// GroupNorm of the lateral convolution applied on the fly (dvis_group_norm_affine), one pass over the map saved.
 template <bool X2>
 __global__ __launch_bounds__(256) void upsample_add_kernel(const float *__restrict__ lateral, const float *__restrict__ top,
-                                                           float *__restrict__ out, int planes, int H, int W, int h, int w) {
+                                                           float *__restrict__ out, int planes, int H, int W, int h, int w,
+                                                           const float *__restrict__ lat_scale,
+                                                           const float *__restrict__ lat_shift) {
   const unsigned W4 = (unsigned)W / 4u;
   const unsigned total = (unsigned)planes * (unsigned)H * W4;   // < 2^32 (host check)
   const float sy = (float)h / (float)H, sx = (float)w / (float)W;
@@ -93,7 +97,11 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const float *__restri
     const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
     const float *t0 = top + ((size_t)pl * h + y0) * (size_t)w, *t1 = top + ((size_t)pl * h + y1) * (size_t)w;
     const size_t o = ((size_t)pl * H + y) * (size_t)W + 4 * xq;
-    const float4 lat = *reinterpret_cast<const float4 *>(lateral + o);
+    float4 lat = *reinterpret_cast<const float4 *>(lateral + o);
+    if (lat_scale) {
+      const float a = lat_scale[pl], b = lat_shift[pl];
+      lat.x = lat.x * a + b; lat.y = lat.y * a + b; lat.z = lat.z * a + b; lat.w = lat.w * a + b;
+    }
     float c0[4], c1[4];     // X2: source columns 2xq-1 (clamped), 2xq, 2xq+1, 2xq+2 (clamped) of rows y0 / y1
     if (X2) {
       const int xm = max(2 * xq - 1, 0), xp = min(2 * xq + 2, w - 1);
@@ -253,11 +261,12 @@ DVIS_EXPORT int dvis_add_layernorm(const float *x, const float *res, int64_t res
   return dvis_check_launch("add_layernorm_kernel");
 }
 
-DVIS_EXPORT int dvis_upsample_add(const float *lateral, const float *top, float *out, int64_t planes, int H, int W, int h,
-                                  int w, void *stream) {
+static int upsample_add_launch(const float *lateral, const float *top, float *out, int64_t planes, int H, int W, int h,
+                               int w, const float *lat_scale, const float *lat_shift, void *stream) {
   DVIS_REQUIRE(planes >= 0 && H > 0 && W > 0 && h > 0 && w > 0, "upsample_add: bad sizes");
   if (planes == 0) return DVIS_OK;
   DVIS_REQUIRE(lateral && top && out, "upsample_add: null pointer");
+  DVIS_REQUIRE((lat_scale == nullptr) == (lat_shift == nullptr), "upsample_add: scale and shift come together");
   DVIS_REQUIRE(W % 4 == 0 && (((uintptr_t)lateral | (uintptr_t)out) & 15) == 0,
                "upsample_add: W must be a multiple of 4 and lateral/out 16-byte aligned");
   DVIS_REQUIRE(planes < (1ll << 31), "upsample_add: too many planes");
@@ -268,11 +277,23 @@ DVIS_EXPORT int dvis_upsample_add(const float *lateral, const float *top, float 
   const bool x2 = H == 2 * h && W == 2 * w && (w & 1) == 0 && ((uintptr_t)top & 7) == 0;
   if (x2)
     hipLaunchKernelGGL(upsample_add_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, lateral, top,
-                       out, (int)planes, H, W, h, w);
+                       out, (int)planes, H, W, h, w, lat_scale, lat_shift);
   else
     hipLaunchKernelGGL(upsample_add_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, lateral, top,
-                       out, (int)planes, H, W, h, w);
+                       out, (int)planes, H, W, h, w, lat_scale, lat_shift);
   return dvis_check_launch("upsample_add_kernel");
+}
+
+DVIS_EXPORT int dvis_upsample_add(const float *lateral, const float *top, float *out, int64_t planes, int H, int W, int h,
+                                  int w, void *stream) {
+  return upsample_add_launch(lateral, top, out, planes, H, W, h, w, nullptr, nullptr, stream);
+}
+
+DVIS_EXPORT int dvis_upsample_add_affine(const float *lateral, const float *lat_scale, const float *lat_shift,
+                                         const float *top, float *out, int64_t planes, int H, int W, int h, int w,
+                                         void *stream) {
+  DVIS_REQUIRE(lat_scale && lat_shift, "upsample_add_affine: null scale / shift");
+  return upsample_add_launch(lateral, top, out, planes, H, W, h, w, lat_scale, lat_shift, stream);
 }
 
 DVIS_EXPORT int dvis_bias_relu_maxpool(const float *x, const float *bias, float *out, int64_t planes, int C, int H, int W,
@@ -289,4 +310,100 @@ DVIS_EXPORT int dvis_bias_relu_maxpool(const float *x, const float *bias, float 
   hipLaunchKernelGGL(bias_relu_maxpool_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, bias, out,
                      (int)planes, C, H, W);
   return dvis_check_launch("bias_relu_maxpool_kernel");
+}
+
+namespace {
+
+// One workgroup per (sample, group): sum and sum of squares of the group's Cg * HW contiguous floats in fp64 (the kernel
+// is HBM-bound; fp64 adds are free and make E[x^2] - E[x]^2 safe), then scale = rstd * gamma[c], shift = beta[c] -
+// mean * scale for the group's Cg planes.
+__global__ __launch_bounds__(1024) void group_norm_affine_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                                 const float *__restrict__ beta, float *__restrict__ scale,
+                                                                 float *__restrict__ shift, int C, int G, long long HW,
+                                                                 float eps) {
+  __shared__ double s_sum[16], s_sq[16];
+  const int Cg = C / G;
+  const int n = blockIdx.x / G, g = blockIdx.x - n * G;
+  const long long count = (long long)Cg * HW, count4 = count / 4;
+  const float4 *xp = reinterpret_cast<const float4 *>(x + ((size_t)n * C + (size_t)g * Cg) * HW);
+  double sum = 0.0, sq = 0.0;
+  for (long long i = threadIdx.x; i < count4; i += 1024) {
+    const float4 v = xp[i];
+    sum += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+    sq += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sum += __shfl_down(sum, o);
+    sq += __shfl_down(sq, o);
+  }
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    s_sum[wv] = sum;
+    s_sq[wv] = sq;
+  }
+  __syncthreads();
+  if (threadIdx.x < Cg) {
+    double ts = 0.0, tq = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      ts += s_sum[i];
+      tq += s_sq[i];
+    }
+    const double mean = ts / (double)count;
+    double var = tq / (double)count - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const int c = g * Cg + threadIdx.x;
+    const float a = rstd * (gamma ? gamma[c] : 1.f);
+    scale[(size_t)n * C + c] = a;
+    shift[(size_t)n * C + c] = (beta ? beta[c] : 0.f) - (float)mean * a;
+  }
+}
+
+// x[plane][i] = relu?(x * scale[plane] + shift[plane]); grid.x = planes * chunks_per_plane
+__global__ __launch_bounds__(256) void scale_shift_act_kernel(float *__restrict__ x, const float *__restrict__ scale,
+                                                              const float *__restrict__ shift, int HW4, int chunks, int relu) {
+  const unsigned plane = blockIdx.x / chunks;
+  const int chunk = blockIdx.x - plane * chunks;
+  const float a = scale[plane], b = shift[plane];
+  float4 *xp = reinterpret_cast<float4 *>(x) + (size_t)plane * HW4;
+  for (int i = chunk * 256 + threadIdx.x; i < HW4; i += chunks * 256) {
+    float4 v = xp[i];
+    v.x = v.x * a + b; v.y = v.y * a + b; v.z = v.z * a + b; v.w = v.w * a + b;
+    if (relu) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    xp[i] = v;
+  }
+}
+
+}  // namespace
+
+DVIS_EXPORT int dvis_group_norm_affine(const float *x, const float *gamma, const float *beta, float *scale, float *shift,
+                                       int64_t N, int C, int G, int64_t HW, float eps, void *stream) {
+  DVIS_REQUIRE(N >= 0 && C > 0 && G > 0 && HW > 0 && C % G == 0, "group_norm_affine: bad sizes (C=%d G=%d)", C, G);
+  if (N == 0) return DVIS_OK;
+  DVIS_REQUIRE(x && scale && shift, "group_norm_affine: null pointer");
+  DVIS_REQUIRE(C / G <= 1024 && ((int64_t)(C / G) * HW) % 4 == 0 && ((uintptr_t)x & 15) == 0 && (HW % 4 == 0 || G == 1),
+               "group_norm_affine: a group must be a multiple of 4 floats, 16-byte aligned");
+  DVIS_REQUIRE(N * G < (1ll << 31), "group_norm_affine: too many groups");
+  hipLaunchKernelGGL(group_norm_affine_kernel, dim3((unsigned)(N * G)), dim3(1024), 0, (hipStream_t)stream, x, gamma, beta,
+                     scale, shift, C, G, (long long)HW, eps);
+  return dvis_check_launch("group_norm_affine_kernel");
+}
+
+DVIS_EXPORT int dvis_scale_shift_act(float *x, const float *scale, const float *shift, int64_t planes, int64_t HW, int relu,
+                                     void *stream) {
+  DVIS_REQUIRE(planes >= 0 && HW > 0, "scale_shift_act: bad sizes");
+  if (planes == 0) return DVIS_OK;
+  DVIS_REQUIRE(x && scale && shift, "scale_shift_act: null pointer");
+  DVIS_REQUIRE(HW % 4 == 0 && ((uintptr_t)x & 15) == 0, "scale_shift_act: HW must be a multiple of 4 and x 16-byte aligned");
+  const int HW4 = (int)(HW / 4);
+  int chunks = (HW4 + 1023) / 1024;
+  if (chunks < 1) chunks = 1;
+  DVIS_REQUIRE(planes * chunks < (1ll << 31), "scale_shift_act: too many planes");
+  hipLaunchKernelGGL(scale_shift_act_kernel, dim3((unsigned)(planes * chunks)), dim3(256), 0, (hipStream_t)stream, x, scale,
+                     shift, HW4, chunks, relu);
+  return dvis_check_launch("scale_shift_act_kernel");
 }

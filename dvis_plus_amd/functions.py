@@ -324,19 +324,63 @@ def bias_relu_maxpool(x, bias=None):
     return out
 
 
-def upsample_add(lateral, top):
-    """``lateral + F.interpolate(top, size=lateral.shape[-2:], mode="bilinear", align_corners=False)`` in one pass."""
+def _fused_map_ok(x):
+    """fp32 NCHW GPU map outside autograd: the fused glue kernels apply; anything else takes the torch ops."""
+    return x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and not torch.is_grad_enabled()
+
+
+def group_norm_affine(x, norm):
+    """Statistics of ``nn.GroupNorm`` `norm` on x (N,C,H,W) in one read, as the per-plane affine (scale, shift), each
+    (N*C,), with  norm(x)[n, c] == x[n, c] * scale[n*C + c] + shift[n*C + c].  None when the fused path does not apply
+    (caller falls back to ``norm(x)``)."""
+    N, C, H, W = x.shape
+    G = norm.num_groups
+    if not (_fused_map_ok(x) and (C // G) * H * W % 4 == 0 and C // G <= 1024):
+        return None
+    scale = torch.empty(N * C, dtype=torch.float32, device=x.device)
+    shift = torch.empty(N * C, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = native.lib().dvis_group_norm_affine(
+            native.dev_ptr(x, "x"), None if norm.weight is None else native.dev_ptr(norm.weight.detach(), "gamma"),
+            None if norm.bias is None else native.dev_ptr(norm.bias.detach(), "beta"), native.dev_ptr(scale, "scale"),
+            native.dev_ptr(shift, "shift"), N, C, G, H * W, float(norm.eps), native.stream_ptr(x.device))
+    native.check(rc, "dvis_group_norm_affine")
+    return scale, shift
+
+
+def scale_shift_act_(x, scale, shift, relu=False):
+    """In place: x[n, c] = relu?(x[n, c] * scale[n*C + c] + shift[n*C + c]) on an fp32 NCHW GPU map (HW % 4 == 0)."""
+    N, C, H, W = x.shape
+    with torch.cuda.device(x.device):
+        rc = native.lib().dvis_scale_shift_act(native.dev_ptr(x, "x"), native.dev_ptr(scale, "scale"),
+                                               native.dev_ptr(shift, "shift"), N * C, H * W, 1 if relu else 0,
+                                               native.stream_ptr(x.device))
+    native.check(rc, "dvis_scale_shift_act")
+    return x
+
+
+def upsample_add(lateral, top, lat_affine=None):
+    """``lateral + F.interpolate(top, size=lateral.shape[-2:], mode="bilinear", align_corners=False)`` in one pass.
+    lat_affine = (scale, shift) from ``group_norm_affine``: the lateral operand is read as lateral * scale + shift (its
+    GroupNorm applied on the fly)."""
     N, C, H, W = lateral.shape
-    if not (lateral.is_cuda and lateral.dtype == torch.float32 and top.dtype == torch.float32 and W % 4 == 0
-            and lateral.is_contiguous() and not torch.is_grad_enabled()):
+    if not (_fused_map_ok(lateral) and top.dtype == torch.float32 and W % 4 == 0):
         import torch.nn.functional as F
+        if lat_affine is not None:
+            lateral = lateral * lat_affine[0].view(N, C, 1, 1) + lat_affine[1].view(N, C, 1, 1)
         return lateral + F.interpolate(top, size=(H, W), mode="bilinear", align_corners=False)
     top = top.contiguous()
     out = torch.empty_like(lateral)
     with torch.cuda.device(lateral.device):
-        rc = native.lib().dvis_upsample_add(native.dev_ptr(lateral, "lateral"), native.dev_ptr(top, "top"),
-                                            native.dev_ptr(out, "out"), N * C, H, W, top.shape[-2], top.shape[-1],
-                                            native.stream_ptr(lateral.device))
+        if lat_affine is None:
+            rc = native.lib().dvis_upsample_add(native.dev_ptr(lateral, "lateral"), native.dev_ptr(top, "top"),
+                                                native.dev_ptr(out, "out"), N * C, H, W, top.shape[-2], top.shape[-1],
+                                                native.stream_ptr(lateral.device))
+        else:
+            rc = native.lib().dvis_upsample_add_affine(
+                native.dev_ptr(lateral, "lateral"), native.dev_ptr(lat_affine[0], "scale"),
+                native.dev_ptr(lat_affine[1], "shift"), native.dev_ptr(top, "top"), native.dev_ptr(out, "out"), N * C, H,
+                W, top.shape[-2], top.shape[-1], native.stream_ptr(lateral.device))
     native.check(rc, "dvis_upsample_add")
     return out
 

@@ -289,11 +289,29 @@ class ConvNorm(nn.Conv2d):
         super().__init__(*args, **kwargs)
         self.norm, self.activation = norm, activation
 
-    def forward(self, x):
+    def conv(self, x):
         if self.kernel_size == (1, 1) and self.stride == (1, 1) and self.groups == 1 and self.padding == (0, 0):
-            x = Fn.conv1x1(x, self.weight, self.bias)
-        else:
-            x = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+            return Fn.conv1x1(x, self.weight, self.bias)
+        return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+
+    def conv_and_affine(self, x):
+        """(conv(x), (scale, shift)) with forward(x) == conv(x) * scale + shift per plane, for a GroupNorm without
+        activation whose application the consumer fuses (Fn.upsample_add); (forward(x), None) when that does not apply."""
+        if isinstance(self.norm, nn.GroupNorm) and self.activation is None:
+            y = self.conv(x)
+            aff = Fn.group_norm_affine(y, self.norm)
+            if aff is not None:
+                return y, aff
+            return self.norm(y), None
+        return self.forward(x), None
+
+    def forward(self, x):
+        x = self.conv(x)
+        if isinstance(self.norm, nn.GroupNorm) and self.activation in (None, F.relu):
+            # statistics in one read, normalisation (+ReLU) in one in-place pass (torch: moments, apply, clamp)
+            aff = Fn.group_norm_affine(x, self.norm)
+            if aff is not None:
+                return Fn.scale_shift_act_(x, aff[0], aff[1], relu=self.activation is not None)
         if self.norm is not None:
             x = self.norm(x)
         if self.activation is not None:
@@ -392,8 +410,8 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 start += h * w
             for idx, f in enumerate(self.in_features[:self.num_fpn_levels][::-1]):
                 x = features[f].float()
-                cur_fpn = self.lateral_convs[idx](x)
-                out.append(self.output_convs[idx](Fn.upsample_add(cur_fpn, out[-1])))
+                cur_fpn, affine = self.lateral_convs[idx].conv_and_affine(x)    # GroupNorm applied inside upsample_add
+                out.append(self.output_convs[idx](Fn.upsample_add(cur_fpn, out[-1], affine)))
             multi_scale_features = TokenMaps(out[:self.maskformer_num_feature_levels])
             multi_scale_features.tokens = tokens[:self.maskformer_num_feature_levels]
             return self.mask_features(out[-1]), out[0], multi_scale_features

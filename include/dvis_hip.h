@@ -27,6 +27,9 @@
  *   dvis_bias_act            <- FrozenBN shift + shortcut add + ReLU after each backbone convolution (detectron2 BottleneckBlock)
  *   dvis_bias_relu_maxpool   <- FrozenBN shift + ReLU + max_pool2d(3, stride 2, padding 1) of the ResNet stem (detectron2 BasicStem)
  *   dvis_upsample_add        <- `cur_fpn + F.interpolate(out[-1], size=..., mode="bilinear")`, msdeformattn.py:347
+ *   dvis_group_norm_affine / dvis_scale_shift_act / dvis_upsample_add_affine
+ *                            <- the GroupNorm (+ReLU) of detectron2's Conv2d wrapper around the FPN lateral / output
+ *                               convolutions, msdeformattn.py:280-300 (built) and :343-349 (applied)
  *   dvis_vps_argmax          <- two-stage resize + sigmoid + score-weighted argmax + segment areas of inference_video_vps,
  *                               dvis_Plus/meta_architecture.py:890-925
  *   dvis_vss_argmax          <- two-stage resize + sigmoid + einsum("qc,qthw->cthw") + max(0) of inference_video_vss,
@@ -192,6 +195,22 @@ int dvis_bias_act(float *x, const float *bias, const float *res, int64_t planes,
  */
 int dvis_bias_relu_maxpool(const float *x, const float *bias, float *out, int64_t planes, int C, int H, int W,
                            void *stream);
+
+/*
+ * GroupNorm as two cheap steps (nn.GroupNorm(G, C) on (N, C, HW) fp32, eps as given):
+ *   dvis_group_norm_affine  statistics of every (sample, group) in ONE read of x (fp64 sums), returned as the per-plane
+ *                           affine  scale[n*C + c] = rstd * gamma[c],  shift[n*C + c] = beta[c] - mean * scale
+ *                           (gamma / beta may be NULL = 1 / 0);  (C / G) * HW % 4 == 0, x 16-byte aligned;
+ *   dvis_scale_shift_act    in place x[plane] = relu?(x[plane] * scale[plane] + shift[plane]) — GroupNorm (+ReLU) applied;
+ *   dvis_upsample_add_affine  as dvis_upsample_add with the lateral operand read as lateral * scale + shift — the
+ *                           lateral convolution's GroupNorm applied on the fly (msdeformattn.py:345-347).
+ */
+int dvis_group_norm_affine(const float *x, const float *gamma, const float *beta, float *scale, float *shift, int64_t N,
+                           int C, int G, int64_t HW, float eps, void *stream);
+int dvis_scale_shift_act(float *x, const float *scale, const float *shift, int64_t planes, int64_t HW, int relu,
+                         void *stream);
+int dvis_upsample_add_affine(const float *lateral, const float *lat_scale, const float *lat_shift, const float *top,
+                             float *out, int64_t planes, int H, int W, int h, int w, void *stream);
 
 /*
  * Panoptic arg-max of a clip in one pass (inference_video_vps, dvis_Plus/meta_architecture.py:890-925):

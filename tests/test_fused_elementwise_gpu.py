@@ -97,3 +97,33 @@ def test_bias_relu_maxpool_is_bit_identical_to_the_three_torch_ops(N, C, H, W):
         out_nob = bias_relu_maxpool(x.to(DEV)).cpu()
     assert torch.equal(out, ref)
     assert torch.equal(out_nob, F.max_pool2d(torch.relu(x), kernel_size=3, stride=2, padding=1))
+
+
+@pytest.mark.parametrize("N,C,H,W,relu", [(2, 64, 6, 10, True), (3, 256, 23, 40, False), (1, 32, 92, 160, True)])
+def test_group_norm_affine_plus_apply_equals_torch_group_norm(N, C, H, W, relu):
+    from dvis_plus_amd import functions as Fn
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(N, C, H, W, generator=g) * 3 + 5           # mean >> std: E[x^2] - E[x]^2 must not cancel
+    gn = torch.nn.GroupNorm(32, C)
+    with torch.no_grad():
+        gn.weight.normal_(1, 0.2, generator=g)
+        gn.bias.normal_(0, 0.2, generator=g)
+        ref = gn(x)
+        ref = torch.relu(ref) if relu else ref
+        xd = x.to(DEV)
+        scale, shift = Fn.group_norm_affine(xd, gn.to(DEV))
+        out = Fn.scale_shift_act_(xd.clone(), scale, shift, relu=relu).cpu()
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=2e-5)
+
+
+def test_upsample_add_with_lateral_group_norm():
+    from dvis_plus_amd import functions as Fn
+    g = torch.Generator().manual_seed(3)
+    lat, top = torch.randn(2, 64, 46, 80, generator=g) + 2, torch.randn(2, 64, 23, 40, generator=g)
+    gn = torch.nn.GroupNorm(32, 64)
+    with torch.no_grad():
+        gn.weight.normal_(1, 0.2, generator=g)
+        ref = gn(lat) + F.interpolate(top, size=(46, 80), mode="bilinear", align_corners=False)
+        latd = lat.to(DEV)
+        out = Fn.upsample_add(latd, top.to(DEV), Fn.group_norm_affine(latd, gn.to(DEV))).cpu()
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=2e-5)
