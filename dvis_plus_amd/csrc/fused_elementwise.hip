@@ -21,7 +21,9 @@ template <int V>
 __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restrict__ x, const float *__restrict__ res,
                                                             int64_t res_row_stride, const float *__restrict__ gamma,
                                                             const float *__restrict__ beta, float *__restrict__ out,
-                                                            size_t rows, int C, float eps) {
+                                                            size_t rows, int C, float eps,
+                                                            const float *__restrict__ pos, size_t pos_rows,
+                                                            float *__restrict__ out_pos) {
   const int lane = threadIdx.x & 63;
   const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -66,8 +68,13 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float *__restr
     const int c4 = lane + 64 * i;
     if (c4 * 4 < C) {
       const float4 g = g4[c4], b = b4[c4];
-      orow[c4] = make_float4((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
-                             (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
+      const float4 o = make_float4((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
+                                   (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
+      orow[c4] = o;
+      if (pos) {   // second output: out + pos[row mod pos_rows] — the next layer's query (src + pos), never a pass of its own
+        const float4 p = reinterpret_cast<const float4 *>(pos + (row % pos_rows) * C)[c4];
+        reinterpret_cast<float4 *>(out_pos + row * C)[c4] = make_float4(o.x + p.x, o.y + p.y, o.z + p.z, o.w + p.w);
+      }
     }
   }
 }
@@ -241,24 +248,40 @@ DVIS_EXPORT int dvis_bias_act(float *x, const float *bias, const float *res, int
   return dvis_check_launch("bias_act_kernel");
 }
 
-DVIS_EXPORT int dvis_add_layernorm(const float *x, const float *res, int64_t res_row_stride, const float *gamma,
-                                   const float *beta, float *out, int64_t rows, int C, float eps, void *stream) {
+static int add_layernorm_launch(const float *x, const float *res, int64_t res_row_stride, const float *gamma,
+                                const float *beta, float *out, int64_t rows, int C, float eps, const float *pos,
+                                int64_t pos_rows, float *out_pos, void *stream) {
   DVIS_REQUIRE(rows >= 0 && C > 0, "add_layernorm: bad sizes");
   if (rows == 0) return DVIS_OK;
   DVIS_REQUIRE(x && gamma && beta && out, "add_layernorm: null pointer");
   DVIS_REQUIRE(C % 4 == 0 && C <= 1024, "add_layernorm: C must be a multiple of 4 and <= 1024 (got %d)", C);
   DVIS_REQUIRE(res == nullptr || res_row_stride % 4 == 0, "add_layernorm: residual row stride must be a multiple of 4");
-  const uintptr_t al = (uintptr_t)x | (uintptr_t)res | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out;
+  DVIS_REQUIRE(pos == nullptr || (pos_rows > 0 && out_pos != nullptr), "add_layernorm: pos needs pos_rows > 0 and out_pos");
+  const uintptr_t al = (uintptr_t)x | (uintptr_t)res | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out |
+                       (uintptr_t)pos | (uintptr_t)out_pos;
   DVIS_REQUIRE((al & 15) == 0, "add_layernorm: pointers must be 16-byte aligned");
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
+  const size_t pr = pos ? (size_t)pos_rows : 1;
   if (C <= 256)
-    hipLaunchKernelGGL((add_layernorm_kernel<1>), grid, block, 0, st, x, res, res_row_stride, gamma, beta, out, (size_t)rows, C, eps);
+    hipLaunchKernelGGL((add_layernorm_kernel<1>), grid, block, 0, st, x, res, res_row_stride, gamma, beta, out, (size_t)rows, C, eps, pos, pr, out_pos);
   else if (C <= 512)
-    hipLaunchKernelGGL((add_layernorm_kernel<2>), grid, block, 0, st, x, res, res_row_stride, gamma, beta, out, (size_t)rows, C, eps);
+    hipLaunchKernelGGL((add_layernorm_kernel<2>), grid, block, 0, st, x, res, res_row_stride, gamma, beta, out, (size_t)rows, C, eps, pos, pr, out_pos);
   else
-    hipLaunchKernelGGL((add_layernorm_kernel<4>), grid, block, 0, st, x, res, res_row_stride, gamma, beta, out, (size_t)rows, C, eps);
+    hipLaunchKernelGGL((add_layernorm_kernel<4>), grid, block, 0, st, x, res, res_row_stride, gamma, beta, out, (size_t)rows, C, eps, pos, pr, out_pos);
   return dvis_check_launch("add_layernorm_kernel");
+}
+
+DVIS_EXPORT int dvis_add_layernorm(const float *x, const float *res, int64_t res_row_stride, const float *gamma,
+                                   const float *beta, float *out, int64_t rows, int C, float eps, void *stream) {
+  return add_layernorm_launch(x, res, res_row_stride, gamma, beta, out, rows, C, eps, nullptr, 0, nullptr, stream);
+}
+
+DVIS_EXPORT int dvis_add_layernorm_pos(const float *x, const float *res, int64_t res_row_stride, const float *gamma,
+                                       const float *beta, float *out, const float *pos, int64_t pos_rows, float *out_pos,
+                                       int64_t rows, int C, float eps, void *stream) {
+  DVIS_REQUIRE(pos && out_pos, "add_layernorm_pos: null pos / out_pos");
+  return add_layernorm_launch(x, res, res_row_stride, gamma, beta, out, rows, C, eps, pos, pos_rows, out_pos, stream);
 }
 
 static int upsample_add_launch(const float *lateral, const float *top, float *out, int64_t planes, int H, int W, int h,

@@ -281,28 +281,45 @@ def vss_argmax(mask_logits_qthw, mask_cls, first_resize_size, img_size, out_hw):
     return out
 
 
-def add_layer_norm(x, res, norm):
+def add_layer_norm(x, res, norm, pos=None):
     """``norm(x + res)`` for an ``nn.LayerNorm`` `norm` in ONE pass.  x contiguous float32 GPU (..., C); res: None or a
     tensor broadcast-free of x's shape whose rows (last dim) are contiguous.  CPU tensors / other dtypes use torch ops
-    (library code, not one of the named hot ops)."""
+    (library code, not one of the named hot ops).
+    pos: optional (1, S, C) / (S, C) position embedding for x of shape (N, S, C): returns ``(out, out + pos)`` — the
+    second tensor (the next encoder layer's query) is written by the same kernel."""
     C = x.shape[-1]
+
+    def with_pos(out):
+        return out if pos is None else (out, out + pos.reshape(1, -1, C))
     if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and C % 4 == 0 and C <= 1024
             and norm.weight is not None and not torch.is_grad_enabled()):
-        return norm(x if res is None else x + res)
+        return with_pos(norm(x if res is None else x + res))
     rp, rs = None, 0
     if res is not None:
         if res.shape != x.shape or res.dtype != torch.float32 or not res.is_cuda:
-            return norm(x + res)
+            return with_pos(norm(x + res))
         if not res.is_contiguous():
             res = res.contiguous()
         rp, rs = ctypes.c_void_p(res.data_ptr()), C
     out = torch.empty_like(x)
+    rows = x.numel() // C
     with torch.cuda.device(x.device):
-        rc = native.lib().dvis_add_layernorm(ctypes.c_void_p(x.data_ptr()), rp, rs, native.dev_ptr(norm.weight, "gamma"),
-                                             native.dev_ptr(norm.bias, "beta"), ctypes.c_void_p(out.data_ptr()),
-                                             x.numel() // C, C, float(norm.eps), native.stream_ptr(x.device))
+        if pos is None:
+            rc = native.lib().dvis_add_layernorm(ctypes.c_void_p(x.data_ptr()), rp, rs, native.dev_ptr(norm.weight, "gamma"),
+                                                 native.dev_ptr(norm.bias, "beta"), ctypes.c_void_p(out.data_ptr()),
+                                                 rows, C, float(norm.eps), native.stream_ptr(x.device))
+        else:
+            pos_rows = pos.numel() // C
+            if x.dim() != 3 or x.shape[1] != pos_rows or pos.dtype != torch.float32 or not pos.is_cuda:
+                raise RuntimeError("add_layer_norm: pos must be a float32 GPU (S, C) embedding for x of shape (N, S, C)")
+            pos = pos.contiguous()
+            out_pos = torch.empty_like(x)
+            rc = native.lib().dvis_add_layernorm_pos(
+                ctypes.c_void_p(x.data_ptr()), rp, rs, native.dev_ptr(norm.weight, "gamma"),
+                native.dev_ptr(norm.bias, "beta"), ctypes.c_void_p(out.data_ptr()), native.dev_ptr(pos, "pos"), pos_rows,
+                ctypes.c_void_p(out_pos.data_ptr()), rows, C, float(norm.eps), native.stream_ptr(x.device))
     native.check(rc, "dvis_add_layernorm")
-    return out
+    return out if pos is None else (out, out_pos)
 
 
 def bias_relu_maxpool(x, bias=None):

@@ -191,12 +191,22 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         self.dropout_p = dropout     # inference path: dropout is the identity
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None,
-                shapes_py=None):
-        src2 = self.self_attn(src, reference_points, src, spatial_shapes, level_start_index, padding_mask,
-                              spatial_shapes_py=shapes_py, query_pos=pos)
+                shapes_py=None, query=None, emit_next_query=False):
+        """Reference signature + three optional extras (shapes_py: see MSDeformAttn.forward).  `query`: src + pos when
+        the previous layer already wrote it; emit_next_query: return (out, out + pos), the sum written by the final
+        add+LayerNorm kernel — the encoder then never runs an add pass for `with_pos_embed` after the first layer."""
+        if query is not None:
+            src2 = self.self_attn(query, reference_points, src, spatial_shapes, level_start_index, padding_mask,
+                                  spatial_shapes_py=shapes_py)
+        else:
+            src2 = self.self_attn(src, reference_points, src, spatial_shapes, level_start_index, padding_mask,
+                                  spatial_shapes_py=shapes_py, query_pos=pos)
         src = Fn.add_layer_norm(src2, src, self.norm1)
         src2 = self.linear2(Fn.linear_relu(src, self.linear1))
-        return Fn.add_layer_norm(src2, src, self.norm2)
+        if emit_next_query and pos is not None and pos.shape[0] == 1:
+            return Fn.add_layer_norm(src2, src, self.norm2, pos=pos)
+        out = Fn.add_layer_norm(src2, src, self.norm2)
+        return (out, None) if emit_next_query else out
 
 
 class MSDeformAttnTransformerEncoder(nn.Module):
@@ -234,10 +244,12 @@ class MSDeformAttnTransformerEncoder(nn.Module):
             reference_points = self.reference_points_unpadded(shapes_py, src.device)
         else:
             reference_points = self.get_reference_points(spatial_shapes.tolist(), valid_ratios, src.device)
-        output = src
-        for layer in self.layers:
-            output = layer(output, pos, reference_points, spatial_shapes, level_start_index, padding_mask,
-                           shapes_py=shapes_py)
+        output, query = src, None
+        for i, layer in enumerate(self.layers):
+            last = i + 1 == len(self.layers)
+            r = layer(output, pos, reference_points, spatial_shapes, level_start_index, padding_mask,
+                      shapes_py=shapes_py, query=query, emit_next_query=not last)
+            output, query = (r, None) if last else r
         return output
 
 

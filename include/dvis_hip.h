@@ -167,6 +167,15 @@ int dvis_add_layernorm(const float *x, const float *res, int64_t res_row_stride,
                        float *out, int64_t rows, int C, float eps, void *stream);
 
 /*
+ * dvis_add_layernorm with a second output  out_pos[r, :] = out[r, :] + pos[r mod pos_rows, :]  (pos: pos_rows x C): the
+ * deformable encoder's next-layer query `with_pos_embed(src, pos)` (msdeformattn.py:121-123 / ms_deform_attn.py:108) is
+ * written while the row is still in registers instead of by an add kernel of its own.
+ */
+int dvis_add_layernorm_pos(const float *x, const float *res, int64_t res_row_stride, const float *gamma, const float *beta,
+                           float *out, const float *pos, int64_t pos_rows, float *out_pos, int64_t rows, int C, float eps,
+                           void *stream);
+
+/*
  * out = lateral + F.interpolate(top, size=(H, W), mode="bilinear", align_corners=False) for `planes` = N*C planes;
  * lateral / out (planes, H, W), top (planes, h, w); W % 4 == 0.  (FPN top-down step, msdeformattn.py:347.)
  */

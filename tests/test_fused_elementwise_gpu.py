@@ -127,3 +127,15 @@ def test_upsample_add_with_lateral_group_norm():
         latd = lat.to(DEV)
         out = Fn.upsample_add(latd, top.to(DEV), Fn.group_norm_affine(latd, gn.to(DEV))).cpu()
     torch.testing.assert_close(out, ref, rtol=1e-5, atol=2e-5)
+
+
+def test_add_layernorm_second_output_with_position_embedding():
+    from dvis_plus_amd.functions import add_layer_norm
+    g = torch.Generator().manual_seed(11)
+    x, r, pos = torch.randn(3, 50, 256, generator=g), torch.randn(3, 50, 256, generator=g), torch.randn(1, 50, 256, generator=g)
+    ln = torch.nn.LayerNorm(256)
+    with torch.no_grad():
+        ref = ln(x + r)
+        out, out_pos = add_layer_norm(x.to(DEV), r.to(DEV), ln.to(DEV), pos=pos.to(DEV))
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=5e-6)
+    assert torch.equal(out_pos, out + pos.to(DEV))
