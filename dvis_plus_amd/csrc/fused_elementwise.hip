@@ -200,7 +200,9 @@ __global__ __launch_bounds__(256) void bias_act_kernel(float *__restrict__ x, co
 // the flatten(2).transpose(1, 2) + cat of MSDeformAttnTransformerEncoderOnly.forward (msdeformattn.py:64-79) without
 // torch's strided-copy kernel (0.6 TB/s).  64 x 64 tiles through LDS: reads run along p, writes along c.
 __global__ __launch_bounds__(256) void nchw_to_tokens_kernel(const float *__restrict__ x, float *__restrict__ out, int C,
-                                                             int HW, int64_t S, int64_t row0) {
+                                                             int HW, int64_t S, int64_t row0,
+                                                             const float *__restrict__ scale, const float *__restrict__ shift,
+                                                             const float *__restrict__ pos, float *__restrict__ out_pos) {
   __shared__ float tile[64][65];
   const int n = blockIdx.z, c0 = blockIdx.y * 64, p0 = blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -208,28 +210,48 @@ __global__ __launch_bounds__(256) void nchw_to_tokens_kernel(const float *__rest
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int c = c0 + ty + 4 * i, p = p0 + tx;
-    tile[ty + 4 * i][tx] = (c < C && p < HW) ? xb[(size_t)c * HW + p] : 0.f;
+    float v = (c < C && p < HW) ? xb[(size_t)c * HW + p] : 0.f;
+    if (scale && c < C) v = v * scale[(size_t)n * C + c] + shift[(size_t)n * C + c];   // the map's GroupNorm, per plane
+    tile[ty + 4 * i][tx] = v;
   }
   __syncthreads();
   float *ob = out + ((size_t)n * S + row0) * C;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int p = p0 + ty + 4 * i, c = c0 + tx;
-    if (p < HW && c < C) ob[(size_t)p * C + c] = tile[tx][ty + 4 * i];
+    if (p < HW && c < C) {
+      const float v = tile[tx][ty + 4 * i];
+      ob[(size_t)p * C + c] = v;
+      if (pos)   // second output: tokens + position embedding (the first encoder layer's query)
+        out_pos[((size_t)n * S + row0 + p) * C + c] = v + pos[((size_t)row0 + p) * C + c];
+    }
   }
 }
 
 }  // namespace
 
-DVIS_EXPORT int dvis_nchw_to_tokens(const float *x, float *out, int64_t N, int C, int64_t HW, int64_t S, int64_t row0,
-                                    void *stream) {
+static int nchw_to_tokens_launch(const float *x, float *out, int64_t N, int C, int64_t HW, int64_t S, int64_t row0,
+                                 const float *scale, const float *shift, const float *pos, float *out_pos, void *stream) {
   DVIS_REQUIRE(N >= 0 && C > 0 && HW > 0 && S >= HW && row0 >= 0 && row0 + HW <= S, "nchw_to_tokens: bad sizes");
   if (N == 0) return DVIS_OK;
   DVIS_REQUIRE(x && out, "nchw_to_tokens: null pointer");
+  DVIS_REQUIRE((scale == nullptr) == (shift == nullptr) && (pos == nullptr) == (out_pos == nullptr),
+               "nchw_to_tokens: scale/shift and pos/out_pos come in pairs");
   DVIS_REQUIRE(N <= 65535 && (C + 63) / 64 <= 65535 && HW < (1ll << 31), "nchw_to_tokens: grid too large");
   hipLaunchKernelGGL(nchw_to_tokens_kernel, dim3((unsigned)((HW + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)N), dim3(256),
-                     0, (hipStream_t)stream, x, out, C, (int)HW, S, row0);
+                     0, (hipStream_t)stream, x, out, C, (int)HW, S, row0, scale, shift, pos, out_pos);
   return dvis_check_launch("nchw_to_tokens_kernel");
+}
+
+DVIS_EXPORT int dvis_nchw_to_tokens(const float *x, float *out, int64_t N, int C, int64_t HW, int64_t S, int64_t row0,
+                                    void *stream) {
+  return nchw_to_tokens_launch(x, out, N, C, HW, S, row0, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+DVIS_EXPORT int dvis_nchw_to_tokens_affine(const float *x, const float *scale, const float *shift, const float *pos,
+                                           float *out, float *out_pos, int64_t N, int C, int64_t HW, int64_t S,
+                                           int64_t row0, void *stream) {
+  return nchw_to_tokens_launch(x, out, N, C, HW, S, row0, scale, shift, pos, out_pos, stream);
 }
 
 DVIS_EXPORT int dvis_bias_act(float *x, const float *bias, const float *res, int64_t planes, int C, int64_t HW, int relu,
@@ -408,8 +430,8 @@ DVIS_EXPORT int dvis_group_norm_affine(const float *x, const float *gamma, const
   DVIS_REQUIRE(N >= 0 && C > 0 && G > 0 && HW > 0 && C % G == 0, "group_norm_affine: bad sizes (C=%d G=%d)", C, G);
   if (N == 0) return DVIS_OK;
   DVIS_REQUIRE(x && scale && shift, "group_norm_affine: null pointer");
-  DVIS_REQUIRE(C / G <= 1024 && ((int64_t)(C / G) * HW) % 4 == 0 && ((uintptr_t)x & 15) == 0 && (HW % 4 == 0 || G == 1),
-               "group_norm_affine: a group must be a multiple of 4 floats, 16-byte aligned");
+  DVIS_REQUIRE(C / G <= 1024 && ((int64_t)(C / G) * HW) % 4 == 0 && ((uintptr_t)x & 15) == 0,
+               "group_norm_affine: a group must be a multiple of 4 floats, x 16-byte aligned");
   DVIS_REQUIRE(N * G < (1ll << 31), "group_norm_affine: too many groups");
   hipLaunchKernelGGL(group_norm_affine_kernel, dim3((unsigned)(N * G)), dim3(1024), 0, (hipStream_t)stream, x, gamma, beta,
                      scale, shift, C, G, (long long)HW, eps);

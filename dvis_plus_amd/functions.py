@@ -352,7 +352,7 @@ def group_norm_affine(x, norm):
     (caller falls back to ``norm(x)``)."""
     N, C, H, W = x.shape
     G = norm.num_groups
-    if not (_fused_map_ok(x) and (C // G) * H * W % 4 == 0 and C // G <= 1024):
+    if not (_fused_map_ok(x) and (C // G) * H * W % 4 == 0 and C // G <= 1024 and x.data_ptr() % 16 == 0):
         return None
     scale = torch.empty(N * C, dtype=torch.float32, device=x.device)
     shift = torch.empty(N * C, dtype=torch.float32, device=x.device)
@@ -420,23 +420,38 @@ def linear_relu(x, lin):
     return linear(x, lin.weight, lin.bias, relu=True)
 
 
-def maps_to_tokens(maps):
+def maps_to_tokens(maps, affines=None, pos=None):
     """[(N, C, h_l, w_l)] -> (N, sum h_l*w_l, C): ``torch.cat([m.flatten(2).transpose(1, 2) for m in maps], 1)`` with one
-    tiled transpose per level instead of torch's strided copy.  CPU / non-fp32 / non-contiguous inputs use the torch ops."""
-    if not all(m.is_cuda and m.dtype == torch.float32 and m.is_contiguous() for m in maps) or torch.is_grad_enabled():
-        return torch.cat([m.flatten(2).transpose(1, 2) for m in maps], 1)
+    tiled transpose per level instead of torch's strided copy.  CPU / non-fp32 / non-contiguous inputs use the torch ops.
+    affines: per level None or (scale, shift) from ``group_norm_affine`` — the map is read as m * scale + shift.
+    pos: optional (1, S, C) / (S, C) token-major embedding: returns (tokens, tokens + pos), both written in the one pass."""
+    affines = affines or [None] * len(maps)
     N, C = maps[0].shape[:2]
+    if not all(m.is_cuda and m.dtype == torch.float32 and m.is_contiguous() for m in maps) or torch.is_grad_enabled():
+        maps = [m if a is None else m * a[0].view(N, C, 1, 1) + a[1].view(N, C, 1, 1) for m, a in zip(maps, affines)]
+        out = torch.cat([m.flatten(2).transpose(1, 2) for m in maps], 1)
+        return out if pos is None else (out, out + pos.reshape(1, -1, C))
     S = sum(m.shape[2] * m.shape[3] for m in maps)
     out = torch.empty((N, S, C), dtype=torch.float32, device=maps[0].device)
+    out_pos = pp = None
+    if pos is not None:
+        if pos.numel() != S * C or pos.dtype != torch.float32 or not pos.is_cuda:
+            raise RuntimeError("maps_to_tokens: pos must be a float32 GPU (S, C) embedding")
+        pos = pos.contiguous()
+        out_pos = torch.empty_like(out)
+        pp = native.dev_ptr(pos, "pos")
     row0 = 0
     with torch.cuda.device(out.device):
-        for m in maps:
+        for m, a in zip(maps, affines):
             HW = m.shape[2] * m.shape[3]
-            rc = native.lib().dvis_nchw_to_tokens(ctypes.c_void_p(m.data_ptr()), ctypes.c_void_p(out.data_ptr()), N, C, HW, S,
-                                                  row0, native.stream_ptr(out.device))
-            native.check(rc, "dvis_nchw_to_tokens")
+            rc = native.lib().dvis_nchw_to_tokens_affine(
+                ctypes.c_void_p(m.data_ptr()), None if a is None else native.dev_ptr(a[0], "scale"),
+                None if a is None else native.dev_ptr(a[1], "shift"), pp, ctypes.c_void_p(out.data_ptr()),
+                None if out_pos is None else ctypes.c_void_p(out_pos.data_ptr()), N, C, HW, S, row0,
+                native.stream_ptr(out.device))
+            native.check(rc, "dvis_nchw_to_tokens_affine")
             row0 += HW
-    return out
+    return out if pos is None else (out, out_pos)
 
 
 def conv1x1(x, weight, bias=None):

@@ -239,12 +239,12 @@ class MSDeformAttnTransformerEncoder(nn.Module):
         return self._ref_cache[key]
 
     def forward(self, src, spatial_shapes, level_start_index, valid_ratios=None, pos=None, padding_mask=None,
-                shapes_py=None):
+                shapes_py=None, query0=None):
         if valid_ratios is None:
             reference_points = self.reference_points_unpadded(shapes_py, src.device)
         else:
             reference_points = self.get_reference_points(spatial_shapes.tolist(), valid_ratios, src.device)
-        output, query = src, None
+        output, query = src, query0            # query0: src + pos when the caller already has it
         for i, layer in enumerate(self.layers):
             last = i + 1 == len(self.layers)
             r = layer(output, pos, reference_points, spatial_shapes, level_start_index, padding_mask,
@@ -283,14 +283,21 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
             self._shape_cache[key] = (s, lsi)
         return self._shape_cache[key]
 
-    def forward(self, srcs, pos_embeds):
-        """srcs: per level (N, C, H, W); pos_embeds: per level (1|N, C, H, W).  No padding (masks all False)."""
+    def forward(self, srcs, pos_embeds, affines=None):
+        """srcs: per level (N, C, H, W); pos_embeds: per level (1|N, C, H, W).  No padding (masks all False).
+        affines: per level None or the (scale, shift) of a GroupNorm still to be applied to the map
+        (Fn.group_norm_affine) — done while the map is transposed into tokens."""
         shapes_py = [(int(s.shape[2]), int(s.shape[3])) for s in srcs]
-        src_flatten = Fn.maps_to_tokens(srcs)
         lvl_pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1)
                              for lvl, p in enumerate(pos_embeds)], 1)
+        query0 = None
+        if lvl_pos.shape[0] == 1 and srcs[0].is_cuda and not torch.is_grad_enabled():
+            src_flatten, query0 = Fn.maps_to_tokens(srcs, affines, pos=lvl_pos)   # tokens and tokens + pos in one pass
+        else:
+            src_flatten = Fn.maps_to_tokens(srcs, affines)
         spatial_shapes, level_start_index = self._shape_tensors(shapes_py, src_flatten.device)
-        memory = self.encoder(src_flatten, spatial_shapes, level_start_index, None, lvl_pos, None, shapes_py=shapes_py)
+        memory = self.encoder(src_flatten, spatial_shapes, level_start_index, None, lvl_pos, None, shapes_py=shapes_py,
+                              query0=query0)
         return memory, spatial_shapes, level_start_index, shapes_py
 
 
@@ -408,12 +415,16 @@ class MSDeformAttnPixelDecoder(nn.Module):
         """features: dict name -> (N, C, H, W).  fp32 island like the reference (msdeformattn.py:314-320).
         Returns (mask_features, out[0], multi_scale_features[:3])."""
         with torch.autocast(device_type="cuda", enabled=False):
-            srcs, pos = [], []
+            srcs, pos, affines = [], [], []
             for idx, f in enumerate(self.transformer_in_features[::-1]):
                 x = features[f].float()
-                srcs.append(self.input_proj[idx](x))
+                conv, gn = self.input_proj[idx][0], self.input_proj[idx][1]
+                s_ = conv(x)
+                affine = Fn.group_norm_affine(s_, gn)        # GroupNorm applied while the map is laid down as tokens
+                srcs.append(s_ if affine is not None else gn(s_))
+                affines.append(affine)
                 pos.append(self.pe_layer.compute(x.shape[2], x.shape[3], x.device))
-            y, _, _, shapes_py = self.transformer(srcs, pos)
+            y, _, _, shapes_py = self.transformer(srcs, pos, affines)
             bs = y.shape[0]
             out, tokens, start = [], [], 0
             for (h, w) in shapes_py:

@@ -190,6 +190,15 @@ int dvis_upsample_add(const float *lateral, const float *top, float *out, int64_
 int dvis_nchw_to_tokens(const float *x, float *out, int64_t N, int C, int64_t HW, int64_t S, int64_t row0, void *stream);
 
 /*
+ * dvis_nchw_to_tokens with the map read as x[n][c] * scale[n*C + c] + shift[n*C + c] (the input projection's GroupNorm,
+ * msdeformattn.py:231-247, from dvis_group_norm_affine; NULL pair = identity) and an optional second output
+ * out_pos[n][row0 + p][c] = out[n][row0 + p][c] + pos[row0 + p][c] (pos: (S, C) token-major position + level embedding;
+ * the first encoder layer's query, msdeformattn.py:121-123; NULL pair = not written).
+ */
+int dvis_nchw_to_tokens_affine(const float *x, const float *scale, const float *shift, const float *pos, float *out,
+                               float *out_pos, int64_t N, int C, int64_t HW, int64_t S, int64_t row0, void *stream);
+
+/*
  * In place on `planes` = N*C contiguous planes of HW floats (NCHW): x = relu?(x + bias[c] + res).  bias (C,) or NULL,
  * res same shape as x or NULL.  The folded-FrozenBN bias, bottleneck shortcut add and ReLU after a library convolution
  * in one pass.  HW % 4 == 0.
