@@ -42,6 +42,21 @@ class MaskFormerHead(nn.Module):
         return self.predictor(multi_scale_features, mask_features, mask)
 
 
+def segmenter_frames_per_call(n, H, W, requested=0):
+    """Frames per segmenter call for n frames of H x W input (requested: the user's chunk, 0 = as many as possible).
+    No activation of one call may reach 4 GiB: the largest is the encoder's FFN hidden tensor, 1024 floats for each of
+    the H*W*(1/64 + 1/256 + 1/1024) tokens of a frame = 84 B per input pixel (55 frames at 720p).  Beyond that the
+    streamed schedule (two segmenter passes in flight on two streams) stopped making progress on MI355X / ROCm 7.2
+    (T >= 56; T <= 54, and the clip-by-clip schedule at T = 64, are fine) — not understood, so larger batches are cut
+    into equal calls below the limit (cost: one more launch sequence; T = 64 streams at 183 frames/s as 2 x 32)."""
+    cap = max(1, (2 ** 32 - 1) // (84 * H * W))
+    chunk = min(requested or max(1, n), cap)
+    if 0 < chunk < n:
+        calls = (n + chunk - 1) // chunk
+        chunk = (n + calls - 1) // calls          # equal shares
+    return max(1, chunk)
+
+
 class _VideoBase(nn.Module):
     def __init__(self, *, backbone, sem_seg_head, num_queries, object_mask_threshold=0.8, overlap_threshold=0.8,
                  n_things=0, size_divisibility=32, pixel_mean=(123.675, 116.280, 103.530),
@@ -95,7 +110,7 @@ class _VideoBase(nn.Module):
 
     def encode(self, images):
         """Backbone + pixel decoder over this rank's frames: (multi_scale_features, mask_features (t,Cm,h,w))."""
-        chunk = self.segmenter_chunk or max(1, len(images))
+        chunk = segmenter_frames_per_call(len(images), images.shape[-2], images.shape[-1], self.segmenter_chunk)
         ms, mf = [], []
         for s in range(0, len(images), chunk):
             f, _, m = self.sem_seg_head.pixel_decoder.forward_features(self.backbone(images[s:s + chunk]))

@@ -450,3 +450,11 @@ def test_rotated_blocks_cover_every_frame_once():
                 total[r] += hi - lo
             assert sorted(seen) == list(range(T))
         assert len(set(total)) == 1 and total[0] == T
+
+
+def test_segmenter_batches_stay_below_4gib_activations():
+    from dvis_plus_amd.meta_architecture import segmenter_frames_per_call as f
+    assert f(30, 736, 1280) == 30 and f(54, 736, 1280) == 54            # one call
+    assert f(64, 736, 1280) == 32 and f(56, 736, 1280) == 28            # equal shares below the 55-frame limit
+    assert f(30, 736, 1280, requested=4) == 4 and f(64, 736, 1280, requested=60) == 32
+    assert f(200, 480, 640) == 100 and f(0, 736, 1280) == 1 and f(1, 4000, 6000) == 1
