@@ -23,6 +23,8 @@ def mean_logits(pred_logits, aux_logits=None):
 
 
 def _resize2(masks, first_resize_size, img_size, out_hw, sigmoid):
+    if masks.shape[1] == 0:                      # a rank that holds no frame of this clip (T < world * frames_per_rank)
+        return masks.new_zeros((masks.shape[0], 0, *out_hw))
     m = F.interpolate(masks, size=tuple(first_resize_size), mode="bilinear", align_corners=False)
     m = m[:, :, :img_size[0], :img_size[1]]
     if sigmoid:
@@ -72,7 +74,12 @@ def inference_video_vps(pred_cls, mask_fn, img_size, out_hw, first_resize_size, 
     cur_scores, cur_classes = scores[ids], labels[ids]
     K = ids.numel()
     logits = mask_fn(ids)                                                                     # (K', T, h, w)
-    if logits.is_cuda and K <= 256:
+    if logits.shape[1] == 0:
+        # no frame of the clip on this rank: empty panoptic map, zero areas — but the same collective as everyone else
+        cur_mask_ids = torch.zeros((0, *out_hw), dtype=torch.long, device=dev)
+        conf = torch.zeros((0, *out_hw), dtype=torch.bool, device=dev)
+        areas = torch.zeros((3, K), dtype=torch.float64, device=dev)
+    elif logits.is_cuda and K <= 256:
         # one fused pass over the stride-4 logits (two-stage resize + sigmoid + weighted arg-max + areas)
         from . import functions as Fn
         cur_mask_ids, conf, areas = Fn.vps_argmax(logits, cur_scores, first_resize_size, img_size, out_hw)
@@ -118,6 +125,9 @@ def inference_video_vss(pred_cls, mask_fn, img_size, out_hw, first_resize_size, 
     if aux_pred_cls is not None:
         mask_cls = torch.maximum(mask_cls, F.softmax(aux_pred_cls, dim=-1)[..., :-1].to(mask_cls))
     masks = mask_fn(None)                                                                     # (Q, T, h, w)
+    if masks.shape[1] == 0:
+        return {"image_size": tuple(out_hw), "pred_masks": torch.zeros((0, *out_hw), dtype=torch.long, device=masks.device),
+                "task": "vss"}
     if masks.is_cuda and mask_cls.shape[1] <= 128:
         from . import functions as Fn
         if masks.stride(3) != 1 or masks.stride(2) != masks.shape[3]:

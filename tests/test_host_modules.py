@@ -273,25 +273,28 @@ def _stream_worker(rank, world, port, out_dir, owner_rounds):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("owner_rounds", [1, 0])
-def test_clip_stream_world_size_2_gloo(oracle_ops, tmp_path, owner_rounds):
+@pytest.mark.parametrize("world,owner_rounds", [(2, 1), (2, 0), (3, 1)])
+def test_clip_stream_world_size_2_gloo(oracle_ops, tmp_path, world, owner_rounds):
     """stream() under frame sharding: phase A has no collective, phase B issues them in the same order on every rank.
-    owner_rounds=1: clips go in rounds of 2, clip j of a round is tracked + refined by rank j only (3 clips -> rank 0
-    tracks two, rank 1 one) and the results are all-gathered; owner_rounds=0: every rank tracks every clip."""
+    owner_rounds=1: clips go in rounds of `world`, clip j of a round is tracked + refined by rank j only (3 clips on 2
+    ranks -> rank 0 tracks two, rank 1 one; on 3 ranks one each) and the results are all-gathered; a rank's frames of a
+    round are one segmenter batch; the ragged split rotates clip by clip.  owner_rounds=0: every rank tracks every clip."""
     import torch.multiprocessing as mp
-    port = 33500 + (os.getpid() % 2000) + owner_rounds
-    mp.spawn(_stream_worker, args=(2, port, str(tmp_path), owner_rounds), nprocs=2, join=True)
+    port = 33500 + (os.getpid() % 2000) + 10 * world + owner_rounds
+    mp.spawn(_stream_worker, args=(world, port, str(tmp_path), owner_rounds), nprocs=world, join=True)
     m = _tiny_model("offline", "vps")
-    parts = [torch.load(tmp_path / f"s{r}.pt") for r in range(2)]
-    assert [p["tracked"] for p in parts] == ([2, 1] if owner_rounds else [3, 3])
+    parts = [torch.load(tmp_path / f"s{r}.pt") for r in range(world)]
+    n = len(STREAM_CLIPS)
+    want_tracked = [len(range(r, n, world)) for r in range(world)] if owner_rounds else [n] * world
+    assert [p["tracked"] for p in parts] == want_tracked
     for ci, (T, seed) in enumerate(STREAM_CLIPS):
         single = m([{"image": _tiny_clip(T, seed=seed), "height": 70, "width": 100}])
         # clip ci shards with the block -> rank assignment rotated by ci (the short block changes rank every clip)
-        order = [(r - ci) % 2 for r in range(2)]                       # block held by rank r
-        per = (T + 1) // 2
-        blocks = [list(range(per)), list(range(per, T))]
+        per = (T + world - 1) // world
+        blocks = [list(range(min(T, b * per), min(T, (b + 1) * per))) for b in range(world)]
+        order = [(r - ci) % world for r in range(world)]               # block held by rank r
         assert [p["outs"][ci]["frame_ids"] for p in parts] == [blocks[b] for b in order]
-        by_block = sorted(range(2), key=lambda r: order[r])
+        by_block = sorted(range(world), key=lambda r: order[r])
         assert torch.equal(torch.cat([parts[r]["outs"][ci]["masks"] for r in by_block], 0), single["pred_masks"])
         assert all(p["outs"][ci]["segs"] == single["segments_infos"] for p in parts)
 
