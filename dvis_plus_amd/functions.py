@@ -465,7 +465,7 @@ def conv1x1(x, weight, bias=None):
         # bmm with a stride-0 batch of W, not torch.matmul: matmul folds the batch (transpose + copy of X, 4x slower)
         # whenever the 2-D operand is a Parameter that requires grad, even under no_grad
         y = torch.bmm(weight.detach().view(1, Co, Ci).expand(N, Co, Ci), x.view(N, Ci, H * W)).view(N, Co, H, W)
-        return y if bias is None else y.add_(bias.view(1, -1, 1, 1))
+        return y if bias is None else bias_act_(y, bias.detach(), None, relu=False)   # in place, at the HBM stream rate
     return torch.nn.functional.conv2d(x, weight, bias)
 
 
