@@ -461,3 +461,40 @@ def test_segmenter_batches_stay_below_4gib_activations():
     assert f(64, 736, 1280) == 32 and f(56, 736, 1280) == 28            # equal shares below the 55-frame limit
     assert f(30, 736, 1280, requested=4) == 4 and f(64, 736, 1280, requested=60) == 32
     assert f(200, 480, 640) == 100 and f(0, 736, 1280) == 1 and f(1, 4000, 6000) == 1
+
+
+def _keep_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import conftest as c
+    from dvis_plus_amd import functions as Fn
+    Fn.attention, Fn.attn_mask, Fn.mask_logits = c._o_attention, c._o_attn_mask, c._o_mask_logits
+    Fn.msda_fused_forward, Fn.MSDeformAttnFunction = c._o_msda_fused, c._OMSDAFunction
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _tiny_model("offline", "vps")
+    frames = _tiny_clip(8, seed=9)
+    clips = [{"image": frames[:4], "height": 70, "width": 100},
+             {"image": frames[4:], "height": 70, "width": 100, "keep": True}]     # second half resumes the tracker
+    outs = [{"masks": o["pred_masks"], "segs": o["segments_infos"], "frame_ids": o["frame_ids"]} for o in m.stream(clips)]
+    torch.save(outs, os.path.join(out_dir, f"k{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_clip_stream_with_resumed_tracker_state_takes_the_replicated_path(oracle_ops, tmp_path):
+    """A round that contains a `keep` clip (tracker state carried over from the previous call) cannot hand its clips to
+    different tracker ranks: every rank runs the tracker of both clips, in order — same results as one process."""
+    import torch.multiprocessing as mp
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_keep_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    m = _tiny_model("offline", "vps")
+    frames = _tiny_clip(8, seed=9)
+    first = m([{"image": frames[:4], "height": 70, "width": 100}])
+    second = m([{"image": frames[4:], "height": 70, "width": 100, "keep": True}])
+    parts = [torch.load(tmp_path / f"k{r}.pt") for r in range(2)]
+    for ci, single in enumerate((first, second)):
+        order = sorted(range(2), key=lambda r: parts[r][ci]["frame_ids"][0])
+        assert torch.equal(torch.cat([parts[r][ci]["masks"] for r in order], 0), single["pred_masks"])
+        assert all(p[ci]["segs"] == single["segments_infos"] for p in parts)
