@@ -162,3 +162,23 @@ def test_maps_to_tokens_with_group_norm_and_position_output():
         plain = Fn.maps_to_tokens(md, aff)
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=2e-5)
     assert torch.equal(out_pos, out + pos.to(DEV)) and torch.equal(plain, out)
+
+
+def test_zero_size_batches_pass_through_every_glue_op():
+    """A rank that holds no frame of a clip calls the ops with N = 0: no launch, correctly shaped empty outputs."""
+    from dvis_plus_amd import functions as Fn
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    with torch.no_grad():
+        assert Fn.mask_logits(z(0, 10, 64), z(0, 64, 8, 12)).shape == (0, 10, 8, 12)
+        m, a = Fn.attn_mask(z(0, 10, 64), z(0, 64, 8, 12), (4, 6))
+        assert m.shape == (0, 10, 24) and a.shape == (0, 10)
+        ln = torch.nn.LayerNorm(64).to(DEV)
+        assert Fn.add_layer_norm(z(0, 5, 64), z(0, 5, 64), ln).shape == (0, 5, 64)
+        assert Fn.bias_act_(z(0, 8, 4, 8), z(8)).shape == (0, 8, 4, 8)
+        assert Fn.bias_relu_maxpool(z(0, 8, 4, 8), z(8)).shape == (0, 8, 2, 4)
+        assert Fn.upsample_add(z(0, 8, 4, 8), z(0, 8, 2, 4)).shape == (0, 8, 4, 8)
+        assert Fn.maps_to_tokens([z(0, 8, 2, 4), z(0, 8, 4, 8)]).shape == (0, 40, 8)
+        gn = torch.nn.GroupNorm(4, 8).to(DEV)
+        sc, sh = Fn.group_norm_affine(z(0, 8, 4, 8), gn)
+        assert sc.numel() == 0 and sh.numel() == 0
+        assert Fn.scale_shift_act_(z(0, 8, 4, 8), sc, sh, relu=True).shape == (0, 8, 4, 8)
