@@ -4,13 +4,16 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the whole hot path over one synthetic clip of T=30 uint8 720x1280 frames that is already
-resident in HBM: normalise/pad -> R50 backbone -> MSDeformAttn pixel decoder -> masked-attention decoder ->
+resident in HBM (step i gets its own clip, seed 1234 + i): normalise/pad -> R50 backbone -> MSDeformAttn pixel decoder -> masked-attention decoder ->
 (all-gather of per-frame queries when N > 1) -> referring tracker (incl. host assignment) -> temporal refiner ->
 mask contraction -> panoptic post-processing to integer masks on the device.  With N GPUs the SAME clip is sharded by
 frame (strong scaling); value = T * K / max-over-ranks(wall time).  Weights: deterministic random init with the
 reference's init rules (no checkpoints offline).  fp32 throughout (the parity target is the fp32 path).
 
 Also reported on the one JSON line:
+  latency_ms    per-clip latency (first enqueue of the clip -> its outputs complete), p10 / p50 / p90 over the timed clips;
+  stages_ms     stage-synchronised breakdown of one clip (untimed extra pass);
+  candidates_100  the same workload with every non-void query sent to the panoptic stage (short second timed pass);
   roofline      the dominant hand-written kernel of the path, MSDeformAttn forward: algorithmic bytes (61 824 000 B
                 per frame-layer) / its mean launch time (HIP events on the launch stream) vs 8 TB/s.
   cpu_baseline  the oracle's C port of that kernel (OpenMP, all host cores) on a bounded sample, frames-layers/s
@@ -98,8 +101,7 @@ def cpu_baseline(model, clip, frames=3):
     """The metric's own unit on the host cores: the oracle's restatement of the reference pipeline (windowed,
     frame-by-frame tracker, torch ops; oracle/dvis_torch.py) on a bounded sample = the first `frames` frames of the same
     synthetic clip = one window of the reference's loop (TEST.WINDOW_SIZE = 3), same weights, backbone = the same torch
-    modules on the CPU.  Timed once after nothing (the first call pays torch's one-off thread-pool start: it is part of
-    what a CPU user sees on a single clip, and the sample is too long to repeat inside the bench's time budget)."""
+    modules on the CPU.  One warm-up window, one timed window."""
     import copy
     from oracle import dvis_torch as O
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
@@ -107,17 +109,80 @@ def cpu_baseline(model, clip, frames=3):
     backbone = copy.deepcopy(model.backbone).cpu().eval()
     sample = [f for f in clip[:frames].cpu()]
     threads = torch.get_num_threads()
-    t0 = time.time()
-    with torch.no_grad():
-        O.dvis_plus_forward(sd, backbone, sample, offline=True, nheads=8, enc_layers=6, dec_layers=9, tracker_layers=6,
-                            refiner_layers=6, window_size=3, num_classes=124, n_things=58, task="vps",
-                            object_mask_threshold=model.object_mask_threshold, overlap_threshold=0.8,
-                            out_hw=(720, 1280))
-    dt = time.time() - t0
+
+    def run():
+        t0 = time.time()
+        with torch.no_grad():
+            O.dvis_plus_forward(sd, backbone, sample, offline=True, nheads=8, enc_layers=6, dec_layers=9,
+                                tracker_layers=6, refiner_layers=6, window_size=3, num_classes=124, n_things=58,
+                                task="vps", object_mask_threshold=model.object_mask_threshold, overlap_threshold=0.8,
+                                out_hw=(720, 1280))
+        return time.time() - t0
+    warm = run()                               # thread pools, oneDNN primitives, allocator
+    dt = run()
     return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"first {frames} frames (one reference window) of the same 720p synthetic clip through "
-                      f"oracle/dvis_torch.py (fp32 torch CPU ops, {threads} threads), {dt:.1f} s",
+            "sample": f"first {frames} frames (one reference window, TEST.WINDOW_SIZE=3) of the same 720p synthetic clip "
+                      f"through oracle/dvis_torch.py (fp32 torch CPU ops, {threads} threads): 1 warm-up window "
+                      f"({warm:.1f} s) + 1 timed window ({dt:.1f} s)",
             "msda_op": cpu_baseline_msda()}
+
+
+def calibrate_threshold(model, inputs, candidates):
+    """Random-init class logits are near-uniform (max prob ~ 1/125), so the reference's 0.8 score threshold would keep no
+    query and the panoptic stage would be skipped.  One untimed pass finds the score threshold that sends `candidates`
+    queries of THIS clip there (mid-way between the k-th and the (k+1)-th best non-void score)."""
+    from dvis_plus_amd import postprocess as PP
+    seen = {}
+    orig_sel = PP.vps_select
+
+    def spy(pred_cls, num_classes, thr, aux=None):
+        scores, labels, keep = orig_sel(pred_cls, num_classes, thr, aux)
+        seen["s"] = scores[labels.ne(num_classes)].sort(descending=True)[0]
+        return scores, labels, keep
+    PP.vps_select = spy
+    old = model.object_mask_threshold
+    model.object_mask_threshold = 2.0          # keep nothing: cheap calibration pass
+    try:
+        model(inputs)
+    finally:
+        PP.vps_select = orig_sel
+        model.object_mask_threshold = old
+    s = seen["s"]
+    if candidates >= s.numel():
+        return 0.0                             # every non-void query
+    k = max(0, min(candidates, s.numel() - 1))
+    return float((s[k - 1] + s[k]) / 2) if k > 0 else 2.0
+
+
+def stage_breakdown(model, clip, task):
+    """One clip with a device synchronisation after every stage (ms).  Untimed extra pass, offline mode."""
+    from dvis_plus_amd import postprocess as PP
+    acc = {}
+
+    def timed(name, fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        acc[name] = round((time.perf_counter() - t0) * 1e3, 2)
+        return out
+    m = model
+    with torch.no_grad():
+        images, img_size = timed("preprocess", lambda: m.preprocess(clip))
+        feats = timed("backbone", lambda: m.backbone(images))
+        mf, _, ms = timed("pixel_decoder", lambda: m.sem_seg_head.pixel_decoder.forward_features(feats))
+        e, e_nn, lg = timed("decoder", lambda: m.decode(ms, mf))
+        to_bctq = lambda z: z.permute(2, 0, 1).unsqueeze(0)
+        track = timed("tracker", lambda: m.tracker(to_bctq(e), None, resume=False, frame_embeds_no_norm=to_bctq(e_nn),
+                                                   need_masks=False))
+        if m.refiner is None:
+            return acc
+        ref = timed("refiner", lambda: m.refiner(track["pred_embds"], to_bctq(e_nn), None, need_masks=False))
+        cls, aux = PP.mean_logits(ref["pred_logits"], track["pred_logits"])
+        mask_fn = lambda idx: m.refiner.predict_masks(ref["mask_embed"], mf.unsqueeze(0), idx)[0]
+        timed("masks+postprocess", lambda: m._task_output(cls, aux, mask_fn, img_size, (720, 1280), images.shape[-2:],
+                                                          len(images)))
+    return acc
 
 
 BB_NAME = {"r50": "R50", "vitl": "ViT-Adapter-L", "vitb": "ViT-Adapter-B"}
@@ -134,6 +199,7 @@ def main():
                     help="offline = BASELINE headline config (T=30, refiner on); online = config #2 (use --frames 5)")
     ap.add_argument("--candidates", type=int, default=20, help="queries sent to the panoptic stage (see main)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the untimed stage breakdown and the 100-candidate pass")
     ap.add_argument("--backbone", default="r50", choices=["r50", "vitl", "vitb"],
                     help="r50 = the headline config; vitl = BASELINE config #5 (ViT-Adapter-L, use --queries 200)")
     ap.add_argument("--queries", type=int, default=100)
@@ -184,80 +250,106 @@ def main():
     if args.rounds:
         model.pipeline_rounds = args.rounds
     T = args.frames
-    clip = synthetic_clip(T, device)
-    inputs = [{"image": clip, "height": 720, "width": 1280}]
+    # step i runs on its own clip (seed 1234 + i); all of them resident in HBM before timing
+    clips = [synthetic_clip(T, device, seed=1234 + i) for i in range(max(1, args.steps))]
+    videos = [{"image": c, "height": 720, "width": 1280} for c in clips]
+    streamed = bool(args.clip_stream and args.mode == "offline")
 
-    def step():
-        return model(inputs)
-
-    # calibration (untimed): pick the score threshold that sends args.candidates queries to the panoptic stage
+    # calibration (untimed, on clip 0): the score threshold that sends args.candidates queries to the panoptic stage
     if args.task == "vps":
-        from dvis_plus_amd import postprocess as PP
-        PP_scores = {}
-        orig_sel = PP.vps_select
+        model.object_mask_threshold = calibrate_threshold(model, videos[:1], args.candidates)
 
-        def spy(pred_cls, num_classes, thr, aux=None):
-            scores, labels, keep = orig_sel(pred_cls, num_classes, thr, aux)
-            PP_scores["s"] = scores[labels.ne(num_classes)].sort(descending=True)[0]
-            return scores, labels, keep
-        PP.vps_select = spy
-        model.object_mask_threshold = 2.0          # keep nothing: cheap calibration pass
-        step()
-        PP.vps_select = orig_sel
-        s = PP_scores["s"]
-        k = min(args.candidates, s.numel() - 1)
-        model.object_mask_threshold = float((s[k - 1] + s[k]) / 2) if k > 0 else 2.0
+    def run_pass(vids, latencies=None):
+        """All of `vids` through the model.  latencies: list that receives (start event, end event) per clip."""
+        outs = []
+        if streamed:
+            starts = []
+
+            def feed():
+                for v in vids:
+                    if latencies is not None:
+                        e = torch.cuda.Event(enable_timing=True)
+                        e.record()
+                        starts.append(e)
+                    yield v
+            for i, out in enumerate(model.stream(feed())):
+                if latencies is not None:
+                    latencies.append((starts[i], out["ready_event"]))
+                outs.append(out)
+        else:
+            for v in vids:
+                if mark:
+                    torch.empty(64, device=device).uniform_()
+                if latencies is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                outs.append(model([v]))
+                if latencies is not None:
+                    e1.record()
+                    latencies.append((e0, e1))
+        return outs
 
     # Warm-up must see every convolution shape of the timed region: MIOpen searches its solvers (naive kernels
     # included, seconds per shape) the first time a shape appears.  One clip per step on a single GPU; with several
     # ranks stream() batches this rank's frames of a whole round of `world` clips into one segmenter call, so the
     # shapes are those of a full round and of the last, partial round (K mod world clips, same rotation of the ragged
     # split as in the timed pass) — warm up with exactly that sequence.
-    streamed = bool(args.clip_stream and args.mode == "offline")
+    mark = os.environ.get("DVIS_BENCH_MARK") == "1"     # tools/steady_stats.py: marker kernel at each timed step start
     warm_clips = args.warmup
     if streamed and world > 1 and model.owner_rounds:
         warm_clips = max(args.warmup, args.steps if args.steps < world else world + args.steps % world)
-    if streamed:
-        for out in model.stream(inputs * warm_clips):
-            pass
-    else:
-        for _ in range(args.warmup):
-            out = step()
+    run_pass([videos[i % len(videos)] for i in range(warm_clips)])
     torch.cuda.synchronize()
     if dist_on:
         torch.distributed.barrier()
+    model.stream_timing = True
     timer = MsdaTimer()
+    lat = []
     t0 = time.perf_counter()
-    mark = os.environ.get("DVIS_BENCH_MARK") == "1"     # tools/steady_stats.py: marker kernel at each timed step start
     with timer:
-        if streamed:
-            for out in model.stream(inputs * args.steps):
-                pass
-        else:
-            for _ in range(args.steps):
-                if mark:
-                    torch.empty(64, device=device).uniform_()
-                out = step()
+        outs = run_pass(videos[:args.steps], lat)
     torch.cuda.synchronize()
     if dist_on:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
+    out = outs[-1]
+    ncands = [float(o.get("num_candidates") or 0) for o in outs]
     if dist_on:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = tt.item()
-        ncand = torch.tensor([float(out.get("num_candidates") or 0)], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(ncand, op=torch.distributed.ReduceOp.MAX)
+
+    # second, short timed pass: every non-void query goes to the panoptic stage (the upper end of the work that the
+    # candidate count controls).  Same protocol, up to 4 clips; single GPU only.
+    cand100 = None
+    if args.task == "vps" and world == 1 and not dist_on and args.candidates < args.queries and not args.no_extra:
+        thr = model.object_mask_threshold
+        model.object_mask_threshold = 0.0
+        n2 = min(4, args.steps)
+        run_pass(videos[:1])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        o2 = run_pass(videos[:n2])
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t1
+        model.object_mask_threshold = thr
+        cand100 = {"value": round(T * n2 / dt2, 3), "unit": "frames/s", "steps": n2,
+                   "panoptic_candidates": [int(o.get("num_candidates") or 0) for o in o2]}
 
     if rank == 0:
         fps = T * args.steps / dt
         sec, nfr, nlaunch = timer.summary()
         achieved = MSDA_BYTES_PER_FRAME_LAYER * nfr / sec / 1e9
-        traffic = None     # HBM bytes per launch from the committed rocprofv3 PMC passes (bench.py cannot read PMCs itself)
-        tj = os.path.join(ROOT, "profiles", "r01_msda_traffic.json")
-        if os.path.exists(tj):
-            t = json.load(open(tj))
-            traffic = round(t["hbm_bytes_per_launch"] * nfr / t["frames_per_launch"])
+        traffic, traffic_src = None, None     # HBM bytes per launch from the committed rocprofv3 PMC passes (bench.py cannot read PMCs itself)
+        for name in ("r02_msda_traffic.json", "r01_msda_traffic.json"):
+            tj = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(tj):
+                t = json.load(open(tj))
+                traffic = round(t["hbm_bytes_per_launch"] * nfr / t["frames_per_launch"])
+                traffic_src = f"profiles/{name} (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE)"
+                break
+        ms = sorted(e0.elapsed_time(e1) for e0, e1 in lat)
+        pct = lambda q: round(ms[min(len(ms) - 1, int(q * len(ms)))], 2) if ms else None
         res = {
             "metric": f"frames/sec DVIS++ {BB_NAME[args.backbone]} {args.mode}, 720p T={T} synthetic", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
@@ -266,21 +358,30 @@ def main():
                                    f"{args.queries} queries, "
                                    f"temporal refiner {'on' if args.mode == 'offline' else 'off'}, task={args.task}, "
                                    f"frames sharded {world}-way",
-                       "panoptic_candidates": out.get("num_candidates"), "segments": len(out.get("segments_infos", [])),
+                       "clips": f"{args.steps} distinct clips, seed 1234 + i",
+                       "panoptic_candidates": [int(min(ncands)), int(max(ncands))] if ncands else None,
+                       "segments": len(out.get("segments_infos", [])),
                        "tracker_spans": len(model.clip_shard.round_plan(T, getattr(model, "pipeline_rounds", 1))[0]),
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                        "clip_stream": streamed, "warmup_clips_run": warm_clips,
                        "tracker_owner_rounds": bool(streamed and world > 1 and model.owner_rounds)},
-            "roofline": {"bound": "hbm", "kernel": "msda_fwd_tile_f32 (fused MSDeformAttn forward)",
+            "latency_ms": {"p10": pct(0.1), "p50": pct(0.5), "p90": pct(0.9), "n": len(ms),
+                           "note": "clip handed to the model -> its outputs complete (HIP events); under clip streaming a "
+                                   "clip waits one segmenter pass of the previous clip"},
+            "roofline": {"bound": "hbm", "kernel": "msda_fwd (fused MSDeformAttn forward)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": "profiles/r01_msda_traffic.json (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE)",
+                         "traffic_source": traffic_src,
                          "alg_bytes_per_launch": int(MSDA_BYTES_PER_FRAME_LAYER * nfr),
                          "us_per_launch": round(sec * 1e6, 1), "frames_per_launch": nfr, "launches_timed": nlaunch,
                          "alg_bytes_per_frame_layer": MSDA_BYTES_PER_FRAME_LAYER},
         }
+        if cand100 is not None:
+            res["candidates_100"] = cand100
+        if world == 1 and not dist_on and args.mode == "offline" and not args.no_extra:
+            res["stages_ms"] = stage_breakdown(model, clips[0], args.task)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(model, clip)
+            res["cpu_baseline"] = cpu_baseline(model, clips[0])
         print(json.dumps(res))
     if dist_on:
         torch.distributed.destroy_process_group()

@@ -12,42 +12,19 @@
 // (141 MB, cache resident), keeps a running arg-max, and the areas are reduced per block in LDS then with one atomic
 // per (block, segment).  HBM traffic: read 141 MB, write 5 bytes per output pixel.
 //
-// Bilinear taps follow torch's upsample_bilinear2d (align_corners=False):
-//   src = max(scale * (dst + 0.5) - 0.5, 0), i0 = int(src), i1 = i0 + (i0 < in - 1), l1 = src - i0, l0 = 1 - l1,
-//   val = h0 * (w0 * a + w1 * b) + h1 * (w0 * c + w1 * d),  scale = in / out in fp32.
+// Every float that feeds an integer decision (arg-max, >= 0.5, > 0) is evaluated in the operation order of torch's CPU
+// kernels — the device the reference post-processes on — see torch_cpu_math.h: the integer outputs then equal the
+// reference's wherever its own result does not depend on its thread count.
 #include <math.h>
 
 #include "dvis_common.h"
+#include "torch_cpu_math.h"
 
 namespace {
 
 constexpr int kMaxK = 256;
-
-struct Tap {
-  int i0, i1;
-  float l0, l1;
-};
-
-__device__ __forceinline__ Tap make_tap(int dst, float scale, int in) {
-  float src = scale * ((float)dst + 0.5f) - 0.5f;
-  src = src < 0.f ? 0.f : src;
-  Tap t;
-  t.i0 = min((int)src, in - 1);
-  t.i1 = t.i0 + (t.i0 < in - 1 ? 1 : 0);
-  t.l1 = src - (float)t.i0;
-  t.l0 = 1.f - t.l1;
-  return t;
-}
-
-// sigmoid(first-stage bilinear) at pixel (yy, xx) of the padded-size image
-__device__ __forceinline__ float stage1_sigmoid(const float *__restrict__ lg, int h, int w, float sy, float sx, int yy,
-                                                int xx) {
-  const Tap ty = make_tap(yy, sy, h), tx = make_tap(xx, sx, w);
-  const float a = lg[ty.i0 * w + tx.i0], b = lg[ty.i0 * w + tx.i1];
-  const float c = lg[ty.i1 * w + tx.i0], d = lg[ty.i1 * w + tx.i1];
-  const float v = ty.l0 * (tx.l0 * a + tx.l1 * b) + ty.l1 * (tx.l0 * c + tx.l1 * d);
-  return 1.f / (1.f + expf(-v));
-}
+using tcpu::Geometry;
+using tcpu::Tap;
 
 __global__ __launch_bounds__(256) void vps_argmax_kernel(
     const float *__restrict__ logits, int64_t stride_k, int64_t stride_t, const float *__restrict__ scores, int K, int T,
@@ -58,9 +35,7 @@ __global__ __launch_bounds__(256) void vps_argmax_kernel(
   __syncthreads();
 
   const size_t npix = (size_t)T * out_h * out_w;
-  const float s1y = (float)h / (float)first_h, s1x = (float)w / (float)first_w;
-  const float s2y = (float)img_h / (float)out_h, s2x = (float)img_w / (float)out_w;
-  const bool identity2 = img_h == out_h && img_w == out_w;
+  const Geometry g(h, w, first_h, first_w, img_h, img_w, out_h, out_w);
   const int lane = threadIdx.x & 63;
   for (size_t base = (size_t)blockIdx.x * 256; base < npix; base += (size_t)gridDim.x * 256) {   // wave-uniform trip count
     const size_t p = base + threadIdx.x;
@@ -70,19 +45,13 @@ __global__ __launch_bounds__(256) void vps_argmax_kernel(
     const size_t r = pc / out_w;
     const int Y = (int)(r % out_h);
     const int t = (int)(r / out_h);
-    const Tap ty = make_tap(Y, s2y, img_h), tx = make_tap(X, s2x, img_w);
+    const Tap ty = tcpu::make_tap(Y, g.s2y, img_h, out_h), tx = tcpu::make_tap(X, g.s2x, img_w, out_w);
+    const int kind1 = tcpu::bilinear_kind(first_h, first_w, t, T), kind2 = tcpu::bilinear_kind(out_h, out_w, t, T);
     float best = -INFINITY, best_prob = 0.f;
     int best_k = 0;
     for (int k = 0; k < K; ++k) {
       const float *lg = logits + (size_t)k * stride_k + (size_t)t * stride_t;
-      float prob;
-      if (identity2) {     // same size: the second resize is the identity (taps (i, i) with weights (1, 0))
-        prob = stage1_sigmoid(lg, h, w, s1y, s1x, Y, X);
-      } else {
-        const float a = stage1_sigmoid(lg, h, w, s1y, s1x, ty.i0, tx.i0), b = stage1_sigmoid(lg, h, w, s1y, s1x, ty.i0, tx.i1);
-        const float c = stage1_sigmoid(lg, h, w, s1y, s1x, ty.i1, tx.i0), d = stage1_sigmoid(lg, h, w, s1y, s1x, ty.i1, tx.i1);
-        prob = ty.l0 * (tx.l0 * a + tx.l1 * b) + ty.l1 * (tx.l0 * c + tx.l1 * d);
-      }
+      const float prob = tcpu::two_stage<true>(lg, g, Y, X, ty, tx, kind1, kind2);
       // original_area[k]: one LDS atomic per wave instead of one per pixel
       const unsigned long long over = __ballot(valid && prob >= 0.5f);
       if (lane == 0 && over) atomicAdd(&s_area[K + k], __popcll(over));
@@ -117,8 +86,7 @@ __global__ __launch_bounds__(256) void vss_argmax_kernel(
     const float *__restrict__ logits, int64_t stride_q, int64_t stride_t, const float *__restrict__ cls, int Q, int C, int T,
     int h, int w, int first_h, int first_w, int img_h, int img_w, int out_h, int out_w, int64_t *__restrict__ out) {
   const size_t npix = (size_t)T * out_h * out_w;
-  const float s1y = (float)h / (float)first_h, s1x = (float)w / (float)first_w;
-  const float s2y = (float)img_h / (float)out_h, s2x = (float)img_w / (float)out_w;
+  const Geometry g(h, w, first_h, first_w, img_h, img_w, out_h, out_w);
   const bool identity2 = img_h == out_h && img_w == out_w;
   for (size_t base = (size_t)blockIdx.x * 256; base < npix; base += (size_t)gridDim.x * 256) {
     const size_t p = base + threadIdx.x;
@@ -128,7 +96,8 @@ __global__ __launch_bounds__(256) void vss_argmax_kernel(
     const size_t r = pc / out_w;
     const int Y = (int)(r % out_h);
     const int t = (int)(r / out_h);
-    const Tap ty = make_tap(Y, s2y, img_h), tx = make_tap(X, s2x, img_w);
+    const Tap ty = tcpu::make_tap(Y, g.s2y, img_h, out_h), tx = tcpu::make_tap(X, g.s2x, img_w, out_w);
+    const int kind1 = tcpu::bilinear_kind(first_h, first_w, t, T), kind2 = tcpu::bilinear_kind(out_h, out_w, t, T);
     float4 acc[K4];
 #pragma unroll
     for (int k = 0; k < K4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -144,26 +113,25 @@ __global__ __launch_bounds__(256) void vss_argmax_kernel(
       // same size: the second resize is the identity.  The 4 first-stage taps do not depend on q: indices once, and the
       // 4 logits of query q+1 are loaded while query q's class sums are accumulated (the loop is latency-bound otherwise:
       // 128 accumulators leave 2 waves per SIMD).
-      const Tap sy = make_tap(Y, s1y, h), sx = make_tap(X, s1x, w);
+      const Tap sy = tcpu::make_tap(Y, g.s1y, h, first_h), sx = tcpu::make_tap(X, g.s1x, w, first_w);
       const int o00 = sy.i0 * w + sx.i0, o01 = sy.i0 * w + sx.i1, o10 = sy.i1 * w + sx.i0, o11 = sy.i1 * w + sx.i1;
       const float *lg = logits + (size_t)t * stride_t;
+      const bool tail = X >= g.tail_x;
       float a = lg[o00], b = lg[o01], c = lg[o10], d = lg[o11];
 #pragma unroll 1
       for (int q = 0; q < Q; ++q) {
-        const float v = sy.l0 * (sx.l0 * a + sx.l1 * b) + sy.l1 * (sx.l0 * c + sx.l1 * d);
+        const float v = tcpu::bilinear(a, b, c, d, sy, sx, kind1);
         if (q + 1 < Q) {
           const float *nx = lg + (size_t)(q + 1) * stride_q;
           a = nx[o00]; b = nx[o01]; c = nx[o10]; d = nx[o11];
         }
-        accumulate(q, 1.f / (1.f + expf(-v)));
+        accumulate(q, tcpu::sigmoid(v, tail));
       }
     } else {
 #pragma unroll 1
       for (int q = 0; q < Q; ++q) {
         const float *lg = logits + (size_t)q * stride_q + (size_t)t * stride_t;
-        const float a = stage1_sigmoid(lg, h, w, s1y, s1x, ty.i0, tx.i0), b = stage1_sigmoid(lg, h, w, s1y, s1x, ty.i0, tx.i1);
-        const float c = stage1_sigmoid(lg, h, w, s1y, s1x, ty.i1, tx.i0), d = stage1_sigmoid(lg, h, w, s1y, s1x, ty.i1, tx.i1);
-        accumulate(q, ty.l0 * (tx.l0 * a + tx.l1 * b) + ty.l1 * (tx.l0 * c + tx.l1 * d));
+        accumulate(q, tcpu::two_stage<true>(lg, g, Y, X, ty, tx, kind1, kind2));
       }
     }
     float best = -INFINITY;
@@ -195,25 +163,29 @@ __global__ __launch_bounds__(256) void vss_argmax_mfma_kernel(
   for (int i = threadIdx.x; i < Qp * 128; i += 256) s_cls[(i >> 7) * LSC + (i & 127)] = cls[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int j = lane & 15, g = lane >> 4;
+  const int j = lane & 15, gq = lane >> 4;
   const size_t npix = (size_t)T * out_h * out_w;
-  const float s1y = (float)h / (float)first_h, s1x = (float)w / (float)first_w;
+  const Geometry g(h, w, first_h, first_w, out_h, out_w, out_h, out_w);
   const size_t nchunks = (npix + 16 * NT - 1) / (16 * NT);
   for (size_t chunk = (size_t)blockIdx.x * 4 + wv; chunk < nchunks; chunk += (size_t)gridDim.x * 4) {
     // this lane's NT pixels (one per 16-pixel tile) and their first-stage taps
     const float *l00[NT], *l01[NT], *l10[NT], *l11[NT];
-    float wy0[NT], wy1[NT], wx0[NT], wx1[NT];
+    Tap ty1[NT], tx1[NT];
+    int kind1[NT];
+    bool tail[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       const size_t p = min(chunk * (16 * NT) + (size_t)n * 16 + j, npix - 1);
       const int X = (int)(p % out_w);
       const size_t r = p / out_w;
       const int Y = (int)(r % out_h);
-      const Tap sy = make_tap(Y, s1y, h), sx = make_tap(X, s1x, w);
-      const float *base = logits + (size_t)(r / out_h) * stride_t + (size_t)g * stride_q;   // query g of k-step 0
+      const Tap sy = tcpu::make_tap(Y, g.s1y, h, first_h), sx = tcpu::make_tap(X, g.s1x, w, first_w);
+      const float *base = logits + (size_t)(r / out_h) * stride_t + (size_t)gq * stride_q;   // query gq of k-step 0
       l00[n] = base + sy.i0 * w + sx.i0; l01[n] = base + sy.i0 * w + sx.i1;
       l10[n] = base + sy.i1 * w + sx.i0; l11[n] = base + sy.i1 * w + sx.i1;
-      wy0[n] = sy.l0; wy1[n] = sy.l1; wx0[n] = sx.l0; wx1[n] = sx.l1;
+      ty1[n] = sy; tx1[n] = sx;
+      kind1[n] = tcpu::bilinear_kind(first_h, first_w, (int)(r / out_h), T);
+      tail[n] = X >= g.tail_x;
     }
     dvis_f4 acc[8][NT];
 #pragma unroll
@@ -221,7 +193,7 @@ __global__ __launch_bounds__(256) void vss_argmax_mfma_kernel(
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[mt][n] = dvis_f4{0.f, 0.f, 0.f, 0.f};
     // logits of the lane's query of the NEXT k-step are loaded while this k-step's MFMAs run (Qp % 4 == 0, Qp <= Q + 3:
-    // the caller guarantees Qp == Q, so every (ks + g) row exists)
+    // the caller guarantees Qp == Q, so every (ks + gq) row exists)
     float va[NT], vb[NT], vc[NT], vd[NT];
     const size_t step = (size_t)4 * stride_q;
 #pragma unroll
@@ -231,8 +203,7 @@ __global__ __launch_bounds__(256) void vss_argmax_mfma_kernel(
       float pb[NT];
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        const float v = wy0[n] * (wx0[n] * va[n] + wx1[n] * vb[n]) + wy1[n] * (wx0[n] * vc[n] + wx1[n] * vd[n]);
-        pb[n] = 1.f / (1.f + expf(-v));
+        pb[n] = tcpu::sigmoid(tcpu::bilinear(va[n], vb[n], vc[n], vd[n], ty1[n], tx1[n], kind1[n]), tail[n]);
       }
       if (ks + 4 < Qp) {
 #pragma unroll
@@ -241,7 +212,7 @@ __global__ __launch_bounds__(256) void vss_argmax_mfma_kernel(
           va[n] = *l00[n]; vb[n] = *l01[n]; vc[n] = *l10[n]; vd[n] = *l11[n];
         }
       }
-      const float *arow = s_cls + (size_t)(ks + g) * LSC + j;
+      const float *arow = s_cls + (size_t)(ks + gq) * LSC + j;
 #pragma unroll
       for (int mt = 0; mt < 8; ++mt) {
         const float a = arow[16 * mt];
@@ -249,7 +220,7 @@ __global__ __launch_bounds__(256) void vss_argmax_mfma_kernel(
         for (int n = 0; n < NT; ++n) acc[mt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, pb[n], acc[mt][n], 0, 0, 0);
       }
     }
-    // acc[mt][n][r] = sem[class 16*mt + 4*g + r][pixel tile n, column j]: arg-max over classes, first maximum wins
+    // acc[mt][n][r] = sem[class 16*mt + 4*gq + r][pixel tile n, column j]: arg-max over classes, first maximum wins
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       float best = -INFINITY;
@@ -258,7 +229,7 @@ __global__ __launch_bounds__(256) void vss_argmax_mfma_kernel(
       for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int c = 16 * mt + 4 * g + r;
+          const int c = 16 * mt + 4 * gq + r;
           const float v = acc[mt][n][r];
           if (c < C && v > best) { best = v; best_c = c; }      // ascending within the lane
         }
@@ -269,8 +240,67 @@ __global__ __launch_bounds__(256) void vss_argmax_mfma_kernel(
         if (ov > best || (ov == best && oc < best_c)) { best = ov; best_c = oc; }
       }
       const size_t p = chunk * (16 * NT) + (size_t)n * 16 + j;
-      if (g == 0 && p < npix) out[p] = best_c;
+      if (gq == 0 && p < npix) out[p] = best_c;
     }
+  }
+}
+
+// Instance masks (inference_video_vis, dvis_Plus/meta_architecture.py:843-853; MinVIS :390-399):
+//   masks = resize2(resize1(logits)[:img_h, :img_w]) > 0      — no sigmoid between the stages.
+// The reference materialises (K', T, first_h, first_w) and (K', T, H, W) floats; here one thread owns 4 consecutive
+// output pixels of a row and writes them as one 32-bit word of the bool tensor.
+__global__ __launch_bounds__(256) void resize2_gt0_kernel(
+    const float *__restrict__ logits, int64_t stride_k, int64_t stride_t, int K, int T, int h, int w, int first_h,
+    int first_w, int img_h, int img_w, int out_h, int out_w, uint8_t *__restrict__ out) {
+  const Geometry g(h, w, first_h, first_w, img_h, img_w, out_h, out_w);
+  const int wq = (out_w + 3) >> 2;                                   // 4-pixel groups per row
+  const size_t ngroups = (size_t)K * T * out_h * wq;
+  const bool word_ok = (out_w & 3) == 0;
+  for (size_t gi = (size_t)blockIdx.x * 256 + threadIdx.x; gi < ngroups; gi += (size_t)gridDim.x * 256) {
+    const int xg = (int)(gi % wq);
+    size_t r = gi / wq;
+    const int Y = (int)(r % out_h);
+    r /= out_h;
+    const int t = (int)(r % T);
+    const int k = (int)(r / T);
+    const float *lg = logits + (size_t)k * stride_k + (size_t)t * stride_t;
+    const Tap ty = tcpu::make_tap(Y, g.s2y, img_h, out_h);
+    const int kind1 = tcpu::bilinear_kind(first_h, first_w, t, T), kind2 = tcpu::bilinear_kind(out_h, out_w, t, T);
+    uint8_t *orow = out + (((size_t)k * T + t) * out_h + Y) * out_w;
+    unsigned word = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int X = 4 * xg + i;
+      if (X < out_w) {
+        const Tap tx = tcpu::make_tap(X, g.s2x, img_w, out_w);
+        const bool on = tcpu::two_stage<false>(lg, g, Y, X, ty, tx, kind1, kind2) > 0.f;
+        if (word_ok) word |= (on ? 1u : 0u) << (8 * i);
+        else orow[X] = on ? 1 : 0;
+      }
+    }
+    if (word_ok) *reinterpret_cast<unsigned *>(orow + 4 * xg) = word;
+  }
+}
+
+// The float values behind the integer decisions above: out = resize2(maybe_sigmoid(resize1(logits)[:img_h, :img_w])).
+// Exists so that the operation order can be pinned bit for bit against torch's CPU ops (tests), and as the fused form of
+// the reference's interpolate -> crop -> (sigmoid) -> interpolate sequence for callers that want the values.
+template <bool SIGMOID>
+__global__ __launch_bounds__(256) void resize2_kernel(
+    const float *__restrict__ logits, int64_t stride_k, int64_t stride_t, int K, int T, int h, int w, int first_h,
+    int first_w, int img_h, int img_w, int out_h, int out_w, float *__restrict__ out) {
+  const Geometry g(h, w, first_h, first_w, img_h, img_w, out_h, out_w);
+  const size_t npix = (size_t)K * T * out_h * out_w;
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
+    const int X = (int)(p % out_w);
+    size_t r = p / out_w;
+    const int Y = (int)(r % out_h);
+    r /= out_h;
+    const int t = (int)(r % T);
+    const int k = (int)(r / T);
+    const Tap ty = tcpu::make_tap(Y, g.s2y, img_h, out_h), tx = tcpu::make_tap(X, g.s2x, img_w, out_w);
+    const int kind1 = tcpu::bilinear_kind(first_h, first_w, t, T), kind2 = tcpu::bilinear_kind(out_h, out_w, t, T);
+    out[p] = tcpu::two_stage<SIGMOID>(logits + (size_t)k * stride_k + (size_t)t * stride_t, g, Y, X, ty, tx, kind1, kind2);
   }
 }
 
@@ -336,4 +366,43 @@ DVIS_EXPORT int dvis_vss_argmax(const float *logits, int64_t stride_q, int64_t s
   else DVIS_VSS(32);
 #undef DVIS_VSS
   return dvis_check_launch("vss_argmax_kernel");
+}
+
+DVIS_EXPORT int dvis_resize2_gt0(const float *logits, int64_t stride_k, int64_t stride_t, int K, int T, int h, int w,
+                                 int first_h, int first_w, int img_h, int img_w, int out_h, int out_w, uint8_t *out,
+                                 void *stream) {
+  DVIS_REQUIRE(K >= 0 && T >= 0 && h > 0 && w > 0 && first_h > 0 && first_w > 0 && img_h > 0 && img_w > 0 && out_h > 0 &&
+                   out_w > 0,
+               "resize2_gt0: bad sizes");
+  DVIS_REQUIRE(img_h <= first_h && img_w <= first_w, "resize2_gt0: image size exceeds the padded size");
+  if (K == 0 || T == 0) return DVIS_OK;
+  DVIS_REQUIRE(logits && out, "resize2_gt0: null pointer");
+  DVIS_REQUIRE((((uintptr_t)out) & 3) == 0, "resize2_gt0: out must be 4-byte aligned");
+  const size_t ngroups = (size_t)K * T * out_h * ((out_w + 3) / 4);
+  size_t blocks = (ngroups + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipLaunchKernelGGL(resize2_gt0_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, logits, stride_k,
+                     stride_t, K, T, h, w, first_h, first_w, img_h, img_w, out_h, out_w, out);
+  return dvis_check_launch("resize2_gt0_kernel");
+}
+
+DVIS_EXPORT int dvis_resize2(const float *logits, int64_t stride_k, int64_t stride_t, int K, int T, int h, int w,
+                             int first_h, int first_w, int img_h, int img_w, int out_h, int out_w, int sigmoid, float *out,
+                             void *stream) {
+  DVIS_REQUIRE(K >= 0 && T >= 0 && h > 0 && w > 0 && first_h > 0 && first_w > 0 && img_h > 0 && img_w > 0 && out_h > 0 &&
+                   out_w > 0,
+               "resize2: bad sizes");
+  DVIS_REQUIRE(img_h <= first_h && img_w <= first_w, "resize2: image size exceeds the padded size");
+  if (K == 0 || T == 0) return DVIS_OK;
+  DVIS_REQUIRE(logits && out, "resize2: null pointer");
+  const size_t npix = (size_t)K * T * out_h * out_w;
+  size_t blocks = (npix + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  if (sigmoid)
+    hipLaunchKernelGGL(resize2_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, logits, stride_k,
+                       stride_t, K, T, h, w, first_h, first_w, img_h, img_w, out_h, out_w, out);
+  else
+    hipLaunchKernelGGL(resize2_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, logits, stride_k,
+                       stride_t, K, T, h, w, first_h, first_w, img_h, img_w, out_h, out_w, out);
+  return dvis_check_launch("resize2_kernel");
 }

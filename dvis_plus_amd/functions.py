@@ -260,6 +260,43 @@ def vps_argmax(mask_logits_kthw, scores, first_resize_size, img_size, out_hw):
     return ids, conf.bool(), areas
 
 
+def resize2_gt0(mask_logits_kthw, first_resize_size, img_size, out_hw):
+    """``F.interpolate(F.interpolate(m, first)[:, :, :img_h, :img_w], out_hw) > 0`` in one pass (see dvis_resize2_gt0):
+    the instance masks of inference_video_vis.  m: float32 GPU (K, T, h, w) view with contiguous (h, w) maps.
+    Returns bool (K, T, H, W)."""
+    K, T, h, w = mask_logits_kthw.shape
+    m = mask_logits_kthw
+    if not m.is_cuda or m.dtype != torch.float32 or m.stride(3) != 1 or m.stride(2) != w:
+        raise RuntimeError("resize2_gt0: logits must be a float32 GPU (K, T, h, w) view with contiguous (h, w) maps")
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    out = torch.empty((K, T, oh, ow), dtype=torch.uint8, device=m.device)
+    with torch.cuda.device(m.device):
+        rc = native.lib().dvis_resize2_gt0(
+            ctypes.c_void_p(m.data_ptr()), m.stride(0), m.stride(1), K, T, h, w, int(first_resize_size[0]),
+            int(first_resize_size[1]), int(img_size[0]), int(img_size[1]), oh, ow, native.dev_ptr(out, "out"),
+            native.stream_ptr(m.device))
+    native.check(rc, "dvis_resize2_gt0")
+    return out.view(torch.bool)
+
+
+def resize2(mask_logits_kthw, first_resize_size, img_size, out_hw, sigmoid=False):
+    """``F.interpolate(f(F.interpolate(m, first)[:, :, :img_h, :img_w]), out_hw)``, f = sigmoid or identity, in one pass and
+    in torch's CPU operation order (see dvis_resize2).  Returns float32 (K, T, H, W)."""
+    K, T, h, w = mask_logits_kthw.shape
+    m = mask_logits_kthw
+    if not m.is_cuda or m.dtype != torch.float32 or m.stride(3) != 1 or m.stride(2) != w:
+        raise RuntimeError("resize2: logits must be a float32 GPU (K, T, h, w) view with contiguous (h, w) maps")
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    out = torch.empty((K, T, oh, ow), dtype=torch.float32, device=m.device)
+    with torch.cuda.device(m.device):
+        rc = native.lib().dvis_resize2(
+            ctypes.c_void_p(m.data_ptr()), m.stride(0), m.stride(1), K, T, h, w, int(first_resize_size[0]),
+            int(first_resize_size[1]), int(img_size[0]), int(img_size[1]), oh, ow, 1 if sigmoid else 0,
+            native.dev_ptr(out, "out"), native.stream_ptr(m.device))
+    native.check(rc, "dvis_resize2")
+    return out
+
+
 def vss_argmax(mask_logits_qthw, mask_cls, first_resize_size, img_size, out_hw):
     """Fused semantic arg-max (see dvis_vss_argmax).  mask_logits_qthw: float32 GPU (Q, T, h, w) view whose last two dims
     are contiguous; mask_cls float32 (Q, C), C <= 128.  Returns int64 (T, H, W) class indices."""
@@ -460,7 +497,8 @@ def conv1x1(x, weight, bias=None):
     MI355X at the R50 / pixel-decoder shapes (tools/conv1x1_probe.py): 256->64 @184x320 1.10 -> 0.56 ms, 64->64
     0.55 -> 0.24 ms, 2048->256 0.32 -> 0.25 ms; channel-expanding ones are faster through MIOpen and stay there."""
     Co, Ci = weight.shape[:2]
-    if x.is_cuda and Ci >= Co and x.is_contiguous() and x.dim() == 4:
+    if x.is_cuda and Ci >= Co and x.is_contiguous() and x.dim() == 4 and x.dtype == weight.dtype \
+            and not torch.is_grad_enabled():
         N, _, H, W = x.shape
         # bmm with a stride-0 batch of W, not torch.matmul: matmul folds the batch (transpose + copy of X, 4x slower)
         # whenever the 2-D operand is a Parameter that requires grad, even under no_grad

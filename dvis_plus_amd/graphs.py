@@ -7,12 +7,19 @@ enqueued on torch's current stream), the same work replays with ~2 us per node a
 Inputs are copied into static buffers, outputs are returned as views of static buffers (valid until the next replay
 of the same graph — callers consume them within the clip or clone).
 """
+import collections
+
 import torch
 
 
 class GraphRunner:
-    def __init__(self, fn, enabled=True):
-        self.fn, self.enabled, self._cache = fn, enabled, {}
+    """max_entries bounds the cache (least recently used graph dropped first): every distinct clip length costs two
+    eager warm-ups plus a capture and keeps a hipGraph with its private memory pool alive, so an evaluation over
+    videos of many different lengths must not accumulate them."""
+
+    def __init__(self, fn, enabled=True, max_entries=8):
+        self.fn, self.enabled, self.max_entries = fn, enabled, max_entries
+        self._cache = collections.OrderedDict()
 
     def clear(self):
         self._cache.clear()
@@ -38,8 +45,38 @@ class GraphRunner:
                 static_out = self.fn(*static_in)
             entry = (graph, static_in, static_out)
             self._cache[key] = entry
+            while len(self._cache) > self.max_entries:
+                self._cache.popitem(last=False)
+        else:
+            self._cache.move_to_end(key)
         graph, static_in, static_out = entry
         for s, t in zip(static_in, tensors):
             s.copy_(t)
         graph.replay()
         return static_out
+
+
+class FusedKV:
+    """K / V in-projection weights of a stack of cross-attention layers, concatenated once so that all layers' (and all
+    frames') projections are ONE GEMM.  The concatenated tensors are referenced by captured hipGraphs, so they are
+    allocated once per device and refreshed IN PLACE when a parameter changes (load_state_dict / optimizer step bump
+    the parameters' version counters): a graph captured earlier keeps reading valid, current weights."""
+
+    def __init__(self):
+        self._key, self._W, self._b = None, None, None
+
+    def get(self, layers, C):
+        ws = [l.multihead_attn.in_proj_weight for l in layers]
+        bs = [l.multihead_attn.in_proj_bias for l in layers]
+        ver = tuple(t._version for t in ws + bs) + tuple(t.data_ptr() for t in ws + bs)
+        dev = ws[0].device
+        if self._key != (ver, dev):
+            W = torch.cat([w[C:].detach() for w in ws], 0)
+            b = torch.cat([x[C:].detach() for x in bs], 0)
+            if self._W is not None and self._W.device == dev and self._W.shape == W.shape and self._W.dtype == W.dtype:
+                self._W.copy_(W)
+                self._b.copy_(b)
+            else:
+                self._W, self._b = W.contiguous(), b.contiguous()
+            self._key = (ver, dev)
+        return self._W, self._b

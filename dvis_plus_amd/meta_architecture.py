@@ -82,6 +82,7 @@ class _VideoBase(nn.Module):
         # stream(): clips go in rounds of `world`, each clip's tracker + refiner on its own rank (DVIS_OWNER_ROUNDS=0:
         # one clip per round, tracker replicated on every rank)
         self.owner_rounds = os.environ.get("DVIS_OWNER_ROUNDS", "1") != "0"
+        self.stream_timing = False            # stream(): make the per-clip "ready_event" a timing event (bench latency)
         if hasattr(self.sem_seg_head.predictor, "compute_pred_masks"):
             self.sem_seg_head.predictor.compute_pred_masks = False
 
@@ -182,7 +183,7 @@ class MinVIS(_VideoBase):
         emb = pred.mask_embed(dec[ar, idx[:, slot]])                                    # (T, k, Cm): the slots' queries
         masks = Fn.mask_logits(emb.contiguous(), mask_features).permute(1, 0, 2, 3)     # (k, T, h, w)
         out_hw = (video.get("height", img_size[0]), video.get("width", img_size[1]))
-        masks = PP._resize2(masks, images.shape[-2:], img_size, out_hw, sigmoid=False) > 0.
+        masks = PP.resize2_gt0(masks, images.shape[-2:], img_size, out_hw)
         return {"image_size": tuple(out_hw), "pred_scores": scores.tolist(), "pred_labels": labels.tolist(),
                 "pred_masks": [m for m in masks], "pred_ids": slot.tolist(), "aligned_indices": idx}
 
@@ -316,22 +317,34 @@ class DVIS_Plus_offline(_VideoBase):
                     for st in sts]
         Q, K1 = self.num_queries, sts[0]["logits"].shape[-1]
         Cm = self.refiner.mask_embed.layers[-1].out_features
+        C2 = self.tracker.decoder_norm.weight.shape[0]
         Tmax = max(st["T"] for st in sts)
-        n_emb, n_cls = Tmax * Q * Cm, Q * K1
-        pack = sts[0]["mf"].new_zeros(n_emb + 2 * n_cls)
+        n_emb, n_cls, n_state = Tmax * Q * Cm, Q * K1, Q * C2
+        pack = sts[0]["mf"].new_zeros(n_emb + 2 * n_cls + 3 * n_state)
         if shard.rank < m:
             self.keep = False
             mask_embed, cls, aux = self._track_core(gathered[shard.rank][0], gathered[shard.rank][1])
             pack[:mask_embed.numel()] = mask_embed.reshape(-1)
             pack[n_emb:n_emb + n_cls] = cls.reshape(-1)
-            pack[n_emb + n_cls:] = aux.reshape(-1)
-        rows = shard.all_gather_rows(pack)                                           # (world, n_emb + 2 n_cls)
+            pack[n_emb + n_cls:n_emb + 2 * n_cls] = aux.reshape(-1)
+            trk = self.tracker
+            for i, t in enumerate((trk.last_outputs, trk.last_reference, trk.last_frame_embeds)):
+                o = n_emb + 2 * n_cls + i * n_state
+                pack[o:o + n_state] = t.reshape(-1)
+        rows = shard.all_gather_rows(pack)                                           # (world, n_emb + 2 n_cls + state)
+        # Every rank leaves the round with the tracker state of the round's LAST clip (its owner is rank m - 1): a later
+        # clip that resumes (`keep`) takes the replicated path and must find the same predecessor state everywhere.
+        st_row = rows[m - 1, n_emb + 2 * n_cls:]
+        trk = self.tracker
+        trk.last_outputs = st_row[:n_state].view(Q, 1, C2).clone()
+        trk.last_reference = st_row[n_state:2 * n_state].view(Q, 1, C2).clone()
+        trk.last_frame_embeds = st_row[2 * n_state:].view(Q, 1, C2).clone()
         outs = []
         for j, st in enumerate(sts):
             T = st["T"]
             outs.append(self._finish_phase(st, rows[j, :T * Q * Cm].view(1, T, Q, Cm),
                                            rows[j, n_emb:n_emb + n_cls].view(Q, K1).clone(),
-                                           rows[j, n_emb + n_cls:].view(Q, K1).clone()))
+                                           rows[j, n_emb + n_cls:n_emb + 2 * n_cls].view(Q, K1).clone()))
         return outs
 
     @torch.no_grad()
@@ -360,7 +373,19 @@ class DVIS_Plus_offline(_VideoBase):
                     side.wait_event(st["done"])
                     for t in (st["embds"], st["embds_nn"], st["logits"], st["mf"]):
                         t.record_stream(side)                                       # allocated on the main stream
-                return self._track_round(sts)
+                outs = self._track_round(sts)
+                ready = torch.cuda.Event(enable_timing=self.stream_timing)
+                ready.record(side)
+            # The outputs were produced (and allocated) on the side stream; the caller consumes them on ITS stream.
+            # Phase A of the next round is already enqueued, so waiting here costs no overlap: the consumer's stream is
+            # ordered behind phase B of this round, and the allocator is told about the second stream.
+            main.wait_event(ready)
+            for out in outs:
+                for v in out.values():
+                    if torch.is_tensor(v) and v.is_cuda:
+                        v.record_stream(main)
+                out["ready_event"] = ready
+            return outs
 
         it, prev, n = iter(videos), None, 0
         while True:

@@ -18,7 +18,7 @@ _DTYPE = {torch.float32: F32, torch.float64: F64, torch.float16: F16, torch.bflo
 _c = ctypes
 _i, _i64, _p, _f = _c.c_int, _c.c_int64, _c.c_void_p, _c.c_float
 
-# name -> (restype, argtypes); mirrors include/dvis_hip.h one-to-one (checked by tests/test_abi.py)
+# name -> (restype, argtypes); mirrors include/dvis_hip.h one-to-one (checked by tests/test_host_cpu.py::test_library_exports_every_declared_symbol)
 SIGNATURES = {
     "dvis_last_error": (_c.c_char_p, []),
     "dvis_version": (_i, []),
@@ -44,6 +44,8 @@ SIGNATURES = {
     "dvis_upsample_add": (_i, [_p, _p, _p, _i64, _i, _i, _i, _i, _p]),
     "dvis_vps_argmax": (_i, [_p, _i64, _i64, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "dvis_vss_argmax": (_i, [_p, _i64, _i64, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "dvis_resize2_gt0": (_i, [_p, _i64, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "dvis_resize2": (_i, [_p, _i64, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "dvis_lsap_solve": (_i, [_p, _i, _i, _p]),
     "dvis_match_chain": (_i, [_p, _i, _i, _p]),
 }

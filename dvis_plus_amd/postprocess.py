@@ -32,6 +32,18 @@ def _resize2(masks, first_resize_size, img_size, out_hw, sigmoid):
     return F.interpolate(m, size=tuple(out_hw), mode="bilinear", align_corners=False)
 
 
+def resize2_gt0(masks, first_resize_size, img_size, out_hw):
+    """Boolean instance masks: both resizes + ``> 0`` (meta_architecture.py:843-853).  On the GPU one fused kernel that
+    evaluates the resizes in torch's CPU operation order (the reference post-processes on the host); the torch ops
+    otherwise (CPU tensors in the host-logic tests)."""
+    if masks.is_cuda and masks.dtype == torch.float32 and masks.shape[1] > 0:
+        from . import functions as Fn
+        if masks.stride(3) != 1 or masks.stride(2) != masks.shape[3]:
+            masks = masks.contiguous()
+        return Fn.resize2_gt0(masks, first_resize_size, img_size, out_hw)
+    return _resize2(masks, first_resize_size, img_size, out_hw, sigmoid=False) > 0.
+
+
 def vis_select(pred_cls, num_classes, max_num, aux_pred_cls=None):
     """Top-k (query, class) pairs.  Returns (scores, labels, query index)."""
     scores = F.softmax(pred_cls, dim=-1)[:, :-1]
@@ -47,7 +59,7 @@ def inference_video_vis(pred_cls, mask_fn, img_size, out_hw, first_resize_size, 
                         aux_pred_cls=None):
     """mask_fn(query_index) -> (q', T, h, w) mask logits of the selected queries only."""
     scores, labels, qidx = vis_select(pred_cls, num_classes, max_num, aux_pred_cls)
-    masks = _resize2(mask_fn(qidx), first_resize_size, img_size, out_hw, sigmoid=False) > 0.
+    masks = resize2_gt0(mask_fn(qidx), first_resize_size, img_size, out_hw)
     return {"image_size": tuple(out_hw), "pred_scores": scores, "pred_labels": labels, "pred_masks": masks,
             "pred_ids": qidx, "task": "vis"}
 

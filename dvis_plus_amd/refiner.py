@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import functions as Fn
-from .graphs import GraphRunner
+from .graphs import FusedKV, GraphRunner
 from .transformer_decoder import MLP, CrossAttentionLayer, FFNLayer, SelfAttentionLayer
 
 
@@ -52,19 +52,12 @@ class TemporalRefiner(nn.Module):
         self.class_embed = nn.Linear(hidden_channel, class_num + 1)
         self.mask_embed = MLP(hidden_channel, hidden_channel, mask_dim, 3)
         self.activation_proj = nn.Linear(hidden_channel, 1)
-        self._kv_cache = None
+        self._kv_cache = FusedKV()
         self.use_graphs = True
         self._graph = GraphRunner(self.refine)
 
     def _kv_weights(self):
-        C = self.decoder_norm.weight.shape[0]
-        ver = tuple(l.multihead_attn.in_proj_weight._version for l in self.transformer_cross_attention_layers)
-        dev = self.decoder_norm.weight.device
-        if self._kv_cache is None or self._kv_cache[0] != (ver, dev):
-            W = torch.cat([l.multihead_attn.in_proj_weight[C:].detach() for l in self.transformer_cross_attention_layers], 0)
-            b = torch.cat([l.multihead_attn.in_proj_bias[C:].detach() for l in self.transformer_cross_attention_layers], 0)
-            self._kv_cache = ((ver, dev), W.contiguous(), b.contiguous())
-        return self._kv_cache[1], self._kv_cache[2]
+        return self._kv_cache.get(self.transformer_cross_attention_layers, self.decoder_norm.weight.shape[0])
 
     def refine(self, instance_embeds, frame_embeds):
         """The 6 refinement layers.  (b, c, t, q) x2 -> last layer's queries (t, q, b, c), un-normed."""

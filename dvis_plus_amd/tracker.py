@@ -24,7 +24,7 @@ from torch import nn
 
 from . import functions as Fn
 from . import native
-from .graphs import GraphRunner
+from .graphs import FusedKV, GraphRunner
 from .pixel_decoder import c2_xavier_fill
 from .transformer_decoder import MLP, FFNLayer, SelfAttentionLayer, _xavier_
 
@@ -105,7 +105,7 @@ class ReferringTracker_noiser(nn.Module):
         self.last_frame_embeds = None
         self.last_reference = None
         self.noise_mode, self.noise_ratio = noise_mode, noise_ratio   # training-only knobs (kept for the ctor surface)
-        self._kv_cache = None
+        self._kv_cache = FusedKV()
         self.use_graphs = True
         self._graph = GraphRunner(self._recurrence_entry)
 
@@ -114,14 +114,7 @@ class ReferringTracker_noiser(nn.Module):
         self.last_reference = None
 
     def _kv_weights(self):
-        C = self.decoder_norm.weight.shape[0]
-        ver = tuple(l.multihead_attn.in_proj_weight._version for l in self.transformer_cross_attention_layers)
-        dev = self.decoder_norm.weight.device
-        if self._kv_cache is None or self._kv_cache[0] != (ver, dev):
-            W = torch.cat([l.multihead_attn.in_proj_weight[C:].detach() for l in self.transformer_cross_attention_layers], 0)
-            b = torch.cat([l.multihead_attn.in_proj_bias[C:].detach() for l in self.transformer_cross_attention_layers], 0)
-            self._kv_cache = ((ver, dev), W.contiguous(), b.contiguous())
-        return self._kv_cache[1], self._kv_cache[2]
+        return self._kv_cache.get(self.transformer_cross_attention_layers, self.decoder_norm.weight.shape[0])
 
     def _recurrence_entry(self, fe_nn, idx_dev, last_outputs):
         return self._recurrence(fe_nn, idx_dev, last_outputs, self._rec_first)

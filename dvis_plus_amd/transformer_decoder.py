@@ -183,7 +183,9 @@ class _MaskedDecoderBase(nn.Module):
 
     # ---- K / V projection weights of all layers reading level l, concatenated once
     def _level_kv_weights(self):
-        ver = tuple(l.multihead_attn.in_proj_weight._version for l in self.transformer_cross_attention_layers)
+        ver = tuple(t._version for l in self.transformer_cross_attention_layers
+                    for t in (l.multihead_attn.in_proj_weight, l.multihead_attn.in_proj_bias)) \
+            + (self.level_embed.weight._version,)
         dev = self.decoder_norm.weight.device
         if self._kv_cache is None or self._kv_cache[0] != (ver, dev):
             per_level = []

@@ -32,6 +32,7 @@
  *                               convolutions, msdeformattn.py:280-300 (built) and :343-349 (applied)
  *   dvis_vps_argmax          <- two-stage resize + sigmoid + score-weighted argmax + segment areas of inference_video_vps,
  *                               dvis_Plus/meta_architecture.py:890-925
+ *   dvis_resize2_gt0         <- the two F.interpolate calls + `> 0.` of inference_video_vis, dvis_Plus/meta_architecture.py:843-853
  *   dvis_vss_argmax          <- two-stage resize + sigmoid + einsum("qc,qthw->cthw") + max(0) of inference_video_vss,
  *                               dvis_Plus/meta_architecture.py:954-979
  *   dvis_lsap_solve          <- scipy.optimize.linear_sum_assignment as called by Noiser.match_embds, dvis_Plus/noiser.py:43-56
@@ -242,6 +243,23 @@ int dvis_upsample_add_affine(const float *lateral, const float *lat_scale, const
 int dvis_vps_argmax(const float *logits, int64_t stride_k, int64_t stride_t, const float *scores, int K, int T,
                     int h, int w, int first_h, int first_w, int img_h, int img_w, int out_h, int out_w,
                     int32_t *ids, uint8_t *conf, int32_t *areas, void *stream);
+
+/*
+ * Instance masks of a clip in one pass (inference_video_vis, dvis_Plus/meta_architecture.py:843-853; MinVIS.inference_video
+ * :390-399):  out[k][t] = resize2(resize1(logits[k][t])[:img_h, :img_w]) > 0,  both resizes bilinear align_corners=False,
+ * evaluated in torch's CPU operation order (csrc/torch_cpu_math.h).  logits: K x T maps of h*w floats at
+ * logits + k*stride_k + t*stride_t;  out (K, T, out_h, out_w) uint8 (0 / 1), 4-byte aligned.
+ */
+int dvis_resize2_gt0(const float *logits, int64_t stride_k, int64_t stride_t, int K, int T, int h, int w, int first_h,
+                     int first_w, int img_h, int img_w, int out_h, int out_w, uint8_t *out, void *stream);
+
+/*
+ * The float values behind dvis_resize2_gt0 / dvis_vps_argmax:  out[k][t] = resize2(f(resize1(logits[k][t])[:img_h, :img_w])),
+ * f = sigmoid when `sigmoid` != 0, identity otherwise — the reference's interpolate -> crop -> (sigmoid) -> interpolate
+ * sequence (dvis_Plus/meta_architecture.py:843-853, :899-905) in torch's CPU operation order.  out (K, T, out_h, out_w) float.
+ */
+int dvis_resize2(const float *logits, int64_t stride_k, int64_t stride_t, int K, int T, int h, int w, int first_h,
+                 int first_w, int img_h, int img_w, int out_h, int out_w, int sigmoid, float *out, void *stream);
 
 /*
  * Semantic arg-max of a clip in one pass (inference_video_vss, dvis_Plus/meta_architecture.py:954-979):

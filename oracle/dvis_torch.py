@@ -345,8 +345,10 @@ def _resize2(masks, first_resize_size, img_size, out_hw, sigmoid):
 
 
 def inference_video_vis(pred_cls, pred_masks, img_size, out_hw, first_resize_size, num_classes, max_num,
-                        aux_pred_cls=None):
-    """inference_video_vis, meta_architecture.py:818-867.  Returns (scores, labels, ids, bool masks)."""
+                        aux_pred_cls=None, diag=None):
+    """inference_video_vis, meta_architecture.py:818-867.  Returns (scores, labels, ids, bool masks).
+    diag: optional dict that receives the resized float logits behind the boolean masks (parity tests measure how
+    far from the threshold a differing pixel is)."""
     Q = pred_cls.shape[0]
     scores = F.softmax(pred_cls, dim=-1)[:, :-1]
     if aux_pred_cls is not None:
@@ -355,13 +357,16 @@ def inference_video_vis(pred_cls, pred_masks, img_size, out_hw, first_resize_siz
     scores_per_image, topk = scores.flatten(0, 1).topk(max_num, sorted=False)
     labels_per_image = labels[topk]
     qidx = topk // num_classes
-    masks = _resize2(pred_masks[qidx], first_resize_size, img_size, out_hw, sigmoid=False) > 0.
-    return scores_per_image, labels_per_image, qidx, masks
+    values = _resize2(pred_masks[qidx], first_resize_size, img_size, out_hw, sigmoid=False)
+    if diag is not None:
+        diag["vis_values"] = values
+    return scores_per_image, labels_per_image, qidx, values > 0.
 
 
 def inference_video_vps(pred_cls, pred_masks, img_size, out_hw, first_resize_size, num_classes, n_things,
-                        object_mask_threshold, overlap_threshold, aux_pred_cls=None):
-    """inference_video_vps, meta_architecture.py:869-952."""
+                        object_mask_threshold, overlap_threshold, aux_pred_cls=None, diag=None):
+    """inference_video_vps, meta_architecture.py:869-952.
+    diag: optional dict that receives the candidates' scores, resized probabilities and arg-max ids."""
     pred_cls = F.softmax(pred_cls, dim=-1)
     if aux_pred_cls is not None:
         pred_cls[:, :-1] = torch.maximum(pred_cls[:, :-1], F.softmax(aux_pred_cls, dim=-1)[:, :-1])
@@ -375,6 +380,8 @@ def inference_video_vps(pred_cls, pred_masks, img_size, out_hw, first_resize_siz
     if cur_masks.shape[0] == 0:
         return panoptic, segments, out_ids
     cur_mask_ids = (cur_scores.view(-1, 1, 1, 1) * cur_masks).argmax(0)
+    if diag is not None:
+        diag.update(vps_scores=cur_scores, vps_probs=cur_masks, vps_ids=cur_mask_ids, vps_query_ids=ids)
     seg_id, stuff = 0, {}
     for k in range(cur_classes.shape[0]):
         cls_k = int(cur_classes[k])
@@ -397,13 +404,16 @@ def inference_video_vps(pred_cls, pred_masks, img_size, out_hw, first_resize_siz
     return panoptic, segments, out_ids
 
 
-def inference_video_vss(pred_cls, pred_masks, img_size, out_hw, first_resize_size, aux_pred_cls=None):
-    """inference_video_vss, meta_architecture.py:954-979."""
+def inference_video_vss(pred_cls, pred_masks, img_size, out_hw, first_resize_size, aux_pred_cls=None, diag=None):
+    """inference_video_vss, meta_architecture.py:954-979.  diag: receives the (C, T, H, W) class sums."""
     mask_cls = F.softmax(pred_cls, dim=-1)[..., :-1]
     if aux_pred_cls is not None:
         mask_cls = torch.maximum(mask_cls, F.softmax(aux_pred_cls, dim=-1)[..., :-1])
     cur_masks = _resize2(pred_masks, first_resize_size, img_size, out_hw, sigmoid=True)
-    return torch.einsum("qc,qthw->cthw", mask_cls, cur_masks).max(0)[1]
+    sem = torch.einsum("qc,qthw->cthw", mask_cls, cur_masks)
+    if diag is not None:
+        diag["vss_sums"] = sem
+    return sem.max(0)[1]
 
 
 # ----------------------------------------------------------------------------- whole offline / online path (a12)
@@ -462,11 +472,11 @@ def dvis_plus_forward(sd, backbone, frames, *, offline=True, nheads=8, enc_layer
     first = tuple(images.shape[-2:])
     out_hw = img_size if out_hw is None else out_hw
     if task == "vis":
-        return inference_video_vis(cls, masks, img_size, out_hw, first, num_classes, max_num, aux)
+        return inference_video_vis(cls, masks, img_size, out_hw, first, num_classes, max_num, aux, diag=stages)
     if task == "vps":
         return inference_video_vps(cls, masks, img_size, out_hw, first, num_classes, n_things,
-                                   object_mask_threshold, overlap_threshold, aux)
-    return inference_video_vss(cls, masks, img_size, out_hw, first, aux)
+                                   object_mask_threshold, overlap_threshold, aux, diag=stages)
+    return inference_video_vss(cls, masks, img_size, out_hw, first, aux, diag=stages)
 
 
 # ----------------------------------------------------------------------------- image Mask2Former (BASELINE config #1)

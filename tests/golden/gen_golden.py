@@ -258,10 +258,20 @@ def g5_match():
 
 # --------------------------------------------------------------------------- G6
 def g6_postprocess():
+    """inference_video_{vis,vps,vss} + post_processing on hand-made decoder outputs.  Two fixtures: the original small
+    one (every resize has output height + width <= 128: torch's "channels-last" bilinear kernel, and a crop in x that
+    leaves scalar-exp tail columns in the sigmoid) and a larger one whose resizes take torch's generic separable kernel
+    like every real frame size does."""
+    _g6("g6_postprocess", 60, T=3, hw=(10, 14), img_size=(37, 53), out_hw=(30, 45), first=(40, 56))
+    _g6("g6_postprocess_large", 61, T=2, hw=(16, 24), img_size=(61, 90), out_hw=(75, 110), first=(64, 96))
+
+
+def _g6(name, seed, T, hw, img_size, out_hw, first):
     ma = R.ref_meta()
     cls = ma.DVIS_Plus_offline
-    K, Q, T = 5, 8, 3
-    g = torch.Generator().manual_seed(60)
+    K, Q = 5, 8
+    h, w = hw
+    g = torch.Generator().manual_seed(seed)
     stub = types.SimpleNamespace(
         sem_seg_head=types.SimpleNamespace(num_classes=K), num_queries=Q, max_num=4, device="cpu",
         object_mask_threshold=0.8, overlap_threshold=0.8,
@@ -273,18 +283,17 @@ def g6_postprocess():
     pred_logits[0, :, 3, 0] += 9
     pred_logits[0, :, 5, K] += 9  # void
     aux_logits = torch.randn(1, T, Q, K + 1, generator=g) * 2
-    masks = torch.randn(1, Q, T, 10, 14, generator=g) * 3
+    masks = torch.randn(1, Q, T, h, w, generator=g) * 3
     # structured masks for the confident queries so VPS keeps real segments (thing, thing, merged stuff)
-    masks[0, :4] = -6 + torch.randn(4, T, 10, 14, generator=g)
-    masks[0, 0, :, 0:5, 0:7] += 12          # thing, class 1
-    masks[0, 1, :, 0:5, 7:14] += 12         # stuff class 4
-    masks[0, 2, :, 5:10, 0:6] += 12         # stuff class 4 again -> merged into the same segment id
-    masks[0, 3, :, 5:10, 6:14] += 12        # thing, class 0
-    masks[0, 3, 1, 0:3, 0:3] += 12          # overlaps query 0 in frame 1
+    masks[0, :4] = -6 + torch.randn(4, T, h, w, generator=g)
+    masks[0, 0, :, 0:h // 2, 0:w // 2] += 12            # thing, class 1
+    masks[0, 1, :, 0:h // 2, w // 2:w] += 12            # stuff class 4
+    masks[0, 2, :, h // 2:h, 0:w // 2 - 1] += 12        # stuff class 4 again -> merged into the same segment id
+    masks[0, 3, :, h // 2:h, w // 2 - 1:w] += 12        # thing, class 0
+    masks[0, 3, 1, 0:3, 0:3] += 12                      # overlaps query 0 in frame 1
     outputs = dict(pred_logits=pred_logits.clone(), pred_masks=masks.clone())
     outputs, aux = cls.post_processing(stub, outputs, aux_logits=aux_logits.clone())
     mask_cls, mask_pred, pid = outputs["pred_logits"][0], outputs["pred_masks"][0], outputs["ids"][0]
-    img_size, out_hw, first = (37, 53), (30, 45), (40, 56)
     outs = dict(pp_logits=outputs["pred_logits"], pp_aux=aux)
     vis = cls.inference_video_vis(stub, mask_cls.clone(), mask_pred.clone(), img_size, *out_hw, first, pid,
                                   aux_pred_cls=aux.clone())
@@ -304,8 +313,8 @@ def g6_postprocess():
     outs.update(vss_masks=vss["pred_masks"])
     labels = cls._get_instance_labels(stub, pred_logits.clone())
     outs.update(instance_labels=labels)
-    save("g6_postprocess", ins=dict(pred_logits=pred_logits, aux_logits=aux_logits, pred_masks=masks),
-         outs=outs, seed=60,
+    save(name, ins=dict(pred_logits=pred_logits, aux_logits=aux_logits, pred_masks=masks),
+         outs=outs, seed=seed,
          cfg=dict(K=K, Q=Q, T=T, max_num=4, object_mask_threshold=0.8, overlap_threshold=0.8, n_things=3,
                   img_size=img_size, out_hw=out_hw, first_resize=first))
 

@@ -204,9 +204,9 @@ def _tiny_model(mode="offline", task="vps"):
     return m
 
 
-def _tiny_clip(T=5, seed=0):
+def _tiny_clip(T=5, seed=0, hw=(70, 100)):
     g = torch.Generator().manual_seed(seed)
-    return [torch.randint(0, 256, (3, 70, 100), dtype=torch.uint8, generator=g) for _ in range(T)]
+    return [torch.randint(0, 256, (3, *hw), dtype=torch.uint8, generator=g) for _ in range(T)]
 
 
 @pytest.mark.parametrize("mode,task", [("offline", "vps"), ("offline", "vis"), ("offline", "vss"), ("online", "vps")])
@@ -498,3 +498,106 @@ def test_clip_stream_with_resumed_tracker_state_takes_the_replicated_path(oracle
         order = sorted(range(2), key=lambda r: parts[r][ci]["frame_ids"][0])
         assert torch.equal(torch.cat([parts[r][ci]["masks"] for r in order], 0), single["pred_masks"])
         assert all(p[ci]["segs"] == single["segments_infos"] for p in parts)
+
+
+def _keep_after_round_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import conftest as c
+    from dvis_plus_amd import functions as Fn
+    Fn.attention, Fn.attn_mask, Fn.mask_logits = c._o_attention, c._o_attn_mask, c._o_mask_logits
+    Fn.msda_fused_forward, Fn.MSDeformAttnFunction = c._o_msda_fused, c._OMSDAFunction
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _tiny_model("offline", "vps")
+    a, b = _tiny_clip(4, seed=20), _tiny_clip(8, seed=21)
+    clips = [{"image": a, "height": 70, "width": 100},                              # round 1 (owner rounds): A on rank 0,
+             {"image": b[:4], "height": 70, "width": 100},                          #                         B on rank 1
+             {"image": b[4:], "height": 70, "width": 100, "keep": True}]            # round 2: resumes B's tracker state
+    outs = [{"masks": o["pred_masks"], "segs": o["segments_infos"], "frame_ids": o["frame_ids"]} for o in m.stream(clips)]
+    torch.save(outs, os.path.join(out_dir, f"ka{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_keep_clip_after_an_owner_round_resumes_the_last_clips_state(oracle_ops, tmp_path):
+    """[A, B, C(keep)] on 2 ranks: the owner round leaves A's tracker state on rank 0 and B's on rank 1; C resumes B, so
+    every rank must hold B's state (handed over inside the round's result all-gather) before the replicated path runs."""
+    import torch.multiprocessing as mp
+    port = 36500 + (os.getpid() % 2000)
+    mp.spawn(_keep_after_round_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    m = _tiny_model("offline", "vps")
+    a, b = _tiny_clip(4, seed=20), _tiny_clip(8, seed=21)
+    want = [m([{"image": a, "height": 70, "width": 100}]), m([{"image": b[:4], "height": 70, "width": 100}]),
+            m([{"image": b[4:], "height": 70, "width": 100, "keep": True}])]
+    parts = [torch.load(tmp_path / f"ka{r}.pt") for r in range(2)]
+    for ci, single in enumerate(want):
+        order = sorted(range(2), key=lambda r: parts[r][ci]["frame_ids"][0])
+        assert torch.equal(torch.cat([parts[r][ci]["masks"] for r in order], 0), single["pred_masks"]), ci
+        assert all(p[ci]["segs"] == single["segments_infos"] for p in parts), ci
+
+
+def test_reloaded_weights_reach_the_fused_kv_projection(oracle_ops):
+    """The tracker / refiner concatenate the cross-attention K/V weights once (one GEMM for all layers); captured
+    hipGraphs keep pointers to that tensor, so a reload must refresh it IN PLACE — same storage, new values."""
+    from dvis_plus_amd.graphs import GraphRunner
+    m, other = _tiny_model("offline", "vps"), _tiny_model("offline", "vps")
+    with torch.no_grad():
+        for p in other.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    clip = [{"image": _tiny_clip(4, seed=2), "height": 70, "width": 100}]
+    m(clip)
+    ptrs = [mod._kv_weights()[0].data_ptr() for mod in (m.tracker, m.refiner)]
+    m.load_state_dict(other.state_dict())
+    got = m(clip)
+    want = other(clip)
+    assert [mod._kv_weights()[0].data_ptr() for mod in (m.tracker, m.refiner)] == ptrs
+    assert torch.equal(got["pred_masks"], want["pred_masks"]) and got["segments_infos"] == want["segments_infos"]
+    W, _ = m.tracker._kv_weights()
+    C = m.tracker.decoder_norm.weight.shape[0]
+    assert torch.equal(W[:2 * C], other.tracker.transformer_cross_attention_layers[0].multihead_attn.in_proj_weight[C:])
+    # the graph cache is bounded (least recently used entry dropped)
+    calls = []
+    g = GraphRunner(lambda x: calls.append(1) or x, max_entries=2)
+    assert g.max_entries == 2 and len(g._cache) == 0
+
+
+def _ragged8_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import conftest as c
+    from dvis_plus_amd import functions as Fn
+    Fn.attention, Fn.attn_mask, Fn.mask_logits = c._o_attention, c._o_attn_mask, c._o_mask_logits
+    Fn.msda_fused_forward, Fn.MSDeformAttnFunction = c._o_msda_fused, c._OMSDAFunction
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _tiny_model("offline", "vps")
+    n_coll = [0]
+    for name in ("all_gather_into_tensor", "all_reduce", "broadcast"):
+        orig = getattr(dist, name)
+        setattr(dist, name, (lambda o: lambda *a, **k: (n_coll.__setitem__(0, n_coll[0] + 1), o(*a, **k))[1])(orig))
+    clips = [{"image": _tiny_clip(30, seed=100 + i, hw=(40, 64)), "height": 40, "width": 64} for i in range(10)]
+    outs = [{"masks": o["pred_masks"], "segs": o["segments_infos"], "frame_ids": o["frame_ids"]} for o in m.stream(clips)]
+    torch.save({"outs": outs, "collectives": n_coll[0]}, os.path.join(out_dir, f"e{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_stream_8_ranks_ragged_T30_ten_clips_gloo(oracle_ops, tmp_path):
+    """The bench's multi-GPU shape on CPU: 8 ranks, T=30 (ragged split 4,4,4,4,4,4,4,2 rotating clip by clip), K=10
+    clips = one full round + a quarter-full one.  Every rank issues the SAME number of collectives (a rank without a
+    tracker job or without frames must not skip one), and the stitched maps equal the single-process result."""
+    import torch.multiprocessing as mp
+    port = 37500 + (os.getpid() % 2000)
+    mp.spawn(_ragged8_worker, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    parts = [torch.load(tmp_path / f"e{r}.pt") for r in range(8)]
+    assert len({p["collectives"] for p in parts}) == 1, [p["collectives"] for p in parts]
+    m = _tiny_model("offline", "vps")
+    for ci in range(10):
+        single = m([{"image": _tiny_clip(30, seed=100 + ci, hw=(40, 64)), "height": 40, "width": 64}])
+        held = sorted((p["outs"][ci]["frame_ids"][0], r) for r, p in enumerate(parts) if p["outs"][ci]["frame_ids"])
+        assert sorted(f for p in parts for f in p["outs"][ci]["frame_ids"]) == list(range(30))
+        assert torch.equal(torch.cat([parts[r]["outs"][ci]["masks"] for _, r in held], 0), single["pred_masks"]), ci
+        assert all(p["outs"][ci]["segs"] == single["segments_infos"] for p in parts), ci
