@@ -97,7 +97,7 @@ def cpu_baseline_msda(budget_s=8.0):
                       f"{dt * 1e3:.1f} ms each"}
 
 
-def cpu_baseline(model, clip, frames=3):
+def cpu_baseline(model, clip, frames=3, thr=0.8):
     """The metric's own unit on the host cores: the oracle's restatement of the reference pipeline (windowed,
     frame-by-frame tracker, torch ops; oracle/dvis_torch.py) on a bounded sample = the first `frames` frames of the same
     synthetic clip = one window of the reference's loop (TEST.WINDOW_SIZE = 3), same weights, backbone = the same torch
@@ -115,8 +115,7 @@ def cpu_baseline(model, clip, frames=3):
         with torch.no_grad():
             O.dvis_plus_forward(sd, backbone, sample, offline=True, nheads=8, enc_layers=6, dec_layers=9,
                                 tracker_layers=6, refiner_layers=6, window_size=3, num_classes=124, n_things=58,
-                                task="vps", object_mask_threshold=model.object_mask_threshold, overlap_threshold=0.8,
-                                out_hw=(720, 1280))
+                                task="vps", object_mask_threshold=thr, overlap_threshold=0.8, out_hw=(720, 1280))
         return time.time() - t0
     warm = run()                               # thread pools, oneDNN primitives, allocator
     dt = run()
@@ -140,13 +139,11 @@ def calibrate_threshold(model, inputs, candidates):
         seen["s"] = scores[labels.ne(num_classes)].sort(descending=True)[0]
         return scores, labels, keep
     PP.vps_select = spy
-    old = model.object_mask_threshold
-    model.object_mask_threshold = 2.0          # keep nothing: cheap calibration pass
+    probe = [dict(inputs[0], object_mask_threshold=2.0)]     # keep nothing: cheap calibration pass
     try:
-        model(inputs)
+        model(probe)
     finally:
         PP.vps_select = orig_sel
-        model.object_mask_threshold = old
     s = seen["s"]
     if candidates >= s.numel():
         return 0.0                             # every non-void query
@@ -154,7 +151,7 @@ def calibrate_threshold(model, inputs, candidates):
     return float((s[k - 1] + s[k]) / 2) if k > 0 else 2.0
 
 
-def stage_breakdown(model, clip, task):
+def stage_breakdown(model, video, task):
     """One clip with a device synchronisation after every stage (ms).  Untimed extra pass, offline mode."""
     from dvis_plus_amd import postprocess as PP
     acc = {}
@@ -168,7 +165,7 @@ def stage_breakdown(model, clip, task):
         return out
     m = model
     with torch.no_grad():
-        images, img_size = timed("preprocess", lambda: m.preprocess(clip))
+        images, img_size = timed("preprocess", lambda: m.preprocess(video["image"]))
         feats = timed("backbone", lambda: m.backbone(images))
         mf, _, ms = timed("pixel_decoder", lambda: m.sem_seg_head.pixel_decoder.forward_features(feats))
         e, e_nn, lg = timed("decoder", lambda: m.decode(ms, mf))
@@ -181,7 +178,7 @@ def stage_breakdown(model, clip, task):
         cls, aux = PP.mean_logits(ref["pred_logits"], track["pred_logits"])
         mask_fn = lambda idx: m.refiner.predict_masks(ref["mask_embed"], mf.unsqueeze(0), idx)[0]
         timed("masks+postprocess", lambda: m._task_output(cls, aux, mask_fn, img_size, (720, 1280), images.shape[-2:],
-                                                          len(images)))
+                                                          len(images), video))
     return acc
 
 
@@ -255,9 +252,12 @@ def main():
     videos = [{"image": c, "height": 720, "width": 1280} for c in clips]
     streamed = bool(args.clip_stream and args.mode == "offline")
 
-    # calibration (untimed, on clip 0): the score threshold that sends args.candidates queries to the panoptic stage
+    # calibration (untimed, per clip): the score threshold that sends args.candidates queries of THAT clip to the
+    # panoptic stage — random-init class scores are near-uniform, so a threshold does not transfer between clips (one
+    # calibrated on clip 0 lets anything between 0 and 99 queries of the other clips through)
     if args.task == "vps":
-        model.object_mask_threshold = calibrate_threshold(model, videos[:1], args.candidates)
+        for v in videos:
+            v["object_mask_threshold"] = calibrate_threshold(model, [v], args.candidates)
 
     def run_pass(vids, latencies=None):
         """All of `vids` through the model.  latencies: list that receives (start event, end event) per clip."""
@@ -323,16 +323,14 @@ def main():
     # candidate count controls).  Same protocol, up to 4 clips; single GPU only.
     cand100 = None
     if args.task == "vps" and world == 1 and not dist_on and args.candidates < args.queries and not args.no_extra:
-        thr = model.object_mask_threshold
-        model.object_mask_threshold = 0.0
         n2 = min(4, args.steps)
-        run_pass(videos[:1])
+        all_q = [dict(v, object_mask_threshold=0.0) for v in videos[:n2]]
+        run_pass(all_q[:1])
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        o2 = run_pass(videos[:n2])
+        o2 = run_pass(all_q)
         torch.cuda.synchronize()
         dt2 = time.perf_counter() - t1
-        model.object_mask_threshold = thr
         cand100 = {"value": round(T * n2 / dt2, 3), "unit": "frames/s", "steps": n2,
                    "panoptic_candidates": [int(o.get("num_candidates") or 0) for o in o2]}
 
@@ -379,9 +377,9 @@ def main():
         if cand100 is not None:
             res["candidates_100"] = cand100
         if world == 1 and not dist_on and args.mode == "offline" and not args.no_extra:
-            res["stages_ms"] = stage_breakdown(model, clips[0], args.task)
+            res["stages_ms"] = stage_breakdown(model, videos[0], args.task)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(model, clips[0])
+            res["cpu_baseline"] = cpu_baseline(model, clips[0], thr=videos[0].get("object_mask_threshold", 0.8))
         print(json.dumps(res))
     if dist_on:
         torch.distributed.destroy_process_group()

@@ -12,6 +12,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import functions as Fn
+from .registry import BACKBONE_REGISTRY, ShapeSpec
 
 
 class FrozenBatchNorm2d(nn.Module):
@@ -102,6 +103,11 @@ class ResNet(nn.Module):
             self.add_module(name, nn.Sequential(*blocks))
             self.stage_names.append(name)
         self.size_divisibility = 0
+        self._out_channels = dict(zip(self.stage_names, (256, 512, 1024, 2048)))
+
+    def output_shape(self):
+        return {k: ShapeSpec(channels=self._out_channels[k], stride=2 ** int(k[3:]))
+                for k in self._out_features}
 
     def forward(self, x):
         out = {}
@@ -115,3 +121,16 @@ class ResNet(nn.Module):
 
 def build_resnet50():
     return ResNet((3, 4, 6, 3))
+
+
+@BACKBONE_REGISTRY.register()
+def build_resnet_backbone(cfg, input_shape=None):
+    """detectron2's ``build_resnet_backbone`` for the configuration every R50 yaml of the reference uses
+    (configs/dvis_Plus/*/Base-*.yaml: DEPTH 50, STRIDE_IN_1X1 False, FrozenBN, res2..res5).  Other ResNet settings are
+    detectron2's to build."""
+    r = cfg.MODEL.get("RESNETS", {}) if hasattr(cfg.MODEL, "get") else getattr(cfg.MODEL, "RESNETS", {})
+    get = (lambda k, d: r.get(k, d)) if hasattr(r, "get") else (lambda k, d: getattr(r, k, d))
+    if int(get("DEPTH", 50)) != 50 or bool(get("STRIDE_IN_1X1", False)) or get("NORM", "FrozenBN") != "FrozenBN":
+        raise NotImplementedError("dvis_plus_amd serves ResNet-50 with FrozenBN and STRIDE_IN_1X1 False "
+                                  "(the reference's R50 configs); use detectron2's builder for other ResNets")
+    return ResNet((3, 4, 6, 3), tuple(get("OUT_FEATURES", ["res2", "res3", "res4", "res5"])))

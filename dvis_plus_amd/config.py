@@ -93,47 +93,13 @@ def get_default_cfg():
     })
 
 
-def build_model(cfg, n_things=0):
-    """cfg -> DVIS_Plus_{online,offline} with an R50 backbone, resolved through the registries by the yaml names
-    (MODEL.META_ARCHITECTURE / SEM_SEG_HEAD.PIXEL_DECODER_NAME / MASK_FORMER.TRANSFORMER_DECODER_NAME), like
-    detectron2's build_model does for the reference."""
-    from . import meta_architecture as MA
-    from .backbone import build_resnet50
-    from .pixel_decoder import r50_input_shape
-    from .refiner import TemporalRefiner
-    from .registry import META_ARCH_REGISTRY, SEM_SEG_HEADS_REGISTRY, TRANSFORMER_DECODER_REGISTRY
-    from .tracker import ReferringTracker_noiser
-    mf, hd = cfg.MODEL.MASK_FORMER, cfg.MODEL.SEM_SEG_HEAD
-    if cfg.MODEL.BACKBONE.get("NAME", "build_resnet_backbone") == "D2VitAdapterDinoV2":   # vit_adapter/*.yaml
-        from .vit_adapter import D2VitAdapterDinoV2
-        backbone = D2VitAdapterDinoV2(cfg.MODEL.VIT_ADAPTER.NAME)
-        in_shape = backbone.output_shape()
-    else:
-        backbone, in_shape = build_resnet50(), r50_input_shape()
-    pd_cls = SEM_SEG_HEADS_REGISTRY.get(hd.PIXEL_DECODER_NAME)
-    pixel_decoder = pd_cls(**pd_cls.from_config(cfg, in_shape))
-    dec_cls = TRANSFORMER_DECODER_REGISTRY.get(mf.TRANSFORMER_DECODER_NAME)
-    predictor = dec_cls(**dec_cls.from_config(cfg, hd.CONVS_DIM, True))
-    head = SEM_SEG_HEADS_REGISTRY.get(hd.NAME)(num_classes=hd.NUM_CLASSES, pixel_decoder=pixel_decoder,
-                                               transformer_predictor=predictor)
-    arch = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)
-    if arch is MA.MinVIS:                                                     # no tracker / refiner
-        return arch(backbone=backbone, sem_seg_head=head, num_queries=mf.NUM_OBJECT_QUERIES,
-                    size_divisibility=mf.SIZE_DIVISIBILITY, pixel_mean=cfg.MODEL.PIXEL_MEAN,
-                    pixel_std=cfg.MODEL.PIXEL_STD, task="vis").eval()
-    hidden = mf.HIDDEN_DIM * (2 if mf.get("REID_BRANCH", True) else 1)       # meta_architecture.py:550-551
-    tracker = ReferringTracker_noiser(hidden_channel=hidden, feedforward_channel=mf.DIM_FEEDFORWARD,
-                                      num_head=mf.NHEADS, decoder_layer_num=cfg.MODEL.TRACKER.DECODER_LAYERS,
-                                      noise_mode=cfg.MODEL.TRACKER.NOISE_MODE, mask_dim=hd.MASK_DIM,
-                                      class_num=hd.NUM_CLASSES)
-    kw = dict(backbone=backbone, sem_seg_head=head, num_queries=mf.NUM_OBJECT_QUERIES,
-              object_mask_threshold=mf.TEST.OBJECT_MASK_THRESHOLD, overlap_threshold=mf.TEST.OVERLAP_THRESHOLD,
-              n_things=n_things, size_divisibility=mf.SIZE_DIVISIBILITY, pixel_mean=cfg.MODEL.PIXEL_MEAN,
-              pixel_std=cfg.MODEL.PIXEL_STD, tracker=tracker, task=mf.TEST.TASK, max_num=mf.TEST.MAX_NUM,
-              window_size=mf.TEST.WINDOW_SIZE)
-    arch = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)
-    if arch is MA.DVIS_Plus_offline:
-        kw["refiner"] = TemporalRefiner(hidden_channel=hidden, feedforward_channel=mf.DIM_FEEDFORWARD,
-                                        num_head=mf.NHEADS, decoder_layer_num=cfg.MODEL.REFINER.DECODER_LAYERS,
-                                        mask_dim=hd.MASK_DIM, class_num=hd.NUM_CLASSES, windows=mf.TEST.WINDOW_SIZE)
-    return arch(**kw).eval()
+def build_model(cfg, n_things=None):
+    """cfg -> model, resolved through the registries by the yaml names (MODEL.META_ARCHITECTURE / BACKBONE.NAME /
+    SEM_SEG_HEAD.NAME / SEM_SEG_HEAD.PIXEL_DECODER_NAME / MASK_FORMER.TRANSFORMER_DECODER_NAME) exactly like
+    detectron2's ``build_model`` does for the reference: ``META_ARCH_REGISTRY.get(name)(cfg)``.
+    n_things: thing classes 0..n-1 when no dataset metadata is available (standalone runs without detectron2)."""
+    from . import d2
+    d2_model = d2.build_model(cfg)
+    if n_things is not None and hasattr(d2_model, "thing_ids") and d2_model.metadata is None:
+        d2_model.thing_ids = frozenset(range(int(n_things)))
+    return d2_model.eval()

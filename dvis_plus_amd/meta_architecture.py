@@ -22,20 +22,57 @@ import os
 import torch
 from torch import nn
 
+from . import d2
 from . import postprocess as PP
 from .clip_shard import ClipShard
+from .d2 import configurable
 from .registry import META_ARCH_REGISTRY, SEM_SEG_HEADS_REGISTRY
+
+
+def _get(node, key, default):
+    """cfg key that only some of the reference's config revisions define."""
+    if hasattr(node, "get"):
+        return node.get(key, default)
+    return getattr(node, key, default)
 
 
 @SEM_SEG_HEADS_REGISTRY.register()
 class MaskFormerHead(nn.Module):
+    """mask2former/modeling/meta_arch/mask_former_head.py:19-152: ``MaskFormerHead(cfg, input_shape)`` or explicit
+    keyword arguments."""
+
+    @configurable
     def __init__(self, input_shape=None, *, num_classes, pixel_decoder, loss_weight=1.0, ignore_value=-1,
-                 transformer_predictor, transformer_in_feature="multi_scale_pixel_decoder"):
+                 transformer_predictor, transformer_in_feature="multi_scale_pixel_decoder",
+                 return_transformer_feature=False):
         super().__init__()
-        assert transformer_in_feature == "multi_scale_pixel_decoder"
+        assert transformer_in_feature == "multi_scale_pixel_decoder", \
+            "DVIS++ / Mask2Former configs feed the decoder from the multi-scale pixel decoder"
+        if input_shape is not None:
+            self.in_features = [k for k, _ in sorted(input_shape.items(), key=lambda x: x[1].stride)]
         self.pixel_decoder, self.predictor = pixel_decoder, transformer_predictor
         self.num_classes, self.ignore_value, self.loss_weight = num_classes, ignore_value, loss_weight
         self.transformer_in_feature = transformer_in_feature
+        self.return_transformer_feature = return_transformer_feature
+        self.common_stride = 4
+
+    @classmethod
+    def from_config(cls, cfg, input_shape):
+        """mask_former_head.py:88-116 (same keys; TRANSFORMER_IN_FEATURE selects the decoder's input width)."""
+        hd, mf = cfg.MODEL.SEM_SEG_HEAD, cfg.MODEL.MASK_FORMER
+        feat = mf.TRANSFORMER_IN_FEATURE
+        in_channels = hd.MASK_DIM if feat == "pixel_embedding" else hd.CONVS_DIM \
+            if feat in ("transformer_encoder", "multi_scale_pixel_decoder") else input_shape[feat].channels
+        return {
+            "input_shape": {k: v for k, v in input_shape.items() if k in hd.IN_FEATURES},
+            "ignore_value": _get(hd, "IGNORE_VALUE", 255),
+            "return_transformer_feature": _get(hd, "RETURN_TRANSFORMER_FEATURE", False),
+            "num_classes": hd.NUM_CLASSES,
+            "pixel_decoder": d2.build_pixel_decoder(cfg, input_shape),
+            "loss_weight": _get(hd, "LOSS_WEIGHT", 1.0),
+            "transformer_in_feature": feat,
+            "transformer_predictor": d2.build_transformer_decoder(cfg, in_channels, mask_classification=True),
+        }
 
     def forward(self, features, mask=None):
         mask_features, _, multi_scale_features = self.pixel_decoder.forward_features(features)
@@ -58,15 +95,27 @@ def segmenter_frames_per_call(n, H, W, requested=0):
 
 
 class _VideoBase(nn.Module):
+    """Constructor surface of the reference's meta-architectures (dvis_Plus/meta_architecture.py:29-90, 409-500,
+    1073-1160): ``Cls(cfg)`` through ``from_config`` like detectron2's ``build_model`` does, or explicit keyword
+    arguments.  Training-only arguments (criterion, num_frames, max_iter_num, use_cl, ...) are accepted and ignored;
+    ``metadata`` supplies the thing classes (``thing_dataset_id_to_contiguous_id``), ``n_things`` is the short form
+    for datasets whose thing classes are 0..n-1 (VIPSeg)."""
+
+    @configurable
     def __init__(self, *, backbone, sem_seg_head, num_queries, object_mask_threshold=0.8, overlap_threshold=0.8,
                  n_things=0, size_divisibility=32, pixel_mean=(123.675, 116.280, 103.530),
                  pixel_std=(58.395, 57.120, 57.375), tracker=None, refiner=None, task="vis", max_num=20,
-                 window_size=3, segmenter_chunk=0):
+                 window_size=3, segmenter_chunk=0, metadata=None, criterion=None,
+                 sem_seg_postprocess_before_inference=True, num_frames=1, window_inference=True, max_iter_num=0,
+                 use_cl=False, **ignored_training_args):
         super().__init__()
         self.backbone, self.sem_seg_head, self.tracker, self.refiner = backbone, sem_seg_head, tracker, refiner
         self.num_queries = num_queries
         self.object_mask_threshold, self.overlap_threshold = object_mask_threshold, overlap_threshold
-        self.n_things = n_things
+        self.metadata = metadata
+        ids = d2.thing_ids_from_metadata(metadata)
+        self.thing_ids = frozenset(range(int(n_things))) if ids is None else ids
+        self.num_frames, self.window_inference = num_frames, window_inference
         self.size_divisibility = size_divisibility
         self.register_buffer("pixel_mean", torch.tensor(pixel_mean, dtype=torch.float32).view(-1, 1, 1), False)
         self.register_buffer("pixel_std", torch.tensor(pixel_std, dtype=torch.float32).view(-1, 1, 1), False)
@@ -89,6 +138,42 @@ class _VideoBase(nn.Module):
     @property
     def device(self):
         return self.pixel_mean.device
+
+    @property
+    def n_things(self):
+        return len(self.thing_ids)
+
+    @classmethod
+    def _common_from_config(cls, cfg):
+        """Keys every video meta-architecture of the reference reads (meta_architecture.py:91-181, 502-588, 1161-1262),
+        minus the training criterion."""
+        mf = cfg.MODEL.MASK_FORMER
+        backbone = d2.build_backbone(cfg)
+        sem_seg_head = d2.build_sem_seg_head(cfg, backbone.output_shape())
+        test = mf.TEST
+        return {
+            "backbone": backbone, "sem_seg_head": sem_seg_head, "criterion": None,
+            "num_queries": mf.NUM_OBJECT_QUERIES,
+            "object_mask_threshold": test.OBJECT_MASK_THRESHOLD, "overlap_threshold": test.OVERLAP_THRESHOLD,
+            "metadata": d2.dataset_metadata(cfg),
+            "size_divisibility": mf.SIZE_DIVISIBILITY, "sem_seg_postprocess_before_inference": True,
+            "pixel_mean": cfg.MODEL.PIXEL_MEAN, "pixel_std": cfg.MODEL.PIXEL_STD,
+            "num_frames": cfg.INPUT.SAMPLING_FRAME_NUM, "window_inference": _get(test, "WINDOW_INFERENCE", False),
+            "task": _get(test, "TASK", "vis"), "max_num": _get(test, "MAX_NUM", 20),
+            "window_size": _get(test, "WINDOW_SIZE", 3),
+        }
+
+    @staticmethod
+    def _tracker_from_config(cfg):
+        from .tracker import ReferringTracker_noiser
+        mf = cfg.MODEL.MASK_FORMER
+        hidden = mf.HIDDEN_DIM * (2 if _get(mf, "REID_BRANCH", True) else 1)               # meta_architecture.py:550-553
+        trk = cfg.MODEL.TRACKER
+        return ReferringTracker_noiser(hidden_channel=hidden, feedforward_channel=mf.DIM_FEEDFORWARD,
+                                       num_head=mf.NHEADS, decoder_layer_num=trk.DECODER_LAYERS,
+                                       noise_mode=_get(trk, "NOISE_MODE", "none"),
+                                       noise_ratio=_get(trk, "NOISE_RATIO", 0.5), mask_dim=mf.HIDDEN_DIM,
+                                       class_num=cfg.MODEL.SEM_SEG_HEAD.NUM_CLASSES), hidden
 
     @property
     def clip_shard(self):
@@ -137,13 +222,16 @@ class _VideoBase(nn.Module):
         ms, mf = self.encode(images)
         return (*self.decode(ms, mf), mf)
 
-    def _task_output(self, cls, aux, mask_fn, img_size, out_hw, padded_size, T_local):
+    def _task_output(self, cls, aux, mask_fn, img_size, out_hw, padded_size, T_local, video=None):
+        """video: the input dict; an optional "object_mask_threshold" entry overrides the model's for this clip (used by
+        bench.py: random-init class scores are near-uniform, the threshold is calibrated per synthetic clip)."""
         K = self.sem_seg_head.num_classes
+        thr = self.object_mask_threshold if video is None else video.get("object_mask_threshold", self.object_mask_threshold)
         if self.task == "vis":
             return PP.inference_video_vis(cls, mask_fn, img_size, out_hw, padded_size, K, self.max_num, aux)
         if self.task == "vps":
-            return PP.inference_video_vps(cls, mask_fn, img_size, out_hw, padded_size, K, self.n_things,
-                                          self.object_mask_threshold, self.overlap_threshold, aux,
+            return PP.inference_video_vps(cls, mask_fn, img_size, out_hw, padded_size, K, self.thing_ids,
+                                          thr, self.overlap_threshold, aux,
                                           num_frames=T_local, reduce_fn=self.clip_shard.all_reduce_sum)
         return PP.inference_video_vss(cls, mask_fn, img_size, out_hw, padded_size, aux)
 
@@ -158,6 +246,13 @@ class MinVIS(_VideoBase):
     the alignment recurrence runs in one host call (dvis_match_chain — permuting the previous frame only permutes the
     columns of the cost matrix); masks are contracted for the 10 selected query slots only."""
     TOPK = 10      # hard-coded in the reference (:371)
+
+    @classmethod
+    def from_config(cls, cfg):
+        """meta_architecture.py:91-181."""
+        ret = cls._common_from_config(cfg)
+        ret["task"] = "vis"
+        return ret
 
     @torch.no_grad()
     def forward(self, batched_inputs):
@@ -192,6 +287,15 @@ class MinVIS(_VideoBase):
 class DVIS_Plus_online(_VideoBase):
     """Segmenter + referring tracker; masks come from the tracker (projected mask features)."""
 
+    @classmethod
+    def from_config(cls, cfg):
+        """meta_architecture.py:502-588."""
+        ret = cls._common_from_config(cfg)
+        ret["tracker"], _ = cls._tracker_from_config(cfg)
+        ret["max_iter_num"] = _get(_get(cfg, "SOLVER", {}), "MAX_ITER", 0)
+        ret["use_cl"] = _get(cfg.MODEL.TRACKER, "USE_CL", False)
+        return ret
+
     @torch.no_grad()
     def forward(self, batched_inputs):
         assert len(batched_inputs) == 1 and not self.training
@@ -212,12 +316,27 @@ class DVIS_Plus_online(_VideoBase):
             e = emb if idx is None else emb[:, idx]
             return Fn.mask_logits(e.contiguous(), proj).permute(1, 0, 2, 3)
         out_hw = (video.get("height", img_size[0]), video.get("width", img_size[1]))
-        return self._task_output(cls, None, mask_fn, img_size, out_hw, images.shape[-2:], len(images))
+        return self._task_output(cls, None, mask_fn, img_size, out_hw, images.shape[-2:], len(images), video)
 
 
 @META_ARCH_REGISTRY.register()
 class DVIS_Plus_offline(_VideoBase):
     """Segmenter + referring tracker + temporal refiner (the north-star path)."""
+
+    @classmethod
+    def from_config(cls, cfg):
+        """meta_architecture.py:1161-1262."""
+        from .refiner import TemporalRefiner
+        ret = cls._common_from_config(cfg)
+        ret["tracker"], hidden = cls._tracker_from_config(cfg)
+        mf = cfg.MODEL.MASK_FORMER
+        ret["refiner"] = TemporalRefiner(hidden_channel=hidden, feedforward_channel=mf.DIM_FEEDFORWARD,
+                                         num_head=mf.NHEADS, decoder_layer_num=cfg.MODEL.REFINER.DECODER_LAYERS,
+                                         mask_dim=mf.HIDDEN_DIM, class_num=cfg.MODEL.SEM_SEG_HEAD.NUM_CLASSES,
+                                         windows=_get(mf.TEST, "WINDOW_SIZE", 3))
+        ret["max_iter_num"] = _get(_get(cfg, "SOLVER", {}), "MAX_ITER", 0)
+        ret["use_cl"] = _get(cfg.MODEL.REFINER, "USE_CL", False)
+        return ret
 
     # ---- the clip as two phases: everything up to the per-frame queries is asynchronous and rank-local (phase A);
     # everything after needs the other ranks' queries, host-side assignment and the VPS statistics (phase B).
@@ -280,7 +399,7 @@ class DVIS_Plus_offline(_VideoBase):
             return self.refiner.predict_masks(emb_local, mf, idx)[0]                # (q', t_local, h, w)
         img_size = st["img_size"]
         out_hw = (video.get("height", img_size[0]), video.get("width", img_size[1]))
-        out = self._task_output(cls, aux, mask_fn, img_size, out_hw, st["padded"], hi - lo)
+        out = self._task_output(cls, aux, mask_fn, img_size, out_hw, st["padded"], hi - lo, video)
         out["frame_ids"] = list(range(lo, hi))
         out["frame_range"] = (lo, hi)
         return out
@@ -500,7 +619,7 @@ class DVIS_Plus_offline(_VideoBase):
         def mask_fn(idx):
             return self.refiner.predict_masks(emb_local, mf, idx)[0]                # (q', t_local, h, w)
         out_hw = (video.get("height", img_size[0]), video.get("width", img_size[1]))
-        out = self._task_output(cls, aux, mask_fn, img_size, out_hw, padded, len(local_ids))
+        out = self._task_output(cls, aux, mask_fn, img_size, out_hw, padded, len(local_ids), video)
         out["frame_ids"] = local_ids                                                # which frames of the clip the masks are
         out["frame_range"] = (local_ids[0], local_ids[-1] + 1) if local_ids and contiguous else None
         return out
@@ -585,14 +704,17 @@ class MaskFormer(nn.Module):
     ``forward([{"image": (3,H,W), "height", "width"}, ...])`` -> list of dicts with "sem_seg" (K,H,W),
     "panoptic_seg" (map int32, segments_info) and/or "instances" ({"pred_masks","scores","pred_classes"})."""
 
+    @configurable
     def __init__(self, *, backbone, sem_seg_head, num_queries, object_mask_threshold=0.8, overlap_threshold=0.8,
                  thing_ids=(), size_divisibility=32, sem_seg_postprocess_before_inference=True,
                  pixel_mean=(123.675, 116.280, 103.530), pixel_std=(58.395, 57.120, 57.375), semantic_on=True,
-                 panoptic_on=False, instance_on=False, test_topk_per_image=100):
+                 panoptic_on=False, instance_on=False, test_topk_per_image=100, metadata=None, criterion=None):
         super().__init__()
         self.backbone, self.sem_seg_head, self.num_queries = backbone, sem_seg_head, num_queries
         self.object_mask_threshold, self.overlap_threshold = object_mask_threshold, overlap_threshold
-        self.thing_ids = set(int(t) for t in thing_ids)
+        self.metadata = metadata
+        ids = d2.thing_ids_from_metadata(metadata)
+        self.thing_ids = set(int(t) for t in thing_ids) if ids is None else set(ids)
         self.size_divisibility = size_divisibility
         self.sem_seg_postprocess_before_inference = sem_seg_postprocess_before_inference
         self.register_buffer("pixel_mean", torch.tensor(pixel_mean, dtype=torch.float32).view(-1, 1, 1), False)
@@ -603,6 +725,26 @@ class MaskFormer(nn.Module):
     @property
     def device(self):
         return self.pixel_mean.device
+
+    @classmethod
+    def from_config(cls, cfg):
+        """mask2former/maskformer_model.py:100-162, minus the training criterion."""
+        mf = cfg.MODEL.MASK_FORMER
+        backbone = d2.build_backbone(cfg)
+        test = mf.TEST
+        return {
+            "backbone": backbone, "sem_seg_head": d2.build_sem_seg_head(cfg, backbone.output_shape()),
+            "criterion": None, "num_queries": mf.NUM_OBJECT_QUERIES,
+            "object_mask_threshold": test.OBJECT_MASK_THRESHOLD, "overlap_threshold": test.OVERLAP_THRESHOLD,
+            "metadata": d2.dataset_metadata(cfg), "size_divisibility": mf.SIZE_DIVISIBILITY,
+            "sem_seg_postprocess_before_inference": bool(_get(test, "SEM_SEG_POSTPROCESSING_BEFORE_INFERENCE", False)
+                                                         or _get(test, "PANOPTIC_ON", False)
+                                                         or _get(test, "INSTANCE_ON", False)),
+            "pixel_mean": cfg.MODEL.PIXEL_MEAN, "pixel_std": cfg.MODEL.PIXEL_STD,
+            "semantic_on": _get(test, "SEMANTIC_ON", True), "instance_on": _get(test, "INSTANCE_ON", False),
+            "panoptic_on": _get(test, "PANOPTIC_ON", False),
+            "test_topk_per_image": _get(_get(cfg, "TEST", {}), "DETECTIONS_PER_IMAGE", 100),
+        }
 
     @staticmethod
     def sem_seg_postprocess(result, img_size, output_height, output_width):

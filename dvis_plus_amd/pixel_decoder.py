@@ -28,6 +28,7 @@ from torch import nn
 from torch.nn.init import constant_, normal_, xavier_uniform_
 
 from . import functions as Fn
+from .d2 import configurable
 from .registry import SEM_SEG_HEADS_REGISTRY, ShapeSpec
 
 # DVIS_MSDA_POS=1: add the position embedding's projection inside the MSDA kernel instead of forming src + pos.  Measured
@@ -354,6 +355,7 @@ def c2_xavier_fill(module):
 
 @SEM_SEG_HEADS_REGISTRY.register()
 class MSDeformAttnPixelDecoder(nn.Module):
+    @configurable
     def __init__(self, input_shape, *, transformer_dropout, transformer_nheads, transformer_dim_feedforward,
                  transformer_enc_layers, conv_dim, mask_dim, norm=None, transformer_in_features, common_stride):
         super().__init__()

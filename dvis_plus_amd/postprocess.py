@@ -75,7 +75,10 @@ def vps_select(pred_cls, num_classes, object_mask_threshold, aux_pred_cls=None):
 
 def inference_video_vps(pred_cls, mask_fn, img_size, out_hw, first_resize_size, num_classes, n_things,
                         object_mask_threshold, overlap_threshold, aux_pred_cls=None, num_frames=None, reduce_fn=None):
-    """reduce_fn: sums a tensor over the ranks that hold the other frames of the clip (segment areas are per clip)."""
+    """n_things: the thing classes — an int n (classes 0..n-1, VIPSeg's layout) or a collection of contiguous class ids
+    (``metadata.thing_dataset_id_to_contiguous_id.values()``, meta_architecture.py:940).
+    reduce_fn: sums a tensor over the ranks that hold the other frames of the clip (segment areas are per clip)."""
+    thing_ids = frozenset(range(n_things)) if isinstance(n_things, int) else frozenset(int(t) for t in n_things)
     scores, labels, keep = vps_select(pred_cls, num_classes, object_mask_threshold, aux_pred_cls)
     ids = torch.nonzero(keep).flatten()                       # sync #1: how many queries survive
     dev = pred_cls.device
@@ -114,7 +117,7 @@ def inference_video_vps(pred_cls, mask_fn, img_size, out_hw, first_resize_size, 
     for k in range(K):
         area, orig, it = int(stats[0, k]), int(stats[1, k]), int(stats[2, k])
         cls_k = int(stats[3, k])
-        isthing = cls_k < n_things
+        isthing = cls_k in thing_ids
         if area > 0 and orig > 0 and it > 0:
             if area / orig < overlap_threshold:
                 continue

@@ -24,6 +24,7 @@ from torch import nn
 
 from . import functions as Fn
 from .pixel_decoder import ConvNorm, PositionEmbeddingSine, c2_xavier_fill
+from .d2 import configurable
 from .registry import TRANSFORMER_DECODER_REGISTRY
 
 
@@ -126,6 +127,7 @@ class _MaskedDecoderBase(nn.Module):
 
     _version = 2
 
+    @configurable
     def __init__(self, in_channels, mask_classification=True, *, num_classes, hidden_dim, num_queries, nheads,
                  dim_feedforward, dec_layers, pre_norm, mask_dim, enforce_input_project):
         super().__init__()
@@ -266,6 +268,7 @@ class MultiScaleMaskedTransformerDecoder(_MaskedDecoderBase):
 
 @TRANSFORMER_DECODER_REGISTRY.register()
 class VideoMultiScaleMaskedTransformerDecoder_dvisPlus(_MaskedDecoderBase):
+    @configurable
     def __init__(self, in_channels, mask_classification=True, *, num_classes, hidden_dim, num_queries, nheads,
                  dim_feedforward, dec_layers, pre_norm, mask_dim, enforce_input_project, num_frames,
                  num_reid_head_layers, reid_hidden_dim):
@@ -316,6 +319,7 @@ class VideoMultiScaleMaskedTransformerDecoder_dvisPlus(_MaskedDecoderBase):
 class VideoMultiScaleMaskedTransformerDecoder_dvis(_MaskedDecoderBase):
     """DVIS (v1) per-frame decoder: single-branch embeddings, no re-id head (dvis_Plus/…decoder.py:11-145)."""
 
+    @configurable
     def __init__(self, in_channels, mask_classification=True, *, num_classes, hidden_dim, num_queries, nheads,
                  dim_feedforward, dec_layers, pre_norm, mask_dim, enforce_input_project, num_frames):
         super().__init__(in_channels, mask_classification, num_classes=num_classes, hidden_dim=hidden_dim,

@@ -23,7 +23,7 @@ from torch import nn
 
 from . import functions as Fn
 from .pixel_decoder import MSDeformAttn
-from .registry import ShapeSpec
+from .registry import BACKBONE_REGISTRY, ShapeSpec
 
 LayerNorm = partial(nn.LayerNorm, eps=1e-6)
 
@@ -392,10 +392,15 @@ def get_adapter_args(name="vitl"):
                                      "vitb": [[0, 2], [3, 5], [6, 8], [9, 11]]}[name])
 
 
+@BACKBONE_REGISTRY.register()
 class D2VitAdapterDinoV2(DinoV2ViTAdapter):
-    """detectron2 backbone surface: forward -> {res2..res5}, output_shape(), size_divisibility (adapter.py:589-651)."""
+    """detectron2 backbone surface: forward -> {res2..res5}, output_shape(), size_divisibility (adapter.py:589-651).
+    Built like the reference's, ``D2VitAdapterDinoV2(cfg, input_shape)`` (size from cfg.MODEL.VIT_ADAPTER.NAME; the
+    weight-file / freezing / checkpointing keys are training-time settings), or directly by size name."""
 
-    def __init__(self, name="vitl", **overrides):
+    def __init__(self, name="vitl", input_shape=None, **overrides):
+        if not isinstance(name, str):                       # a config node
+            name = name.MODEL.VIT_ADAPTER.NAME
         args = get_adapter_args(name)
         args.update(overrides)
         super().__init__(**args)

@@ -38,9 +38,13 @@ def test_online_T5_720p_vs_oracle(task):
     video = {"image": clip, "height": 720, "width": 1280}
     if task == "vps":
         m.object_mask_threshold = bench.calibrate_threshold(m, [video], 20)
+        # random weights give every candidate a diffuse mask: with the reference's 0.8 overlap rule no segment would
+        # survive and the comparison would be between two empty maps
+        m.overlap_threshold = 0.0
     out = m([video])
     ref, stages = PPar.run_oracle(m, sd, [f for f in clip.cpu()], offline=False, task=task, max_num=10,
-                                  object_mask_threshold=m.object_mask_threshold, out_hw=(720, 1280))
+                                  object_mask_threshold=m.object_mask_threshold, overlap_threshold=m.overlap_threshold,
+                                  out_hw=(720, 1280))
     what = f"config #2 online {task} T=5 720p"
     if task == "vps":
         assert out["pred_masks"].shape == (5, 720, 1280) and out["num_candidates"] == 20 and len(ref[1]) > 0
@@ -63,9 +67,21 @@ def test_bench_workload_T30_vps_stream_vs_oracle():
         outs.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in out.items()})
     assert outs[0]["num_candidates"] == 20 and outs[0]["pred_masks"].shape == (30, 720, 1280)
     # clip 0 (the calibrated one) against the oracle; clip 1 keeps stream()'s overlap honest: it must equal forward()
+    from oracle import dvis_torch as O
     ref, stages = PPar.run_oracle(m, sd, [f for f in clips[0].cpu()], offline=True, task="vps",
                                   object_mask_threshold=m.object_mask_threshold, out_hw=(720, 1280))
-    assert len(ref[1]) > 0
     PPar.compare_vps(outs[0], ref, stages, "config #3 offline vps T=30 720p through stream() (bench workload)")
     again = m([videos[1]])
     assert torch.equal(again["pred_masks"], outs[1]["pred_masks"]) and again["segments_infos"] == outs[1]["segments_infos"]
+    # Random weights give diffuse masks, so the reference's 0.8 overlap rule keeps few (or no) segments.  Second
+    # comparison on the same clip with the overlap rule off: every candidate that wins a pixel becomes a segment, i.e.
+    # the whole 30 x 720 x 1280 arg-max map is compared.  (The oracle's post-processing is re-run on its stored class
+    # logits and masks; the product re-runs the clip.)
+    m.overlap_threshold = 0.0
+    out0 = m([videos[0]])
+    diag = {}
+    with torch.no_grad():
+        ref0 = O.inference_video_vps(stages["cls"], stages["masks"], (720, 1280), (720, 1280), (736, 1280), 124, 58,
+                                     m.object_mask_threshold, 0.0, stages["aux"], diag=diag)
+    assert len(ref0[1]) >= 10
+    PPar.compare_vps(out0, ref0, diag, "config #3 offline vps T=30 720p, overlap rule off (full arg-max map)")
