@@ -29,20 +29,6 @@
 #include "dvis_common.h"
 #include "msda_tap.h"
 
-int dvis_msda_l0lds_launch(const float *value, const int64_t *shapes, const int64_t *level_start, const float *ref, int nref,
-                           const float *offsets, int64_t off_stride, const float *logits, int64_t logit_stride, int N, int S,
-                           int M, int D, int L, int Lq, int P, float *out, const int64_t *shapes_host, hipStream_t st,
-                           bool *handled);
-
-int dvis_msda_pipe_launch(const float *value, const int64_t *shapes, const int64_t *level_start, const float *ref, int nref,
-                          const float *offsets, int64_t off_stride, const float *logits, int64_t logit_stride, int N, int S,
-                          int M, int D, int L, int Lq, int P, float *out, const int64_t *shapes_host, hipStream_t st,
-                          bool *handled);
-int dvis_msda_box_launch(const float *value, const int64_t *shapes, const int64_t *level_start, const float *ref, int nref,
-                         const float *offsets, int64_t off_stride, const float *logits, int64_t logit_stride, int N, int S,
-                         int M, int D, int L, int Lq, int P, float *out, const int64_t *shapes_host, hipStream_t st,
-                         bool *handled);
-
 namespace {
 
 using dvis_msda::kOOB;
@@ -415,18 +401,7 @@ DVIS_EXPORT int dvis_msda_fused_forward_pos(const float *value, const int64_t *s
     dvis_set_error("msda_fused_forward: unsupported (D=%d, L=%d, P=%d)", D, L, P);
     return DVIS_E_UNSUPPORTED;
   }
-  // encoder self-attention, persistent software-pipelined LDS kernel (msda_forward_pipe.hip; env-gated)
-  int rc = dvis_msda_pipe_launch(value, shapes, level_start, ref, Nref, offsets, off_stride, logits, logit_stride, N, S, M,
-                                 D, L, Lq, P, out, shapes_host, (hipStream_t)stream, &handled);
-  if (handled) return rc;
-  // experiment (off by default): corners served from LDS-staged per-level boxes (msda_forward_box.hip)
-  rc = dvis_msda_box_launch(value, shapes, level_start, ref, Nref, offsets, off_stride, logits, logit_stride, N, S, M,
-                                D, L, Lq, P, out, shapes_host, (hipStream_t)stream, &handled);
-  if (handled) return rc;
-  // experiment (off by default): persistent kernel with the coarsest value map LDS-resident (msda_forward_lds.hip)
-  rc = dvis_msda_l0lds_launch(value, shapes, level_start, ref, Nref, offsets, off_stride, logits, logit_stride, N, S, M,
-                                  D, L, Lq, P, out, shapes_host, (hipStream_t)stream, &handled);
-  if (handled) return rc;
+  int rc;
   rc = dispatch_tile<true>(D, L, P, value, shapes, level_start, offsets, off_stride, logits, logit_stride, ref,
                            Nref, N, S, M, Lq, out, (hipStream_t)stream, &handled);
   if (handled) return rc;

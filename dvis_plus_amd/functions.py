@@ -10,12 +10,24 @@ unchanged.  Differences, all deliberate:
   * failures raise ``RuntimeError`` — there is no torch/CPU fallback to hide them.
 """
 import ctypes
+import os
 
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import native
+
+
+def _torch_path(op, x, why):
+    """Called where a fused glue op is about to take its torch formulation instead of the HIP kernel.  That is the right
+    thing for CPU tensors (host-logic tests) and under autograd (the kernels are inference-only), and otherwise a shape /
+    layout the kernel does not serve.  With DVIS_STRICT=1 the latter raises instead of silently running torch ops on the
+    GPU — the invisible dual path the reference has in ops/modules/ms_deform_attn.py:116-121.  The GPU test suite runs
+    with it (tests/conftest.py)."""
+    if os.environ.get("DVIS_STRICT", "0") == "1" and x.is_cuda and not torch.is_grad_enabled():
+        raise RuntimeError(f"DVIS_STRICT: {op} would run its torch formulation on a GPU tensor ({why}; shape "
+                           f"{tuple(x.shape)}, dtype {x.dtype}, contiguous {x.is_contiguous()})")
 
 
 def _check_msda_inputs(value, spatial_shapes, level_start_index, sampling_loc, attn_weight):
@@ -330,10 +342,12 @@ def add_layer_norm(x, res, norm, pos=None):
         return out if pos is None else (out, out + pos.reshape(1, -1, C))
     if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and C % 4 == 0 and C <= 1024
             and norm.weight is not None and not torch.is_grad_enabled()):
+        _torch_path("add_layer_norm", x, "needs contiguous fp32 rows with C % 4 == 0, C <= 1024 and an affine norm")
         return with_pos(norm(x if res is None else x + res))
     rp, rs = None, 0
     if res is not None:
         if res.shape != x.shape or res.dtype != torch.float32 or not res.is_cuda:
+            _torch_path("add_layer_norm", x, "residual must be fp32 of x's shape")
             return with_pos(norm(x + res))
         if not res.is_contiguous():
             res = res.contiguous()
@@ -365,6 +379,7 @@ def bias_relu_maxpool(x, bias=None):
     N, C, H, W = x.shape
     if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and H % 2 == 0 and W % 8 == 0
             and not torch.is_grad_enabled()):
+        _torch_path("bias_relu_maxpool", x, "needs contiguous fp32 NCHW with H % 2 == 0 and W % 8 == 0")
         import torch.nn.functional as F
         if bias is not None:
             x = x + bias.view(1, -1, 1, 1)
@@ -390,6 +405,7 @@ def group_norm_affine(x, norm):
     N, C, H, W = x.shape
     G = norm.num_groups
     if not (_fused_map_ok(x) and (C // G) * H * W % 4 == 0 and C // G <= 1024 and x.data_ptr() % 16 == 0):
+        _torch_path("group_norm_affine", x, "needs contiguous 16-byte aligned fp32 NCHW, group size % 4 == 0")
         return None
     scale = torch.empty(N * C, dtype=torch.float32, device=x.device)
     shift = torch.empty(N * C, dtype=torch.float32, device=x.device)
@@ -419,6 +435,7 @@ def upsample_add(lateral, top, lat_affine=None):
     GroupNorm applied on the fly)."""
     N, C, H, W = lateral.shape
     if not (_fused_map_ok(lateral) and top.dtype == torch.float32 and W % 4 == 0):
+        _torch_path("upsample_add", lateral, "needs contiguous fp32 NCHW with W % 4 == 0")
         import torch.nn.functional as F
         if lat_affine is not None:
             lateral = lateral * lat_affine[0].view(N, C, 1, 1) + lat_affine[1].view(N, C, 1, 1)
@@ -465,6 +482,7 @@ def maps_to_tokens(maps, affines=None, pos=None):
     affines = affines or [None] * len(maps)
     N, C = maps[0].shape[:2]
     if not all(m.is_cuda and m.dtype == torch.float32 and m.is_contiguous() for m in maps) or torch.is_grad_enabled():
+        _torch_path("maps_to_tokens", maps[0], "needs contiguous fp32 NCHW maps")
         maps = [m if a is None else m * a[0].view(N, C, 1, 1) + a[1].view(N, C, 1, 1) for m, a in zip(maps, affines)]
         out = torch.cat([m.flatten(2).transpose(1, 2) for m in maps], 1)
         return out if pos is None else (out, out + pos.reshape(1, -1, C))
@@ -504,7 +522,9 @@ def conv1x1(x, weight, bias=None):
         # whenever the 2-D operand is a Parameter that requires grad, even under no_grad
         y = torch.bmm(weight.detach().view(1, Co, Ci).expand(N, Co, Ci), x.view(N, Ci, H * W)).view(N, Co, H, W)
         return y if bias is None else bias_act_(y, bias.detach(), None, relu=False)   # in place, at the HBM stream rate
-    return torch.nn.functional.conv2d(x, weight, bias)
+    if x.is_cuda and Ci >= Co:
+        _torch_path("conv1x1", x, "the batched-GEMM form needs a contiguous 4-D input of the weight's dtype")
+    return torch.nn.functional.conv2d(x, weight, bias)      # channel-expanding: MIOpen is the faster library call
 
 
 def bias_act_(x, bias=None, res=None, relu=True):
@@ -514,6 +534,7 @@ def bias_act_(x, bias=None, res=None, relu=True):
     if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and (H * W) % 4 == 0
             and (res is None or (res.is_contiguous() and res.shape == x.shape and res.dtype == torch.float32))
             and not torch.is_grad_enabled()):
+        _torch_path("bias_act_", x, "needs contiguous fp32 NCHW with H*W % 4 == 0 (and a matching residual)")
         if bias is not None:
             x = x + bias.view(1, -1, 1, 1)
         if res is not None:

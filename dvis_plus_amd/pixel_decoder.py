@@ -97,21 +97,23 @@ class MSDeformAttn(nn.Module):
         self._reset_parameters()
 
     def _reset_parameters(self):
-        constant_(self.sampling_offsets.weight.data, 0.)
-        thetas = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
-        grid_init = torch.stack([thetas.cos(), thetas.sin()], -1)
-        grid_init = (grid_init / grid_init.abs().max(-1, keepdim=True)[0]).view(self.n_heads, 1, 1, 2).repeat(
-            1, self.n_levels, self.n_points, 1)
-        for i in range(self.n_points):
-            grid_init[:, :, i, :] *= i + 1
+        """Init rule of ops/modules/ms_deform_attn.py:66-80: offsets and attention logits start input-independent
+        (zero weights); head m looks along the direction of angle 2*pi*m/M, stretched to the unit SQUARE, and its p-th
+        point sits p + 1 steps out, the same on every level; both projections get Xavier-uniform weights."""
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+        angle = torch.arange(M, dtype=torch.float32) * (2.0 * math.pi / M)
+        direction = torch.stack([angle.cos(), angle.sin()], -1)
+        direction = direction / direction.abs().max(-1, keepdim=True)[0]                    # (M, 2) on the unit square
+        steps = torch.arange(1, P + 1, dtype=torch.float32)                                 # (P,)
+        bias = direction[:, None, None, :] * steps[None, None, :, None]                     # (M, 1, P, 2)
         with torch.no_grad():
-            self.sampling_offsets.bias = nn.Parameter(grid_init.view(-1))
-        constant_(self.attention_weights.weight.data, 0.)
-        constant_(self.attention_weights.bias.data, 0.)
-        xavier_uniform_(self.value_proj.weight.data)
-        constant_(self.value_proj.bias.data, 0.)
-        xavier_uniform_(self.output_proj.weight.data)
-        constant_(self.output_proj.bias.data, 0.)
+            self.sampling_offsets.bias = nn.Parameter(bias.expand(M, L, P, 2).reshape(-1).clone())
+            self.sampling_offsets.weight.zero_()
+            self.attention_weights.weight.zero_()
+            self.attention_weights.bias.zero_()
+            for proj in (self.value_proj, self.output_proj):
+                xavier_uniform_(proj.weight)
+                proj.bias.zero_()
 
     def _fused_projection(self):
         so, aw = self.sampling_offsets, self.attention_weights

@@ -242,114 +242,3 @@ def test_fused_forward_2d_query_tiling_is_only_a_schedule():
         c = msda_fused_forward(value, s.to(DEV), lsi.to(DEV), ref_pts[:, :100].contiguous(), proj[:2 * 100, :n_off],
                                proj[:2 * 100, n_off:], L, P, shapes_host=shapes)
         assert c.shape == (N, 100, M * D)
-
-
-def test_lds_resident_variant_is_bit_identical(monkeypatch):
-    """The experimental persistent kernel (coarsest map in LDS, DVIS_MSDA_L0LDS=1) must give the tiled kernel's bits.
-    The knob is read once per process, so run it in a subprocess."""
-    import subprocess
-    import sys
-    code = """
-import sys, torch
-sys.path.insert(0, %r); sys.path.insert(0, %r)
-from conftest import level_tensors
-from dvis_plus_amd.functions import msda_fused_forward
-shapes = [(23, 40), (46, 80), (92, 160)]
-N, M, D, L, P = 2, 8, 32, 3, 4
-s, lsi = level_tensors(shapes)
-S = Lq = int(s.prod(1).sum())
-g = torch.Generator().manual_seed(5)
-value = torch.randn(N, S, M, D, generator=g).cuda()
-proj = (torch.randn(N * Lq, M * L * P * 3, generator=g) * 2).cuda()
-ref = torch.rand(1, Lq, L, 2, generator=g).cuda()
-n_off = M * L * P * 2
-out = msda_fused_forward(value, s.cuda(), lsi.cuda(), ref, proj[:, :n_off], proj[:, n_off:], L, P, shapes_host=shapes)
-torch.save(out.cpu(), sys.argv[1])
-"""
-    import os
-    import tempfile
-    from conftest import ROOT
-    outs = []
-    for knob in ("0", "1"):
-        with tempfile.NamedTemporaryFile(suffix=".pt") as f:
-            env = dict(os.environ, DVIS_MSDA_L0LDS=knob)
-            subprocess.check_call([sys.executable, "-c", code % (ROOT, os.path.join(ROOT, "tests")), f.name], env=env)
-            outs.append(torch.load(f.name))
-    assert torch.equal(outs[0], outs[1])
-
-
-@pytest.mark.parametrize("knob", ["DVIS_MSDA_BOX", "DVIS_MSDA_PIPE"])
-def test_lds_staged_variants_match_tiled_kernel(knob):
-    """The experimental LDS kernels (DVIS_MSDA_BOX=1: per-level bounding boxes of an 8x8 query tile staged in LDS, global
-    fallback where a box does not fit; DVIS_MSDA_PIPE=1: the persistent software-pipelined form of the same idea) compute
-    the same sums as the tiled kernel.  Self-attention geometry:
-    reference points = pixel centres, offsets of a few pixels (boxes fit) and of many pixels (fallback), ragged maps."""
-    import os
-    import subprocess
-    import sys
-    import tempfile
-    from conftest import ROOT
-    code = """
-import sys, torch
-sys.path.insert(0, %r); sys.path.insert(0, %r)
-from conftest import level_tensors
-from dvis_plus_amd.functions import msda_fused_forward
-res = []
-for shapes, spread in (([(23, 40), (46, 80), (92, 160)], 3.0), ([(5, 7), (9, 13), (17, 30)], 2.0),
-                       ([(23, 40), (46, 80), (92, 160)], 40.0)):
-    N, M, D, L, P = 2, 8, 32, 3, 4
-    s, lsi = level_tensors(shapes)
-    S = Lq = int(s.prod(1).sum())
-    g = torch.Generator().manual_seed(7)
-    value = torch.randn(N, S, M, D, generator=g).cuda()
-    proj = torch.randn(N * Lq, M * L * P * 3, generator=g)
-    proj[:, :M * L * P * 2] *= spread
-    cen = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w,
-                                                indexing="ij"), -1).flip(-1).reshape(-1, 2) for h, w in shapes])
-    ref = cen[None, :, None, :].expand(1, Lq, L, 2).contiguous().cuda()
-    n_off = M * L * P * 2
-    pr = proj.cuda()
-    res.append(msda_fused_forward(value, s.cuda(), lsi.cuda(), ref, pr[:, :n_off], pr[:, n_off:], L, P,
-                                  shapes_host=shapes).cpu())
-torch.save(res, sys.argv[1])
-"""
-    outs = []
-    for val in ("0", "1"):
-        with tempfile.NamedTemporaryFile(suffix=".pt") as f:
-            env = dict(os.environ, **{knob: val})
-            subprocess.check_call([sys.executable, "-c", code % (ROOT, os.path.join(ROOT, "tests")), f.name], env=env)
-            outs.append(torch.load(f.name))
-    for a, b in zip(*outs):
-        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
-
-
-def test_fp16_value_experiment_error_bound():
-    """dvis_msda_fused_forward_h16 (experiment): only the sampled values are rounded to fp16, so the output differs from
-    the fp32 kernel by at most 2^-11 * max|value| (convex combination of rounded values) — inside BASELINE's 1e-3."""
-    import ctypes
-    from dvis_plus_amd import native
-    from dvis_plus_amd.functions import msda_fused_forward
-    shapes = [(23, 40), (46, 80), (92, 160)]
-    N, M, D, L, P = 2, 8, 32, 3, 4
-    s, lsi = level_tensors(shapes)
-    S = Lq = int(s.prod(1).sum())
-    g = torch.Generator().manual_seed(21)
-    value = torch.randn(N, S, M, D, generator=g).to(DEV)
-    proj = (torch.randn(N * Lq, M * L * P * 3, generator=g) * 2).to(DEV)
-    ref = torch.rand(1, Lq, L, 2, generator=g).to(DEV)
-    n_off = M * L * P * 2
-    sd, ld = s.to(DEV), lsi.to(DEV)
-    want = msda_fused_forward(value, sd, ld, ref, proj[:, :n_off], proj[:, n_off:], L, P)
-    v16 = value.half().contiguous()
-    out = torch.empty_like(want)
-    p = lambda t: ctypes.c_void_p(t.data_ptr())
-    offs, lgs = proj[:, :n_off], proj[:, n_off:]
-    rc = native.lib().dvis_msda_fused_forward_h16(p(v16), p(sd), p(ld), p(ref), 1, p(offs), offs.stride(0), p(lgs),
-                                                  lgs.stride(0), N, S, M, D, L, Lq, P, p(out),
-                                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
-    assert rc == 0
-    bound = 2.0 ** -11 * value.abs().max().item()
-    assert (out - want).abs().max().item() <= bound * 1.01
-    # and exactly the fp32 kernel on the rounded values
-    exact = msda_fused_forward(v16.float(), sd, ld, ref, offs, lgs, L, P)
-    torch.testing.assert_close(out, exact, rtol=1e-5, atol=1e-6)
