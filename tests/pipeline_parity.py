@@ -36,6 +36,17 @@ def perturb_msda(pd):
             l.self_attn.attention_weights.weight.normal_(0, 0.1)
 
 
+def sharpen_masks(m, gain):
+    """Random-init mask heads give logits of order 1e-2: every sigmoid is 0.5 +- 0.005, every candidate ties with every
+    other and an arg-max comparison would accept anything.  Scale the last layer of the three mask-embedding MLPs (both
+    sides read the same state_dict afterwards) so that masks are decisive — as trained ones are."""
+    heads = [m.sem_seg_head.predictor.mask_embed]
+    heads += [mod.mask_embed for mod in (m.tracker, m.refiner) if mod is not None]
+    with torch.no_grad():
+        for h in heads:
+            h.layers[-1].weight.mul_(gain)
+
+
 def gpu_backbone(m):
     def backbone_from_gpu(images_cpu):
         with torch.no_grad():
@@ -59,6 +70,7 @@ def compare_vps(out, ref, stages, what, max_count=None):
     got = out["pred_masks"].cpu()
     if not segs:
         assert int(got.abs().sum()) == 0
+        intcmp._report(f"{what}: no segment survives on either side (empty maps)")
         return 0
     probs, scores, best = stages["vps_probs"], stages["vps_scores"], stages["vps_ids"]
     margin = intcmp.argmax_margin(scores.view(-1, 1, 1, 1) * probs)

@@ -26,6 +26,7 @@ def _model(mode, task, **kw):
     from dvis_plus_amd.meta_architecture import build_dvis_plus_r50
     m = build_dvis_plus_r50(mode, task=task, object_mask_threshold=0.0, **kw)
     PPar.perturb_msda(m.sem_seg_head.pixel_decoder)
+    PPar.sharpen_masks(m, 40.0)
     return m, PPar.cpu_state(m)
 
 
@@ -38,8 +39,8 @@ def test_online_T5_720p_vs_oracle(task):
     video = {"image": clip, "height": 720, "width": 1280}
     if task == "vps":
         m.object_mask_threshold = bench.calibrate_threshold(m, [video], 20)
-        # random weights give every candidate a diffuse mask: with the reference's 0.8 overlap rule no segment would
-        # survive and the comparison would be between two empty maps
+        # random masks overlap heavily: with the reference's 0.8 overlap rule few segments survive; with the rule off
+        # every candidate that wins a pixel becomes a segment, i.e. the whole arg-max map is compared
         m.overlap_threshold = 0.0
     out = m([video])
     ref, stages = PPar.run_oracle(m, sd, [f for f in clip.cpu()], offline=False, task=task, max_num=10,
@@ -73,9 +74,9 @@ def test_bench_workload_T30_vps_stream_vs_oracle():
     PPar.compare_vps(outs[0], ref, stages, "config #3 offline vps T=30 720p through stream() (bench workload)")
     again = m([videos[1]])
     assert torch.equal(again["pred_masks"], outs[1]["pred_masks"]) and again["segments_infos"] == outs[1]["segments_infos"]
-    # Random weights give diffuse masks, so the reference's 0.8 overlap rule keeps few (or no) segments.  Second
-    # comparison on the same clip with the overlap rule off: every candidate that wins a pixel becomes a segment, i.e.
-    # the whole 30 x 720 x 1280 arg-max map is compared.  (The oracle's post-processing is re-run on its stored class
+    # Random masks overlap heavily, so the reference's 0.8 overlap rule keeps few segments.  Second comparison on the
+    # same clip with the overlap rule off: every candidate that wins a pixel becomes a segment, i.e. the whole
+    # 30 x 720 x 1280 arg-max map is compared.  (The oracle's post-processing is re-run on its stored class
     # logits and masks; the product re-runs the clip.)
     m.overlap_threshold = 0.0
     out0 = m([videos[0]])
@@ -83,5 +84,5 @@ def test_bench_workload_T30_vps_stream_vs_oracle():
     with torch.no_grad():
         ref0 = O.inference_video_vps(stages["cls"], stages["masks"], (720, 1280), (720, 1280), (736, 1280), 124, 58,
                                      m.object_mask_threshold, 0.0, stages["aux"], diag=diag)
-    assert len(ref0[1]) >= 10
+    assert len(ref0[1]) >= 5, ref0[1]
     PPar.compare_vps(out0, ref0, diag, "config #3 offline vps T=30 720p, overlap rule off (full arg-max map)")

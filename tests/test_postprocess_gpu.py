@@ -3,7 +3,8 @@
 The reference post-processes on CPU tensors, so its integer outputs are defined by the arithmetic of torch's CPU
 kernels.  The product evaluates that arithmetic operation for operation (csrc/torch_cpu_math.h), which these tests pin in
 three layers:
-  1. floats: dvis_resize2 == torch's CPU interpolate -> crop -> (sigmoid) -> interpolate, bit for bit;
+  1. floats: dvis_resize2 == torch's CPU interpolate -> crop -> (sigmoid) -> interpolate, bit for bit (with the sigmoid:
+     up to ~1e-4 of the floats by 1 ulp, where torch's own result depends on its thread count);
   2. decisions on the same logits: masks / arg-max ids / confidences / areas == the torch CPU sequence, torch.equal;
   3. the reference's own outputs: the golden fixtures g6_postprocess (small sizes) and g6_postprocess_large, torch.equal.
 The semantic class sums are a (C x Q) GEMM whose summation order is the BLAS library's on the CPU and the MFMA's here:
@@ -54,10 +55,13 @@ def test_resize2_floats_bitwise_vs_torch_cpu(K, T, hw, first, img, out, sigmoid)
     n = int(diff.sum())
     intcmp._report(f"resize2 floats K={K} T={T} {hw}->{first}->{img}->{out} sigmoid={sigmoid}: {n} of {got.numel()} "
                    f"floats differ bitwise; max |d| {float((got - want).abs().max()):.2e}")
-    if sigmoid and img[1] != first[1]:
-        # the tail columns go through glibc's scalar expf on the CPU and a double-precision exp here: both round the
-        # exact exponential to float, they may disagree on the rare value that sits on a rounding boundary
-        assert n <= 4 and float((got - want).abs().max()) <= 1.2e-7
+    if sigmoid:
+        # torch's CPU sigmoid evaluates the last (n mod 32) elements of every contiguous run it hands to a thread with the
+        # SCALAR exp (glibc) instead of the vector one (Sleef); where those runs end depends on the size of the tensor and
+        # on the number of host threads (128 on the GPU box, 8 in the build container), so torch's own result is not unique
+        # there.  The kernel follows the vector evaluation (and the scalar one for the tail columns of an x-cropped row,
+        # which is independent of the thread count): a handful of floats may differ, each by one unit in the last place.
+        assert n <= max(4, got.numel() // 10000) and float((got - want).abs().max()) <= 1.2e-7
     else:
         assert n == 0
 
