@@ -35,20 +35,99 @@ using dvis_msda::kOOB;
 using dvis_msda::make_tap;
 using dvis_msda::Tap;
 
+// Storage types of the tiled kernel: a lane always moves 16 bytes per corner — 4 fp32 channels or 8 fp16 / bf16 channels —
+// and accumulates in fp32 (the reference dispatches float / double only, ms_deform_attn_cuda.cu:69; under autocast its
+// ViT-Adapter extractors therefore fall into the grid_sample path, ms_deform_attn.py:116-121).
+template <typename T> struct Chan;
+template <> struct Chan<float> {
+  static constexpr int kPerLane = 4;
+  static __device__ __forceinline__ void unpack(const dvis_v4u &r, float (&f)[4]) {
+    f[0] = __uint_as_float(r.x); f[1] = __uint_as_float(r.y); f[2] = __uint_as_float(r.z); f[3] = __uint_as_float(r.w);
+  }
+  static __device__ __forceinline__ void store(float *dst, const float (&a)[4]) {
+    *reinterpret_cast<float4 *>(dst) = make_float4(a[0], a[1], a[2], a[3]);
+  }
+  static __device__ __forceinline__ float load(const float *p) { return *p; }
+  static __device__ __forceinline__ float2 load2(const float *p) { return *reinterpret_cast<const float2 *>(p); }
+};
+template <> struct Chan<__half> {
+  static constexpr int kPerLane = 8;
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ void unpack(const dvis_v4u &r, float (&f)[8]) {
+    const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const h2 v = __builtin_bit_cast(h2, w[i]);
+      f[2 * i] = (float)v[0];
+      f[2 * i + 1] = (float)v[1];
+    }
+  }
+  static __device__ __forceinline__ void store(__half *dst, const float (&a)[8]) {
+    dvis_v4u o;
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      h2 v;
+      v[0] = (_Float16)a[2 * i];
+      v[1] = (_Float16)a[2 * i + 1];
+      w[i] = __builtin_bit_cast(unsigned, v);
+    }
+    o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
+    *reinterpret_cast<dvis_v4u *>(dst) = o;
+  }
+  static __device__ __forceinline__ float load(const __half *p) { return __half2float(*p); }
+  static __device__ __forceinline__ float2 load2(const __half *p) {
+    const h2 v = *reinterpret_cast<const h2 *>(p);
+    return make_float2((float)v[0], (float)v[1]);
+  }
+};
+template <> struct Chan<__hip_bfloat16> {
+  static constexpr int kPerLane = 8;
+  static __device__ __forceinline__ void unpack(const dvis_v4u &r, float (&f)[8]) {
+    const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = __uint_as_float(w[i] << 16);             // bf16 = the upper half of an fp32
+      f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ unsigned short rne(float x) {   // round to nearest even, NaN kept quiet
+    const unsigned u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+  }
+  static __device__ __forceinline__ void store(__hip_bfloat16 *dst, const float (&a)[8]) {
+    dvis_v4u o;
+    o.x = (unsigned)rne(a[0]) | ((unsigned)rne(a[1]) << 16);
+    o.y = (unsigned)rne(a[2]) | ((unsigned)rne(a[3]) << 16);
+    o.z = (unsigned)rne(a[4]) | ((unsigned)rne(a[5]) << 16);
+    o.w = (unsigned)rne(a[6]) | ((unsigned)rne(a[7]) << 16);
+    *reinterpret_cast<dvis_v4u *>(dst) = o;
+  }
+  static __device__ __forceinline__ float load(const __hip_bfloat16 *p) {
+    return __uint_as_float((unsigned)(*reinterpret_cast<const unsigned short *>(p)) << 16);
+  }
+  static __device__ __forceinline__ float2 load2(const __hip_bfloat16 *p) {
+    const unsigned w = *reinterpret_cast<const unsigned *>(p);
+    return make_float2(__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u));
+  }
+};
+
 // QB queries per workgroup; WPS = register budget in waves/SIMD; B = samples per batch of corner loads.
-template <int D, int L, int P, bool FUSED, int WPS, int B, int QB>
-__global__ __launch_bounds__(256, WPS) void msda_fwd_tile_f32(
-    const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
-    const float *__restrict__ loc_or_off, int64_t off_stride, const float *__restrict__ w_or_logit,
-    int64_t logit_stride, const float *__restrict__ refp, int nref, int S, int M, int Lq, float *__restrict__ out,
+// T: storage type of value / locations / weights / output (the FUSED form takes raw fp32 projections: T = float only).
+template <typename T, int D, int L, int P, bool FUSED, int WPS, int B, int QB>
+__global__ __launch_bounds__(256, WPS) void msda_fwd_tile(
+    const T *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
+    const T *__restrict__ loc_or_off, int64_t off_stride, const T *__restrict__ w_or_logit,
+    int64_t logit_stride, const float *__restrict__ refp, int nref, int S, int M, int Lq, T *__restrict__ out,
     const float *__restrict__ pos_off, const float *__restrict__ pos_logit, int64_t pos_stride) {
   constexpr int LP = L * P;
-  constexpr int G = D / 4;          // lanes per (query, head) pair
+  constexpr int CPL = Chan<T>::kPerLane;   // channels per lane (16 bytes)
+  constexpr int G = D / CPL;        // lanes per (query, head) pair
   constexpr int GPW = 64 / G;       // pairs per wave-instruction
-  constexpr int LOCV = LP / 2;      // float4s of (x, y) per pair
-  constexpr int WV = LP / 4;        // float4s of weights per pair
-  constexpr int ITERS = QB / (4 * GPW);
-  static_assert(LP % 4 == 0 && D % 4 == 0 && 64 % G == 0 && P % B == 0 && QB % (4 * GPW) == 0, "tile shape");
+  constexpr int ITERS = (QB + 4 * GPW - 1) / (4 * GPW);
+  static_assert(LP % 4 == 0 && D % CPL == 0 && 64 % G == 0 && P % B == 0, "tile shape");
+  static_assert(!FUSED || sizeof(T) == 4, "the fused form reads raw fp32 projections");
 
   // Bilinear set-up of every (query, sample) of the block, computed ONCE by one thread.  The D/4 lanes of a pair used
   // to redo the same ~50 VALU instructions per sample each: PMC showed 4.1e8 VALU instructions per 30-frame launch =
@@ -79,7 +158,7 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile_f32(
   // then softmax, loc = ref + off / (W_l, H_l) and the taps, and ONE barrier.  (The first form staged the rows in LDS,
   // synchronised, loaded the reference points, computed, synchronised again: with the gather switched off that set-up
   // alone took 12.7-15.5 us per 720p frame-layer, and with the loads switched off the kernel still took 23.5 of 35 us.)
-  const unsigned pix_bytes = (unsigned)MD * 4u;
+  const unsigned pix_bytes = (unsigned)MD * (unsigned)sizeof(T);
   static_assert(QB * P <= 256, "one set-up thread per (query, point)");
   if (tid < QB * P) {
     const int ql = tid / P, p = tid - ql * P;
@@ -88,7 +167,7 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile_f32(
     const size_t qq = active ? q : 0;
     float2 xy[L];
     float aw[L];
-    if (FUSED) {
+    if constexpr (FUSED) {
       const float *orow = loc_or_off + ((size_t)n * Lq + qq) * off_stride + (size_t)m * (LP * 2);
       const float *lrow = w_or_logit + ((size_t)n * Lq + qq) * logit_stride + (size_t)m * LP;
       float2 ro[L], rr[L];
@@ -134,12 +213,12 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile_f32(
         aw[l] = ev / sum;
       }
     } else {
-      const float *lrow = loc_or_off + (((size_t)n * Lq + qq) * M + m) * (size_t)(LP * 2);
-      const float *wrow = w_or_logit + (((size_t)n * Lq + qq) * M + m) * (size_t)LP;
+      const T *lrow = loc_or_off + (((size_t)n * Lq + qq) * M + m) * (size_t)(LP * 2);
+      const T *wrow = w_or_logit + (((size_t)n * Lq + qq) * M + m) * (size_t)LP;
 #pragma unroll
       for (int l = 0; l < L; ++l) {
-        xy[l] = *reinterpret_cast<const float2 *>(lrow + 2 * (l * P + p));
-        aw[l] = wrow[l * P + p];
+        xy[l] = Chan<T>::load2(lrow + 2 * (l * P + p));
+        aw[l] = Chan<T>::load(wrow + l * P + p);
       }
     }
 #pragma unroll
@@ -158,14 +237,14 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile_f32(
   __amdgpu_buffer_rsrc_t rs[L];
 #pragma unroll
   for (int l = 0; l < L; ++l) {
-    const float *base = value + (((size_t)n * S + (size_t)level_start[l]) * M + m) * D;
-    rs[l] = dvis_make_rsrc_uniform(base, (unsigned)(((size_t)(Hs[l] * Ws[l] - 1) * MD + D) * sizeof(float)));
+    const T *base = value + (((size_t)n * S + (size_t)level_start[l]) * M + m) * D;
+    rs[l] = dvis_make_rsrc_uniform(base, (unsigned)(((size_t)(Hs[l] * Ws[l] - 1) * MD + D) * sizeof(T)));
   }
 
   const int lane = tid & 63, wv = tid >> 6;
   const int g = lane / G, j = lane - g * G;
   const unsigned lane_bytes = (unsigned)j * 16u;   // kOOB + lane_bytes is still out of range
-  float *const out_frame = out + ((size_t)n * Lq * M + m) * D;   // uniform
+  T *const out_frame = out + ((size_t)n * Lq * M + m) * D;   // uniform
 
   // Latency is hidden by WAVES, not by a deep per-wave pipeline: each wave keeps one batch of B samples
   // (4*B corner loads) in flight, reads that batch's taps from LDS just in time, and stays within the
@@ -174,8 +253,11 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile_f32(
 #pragma unroll 1
   for (int it = 0; it < ITERS; ++it) {
     const int ql = (it * 4 + wv) * GPW + g;
+    if (QB % (4 * GPW) != 0 && ql >= QB) break;          // wave-uniform: a wave's GPW pairs are one slot range
     const int q = slot_query(ql);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    float acc[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) acc[k] = 0.f;
 #pragma unroll
     for (int l = 0; l < L; ++l) {
 #pragma unroll 1
@@ -200,24 +282,19 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile_f32(
         }
 #pragma unroll
         for (int i = 0; i < B; ++i) {
-          const dvis_v4u r1 = r[4 * i], r2 = r[4 * i + 1], r3 = r[4 * i + 2], r4 = r[4 * i + 3];
+          float v1[CPL], v2[CPL], v3[CPL], v4[CPL];
+          Chan<T>::unpack(r[4 * i], v1);
+          Chan<T>::unpack(r[4 * i + 1], v2);
+          Chan<T>::unpack(r[4 * i + 2], v3);
+          Chan<T>::unpack(r[4 * i + 3], v4);
           const float c1 = c[i].x, c2 = c[i].y, c3 = c[i].z, c4 = c[i].w;
           // reference order: (w1 v1 + w2 v2 + w3 v3 + w4 v4) * weight, accumulated over samples
-          a0 += (c1 * __uint_as_float(r1.x) + c2 * __uint_as_float(r2.x) + c3 * __uint_as_float(r3.x) +
-                 c4 * __uint_as_float(r4.x)) * aw[i];
-          a1 += (c1 * __uint_as_float(r1.y) + c2 * __uint_as_float(r2.y) + c3 * __uint_as_float(r3.y) +
-                 c4 * __uint_as_float(r4.y)) * aw[i];
-          a2 += (c1 * __uint_as_float(r1.z) + c2 * __uint_as_float(r2.z) + c3 * __uint_as_float(r3.z) +
-                 c4 * __uint_as_float(r4.z)) * aw[i];
-          a3 += (c1 * __uint_as_float(r1.w) + c2 * __uint_as_float(r2.w) + c3 * __uint_as_float(r3.w) +
-                 c4 * __uint_as_float(r4.w)) * aw[i];
+#pragma unroll
+          for (int k = 0; k < CPL; ++k) acc[k] += (c1 * v1[k] + c2 * v2[k] + c3 * v3[k] + c4 * v4[k]) * aw[i];
         }
       }
     }
-    if (q >= 0) {
-      float *dst = out_frame + (size_t)q * MD + 4 * j;
-      *reinterpret_cast<float4 *>(dst) = make_float4(a0, a1, a2, a3);
-    }
+    if (q >= 0) Chan<T>::store(out_frame + (size_t)q * MD + CPL * j, acc);
   }
 }
 
@@ -277,60 +354,47 @@ int launch_generic(const void *value, const int64_t *shapes, const int64_t *ls, 
   return dvis_check_launch("msda_fwd_generic");
 }
 
-// Developer knob (tools/msda_sweep.py): DVIS_MSDA_VARIANT selects the tile-kernel build variant.
-// Schedules that were measured on MI355X and removed (bit-identical results, history in git and DESIGN.md §3.1):
-// 8x8 query tiles (neutral: 49.0 vs 49.2 us), band-interleaved chunk order (HBM fetch -19 %, time +4 %).
-int tile_variant() {
-  static const int v = [] {
-    const char *e = getenv("DVIS_MSDA_VARIANT");
-    return e ? atoi(e) : 0;
-  }();
-  return v;
-}
-
-template <int D, int L, int P, bool FUSED, int WPS, int B, int QB>
-int launch_variant(const float *value, const int64_t *shapes, const int64_t *ls, const float *a, int64_t a_stride,
-                   const float *b, int64_t b_stride, const float *refp, int nref, int N, int S, int M, int Lq, float *out,
+template <typename T, int D, int L, int P, bool FUSED, int WPS, int B, int QB>
+int launch_variant(const T *value, const int64_t *shapes, const int64_t *ls, const T *a, int64_t a_stride,
+                   const T *b, int64_t b_stride, const float *refp, int nref, int N, int S, int M, int Lq, T *out,
                    hipStream_t st, const float *pos_off, const float *pos_logit, int64_t pos_stride) {
   const int nchunks = (Lq + QB - 1) / QB;
   if (nchunks > 65535 || N > 65535) {
     dvis_set_error("msda: grid too large (Lq/%d and N must be <= 65535)", QB);
     return DVIS_E_ARG;
   }
-  hipLaunchKernelGGL((msda_fwd_tile_f32<D, L, P, FUSED, WPS, B, QB>), dim3(M, nchunks, N), dim3(256), 0, st, value, shapes,
+  hipLaunchKernelGGL((msda_fwd_tile<T, D, L, P, FUSED, WPS, B, QB>), dim3(M, nchunks, N), dim3(256), 0, st, value, shapes,
                      ls, a, a_stride, b, b_stride, refp, nref, S, M, Lq, out, pos_off, pos_logit, pos_stride);
-  return dvis_check_launch("msda_fwd_tile_f32");
+  return dvis_check_launch("msda_fwd_tile");
 }
 
-template <int D, int L, int P, bool FUSED>
-int launch_tile(const float *value, const int64_t *shapes, const int64_t *ls, const float *a, int64_t a_stride,
-                const float *b, int64_t b_stride, const float *refp, int nref, int N, int S, int M, int Lq, float *out,
+template <typename T, int D, int L, int P, bool FUSED>
+int launch_tile(const T *value, const int64_t *shapes, const int64_t *ls, const T *a, int64_t a_stride,
+                const T *b, int64_t b_stride, const float *refp, int nref, int N, int S, int M, int Lq, T *out,
                 hipStream_t st, const float *pos_off, const float *pos_logit, int64_t pos_stride) {
 #define DVIS_LAUNCH_VARIANT(wps, bsz, qb) \
-  return launch_variant<D, L, P, FUSED, wps, bsz, qb>(value, shapes, ls, a, a_stride, b, b_stride, refp, nref, N, S, M, Lq, \
-                                                      out, st, pos_off, pos_logit, pos_stride)
-  constexpr int QMIN = 4 * (64 / (D / 4));   // queries covered by one pass of the 4 waves
+  return launch_variant<T, D, L, P, FUSED, wps, bsz, qb>(value, shapes, ls, a, a_stride, b, b_stride, refp, nref, N, S, M, \
+                                                         Lq, out, st, pos_off, pos_logit, pos_stride)
+  // queries covered by one pass of the 4 waves (fp32: 16 B = 4 channels per lane), never more than one set-up thread
+  // per (query, point) allows
+  constexpr int QMIN = 4 * (64 / (D / 4)) < 256 / P / 2 ? 4 * (64 / (D / 4)) : 256 / P / 2;
   // (min waves/SIMD the register allocator must allow) x (samples per load batch) x (queries per block).  Measured on
-  // MI355X, 720p, 30 frames: 35.2 / 35.2 / 37.0 us per frame-layer — occupancy-insensitive (4 vs 8 waves/SIMD), the
-  // per-CU L1 data path is the limit.  With 2*QMIN queries the taps take 33 KB of LDS -> 4 workgroups per CU.
-  switch (tile_variant()) {
-    case 1: DVIS_LAUNCH_VARIANT(6, 2, QMIN);
-    case 2: DVIS_LAUNCH_VARIANT(4, 4, QMIN);
-    default: DVIS_LAUNCH_VARIANT(2, 2, 2 * QMIN);
-  }
+  // MI355X, 720p, 30 frames (round 1): (2, 2, 2 QMIN) 35.2 us per frame-layer = (6, 2, QMIN) 35.2 < (4, 4, QMIN) 37.0 —
+  // occupancy-insensitive, the per-CU vector-memory path is the limit.  With 2 QMIN queries the taps take 27 KB of LDS.
+  DVIS_LAUNCH_VARIANT(2, 2, 2 * QMIN);
 #undef DVIS_LAUNCH_VARIANT
 }
 
-template <bool FUSED>
-int dispatch_tile(int D, int L, int P, const float *value, const int64_t *shapes, const int64_t *ls, const float *a,
-                  int64_t a_stride, const float *b, int64_t b_stride, const float *refp, int nref, int N, int S, int M,
-                  int Lq, float *out, hipStream_t st, bool *handled, const float *pos_off = nullptr,
+template <typename T, bool FUSED>
+int dispatch_tile(int D, int L, int P, const T *value, const int64_t *shapes, const int64_t *ls, const T *a,
+                  int64_t a_stride, const T *b, int64_t b_stride, const float *refp, int nref, int N, int S, int M,
+                  int Lq, T *out, hipStream_t st, bool *handled, const float *pos_off = nullptr,
                   const float *pos_logit = nullptr, int64_t pos_stride = 0) {
   *handled = true;
 #define DVIS_TILE_CASE(d, l, p)  \
   if (D == d && L == l && P == p) \
-    return launch_tile<d, l, p, FUSED>(value, shapes, ls, a, a_stride, b, b_stride, refp, nref, N, S, M, Lq, out, st, \
-                                       pos_off, pos_logit, pos_stride);
+    return launch_tile<T, d, l, p, FUSED>(value, shapes, ls, a, a_stride, b, b_stride, refp, nref, N, S, M, Lq, out, st, \
+                                          pos_off, pos_logit, pos_stride);
   DVIS_TILE_CASE(32, 3, 4)
   DVIS_TILE_CASE(32, 4, 4)
   DVIS_TILE_CASE(32, 1, 4)
@@ -358,16 +422,30 @@ DVIS_EXPORT int dvis_msda_forward(int dtype, const void *value, const int64_t *s
                       (size_t)Lq * M * L * P * 2 * sizeof(float) < 0x7fffffffu;
     if (fits && aligned16(value) && aligned16(loc) && aligned16(w) && aligned16(out)) {
       bool handled = false;
-      int rc = dispatch_tile<false>(D, L, P, (const float *)value, shapes, level_start, (const float *)loc, 0,
-                                    (const float *)w, 0, nullptr, 0, N, S, M, Lq, (float *)out, st, &handled);
+      int rc = dispatch_tile<float, false>(D, L, P, (const float *)value, shapes, level_start, (const float *)loc, 0,
+                                           (const float *)w, 0, nullptr, 0, N, S, M, Lq, (float *)out, st, &handled);
       if (handled) return rc;
     }
     return launch_generic<float>(value, shapes, level_start, loc, w, N, S, M, D, L, Lq, P, out, st);
   }
   if (dtype == DVIS_F64) return launch_generic<double>(value, shapes, level_start, loc, w, N, S, M, D, L, Lq, P, out, st);
-  if (dtype == DVIS_F16) return launch_generic<__half>(value, shapes, level_start, loc, w, N, S, M, D, L, Lq, P, out, st);
-  if (dtype == DVIS_BF16)
-    return launch_generic<__hip_bfloat16>(value, shapes, level_start, loc, w, N, S, M, D, L, Lq, P, out, st);
+  if (dtype == DVIS_F16 || dtype == DVIS_BF16) {
+    // tiled path: 16 bytes = 8 channels per lane, fp32 accumulation (what the ViT-Adapter extractors need under autocast)
+    const bool fits = (size_t)S * M * D * 2 < 0x7fffffffu && (size_t)Lq * M * L * P * 2 * 2 < 0x7fffffffu;
+    if (fits && aligned16(value) && aligned16(out) && ((uintptr_t)loc & 3u) == 0 && (M * D) % 8 == 0) {
+      bool handled = false;
+      int rc = dtype == DVIS_F16
+                   ? dispatch_tile<__half, false>(D, L, P, (const __half *)value, shapes, level_start, (const __half *)loc, 0,
+                                                  (const __half *)w, 0, nullptr, 0, N, S, M, Lq, (__half *)out, st, &handled)
+                   : dispatch_tile<__hip_bfloat16, false>(D, L, P, (const __hip_bfloat16 *)value, shapes, level_start,
+                                                          (const __hip_bfloat16 *)loc, 0, (const __hip_bfloat16 *)w, 0,
+                                                          nullptr, 0, N, S, M, Lq, (__hip_bfloat16 *)out, st, &handled);
+      if (handled) return rc;
+    }
+    return dtype == DVIS_F16
+               ? launch_generic<__half>(value, shapes, level_start, loc, w, N, S, M, D, L, Lq, P, out, st)
+               : launch_generic<__hip_bfloat16>(value, shapes, level_start, loc, w, N, S, M, D, L, Lq, P, out, st);
+  }
   dvis_set_error("msda_forward: unsupported dtype %d", dtype);
   return DVIS_E_ARG;
 }
@@ -395,14 +473,14 @@ DVIS_EXPORT int dvis_msda_fused_forward_pos(const float *value, const int64_t *s
     DVIS_REQUIRE(pos_offsets && pos_logits && pos_stride >= (int64_t)M * L * P * 2 && pos_stride % 4 == 0 &&
                      aligned16(pos_offsets) && aligned16(pos_logits),
                  "msda_fused_forward: position rows need both pointers, 16-byte alignment and a row stride multiple of 4");
-    int rc2 = dispatch_tile<true>(D, L, P, value, shapes, level_start, offsets, off_stride, logits, logit_stride, ref, Nref,
+    int rc2 = dispatch_tile<float, true>(D, L, P, value, shapes, level_start, offsets, off_stride, logits, logit_stride, ref, Nref,
                                   N, S, M, Lq, out, (hipStream_t)stream, &handled, pos_offsets, pos_logits, pos_stride);
     if (handled) return rc2;
     dvis_set_error("msda_fused_forward: unsupported (D=%d, L=%d, P=%d)", D, L, P);
     return DVIS_E_UNSUPPORTED;
   }
   int rc;
-  rc = dispatch_tile<true>(D, L, P, value, shapes, level_start, offsets, off_stride, logits, logit_stride, ref,
+  rc = dispatch_tile<float, true>(D, L, P, value, shapes, level_start, offsets, off_stride, logits, logit_stride, ref,
                            Nref, N, S, M, Lq, out, (hipStream_t)stream, &handled);
   if (handled) return rc;
   dvis_set_error("msda_fused_forward: unsupported (D=%d, L=%d, P=%d); supported D in {32,64}, (L,P) in {(1,4),(3,4),(4,4)}",

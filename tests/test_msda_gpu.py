@@ -168,6 +168,32 @@ def test_half_precision_forward(dt):
     torch.testing.assert_close(out.float(), ref, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("dt,rel", [(torch.float16, 2.0 ** -10), (torch.bfloat16, 2.0 ** -7)])
+@pytest.mark.parametrize("M,D,shapes", [(8, 32, [(6, 10), (12, 20), (24, 40)]),      # pixel-decoder layout
+                                        (16, 64, [(23, 40)]),                          # ViT-Adapter extractor layout
+                                        (8, 64, [(5, 8), (10, 16), (20, 32), (40, 64)])])
+def test_half_precision_tiled_kernel(dt, rel, M, D, shapes):
+    """fp16 / bf16 storage on the TILED kernel (16 bytes = 8 channels per lane, fp32 accumulation): equal to the fp32
+    oracle evaluated on the rounded inputs up to the rounding of the output (one half-precision ulp)."""
+    value, s, lsi, loc, w = make_msda_inputs(2, M, D, shapes, 333, 4, torch.float32, seed=17, spread=1.2)
+    vq, lq, wq = value.to(dt), loc.to(dt), w.to(dt)
+    ref = torch.from_numpy(omsda.msda_forward(vq.float(), s, lsi, lq.float(), wq.float()))
+    out = _run(vq, s, lsi, lq, wq)
+    assert out.dtype == dt
+    torch.testing.assert_close(out.float(), ref, rtol=rel, atol=rel * float(ref.abs().max()) * 0.25)
+
+
+@pytest.mark.parametrize("dt,rel", [(torch.float16, 2.0 ** -10), (torch.bfloat16, 2.0 ** -7)])
+def test_half_precision_vs_reference_golden_vitl(dt, rel):
+    """The reference's own outputs on the ViT-Adapter extractor layout (g1_msda_vitl: D = 64, L = 1, P = 4), inputs rounded
+    to half precision: within the storage type's precision of the fp32 reference output."""
+    g = Golden("g1_msda_vitl")
+    i, o = g.ins, g.outs
+    out = _run(i["value"].to(dt), i["shapes"], i["level_start"], i["loc"].to(dt), i["w"].to(dt))
+    scale = float(o["out"].abs().max())
+    assert float((out.float() - o["out"]).abs().max()) <= 4 * rel * scale      # value, location and weight rounding
+
+
 def test_edge_cases():
     shapes = [(5, 8), (10, 16), (20, 32)]
     value, s, lsi, loc, w = make_msda_inputs(2, 8, 32, shapes, 100, 4, torch.float32, seed=9)
