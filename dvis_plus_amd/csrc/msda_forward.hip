@@ -29,6 +29,13 @@
 #include "dvis_common.h"
 #include "msda_tap.h"
 
+// msda_forward_2d.hip: the deformable encoder's self-attention geometry (queries = pixels): 8 x 8 query tiles, coarser
+// levels served from LDS.  *handled = false -> not that geometry, take the kernels below.
+int dvis_msda_tile2d_launch(const float *value, const int64_t *shapes, const int64_t *level_start, const float *ref,
+                            int nref, const float *offsets, int64_t off_stride, const float *logits, int64_t logit_stride,
+                            int N, int S, int M, int D, int L, int Lq, int P, float *out, const int64_t *shapes_host,
+                            hipStream_t st, bool *handled);
+
 namespace {
 
 using dvis_msda::kOOB;
@@ -479,7 +486,10 @@ DVIS_EXPORT int dvis_msda_fused_forward_pos(const float *value, const int64_t *s
     dvis_set_error("msda_fused_forward: unsupported (D=%d, L=%d, P=%d)", D, L, P);
     return DVIS_E_UNSUPPORTED;
   }
-  int rc;
+  int rc = dvis_msda_tile2d_launch(value, shapes, level_start, ref, Nref, offsets, off_stride, logits, logit_stride, N, S, M,
+                                   D, L, Lq, P, out, getenv("DVIS_MSDA_2D") && getenv("DVIS_MSDA_2D")[0] == '0' ? nullptr : shapes_host,
+                                   (hipStream_t)stream, &handled);
+  if (handled) return rc;
   rc = dispatch_tile<float, true>(D, L, P, value, shapes, level_start, offsets, off_stride, logits, logit_stride, ref,
                            Nref, N, S, M, Lq, out, (hipStream_t)stream, &handled);
   if (handled) return rc;

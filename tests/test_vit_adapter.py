@@ -63,3 +63,50 @@ def test_vit_adapter_gpu_matches_reference():
     for got, k in zip(f, ("f1", "f2", "f3", "f4")):
         torch.testing.assert_close(got.cpu(), g.outs[k], rtol=1e-3, atol=1e-3)
         torch.testing.assert_close(got.cpu(), g.outs[k], rtol=5e-4, atol=1e-4)
+
+
+def _vit_pipeline(device):
+    """DVIS++ offline with the ViT-Adapter-B backbone (BASELINE config #5's family: ViT-Adapter + 200 queries; ViT-B so
+    that the CPU oracle stays light), small frames.  Both sides run their OWN backbone: the ViT-Adapter is vendored by the
+    reference, so its parity is pinned (g8) and the pipeline is compared from the pixels onward."""
+    from dvis_plus_amd.meta_architecture import build_dvis_plus
+    from oracle import dvis_torch as O
+    from oracle import vit_adapter_torch as OV
+    import pipeline_parity as PPar
+    cfg = dict(num_classes=20, n_things=10, enc_layers=2, tracker_layers=2, refiner_layers=2)
+    m = build_dvis_plus("offline", task="vis", backbone="vitb", num_queries=200, dec_layers=4, max_num=10, **cfg)
+    PPar.perturb_msda(m.sem_seg_head.pixel_decoder)
+    PPar.sharpen_masks(m, 40.0)
+    with torch.no_grad():                                # LayerScale 1e-5 would switch the ViT blocks off
+        for name, p in m.backbone.named_parameters():
+            if name.endswith("ls1.gamma") or name.endswith("ls2.gamma"):
+                p.fill_(0.3)
+    g = torch.Generator().manual_seed(8)
+    frames = [torch.randint(0, 256, (3, 128, 192), dtype=torch.uint8, generator=g) for _ in range(4)]
+    sd = PPar.cpu_state(m)
+    bsd = {k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")}
+
+    def oracle_backbone(images):
+        f = OV.vit_adapter_forward(bsd, images, heads=12, deform_heads=12,
+                                   interaction_indexes=[[0, 2], [3, 5], [6, 8], [9, 11]])
+        return dict(zip(("res2", "res3", "res4", "res5"), f))
+    m = m.to(device)
+    out = m([{"image": [f.to(device) for f in frames], "height": 128, "width": 192}])
+    stages = {}
+    with torch.no_grad():
+        ref = O.dvis_plus_forward(sd, oracle_backbone, frames, offline=True, task="vis", nheads=8, dec_layers=3,
+                                  max_num=10, stages=stages, **cfg)
+    return out, ref, stages, PPar
+
+
+def test_vit_adapter_pipeline_host_logic(oracle_ops):
+    out, ref, stages, PPar = _vit_pipeline("cpu")
+    PPar.compare_vis(out, ref, stages, "DVIS++ offline ViT-Adapter-B 200 queries (CPU host logic)")
+
+
+@pytest.mark.gpu
+def test_vit_adapter_pipeline_gpu_vs_oracle():
+    """End to end on the GPU: ViT attention (head dim 64), extractor MSDeformAttn (D = 64, L = 1, P = 4, tiled kernel),
+    segmenter with 200 queries, tracker, refiner, instance masks — vs the CPU oracle running its own ViT-Adapter."""
+    out, ref, stages, PPar = _vit_pipeline("cuda:0")
+    PPar.compare_vis(out, ref, stages, "DVIS++ offline ViT-Adapter-B 200 queries, 4 x 128 x 192")
