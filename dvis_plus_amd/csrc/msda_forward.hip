@@ -34,7 +34,7 @@
 int dvis_msda_tile2d_launch(const float *value, const int64_t *shapes, const int64_t *level_start, const float *ref,
                             int nref, const float *offsets, int64_t off_stride, const float *logits, int64_t logit_stride,
                             int N, int S, int M, int D, int L, int Lq, int P, float *out, const int64_t *shapes_host,
-                            hipStream_t st, bool *handled);
+                            hipStream_t st, bool *handled, int boxes);
 
 namespace {
 
@@ -297,7 +297,8 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile(
           const float c1 = c[i].x, c2 = c[i].y, c3 = c[i].z, c4 = c[i].w;
           // reference order: (w1 v1 + w2 v2 + w3 v3 + w4 v4) * weight, accumulated over samples
 #pragma unroll
-          for (int k = 0; k < CPL; ++k) acc[k] += (c1 * v1[k] + c2 * v2[k] + c3 * v3[k] + c4 * v4[k]) * aw[i];
+          for (int k = 0; k < CPL; ++k)
+            acc[k] = dvis_msda::accumulate_sample(acc[k], c1, c2, c3, c4, v1[k], v2[k], v3[k], v4[k], aw[i]);
         }
       }
     }
@@ -486,9 +487,12 @@ DVIS_EXPORT int dvis_msda_fused_forward_pos(const float *value, const int64_t *s
     dvis_set_error("msda_fused_forward: unsupported (D=%d, L=%d, P=%d)", D, L, P);
     return DVIS_E_UNSUPPORTED;
   }
+  // DVIS_MSDA_2D (development knob): 0 = tile kernel, 1 = 8 x 8 query tiles + LDS boxes, 2 = 8 x 8 query tiles only
+  const char *knob = getenv("DVIS_MSDA_2D");
+  const int mode2d = knob ? knob[0] - '0' : 2;
   int rc = dvis_msda_tile2d_launch(value, shapes, level_start, ref, Nref, offsets, off_stride, logits, logit_stride, N, S, M,
-                                   D, L, Lq, P, out, getenv("DVIS_MSDA_2D") && getenv("DVIS_MSDA_2D")[0] == '0' ? nullptr : shapes_host,
-                                   (hipStream_t)stream, &handled);
+                                   D, L, Lq, P, out, mode2d == 0 ? nullptr : shapes_host, (hipStream_t)stream, &handled,
+                                   mode2d == 1);
   if (handled) return rc;
   rc = dispatch_tile<float, true>(D, L, P, value, shapes, level_start, offsets, off_stride, logits, logit_stride, ref,
                            Nref, N, S, M, Lq, out, (hipStream_t)stream, &handled);

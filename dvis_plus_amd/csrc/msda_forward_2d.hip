@@ -39,7 +39,7 @@ struct TileMap {
   int tiles_x[kMaxL];               // tiles per row of every level
 };
 
-template <int L, int P, int D>
+template <int L, int P, int D, bool BOXES>
 __global__ __launch_bounds__(256, 2) void msda_fwd_tile2d_f32(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const float *__restrict__ off, int64_t off_stride, const float *__restrict__ logit, int64_t logit_stride,
@@ -54,8 +54,8 @@ __global__ __launch_bounds__(256, 2) void msda_fwd_tile2d_f32(
   __shared__ uint4 s_tap_o[kQB * LP];                  // 4 corner byte offsets in the level's global slice (kOOB = zero)
   __shared__ float4 s_tap_c[kQB * LP];                 // 4 corner weights
   __shared__ float s_aw[kQB * LP];                     // attention weights
-  __shared__ unsigned s_lds_o[kQB * 2 * P];            // box byte offset of corner (y0, x0) for the two staged levels
-  __shared__ __attribute__((aligned(16))) float s_box[(kBoxA * kBoxA + kBoxB * kBoxB) * D];
+  __shared__ unsigned s_lds_o[BOXES ? kQB * 2 * P : 1];   // box byte offset of corner (y0, x0) for the two staged levels
+  __shared__ __attribute__((aligned(16))) float s_box[BOXES ? (kBoxA * kBoxA + kBoxB * kBoxB) * D : 4];
   __shared__ unsigned s_miss[4];                       // per wave: bit k = a sample of slot k's level left its box
 
   const int tid = threadIdx.x;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void msda_fwd_tile2d_f32(
     b.l = lq - 1 - k;
     b.edge = k == 0 ? kBoxA : kBoxB;
     b.lds = k == 0 ? 0 : kBoxA * kBoxA * PIX;
-    b.on = b.l >= 0;
+    b.on = BOXES && b.l >= 0;
     b.y0 = b.x0 = 0;
     if (b.on) {
       int Hl = Hs[0], Wl = Ws[0];
@@ -246,15 +246,13 @@ __global__ __launch_bounds__(256, 2) void msda_fwd_tile2d_f32(
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     auto accumulate = [&](const dvis_v4u &r1, const dvis_v4u &r2, const dvis_v4u &r3, const dvis_v4u &r4, const float4 &c,
                           float aw) {
-      // reference order: (w1 v1 + w2 v2 + w3 v3 + w4 v4) * weight, accumulated over samples
-      acc[0] += (c.x * __uint_as_float(r1.x) + c.y * __uint_as_float(r2.x) + c.z * __uint_as_float(r3.x) +
-                 c.w * __uint_as_float(r4.x)) * aw;
-      acc[1] += (c.x * __uint_as_float(r1.y) + c.y * __uint_as_float(r2.y) + c.z * __uint_as_float(r3.y) +
-                 c.w * __uint_as_float(r4.y)) * aw;
-      acc[2] += (c.x * __uint_as_float(r1.z) + c.y * __uint_as_float(r2.z) + c.z * __uint_as_float(r3.z) +
-                 c.w * __uint_as_float(r4.z)) * aw;
-      acc[3] += (c.x * __uint_as_float(r1.w) + c.y * __uint_as_float(r2.w) + c.z * __uint_as_float(r3.w) +
-                 c.w * __uint_as_float(r4.w)) * aw;
+      const float f1[4] = {__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w)};
+      const float f2[4] = {__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w)};
+      const float f3[4] = {__uint_as_float(r3.x), __uint_as_float(r3.y), __uint_as_float(r3.z), __uint_as_float(r3.w)};
+      const float f4[4] = {__uint_as_float(r4.x), __uint_as_float(r4.y), __uint_as_float(r4.z), __uint_as_float(r4.w)};
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch)
+        acc[ch] = dvis_msda::accumulate_sample(acc[ch], c.x, c.y, c.z, c.w, f1[ch], f2[ch], f3[ch], f4[ch], aw);
     };
 #pragma unroll
     for (int l = 0; l < L; ++l) {
@@ -319,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void msda_fwd_tile2d_f32(
 int dvis_msda_tile2d_launch(const float *value, const int64_t *shapes, const int64_t *level_start, const float *ref,
                             int nref, const float *offsets, int64_t off_stride, const float *logits, int64_t logit_stride,
                             int N, int S, int M, int D, int L, int Lq, int P, float *out, const int64_t *shapes_host,
-                            hipStream_t st, bool *handled) {
+                            hipStream_t st, bool *handled, int boxes) {
   *handled = false;
   if (shapes_host == nullptr || D != 32 || P != 4 || L != 3 || Lq != S || N > 65535) return DVIS_OK;
   TileMap tm;
@@ -339,7 +337,11 @@ int dvis_msda_tile2d_launch(const float *value, const int64_t *shapes, const int
   for (int l = L; l < kMaxL; ++l) tm.tiles_x[l] = 1;
   if (total != Lq || tiles > 65535) return DVIS_OK;
   *handled = true;
-  hipLaunchKernelGGL((msda_fwd_tile2d_f32<3, 4, 32>), dim3(M, tiles, N), dim3(256), 0, st, value, shapes, level_start, offsets,
-                     off_stride, logits, logit_stride, ref, nref, S, M, Lq, out, tm);
+  if (boxes)
+    hipLaunchKernelGGL((msda_fwd_tile2d_f32<3, 4, 32, true>), dim3(M, tiles, N), dim3(256), 0, st, value, shapes, level_start,
+                       offsets, off_stride, logits, logit_stride, ref, nref, S, M, Lq, out, tm);
+  else
+    hipLaunchKernelGGL((msda_fwd_tile2d_f32<3, 4, 32, false>), dim3(M, tiles, N), dim3(256), 0, st, value, shapes, level_start,
+                       offsets, off_stride, logits, logit_stride, ref, nref, S, M, Lq, out, tm);
   return dvis_check_launch("msda_fwd_tile2d_f32");
 }

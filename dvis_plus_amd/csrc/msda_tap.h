@@ -1,4 +1,4 @@
-// Shared device helpers of the MSDeformAttn forward kernels (msda_forward.hip, msda_forward_lds.hip).
+// Shared device helpers of the MSDeformAttn forward kernels (msda_forward.hip, msda_forward_2d.hip).
 #pragma once
 #include "dvis_common.h"
 
@@ -36,6 +36,19 @@ __device__ __forceinline__ Tap make_tap(float x, float y, int H, int W, bool act
   t.c[2] = ok ? lh * hw : 0.f;
   t.c[3] = ok ? lh * lw : 0.f;
   return t;
+}
+
+// One sample's contribution to one channel, in ONE pinned operation order (every forward kernel uses it, so different
+// schedules of the op give the same bits):  acc + ((((c1 v1) + c2 v2) + c3 v3) + c4 v4) * aw  with fused multiply-adds —
+// the reference's `val = w1*v1 + w2*v2 + w3*v3 + w4*v4; col += val * weight` (ms_deform_im2col_cuda.cuh:82-88, :296)
+// as a compiler contracts it.
+__device__ __forceinline__ float accumulate_sample(float acc, float c1, float c2, float c3, float c4, float v1, float v2,
+                                                   float v3, float v4, float aw) {
+  float t = c1 * v1;
+  t = __builtin_fmaf(c2, v2, t);
+  t = __builtin_fmaf(c3, v3, t);
+  t = __builtin_fmaf(c4, v4, t);
+  return __builtin_fmaf(t, aw, acc);
 }
 
 }  // namespace dvis_msda

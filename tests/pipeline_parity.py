@@ -10,7 +10,8 @@ Integer outputs: segment lists, query ids, top-k (query, class) pairs must be EQ
 intcmp.near_boundary: the product's mask logits agree with the oracle's to ~1e-5 (different fp32 summation orders), so a
 pixel may differ only where the ORACLE's own value is within `tol` of the decision boundary; the differing count and the
 worst distance are reported.  tol = BASELINE.json's 1e-3 on logits (instance masks: |resized logit|), resp. 1e-3 x the
-sigmoid's largest slope 0.25 on probabilities (panoptic arg-max margin and the 0.5 confidence test).
+sigmoid's largest slope 0.25 on probabilities (panoptic arg-max margin in units of the largest class score, and the 0.5
+confidence test).
 """
 import torch
 
@@ -73,7 +74,9 @@ def compare_vps(out, ref, stages, what, max_count=None):
         intcmp._report(f"{what}: no segment survives on either side (empty maps)")
         return 0
     probs, scores, best = stages["vps_probs"], stages["vps_scores"], stages["vps_ids"]
-    margin = intcmp.argmax_margin(scores.view(-1, 1, 1, 1) * probs)
+    # arg-max of score_k * prob_k: the margin is measured in units of the largest score (random-init class scores are all
+    # ~ 1 / (K + 1), so the raw products differ by 1e-4 even where the masks are decisive), i.e. on the scale of prob
+    margin = intcmp.argmax_margin(scores.view(-1, 1, 1, 1) * probs) / float(scores.max())
     conf_dist = (probs.gather(0, best[None])[0] - 0.5).abs()
     return intcmp.near_boundary(got, pan, torch.minimum(margin, conf_dist), TOL_PROB,
                                 f"{what}: panoptic map vs oracle ({len(segs)} segments, {probs.shape[0]} candidates)",

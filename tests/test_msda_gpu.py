@@ -305,14 +305,14 @@ def test_encoder_geometry_kernel_is_bit_identical_to_tile_kernel(shapes, spread,
     ref = _centres(shapes) if centred else torch.rand(Lq, 2, generator=g)
     ref = ref[None, :, None, :].expand(1, Lq, L, 2).contiguous().to(DEV)
     outs = []
-    for knob in ("1", "0"):
+    for knob in ("1", "0", "2"):
         os.environ["DVIS_MSDA_2D"] = knob
         try:
             outs.append(msda_fused_forward(value, s.to(DEV), lsi.to(DEV), ref, proj[:, :n_off], proj[:, n_off:], L, P,
                                            shapes_host=shapes))
         finally:
             os.environ.pop("DVIS_MSDA_2D", None)
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[2], outs[1])
     # and against the oracle (plain op on locations / weights formed with torch)
     w = torch.softmax(lg.view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
     norm = torch.tensor([[wd, h] for h, wd in shapes], dtype=torch.float32)
