@@ -132,6 +132,7 @@ class _VideoBase(nn.Module):
         # one clip per round, tracker replicated on every rank)
         self.owner_rounds = os.environ.get("DVIS_OWNER_ROUNDS", "1") != "0"
         self.stream_timing = False            # stream(): make the per-clip "ready_event" a timing event (bench latency)
+        self.debug_stages = None              # tests: a dict here receives the floats behind the last clip's decisions
         if hasattr(self.sem_seg_head.predictor, "compute_pred_masks"):
             self.sem_seg_head.predictor.compute_pred_masks = False
 
@@ -315,6 +316,8 @@ class DVIS_Plus_online(_VideoBase):
             from . import functions as Fn
             e = emb if idx is None else emb[:, idx]
             return Fn.mask_logits(e.contiguous(), proj).permute(1, 0, 2, 3)
+        if self.debug_stages is not None:
+            self.debug_stages.update(mask_fn=mask_fn, cls=cls, aux=None)
         out_hw = (video.get("height", img_size[0]), video.get("width", img_size[1]))
         return self._task_output(cls, None, mask_fn, img_size, out_hw, images.shape[-2:], len(images), video)
 
@@ -397,6 +400,8 @@ class DVIS_Plus_offline(_VideoBase):
 
         def mask_fn(idx):
             return self.refiner.predict_masks(emb_local, mf, idx)[0]                # (q', t_local, h, w)
+        if self.debug_stages is not None:
+            self.debug_stages.update(mask_fn=mask_fn, cls=cls, aux=aux)
         img_size = st["img_size"]
         out_hw = (video.get("height", img_size[0]), video.get("width", img_size[1]))
         out = self._task_output(cls, aux, mask_fn, img_size, out_hw, st["padded"], hi - lo, video)

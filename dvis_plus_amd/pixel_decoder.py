@@ -421,7 +421,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         with torch.autocast(device_type="cuda", enabled=False):
             srcs, pos, affines = [], [], []
             for idx, f in enumerate(self.transformer_in_features[::-1]):
-                x = features[f].float()
+                x = features[f].float().contiguous()      # (a backbone may hand over channels-last strided maps)
                 conv, gn = self.input_proj[idx][0], self.input_proj[idx][1]
                 s_ = conv(x)
                 affine = Fn.group_norm_affine(s_, gn)        # GroupNorm applied while the map is laid down as tokens

