@@ -126,6 +126,26 @@ def cpu_baseline(model, clip, frames=3, thr=0.8):
             "msda_op": cpu_baseline_msda()}
 
 
+def round_sizes(n_clips, per_round):
+    """stream() takes clips in rounds of `per_round`: sizes of the rounds for n_clips clips."""
+    return [min(per_round, n_clips - i) for i in range(0, n_clips, per_round)]
+
+
+def warmup_clip_count(warmup, steps, world, owner_rounds, streamed):
+    """Clips to run untimed so that EVERY segmenter batch shape of the timed pass has been seen (MIOpen searches its
+    solvers, seconds per shape, the first time a convolution shape appears).  One clip per step on a single GPU.  With
+    several ranks stream() batches a rank's frames of a whole round of `world` clips into one segmenter call, so the shapes
+    are those of a full round and of the last, partial round (steps mod world clips, same rotation of the ragged split):
+    the warm-up replays exactly that round structure."""
+    if not (streamed and world > 1 and owner_rounds):
+        return warmup
+    r, full = steps % world, steps >= world
+    k = max(1 if full else 0, -(-(warmup - r) // world))          # smallest k with k * world + r >= warmup
+    if r == 0:
+        k = max(k, 1)
+    return k * world + r
+
+
 def calibrate_threshold(model, inputs, candidates):
     """Random-init class logits are near-uniform (max prob ~ 1/125), so the reference's 0.8 score threshold would keep no
     query and the panoptic stage would be skipped.  One untimed pass finds the score threshold that sends `candidates`
@@ -295,9 +315,7 @@ def main():
     # shapes are those of a full round and of the last, partial round (K mod world clips, same rotation of the ragged
     # split as in the timed pass) — warm up with exactly that sequence.
     mark = os.environ.get("DVIS_BENCH_MARK") == "1"     # tools/steady_stats.py: marker kernel at each timed step start
-    warm_clips = args.warmup
-    if streamed and world > 1 and model.owner_rounds:
-        warm_clips = max(args.warmup, args.steps if args.steps < world else world + args.steps % world)
+    warm_clips = warmup_clip_count(args.warmup, args.steps, world, model.owner_rounds, streamed)
     run_pass([videos[i % len(videos)] for i in range(warm_clips)])
     torch.cuda.synchronize()
     if dist_on:

@@ -21,6 +21,7 @@
 //     on the device without the torch.where host sync.
 //   * v_mfma_f32_16x16x4_f32 = fp32 fma chain, online softmax in fp32 with expf: parity well inside 1e-3.
 #include <math.h>
+#include <stdlib.h>
 
 #include "dvis_common.h"
 
@@ -50,7 +51,7 @@ SplitPlan plan_split(int BH, int Lq, int Lk) {
   return p;
 }
 
-template <int DH, bool SHORT>
+template <int DH, bool SHORT, int NGMAX>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(
     const float *__restrict__ q, dvis_strides qs, const float *__restrict__ k, dvis_strides ks_, const float *__restrict__ v,
     dvis_strides vs, float *__restrict__ out, dvis_strides os, const uint8_t *__restrict__ mask,
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(
     // cross-row maximum exchanges, the rescale of O — is paid once per 64 keys instead of once per 16.  (The per-tile
     // form had the MFMA pipe 38 % busy on the decoder's cross-attention: every tile exposed an LDS read, two ds_bpermute
     // round trips and four expf between its 8 + 8 MFMAs.)
-    constexpr int NG = KT / 16 < 4 ? KT / 16 : 4;
+    constexpr int NG = KT / 16 < NGMAX ? KT / 16 : NGMAX;
 #pragma unroll 1
     for (int kg = 0; kg < KT / 16; kg += NG) {
       const int key0 = ks + kg * 16;
@@ -526,9 +527,20 @@ DVIS_EXPORT int dvis_attention_forward(const float *q, const int64_t *q_strides,
                          heads, Lq, Lk, scale);
     return dvis_check_launch("attn_short_kernel");
   }
-  #define DVIS_ATTN(DH_, SHORT_)                                                                                     \
-  hipLaunchKernelGGL((attn_fwd_kernel<DH_, SHORT_>), grid, block, 0, st, q, qs, k, ks, v, vs, out, os, mask, allowed_count, \
-                     heads, Lq, Lk, scale, p.nsplit, p.keys_per_split, ws_o, ws_ml)
+  // key tiles per softmax group (development knob DVIS_ATTN_NG = 1 | 2 | 4)
+  static const int ng = [] { const char *e = getenv("DVIS_ATTN_NG"); return e ? atoi(e) : 1; }();
+#define DVIS_ATTN(DH_, SHORT_)                                                                                               \
+  do {                                                                                                                       \
+    if (ng == 4)                                                                                                             \
+      hipLaunchKernelGGL((attn_fwd_kernel<DH_, SHORT_, 4>), grid, block, 0, st, q, qs, k, ks, v, vs, out, os, mask,          \
+                         allowed_count, heads, Lq, Lk, scale, p.nsplit, p.keys_per_split, ws_o, ws_ml);                      \
+    else if (ng == 2)                                                                                                        \
+      hipLaunchKernelGGL((attn_fwd_kernel<DH_, SHORT_, 2>), grid, block, 0, st, q, qs, k, ks, v, vs, out, os, mask,          \
+                         allowed_count, heads, Lq, Lk, scale, p.nsplit, p.keys_per_split, ws_o, ws_ml);                      \
+    else                                                                                                                     \
+      hipLaunchKernelGGL((attn_fwd_kernel<DH_, SHORT_, 1>), grid, block, 0, st, q, qs, k, ks, v, vs, out, os, mask,          \
+                         allowed_count, heads, Lq, Lk, scale, p.nsplit, p.keys_per_split, ws_o, ws_ml);                      \
+  } while (0)
   const bool shrt = Lk <= 128 && p.nsplit == 1;
   if (d == 32 && shrt) DVIS_ATTN(32, true);
   else if (d == 32) DVIS_ATTN(32, false);

@@ -91,8 +91,10 @@ def test_refold_after_weight_reload(monkeypatch):
     _randomise_frozen_bn(b, torch.Generator().manual_seed(4))
     x = torch.randn(1, 3, 64, 96, device=DEV)
     with torch.no_grad():
-        a(x)
+        before = a(x)["res5"].clone()
         a.load_state_dict(b.state_dict())
         got = a(x)["res5"]
         want = b.to(DEV)(x)["res5"]
-    assert torch.equal(got, want)
+    # (two module instances may get different convolution algorithms from MIOpen: close, not bit-equal)
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4 * float(want.abs().max()))
+    assert float((before - want).abs().max()) > 1e-2 * float(want.abs().max())      # the stale fold would give `before`

@@ -36,3 +36,20 @@ def test_library_exports_every_declared_symbol():
 def test_import_name_shim():
     import MultiScaleDeformableAttention as MSDA
     assert callable(MSDA.ms_deform_attn_forward) and callable(MSDA.ms_deform_attn_backward)
+
+
+def test_bench_warmup_replays_the_round_structure_of_the_timed_pass():
+    """bench.py (multi-GPU, stream()): every round size that occurs in the timed pass also occurs in the warm-up, so no
+    MIOpen solver search lands in the timed region."""
+    import bench
+    for world in (1, 2, 4, 8):
+        for steps in (1, 3, 8, 10, 16, 20):
+            for warmup in (0, 2, 3):
+                w = bench.warmup_clip_count(warmup, steps, world, True, True)
+                assert w >= warmup
+                if world > 1:
+                    timed, warm = set(bench.round_sizes(steps, world)), set(bench.round_sizes(w, world))
+                    assert timed <= warm, (world, steps, warmup, timed, warm)
+                else:
+                    assert w == warmup
+    assert bench.warmup_clip_count(2, 10, 8, False, True) == 2 and bench.warmup_clip_count(2, 10, 8, True, False) == 2

@@ -563,6 +563,9 @@ def test_reloaded_weights_reach_the_fused_kv_projection(oracle_ops):
     assert g.max_entries == 2 and len(g._cache) == 0
 
 
+RAGGED8 = [30] * 9 + [5]        # the last clip leaves three of the eight ranks without a frame
+
+
 def _ragged8_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
@@ -579,7 +582,7 @@ def _ragged8_worker(rank, world, port, out_dir):
     for name in ("all_gather_into_tensor", "all_reduce", "broadcast"):
         orig = getattr(dist, name)
         setattr(dist, name, (lambda o: lambda *a, **k: (n_coll.__setitem__(0, n_coll[0] + 1), o(*a, **k))[1])(orig))
-    clips = [{"image": _tiny_clip(30, seed=100 + i, hw=(40, 64)), "height": 40, "width": 64} for i in range(10)]
+    clips = [{"image": _tiny_clip(T, seed=100 + i, hw=(40, 64)), "height": 40, "width": 64} for i, T in enumerate(RAGGED8)]
     outs = [{"masks": o["pred_masks"], "segs": o["segments_infos"], "frame_ids": o["frame_ids"]} for o in m.stream(clips)]
     torch.save({"outs": outs, "collectives": n_coll[0]}, os.path.join(out_dir, f"e{rank}.pt"))
     dist.destroy_process_group()
@@ -587,17 +590,18 @@ def _ragged8_worker(rank, world, port, out_dir):
 
 def test_stream_8_ranks_ragged_T30_ten_clips_gloo(oracle_ops, tmp_path):
     """The bench's multi-GPU shape on CPU: 8 ranks, T=30 (ragged split 4,4,4,4,4,4,4,2 rotating clip by clip), K=10
-    clips = one full round + a quarter-full one.  Every rank issues the SAME number of collectives (a rank without a
-    tracker job or without frames must not skip one), and the stitched maps equal the single-process result."""
+    clips = one full round + a quarter-full one whose last clip has only 5 frames (three ranks hold none of it).  Every
+    rank issues the SAME number of collectives (a rank without a tracker job or without frames must not skip one — the
+    post-processing reduction included), and the stitched maps equal the single-process result."""
     import torch.multiprocessing as mp
     port = 37500 + (os.getpid() % 2000)
     mp.spawn(_ragged8_worker, args=(8, port, str(tmp_path)), nprocs=8, join=True)
     parts = [torch.load(tmp_path / f"e{r}.pt") for r in range(8)]
     assert len({p["collectives"] for p in parts}) == 1, [p["collectives"] for p in parts]
     m = _tiny_model("offline", "vps")
-    for ci in range(10):
-        single = m([{"image": _tiny_clip(30, seed=100 + ci, hw=(40, 64)), "height": 40, "width": 64}])
+    for ci, T in enumerate(RAGGED8):
+        single = m([{"image": _tiny_clip(T, seed=100 + ci, hw=(40, 64)), "height": 40, "width": 64}])
         held = sorted((p["outs"][ci]["frame_ids"][0], r) for r, p in enumerate(parts) if p["outs"][ci]["frame_ids"])
-        assert sorted(f for p in parts for f in p["outs"][ci]["frame_ids"]) == list(range(30))
+        assert sorted(f for p in parts for f in p["outs"][ci]["frame_ids"]) == list(range(T))
         assert torch.equal(torch.cat([parts[r]["outs"][ci]["masks"] for _, r in held], 0), single["pred_masks"]), ci
         assert all(p["outs"][ci]["segs"] == single["segments_infos"] for p in parts), ci
