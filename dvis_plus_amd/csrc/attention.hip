@@ -21,7 +21,6 @@
 //     on the device without the torch.where host sync.
 //   * v_mfma_f32_16x16x4_f32 = fp32 fma chain, online softmax in fp32 with expf: parity well inside 1e-3.
 #include <math.h>
-#include <stdlib.h>
 
 #include "dvis_common.h"
 
@@ -51,7 +50,7 @@ SplitPlan plan_split(int BH, int Lq, int Lk) {
   return p;
 }
 
-template <int DH, bool SHORT, int NGMAX>
+template <int DH, bool SHORT>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(
     const float *__restrict__ q, dvis_strides qs, const float *__restrict__ k, dvis_strides ks_, const float *__restrict__ v,
     dvis_strides vs, float *__restrict__ out, dvis_strides os, const uint8_t *__restrict__ mask,
@@ -160,75 +159,52 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(
     __syncthreads();
     if (!SHORT && ks + KT < key_hi) prefetch(ks + KT);
     if (!wave_on) continue;
-    // Key tiles are taken NG at a time (64 keys): the NG score tiles are independent MFMA chains (no back-to-back
-    // dependency stall), their K fragments are read from LDS as one batch, and the online-softmax bookkeeping — two
-    // cross-row maximum exchanges, the rescale of O — is paid once per 64 keys instead of once per 16.  (The per-tile
-    // form had the MFMA pipe 38 % busy on the decoder's cross-attention: every tile exposed an LDS read, two ds_bpermute
-    // round trips and four expf between its 8 + 8 MFMAs.)
-    constexpr int NG = KT / 16 < NGMAX ? KT / 16 : NGMAX;
 #pragma unroll 1
-    for (int kg = 0; kg < KT / 16; kg += NG) {
-      const int key0 = ks + kg * 16;
+    for (int kt = 0; kt < KT / 16; ++kt) {
+      const int key0 = ks + kt * 16;
       if (key0 >= key_hi) break;   // uniform
-      // mask bytes of this lane's 4 keys in every tile of the group: issued first, consumed after the score MFMAs
-      unsigned mw[NG];
-      const int kbase0 = key0 + 4 * g;
-      if (use_mask) {
+      // ---- S^T tile: rows = 16 keys, cols = 16 queries
+      dvis_f4 s = dvis_f4{0.f, 0.f, 0.f, 0.f};
+      {
+        const float *krow = &k_lds[(kt * 16 + j) * LS + g * DQ];
 #pragma unroll
-        for (int t = 0; t < NG; ++t) {
-          const int kb4 = kbase0 + 16 * t;
-          if (lk4 && kb4 + 3 < key_hi) {
-            mw[t] = *reinterpret_cast<const unsigned *>(mrow + kb4);
-          } else {
-            mw[t] = 0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mw[t] |= (kb4 + r < key_hi && mrow[kb4 + r] != 0) ? (0xffu << (8 * r)) : 0u;
-          }
+        for (int c = 0; c < DQ / 4; ++c) {
+          const float4 kk = *reinterpret_cast<const float4 *>(krow + 4 * c);
+          s = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.x, qf[4 * c], s, 0, 0, 0);
+          s = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.y, qf[4 * c + 1], s, 0, 0, 0);
+          s = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.z, qf[4 * c + 2], s, 0, 0, 0);
+          s = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.w, qf[4 * c + 3], s, 0, 0, 0);
         }
       }
-      // ---- S^T tiles: rows = 16 keys, cols = 16 queries
-      dvis_f4 sc[NG];
+      // lane (j, g) now holds S[query myq][key0 + 4g + r], r = 0..3
+      const int kbase = key0 + 4 * g;
+      bool dead[4];
+      if (use_mask) {
+        if (lk4 && kbase + 3 < key_hi) {
+          const unsigned mw = *reinterpret_cast<const unsigned *>(mrow + kbase);
 #pragma unroll
-      for (int t = 0; t < NG; ++t) sc[t] = dvis_f4{0.f, 0.f, 0.f, 0.f};
+          for (int r = 0; r < 4; ++r) dead[r] = ((mw >> (8 * r)) & 0xffu) != 0;
+        } else {
 #pragma unroll
-      for (int c = 0; c < DQ / 4; ++c) {
-        float4 kk[NG];
+          for (int r = 0; r < 4; ++r) dead[r] = kbase + r >= key_hi || mrow[kbase + r] != 0;
+        }
+      } else {
 #pragma unroll
-        for (int t = 0; t < NG; ++t)
-          kk[t] = *reinterpret_cast<const float4 *>(&k_lds[((kg + t) * 16 + j) * LS + g * DQ + 4 * c]);
-#pragma unroll
-        for (int t = 0; t < NG; ++t) sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[t].x, qf[4 * c], sc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NG; ++t) sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[t].y, qf[4 * c + 1], sc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NG; ++t) sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[t].z, qf[4 * c + 2], sc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NG; ++t) sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk[t].w, qf[4 * c + 3], sc[t], 0, 0, 0);
+        for (int r = 0; r < 4; ++r) dead[r] = kbase + r >= key_hi;
       }
-      // lane (j, g) now holds S[query myq][key0 + 16 t + 4g + r], r = 0..3
-      bool dead[NG][4];
-#pragma unroll
-      for (int t = 0; t < NG; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          dead[t][r] = kbase0 + 16 * t + r >= key_hi || (use_mask && ((mw[t] >> (8 * r)) & 0xffu) != 0);
       float tmax = -INFINITY;
 #pragma unroll
-      for (int t = 0; t < NG; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) tmax = dead[t][r] ? tmax : fmaxf(tmax, sc[t][r]);
+      for (int r = 0; r < 4; ++r) tmax = dead[r] ? tmax : fmaxf(tmax, s[r]);
       tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
       const float m_new = fmaxf(m_run, tmax);
       const float alpha = (m_new == -INFINITY) ? 1.f : expf(m_run - m_new);   // exp(-inf) = 0 on first live tile
-      float p[NG][4], psum = 0.f;
+      float p[4], psum = 0.f;
 #pragma unroll
-      for (int t = 0; t < NG; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          p[t][r] = dead[t][r] ? 0.f : expf(sc[t][r] - m_new);
-          psum += p[t][r];
-        }
+      for (int r = 0; r < 4; ++r) {
+        p[r] = dead[r] ? 0.f : expf(s[r] - m_new);
+        psum += p[r];
+      }
       l_part = l_part * alpha + psum;
       m_run = m_new;
       // rescale O rows: row (4g + r) of the accumulator belongs to query q0 + 4g + r, whose alpha lives in lane 4g + r
@@ -238,18 +214,12 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(
 #pragma unroll
         for (int n = 0; n < NT; ++n) o[n] = o[n] * av;
       }
-      // ---- O += P V : A = P (already in A layout), B = V rows key0 + 16 t + 4g + r
+      // ---- O += P V : A = P (already in A layout), B = V rows key0 + 4g + r
 #pragma unroll
-      for (int t = 0; t < NG; ++t) {
-        float vv[4][NT];
+      for (int r = 0; r < 4; ++r) {
+        const float *vrow = &v_lds[(kt * 16 + 4 * g + r) * LS + j];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int n = 0; n < NT; ++n) vv[r][n] = v_lds[((kg + t) * 16 + 4 * g + r) * LS + j + 16 * n];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int n = 0; n < NT; ++n) o[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[t][r], vv[r][n], o[n], 0, 0, 0);
+        for (int n = 0; n < NT; ++n) o[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[r], vrow[16 * n], o[n], 0, 0, 0);
       }
     }
   }
@@ -527,20 +497,9 @@ DVIS_EXPORT int dvis_attention_forward(const float *q, const int64_t *q_strides,
                          heads, Lq, Lk, scale);
     return dvis_check_launch("attn_short_kernel");
   }
-  // key tiles per softmax group (development knob DVIS_ATTN_NG = 1 | 2 | 4)
-  static const int ng = [] { const char *e = getenv("DVIS_ATTN_NG"); return e ? atoi(e) : 1; }();
-#define DVIS_ATTN(DH_, SHORT_)                                                                                               \
-  do {                                                                                                                       \
-    if (ng == 4)                                                                                                             \
-      hipLaunchKernelGGL((attn_fwd_kernel<DH_, SHORT_, 4>), grid, block, 0, st, q, qs, k, ks, v, vs, out, os, mask,          \
-                         allowed_count, heads, Lq, Lk, scale, p.nsplit, p.keys_per_split, ws_o, ws_ml);                      \
-    else if (ng == 2)                                                                                                        \
-      hipLaunchKernelGGL((attn_fwd_kernel<DH_, SHORT_, 2>), grid, block, 0, st, q, qs, k, ks, v, vs, out, os, mask,          \
-                         allowed_count, heads, Lq, Lk, scale, p.nsplit, p.keys_per_split, ws_o, ws_ml);                      \
-    else                                                                                                                     \
-      hipLaunchKernelGGL((attn_fwd_kernel<DH_, SHORT_, 1>), grid, block, 0, st, q, qs, k, ks, v, vs, out, os, mask,          \
-                         allowed_count, heads, Lq, Lk, scale, p.nsplit, p.keys_per_split, ws_o, ws_ml);                      \
-  } while (0)
+  #define DVIS_ATTN(DH_, SHORT_)                                                                                     \
+  hipLaunchKernelGGL((attn_fwd_kernel<DH_, SHORT_>), grid, block, 0, st, q, qs, k, ks, v, vs, out, os, mask, allowed_count, \
+                     heads, Lq, Lk, scale, p.nsplit, p.keys_per_split, ws_o, ws_ml)
   const bool shrt = Lk <= 128 && p.nsplit == 1;
   if (d == 32 && shrt) DVIS_ATTN(32, true);
   else if (d == 32) DVIS_ATTN(32, false);

@@ -522,9 +522,8 @@ def conv1x1(x, weight, bias=None):
         # whenever the 2-D operand is a Parameter that requires grad, even under no_grad
         y = torch.bmm(weight.detach().view(1, Co, Ci).expand(N, Co, Ci), x.view(N, Ci, H * W)).view(N, Co, H, W)
         return y if bias is None else bias_act_(y, bias.detach(), None, relu=False)   # in place, at the HBM stream rate
-    if x.is_cuda and Ci >= Co:
-        _torch_path("conv1x1", x, "the batched-GEMM form needs a contiguous 4-D input of the weight's dtype")
-    return torch.nn.functional.conv2d(x, weight, bias)      # channel-expanding: MIOpen is the faster library call
+    # channel-expanding, strided (e.g. channels-last) or autograd inputs: MIOpen — a library call either way
+    return torch.nn.functional.conv2d(x, weight, bias)
 
 
 def bias_act_(x, bias=None, res=None, relu=True):

@@ -436,7 +436,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 out.append(tokens[-1].transpose(1, 2).reshape(bs, -1, h, w))      # a strided view, no copy
                 start += h * w
             for idx, f in enumerate(self.in_features[:self.num_fpn_levels][::-1]):
-                x = features[f].float()
+                x = features[f].float().contiguous()      # NCHW for the fused FPN path (no-op for the R50's maps)
                 cur_fpn, affine = self.lateral_convs[idx].conv_and_affine(x)    # GroupNorm applied inside upsample_add
                 out.append(self.output_convs[idx](Fn.upsample_add(cur_fpn, out[-1], affine)))
             multi_scale_features = TokenMaps(out[:self.maskformer_num_feature_levels])
