@@ -1,5 +1,5 @@
-"""profiles/<tag>_pmc.txt (tools/prof.sh) -> profiles/r01_msda_traffic.json: HBM bytes per launch of the MSDA forward.
-    python tools/traffic_json.py profiles/r01_bench_pmc.txt profiles/r01_msda_traffic.json [frames_per_launch]
+"""profiles/<tag>_pmc.txt (tools/prof.sh) -> profiles/rNN_msda_traffic.json: HBM bytes per launch of the MSDA forward.
+    python tools/traffic_json.py profiles/r02_bench_pmc.txt profiles/r02_msda_traffic.json [frames_per_launch]
 HBM bytes = 2 * FETCH_SIZE + WRITE_SIZE (KB counters): on gfx950 FETCH_SIZE counts 64 B per 128-byte request for the
 16 B/lane reads this kernel issues (MI355X_MICROARCH.md, HBM / rocprofv3 section); WRITE_SIZE is used as reported."""
 import json
@@ -8,17 +8,20 @@ import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 frames = int(sys.argv[3]) if len(sys.argv) > 3 else 30
-vals, name, disp, cur = {}, None, 0, None
-for line in open(src):
+lines = open(src).read().split("\n")
+# pass 1: the MSDA forward kernel with the most dispatches (the fused fp32 form of the pixel decoder)
+name, disp = None, 0
+for line in lines:
+    m = re.match(r"(msda_fwd_tile\w*<.*>)\s+dispatches=(\d+)", line)
+    if m and int(m.group(2)) > disp:
+        name, disp = m.group(1), int(m.group(2))
+# pass 2: its counters (one block per PMC group)
+vals, on = {}, False
+for line in lines:
     if not line.startswith(" "):
-        cur = line.strip()
-        m = re.match(r"(msda_fwd_tile_f32<[^>]*>)\s+dispatches=(\d+)", cur)
-        if m:
-            name, disp = m.group(1), int(m.group(2))
-        else:
-            cur = None if not cur.startswith("msda_fwd_tile_f32") else cur
+        on = name is not None and line.startswith(name)
         continue
-    if cur and cur.startswith("msda_fwd_tile_f32"):
+    if on:
         m = re.match(r"\s+(\S+)\s+mean=(\S+)", line)
         if m:
             vals[m.group(1)] = float(m.group(2))
