@@ -19,12 +19,19 @@
 //   * mask: uint8 (1 = blocked), ONE copy per frame shared by all heads (the reference repeats it 8x);
 //     a row whose allowed_count is 0 ignores the mask = the reference's "fully masked row" reset (…:297), done
 //     on the device without the torch.where host sync.
-//   * v_mfma_f32_16x16x4_f32 = fp32 fma chain, online softmax in fp32 with expf: parity well inside 1e-3.
+//   * v_mfma_f32_16x16x4_f32 = fp32 fma chain, online softmax in fp32 (base 2, v_exp_f32): parity well inside 1e-3.
 #include <math.h>
 
 #include "dvis_common.h"
 
 namespace {
+
+// The softmax runs in base 2: q is pre-scaled by scale * log2(e), so exp(s - m) is ONE v_exp_f32 (a quarter-rate
+// transcendental) per score instead of expf's range reduction around it — the VALU work per 16 x 16 score tile was
+// 154 instructions against 16 MFMAs (PMC, decoder cross-attention), i.e. as many issue cycles as the matrix work.
+// Row statistics (m, and the combine kernel's weights) live in the same base-2 units; the normalised output does not care.
+constexpr float kLog2e = 1.4426950408889634f;
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 constexpr int kKT = 64;   // keys per LDS stage
 
@@ -88,10 +95,10 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(
 #pragma unroll
     for (int c = 0; c < DQ / 4; ++c) {
       const float4 t = *reinterpret_cast<const float4 *>(qrow + 4 * c);
-      qf[4 * c] = q_ok ? t.x * scale : 0.f;
-      qf[4 * c + 1] = q_ok ? t.y * scale : 0.f;
-      qf[4 * c + 2] = q_ok ? t.z * scale : 0.f;
-      qf[4 * c + 3] = q_ok ? t.w * scale : 0.f;
+      qf[4 * c] = q_ok ? t.x * (scale * kLog2e) : 0.f;
+      qf[4 * c + 1] = q_ok ? t.y * (scale * kLog2e) : 0.f;
+      qf[4 * c + 2] = q_ok ? t.z * (scale * kLog2e) : 0.f;
+      qf[4 * c + 3] = q_ok ? t.w * (scale * kLog2e) : 0.f;
     }
   }
   const int mb = bi;
@@ -198,11 +205,14 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(
       tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
       const float m_new = fmaxf(m_run, tmax);
-      const float alpha = (m_new == -INFINITY) ? 1.f : expf(m_run - m_new);   // exp(-inf) = 0 on first live tile
+      // alpha = 2^(m_run - m_new): 1 unless this tile raised the row maximum (rare after the first tiles) — the
+      // transcendental is only issued when some lane needs it (wave-uniform branch)
+      float alpha = 1.f;
+      if (!__all(m_new == m_run)) alpha = (m_new == -INFINITY) ? 1.f : ex2(m_run - m_new);
       float p[4], psum = 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        p[r] = dead[r] ? 0.f : expf(s[r] - m_new);
+        p[r] = dead[r] ? 0.f : ex2(s[r] - m_new);
         psum += p[r];
       }
       l_part = l_part * alpha + psum;
@@ -298,10 +308,10 @@ __global__ __launch_bounds__(256) void attn_short_kernel(
 #pragma unroll
     for (int c = 0; c < DQ / 4; ++c) {
       const float4 t = *reinterpret_cast<const float4 *>(qrow + 4 * c);
-      qf[4 * c] = q_ok ? t.x * scale : 0.f;
-      qf[4 * c + 1] = q_ok ? t.y * scale : 0.f;
-      qf[4 * c + 2] = q_ok ? t.z * scale : 0.f;
-      qf[4 * c + 3] = q_ok ? t.w * scale : 0.f;
+      qf[4 * c] = q_ok ? t.x * (scale * kLog2e) : 0.f;
+      qf[4 * c + 1] = q_ok ? t.y * (scale * kLog2e) : 0.f;
+      qf[4 * c + 2] = q_ok ? t.z * (scale * kLog2e) : 0.f;
+      qf[4 * c + 3] = q_ok ? t.w * (scale * kLog2e) : 0.f;
     }
   }
   const float *kb = k + (size_t)bi * ks_.b + (size_t)hi * ks_.h;
@@ -360,7 +370,7 @@ __global__ __launch_bounds__(256) void attn_short_kernel(
   for (int t = 0; t < NKT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float pr = dead[t][r] ? 0.f : expf(sa[t][r] - tmax);
+      const float pr = dead[t][r] ? 0.f : ex2(sa[t][r] - tmax);
       sa[t][r] = pr;
       lsum += pr;
     }
@@ -399,10 +409,10 @@ __global__ __launch_bounds__(256) void attn_short_kernel(
 #pragma unroll
     for (int w2 = 0; w2 < 4; ++w2) {
       const float mw = ml_lds[(w2 * 16 + jq) * 2];
-      L += (mw == -INFINITY) ? 0.f : ml_lds[(w2 * 16 + jq) * 2 + 1] * expf(mw - M);
+      L += (mw == -INFINITY) ? 0.f : ml_lds[(w2 * 16 + jq) * 2 + 1] * ex2(mw - M);
     }
     const float mine = ml_lds[(wv * 16 + jq) * 2];
-    wgt[r] = (mine == -INFINITY) ? 0.f : expf(mine - M);
+    wgt[r] = (mine == -INFINITY) ? 0.f : ex2(mine - M);
     inv[r] = L > 0.f ? 1.f / L : 0.f;
   }
 #pragma unroll
@@ -444,7 +454,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restri
   for (int s = 0; s < nsplit; ++s) {
     const size_t row = (bh * nsplit + s) * Lq + qq;
     const float ms = ws_ml[row * 2];
-    const float wgt = (ms == -INFINITY) ? 0.f : expf(ms - M);
+    const float wgt = (ms == -INFINITY) ? 0.f : ex2(ms - M);
     num += ws_o[row * DH + d] * wgt;
     den += ws_ml[row * 2 + 1] * wgt;
   }
