@@ -29,11 +29,14 @@
 
 namespace {
 
-constexpr int kKC = 64;         // channels per LDS stage (16 k-steps x 4 lane groups)
+#ifndef DVIS_MASK_KC
+#define DVIS_MASK_KC 128
+#endif
+constexpr int kKC = DVIS_MASK_KC;   // channels per LDS stage (k-steps x 4 lane groups)
 constexpr int kU = kKC / 4;     // k-steps per stage
 constexpr int kNPix = 128;      // source pixels per stage = 8 MFMA pixel tiles
 constexpr int kLStride = 144;   // floats per LDS row: rows of lane groups 0/1 land in different bank halves
-constexpr int kMaxStages = 4;   // C <= 256
+constexpr int kMaxStages = 256 / kKC;   // C <= 256
 constexpr size_t kLdsBytes = 2 * kKC * kLStride * sizeof(float);   // two stage buffers
 
 // Lane exchanges of the MODE 1 epilogue as DPP modifiers (VALU, no LDS round trip): __shfl_xor compiled to 64
