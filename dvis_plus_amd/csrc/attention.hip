@@ -183,25 +183,30 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(
           s = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.w, qf[4 * c + 3], s, 0, 0, 0);
         }
       }
-      // lane (j, g) now holds S[query myq][key0 + 4g + r], r = 0..3
+      // lane (j, g) now holds S[query myq][key0 + 4g + r], r = 0..3.  Dead keys (masked, or past the split's end) are
+      // set to -inf ONCE, branch-free for the common full tile; 2^(-inf - m) is exactly 0, so the probabilities need no
+      // second select.  (Uniform branches only: `mask`, the tail tile.)
       const int kbase = key0 + 4 * g;
-      bool dead[4];
-      if (use_mask) {
-        if (lk4 && kbase + 3 < key_hi) {
-          const unsigned mw = *reinterpret_cast<const unsigned *>(mrow + kbase);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) dead[r] = ((mw >> (8 * r)) & 0xffu) != 0;
+      float sv[4] = {s[0], s[1], s[2], s[3]};
+      const bool full = key0 + 16 <= key_hi;                  // wave-uniform
+      if (mask != nullptr) {                                  // wave-uniform
+        unsigned mw;
+        if (lk4 && full) {
+          mw = *reinterpret_cast<const unsigned *>(mrow + kbase);
         } else {
+          mw = 0;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) dead[r] = kbase + r >= key_hi || mrow[kbase + r] != 0;
+          for (int r = 0; r < 4; ++r) mw |= (kbase + r < key_hi && mrow[kbase + r] != 0) ? (0xffu << (8 * r)) : 0u;
         }
-      } else {
+        mw = use_mask ? mw : 0u;                              // rows that ignore the mask (allowed_count == 0)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dead[r] = kbase + r >= key_hi;
+        for (int r = 0; r < 4; ++r) sv[r] = (mw & (0xffu << (8 * r))) ? -INFINITY : sv[r];
       }
-      float tmax = -INFINITY;
+      if (!full) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tmax = dead[r] ? tmax : fmaxf(tmax, s[r]);
+        for (int r = 0; r < 4; ++r) sv[r] = kbase + r >= key_hi ? -INFINITY : sv[r];
+      }
+      float tmax = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
       tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
       const float m_new = fmaxf(m_run, tmax);
@@ -209,10 +214,11 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(
       // transcendental is only issued when some lane needs it (wave-uniform branch)
       float alpha = 1.f;
       if (!__all(m_new == m_run)) alpha = (m_new == -INFINITY) ? 1.f : ex2(m_run - m_new);
+      const float m_sub = (m_new == -INFINITY) ? 0.f : m_new;   // no live key yet: -inf - 0 = -inf, not NaN
       float p[4], psum = 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        p[r] = dead[r] ? 0.f : ex2(s[r] - m_new);
+        p[r] = ex2(sv[r] - m_sub);
         psum += p[r];
       }
       l_part = l_part * alpha + psum;
