@@ -97,6 +97,26 @@ def test_gradcheck_like_reference():
         assert torch.autograd.gradcheck(_fn().apply, (value, s.to(DEV), lsi.to(DEV), loc, w, 2))
 
 
+@pytest.mark.parametrize("D", [1025, 2048, 3096])
+def test_gradcheck_large_head_dims_like_reference(D):
+    """ops/test.py:88-89 also runs D = 1025, 2048, 3096 (the reference needs a dedicated multi-block backward kernel
+    there, ms_deform_im2col_cuda.cuh:736-848; here one kernel serves every D).  gradcheck in fast mode (random
+    projections of the Jacobian: the full one would be 185 k x 12 k doubles), plus the analytic gradients against the C
+    oracle's backward."""
+    shapes = [(6, 4), (3, 2)]
+    value, s, lsi, loc, w = make_msda_inputs(1, 2, D, shapes, 2, 2, torch.float64, seed=D, spread=1.0)
+    v = (value * 0.01).to(DEV).requires_grad_(True)
+    l_, w_ = loc.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    assert torch.autograd.gradcheck(_fn().apply, (v, s.to(DEV), lsi.to(DEV), l_, w_, 2), fast_mode=True)
+    out = _fn().apply(v, s.to(DEV), lsi.to(DEV), l_, w_, 2)
+    g = torch.randn(out.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(D))
+    out.backward(g.to(DEV))
+    gv, gl, gw = omsda.msda_backward(value * 0.01, s, lsi, loc, w, g.numpy())
+    torch.testing.assert_close(v.grad.cpu(), torch.from_numpy(gv), rtol=1e-9, atol=1e-12)
+    torch.testing.assert_close(l_.grad.cpu(), torch.from_numpy(gl), rtol=1e-9, atol=1e-12)
+    torch.testing.assert_close(w_.grad.cpu(), torch.from_numpy(gw), rtol=1e-9, atol=1e-12)
+
+
 def test_production_frame_720p_vs_oracle():
     """BASELINE config shapes: one 736x1280 frame, S = Lq = 19320, M=8, D=32, L=3, P=4 (fp32)."""
     shapes = [(23, 40), (46, 80), (92, 160)]
