@@ -26,7 +26,7 @@ def t(fn, n=10):
 
 
 ref = None
-for path in sorted(glob.glob(os.path.join(HERE, "libmask_*.so"))):
+for path in sorted(glob.glob(os.path.join(HERE, "libmask_*.so")), key=lambda q: (0 if "base" in q else 1, q)):
     lib = ctypes.CDLL(path)
     lib.dvis_attn_mask.restype = lib.dvis_mask_logits.restype = ctypes.c_int
     line = os.path.basename(path).ljust(24)
@@ -45,5 +45,7 @@ for path in sorted(glob.glob(os.path.join(HERE, "libmask_*.so"))):
     outs.append(out.clone())
     if ref is None:
         ref = outs
-    same = all(torch.equal(a, b) for a, b in zip(outs, ref))
-    print(line, " same as base:", same)
+    same = [bool(torch.equal(a, b)) for a, b in zip(outs, ref)]
+    diff = float((outs[3] - ref[3]).abs().max())
+    nm = [int((a != b).sum()) for a, b in zip(outs[:3], ref[:3])]
+    print(line, " same as first:", same, "differing mask bytes", nm, "max|logit diff|", diff)
