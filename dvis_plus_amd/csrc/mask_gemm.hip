@@ -110,17 +110,8 @@ __global__ __launch_bounds__(512) void mask_gemm_kernel(
       const int c = (r & 3) * CQ + kU * t + (r >> 2);
       const bool cv = (c < C) & ((r >> 2) + kU * t < CQ);
       const unsigned off = (unsigned)c * chan_bytes + src * 4u;
-#ifdef DVIS_MASK_B64
-      if (MODE == 1 || true) {
-        typedef unsigned v2u __attribute__((ext_vector_type(2)));
-        const v2u pr = __builtin_amdgcn_raw_buffer_load_b64(rs, (cv & ok0) ? off : kOOB, 0, 0);
-        pre0[i] = __builtin_bit_cast(float, pr.x);
-        pre1[i] = (cv & ok1) ? __builtin_bit_cast(float, pr.y) : 0.f;
-      }
-#else
       pre0[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (cv & ok0) ? off : kOOB, 0, 0));
       pre1[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (cv & ok1) ? off + 4u : kOOB, 0, 0));
-#endif
     }
   };
   auto stage_store = [&](int buf) {
@@ -175,18 +166,14 @@ __global__ __launch_bounds__(512) void mask_gemm_kernel(
 #pragma unroll
               for (int pt = 0; pt < 8; ++pt) bv[(u + 1) & 1][pt] = cur[((u + 1) * 4 + g) * kLStride + pt * 16 + j];
             }
-#ifndef DVIS_MASK_NOSCHED
             __builtin_amdgcn_sched_barrier(0);   // keep the reads above this k-step's MFMAs (the scheduler sinks them)
-#endif
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
               for (int pt = 0; pt < 8; ++pt)
                 acc[qt][pt] =
                     __builtin_amdgcn_mfma_f32_16x16x4f32(efrag[qt][t * kU + u], bv[u & 1][pt], acc[qt][pt], 0, 0, 0);
-#ifndef DVIS_MASK_NOSCHED
             __builtin_amdgcn_sched_barrier(0);
-#endif
           }
         }
         // ... and park it in the other buffer (last read one stage ago, before the previous barrier)

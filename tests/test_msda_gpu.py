@@ -107,7 +107,8 @@ def test_gradcheck_large_head_dims_like_reference(D):
     value, s, lsi, loc, w = make_msda_inputs(1, 2, D, shapes, 2, 2, torch.float64, seed=D, spread=1.0)
     v = (value * 0.01).to(DEV).requires_grad_(True)
     l_, w_ = loc.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
-    assert torch.autograd.gradcheck(_fn().apply, (v, s.to(DEV), lsi.to(DEV), l_, w_, 2), fast_mode=True)
+    # (grad_value is accumulated with atomics: two backward runs differ in the last fp64 bits)
+    assert torch.autograd.gradcheck(_fn().apply, (v, s.to(DEV), lsi.to(DEV), l_, w_, 2), fast_mode=True, nondet_tol=1e-10)
     out = _fn().apply(v, s.to(DEV), lsi.to(DEV), l_, w_, 2)
     g = torch.randn(out.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(D))
     out.backward(g.to(DEV))
