@@ -65,16 +65,21 @@ def test_vit_adapter_gpu_matches_reference():
         torch.testing.assert_close(got.cpu(), g.outs[k], rtol=5e-4, atol=1e-4)
 
 
-def _vit_pipeline(device):
-    """DVIS++ offline with the ViT-Adapter-B backbone (BASELINE config #5's family: ViT-Adapter + 200 queries; ViT-B so
-    that the CPU oracle stays light), small frames.  Both sides run their OWN backbone: the ViT-Adapter is vendored by the
-    reference, so its parity is pinned (g8) and the pipeline is compared from the pixels onward."""
+VIT = {"vitb": dict(heads=12, deform_heads=12, interaction_indexes=[[0, 2], [3, 5], [6, 8], [9, 11]]),
+       "vitl": dict(heads=16, deform_heads=16, interaction_indexes=[[0, 5], [6, 11], [12, 17], [18, 23]])}
+
+
+def _vit_pipeline(device, size="vitb", hw=(128, 192), T=4, full=False):
+    """DVIS++ offline with a ViT-Adapter backbone (BASELINE config #5's family: ViT-Adapter + 200 queries).  Both sides run
+    their OWN backbone: the ViT-Adapter is vendored by the reference, so its parity is pinned (g8) and the pipeline is
+    compared from the pixels onward.  full=True: the layer counts of the reference's yaml (6 / 9 / 6 / 6)."""
     from dvis_plus_amd.meta_architecture import build_dvis_plus
     from oracle import dvis_torch as O
     from oracle import vit_adapter_torch as OV
     import pipeline_parity as PPar
-    cfg = dict(num_classes=20, n_things=10, enc_layers=2, tracker_layers=2, refiner_layers=2)
-    m = build_dvis_plus("offline", task="vis", backbone="vitb", num_queries=200, dec_layers=4, max_num=10, **cfg)
+    cfg = dict(num_classes=124, n_things=58) if full else \
+        dict(num_classes=20, n_things=10, enc_layers=2, tracker_layers=2, refiner_layers=2)
+    m = build_dvis_plus("offline", task="vis", backbone=size, num_queries=200, dec_layers=10 if full else 4, max_num=10, **cfg)
     PPar.perturb_msda(m.sem_seg_head.pixel_decoder)
     PPar.sharpen_masks(m, 40.0)
     with torch.no_grad():                                # LayerScale 1e-5 would switch the ViT blocks off
@@ -82,20 +87,19 @@ def _vit_pipeline(device):
             if name.endswith("ls1.gamma") or name.endswith("ls2.gamma"):
                 p.fill_(0.3)
     g = torch.Generator().manual_seed(8)
-    frames = [torch.randint(0, 256, (3, 128, 192), dtype=torch.uint8, generator=g) for _ in range(4)]
+    frames = [torch.randint(0, 256, (3, *hw), dtype=torch.uint8, generator=g) for _ in range(T)]
     sd = PPar.cpu_state(m)
     bsd = {k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")}
 
     def oracle_backbone(images):
-        f = OV.vit_adapter_forward(bsd, images, heads=12, deform_heads=12,
-                                   interaction_indexes=[[0, 2], [3, 5], [6, 8], [9, 11]])
+        f = OV.vit_adapter_forward(bsd, images, **VIT[size])
         return dict(zip(("res2", "res3", "res4", "res5"), f))
     m = m.to(device)
-    out = m([{"image": [f.to(device) for f in frames], "height": 128, "width": 192}])
+    out = m([{"image": [f.to(device) for f in frames], "height": hw[0], "width": hw[1]}])
     stages = {}
     with torch.no_grad():
-        ref = O.dvis_plus_forward(sd, oracle_backbone, frames, offline=True, task="vis", nheads=8, dec_layers=3,
-                                  max_num=10, stages=stages, **cfg)
+        ref = O.dvis_plus_forward(sd, oracle_backbone, frames, offline=True, task="vis", nheads=8,
+                                  dec_layers=9 if full else 3, max_num=10, stages=stages, **cfg)
     return out, ref, stages, PPar
 
 
@@ -110,3 +114,14 @@ def test_vit_adapter_pipeline_gpu_vs_oracle():
     segmenter with 200 queries, tracker, refiner, instance masks — vs the CPU oracle running its own ViT-Adapter."""
     out, ref, stages, PPar = _vit_pipeline("cuda:0")
     PPar.compare_vis(out, ref, stages, "DVIS++ offline ViT-Adapter-B 200 queries, 4 x 128 x 192")
+
+
+@pytest.mark.gpu
+def test_vitl_720p_full_configuration_vs_oracle():
+    """BASELINE config #5 at full size on one GPU: DINOv2 ViT-L + ViT-Adapter (24 blocks, 16 heads of 64, extractor
+    MSDeformAttn with D = 64, L = 1, P = 4 on 3 681 x 19 320 tokens), 200 queries, 6 / 9 / 6 / 6 layers, 720p frames — two
+    frames (one window of the reference's loop) so that the CPU oracle's ViT-L stays affordable."""
+    out, ref, stages, PPar = _vit_pipeline("cuda:0", size="vitl", hw=(720, 1280), T=2, full=True)
+    assert out["pred_masks"].shape == (10, 2, 720, 1280)
+    tol = PPar.logit_tolerance(float(stages["masks"].abs().max()))
+    PPar.compare_vis(out, ref, stages, "config #5 ViT-Adapter-L, 200 queries, 2 x 720p, full layer counts", tol=tol)
