@@ -166,23 +166,41 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(
     __syncthreads();
     if (!SHORT && ks + KT < key_hi) prefetch(ks + KT);
     if (!wave_on) continue;
+    // Software pipeline over the key tiles of the stage: the score MFMAs of tile kt + 1 are ISSUED before the softmax
+    // VALU work of tile kt, so the matrix pipe executes them in the shadow of that VALU work (an MFMA is asynchronous;
+    // independent VALU instructions of the same wave issue while it runs).  VALU and MFMA of one wave did not overlap at
+    // all before: PMC showed their busy cycles adding up to the kernel time.
+    auto score_tile = [&](int kt) -> dvis_f4 {     // S^T tile: rows = 16 keys, cols = 16 queries
+      dvis_f4 sc = dvis_f4{0.f, 0.f, 0.f, 0.f};
+      const float *krow = &k_lds[(kt * 16 + j) * LS + g * DQ];
+#pragma unroll
+      for (int c = 0; c < DQ / 4; ++c) {
+        const float4 kk = *reinterpret_cast<const float4 *>(krow + 4 * c);
+        sc = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.x, qf[4 * c], sc, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.y, qf[4 * c + 1], sc, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.z, qf[4 * c + 2], sc, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.w, qf[4 * c + 3], sc, 0, 0, 0);
+      }
+      return sc;
+    };
+    // mask bytes of this lane's 4 keys of a FULL tile (one dword), fetched one tile ahead like the scores
+    auto mask_word = [&](int kt) -> unsigned {
+      const int k0 = ks + kt * 16;
+      return (mask != nullptr && lk4 && k0 + 16 <= key_hi) ? *reinterpret_cast<const unsigned *>(mrow + k0 + 4 * g) : 0u;
+    };
+    dvis_f4 s_next = score_tile(0);
+    unsigned mw_next = mask_word(0);
 #pragma unroll 1
     for (int kt = 0; kt < KT / 16; ++kt) {
       const int key0 = ks + kt * 16;
       if (key0 >= key_hi) break;   // uniform
-      // ---- S^T tile: rows = 16 keys, cols = 16 queries
-      dvis_f4 s = dvis_f4{0.f, 0.f, 0.f, 0.f};
-      {
-        const float *krow = &k_lds[(kt * 16 + j) * LS + g * DQ];
-#pragma unroll
-        for (int c = 0; c < DQ / 4; ++c) {
-          const float4 kk = *reinterpret_cast<const float4 *>(krow + 4 * c);
-          s = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.x, qf[4 * c], s, 0, 0, 0);
-          s = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.y, qf[4 * c + 1], s, 0, 0, 0);
-          s = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.z, qf[4 * c + 2], s, 0, 0, 0);
-          s = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.w, qf[4 * c + 3], s, 0, 0, 0);
-        }
+      const dvis_f4 s = s_next;
+      const unsigned mw_cur = mw_next;
+      if (kt + 1 < KT / 16 && key0 + 16 < key_hi) {      // uniform; in flight under the softmax below
+        s_next = score_tile(kt + 1);
+        mw_next = mask_word(kt + 1);
       }
+      __builtin_amdgcn_sched_barrier(0);
       // lane (j, g) now holds S[query myq][key0 + 4g + r], r = 0..3.  Dead keys (masked, or past the split's end) are
       // set to -inf ONCE, branch-free for the common full tile; 2^(-inf - m) is exactly 0, so the probabilities need no
       // second select.  (Uniform branches only: `mask`, the tail tile.)
@@ -192,7 +210,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(
       if (mask != nullptr) {                                  // wave-uniform
         unsigned mw;
         if (lk4 && full) {
-          mw = *reinterpret_cast<const unsigned *>(mrow + kbase);
+          mw = mw_cur;
         } else {
           mw = 0;
 #pragma unroll
