@@ -16,243 +16,290 @@
 //     by ~1e-5 between any two fp32 summation orders, so such pixels are ambiguous in the reference too).
 //   * v_mfma_f32_16x16x4_f32 is a k-ordered fp32 fma chain: no reduced precision.
 //
-// Tiling: a wave owns 16 queries (A operand = its 16 x C slice of mask_embed, resident in VGPRs for the whole
-// block) and streams 16-pixel tiles; 8 waves = up to 128 queries per pass.  The B operand (features) is staged
-// through LDS in 64-channel x 128-pixel stages, double-buffered (2 x 36 KB of dynamic LDS): the next stage (of this or of the next tile) is
-// fetched into registers at the top of the current stage's MFMAs and written to the other buffer behind them, so a
-// stage costs ONE barrier and the MFMA queue only drains there (the single-buffered form — write, barrier, MFMAs,
-// barrier, at one workgroup per CU — ran at twice its MFMA time).  The K index is permuted — lane group g of the MFMA sums channels [g*CQ, (g+1)*CQ) — so each lane's
-// A-slice is one contiguous run of mask_embed.
-// For MODE 1 a 16-pixel tile is 2 centre rows x (4 outputs x 2 centre columns), so the 4 addends of an output
-// sit in lanes j, j^1, j^8 of the accumulator layout and are combined with two wave shuffles.
+// Partition (round 2): by PIXELS, not by queries.  A wave owns 64 source pixels (four 16-column MFMA tiles) and ALL
+// query tiles of the pass (QT <= 7 tiles of 16 = 112 queries): 28 accumulators.  Its B operand (features) is needed by
+// no other wave, so it goes from global memory straight into the MFMA operand layout — lane (j, g) loads the 4 pixels
+// 4j..4j+3 of channel g*CQ + u as one 16-byte word, 16 lanes = 256 contiguous bytes — with no LDS staging and no
+// barrier in the main loop; the A operand (mask_embed of the frame, 112 x 256 floats) sits in LDS for the whole
+// workgroup, laid out [lane group][query][64 + 4] so that the 16-byte fragment reads of a 16-lane group cover all 64
+// banks.  The first form partitioned by queries (8 waves x 16 queries, A in VGPRs, B staged through LDS for all of
+// them): at 100 queries one wave in eight idled and 100 of 112 issued rows were useful, and every stage cost a barrier
+// (DESIGN.md section 3.3 keeps its numbers).  The K index is permuted — lane group g of the MFMA sums channels
+// [g*CQ, (g+1)*CQ) — so an A fragment is one contiguous run of mask_embed.
+// For MODE 1 lane j owns output pixel o0 + j and its four MFMA tiles are the addends a, b, c, d of that output: the
+// down-sizing is three in-lane adds in the reference's order, no lane exchange.
+// Work is cut into steps of 8 wave groups (one per wave) of one frame; a workgroup takes an equal, contiguous share of
+// all steps of all frames (A is reloaded when the frame changes), one workgroup per CU.
 #include "dvis_common.h"
 
 namespace {
 
-// channels per LDS stage (16 k-steps x 4 lane groups).  128-channel stages (half the barriers, 147 KB of LDS, 190 VGPRs)
-// were measured neutral: attention masks of the three levels 2087 vs 2017 us, full logits 1295 vs 1286 us.
-constexpr int kKC = 64;
-constexpr int kU = kKC / 4;     // k-steps per stage
-constexpr int kNPix = 128;      // source pixels per stage = 8 MFMA pixel tiles
-constexpr int kLStride = 144;   // floats per LDS row: rows of lane groups 0/1 land in different bank halves
-constexpr int kMaxStages = 256 / kKC;   // C <= 256
-constexpr size_t kLdsBytes = 2 * kKC * kLStride * sizeof(float);   // two stage buffers
+constexpr int kARow = 68;        // floats per LDS row of A: 64 channels + 4 (16-lane groups of b128 reads hit all banks)
+constexpr int kMaxQT = 7;        // query tiles per pass: 4 * 112 * 68 * 4 B = 119 KB of LDS
+constexpr unsigned kOOB = 0xFFFFFF00u;   // beyond any frame slab (host checks C * HW * 4 < 2^32 - 256)
 
-// Lane exchanges of the MODE 1 epilogue as DPP modifiers (VALU, no LDS round trip): __shfl_xor compiled to 64
-// ds_bpermute_b32 per tile, each followed by a full lgkmcnt wait — ~6000 clk per tile and wave with the MFMA pipe idle.
-__device__ __forceinline__ float lane_xor1(float v) {   // quad_perm [1,0,3,2]
-  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float lane_xor8(float v) {   // row_ror:8 — within a row of 16 lanes (j + 8) % 16 == j ^ 8
-  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
-}
+template <int QT> constexpr size_t lds_bytes() { return (size_t)4 * QT * 16 * kARow * sizeof(float) + QT * 16 * sizeof(int); }
 
-template <int MODE>
+// MODE 0: VEC = rows of `feat` and of the output are 16-byte aligned (HW % 4 == 0 and aligned bases) -> b128 loads/stores.
+// FULLC = C == 4 * CQ (C a multiple of 32, the production 256): no per-channel validity selects in the loop.
+template <int MODE, int QT, bool VEC, bool FULLC>
 __global__ __launch_bounds__(512) void mask_gemm_kernel(
-    const float *__restrict__ embed, const float *__restrict__ feat, int Q, int qbeg, int C, int CQ, int NS, int H, int W,
-    int h, int w, int sfac, int ntiles, int tiles_per_block, float *__restrict__ out_logits,
-    uint8_t *__restrict__ out_mask, int *__restrict__ allowed_count) {
-  extern __shared__ float lds[];
+    const float *__restrict__ embed, const float *__restrict__ feat, int Q, int qbeg, int C, int CQ, int H, int W, int h,
+    int w, int sfac, int gpf, int spf, int total_steps, float *__restrict__ out_logits, uint8_t *__restrict__ out_mask,
+    int *__restrict__ allowed_count) {
+  extern __shared__ float lds[];   // A: [4 lane groups][QT * 16 queries][kARow]
+  constexpr int ROWS = QT * 16;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
-  const int b = blockIdx.y;
   const size_t HW = (size_t)H * W;
   const int OHW = h * w;
-  const float *featb = feat + (size_t)b * C * HW;
-
-  // ---- A operand: this wave's 16 x C slice(s) of mask_embed, lane (i=j, g) holds channels [g*CQ, g*CQ + NS*16)
-  constexpr int QT = 1;   // one 16-query tile per wave; Q > 128 is covered by further launches (qbeg)
-  float efrag[QT][kMaxStages * kU];
-#pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    const int q = qbeg + (wv + 8 * qt) * 16 + j;
-    const float *erow = embed + ((size_t)b * Q + (q < Q ? q : 0)) * C;
-#pragma unroll
-    for (int k = 0; k < kMaxStages * kU; ++k) {
-      const int c = g * CQ + k;
-      efrag[qt][k] = (q < Q && k < NS * kU && c < C) ? erow[c] : 0.f;
-    }
-  }
-
-  // staging geometry: thread -> (pixel pair pp, LDS rows rbase + 8*i)
-  const int pp = tid & 63, rbase = tid >> 6;
-
-  // source pixel offset of this thread's pair (2 consecutive columns of the stage) for a tile; ok = the pair exists
-  auto tile_src = [&](int tile, bool live, unsigned &src, bool &ok0, bool &ok1) {
-    if (MODE == 0) {
-      const size_t p = (size_t)tile * kNPix + 2 * pp;
-      src = (unsigned)p;
-      ok0 = live & (p < HW);
-      ok1 = live & (p + 1 < HW);
-    } else {
-      const int pt = pp >> 3, j2 = pp & 7;
-      const int o = tile * 32 + pt * 4 + (j2 & 3);
-      const int oi = o / w, oj = o - oi * w;
-      const int y = oi * sfac + sfac / 2 - 1 + (j2 >> 2);
-      const int x = oj * sfac + sfac / 2 - 1;
-      src = (unsigned)(y * W + x);
-      ok0 = ok1 = live & (o < OHW);
-    }
-  };
-  // Buffer loads: an out-of-range offset reads 0 in hardware, so no instruction after a load depends on a predicate.
-  // (With flat loads + selects, and with the loads under uniform branches, the compiler put vmcnt(0) waits in front of
-  // the stage's MFMAs — phi copies of loaded values — and the "prefetch" only overlapped across waves.)
-  const __amdgpu_buffer_rsrc_t rs = dvis_make_rsrc_uniform(featb, (unsigned)((size_t)C * HW * sizeof(float)));
-  constexpr unsigned kOOB = 0xFFFFFF00u;   // beyond any frame slab (host checks C * HW * 4 < 2^32 - 256)
   const unsigned chan_bytes = (unsigned)(HW * sizeof(float));
-  float pre0[kKC / 8], pre1[kKC / 8];
-  auto prefetch = [&](int t, unsigned src, bool ok0, bool ok1) {
-#pragma unroll
-    for (int i = 0; i < kKC / 8; ++i) {
-      const int r = rbase + 8 * i;                 // LDS row: u = r >> 2, lane group = r & 3
-      const int c = (r & 3) * CQ + kU * t + (r >> 2);
-      const bool cv = (c < C) & ((r >> 2) + kU * t < CQ);
-      const unsigned off = (unsigned)c * chan_bytes + src * 4u;
-      pre0[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (cv & ok0) ? off : kOOB, 0, 0));
-      pre1[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (cv & ok1) ? off + 4u : kOOB, 0, 0));
+
+  const int s_lo = (int)((long long)blockIdx.x * total_steps / gridDim.x);
+  const int s_hi = (int)((long long)(blockIdx.x + 1) * total_steps / gridDim.x);
+
+  int cur_b = -1;
+  // MODE 1: allowed pixels per query row, summed in LDS over the workgroup's steps of one frame, then one global atomic
+  int *counts = reinterpret_cast<int *>(lds + 4 * ROWS * kARow);
+  if (MODE == 1 && tid < ROWS) counts[tid] = 0;
+  auto flush_counts = [&]() {   // between two barriers
+    if (MODE == 1 && cur_b >= 0 && tid < ROWS) {
+      const int q = qbeg + tid, c = counts[tid];
+      if (q < Q && c > 0) atomicAdd(&allowed_count[(size_t)cur_b * Q + q], c);
+      counts[tid] = 0;
     }
   };
-  auto stage_store = [&](int buf) {
+
+  // byte offsets of this lane's 4 B columns, lane group's first channel included; a column that does not exist gets
+  // an out-of-range offset (reads 0).  The channel of a k-step goes into the load's SCALAR offset.
+  unsigned off[4];
+  bool ok[4];
+  const unsigned gbase = (unsigned)(g * CQ) * chan_bytes;
+  auto set_columns = [&](int group) {
+    if (MODE == 0) {
 #pragma unroll
-    for (int i = 0; i < kKC / 8; ++i)
-      *reinterpret_cast<float2 *>(&lds[buf * (kKC * kLStride) + (rbase + 8 * i) * kLStride + 2 * pp]) =
-          make_float2(pre0[i], pre1[i]);
+      for (int n = 0; n < 4; ++n) {
+        const size_t p = (size_t)group * 64 + 4 * j + n;
+        ok[n] = p < HW;
+        off[n] = ok[n] ? gbase + (unsigned)(p * 4) : kOOB;
+      }
+    } else {
+      const int o = group * 16 + j;
+      const int oi = o / w, oj = o - oi * w;
+      const int y = oi * sfac + sfac / 2 - 1, x = oj * sfac + sfac / 2 - 1;
+      ok[0] = ok[1] = ok[2] = ok[3] = o < OHW;
+      const unsigned o0 = gbase + (unsigned)(y * W + x) * 4u;
+      off[0] = ok[0] ? o0 : kOOB;
+      off[1] = ok[0] ? o0 + 4u : kOOB;
+      off[2] = ok[0] ? o0 + (unsigned)W * 4u : kOOB;
+      off[3] = ok[0] ? o0 + (unsigned)W * 4u + 4u : kOOB;
+    }
   };
+  const int ulim = C - g * CQ;   // this lane group's channels are u < ulim (FULLC: all CQ of them)
+  __amdgpu_buffer_rsrc_t rs = dvis_make_rsrc_uniform(feat, 0);
+  // B fragments of 4 k-steps (channels g*CQ + u0 .. + 3): [k-step][pixel tile]
+  auto load_b = [&](int u0, dvis_f4(&dst)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned so = (unsigned)(u0 + i) * chan_bytes;   // uniform
+      const bool cv = FULLC ? true : (u0 + i < ulim);
+      if (MODE == 0 && VEC) {
+        const dvis_v4u t =
+            __builtin_bit_cast(dvis_v4u, __builtin_amdgcn_raw_buffer_load_b128(rs, cv ? off[0] : kOOB, so, 0));
+        dst[i] = __builtin_bit_cast(dvis_f4, t);
+      } else {
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          dst[i][n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cv ? off[n] : kOOB, so, 0));
+      }
+    }
+  };
+  dvis_f4 b0[4], b1[4];
+  bool have_b0 = false;   // wave-uniform: b0 already holds k-steps 0..3 of this step's group (fetched under the last
+                          // MFMAs of the previous step — otherwise both waves of a SIMD sit out the same load latency)
 
-  const int tile0 = blockIdx.x * tiles_per_block;
-  if (tile0 >= ntiles) return;   // uniform
-  const bool mine = qbeg + (wv * 16) < Q;   // this wave's q-tile holds real queries
-  unsigned src0;
-  bool ok0, ok1;
-  tile_src(tile0, true, src0, ok0, ok1);
-  prefetch(0, src0, ok0, ok1);
-  stage_store(0);
-  __syncthreads();
-  int buf = 0;
+  for (int step = s_lo; step < s_hi; ++step) {
+    const int b = step / spf, sidx = step - b * spf;
+    if (b != cur_b) {   // uniform over the workgroup
+      __syncthreads();   // everyone is done with the previous frame's A (and its counts)
+      flush_counts();
+      const int n4 = CQ >> 2, total4 = 4 * ROWS * n4;
+      for (int base = 0; base < total4; base += 4 * 512) {   // 4 granules in flight per thread
+        dvis_f4 v[4];
+        int dst[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int idx = base + k * 512 + tid;
+          const int u4 = idx % n4, rest = idx / n4;
+          const int row = rest % ROWS, gg = rest / ROWS;
+          const int q = qbeg + row, c = gg * CQ + u4 * 4;
+          const float *erow = embed + ((size_t)b * Q + (q < Q ? q : 0)) * C;
+          dst[k] = idx < total4 ? (gg * ROWS + row) * kARow + u4 * 4 : -1;
+          const bool live = idx < total4 && q < Q;
+          if (FULLC) {
+            v[k] = live ? *reinterpret_cast<const dvis_f4 *>(erow + c) : dvis_f4{0.f, 0.f, 0.f, 0.f};
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[k][i] = (live && c + i < C) ? erow[c + i] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (dst[k] >= 0) *reinterpret_cast<dvis_f4 *>(&lds[dst[k]]) = v[k];
+      }
+      __syncthreads();
+      cur_b = b;
+      rs = dvis_make_rsrc_uniform(feat + (size_t)b * C * HW, (unsigned)((size_t)C * HW * sizeof(float)));
+    }
+    const int group = sidx * 8 + wv;
+    if (group >= gpf) continue;   // wave-uniform; no barrier below (have_b0 is false: only existing groups are prefetched)
 
-  for (int tt = 0; tt < tiles_per_block; ++tt) {
-    const int tile = tile0 + tt;
-    if (tile >= ntiles) break;   // uniform
+    if (!have_b0) {
+      set_columns(group);
+      load_b(0, b0);
+    }
+    bool okc[4];   // `ok` moves on to the next group during the last k-steps
+#pragma unroll
+    for (int n = 0; n < 4; ++n) okc[n] = ok[n];
+    const float *arow = lds + (g * ROWS + j) * kARow;
+    auto load_a = [&](int u0, dvis_f4(&dst)[QT]) {
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) dst[qt] = *reinterpret_cast<const dvis_f4 *>(arow + qt * 16 * kARow + u0);
+    };
 
-    dvis_f4 acc[QT][8];
+    dvis_f4 acc[QT][4];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-      for (int pt = 0; pt < 8; ++pt) acc[qt][pt] = dvis_f4{0.f, 0.f, 0.f, 0.f};
+      for (int n = 0; n < 4; ++n) acc[qt][n] = dvis_f4{0.f, 0.f, 0.f, 0.f};
 
+    auto contract = [&](const dvis_f4(&af)[QT], const dvis_f4(&bf)[4]) {
 #pragma unroll
-    for (int t = 0; t < kMaxStages; ++t) {
-      if (t < NS) {
-        // fetch what the NEXT stage needs — the next channels of this tile or the first channels of the next tile
-        // (nothing: all offsets out of range, zeros parked in a buffer nobody reads) — always the same instructions
-        int nt = t + 1;
-        if (nt == NS) {   // uniform; integer set-up only, no load under the branch
-          nt = 0;
-          tile_src(tile + 1, (tt + 1 < tiles_per_block) & (tile + 1 < ntiles), src0, ok0, ok1);
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+            acc[qt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[qt][i], bf[i][n], acc[qt][n], 0, 0, 0);
+    };
+
+    dvis_f4 af[QT];
+    have_b0 = false;
+#pragma unroll 1
+    for (int u0 = 0; u0 < CQ; u0 += 8) {   // CQ % 8 == 0
+      load_b(u0 + 4, b1);
+      load_a(u0, af);
+      contract(af, b0);
+      if (u0 + 8 < CQ) {   // uniform
+        load_b(u0 + 8, b0);
+      } else if (step + 1 < s_hi) {
+        const int nb = (step + 1) / spf, ng = (step + 1 - nb * spf) * 8 + wv;
+        if (nb == b && ng < gpf) {   // same frame (same A, same descriptor), and the group exists
+          set_columns(ng);
+          load_b(0, b0);
+          have_b0 = true;
         }
-        prefetch(nt, src0, ok0, ok1);
-        const float *cur = lds + buf * (kKC * kLStride);
-        if (mine) {
-          // B fragments one k-step ahead: the compiler's own order was read, wait lgkmcnt(0), 2 MFMAs, read, ... — the
-          // LDS latency exposed every 64 clk of MFMA work
-          float bv[2][8];
-#pragma unroll
-          for (int pt = 0; pt < 8; ++pt) bv[0][pt] = cur[g * kLStride + pt * 16 + j];
-#pragma unroll
-          for (int u = 0; u < kU; ++u) {
-            if (u + 1 < kU) {
-#pragma unroll
-              for (int pt = 0; pt < 8; ++pt) bv[(u + 1) & 1][pt] = cur[((u + 1) * 4 + g) * kLStride + pt * 16 + j];
-            }
-            __builtin_amdgcn_sched_barrier(0);   // keep the reads above this k-step's MFMAs (the scheduler sinks them)
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-              for (int pt = 0; pt < 8; ++pt)
-                acc[qt][pt] =
-                    __builtin_amdgcn_mfma_f32_16x16x4f32(efrag[qt][t * kU + u], bv[u & 1][pt], acc[qt][pt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-        // ... and park it in the other buffer (last read one stage ago, before the previous barrier)
-        stage_store(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
       }
+      load_a(u0 + 4, af);
+      contract(af, b1);
     }
 
     // ---- epilogue.  Accumulator layout: column (pixel) = lane & 15, row (query) = (lane >> 4) * 4 + reg.
+    // Buffer stores: one 32-bit lane offset + a scalar row offset (28 64-bit row pointers would cost 56 VGPRs).
+    if (MODE == 0) {
+      const __amdgpu_buffer_rsrc_t ro =
+          dvis_make_rsrc_uniform(out_logits + (size_t)b * Q * HW, (unsigned)((size_t)Q * HW * sizeof(float)));
+      const unsigned vo = (unsigned)(((size_t)(qbeg + g * 4) * HW + (size_t)group * 64 + 4 * j) * 4);
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-      const int qb = qbeg + (wv + 8 * qt) * 16 + g * 4;
-      if (MODE == 0) {
+      for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-        for (int pt = 0; pt < 8; ++pt) {
-          const size_t p = (size_t)tile * kNPix + pt * 16 + j;
+        for (int r = 0; r < 4; ++r) {
+          const unsigned so = (unsigned)(qt * 16 + r) * chan_bytes;   // uniform
+          if (qbeg + qt * 16 + g * 4 + r >= Q) continue;
+          if (VEC) {
+            const dvis_f4 v = dvis_f4{acc[qt][0][r], acc[qt][1][r], acc[qt][2][r], acc[qt][3][r]};
+            if (okc[0]) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dvis_v4u, v), ro, vo, so, 0);
+          } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (qb + r < Q && p < HW) out_logits[((size_t)b * Q + qb + r) * HW + p] = acc[qt][pt][r];
-        }
-      } else {
-        int cnt[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int pt = 0; pt < 8; ++pt) {
-          const int o = tile * 32 + pt * 4 + (j >> 1);
-          const bool writer = (j & 1) == 0 && j < 8 && o < OHW;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float v = acc[qt][pt][r];
-            const float hs = v + lane_xor1(v);           // (a + b) resp. (c + d)
-            const float s4 = hs + lane_xor8(hs);         // (a + b) + (c + d)   [x 0.25 > 0 dropped]
-            const bool blocked = s4 < 0.f;
-            const unsigned long long bal = __ballot(writer && !blocked);
-            cnt[r] += __popc((unsigned)((bal >> (16 * g)) & 0xffffull));
-            if (writer && qb + r < Q) out_mask[((size_t)b * Q + qb + r) * OHW + o] = blocked ? 1 : 0;
+            for (int n = 0; n < 4; ++n) {
+              const float v = acc[qt][n][r];   // (bit_cast straight from the vector-element lvalue reads element 0)
+              if (okc[n]) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, vo + 4u * n, so, 0);
+            }
           }
         }
-        if (j == 0) {
+    } else {
+      const __amdgpu_buffer_rsrc_t ro = dvis_make_rsrc_uniform(out_mask + (size_t)b * Q * OHW, (unsigned)((size_t)Q * OHW));
+      const unsigned vo = (unsigned)((qbeg + g * 4) * OHW + group * 16 + j);
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (qb + r < Q && cnt[r] > 0) atomicAdd(&allowed_count[(size_t)b * Q + qb + r], cnt[r]);
+      for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float s4 = (acc[qt][0][r] + acc[qt][1][r]) + (acc[qt][2][r] + acc[qt][3][r]);   // [x 0.25 > 0 dropped]
+          const bool blocked = s4 < 0.f;
+          const unsigned long long bal = __ballot(okc[0] && !blocked);
+          const int n_allowed = __popc((unsigned)((bal >> (16 * g)) & 0xffffull));
+          if (j == 0 && n_allowed > 0) atomicAdd(&counts[qt * 16 + g * 4 + r], n_allowed);   // LDS
+          if (okc[0] && qbeg + qt * 16 + g * 4 + r < Q)
+            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(blocked ? 1 : 0), ro, vo, (unsigned)((qt * 16 + r) * OHW), 0);
         }
-      }
     }
   }
+  __syncthreads();
+  flush_counts();
 }
 
-int launch(int mode, const float *embed, const float *feat, int B, int Q, int C, int H, int W, int h, int w,
-           float *out_logits, uint8_t *out_mask, int *allowed, hipStream_t st) {
-  const int CQ = ((C + 3) / 4 + kU - 1) / kU * kU;
-  const int NS = CQ / kU;
-  const int sfac = mode == 1 ? H / h : 1;
-  const long long npx = mode == 1 ? (long long)h * w : (long long)H * W;
-  const int per = mode == 1 ? 32 : kNPix;
-  const int ntiles = (int)((npx + per - 1) / per);
-  int tpb = (int)(((long long)ntiles * B + 2047) / 2048);
-  tpb = tpb < 1 ? 1 : (tpb > 16 ? 16 : tpb);
-  const dim3 grid((ntiles + tpb - 1) / tpb, B), block(512);
-  static bool lds_opt_in = false;   // > 64 KB of dynamic LDS needs the opt-in once per process
+template <int MODE, int QT, bool VEC, bool FULLC>
+int launch_one(const float *embed, const float *feat, int B, int Q, int qbeg, int C, int H, int W, int h, int w,
+               float *out_logits, uint8_t *out_mask, int *allowed, hipStream_t st) {
+  static bool lds_opt_in = false;   // > 64 KB of dynamic LDS needs the opt-in once per process and kernel
   if (!lds_opt_in) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mask_gemm_kernel<0>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mask_gemm_kernel<1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mask_gemm_kernel<MODE, QT, VEC, FULLC>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<QT>());
     if (e != hipSuccess) {
       dvis_set_error("mask_gemm: hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
       return DVIS_E_LAUNCH;
     }
     lds_opt_in = true;
   }
-  for (int qbeg = 0; qbeg < Q; qbeg += 128) {   // 8 waves x 16 queries per launch
-    if (mode == 0)
-      hipLaunchKernelGGL((mask_gemm_kernel<0>), grid, block, kLdsBytes, st, embed, feat, Q, qbeg, C, CQ, NS, H, W, h, w, sfac,
-                         ntiles, tpb, out_logits, out_mask, allowed);
+  const int CQ = ((C + 3) / 4 + 7) / 8 * 8;
+  const int sfac = MODE == 1 ? H / h : 1;
+  const long long npx = MODE == 1 ? (long long)h * w : (long long)H * W;
+  const int per = MODE == 1 ? 16 : 64;
+  const int gpf = (int)((npx + per - 1) / per);
+  const int spf = (gpf + 7) / 8;
+  const long long total = (long long)B * spf;
+  // one workgroup per CU at QT = 7 (LDS, 2 waves per SIMD); the small forms fit two
+  const int nwg = (int)(total < (QT == kMaxQT ? 256 : 512) ? total : (QT == kMaxQT ? 256 : 512));
+  hipLaunchKernelGGL((mask_gemm_kernel<MODE, QT, VEC, FULLC>), dim3(nwg), dim3(512), lds_bytes<QT>(), st, embed, feat, Q, qbeg, C,
+                     CQ, H, W, h, w, sfac, gpf, spf, (int)total, out_logits, out_mask, allowed);
+  return DVIS_OK;
+}
+
+template <int MODE, bool VEC>
+int launch(const float *embed, const float *feat, int B, int Q, int C, int H, int W, int h, int w, float *out_logits,
+           uint8_t *out_mask, int *allowed, hipStream_t st) {
+  const int tiles = (Q + 15) / 16;
+  const int passes = (tiles + kMaxQT - 1) / kMaxQT;
+  const int per_pass = (tiles + passes - 1) / passes;   // 200 queries: 13 tiles -> 7 + 6
+  for (int pass = 0, t0 = 0; pass < passes; ++pass, t0 += per_pass) {
+    const int nt = tiles - t0 < per_pass ? tiles - t0 : per_pass;
+    const int qbeg = t0 * 16;
+    int rc;
+#define DVIS_MG(QT_)                                                                                              \
+  (C % 32 == 0 ? launch_one<MODE, QT_, VEC, true>(embed, feat, B, Q, qbeg, C, H, W, h, w, out_logits, out_mask,  \
+                                                   allowed, st)                                                   \
+               : launch_one<MODE, QT_, false, false>(embed, feat, B, Q, qbeg, C, H, W, h, w, out_logits, out_mask, \
+                                                     allowed, st))
+    if (nt <= 2)
+      rc = DVIS_MG(2);
+    else if (nt <= 4)
+      rc = DVIS_MG(4);
     else
-      hipLaunchKernelGGL((mask_gemm_kernel<1>), grid, block, kLdsBytes, st, embed, feat, Q, qbeg, C, CQ, NS, H, W, h, w, sfac,
-                         ntiles, tpb, out_logits, out_mask, allowed);
+      rc = DVIS_MG(7);
+#undef DVIS_MG
+    if (rc != DVIS_OK) return rc;
   }
   return dvis_check_launch("mask_gemm_kernel");
 }
@@ -265,9 +312,12 @@ DVIS_EXPORT int dvis_mask_logits(const float *embed, const float *feat, int B, i
   if (B == 0) return DVIS_OK;
   DVIS_REQUIRE(embed && feat && out, "mask_logits: null pointer");
   DVIS_REQUIRE(C <= 256, "mask_logits: supports C <= 256 (got C=%d)", C);
-  DVIS_REQUIRE(HW < (1ll << 31) && B <= 65535, "mask_logits: HW / B too large");
-  DVIS_REQUIRE((long long)C * HW * 4 < 0xFFFFFF00ll, "mask_logits: one frame of mask_features must stay below 4 GiB");
-  return launch(0, embed, feat, B, Q, C, 1, (int)HW, 0, 0, out, nullptr, nullptr, (hipStream_t)stream);
+  DVIS_REQUIRE(HW < (1ll << 31) && (long long)Q * HW * 4 < 0xFFFFFF00ll, "mask_logits: one frame of logits must stay below 4 GiB");
+  DVIS_REQUIRE((long long)((C + 31) / 32 * 32) * HW * 4 < 0xFFFFFF00ll,
+               "mask_logits: one frame of mask_features must stay below 4 GiB");
+  const bool vec = HW % 4 == 0 && ((uintptr_t)feat | (uintptr_t)out) % 16 == 0;
+  return vec ? launch<0, true>(embed, feat, B, Q, C, 1, (int)HW, 0, 0, out, nullptr, nullptr, (hipStream_t)stream)
+             : launch<0, false>(embed, feat, B, Q, C, 1, (int)HW, 0, 0, out, nullptr, nullptr, (hipStream_t)stream);
 }
 
 DVIS_EXPORT int dvis_attn_mask(const float *embed, const float *feat, int B, int Q, int C, int H, int W, int h, int w,
@@ -278,12 +328,12 @@ DVIS_EXPORT int dvis_attn_mask(const float *embed, const float *feat, int B, int
   DVIS_REQUIRE(C <= 256, "attn_mask: supports C <= 256 (got C=%d)", C);
   DVIS_REQUIRE(H % h == 0 && W % w == 0 && H / h == W / w && (H / h) % 2 == 0,
                "attn_mask: needs an even integer down-sizing factor (H=%d W=%d -> h=%d w=%d)", H, W, h, w);
-  DVIS_REQUIRE(B <= 65535, "attn_mask: B too large");
-  DVIS_REQUIRE((long long)C * H * W * 4 < 0xFFFFFF00ll, "attn_mask: one frame of mask_features must stay below 4 GiB");
+  DVIS_REQUIRE((long long)((C + 31) / 32 * 32) * H * W * 4 < 0xFFFFFF00ll,
+               "attn_mask: one frame of mask_features must stay below 4 GiB");
   hipError_t e = hipMemsetAsync(allowed_count, 0, (size_t)B * Q * sizeof(int32_t), (hipStream_t)stream);
   if (e != hipSuccess) {
     dvis_set_error("attn_mask: hipMemsetAsync: %s", hipGetErrorString(e));
     return DVIS_E_LAUNCH;
   }
-  return launch(1, embed, feat, B, Q, C, H, W, h, w, nullptr, mask, allowed_count, (hipStream_t)stream);
+  return launch<1, false>(embed, feat, B, Q, C, H, W, h, w, nullptr, mask, allowed_count, (hipStream_t)stream);
 }
