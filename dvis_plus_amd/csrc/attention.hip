@@ -296,6 +296,222 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(
   }
 }
 
+// Few queries, long key sequences, d = 32 (the decoder's masked cross-attention: 100 / 200 queries, 920 ... 14 720 keys):
+// partitioned by KEYS.  A wave owns a key range of one (batch, head) and ALL query tiles of its chunk (QT = 7 tiles of 16
+// = 112 queries): Q fragments (56 VGPRs), O accumulators (56) and the row statistics of all 7 tiles stay in registers,
+// and a 16-key tile of K and V — needed by no other wave — goes from global memory straight into the MFMA operand
+// layouts, fetched one tile ahead: no LDS, no barrier.  Every wave is its own flash-decoding split (partials merged by
+// attn_combine_kernel).  Against the query-partitioned kernel above: 100 of 112 issued rows are useful instead of 100 of
+// 128 with one wave in eight idle, and a K/V fragment is loaded once per 112 MFMAs.
+// The row maximum is LAZY: probabilities are taken relative to a reference m_ref that is only raised (cross-lane
+// reduction + rescale of O and l) when some score of the tile exceeds it by more than 2^kLazy — softmax is invariant to
+// the reference, and the common tile then costs no lane exchange at all (2 ds_bpermute + waits per tile before).
+constexpr float kLazy = 16.f;   // scores are in log2 units: p <= 2^16 between two raises, l <= Lk * 2^16
+
+struct KeySplitPlan {
+  int nsplit, keys_per_split, qchunks;
+};
+constexpr int kQT = 7;
+
+KeySplitPlan plan_keysplit(int BH, int Lq, int Lk) {
+  KeySplitPlan p;
+  p.qchunks = ((Lq + 15) / 16 + kQT - 1) / kQT;
+  const long long units = (long long)BH * p.qchunks;
+  long long ns = 2048 / units;                 // 256 CUs x 8 waves in one round
+  const int max_ns = (Lk + 127) / 128;         // at least 8 key tiles per wave
+  if (ns > max_ns) ns = max_ns;
+  if (ns < 1) ns = 1;
+  const int tiles = (Lk + 15) / 16;
+  const int kps = (int)((tiles + ns - 1) / ns) * 16;
+  p.nsplit = (Lk + kps - 1) / kps;
+  p.keys_per_split = kps;
+  return p;
+}
+
+bool keysplit_applies(int Lq, int Lk, int d, bool has_mask, int64_t k_row, int64_t v_row) {
+  return d == 32 && Lq > 64 && Lk >= 512 && (!has_mask || (Lk & 3) == 0) && (long long)Lk * k_row * 4 < (1ll << 31) &&
+         (long long)Lk * v_row * 4 < (1ll << 31) && (long long)Lq * Lk < (1ll << 31);
+}
+
+__global__ __launch_bounds__(512) void attn_keysplit_kernel(
+    const float *__restrict__ q, dvis_strides qs, const float *__restrict__ k, dvis_strides ks_, const float *__restrict__ v,
+    dvis_strides vs, float *__restrict__ out, dvis_strides os, const uint8_t *__restrict__ mask,
+    const int *__restrict__ allowed, int heads, int Lq, int Lk, float scale, int nsplit, int keys_per_split, int qchunks,
+    int total_units, float *__restrict__ ws_o, float *__restrict__ ws_ml) {
+  constexpr int DH = 32, DQ = 8, NT = 2, QT = kQT;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int unit = blockIdx.x * 8 + wv;
+  if (unit >= total_units) return;   // wave-uniform; the kernel has no barrier
+  const int split = unit % nsplit;
+  const int t = unit / nsplit;
+  const int qc = t % qchunks, bh = t / qchunks;
+  const int bi = bh / heads, hi = bh - bi * heads;
+  const int q_base = qc * (QT * 16);
+  const int key_lo = split * keys_per_split;
+  const int key_hi = min(Lk, key_lo + keys_per_split);
+
+  // ---- B operands of S^T for all query tiles: Q[q_base + 16 qt + j][g*DQ + kk] * scale * log2(e)
+  float qf[QT][DQ];
+  unsigned use_mask_bits = 0;
+  unsigned moff[QT];   // byte offset of this lane's query row in the frame's mask, + 4g
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int myq = q_base + qt * 16 + j;
+    const bool q_ok = myq < Lq;
+    const float *qrow = q + (size_t)bi * qs.b + (size_t)hi * qs.h + (size_t)(q_ok ? myq : 0) * qs.r + g * DQ;
+#pragma unroll
+    for (int c = 0; c < DQ / 4; ++c) {
+      const float4 tq = *reinterpret_cast<const float4 *>(qrow + 4 * c);
+      qf[qt][4 * c] = q_ok ? tq.x * (scale * kLog2e) : 0.f;
+      qf[qt][4 * c + 1] = q_ok ? tq.y * (scale * kLog2e) : 0.f;
+      qf[qt][4 * c + 2] = q_ok ? tq.z * (scale * kLog2e) : 0.f;
+      qf[qt][4 * c + 3] = q_ok ? tq.w * (scale * kLog2e) : 0.f;
+    }
+    const bool um = mask != nullptr && q_ok && (allowed == nullptr || allowed[(size_t)bi * Lq + myq] != 0);
+    use_mask_bits |= um ? (1u << qt) : 0u;
+    moff[qt] = (unsigned)((q_ok ? myq : 0) * Lk + 4 * g);
+  }
+  const __amdgpu_buffer_rsrc_t rk = dvis_make_rsrc_uniform(k + (size_t)bi * ks_.b + (size_t)hi * ks_.h, 0x7FFFFFFFu);
+  const __amdgpu_buffer_rsrc_t rv = dvis_make_rsrc_uniform(v + (size_t)bi * vs.b + (size_t)hi * vs.h, 0x7FFFFFFFu);
+  // mask rows of this frame; a word that starts past the last row's end reads 0 (tail tile of the last query)
+  const __amdgpu_buffer_rsrc_t rm =
+      dvis_make_rsrc_uniform(mask ? mask + (size_t)bi * Lq * Lk : nullptr, mask ? (unsigned)((size_t)Lq * Lk) : 0u);
+  const unsigned k_row_bytes = (unsigned)(ks_.r * 4), v_row_bytes = (unsigned)(vs.r * 4);
+
+  // fragments of one 16-key tile: K as A operand (lane (j, g): key j, dims g*8 ..), V as B operand (lane (j, g): keys
+  // 4g + r, dims j and 16 + j), the 7 mask words (bytes = this lane's 4 keys of query tile qt).  Rows past the split's
+  // last key re-read that last key: finite, and masked out of the softmax below.
+  struct Frag {
+    dvis_f4 k0, k1;
+    float v[4][NT];
+    unsigned mw[QT];
+  };
+  auto load_tile = [&](int key0, Frag &f) {
+    const unsigned ko = (unsigned)min(key0 + j, key_hi - 1) * k_row_bytes + (unsigned)(g * DQ * 4);
+    f.k0 = __builtin_bit_cast(dvis_f4, __builtin_amdgcn_raw_buffer_load_b128(rk, ko, 0, 0));
+    f.k1 = __builtin_bit_cast(dvis_f4, __builtin_amdgcn_raw_buffer_load_b128(rk, ko + 16u, 0, 0));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const unsigned vo = (unsigned)min(key0 + 4 * g + r, key_hi - 1) * v_row_bytes + (unsigned)(j * 4);
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        f.v[r][n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, vo + 64u * n, 0, 0));
+    }
+    if (mask != nullptr) {   // uniform
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) f.mw[qt] = __builtin_amdgcn_raw_buffer_load_b32(rm, moff[qt] + (unsigned)key0, 0, 0);
+    } else {
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) f.mw[qt] = 0u;
+    }
+  };
+  auto score = [&](const Frag &f, int qt) -> dvis_f4 {   // S^T tile: rows = 16 keys, cols = the 16 queries of tile qt
+    dvis_f4 sc = dvis_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.k0[c], qf[qt][c], sc, 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.k1[c], qf[qt][4 + c], sc, 0, 0, 0);
+    return sc;
+  };
+
+  dvis_f4 o[QT][NT];
+  float m_ref[QT], l_part[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) o[qt][n] = dvis_f4{0.f, 0.f, 0.f, 0.f};
+    m_ref[qt] = -INFINITY;
+    l_part[qt] = 0.f;
+  }
+
+  Frag cur, nxt;
+  load_tile(key_lo, cur);
+  dvis_f4 s_next = score(cur, 0);
+#pragma unroll 1
+  for (int key0 = key_lo; key0 < key_hi; key0 += 16) {
+    const bool more = key0 + 16 < key_hi;                 // wave-uniform
+    load_tile(more ? key0 + 16 : key0, nxt);              // (the last tile re-reads itself: same instructions, no branch)
+    // keys of the tile past the split's end, as a mask word (bytes = this lane's 4 keys): computed once per tile and
+    // OR-ed into every query tile's word — the dead-key select below is then the only one
+    const int kbase = key0 + 4 * g;
+    unsigned dead = 0u;
+    const bool full = key0 + 16 <= key_hi;                // wave-uniform
+    if (!full) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dead |= kbase + r >= key_hi ? (0xffu << (8 * r)) : 0u;
+    }
+    const bool any_dead = mask != nullptr || !full;       // wave-uniform
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      const dvis_f4 s = s_next;
+      // score MFMAs of the next query tile (or of the next key tile's first one) run under this tile's softmax VALU work
+      s_next = qt + 1 < QT ? score(cur, qt + 1) : score(nxt, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // lane (j, g) holds S[query q_base + 16 qt + j][key0 + 4g + r], r = 0..3.  Dead keys (masked / past the end) -> -inf
+      float sv[4] = {s[0], s[1], s[2], s[3]};
+      if (any_dead) {
+        // (rows that ignore the mask — allowed_count == 0 — keep only the tile's own dead keys)
+        const unsigned mw = (((use_mask_bits >> qt) & 1u) ? cur.mw[qt] : 0u) | dead;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sv[r] = (mw & (0xffu << (8 * r))) ? -INFINITY : sv[r];
+      }
+      const float tmax = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+      if (__any(tmax > m_ref[qt] + kLazy)) {   // wave-uniform, rare after the first tiles: raise the reference
+        float m_new = fmaxf(tmax, __shfl_xor(tmax, 16));
+        m_new = fmaxf(m_new, __shfl_xor(m_new, 32));
+        m_new = fmaxf(m_new, m_ref[qt]);
+        const float alpha = (m_new == -INFINITY) ? 1.f : ex2(m_ref[qt] - m_new);   // 2^(-inf - finite) = 0: O, l were 0
+        l_part[qt] *= alpha;
+        // row (4g + r) of the accumulator belongs to query 4g + r of the tile, whose alpha lives in lane 4g + r
+        const dvis_f4 av = dvis_f4{__shfl(alpha, 4 * g), __shfl(alpha, 4 * g + 1), __shfl(alpha, 4 * g + 2),
+                                   __shfl(alpha, 4 * g + 3)};
+#pragma unroll
+        for (int n = 0; n < NT; ++n) o[qt][n] = o[qt][n] * av;
+        m_ref[qt] = m_new;
+      }
+      const float m_sub = (m_ref[qt] == -INFINITY) ? 0.f : m_ref[qt];   // no live key yet: -inf - 0 = -inf, not NaN
+      float p[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[r] = ex2(sv[r] - m_sub);
+      l_part[qt] += (p[0] + p[1]) + (p[2] + p[3]);
+      // ---- O += P V : A = P (already in A layout), B = V rows key0 + 4g + r
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) o[qt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[r], cur.v[r][n], o[qt][n], 0, 0, 0);
+    }
+    cur = nxt;
+  }
+
+  // ---- epilogue: l over the 4 lane groups; stats of query (4g + r) come from lane 4g + r
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    float l_tot = l_part[qt] + __shfl_xor(l_part[qt], 16);
+    l_tot += __shfl_xor(l_tot, 32);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float lr = __shfl(l_tot, 4 * g + r), mr = __shfl(m_ref[qt], 4 * g + r);
+      const int qq = q_base + qt * 16 + 4 * g + r;
+      if (qq >= Lq) continue;
+      if (nsplit == 1) {
+        const float inv = lr > 0.f ? 1.f / lr : 0.f;
+        float *orow = out + (size_t)bi * os.b + (size_t)hi * os.h + (size_t)qq * os.r;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) orow[16 * n + j] = o[qt][n][r] * inv;
+      } else {
+        const size_t row = ((size_t)bh * nsplit + split) * Lq + qq;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) ws_o[row * DH + 16 * n + j] = o[qt][n][r];
+        if (j == 0) {
+          ws_ml[row * 2] = mr;
+          ws_ml[row * 2 + 1] = lr;
+        }
+      }
+    }
+  }
+}
+
 // Latency kernel for short key sequences with few (batch, head) pairs — the tracker's 100x100 attentions at batch 1,
 // which are strictly sequential, so latency is what counts.  With the mapping above one (batch, head) sits on ONE CU and
 // its 7 query tiles x 224 fp32 MFMAs (32 clk each) take ~6 us of pure MFMA issue; only 8 CUs are busy.  Here a workgroup is one 16-query tile of one head and its 4 waves (one per SIMD) split
@@ -491,8 +707,10 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restri
 DVIS_EXPORT int64_t dvis_attention_ws_bytes(int BH, int Lq, int Lk, int d) {
   if (BH <= 0 || Lq <= 0 || Lk <= 0 || d <= 0) return 0;
   const SplitPlan p = plan_split(BH, Lq, Lk);
-  if (p.nsplit == 1) return 0;
-  return (int64_t)BH * p.nsplit * Lq * (d + 2) * (int64_t)sizeof(float);
+  int ns = p.nsplit;
+  if (keysplit_applies(Lq, Lk, d, false, 0, 0)) ns = std::max(ns, plan_keysplit(BH, Lq, Lk).nsplit);   // whichever runs
+  if (ns == 1) return 0;
+  return (int64_t)BH * ns * Lq * (d + 2) * (int64_t)sizeof(float);
 }
 
 DVIS_EXPORT int dvis_attention_forward(const float *q, const int64_t *q_strides, const float *k, const int64_t *k_strides,
@@ -511,9 +729,25 @@ DVIS_EXPORT int dvis_attention_forward(const float *q, const int64_t *q_strides,
   DVIS_REQUIRE((al & 15) == 0 && ((qs.b | qs.h | qs.r | ks.b | ks.h | ks.r | vs.b | vs.h | vs.r) & 3) == 0,
                "attention: q/k/v must be 16-byte aligned with strides that are multiples of 4 floats");
   DVIS_REQUIRE(mask == nullptr || ((uintptr_t)mask & 3) == 0, "attention: mask must be 4-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  if (keysplit_applies(Lq, Lk, d, mask != nullptr, ks.r, vs.r)) {
+    const KeySplitPlan kp = plan_keysplit(BH, Lq, Lk);
+    DVIS_REQUIRE(kp.nsplit == 1 || ws, "attention: workspace required (dvis_attention_ws_bytes)");
+    float *kws_o = (float *)ws;
+    float *kws_ml = kws_o ? kws_o + (size_t)BH * kp.nsplit * Lq * d : nullptr;
+    const long long units = (long long)BH * kp.qchunks * kp.nsplit;
+    hipLaunchKernelGGL(attn_keysplit_kernel, dim3((unsigned)((units + 7) / 8)), dim3(512), 0, st, q, qs, k, ks, v, vs, out, os,
+                       mask, allowed_count, heads, Lq, Lk, scale, kp.nsplit, kp.keys_per_split, kp.qchunks, (int)units, kws_o,
+                       kws_ml);
+    int rc = dvis_check_launch("attn_keysplit_kernel");
+    if (rc != DVIS_OK || kp.nsplit == 1) return rc;
+    const size_t total = (size_t)BH * Lq * d;
+    hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, kws_o, kws_ml, kp.nsplit,
+                       Lq, d, heads, total, out, os);
+    return dvis_check_launch("attn_combine_kernel");
+  }
   const SplitPlan p = plan_split(BH, Lq, Lk);
   DVIS_REQUIRE(p.nsplit == 1 || ws, "attention: workspace required (dvis_attention_ws_bytes)");
-  hipStream_t st = (hipStream_t)stream;
   float *ws_o = (float *)ws;
   float *ws_ml = ws_o ? ws_o + (size_t)BH * p.nsplit * Lq * d : nullptr;
   const dim3 grid(p.nsplit, BH, p.qchunks), block(512);

@@ -31,6 +31,10 @@ CASES = [  # (Lq, Lk, B, heads, d, masked)
     # few (batch, head, query-tile) workgroups and Lk <= 128: the key-split latency kernel (tracker shapes)
     (100, 100, 1, 8, 64, True), (100, 100, 1, 8, 32, True), (100, 128, 1, 8, 64, True), (33, 113, 2, 4, 32, True),
     (100, 1, 1, 8, 64, False), (1, 100, 1, 8, 64, False),
+    # key-partitioned kernel (d = 32, > 64 queries, >= 512 keys): two query chunks, ragged last key tile, 65 queries
+    # (one live row in the fifth tile), no mask with Lk % 4 != 0, many (batch, head) pairs (one split per wave)
+    (200, 1000, 2, 8, 32, True), (65, 516, 1, 4, 32, True), (100, 777, 2, 8, 32, False), (112, 2000, 1, 2, 32, False),
+    (100, 640, 40, 8, 32, True), (113, 530, 3, 8, 32, True),
 ]
 
 
@@ -132,6 +136,23 @@ def test_online_softmax_rescale_branch_is_exercised():
     q, k, v = (torch.randn(L, B, H * d, generator=g) for L in (Lq, Lk, Lk))
     k[400] = q[7] * 3.0            # spikes q[7]'s score at key 400
     k[130] = q[50] * 2.0
+    ref = ref_attention(q, k, v, H)
+    out = attention(q.to(DEV), k.to(DEV), v.to(DEV), H).cpu()
+    torch.testing.assert_close(out.double(), ref, rtol=0, atol=2e-5)
+
+
+def test_lazy_row_maximum_between_raises():
+    """The key-partitioned kernel raises its softmax reference only when a score exceeds it by more than 2^16: scores that
+    climb steadily by less than that per tile (probabilities up to 2^16 relative to the stale reference), then a jump far
+    above it, then a fall — against fp64."""
+    from dvis_plus_amd.functions import attention
+    g = torch.Generator().manual_seed(9)
+    Lq, Lk, B, H, d = 100, 1024, 1, 2, 32
+    q, k, v = (torch.randn(L, B, H * d, generator=g) for L in (Lq, Lk, Lk))
+    ramp = torch.linspace(0.0, 1.0, Lk).view(Lk, 1, 1)
+    k = k * 0.2 + q[11:12] * ramp * 0.35        # query 11: score grows ~ linearly to ~ +11 (log2 units) over the keys
+    k[900] = q[11] * 4.0                        # ... then one key far above (a raise), followed by ordinary keys
+    k[37] = q[60] * 1.0
     ref = ref_attention(q, k, v, H)
     out = attention(q.to(DEV), k.to(DEV), v.to(DEV), H).cpu()
     torch.testing.assert_close(out.double(), ref, rtol=0, atol=2e-5)
