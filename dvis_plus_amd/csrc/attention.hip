@@ -22,6 +22,8 @@
 //   * v_mfma_f32_16x16x4_f32 = fp32 fma chain, online softmax in fp32 (base 2, v_exp_f32): parity well inside 1e-3.
 #include <math.h>
 
+#include <type_traits>
+
 #include "dvis_common.h"
 
 namespace {
@@ -406,92 +408,140 @@ __global__ __launch_bounds__(512) void attn_keysplit_kernel(
       for (int qt = 0; qt < QT; ++qt) f.mw[qt] = 0u;
     }
   };
-  auto score = [&](const Frag &f, int qt) -> dvis_f4 {   // S^T tile: rows = 16 keys, cols = the 16 queries of tile qt
-    dvis_f4 sc = dvis_f4{0.f, 0.f, 0.f, 0.f};
+  // S^T tile: rows = 16 keys, cols = the 16 queries of tile qt.  The accumulator starts from the lane's mask BIAS
+  // (0, or a huge negative number for a dead key), so masking costs no select after the product.
+  // Two independent half chains (dims 0-3 / 4-7 of the lane group), summed at the end: a dependent fp32 MFMA waits for
+  // its predecessor's 8 passes, and one 8-long chain next to the two 4-long P V chains left the matrix pipe idle.
+  auto score = [&](const Frag &f, int qt, dvis_f4 sc) -> dvis_f4 {
+    dvis_f4 s2 = dvis_f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < 4; ++c) sc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.k0[c], qf[qt][c], sc, 0, 0, 0);
+    for (int c = 0; c < 4; ++c) {
+      sc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.k0[c], qf[qt][c], sc, 0, 0, 0);
+      s2 = __builtin_amdgcn_mfma_f32_16x16x4f32(f.k1[c], qf[qt][4 + c], s2, 0, 0, 0);
+    }
+    return sc + s2;
+  };
+  // Dead keys (masked, or past the split's end) get the bias 0xFF000000 = -1.7e38: finite, absorbs any score, and
+  // 2^(bias - m_ref) is exactly 0 because m_ref never goes below kNoRef = -1e30.  Bit 0 of the key's mask byte, sign-
+  // extended and masked (v_bfe_i32 + v_and_b32), is that pattern — no compare / select and none of their wait states.
+  auto bias_of = [&](unsigned mw) -> dvis_f4 {
+    dvis_f4 bv;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) sc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.k1[c], qf[qt][4 + c], sc, 0, 0, 0);
-    return sc;
+    for (int r = 0; r < 4; ++r)
+      bv[r] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_sbfe((int)mw, 8 * r, 1) & 0xFF000000u);
+    return bv;
+  };
+  auto mask_word = [&](const Frag &f, int qt, unsigned dead) -> unsigned {
+    // (rows that ignore the mask — allowed_count == 0 — keep only the tile's own dead keys)
+    return (((use_mask_bits >> qt) & 1u) ? f.mw[qt] : 0u) | dead;
+  };
+  // keys of a tile past the split's end, as a mask word (bytes = this lane's 4 keys)
+  auto dead_word = [&](int key0) -> unsigned {
+    unsigned dead = 0u;
+    if (key0 + 16 > key_hi) {   // wave-uniform
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dead |= key0 + 4 * g + r >= key_hi ? (0xffu << (8 * r)) : 0u;
+    }
+    return dead;
   };
 
+  // Row state per query tile as SEPARATE variables: as arrays (float[7], or 2-vectors[7]) hipcc keeps the seven
+  // references in one wide value and copies all of it around the raise branch of every tile (8-14 v_mov per query tile).
+  // m_ref starts at a finite -1e30, not -inf: no special case for "no live key yet", and the first live score raises
+  // the reference with alpha = 2^(-1e30 - m) = 0 on an all-zero state.
+  constexpr float kNoRef = -1e30f;
+  struct Row {
+    float m, l;
+  };
+  Row st0{kNoRef, 0.f}, st1{kNoRef, 0.f}, st2{kNoRef, 0.f}, st3{kNoRef, 0.f}, st4{kNoRef, 0.f}, st5{kNoRef, 0.f},
+      st6{kNoRef, 0.f};
   dvis_f4 o[QT][NT];
-  float m_ref[QT], l_part[QT];
 #pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
+  for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
     for (int n = 0; n < NT; ++n) o[qt][n] = dvis_f4{0.f, 0.f, 0.f, 0.f};
-    m_ref[qt] = -INFINITY;
-    l_part[qt] = 0.f;
-  }
 
-  Frag cur, nxt;
-  load_tile(key_lo, cur);
-  dvis_f4 s_next = score(cur, 0);
+  dvis_f4 s_next;
+  // one query tile of one key tile (fragments `cur`); `next_score` issues the score MFMAs of the following (query, key)
+  // tile, which the compiler places next to this tile's P V MFMAs
+  auto tile_body = [&](auto qt_c, Row &st, const Frag &cur, auto next_score) {
+    constexpr int qt = decltype(qt_c)::value;
+    const dvis_f4 s = s_next;
+    s_next = next_score();
+    __builtin_amdgcn_sched_barrier(0);
+    // lane (j, g) holds S[query q_base + 16 qt + j][key0 + 4g + r] (+ bias), r = 0..3
+    const float tmax = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+    if (__any(tmax > st.m + kLazy)) {   // wave-uniform, rare after the first tiles: raise the reference
+      float m_new = fmaxf(tmax, __shfl_xor(tmax, 16));
+      m_new = fmaxf(m_new, __shfl_xor(m_new, 32));
+      m_new = fmaxf(m_new, st.m);       // (a row with no live key so far keeps kNoRef: its tmax is the bias)
+      const float alpha = ex2(st.m - m_new);
+      // row (4g + r) of the accumulator belongs to query 4g + r of the tile, whose alpha lives in lane 4g + r
+      const dvis_f4 av = dvis_f4{__shfl(alpha, 4 * g), __shfl(alpha, 4 * g + 1), __shfl(alpha, 4 * g + 2),
+                                 __shfl(alpha, 4 * g + 3)};
+#pragma unroll
+      for (int n = 0; n < NT; ++n) o[qt][n] = o[qt][n] * av;
+      st.m = m_new;
+      st.l *= alpha;
+    }
+    float p[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[r] = ex2(s[r] - st.m);
+    st.l += (p[0] + p[1]) + (p[2] + p[3]);
+    // ---- O += P V : A = P (already in A layout), B = V rows key0 + 4g + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) o[qt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[r], cur.v[r][n], o[qt][n], 0, 0, 0);
+  };
+  // all 7 query tiles of the key tile held in `cur`; `nxt` is the following key tile, requested by `fetch_next` after the
+  // third query tile (it is first needed by the seventh)
+  auto key_tile = [&](const Frag &cur, unsigned dead_cur, const Frag &nxt, unsigned &dead_nxt, auto fetch_next) {
+#define DVIS_QT(N_, ST_)                                                                                  \
+  tile_body(std::integral_constant<int, N_>{}, ST_, cur,                                                  \
+            [&]() { return score(cur, N_ + 1, bias_of(mask_word(cur, N_ + 1, dead_cur))); })
+    DVIS_QT(0, st0);
+    DVIS_QT(1, st1);
+    DVIS_QT(2, st2);
+    fetch_next();
+    DVIS_QT(3, st3);
+    DVIS_QT(4, st4);
+    DVIS_QT(5, st5);
+#undef DVIS_QT
+    tile_body(std::integral_constant<int, 6>{}, st6, cur,
+              [&]() { return score(nxt, 0, bias_of(mask_word(nxt, 0, dead_nxt))); });   // the next key tile's first
+  };
+
+  // Two fragment sets, ping-pong over an unrolled pair of key tiles (no register copies).  WHERE the next tile is
+  // requested matters: vmcnt counts loads in issue order, so the first use of a fragment of the CURRENT tile waits until
+  // at most (loads issued after it) are outstanding — requested at the top of the tile, the 17 loads of the next tile
+  // sit behind every such first use in the first query tile and `s_waitcnt vmcnt(15..10)` there waited for loads issued
+  // a few hundred cycles earlier (timing-only ablation, tools/exp/abl: 125 of 653 us came back with the loads removed).
+  // Requested after the third query tile, every fragment has had at least four query tiles (~1.5 us) to arrive.
+  Frag fa, fb;
+  load_tile(key_lo, fa);
+  unsigned dead_a = dead_word(key_lo), dead_b = 0u;
+  s_next = score(fa, 0, bias_of(mask_word(fa, 0, dead_a)));
 #pragma unroll 1
-  for (int key0 = key_lo; key0 < key_hi; key0 += 16) {
-    const bool more = key0 + 16 < key_hi;                 // wave-uniform
-    load_tile(more ? key0 + 16 : key0, nxt);              // (the last tile re-reads itself: same instructions, no branch)
-    // keys of the tile past the split's end, as a mask word (bytes = this lane's 4 keys): computed once per tile and
-    // OR-ed into every query tile's word — the dead-key select below is then the only one
-    const int kbase = key0 + 4 * g;
-    unsigned dead = 0u;
-    const bool full = key0 + 16 <= key_hi;                // wave-uniform
-    if (!full) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dead |= kbase + r >= key_hi ? (0xffu << (8 * r)) : 0u;
-    }
-    const bool any_dead = mask != nullptr || !full;       // wave-uniform
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-      const dvis_f4 s = s_next;
-      // score MFMAs of the next query tile (or of the next key tile's first one) run under this tile's softmax VALU work
-      s_next = qt + 1 < QT ? score(cur, qt + 1) : score(nxt, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      // lane (j, g) holds S[query q_base + 16 qt + j][key0 + 4g + r], r = 0..3.  Dead keys (masked / past the end) -> -inf
-      float sv[4] = {s[0], s[1], s[2], s[3]};
-      if (any_dead) {
-        // (rows that ignore the mask — allowed_count == 0 — keep only the tile's own dead keys)
-        const unsigned mw = (((use_mask_bits >> qt) & 1u) ? cur.mw[qt] : 0u) | dead;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sv[r] = (mw & (0xffu << (8 * r))) ? -INFINITY : sv[r];
-      }
-      const float tmax = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
-      if (__any(tmax > m_ref[qt] + kLazy)) {   // wave-uniform, rare after the first tiles: raise the reference
-        float m_new = fmaxf(tmax, __shfl_xor(tmax, 16));
-        m_new = fmaxf(m_new, __shfl_xor(m_new, 32));
-        m_new = fmaxf(m_new, m_ref[qt]);
-        const float alpha = (m_new == -INFINITY) ? 1.f : ex2(m_ref[qt] - m_new);   // 2^(-inf - finite) = 0: O, l were 0
-        l_part[qt] *= alpha;
-        // row (4g + r) of the accumulator belongs to query 4g + r of the tile, whose alpha lives in lane 4g + r
-        const dvis_f4 av = dvis_f4{__shfl(alpha, 4 * g), __shfl(alpha, 4 * g + 1), __shfl(alpha, 4 * g + 2),
-                                   __shfl(alpha, 4 * g + 3)};
-#pragma unroll
-        for (int n = 0; n < NT; ++n) o[qt][n] = o[qt][n] * av;
-        m_ref[qt] = m_new;
-      }
-      const float m_sub = (m_ref[qt] == -INFINITY) ? 0.f : m_ref[qt];   // no live key yet: -inf - 0 = -inf, not NaN
-      float p[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) p[r] = ex2(sv[r] - m_sub);
-      l_part[qt] += (p[0] + p[1]) + (p[2] + p[3]);
-      // ---- O += P V : A = P (already in A layout), B = V rows key0 + 4g + r
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) o[qt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[r], cur.v[r][n], o[qt][n], 0, 0, 0);
-    }
-    cur = nxt;
+  for (int key0 = key_lo; key0 < key_hi; key0 += 32) {
+    const int kb1 = key0 + 16 < key_hi ? key0 + 16 : key0;   // (past the end: re-read the same tile, result unused)
+    key_tile(fa, dead_a, fb, dead_b, [&]() { load_tile(kb1, fb); dead_b = dead_word(kb1); });
+    if (key0 + 16 >= key_hi) break;                           // wave-uniform
+    const int ka1 = key0 + 32 < key_hi ? key0 + 32 : key0 + 16;
+    key_tile(fb, dead_b, fa, dead_a, [&]() { load_tile(ka1, fa); dead_a = dead_word(ka1); });
   }
 
   // ---- epilogue: l over the 4 lane groups; stats of query (4g + r) come from lane 4g + r
+  const Row *rows[QT] = {&st0, &st1, &st2, &st3, &st4, &st5, &st6};
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
-    float l_tot = l_part[qt] + __shfl_xor(l_part[qt], 16);
+    const float lq = rows[qt]->l, mq = rows[qt]->m;
+    float l_tot = lq + __shfl_xor(lq, 16);
     l_tot += __shfl_xor(l_tot, 32);
+    const float m_out = mq == kNoRef ? -INFINITY : mq;   // no live key in this split: weight 0 in the merge
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float lr = __shfl(l_tot, 4 * g + r), mr = __shfl(m_ref[qt], 4 * g + r);
+      const float lr = __shfl(l_tot, 4 * g + r), mr = __shfl(m_out, 4 * g + r);
       const int qq = q_base + qt * 16 + 4 * g + r;
       if (qq >= Lq) continue;
       if (nsplit == 1) {
