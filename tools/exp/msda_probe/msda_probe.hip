@@ -2,6 +2,9 @@
 //   EXP bit 0: skip the corner gathers of all levels but the last (what an LDS-served level would cost at best)
 //   EXP bit 1: skip every gather (set-up + stores only)
 //   EXP bit 2: value laid out head-major (N, M, S, D) instead of (N, S, M, D)
+//   EXP bit 3 / 4 / 5: left corners of every second query / of every query / three corners of four get an out-of-range
+//                offset (timing only: what register re-use of corners between x-neighbouring queries would save, and
+//                whether an out-of-range lane costs a request at all)
 #include <stdlib.h>
 #include "../../../dvis_plus_amd/csrc/dvis_common.h"
 #include "../../../dvis_plus_amd/csrc/msda_tap.h"
@@ -165,6 +168,9 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile_f32(
 #pragma unroll
         for (int i = 0; i < B; ++i) {
           o[i] = s_tap_o[s0 + i];
+          if ((EXP & 8) && (ql & 1)) { o[i].x = kOOB; o[i].z = kOOB; }   // every second query re-uses its left corners
+          if (EXP & 16) { o[i].x = kOOB; o[i].z = kOOB; }                // every query does (a long walk along x)
+          if (EXP & 32) { o[i].x = kOOB; o[i].z = kOOB; o[i].y = kOOB; }  // one corner of four left
           r[4 * i] = __builtin_amdgcn_raw_buffer_load_b128(rs[l], o[i].x + lane_bytes, 0, 0);
           r[4 * i + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs[l], o[i].y + lane_bytes, 0, 0);
           r[4 * i + 2] = __builtin_amdgcn_raw_buffer_load_b128(rs[l], o[i].z + lane_bytes, 0, 0);
@@ -210,7 +216,7 @@ extern "C" __attribute__((visibility("default"))) int msda_probe(int exp, const 
   dim3 grid(M, (Lq + QB - 1) / QB, N);
 #define RUN(E) hipLaunchKernelGGL((msda_fwd_tile_f32<32, 3, 4, true, 2, 2, QB, E>), grid, dim3(256), 0, (hipStream_t)stream, value, shapes, ls, off, off_stride, lg, lg_stride, ref, nref, S, M, Lq, out, nullptr, nullptr, 0)
   switch (exp) {
-    case 0: RUN(0); break; case 1: RUN(1); break; case 2: RUN(2); break; case 4: RUN(4); break; case 5: RUN(5); break;
+    case 0: RUN(0); break; case 1: RUN(1); break; case 2: RUN(2); break; case 4: RUN(4); break; case 5: RUN(5); break; case 8: RUN(8); break; case 16: RUN(16); break; case 32: RUN(32); break;
     default: return 1;
   }
   return hipGetLastError() == hipSuccess ? 0 : 2;
