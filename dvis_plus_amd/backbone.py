@@ -57,7 +57,7 @@ class ConvBN(nn.Conv2d):
         """conv (MIOpen, no bias) then ONE fused pass: + folded-BN shift (+ residual) (+ ReLU)."""
         w, b = self.folded()
         if self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0):
-            return Fn.bias_act_(Fn.conv1x1(x, w), b, res, relu)
+            return Fn.conv1x1_bias_act(x, w, b, res, relu)
         return Fn.bias_act_(F.conv2d(x, w, None, self.stride, self.padding), b, res, relu)
 
 

@@ -36,7 +36,11 @@ namespace {
 
 constexpr int kARow = 68;        // floats per LDS row of A: 64 channels + 4 (16-lane groups of b128 reads hit all banks)
 constexpr int kMaxQT = 7;        // query tiles per pass: 4 * 112 * 68 * 4 B = 119 KB of LDS
-constexpr unsigned kOOB = 0xFFFFFF00u;   // beyond any frame slab (host checks C * HW * 4 < 2^32 - 256)
+// Out-of-range buffer offset.  It is combined with SCALAR offsets (the channel of a k-step), and the hardware adds the
+// two in 32 bits before its range check: 0xFFFFFF00 + a channel offset wraps back into the slab (harmless here — such
+// a column is never stored and its A entries are zero — but not something to rely on).  2 GiB + an offset into a
+// < 2 GiB slab neither wraps nor lands inside it (host checks).
+constexpr unsigned kOOB = 0x80000000u;
 
 template <int QT> constexpr size_t lds_bytes() { return (size_t)4 * QT * 16 * kARow * sizeof(float) + QT * 16 * sizeof(int); }
 
@@ -220,7 +224,9 @@ __global__ __launch_bounds__(512) void mask_gemm_kernel(
           if (qbeg + qt * 16 + g * 4 + r >= Q) continue;
           if (VEC) {
             const dvis_f4 v = dvis_f4{acc[qt][0][r], acc[qt][1][r], acc[qt][2][r], acc[qt][3][r]};
-            if (okc[0]) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dvis_v4u, v), ro, vo, so, 0);
+            // (row offset in the VECTOR offset: with an SGPR offset LLVM does not pad a VALU write to the data registers
+            // of a > 8-byte store, and on MI355X the store then picks up the next row's value — see conv1x1.hip)
+            if (okc[0]) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dvis_v4u, v), ro, vo + so, 0, 0);
           } else {
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
@@ -313,8 +319,8 @@ DVIS_EXPORT int dvis_mask_logits(const float *embed, const float *feat, int B, i
   DVIS_REQUIRE(embed && feat && out, "mask_logits: null pointer");
   DVIS_REQUIRE(C <= 256, "mask_logits: supports C <= 256 (got C=%d)", C);
   DVIS_REQUIRE(HW < (1ll << 31) && (long long)Q * HW * 4 < 0xFFFFFF00ll, "mask_logits: one frame of logits must stay below 4 GiB");
-  DVIS_REQUIRE((long long)((C + 31) / 32 * 32) * HW * 4 < 0xFFFFFF00ll,
-               "mask_logits: one frame of mask_features must stay below 4 GiB");
+  DVIS_REQUIRE((long long)((C + 31) / 32 * 32) * HW * 4 < (1ll << 31),
+               "mask_logits: one frame of mask_features must stay below 2 GiB");
   const bool vec = HW % 4 == 0 && ((uintptr_t)feat | (uintptr_t)out) % 16 == 0;
   return vec ? launch<0, true>(embed, feat, B, Q, C, 1, (int)HW, 0, 0, out, nullptr, nullptr, (hipStream_t)stream)
              : launch<0, false>(embed, feat, B, Q, C, 1, (int)HW, 0, 0, out, nullptr, nullptr, (hipStream_t)stream);
@@ -328,8 +334,8 @@ DVIS_EXPORT int dvis_attn_mask(const float *embed, const float *feat, int B, int
   DVIS_REQUIRE(C <= 256, "attn_mask: supports C <= 256 (got C=%d)", C);
   DVIS_REQUIRE(H % h == 0 && W % w == 0 && H / h == W / w && (H / h) % 2 == 0,
                "attn_mask: needs an even integer down-sizing factor (H=%d W=%d -> h=%d w=%d)", H, W, h, w);
-  DVIS_REQUIRE((long long)((C + 31) / 32 * 32) * H * W * 4 < 0xFFFFFF00ll,
-               "attn_mask: one frame of mask_features must stay below 4 GiB");
+  DVIS_REQUIRE((long long)((C + 31) / 32 * 32) * H * W * 4 < (1ll << 31),
+               "attn_mask: one frame of mask_features must stay below 2 GiB");
   hipError_t e = hipMemsetAsync(allowed_count, 0, (size_t)B * Q * sizeof(int32_t), (hipStream_t)stream);
   if (e != hipSuccess) {
     dvis_set_error("attn_mask: hipMemsetAsync: %s", hipGetErrorString(e));

@@ -526,6 +526,30 @@ def conv1x1(x, weight, bias=None):
     return torch.nn.functional.conv2d(x, weight, bias)
 
 
+def conv1x1_bias_act(x, weight, bias=None, res=None, relu=False):
+    """relu?(conv1x1(x, weight) + bias[c] + res) on NCHW.  Shapes dvis_conv1x1_bias_act serves (the memory-bound 1x1
+    layers of the bottleneck at the large maps) run as ONE kernel — contraction and epilogue, no second pass over the
+    output; every other shape is the library contraction followed by the in-place ``bias_act_`` pass."""
+    Co, Ci = weight.shape[:2]
+    if x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.is_contiguous() \
+            and not torch.is_grad_enabled() and (res is None or (res.is_contiguous() and res.dtype == torch.float32)):
+        N, _, H, W = x.shape
+        if native.lib().dvis_conv1x1_supported(Ci, Co, H * W) and (res is None or res.shape == (N, Co, H, W)):
+            w2 = weight.detach().reshape(Co, Ci)
+            if not w2.is_contiguous():
+                w2 = w2.contiguous()
+            out = torch.empty((N, Co, H, W), dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device):
+                rc = native.lib().dvis_conv1x1_bias_act(
+                    native.dev_ptr(x, "x"), native.dev_ptr(w2, "weight"),
+                    None if bias is None else native.dev_ptr(bias.detach(), "bias"),
+                    None if res is None else native.dev_ptr(res, "res"), native.dev_ptr(out, "out"), N, Ci, Co, H * W,
+                    1 if relu else 0, native.stream_ptr(x.device))
+            native.check(rc, "dvis_conv1x1_bias_act")
+            return out
+    return bias_act_(conv1x1(x, weight), None if bias is None else bias.detach(), res, relu)
+
+
 def bias_act_(x, bias=None, res=None, relu=True):
     """In place: x = relu?(x + bias[c] + res) on an NCHW float32 tensor — one pass instead of torch's three kernels
     (conv bias add, residual add, ReLU).  Non-GPU / odd shapes use the torch ops."""

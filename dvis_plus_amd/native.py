@@ -36,6 +36,8 @@ SIGNATURES = {
     "dvis_add_layernorm": (_i, [_p, _p, _i64, _p, _p, _p, _i64, _i, _f, _p]),
     "dvis_add_layernorm_pos": (_i, [_p, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _i, _f, _p]),
     "dvis_bias_act": (_i, [_p, _p, _p, _i64, _i, _i64, _i, _p]),
+    "dvis_conv1x1_supported": (_i, [_i, _i, _i64]),
+    "dvis_conv1x1_bias_act": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i64, _i, _p]),
     "dvis_bias_relu_maxpool": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p]),
     "dvis_group_norm_affine": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i64, _f, _p]),
     "dvis_scale_shift_act": (_i, [_p, _p, _p, _i64, _i64, _i, _p]),

@@ -25,6 +25,7 @@
  *                               video_mask2former_transformer_decoder.py:47-50,108-111,166-170, tracker.py:51-53)
  *   dvis_nchw_to_tokens      <- src.flatten(2).transpose(1, 2) + torch.cat over levels, msdeformattn.py:64-79
  *   dvis_bias_act            <- FrozenBN shift + shortcut add + ReLU after each backbone convolution (detectron2 BottleneckBlock)
+ *   dvis_conv1x1_bias_act    <- 1x1 convolution + that epilogue in one pass (conv1 / conv3 / stride-1 shortcut of the bottleneck)
  *   dvis_bias_relu_maxpool   <- FrozenBN shift + ReLU + max_pool2d(3, stride 2, padding 1) of the ResNet stem (detectron2 BasicStem)
  *   dvis_upsample_add        <- `cur_fpn + F.interpolate(out[-1], size=..., mode="bilinear")`, msdeformattn.py:347
  *   dvis_group_norm_affine / dvis_scale_shift_act / dvis_upsample_add_affine
@@ -188,6 +189,19 @@ int dvis_nchw_to_tokens(const float *x, float *out, int64_t N, int C, int64_t HW
  */
 int dvis_nchw_to_tokens_affine(const float *x, const float *scale, const float *shift, const float *pos, float *out,
                                float *out_pos, int64_t N, int C, int64_t HW, int64_t S, int64_t row0, void *stream);
+
+/*
+ * 1x1 stride-1 convolution on NCHW with its epilogue in one pass (exact-fp32 MFMA):
+ *   out[n, m, p] = relu?( sum_k w[m, k] x[n, k, p] + bias[m] (+ res[n, m, p]) )
+ *   x (N, K, HW), w (M, K) (FrozenBN scale folded in), bias (M) or NULL, res (N, M, HW) or NULL, out (N, M, HW); fp32,
+ *   16-byte aligned, K % 4 == 0, HW % 4 == 0.  Replaces conv -> dvis_bias_act for the bottleneck's conv1 / conv3 /
+ *   stride-1 shortcut (detectron2 BottleneckBlock, FrozenBN folded by the caller) where the layer is memory-bound.
+ *   dvis_conv1x1_supported(K, M, HW) != 0 tells whether the shape is served (M <= 64: K <= 512; M <= 128: K <= 256;
+ *   wider: K <= 128); other shapes return DVIS_E_ARG — the caller keeps the library contraction for them.
+ */
+int dvis_conv1x1_supported(int K, int M, int64_t HW);
+int dvis_conv1x1_bias_act(const float *x, const float *w, const float *bias, const float *res, float *out,
+                          int N, int K, int M, int64_t HW, int relu, void *stream);
 
 /*
  * In place on `planes` = N*C contiguous planes of HW floats (NCHW): x = relu?(x + bias[c] + res).  bias (C,) or NULL,

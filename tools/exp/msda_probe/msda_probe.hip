@@ -217,6 +217,8 @@ extern "C" __attribute__((visibility("default"))) int msda_probe(int exp, const 
 #define RUN(E) hipLaunchKernelGGL((msda_fwd_tile_f32<32, 3, 4, true, 2, 2, QB, E>), grid, dim3(256), 0, (hipStream_t)stream, value, shapes, ls, off, off_stride, lg, lg_stride, ref, nref, S, M, Lq, out, nullptr, nullptr, 0)
   switch (exp) {
     case 0: RUN(0); break; case 1: RUN(1); break; case 2: RUN(2); break; case 4: RUN(4); break; case 5: RUN(5); break; case 8: RUN(8); break; case 16: RUN(16); break; case 32: RUN(32); break;
+    case 100: hipLaunchKernelGGL((msda_fwd_tile_f32<32, 3, 4, true, 2, 4, QB, 0>), grid, dim3(256), 0, (hipStream_t)stream, value, shapes, ls, off, off_stride, lg, lg_stride, ref, nref, S, M, Lq, out, nullptr, nullptr, 0); break;
+    case 101: hipLaunchKernelGGL((msda_fwd_tile_f32<32, 3, 4, true, 2, 1, QB, 0>), grid, dim3(256), 0, (hipStream_t)stream, value, shapes, ls, off, off_stride, lg, lg_stride, ref, nref, S, M, Lq, out, nullptr, nullptr, 0); break;
     default: return 1;
   }
   return hipGetLastError() == hipSuccess ? 0 : 2;
