@@ -70,7 +70,10 @@ def main():
         f = lambda x, y: float((x[0][ci]["masks"] != y[0][ci]["masks"]).float().mean()) if x[0][ci]["masks"].numel() else 0.
         print(f"  rank {rank} clip {ci} frames {own2[0][ci]['fr']}: pixels run-to-run {f(own1, own2):.2e}, "
               f"owner vs replicated {f(own2, repl):.2e}, ids {own2[0][ci]['ids']} / {repl[0][ci]['ids']}", flush=True)
-    same = s1 and d1 <= 1e-3      # run-to-run noise (library kernels with atomics) is 3e-6 .. 1e-4
+    # run-to-run noise (library kernels with atomics) is 3e-6 .. 1e-4; the owner's and the replicated tracker are different
+    # hipGraph captures (the library may pick other GEMM algorithms) and the tracker feeds its own output back 6 layers x T
+    # frames: 1e-4 .. 1e-3 observed on embeddings of order 1.  Segment lists and ids must be EQUAL.
+    same = s1 and d1 <= 5e-3
     flag = torch.tensor([0 if same else 1], device=dev if dist.get_backend() == 'nccl' else 'cpu')
     dist.all_reduce(flag)
     os.makedirs(args.out, exist_ok=True)
