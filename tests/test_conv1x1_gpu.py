@@ -61,3 +61,26 @@ def test_unsupported_shapes_take_the_library_path(monkeypatch):
     with torch.no_grad():
         out = conv1x1_bias_act(x.to(DEV), w.to(DEV), b.to(DEV), None, True).cpu()
     torch.testing.assert_close(out, F.conv2d(x, w, b).relu(), rtol=1e-4, atol=1e-4)
+
+
+def test_repeated_launches_agree():
+    """Regression: with the row offset in the SCALAR offset field of the 16-byte stores, dword 0 of lanes 12-15 of a row was
+    stored with the next row's value in most — not all — launches of this shape (an unpadded store-data hazard, DESIGN.md
+    section 3.6b).  50 launches, every one compared."""
+    from dvis_plus_amd.functions import conv1x1_bias_act, mask_logits
+    N, K, M, H, W = 2, 256, 64, 24, 40
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(N, K, H, W, generator=g).to(DEV)
+    w = (torch.randn(M, K, 1, 1, generator=g) / 16).to(DEV)
+    b = torch.randn(M, generator=g).to(DEV)
+    with torch.no_grad():
+        ref = F.conv2d(x.double(), w.double(), b.double()).float()
+        for it in range(50):
+            out = conv1x1_bias_act(x, w, b, None, False)
+            bad = int(((out - ref).abs() > 1e-3).sum())
+            assert bad == 0, f"launch {it}: {bad} elements off"
+        # the mask contraction stores 16-byte pieces the same way
+        e, f = torch.randn(2, 100, 256, device=DEV), torch.randn(2, 256, 24, 40, device=DEV)
+        want = torch.einsum("bqc,bchw->bqhw", e.double(), f.double()).float()
+        for it in range(20):
+            assert int(((mask_logits(e, f) - want).abs() > 1e-3).sum()) == 0
