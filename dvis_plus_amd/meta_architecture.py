@@ -489,9 +489,28 @@ class DVIS_Plus_offline(_VideoBase):
         # DVIS_ROUND_CLIPS: development aid — clips per round on a single GPU (exercises the merged segmenter batch)
         per_round = int(os.environ.get("DVIS_ROUND_CLIPS", "0")) or (self.clip_shard.world if self.owner_rounds else 1)
 
+        def two_streams_safe(sts):
+            """Phase B next to the following round's phase A only for rounds of the proven size.  Two library GEMMs of
+            the stream-K kind in flight on two streams can wait for each other forever (reproduced
+            without the model), and which shapes the library serves with such kernels is its heuristic's business: at
+            T = 30 (the headline configuration: hundreds of streamed runs, profiler attached or not) none of the side
+            stream's GEMMs is one; at T = 64 — the refiner's (64 x 100)-row layers — a streamed run stalled about once in
+            ten, also with the segmenter cut into 32-frame calls.  Longer clips / larger rounds therefore run phase B
+            on the main stream, behind the next round's phase A: same results, no overlap, nothing to wait on."""
+            limit = int(os.environ.get("DVIS_STREAM_OVERLAP_FRAMES", "32"))
+            return all(st["T"] <= limit for st in sts) and sum(st["hi"] - st["lo"] for st in sts) <= limit
+
         def phase_b(sts):
-            if not overlap:
-                return self._track_round(sts)
+            if not overlap or not two_streams_safe(sts):
+                if overlap:
+                    main.wait_stream(side)          # an earlier (overlapped) round may still be on the side stream
+                outs = self._track_round(sts)
+                if overlap:
+                    ready = torch.cuda.Event(enable_timing=self.stream_timing)
+                    ready.record(main)
+                    for out in outs:
+                        out["ready_event"] = ready
+                return outs
             with torch.cuda.stream(side):
                 for st in sts:
                     side.wait_event(st["done"])

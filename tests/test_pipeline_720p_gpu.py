@@ -110,6 +110,8 @@ def test_t64_clips_stream_in_capped_segmenter_calls():
     4.7 GiB activation (the encoder's FFN hidden tensor); batches above 4 GiB are cut into equal calls
     (segmenter_frames_per_call: 2 x 32 frames) because two such passes in flight on two streams stopped making progress
     on MI355X / ROCm 7.2 (a 32-bit overflow in the FFN path was excluded, tools/exp/overflow_probe.py).
+    Since the second half of round 2 stream() also keeps such clips (T > 32) off the second stream: phase B runs on the
+    main stream behind the next clip's phase A (the capped calls alone still stalled about once in ten streamed runs).
     Streamed == clip by clip (up to the run-to-run noise of library kernels), and the cap is what is in effect."""
     import bench
     from dvis_plus_amd.meta_architecture import segmenter_frames_per_call
