@@ -492,11 +492,11 @@ class DVIS_Plus_offline(_VideoBase):
         def two_streams_safe(sts):
             """Phase B next to the following round's phase A only for rounds of the proven size.  Two library GEMMs of
             the stream-K kind in flight on two streams can wait for each other forever (reproduced
-            without the model), and which shapes the library serves with such kernels is its heuristic's business: at
-            T = 30 (the headline configuration: hundreds of streamed runs, profiler attached or not) none of the side
-            stream's GEMMs is one; at T = 64 — the refiner's (64 x 100)-row layers — a streamed run stalled about once in
-            ten, also with the segmenter cut into 32-frame calls.  Longer clips / larger rounds therefore run phase B
-            on the main stream, behind the next round's phase A: same results, no overlap, nothing to wait on."""
+            without the model; most of the pipeline's library GEMMs are such kernels, on both streams).  Whether two of
+            them meet that way depends on shapes and timing: T = 30 (the headline configuration) has not stalled in
+            hundreds of streamed runs, profiler attached or not; T = 64 stalled about once in ten, also with the segmenter
+            cut into 32-frame calls.  Longer clips / larger rounds therefore run phase B on the main stream, behind
+            the next round's phase A: same results, no overlap, nothing to wait on."""
             limit = int(os.environ.get("DVIS_STREAM_OVERLAP_FRAMES", "32"))
             return all(st["T"] <= limit for st in sts) and sum(st["hi"] - st["lo"] for st in sts) <= limit
 
