@@ -119,9 +119,15 @@ class MSDeformAttn(nn.Module):
         so, aw = self.sampling_offsets, self.attention_weights
         key = (so.weight._version, so.bias._version, aw.weight._version, aw.bias._version, so.weight.device)
         if self._fused is None or self._fused[0] != key:
-            w = torch.cat([so.weight.detach(), aw.weight.detach()], 0).contiguous()
-            b = torch.cat([so.bias.detach(), aw.bias.detach()], 0).contiguous()
-            self._fused = (key, w, b)
+            w = torch.cat([so.weight.detach(), aw.weight.detach()], 0)
+            b = torch.cat([so.bias.detach(), aw.bias.detach()], 0)
+            # zero rows up to a multiple of 64 output columns: the library's GEMM for (579 600 x 256) x (256 x 288) runs
+            # at 97 TFLOP/s, for 320 columns at 118 (974 -> 829 us per encoder layer at 30 frames of 720p)
+            pad = -w.shape[0] % 64
+            if pad:
+                w = torch.cat([w, w.new_zeros(pad, w.shape[1])], 0)
+                b = torch.cat([b, b.new_zeros(pad)], 0)
+            self._fused = (key, w.contiguous(), b.contiguous())
         return self._fused[1], self._fused[2]
 
     def _fast_path_ok(self, query, reference_points, input_padding_mask):
@@ -151,13 +157,14 @@ class MSDeformAttn(nn.Module):
             po = pl = None
             if query_pos is not None and query_pos.shape[0] == 1 and _POS_IN_KERNEL:
                 pp = F.linear(query_pos[0], w)                                     # (Lq, 3*M*L*P): tiny, once per call
-                po, pl = pp[:, :n_off], pp[:, n_off:]
+                po, pl = pp[:, :n_off], pp[:, n_off:n_off + M * L * P]
             elif query_pos is not None:
                 query = query + query_pos
             proj = F.linear(query.reshape(N * Len_q, self.d_model), w, b)          # offsets | logits in one GEMM
             ref = reference_points if reference_points.is_contiguous() else reference_points.contiguous()
             output = Fn.msda_fused_forward(value, input_spatial_shapes, input_level_start_index, ref,
-                                           proj[:, :n_off], proj[:, n_off:], L, P, shapes_host=spatial_shapes_py,
+                                           proj[:, :n_off], proj[:, n_off:n_off + M * L * P], L, P,
+                                           shapes_host=spatial_shapes_py,
                                            pos_offsets=po, pos_logits=pl)
             return self.output_proj(output)
         if query_pos is not None:
