@@ -1,0 +1,252 @@
+// Deterministic exact-fp32 GEMM  C = act(A W^T + bias + res)  — gfx950, v_mfma_f32_16x16x4_f32.
+//
+// Replaces, on the tracker / refiner stream, every library GEMM behind
+//   nn.MultiheadAttention in / out projections, FFN linear1 / linear2, MLP layers     dvis_Plus/tracker.py:293-318,
+//                                                                                       dvis_Plus/refiner.py:104-139
+//   the cosine cost matrices of Noiser.match_embds (a batched A B^T)                   dvis_Plus/noiser.py:43-56
+//   nn.Conv1d(k = 5 / 3, replicate 'same' padding) of the refiner as an im2col GEMM    dvis_Plus/refiner.py:42-54,116-119
+// Why own code for "plain library GEMMs": stream() overlaps the tracker / refiner of clip i with the segmenter of clip
+// i + 1 on two HIP streams, and two hipBLASLt stream-K kernels in flight on two streams can spin on each other forever
+// (a stream-K workgroup waits for partial tiles of peers that only become resident when the other
+// kernel's spinning workgroups leave).  A kernel here never waits for another workgroup, so whatever the library runs
+// on the other stream always gets the CUs it waits for.  Second reason: run-to-run reproducibility — no atomics, no
+// data-dependent split; the summation order of every output element is a function of (M, N, K, configuration) only.
+//
+// Work decomposition (not a classic LDS-staged tile GEMM): a workgroup owns a (16 RT) x (16 CT) tile of C and SPLITS K
+// OVER ITS NW WAVES.  A wave's operand fragments are then needed by no other wave of the workgroup, so they go from
+// global memory (L2 / MALL-resident weights and activations) straight into the MFMA operand layout — lane (i, g) loads
+// 16 bytes = k-values 16 s + 4 g .. + 3 of row i of a 16-row tile, a 16-lane group reads 64 contiguous bytes of a row,
+// the k-group index goes into the buffer load's SCALAR offset — with no LDS staging and no barrier in the main loop;
+// PF k-groups of fragments are in flight per wave.  The K index inside a 16-group is permuted (MFMA c of a group sums
+// k = 16 s + 4 g + c over the lane groups g), identically for both operands.  The NW partial tiles meet in LDS once, are
+// summed in wave order by all threads, and leave through the epilogue (bias, residual, ReLU) as 16-byte stores.
+// Rows / columns past M / N and k past K read zeros through the buffer descriptor's range check (no clamped re-reads).
+#include "dvis_common.h"
+
+namespace {
+
+constexpr unsigned kOOB = 0x80000000u;   // + any in-tile offset stays out of range without wrapping (tiles < 2 GiB)
+
+struct GemmArgs {
+  const float *A, *W, *bias, *res;
+  float *C;
+  long long lda, ldw, ldres, ldc;          // row strides in floats
+  long long sA, sW, sRes, sC;              // batch strides in floats
+  int M, N, K, act, row_blocks, vec_store;
+};
+
+template <int RT, int CT, int NW, int PF, bool K16>
+__global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GemmArgs p) {
+  extern __shared__ float lds[];   // [NW][16 RT][16 CT] partial tiles
+  constexpr int BM = 16 * RT, BN = 16 * CT, T = 64 * NW;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int rb = blockIdx.x % p.row_blocks, cb = blockIdx.x / p.row_blocks;
+  const int row0 = rb * BM, col0 = cb * BN;
+  const long long batch = blockIdx.y;
+
+  // ---- descriptors over exactly this tile's rows of A / W: anything outside reads 0
+  const int rows_a = min(BM, p.M - row0), rows_w = min(BN, p.N - col0);
+  const float *Ab = p.A + batch * p.sA + (long long)row0 * p.lda;
+  const float *Wb = p.W + batch * p.sW + (long long)col0 * p.ldw;
+  const __amdgpu_buffer_rsrc_t ra = dvis_make_rsrc_uniform(Ab, (unsigned)((((long long)rows_a - 1) * p.lda + p.K) * 4));
+  const __amdgpu_buffer_rsrc_t rw = dvis_make_rsrc_uniform(Wb, (unsigned)((((long long)rows_w - 1) * p.ldw + p.K) * 4));
+  unsigned aoff[RT], woff[CT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) aoff[rt] = (unsigned)((rt * 16 + i) * p.lda * 4 + g * 16);
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) woff[ct] = (unsigned)((ct * 16 + i) * p.ldw * 4 + g * 16);
+
+  // ---- this wave's k-groups (16 k each)
+  const int G = (p.K + 15) >> 4;
+  const int g0 = (int)((long long)G * wv / NW), g1 = (int)((long long)G * (wv + 1) / NW);
+
+  dvis_f4 a[PF][RT], w[PF][CT];
+  auto load = [&](int slot, int grp) {   // grp is wave-uniform
+    const bool in = grp < g1;            // (never both offsets out of range: 2^31 + 2^31 wraps to 0)
+    const unsigned so = in ? (unsigned)grp * 64u : 0u;
+    const bool kv = in && (K16 || grp * 16 + g * 4 < p.K);   // K % 4 == 0: a 16-byte piece is all in or all out
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+      a[slot][rt] = __builtin_bit_cast(
+          dvis_f4, __builtin_amdgcn_raw_buffer_load_b128(ra, kv ? aoff[rt] : kOOB, so, 0));
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+      w[slot][ct] = __builtin_bit_cast(
+          dvis_f4, __builtin_amdgcn_raw_buffer_load_b128(rw, kv ? woff[ct] : kOOB, so, 0));
+  };
+
+  dvis_f4 acc[RT][CT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = dvis_f4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int s = 0; s < PF; ++s) load(s, g0 + s);
+#pragma unroll 1
+  for (int grp = g0; grp < g1; grp += PF) {
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+      if (grp + s < g1) {   // wave-uniform: the padding groups of the last round hold zeros, skip their MFMAs
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+              acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][rt][c], w[s][ct][c], acc[rt][ct], 0, 0, 0);
+      }
+      if (grp + s + PF < g1) load(s, grp + s + PF);   // uniform
+    }
+  }
+
+  // ---- partial tiles meet in LDS.  Accumulator layout: column = lane & 15, row = (lane >> 4) * 4 + reg.
+  float *mine = lds + wv * (BM * BN);
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[(rt * 16 + g * 4 + r) * BN + ct * 16 + i] = acc[rt][ct][r];
+  __syncthreads();
+
+  // ---- sum in wave order, epilogue, store: one 16-byte unit per thread and round
+  constexpr int U = BM * BN / 4, UR = BN / 4;
+  float *Cb = p.C + batch * p.sC;
+  const float *Rb = p.res ? p.res + batch * p.sRes : nullptr;
+#pragma unroll
+  for (int u0 = 0; u0 < U; u0 += T) {
+    const int u = u0 + tid;
+    if (U % T != 0 && u >= U) break;
+    const int row = u / UR, c4 = (u - row * UR) * 4;
+    dvis_f4 s = *reinterpret_cast<const dvis_f4 *>(lds + row * BN + c4);
+#pragma unroll
+    for (int k = 1; k < NW; ++k) {
+      const dvis_f4 t = *reinterpret_cast<const dvis_f4 *>(lds + k * (BM * BN) + row * BN + c4);
+      s = dvis_f4{s[0] + t[0], s[1] + t[1], s[2] + t[2], s[3] + t[3]};
+    }
+    const int gr = row0 + row, gc = col0 + c4;
+    if (gr >= p.M || gc >= p.N) continue;
+    float *dst = Cb + (long long)gr * p.ldc + gc;
+    if (p.vec_store) {   // N % 4 == 0, 16-byte aligned rows of C / bias / res
+      if (p.bias) {
+        const dvis_f4 b = *reinterpret_cast<const dvis_f4 *>(p.bias + gc);
+        s = dvis_f4{s[0] + b[0], s[1] + b[1], s[2] + b[2], s[3] + b[3]};
+      }
+      if (Rb) {
+        const dvis_f4 t = *reinterpret_cast<const dvis_f4 *>(Rb + (long long)gr * p.ldres + gc);
+        s = dvis_f4{s[0] + t[0], s[1] + t[1], s[2] + t[2], s[3] + t[3]};
+      }
+      if (p.act) s = dvis_f4{fmaxf(s[0], 0.f), fmaxf(s[1], 0.f), fmaxf(s[2], 0.f), fmaxf(s[3], 0.f)};
+      *reinterpret_cast<dvis_f4 *>(dst) = s;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (gc + e >= p.N) break;
+        float v = s[e];
+        if (p.bias) v += p.bias[gc + e];
+        if (Rb) v += Rb[(long long)gr * p.ldres + gc + e];
+        if (p.act) v = fmaxf(v, 0.f);
+        dst[e] = v;
+      }
+    }
+  }
+}
+
+struct Config {
+  int rt, ct, nw;
+  void (*kernel16)(const GemmArgs);
+  void (*kernel4)(const GemmArgs);
+};
+
+#define DVIS_GEMM_CFG(RT_, CT_, NW_, PF_) \
+  { RT_, CT_, NW_, gemm_nt_kernel<RT_, CT_, NW_, PF_, true>, gemm_nt_kernel<RT_, CT_, NW_, PF_, false> }
+const Config kConfigs[] = {
+    DVIS_GEMM_CFG(1, 1, 4, 4),   // 0: 16 x 16
+    DVIS_GEMM_CFG(1, 1, 8, 4),   // 1
+    DVIS_GEMM_CFG(2, 1, 8, 4),   // 2: 32 x 16
+    DVIS_GEMM_CFG(2, 2, 4, 4),   // 3: 32 x 32
+    DVIS_GEMM_CFG(2, 2, 8, 2),   // 4
+    DVIS_GEMM_CFG(4, 1, 8, 4),   // 5: 64 x 16
+    DVIS_GEMM_CFG(4, 2, 4, 2),   // 6: 64 x 32
+    DVIS_GEMM_CFG(4, 2, 8, 2),   // 7
+    DVIS_GEMM_CFG(4, 4, 4, 2),   // 8: 64 x 64
+    DVIS_GEMM_CFG(4, 4, 2, 2),   // 9
+    DVIS_GEMM_CFG(7, 1, 8, 2),   // 10: 112 x 16 (all rows of a 100-query block)
+    DVIS_GEMM_CFG(7, 2, 4, 2),   // 11: 112 x 32
+};
+constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
+
+// Tile configuration from the problem size alone (so that a shape always runs the same summation order).
+int pick_config(int M, int N, int K, int batch) {
+  auto wgs = [&](int c) {
+    const long long rb = (M + 16 * kConfigs[c].rt - 1) / (16 * kConfigs[c].rt);
+    const long long cb = (N + 16 * kConfigs[c].ct - 1) / (16 * kConfigs[c].ct);
+    return rb * cb * batch;
+  };
+  // the largest tile that still gives every CU a workgroup; below that, smaller tiles with a deeper K split
+  if (wgs(8) >= 256) return 8;
+  if (wgs(6) >= 256) return 6;
+  if (wgs(3) >= 192) return K >= 1024 ? 4 : 3;
+  if (wgs(2) >= 96) return 2;
+  return K >= 256 ? 1 : 0;
+}
+
+}  // namespace
+
+DVIS_EXPORT int dvis_gemm_num_configs(void) { return kNumConfigs; }
+
+DVIS_EXPORT int dvis_gemm_nt(const float *A, int64_t lda, int64_t strideA, const float *W, int64_t ldw, int64_t strideW,
+                             const float *bias, const float *res, int64_t ldres, int64_t strideRes, float *C,
+                             int64_t ldc, int64_t strideC, int M, int N, int K, int batch, int act, int config,
+                             void *stream) {
+  DVIS_REQUIRE(M >= 0 && N >= 0 && K > 0 && batch >= 0, "gemm_nt: bad sizes (M=%d N=%d K=%d batch=%d)", M, N, K, batch);
+  if (M == 0 || N == 0 || batch == 0) return DVIS_OK;
+  DVIS_REQUIRE(A && W && C, "gemm_nt: null pointer");
+  DVIS_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && strideA % 4 == 0 && strideW % 4 == 0 &&
+                   ((uintptr_t)A | (uintptr_t)W) % 16 == 0,
+               "gemm_nt: needs K, lda, ldw, batch strides %% 4 == 0 and 16-byte aligned A / W (K=%d lda=%lld ldw=%lld)", K,
+               (long long)lda, (long long)ldw);
+  DVIS_REQUIRE(lda >= K && ldw >= K && ldc >= N && (!res || ldres >= N), "gemm_nt: row strides shorter than the rows");
+  DVIS_REQUIRE(batch <= 65535, "gemm_nt: batch <= 65535");
+  const int c = config >= 0 ? config : pick_config(M, N, K, batch);
+  DVIS_REQUIRE(c < kNumConfigs, "gemm_nt: configuration %d does not exist", c);
+  const Config &cf = kConfigs[c];
+  const int BM = 16 * cf.rt, BN = 16 * cf.ct;
+  DVIS_REQUIRE((long long)BM * lda * 4 < (1ll << 31) && (long long)BN * ldw * 4 < (1ll << 31),
+               "gemm_nt: one tile's rows must span less than 2 GiB");
+  GemmArgs p;
+  p.A = A, p.W = W, p.bias = bias, p.res = res, p.C = C;
+  p.lda = lda, p.ldw = ldw, p.ldres = ldres, p.ldc = ldc;
+  p.sA = strideA, p.sW = strideW, p.sRes = strideRes, p.sC = strideC;
+  p.M = M, p.N = N, p.K = K, p.act = act;
+  p.row_blocks = (M + BM - 1) / BM;
+  p.vec_store = N % 4 == 0 && ldc % 4 == 0 && strideC % 4 == 0 && (uintptr_t)C % 16 == 0 &&
+                (!bias || (uintptr_t)bias % 16 == 0) &&
+                (!res || (ldres % 4 == 0 && strideRes % 4 == 0 && (uintptr_t)res % 16 == 0));
+  const long long col_blocks = (N + BN - 1) / BN;
+  const long long tiles = p.row_blocks * col_blocks;
+  DVIS_REQUIRE(tiles < (1ll << 31), "gemm_nt: too many tiles");
+  const size_t lds = (size_t)cf.nw * BM * BN * sizeof(float);
+  auto kernel = K % 16 == 0 ? cf.kernel16 : cf.kernel4;
+  if (lds > 64 * 1024) {   // > 64 KB of dynamic LDS needs an opt-in per kernel AND per device
+    int dev = 0;
+    hipGetDevice(&dev);
+    static unsigned long long opted[kNumConfigs][2] = {};   // bit d: done on device d (devices >= 64: every call)
+    unsigned long long &bits = opted[c][K % 16 == 0 ? 0 : 1];
+    if (dev >= 64 || !((__atomic_load_n(&bits, __ATOMIC_RELAXED) >> dev) & 1ull)) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) {
+        dvis_set_error("gemm_nt: hipFuncSetAttribute(max dynamic LDS = %zu): %s", lds, hipGetErrorString(e));
+        return DVIS_E_LAUNCH;
+      }
+      if (dev < 64) __atomic_fetch_or(&bits, 1ull << dev, __ATOMIC_RELAXED);
+    }
+  }
+  hipLaunchKernelGGL(kernel, dim3((unsigned)tiles, (unsigned)batch), dim3(64 * cf.nw), lds, (hipStream_t)stream, p);
+  return dvis_check_launch("gemm_nt_kernel");
+}

@@ -456,11 +456,86 @@ def upsample_add(lateral, top, lat_affine=None):
     return out
 
 
-def linear(x, weight, bias=None, relu=False):
-    """``F.linear`` (+ optional ReLU) on the library GEMM; with a bias the ReLU runs as the GEMM's epilogue (hipBLASLt
-    via torch._addmm_activation) instead of a second pass.  (A hand-written latency-optimised MFMA kernel for the
-    tracker's 100-row GEMMs was measured and dropped: 5.8-22 us vs the library's 6.0-7.6 us — it is L2-bandwidth
-    bound without the library's macro-tile reuse.)"""
+# Library GEMMs or the own deterministic kernel (dvis_gemm_nt)?  The tracker / refiner ALWAYS take the own kernel
+# (own=True at their call sites: their stream must never carry a library stream-K kernel, csrc/gemm.hip); everything
+# else follows this switch.  DVIS_DETERMINISTIC=1: every GEMM of the pipeline that goes through this module is the own
+# kernel -> two runs of a clip give bit-identical tensors (the library's split / stream-K kernels do not promise that).
+OWN_GEMM_DEFAULT = os.environ.get("DVIS_DETERMINISTIC", "0") == "1"
+
+
+def _rows2d(x, K):
+    """(..., K) tensor -> (2-D view (M, K) with unit inner stride, row stride in floats); copies only when the leading
+    dims do not collapse into one stride."""
+    if x.dim() == 2 and x.stride(1) == 1 and x.stride(0) >= K:
+        return x, x.stride(0)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    return x.view(-1, K), K
+
+
+def gemm_nt(a, w, bias=None, relu=False, res=None, config=-1):
+    """``relu?(a @ w.T + bias + res)`` on the deterministic exact-fp32 MFMA kernel (dvis_gemm_nt).  a (..., K) float32 GPU
+    tensor (rows with unit inner stride; a row-sliced 2-D view keeps its row stride), w (N, K) in F.linear's layout (row
+    stride >= K allowed), bias (N) or None, res (..., N) or None.  Returns (..., N).  Raises when the kernel cannot serve
+    the operands (K or a row stride not a multiple of 4, unaligned base) — there is no silent library fallback here."""
+    K = a.shape[-1]
+    N = w.shape[0]
+    if not (a.is_cuda and a.dtype == torch.float32 and w.dtype == torch.float32 and w.dim() == 2 and w.shape[1] == K
+            and w.stride(1) == 1):
+        raise RuntimeError("gemm_nt: needs float32 GPU operands a (..., K), w (N, K) with unit inner strides")
+    a2, lda = _rows2d(a, K)
+    M = a2.shape[0]
+    out = torch.empty((*a.shape[:-1], N), dtype=torch.float32, device=a.device)
+    rp, ldres = None, 0
+    if res is not None:
+        if res.shape != out.shape or res.dtype != torch.float32 or not res.is_cuda:
+            raise RuntimeError("gemm_nt: res must be a float32 GPU tensor of the output's shape")
+        r2, ldres = _rows2d(res, N)
+        rp = ctypes.c_void_p(r2.data_ptr())
+    bp = None
+    if bias is not None:
+        if bias.dtype != torch.float32 or bias.numel() != N or not bias.is_contiguous():
+            raise RuntimeError("gemm_nt: bias must be a contiguous float32 (N,) tensor")
+        bp = ctypes.c_void_p(bias.data_ptr())
+    with torch.cuda.device(a.device):
+        rc = native.lib().dvis_gemm_nt(ctypes.c_void_p(a2.data_ptr()), lda, 0, ctypes.c_void_p(w.data_ptr()), w.stride(0), 0,
+                                       bp, rp, ldres, 0, ctypes.c_void_p(out.data_ptr()), N, 0, M, N, K, 1,
+                                       1 if relu else 0, config, native.stream_ptr(a.device))
+    native.check(rc, "dvis_gemm_nt")
+    return out
+
+
+def bmm_nt(a, b, config=-1):
+    """Batched ``a @ b.transpose(1, 2)`` on dvis_gemm_nt: a (B, M, K), b (B, N, K) contiguous float32 GPU -> (B, M, N)."""
+    B, M, K = a.shape
+    N = b.shape[1]
+    if not (a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and b.shape == (B, N, K)):
+        raise RuntimeError("bmm_nt: needs float32 GPU operands a (B, M, K), b (B, N, K)")
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty((B, M, N), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        rc = native.lib().dvis_gemm_nt(ctypes.c_void_p(a.data_ptr()), K, M * K, ctypes.c_void_p(b.data_ptr()), K, N * K, None,
+                                       None, 0, 0, ctypes.c_void_p(out.data_ptr()), N, M * N, M, N, K, B, 0, config,
+                                       native.stream_ptr(a.device))
+    native.check(rc, "dvis_gemm_nt")
+    return out
+
+
+def _own_gemm_ok(x, weight):
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and not torch.is_grad_enabled()
+            and x.shape[-1] % 4 == 0 and weight.stride(-1) == 1 and weight.stride(0) % 4 == 0
+            and weight.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
+
+
+def linear(x, weight, bias=None, relu=False, own=None):
+    """``F.linear`` (+ optional ReLU).  own=True: the deterministic own kernel (tracker / refiner call sites); own=None:
+    OWN_GEMM_DEFAULT decides; otherwise the library GEMM — with a bias the ReLU then runs as the GEMM's epilogue
+    (hipBLASLt via torch._addmm_activation) instead of a second pass.  CPU tensors / autograd always take torch ops."""
+    own = OWN_GEMM_DEFAULT if own is None else own
+    if own and x.is_cuda and not torch.is_grad_enabled():
+        if _own_gemm_ok(x, weight):
+            return gemm_nt(x, weight.detach(), None if bias is None else bias.detach(), relu=relu)
+        _torch_path("linear(own GEMM)", x, "needs fp32, K % 4 == 0 and 16-byte aligned operands")
     if relu and bias is not None and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled():
         K = x.shape[-1]
         y = torch._addmm_activation(bias, x.reshape(-1, K), weight.t(), use_gelu=False)
@@ -469,9 +544,9 @@ def linear(x, weight, bias=None, relu=False):
     return torch.relu(y) if relu else y
 
 
-def linear_relu(x, lin):
+def linear_relu(x, lin, own=None):
     """relu(lin(x)) for an ``nn.Linear``."""
-    return linear(x, lin.weight, lin.bias, relu=True)
+    return linear(x, lin.weight, lin.bias, relu=True, own=own)
 
 
 def maps_to_tokens(maps, affines=None, pos=None):

@@ -80,3 +80,24 @@ class FusedKV:
                 self._W, self._b = W.contiguous(), b.contiguous()
             self._key = (ver, dev)
         return self._W, self._b
+
+
+class ConvAsGemm:
+    """nn.Conv1d weights (Co, Ci, k) re-laid as the (Co, k * Ci) matrix of the im2col GEMM (column = tap * Ci + channel),
+    cached per module and — like FusedKV — refreshed IN PLACE when the parameter changes, because captured hipGraphs
+    point at the cached tensor."""
+
+    def __init__(self):
+        self._cache = {}
+
+    def get(self, conv):
+        w = conv.weight
+        key = (w._version, w.data_ptr(), w.device)
+        ent = self._cache.get(id(conv))
+        if ent is None or ent[0] != key:
+            W = w.detach().permute(0, 2, 1).reshape(w.shape[0], -1).contiguous()
+            if ent is not None and ent[1].device == W.device and ent[1].shape == W.shape:
+                ent[1].copy_(W)
+                W = ent[1]
+            self._cache[id(conv)] = ent = (key, W)
+        return ent[1]

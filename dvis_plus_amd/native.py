@@ -49,6 +49,8 @@ SIGNATURES = {
     "dvis_resize2": (_i, [_p, _i64, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "dvis_lsap_solve": (_i, [_p, _i, _i, _p]),
     "dvis_match_chain": (_i, [_p, _i, _i, _p]),
+    "dvis_gemm_nt": (_i, [_p, _i64, _i64, _p, _i64, _i64, _p, _p, _i64, _i64, _p, _i64, _i64, _i, _i, _i, _i, _i, _i, _p]),
+    "dvis_gemm_num_configs": (_i, []),
 }
 
 _lib = None

@@ -4,6 +4,10 @@ Mirrors ``TemporalRefiner`` (dvis_Plus/refiner.py:6-227): constructor arguments,
 and returned dict (eval branch: last layer only, window-free).
 
 MI355X re-organisation:
+  * one activation layout (T, Q, C) for all four sub-layers: the attention kernel takes row / batch strides, so "over
+    time" and "over queries" are two views of the same buffer (the reference permutes + copies between them), and the
+    short-aggregate nn.Conv1d pair runs as im2col GEMMs over clamped time indices (= replicate padding);
+  * every projection runs on the deterministic own GEMM (csrc/gemm.hip): no library kernel on the refiner's stream;
   * the K / V projections of the 6 cross-attention layers over the frame queries are one GEMM;
   * time / object / cross attention run on the fp32-MFMA attention kernel;
   * mask_features never leave HBM: the reference moves every window of them host->device and every mask
@@ -15,7 +19,8 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import functions as Fn
-from .graphs import FusedKV, GraphRunner
+from .graphs import ConvAsGemm, FusedKV, GraphRunner
+from .tracker import use_own_gemm
 from .transformer_decoder import MLP, CrossAttentionLayer, FFNLayer, SelfAttentionLayer
 
 
@@ -53,40 +58,69 @@ class TemporalRefiner(nn.Module):
         self.mask_embed = MLP(hidden_channel, hidden_channel, mask_dim, 3)
         self.activation_proj = nn.Linear(hidden_channel, 1)
         self._kv_cache = FusedKV()
+        self._conv_weights = ConvAsGemm()
         self.use_graphs = True
         self._graph = GraphRunner(self.refine)
+        use_own_gemm(self)
 
     def _kv_weights(self):
         return self._kv_cache.get(self.transformer_cross_attention_layers, self.decoder_norm.weight.shape[0])
 
+    def _attention(self, q, k, v, over_time):
+        """q / k / v: (T, Q, C) views with unit inner stride.  over_time: sequences run over T (one per query slot),
+        otherwise over Q (one per frame).  -> (T, Q, C) contiguous.  The attention kernel takes row / batch strides, so
+        the reference's permute + flatten copies between its three layouts (refiner.py:104-139) never happen."""
+        out = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+        if over_time:
+            return Fn.attention(q, k, v, self.num_heads, out=out)
+        Fn.attention(q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1), self.num_heads, out=out.transpose(0, 1))
+        return out
+
+    def _self_attention(self, layer, x, over_time):
+        C = x.shape[-1]
+        qkv = Fn.linear(x, layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias, own=True)
+        att = self._attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], over_time)
+        op = layer.self_attn.out_proj
+        return Fn.add_layer_norm(Fn.linear(att, op.weight, op.bias, own=True), x, layer.norm)
+
+    def _short_aggregate(self, i, x):
+        """``conv1d_k3(relu(conv1d_k5(x)))`` over time with replicate 'same' padding (refiner.py:42-54) on x (T, Q, C):
+        each convolution is one GEMM over the im2col rows [x[t-p], ..., x[t+p]] (time indices clamped = replicate)."""
+        T = x.shape[0]
+        for conv, relu in ((self.conv_short_aggregate_layers[i][0], True), (self.conv_short_aggregate_layers[i][2], False)):
+            k = conv.kernel_size[0]
+            idx = (torch.arange(T, device=x.device)[:, None] + torch.arange(k, device=x.device)[None] - k // 2).clamp_(0, T - 1)
+            cols = x[idx].permute(0, 2, 1, 3).flatten(2)                           # (T, Q, k * C)
+            x = Fn.linear(cols, self._conv_weights.get(conv), conv.bias, relu=relu, own=True)
+        return x
+
     def refine(self, instance_embeds, frame_embeds):
-        """The 6 refinement layers.  (b, c, t, q) x2 -> last layer's queries (t, q, b, c), un-normed."""
+        """The 6 refinement layers.  (b, c, t, q) x2 -> last layer's queries (t, q, b, c), un-normed.  b = 1."""
         B, C, T, Q = instance_embeds.shape
-        output = instance_embeds
-        fe = frame_embeds.permute(3, 0, 2, 1).flatten(1, 2)                        # (q, bt, c)
+        assert B == 1, "inference runs one video at a time"
+        x = instance_embeds[0].permute(1, 2, 0).contiguous()                       # (T, Q, C): the one layout used below
+        fe = frame_embeds[0].permute(1, 2, 0).contiguous()
         W, b = self._kv_weights()
-        kv = F.linear(fe, W, b)                                                    # (q, bt, layers * 2C)
+        kv = Fn.linear(fe, W, b, own=True)                                         # (T, Q, layers * 2C): one GEMM
         for i in range(self.num_layers):
-            output = output.permute(2, 0, 3, 1).flatten(1, 2)                      # (t, bq, c)
-            output = self.transformer_time_self_attention_layers[i](output)
-            output = output.permute(1, 2, 0)                                       # (bq, c, t)
-            output = self.conv_norms[i](
-                (self.conv_short_aggregate_layers[i](output) + output).transpose(1, 2)).transpose(1, 2)
-            output = output.reshape(B, Q, C, T).permute(1, 0, 3, 2).flatten(1, 2)  # (q, bt, c)
-            output = self.transformer_obj_self_attention_layers[i](output)
+            x = self._self_attention(self.transformer_time_self_attention_layers[i], x, over_time=True)
+            x = Fn.add_layer_norm(self._short_aggregate(i, x), x, self.conv_norms[i])
+            x = self._self_attention(self.transformer_obj_self_attention_layers[i], x, over_time=False)
             layer = self.transformer_cross_attention_layers[i]
-            output = layer.attend(output, output, kv[..., (2 * i) * C:(2 * i + 1) * C],
-                                  kv[..., (2 * i + 1) * C:(2 * i + 2) * C])
-            output = self.transformer_ffn_layers[i](output)
-            output = output.reshape(Q, B, T, C).permute(1, 3, 2, 0)                # (b, c, t, q)
-        return output.permute(2, 3, 0, 1)                                          # (t, q, b, c)
+            att = self._attention(layer.project_q(x), kv[..., (2 * i) * C:(2 * i + 1) * C],
+                                  kv[..., (2 * i + 1) * C:(2 * i + 2) * C], over_time=False)
+            op = layer.multihead_attn.out_proj
+            x = Fn.add_layer_norm(Fn.linear(att, op.weight, op.bias, own=True), x, layer.norm)
+            x = self.transformer_ffn_layers[i](x)
+        return x.unsqueeze(2)                                                      # (t, q, b, c)
 
     def pred_class(self, decoder_output):
         """(l, b, t, q, c): softmax-over-time pooled class logits, repeated T times (refiner.py:196-210)."""
         T = decoder_output.size(2)
-        activation = self.activation_proj(decoder_output).softmax(dim=2)
+        ap, ce = self.activation_proj, self.class_embed
+        activation = Fn.linear(decoder_output, ap.weight, ap.bias, own=True).softmax(dim=2)
         class_output = (decoder_output * activation).sum(dim=2, keepdim=True).repeat(1, 1, T, 1, 1)
-        return self.class_embed(class_output).transpose(2, 3)
+        return Fn.linear(class_output, ce.weight, ce.bias, own=True).transpose(2, 3)
 
     def forward(self, instance_embeds, frame_embeds, mask_features, need_masks=True, query_index=None):
         """instance_embeds / frame_embeds (b, c, t, q), mask_features (b, t, c, h, w) device-resident.
@@ -95,6 +129,8 @@ class TemporalRefiner(nn.Module):
         if self.training:
             raise NotImplementedError("dvis_plus_amd implements the refiner's inference path")
         self._kv_weights()
+        for seq in self.conv_short_aggregate_layers:                               # cached GEMM weights, outside capture
+            self._conv_weights.get(seq[0]), self._conv_weights.get(seq[2])
         self._graph.enabled = self.use_graphs
         last = self._graph("refine", instance_embeds.contiguous(), frame_embeds.contiguous()).clone()   # (t, q, b, c)
         dec = self.decoder_norm(last)

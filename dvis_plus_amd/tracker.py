@@ -29,8 +29,18 @@ from .pixel_decoder import c2_xavier_fill
 from .transformer_decoder import MLP, FFNLayer, SelfAttentionLayer, _xavier_
 
 
+def use_own_gemm(module):
+    """Every projection under `module` runs on the deterministic own GEMM (csrc/gemm.hip): the tracker / refiner stream
+    of DVIS_Plus_offline.stream() must never carry a library stream-K kernel, and their results must not depend on the
+    library's run-to-run summation order."""
+    for m in module.modules():
+        if hasattr(m, "own_gemm"):
+            m.own_gemm = True
+
+
 class ReferringCrossAttentionLayer(nn.Module):
     """Cross-attention whose residual comes from `indentify` instead of the query (tracker.py:35-53)."""
+    own_gemm = None
 
     def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False):
         super().__init__()
@@ -43,17 +53,18 @@ class ReferringCrossAttentionLayer(nn.Module):
 
     def attend(self, indentify, tgt, k_proj, v_proj):
         C = tgt.shape[-1]
-        q = Fn.linear(tgt, self.multihead_attn.in_proj_weight[:C], self.multihead_attn.in_proj_bias[:C])
+        q = Fn.linear(tgt, self.multihead_attn.in_proj_weight[:C], self.multihead_attn.in_proj_bias[:C], own=self.own_gemm)
         att = Fn.attention(q, k_proj, v_proj, self.nhead)
         op = self.multihead_attn.out_proj
-        return Fn.add_layer_norm(Fn.linear(att, op.weight, op.bias), indentify, self.norm)
+        return Fn.add_layer_norm(Fn.linear(att, op.weight, op.bias, own=self.own_gemm), indentify, self.norm)
 
     def forward(self, indentify, tgt, key, memory, memory_mask=None, memory_key_padding_mask=None, pos=None,
                 query_pos=None):
         assert memory_mask is None and memory_key_padding_mask is None and pos is None and query_pos is None
         C = tgt.shape[-1]
         W, b = self.multihead_attn.in_proj_weight, self.multihead_attn.in_proj_bias
-        return self.attend(indentify, tgt, F.linear(key, W[C:2 * C], b[C:2 * C]), F.linear(memory, W[2 * C:], b[2 * C:]))
+        return self.attend(indentify, tgt, Fn.linear(key, W[C:2 * C], b[C:2 * C], own=self.own_gemm),
+                           Fn.linear(memory, W[2 * C:], b[2 * C:], own=self.own_gemm))
 
 
 def match_chain(cost):
@@ -73,6 +84,8 @@ def cosine_costs(cur, ref_first):
     nrm = cur / (cur.norm(dim=-1, keepdim=True) + 1e-6)
     r0 = ref_first / (ref_first.norm(dim=-1, keepdim=True) + 1e-6)
     ref = torch.cat([r0[None], nrm[:-1]], 0)
+    if cur.is_cuda and cur.dtype == torch.float32 and cur.shape[-1] % 4 == 0 and not torch.is_grad_enabled():
+        return 1 - Fn.bmm_nt(nrm, ref)                                        # own deterministic GEMM (no library kernel)
     return 1 - torch.bmm(nrm, ref.transpose(1, 2))
 
 
@@ -108,6 +121,7 @@ class ReferringTracker_noiser(nn.Module):
         self._kv_cache = FusedKV()
         self.use_graphs = True
         self._graph = GraphRunner(self._recurrence_entry)
+        use_own_gemm(self)
 
     def _clear_memory(self):
         self.last_outputs = None
@@ -125,7 +139,7 @@ class ReferringTracker_noiser(nn.Module):
         Returns (outputs (T,Q,1,C), references (T,Q,1,C), new last_outputs)."""
         T, Q, B, C = fe_nn.shape
         W, b = self._kv_weights()
-        kv = F.linear(fe_nn, W, b)                                             # (T, Q, 1, layers * 2C): one GEMM
+        kv = Fn.linear(fe_nn, W, b, own=True)                                  # (T, Q, 1, layers * 2C): one GEMM
         outputs, refs = [], []
         for i in range(T):
             single_nn = fe_nn[i]                                               # (q, b, c)
@@ -179,7 +193,7 @@ class ReferringTracker_noiser(nn.Module):
 
         # ---- 4. heads
         dec = self.decoder_norm(outputs)
-        logits = self.class_embed(torch.cat([refs, dec], dim=-1))             # (t, q, b, K+1)
+        logits = Fn.linear(torch.cat([refs, dec], dim=-1), self.class_embed.weight, self.class_embed.bias, own=True)  # (t,q,b,K+1)
         out = {
             "pred_logits": logits.permute(2, 0, 1, 3),
             "pred_masks": None,
@@ -189,7 +203,7 @@ class ReferringTracker_noiser(nn.Module):
         }
         if need_masks:
             b_, t_, cm, h, w = mask_features.shape
-            mf = self.mask_feature_proj(mask_features.flatten(0, 1))           # (t, cm, h, w)
+            mf = self.mask_feature_proj(mask_features.flatten(0, 1))           # (t, cm, h, w); online mode, main stream
             emb = self.mask_embed(dec[:, :, 0, :])                             # (t, q, cm)
             out["pred_masks"] = Fn.mask_logits(emb.contiguous(), mf).permute(1, 0, 2, 3).unsqueeze(0)
         if return_indices:

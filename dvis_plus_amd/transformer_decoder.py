@@ -35,6 +35,8 @@ def _xavier_(module):
 
 
 class SelfAttentionLayer(nn.Module):
+    own_gemm = None      # None: Fn.OWN_GEMM_DEFAULT decides; the tracker / refiner set True on their layers
+
     def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False):
         super().__init__()
         if normalize_before:
@@ -48,18 +50,22 @@ class SelfAttentionLayer(nn.Module):
         assert tgt_mask is None and tgt_key_padding_mask is None
         C = tgt.shape[-1]
         W, b = self.self_attn.in_proj_weight, self.self_attn.in_proj_bias
+        own = self.own_gemm
         if query_pos is None:
-            qkv = Fn.linear(tgt, W, b)
+            qkv = Fn.linear(tgt, W, b, own=own)
             q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
         else:
-            qk = Fn.linear(tgt + query_pos, W[:2 * C], b[:2 * C])
+            qk = Fn.linear(tgt + query_pos, W[:2 * C], b[:2 * C], own=own)
             q, k = qk[..., :C], qk[..., C:]
-            v = Fn.linear(tgt, W[2 * C:], b[2 * C:])
+            v = Fn.linear(tgt, W[2 * C:], b[2 * C:], own=own)
         att = Fn.attention(q, k, v, self.nhead)
-        return Fn.add_layer_norm(Fn.linear(att, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias), tgt, self.norm)
+        op = self.self_attn.out_proj
+        return Fn.add_layer_norm(Fn.linear(att, op.weight, op.bias, own=own), tgt, self.norm)
 
 
 class CrossAttentionLayer(nn.Module):
+    own_gemm = None
+
     def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False):
         super().__init__()
         if normalize_before:
@@ -71,7 +77,8 @@ class CrossAttentionLayer(nn.Module):
 
     def project_q(self, x):
         C = x.shape[-1]
-        return Fn.linear(x, self.multihead_attn.in_proj_weight[:C], self.multihead_attn.in_proj_bias[:C])
+        return Fn.linear(x, self.multihead_attn.in_proj_weight[:C], self.multihead_attn.in_proj_bias[:C],
+                         own=self.own_gemm)
 
     def kv_weights(self):
         C = self.multihead_attn.embed_dim
@@ -83,18 +90,20 @@ class CrossAttentionLayer(nn.Module):
         att = Fn.attention(self.project_q(q_in), k_proj, v_proj, self.nhead, mask, allowed)
         res = tgt if identity is None else identity
         op = self.multihead_attn.out_proj
-        return Fn.add_layer_norm(Fn.linear(att, op.weight, op.bias), res, self.norm)
+        return Fn.add_layer_norm(Fn.linear(att, op.weight, op.bias, own=self.own_gemm), res, self.norm)
 
     def forward(self, tgt, memory, memory_mask=None, memory_key_padding_mask=None, pos=None, query_pos=None):
         assert memory_key_padding_mask is None
         Wk, bk, Wv, bv = self.kv_weights()
-        k = F.linear(memory if pos is None else memory + pos, Wk, bk)
-        v = F.linear(memory, Wv, bv)
+        k = Fn.linear(memory if pos is None else memory + pos, Wk, bk, own=self.own_gemm)
+        v = Fn.linear(memory, Wv, bv, own=self.own_gemm)
         q_in = tgt if query_pos is None else tgt + query_pos
         return self.attend(tgt, q_in, k, v, memory_mask)
 
 
 class FFNLayer(nn.Module):
+    own_gemm = None
+
     def __init__(self, d_model, dim_feedforward=2048, dropout=0.0, activation="relu", normalize_before=False):
         super().__init__()
         if normalize_before:
@@ -105,11 +114,13 @@ class FFNLayer(nn.Module):
         _xavier_(self)
 
     def forward(self, tgt):
-        h = Fn.linear_relu(tgt, self.linear1)
-        return Fn.add_layer_norm(Fn.linear(h, self.linear2.weight, self.linear2.bias), tgt, self.norm)
+        h = Fn.linear_relu(tgt, self.linear1, own=self.own_gemm)
+        return Fn.add_layer_norm(Fn.linear(h, self.linear2.weight, self.linear2.bias, own=self.own_gemm), tgt, self.norm)
 
 
 class MLP(nn.Module):
+    own_gemm = None
+
     def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
         super().__init__()
         self.num_layers = num_layers
@@ -118,7 +129,7 @@ class MLP(nn.Module):
 
     def forward(self, x):
         for i, layer in enumerate(self.layers):
-            x = Fn.linear(x, layer.weight, layer.bias, relu=i < self.num_layers - 1)
+            x = Fn.linear(x, layer.weight, layer.bias, relu=i < self.num_layers - 1, own=self.own_gemm)
         return x
 
 

@@ -38,6 +38,10 @@
  *                               dvis_Plus/meta_architecture.py:954-979
  *   dvis_lsap_solve          <- scipy.optimize.linear_sum_assignment as called by Noiser.match_embds, dvis_Plus/noiser.py:43-56
  *   dvis_match_chain         <- the frame-by-frame matching loop of ReferringTracker_noiser.forward, dvis_Plus/tracker.py:210-291
+ *   dvis_gemm_nt             <- the projections around every attention / FFN block of the tracker and the refiner
+ *                               (nn.MultiheadAttention in/out_proj, linear1/2, MLP: dvis_Plus/tracker.py:293-318,
+ *                               dvis_Plus/refiner.py:104-139), the cosine matrices of Noiser.match_embds (noiser.py:43-56)
+ *                               and the refiner's nn.Conv1d layers as im2col GEMMs (refiner.py:42-54,116-119)
  */
 #ifndef DVIS_HIP_H
 #define DVIS_HIP_H
@@ -290,6 +294,21 @@ int dvis_lsap_solve(const double *cost, int nr, int nc, int64_t *col4row);
  * permutation by the previous frame's assignment is applied inside.  indices (T, Q) int64 out.
  */
 int dvis_match_chain(const float *cost, int T, int Q, int64_t *indices);
+
+/*
+ * Deterministic exact-fp32 GEMM (v_mfma_f32_16x16x4_f32, no atomics, no inter-workgroup waiting):
+ *   C[b][m][n] = act( sum_k A[b][m][k] * W[b][n][k] + bias[n] + res[b][m][n] ),   act = 0: identity, 1: ReLU
+ * A (M x K, row stride lda), W (N x K, row stride ldw) — i.e. F.linear's weight layout —, C (M x N, row stride ldc),
+ * res optional (row stride ldres), bias optional (N); strides in floats; `batch` independent problems at the batch
+ * strides (0 = operand shared by the batch).  Needs K, lda, ldw, strideA, strideW multiples of 4 and 16-byte aligned
+ * A / W (returns DVIS_E_ARG otherwise).  The summation order of an output element depends on (M, N, K, batch, config)
+ * only: two calls with the same arguments return bit-identical results.  config: -1 = chosen from the sizes, else an
+ * index < dvis_gemm_num_configs() (tile / K-split variants; tuning aid).
+ */
+int dvis_gemm_nt(const float *A, int64_t lda, int64_t strideA, const float *W, int64_t ldw, int64_t strideW,
+                 const float *bias, const float *res, int64_t ldres, int64_t strideRes, float *C, int64_t ldc,
+                 int64_t strideC, int M, int N, int K, int batch, int act, int config, void *stream);
+int dvis_gemm_num_configs(void);
 
 #ifdef __cplusplus
 }
