@@ -80,14 +80,12 @@ class MaskFormerHead(nn.Module):
 
 
 def segmenter_frames_per_call(n, H, W, requested=0):
-    """Frames per segmenter call for n frames of H x W input (requested: the user's chunk, 0 = as many as possible).
-    No activation of one call may reach 4 GiB: the largest is the encoder's FFN hidden tensor, 1024 floats for each of
-    the H*W*(1/64 + 1/256 + 1/1024) tokens of a frame = 84 B per input pixel (55 frames at 720p).  Beyond that the
-    streamed schedule (two segmenter passes in flight on two streams) stopped making progress on MI355X / ROCm 7.2
-    (T >= 56; T <= 54, and the clip-by-clip schedule at T = 64, are fine) — not understood, so larger batches are cut
-    into equal calls below the limit (cost: one more launch sequence; T = 64 streams at 183 frames/s as 2 x 32)."""
-    cap = max(1, (2 ** 32 - 1) // (84 * H * W))
-    chunk = min(requested or max(1, n), cap)
+    """Frames per segmenter call for n frames (requested: the user's chunk, 0 = all of them in one call), cut into equal
+    shares.  (Rounds 1-2 capped a call at 4 GiB per activation — 55 frames at 720p — because two segmenter passes in
+    flight on two streams stopped making progress beyond that.  The cause was two hipBLASLt stream-K GEMMs running
+    concurrently; stream() no longer puts a library GEMM on its second stream, so the cap is gone:
+    a 64-frame clip is one call.)"""
+    chunk = min(requested or max(1, n), max(1, n))
     if 0 < chunk < n:
         calls = (n + chunk - 1) // chunk
         chunk = (n + calls - 1) // calls          # equal shares
@@ -478,8 +476,8 @@ class DVIS_Plus_offline(_VideoBase):
         blocks on its host-side steps (assignment chain, VPS statistics).  On the GPU phase B runs on a second stream,
         so the tracker's small, strictly sequential kernels fill in next to the next clips' backbone instead of owning
         the device, and with several ranks every clip of the round has its own tracker rank (_track_round).  Same
-        results as calling forward clip by clip (same kernels, same order per clip); per-clip latency is one round's
-        phase A longer."""
+        results as calling forward clip by clip (same kernels, same order per clip; bit-identical from the per-frame
+        queries onward: phase B is deterministic); per-clip latency is one round's phase A longer."""
         import itertools
         overlap = self.device.type == "cuda"
         main = torch.cuda.current_stream() if overlap else None
@@ -489,28 +487,15 @@ class DVIS_Plus_offline(_VideoBase):
         # DVIS_ROUND_CLIPS: development aid — clips per round on a single GPU (exercises the merged segmenter batch)
         per_round = int(os.environ.get("DVIS_ROUND_CLIPS", "0")) or (self.clip_shard.world if self.owner_rounds else 1)
 
-        def two_streams_safe(sts):
-            """Phase B next to the following round's phase A only for rounds of the proven size.  Two library GEMMs of
-            the stream-K kind in flight on two streams can wait for each other forever (reproduced
-            without the model; most of the pipeline's library GEMMs are such kernels, on both streams).  Whether two of
-            them meet that way depends on shapes and timing: T = 30 (the headline configuration) has not stalled in
-            hundreds of streamed runs, profiler attached or not; T = 64 stalled about once in ten, also with the segmenter
-            cut into 32-frame calls.  Longer clips / larger rounds therefore run phase B on the main stream, behind
-            the next round's phase A: same results, no overlap, nothing to wait on."""
-            limit = int(os.environ.get("DVIS_STREAM_OVERLAP_FRAMES", "32"))
-            return all(st["T"] <= limit for st in sts) and sum(st["hi"] - st["lo"] for st in sts) <= limit
-
         def phase_b(sts):
-            if not overlap or not two_streams_safe(sts):
-                if overlap:
-                    main.wait_stream(side)          # an earlier (overlapped) round may still be on the side stream
-                outs = self._track_round(sts)
-                if overlap:
-                    ready = torch.cuda.Event(enable_timing=self.stream_timing)
-                    ready.record(main)
-                    for out in outs:
-                        out["ready_event"] = ready
-                return outs
+            """Always next to the following round's phase A: everything phase B enqueues is own code that never waits for
+            another workgroup (attention, add+LayerNorm, mask contraction, post-processing kernels, and since round 3
+            every GEMM: csrc/gemm.hip) or a torch element-wise / reduction kernel, so the library's stream-K GEMMs of
+            phase A can never find themselves waiting for CUs held by a peer that waits for them (the two-stream stall
+            of rounds 1-2).  tests/test_stream_gpu.py asserts that no GEMM / convolution library
+            call is issued from here, and soaks T = 64 clips."""
+            if not overlap:
+                return self._track_round(sts)
             with torch.cuda.stream(side):
                 for st in sts:
                     side.wait_event(st["done"])

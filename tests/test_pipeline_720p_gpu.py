@@ -105,17 +105,14 @@ def test_bench_workload_T30_vps_stream_vs_oracle():
                      tol_logit=tol)
 
 
-def test_t64_clips_stream_in_capped_segmenter_calls():
-    """BASELINE config #4's clip length on one GPU: T = 64 at 720p through stream().  A 64-frame segmenter batch has a
-    4.7 GiB activation (the encoder's FFN hidden tensor); batches above 4 GiB are cut into equal calls
-    (segmenter_frames_per_call: 2 x 32 frames) because two such passes in flight on two streams stopped making progress
-    on MI355X / ROCm 7.2 (a 32-bit overflow in the FFN path was excluded, tools/exp/overflow_probe.py).
-    Since the second half of round 2 stream() also keeps such clips (T > 32) off the second stream: phase B runs on the
-    main stream behind the next clip's phase A (the capped calls alone still stalled about once in ten streamed runs).
-    Streamed == clip by clip (up to the run-to-run noise of library kernels), and the cap is what is in effect."""
+def test_t64_clips_streamed_equal_clip_by_clip():
+    """BASELINE config #4's clip length on one GPU: T = 64 at 720p through stream(), one 64-frame segmenter call per clip
+    (4.7 GiB FFN activation) with phase B on the second stream — the schedule that stalled in rounds 1-2 and was capped
+    (DESIGN.md section 9); phase B no longer issues library GEMMs, the caps are gone (tests/test_stream_gpu.py soaks it).
+    Streamed == clip by clip: segment lists equal, the maps up to phase A's run-to-run library noise."""
     import bench
     from dvis_plus_amd.meta_architecture import segmenter_frames_per_call
-    assert segmenter_frames_per_call(64, 736, 1280) == 32
+    assert segmenter_frames_per_call(64, 736, 1280) == 64
     m, _ = _model("offline", "vps")
     m = m.to(DEV)
     dev = torch.device(DEV)
@@ -128,5 +125,5 @@ def test_t64_clips_stream_in_capped_segmenter_calls():
         assert o["segments_infos"] == want["segments_infos"] and o["pred_ids"] == want["pred_ids"]
         n_diff = int((o["pred_masks"] != want["pred_masks"]).sum())
         PPar.intcmp._report(f"config #4 clip length (T=64) streamed vs clip by clip: {n_diff} of {want['pred_masks'].numel()} "
-                            f"panoptic pixels differ (run-to-run library noise)")
+                            f"panoptic pixels differ (run-to-run noise of phase A's library kernels)")
         assert n_diff <= 40000
