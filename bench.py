@@ -205,6 +205,31 @@ def stage_breakdown(model, video, task):
 BB_NAME = {"r50": "R50", "vitl": "ViT-Adapter-L", "vitb": "ViT-Adapter-B"}
 
 
+def launch_command(n, argv, n_devices, port):
+    """`python bench.py --gpus N` without a launcher: the command + environment that re-runs this script as N ranks of one
+    node (what detectron2's launch(main, num_gpus) does for the reference, train_net_video.py:322-329).  With fewer than N
+    GPUs visible (development boxes) the ranks share device 0 and talk through gloo — a functional check of the sharded
+    path, flagged in the JSON line, never a scaling number."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if n_devices < n:
+        env.update(DVIS_BENCH_ONE_DEVICE="1", DVIS_DIST_BACKEND="gloo")
+    return cmd, env
+
+
+def self_launch(n):
+    import socket
+    import subprocess
+    with socket.socket() as sk:                    # a free port for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd, env = launch_command(n, sys.argv[1:], torch.cuda.device_count(), port)
+    print("bench.py: launching", " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -228,9 +253,12 @@ def main():
     ap.add_argument("--rounds", type=int, default=0,
                     help="offline mode: spans handed to the tracker while the segmenter runs the next span (0 = default)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))           # one rank per GPU under torch.distributed.run; rank 0 prints the line
     # a hung collective must not hang the box: dump every thread's Python stack and exit after this many seconds
     import faulthandler
     faulthandler.dump_traceback_later(int(os.environ.get("DVIS_BENCH_WATCHDOG", "1500")), exit=True)
+    os.environ.setdefault("DVIS_STRICT", "1")      # a glue op that would quietly run torch ops on the GPU raises instead
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist_on = world > 1 or os.environ.get("DVIS_FORCE_COLLECTIVES") == "1"   # dev aid: RCCL calls on a single rank
@@ -253,7 +281,7 @@ def main():
             torch.distributed.init_process_group("nccl", device_id=device)
         else:
             torch.distributed.init_process_group(backend)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run or let bench.py do it)"
 
     if os.environ.get("DVIS_MIOPEN_FIND", "0") == "1":
         torch.backends.cudnn.benchmark = True      # MIOpen exhaustive find per conv shape (first call of a shape is slow)
@@ -315,27 +343,60 @@ def main():
     # shapes are those of a full round and of the last, partial round (K mod world clips, same rotation of the ragged
     # split as in the timed pass) — warm up with exactly that sequence.
     mark = os.environ.get("DVIS_BENCH_MARK") == "1"     # tools/steady_stats.py: marker kernel at each timed step start
-    warm_clips = warmup_clip_count(args.warmup, args.steps, world, model.owner_rounds, streamed)
-    run_pass([videos[i % len(videos)] for i in range(warm_clips)])
-    torch.cuda.synchronize()
-    if dist_on:
-        torch.distributed.barrier()
-    model.stream_timing = True
-    timer = MsdaTimer()
-    lat = []
-    t0 = time.perf_counter()
-    with timer:
-        outs = run_pass(videos[:args.steps], lat)
-    torch.cuda.synchronize()
-    if dist_on:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
+
+    def timed(owner_rounds):
+        """W warm-up clips (round structure of the timed pass), then EXACTLY K clips between barrier + synchronize on both
+        sides; max over ranks.  -> (seconds, outputs, latencies, MSDA timer, warm-up clips run)."""
+        model.owner_rounds = owner_rounds
+        model.stream_timing = False
+        warm = warmup_clip_count(args.warmup, args.steps, world, owner_rounds, streamed)
+        run_pass([videos[i % len(videos)] for i in range(warm)])
+        torch.cuda.synchronize()
+        if dist_on:
+            torch.distributed.barrier()
+        model.stream_timing = True
+        tm, lt = MsdaTimer(), []
+        t0 = time.perf_counter()
+        with tm:
+            res_ = run_pass(videos[:args.steps], lt)
+        torch.cuda.synchronize()
+        if dist_on:
+            torch.distributed.barrier()
+        secs = time.perf_counter() - t0
+        if dist_on:
+            tt = torch.tensor([secs], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            secs = tt.item()
+        return secs, res_, lt, tm, warm
+
+    # N > 1: the HEADLINE is north_star's split — frames sharded, ONE all-gather of the per-frame queries per clip, tracker
+    # + refiner replicated on every rank (stream(): one clip per round, their sequential kernels overlap the next clip's
+    # segmenter) — and a second timed pass measures stream()'s tracker-owner rounds (clip j of a round of `world` clips is
+    # tracked by rank j alone; one more all-gather per round) as an extra key.
+    owner_default = model.owner_rounds
+    dt, outs, lat, timer, warm_clips = timed(owner_rounds=False if world > 1 else owner_default)
+    owner_line = None
+    if world > 1 and streamed and owner_default:
+        dt_o, outs_o, lat_o, _, warm_o = timed(owner_rounds=True)
+        owner_line = {"value": round(args.frames * args.steps / dt_o, 3), "unit": "frames/s",
+                      "ms_per_step": round(dt_o / args.steps * 1e3, 2), "warmup_clips_run": warm_o,
+                      "collectives_per_round": f"{world} query all-gathers + 1 result all-gather (+ VPS area all-reduces)",
+                      "note": "stream() in rounds of `world` clips, clip j's tracker + refiner on rank j only"}
+        model.owner_rounds = False
     out = outs[-1]
     ncands = [float(o.get("num_candidates") or 0) for o in outs]
+    dist_info = None
     if dist_on:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = tt.item()
+        import socket
+        mine = {"rank": rank, "device": f"cuda:{dev_index}", "name": torch.cuda.get_device_name(dev_index),
+                "pci_bus": getattr(torch.cuda.get_device_properties(dev_index), "pci_bus_id", None),
+                "host": socket.gethostname()}
+        per_rank = [None] * torch.distributed.get_world_size()
+        torch.distributed.all_gather_object(per_rank, mine)
+        dist_info = {"world_size": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
+                     "ranks": per_rank, "ranks_share_one_gpu": bool(one_device),
+                     "split": "frames sharded contiguously (rotating ragged split), one all-gather of per-frame queries "
+                              "per clip, tracker + refiner replicated"}
 
     # second, short timed pass: every non-void query goes to the panoptic stage (the upper end of the work that the
     # candidate count controls).  Same protocol, up to 4 clips; single GPU only.
@@ -380,7 +441,7 @@ def main():
                        "tracker_spans": len(model.clip_shard.round_plan(T, getattr(model, "pipeline_rounds", 1))[0]),
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                        "clip_stream": streamed, "warmup_clips_run": warm_clips,
-                       "tracker_owner_rounds": bool(streamed and world > 1 and model.owner_rounds)},
+                       "tracker_owner_rounds": False if world > 1 else None},
             "latency_ms": {"p10": pct(0.1), "p50": pct(0.5), "p90": pct(0.9), "n": len(ms),
                            "note": "clip handed to the model -> its outputs complete (HIP events); under clip streaming a "
                                    "clip waits one segmenter pass of the previous clip"},
@@ -392,6 +453,10 @@ def main():
                          "us_per_launch": round(sec * 1e6, 1), "frames_per_launch": nfr, "launches_timed": nlaunch,
                          "alg_bytes_per_frame_layer": MSDA_BYTES_PER_FRAME_LAYER},
         }
+        if dist_info is not None:
+            res["dist"] = dist_info
+        if owner_line is not None:
+            res["owner_rounds"] = owner_line
         if cand100 is not None:
             res["candidates_100"] = cand100
         if world == 1 and not dist_on and args.mode == "offline" and not args.no_extra:
