@@ -292,6 +292,7 @@ def main():
     # VIPSeg/DVIS_Plus_Offline_R50.yaml.
     model = build_dvis_plus_r50(args.mode, task=args.task, object_mask_threshold=0.0, backbone=args.backbone,
                                 num_queries=args.queries, segmenter_chunk=args.segmenter_chunk).to(device)
+    model.allow_input_threshold = True     # each synthetic clip carries its own calibrated score threshold (see below)
     if args.rounds:
         model.pipeline_rounds = args.rounds
     T = args.frames

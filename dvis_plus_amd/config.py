@@ -100,6 +100,7 @@ def build_model(cfg, n_things=None):
     n_things: thing classes 0..n-1 when no dataset metadata is available (standalone runs without detectron2)."""
     from . import d2
     d2_model = d2.build_model(cfg)
-    if n_things is not None and hasattr(d2_model, "thing_ids") and d2_model.metadata is None:
+    if n_things is not None and hasattr(d2_model, "thing_ids") \
+            and d2.thing_ids_from_metadata(d2_model.metadata) is None:     # no metadata, or one without a thing table (VSS)
         d2_model.thing_ids = frozenset(range(int(n_things)))
     return d2_model.eval()

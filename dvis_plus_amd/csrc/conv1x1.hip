@@ -215,16 +215,9 @@ int launch(const float *w, const float *x, const float *bias, const float *res, 
            int relu, hipStream_t st) {
   const int CQ = ((K + 3) / 4 + 7) / 8 * 8;
   const size_t lds = (size_t)4 * QT * 16 * (CQ + kPad) * sizeof(float);
-  static size_t lds_opted = 0;   // > 64 KB of dynamic LDS needs the opt-in (once per kernel and size)
-  if (lds > lds_opted) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_kernel<QT, NT>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      dvis_set_error("conv1x1: hipFuncSetAttribute(max dynamic LDS = %zu): %s", lds, hipGetErrorString(e));
-      return DVIS_E_LAUNCH;
-    }
-    lds_opted = lds;
-  }
+  static DvisLdsOptIn opted;   // per kernel instantiation, per device
+  if (const int rc = dvis_lds_opt_in(reinterpret_cast<const void *>(&conv1x1_kernel<QT, NT>), lds, &opted, "conv1x1"))
+    return rc;
   const int PG = 16 * NT;
   const int gpf = (int)((HW + PG - 1) / PG);
   const int spf = (gpf + 7) / 8;

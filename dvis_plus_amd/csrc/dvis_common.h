@@ -23,6 +23,26 @@ static inline int dvis_check_launch(const char *what) {
   return DVIS_OK;
 }
 
+// > 64 KB of dynamic LDS needs hipFuncSetAttribute, and the attribute belongs to the CURRENT DEVICE's function object: a
+// process that drives several GPUs must opt in on each.  `opted`: one static table per kernel instantiation (bytes already
+// granted per device); racing threads at worst repeat the idempotent call.
+struct DvisLdsOptIn {
+  size_t bytes[64] = {};
+};
+static inline int dvis_lds_opt_in(const void *kernel, size_t bytes, DvisLdsOptIn *opted, const char *what) {
+  if (bytes <= 64 * 1024) return DVIS_OK;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+  if (dev >= 0 && dev < 64 && __atomic_load_n(&opted->bytes[dev], __ATOMIC_RELAXED) >= bytes) return DVIS_OK;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) {
+    dvis_set_error("%s: hipFuncSetAttribute(max dynamic LDS = %zu): %s", what, bytes, hipGetErrorString(e));
+    return DVIS_E_LAUNCH;
+  }
+  if (dev >= 0 && dev < 64) __atomic_store_n(&opted->bytes[dev], bytes, __ATOMIC_RELAXED);
+  return DVIS_OK;
+}
+
 #define DVIS_REQUIRE(cond, ...)      \
   do {                               \
     if (!(cond)) {                   \

@@ -232,21 +232,9 @@ DVIS_EXPORT int dvis_gemm_nt(const float *A, int64_t lda, int64_t strideA, const
   DVIS_REQUIRE(tiles < (1ll << 31), "gemm_nt: too many tiles");
   const size_t lds = (size_t)cf.nw * BM * BN * sizeof(float);
   auto kernel = K % 16 == 0 ? cf.kernel16 : cf.kernel4;
-  if (lds > 64 * 1024) {   // > 64 KB of dynamic LDS needs an opt-in per kernel AND per device
-    int dev = 0;
-    hipGetDevice(&dev);
-    static unsigned long long opted[kNumConfigs][2] = {};   // bit d: done on device d (devices >= 64: every call)
-    unsigned long long &bits = opted[c][K % 16 == 0 ? 0 : 1];
-    if (dev >= 64 || !((__atomic_load_n(&bits, __ATOMIC_RELAXED) >> dev) & 1ull)) {
-      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) {
-        dvis_set_error("gemm_nt: hipFuncSetAttribute(max dynamic LDS = %zu): %s", lds, hipGetErrorString(e));
-        return DVIS_E_LAUNCH;
-      }
-      if (dev < 64) __atomic_fetch_or(&bits, 1ull << dev, __ATOMIC_RELAXED);
-    }
-  }
+  static DvisLdsOptIn opted[kNumConfigs][2];
+  if (const int rc = dvis_lds_opt_in(reinterpret_cast<const void *>(kernel), lds, &opted[c][K % 16 == 0 ? 0 : 1], "gemm_nt"))
+    return rc;
   hipLaunchKernelGGL(kernel, dim3((unsigned)tiles, (unsigned)batch), dim3(64 * cf.nw), lds, (hipStream_t)stream, p);
   return dvis_check_launch("gemm_nt_kernel");
 }

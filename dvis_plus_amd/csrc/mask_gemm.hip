@@ -259,16 +259,10 @@ __global__ __launch_bounds__(512) void mask_gemm_kernel(
 template <int MODE, int QT, bool VEC, bool FULLC>
 int launch_one(const float *embed, const float *feat, int B, int Q, int qbeg, int C, int H, int W, int h, int w,
                float *out_logits, uint8_t *out_mask, int *allowed, hipStream_t st) {
-  static bool lds_opt_in = false;   // > 64 KB of dynamic LDS needs the opt-in once per process and kernel
-  if (!lds_opt_in) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mask_gemm_kernel<MODE, QT, VEC, FULLC>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<QT>());
-    if (e != hipSuccess) {
-      dvis_set_error("mask_gemm: hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e));
-      return DVIS_E_LAUNCH;
-    }
-    lds_opt_in = true;
-  }
+  static DvisLdsOptIn opted;   // per kernel instantiation, per device
+  if (const int rc = dvis_lds_opt_in(reinterpret_cast<const void *>(&mask_gemm_kernel<MODE, QT, VEC, FULLC>),
+                                     lds_bytes<QT>(), &opted, "mask_gemm"))
+    return rc;
   const int CQ = ((C + 3) / 4 + 7) / 8 * 8;
   const int sfac = MODE == 1 ? H / h : 1;
   const long long npx = MODE == 1 ? (long long)h * w : (long long)H * W;

@@ -121,12 +121,18 @@ def build_model(cfg):
     return META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg)
 
 
-def thing_ids_from_metadata(metadata):
-    """``metadata.thing_dataset_id_to_contiguous_id.values()`` (dvis_Plus/meta_architecture.py:940): the contiguous class
-    ids that are things.  None when the metadata has no such table."""
+def thing_ids_from_metadata(metadata, video=False):
+    """The contiguous class ids post-processing treats as things; None when the metadata has no
+    ``thing_dataset_id_to_contiguous_id`` table.  The reference uses TWO rules:
+      * image MaskFormer (mask2former/maskformer_model.py:314, :363): ``cls in table.values()``;
+      * the video meta-architectures (dvis_Plus/meta_architecture.py:919): ``cls < len(table)`` — whatever the table's
+        values are.  The reference registers VIPSeg with id -> id (dvis_Plus/data_video/datasets/vps.py:276-285), so the
+        58 thing ids are interleaved over 0..123 and the two rules disagree there; ``video=True`` is the second one."""
     table = getattr(metadata, "thing_dataset_id_to_contiguous_id", None)
     if table is None:
         return None
+    if video:
+        return frozenset(range(len(table)))
     return frozenset(int(v) for v in (table.values() if hasattr(table, "values") else table))
 
 

@@ -95,7 +95,8 @@ def segmenter_frames_per_call(n, H, W, requested=0):
 class _VideoBase(nn.Module):
     """Constructor surface of the reference's meta-architectures (dvis_Plus/meta_architecture.py:29-90, 409-500,
     1073-1160): ``Cls(cfg)`` through ``from_config`` like detectron2's ``build_model`` does, or explicit keyword
-    arguments.  Training-only arguments (criterion, num_frames, max_iter_num, use_cl, ...) are accepted and ignored;
+    arguments — exactly the reference's names; its training-only ones (criterion, num_frames, max_iter_num, use_cl) are
+    accepted and ignored, anything else is a TypeError;
     ``metadata`` supplies the thing classes (``thing_dataset_id_to_contiguous_id``), ``n_things`` is the short form
     for datasets whose thing classes are 0..n-1 (VIPSeg)."""
 
@@ -105,13 +106,13 @@ class _VideoBase(nn.Module):
                  pixel_std=(58.395, 57.120, 57.375), tracker=None, refiner=None, task="vis", max_num=20,
                  window_size=3, segmenter_chunk=0, metadata=None, criterion=None,
                  sem_seg_postprocess_before_inference=True, num_frames=1, window_inference=True, max_iter_num=0,
-                 use_cl=False, **ignored_training_args):
+                 use_cl=False):
         super().__init__()
         self.backbone, self.sem_seg_head, self.tracker, self.refiner = backbone, sem_seg_head, tracker, refiner
         self.num_queries = num_queries
         self.object_mask_threshold, self.overlap_threshold = object_mask_threshold, overlap_threshold
         self.metadata = metadata
-        ids = d2.thing_ids_from_metadata(metadata)
+        ids = d2.thing_ids_from_metadata(metadata, video=True)      # meta_architecture.py:919: cls < len(thing table)
         self.thing_ids = frozenset(range(int(n_things))) if ids is None else ids
         self.num_frames, self.window_inference = num_frames, window_inference
         self.size_divisibility = size_divisibility
@@ -130,6 +131,9 @@ class _VideoBase(nn.Module):
         # one clip per round, tracker replicated on every rank)
         self.owner_rounds = os.environ.get("DVIS_OWNER_ROUNDS", "1") != "0"
         self.stream_timing = False            # stream(): make the per-clip "ready_event" a timing event (bench latency)
+        # bench.py only: let a clip's input dict carry its own calibrated "object_mask_threshold" (random-init class
+        # scores are near-uniform).  Off by default: the reference's input dicts have no such key.
+        self.allow_input_threshold = False
         self.debug_stages = None              # tests: a dict here receives the floats behind the last clip's decisions
         if hasattr(self.sem_seg_head.predictor, "compute_pred_masks"):
             self.sem_seg_head.predictor.compute_pred_masks = False
@@ -225,7 +229,9 @@ class _VideoBase(nn.Module):
         """video: the input dict; an optional "object_mask_threshold" entry overrides the model's for this clip (used by
         bench.py: random-init class scores are near-uniform, the threshold is calibrated per synthetic clip)."""
         K = self.sem_seg_head.num_classes
-        thr = self.object_mask_threshold if video is None else video.get("object_mask_threshold", self.object_mask_threshold)
+        thr = self.object_mask_threshold
+        if video is not None and self.allow_input_threshold:
+            thr = video.get("object_mask_threshold", thr)
         if self.task == "vis":
             return PP.inference_video_vis(cls, mask_fn, img_size, out_hw, padded_size, K, self.max_num, aux)
         if self.task == "vps":

@@ -22,6 +22,10 @@ from conftest import GOLDEN
 sys.path.insert(0, GOLDEN)
 REF_CFG = "/root/reference/DVIS_Plus/configs/dvis_Plus/VIPSeg"
 
+VIPSEG_THING_IDS = [2, 4, 8, 10, 41, 43, 44, 46, 47, 48, 49, 50, 51, 52, 54, 55, 56, 60, 61, 62, 63, 64, 65, 72, 74, 76, 77, 78,
+                    79, 82, 83, 84, 85, 86, 87, 88, 89, 90, 91, 92, 95, 96, 97, 99, 100, 101, 102, 106, 107, 108, 109, 114,
+                    115, 116, 117, 118, 122, 123]
+
 
 def _cfg(name, rel):
     from dvis_plus_amd.config import CfgNode, get_default_cfg
@@ -53,7 +57,9 @@ def d2_stubs(monkeypatch):
         return m
 
     class _Meta:
-        thing_dataset_id_to_contiguous_id = {10 * i + 3: i for i in range(58)}      # VIPSeg: 58 things, ids 0..57
+        # VIPSeg as the reference registers it (dvis_Plus/data_video/datasets/vps.py:276-285): the 58 thing classes map
+        # id -> id, interleaved over 0..123 (ids of the `isthing` entries of its category table)
+        thing_dataset_id_to_contiguous_id = {i: i for i in VIPSEG_THING_IDS}
 
     class _Catalog:
         @staticmethod
@@ -109,7 +115,10 @@ def test_build_model_like_detectron2_from_the_references_offline_yaml(d2_stubs):
     model = arch(cfg)                                                    # detectron2: build_model(cfg)
     assert type(model).__name__ == "DVIS_Plus_offline" and model.task == "vps" and model.window_size == 3
     assert model.num_queries == 100 and model.sem_seg_head.num_classes == 124
-    assert model.thing_ids == frozenset(range(58))                       # from MetadataCatalog.get(cfg.DATASETS.TRAIN[0])
+    # video rule of the reference (dvis_Plus/meta_architecture.py:919): isthing = cls < len(thing table) — NOT membership
+    # in the table's values (that is the image model's rule, maskformer_model.py:314); the oracle's `cls_k < n_things`
+    assert model.thing_ids == frozenset(range(58)) and model.n_things == 58
+    assert d2.thing_ids_from_metadata(model.metadata) == frozenset(VIPSEG_THING_IDS)       # image MaskFormer rule
     assert model.object_mask_threshold == 0.8 and model.overlap_threshold == 0.8
     pred = model.sem_seg_head.predictor
     assert type(pred).__name__ == "VideoMultiScaleMaskedTransformerDecoder_dvisPlus" and pred.num_layers == 9
