@@ -387,10 +387,18 @@ class DVIS_Plus_offline(_VideoBase):
             m.update(embds=e, embds_nn=e_nn, logits=lg, mf=mf)
         return metas
 
+    @property
+    def _resume(self):
+        """Does this clip continue the tracker state of the previous call?  The reference's offline model reads `keep`
+        (meta_architecture.py:1301-1304) but its window loop only resumes for windows i != 0 (:1479-1486), so with
+        TEST.WINDOW_INFERENCE (every shipped config) `keep` has no effect; its non-window branch passes
+        resume=self.keep (:1329-1334).  Same here."""
+        return bool(self.keep) and not self.window_inference
+
     def _track_core(self, embds, embds_nn):
         """Tracker + refiner over the T gathered frames of one clip: (mask_embed (1,T,Q,Cm), cls (Q,K+1), aux (Q,K+1))."""
         to_bctq = lambda z: z.permute(2, 0, 1).unsqueeze(0)
-        track = self.tracker(to_bctq(embds), None, resume=self.keep, frame_embeds_no_norm=to_bctq(embds_nn),
+        track = self.tracker(to_bctq(embds), None, resume=self._resume, frame_embeds_no_norm=to_bctq(embds_nn),
                              need_masks=False)
         ref = self.refiner(track["pred_embds"], to_bctq(embds_nn), None, need_masks=False)
         cls, aux = PP.mean_logits(ref["pred_logits"], track["pred_logits"])
@@ -438,7 +446,7 @@ class DVIS_Plus_offline(_VideoBase):
         shard = self.clip_shard
         m = len(sts)
         if not self.owner_rounds or (shard.world == 1 and not shard.force) \
-                or any(bool(st["video"].get("keep", False)) for st in sts):
+                or (not self.window_inference and any(bool(st["video"].get("keep", False)) for st in sts)):
             return [self._track_phase(st) for st in sts]
         assert m <= shard.world
         gathered = [shard.all_gather_frames([st["embds"], st["embds_nn"], st["logits"]], st["T"], shift=st["shift"])
@@ -600,7 +608,7 @@ class DVIS_Plus_offline(_VideoBase):
             """Round c of the recurrence; under `overlap` on the side stream, behind the span's gather."""
             if seg["work"] is not None:
                 seg["work"].wait()
-            return self.tracker(to_bctq(seg["embds"]), None, resume=self.keep or c > 0,
+            return self.tracker(to_bctq(seg["embds"]), None, resume=self._resume or c > 0,
                                 frame_embeds_no_norm=to_bctq(seg["embds_nn"]), need_masks=False)
 
         segs, tracks = [run_segmenter(0)], []

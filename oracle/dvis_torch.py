@@ -434,22 +434,28 @@ def preprocess(frames, pixel_mean, pixel_std, size_divisibility=32):
 
 def dvis_plus_forward(sd, backbone, frames, *, offline=True, nheads=8, enc_layers=6, dec_layers=9, tracker_layers=6,
                       refiner_layers=6, window_size=3, num_classes=124, n_things=58, task="vps", max_num=20,
-                      object_mask_threshold=0.8, overlap_threshold=0.8, out_hw=None, stages=None):
+                      object_mask_threshold=0.8, overlap_threshold=0.8, out_hw=None, stages=None, keep=False,
+                      tracker=None):
     """DVIS_Plus_offline.forward (eval) = run_window_inference (meta_architecture.py:1446-1500) + post_processing
     (:758-772) + inference_video_{vis,vps,vss}; offline=False: DVIS_Plus_online (:774-816).  `sd` uses the product's /
     reference's checkpoint names (sem_seg_head.pixel_decoder.*, sem_seg_head.predictor.*, tracker.*, refiner.*);
     `backbone` is any callable images -> {res2..res5} (un-pinned third-party part, shared with the product).
-    `stages`: optional dict that receives intermediate tensors (for parity tests)."""
+    `stages`: optional dict that receives intermediate tensors (for parity tests).
+    keep / tracker: the `keep` entry of the input dict (:629-632, :1301-1304) and the Tracker object of the previous
+    call (its cross-call state).  ONLINE: the first window resumes when keep is set (`i != 0 or self.keep`, :793).
+    OFFLINE: the window loop resumes only for i != 0 (:1479-1486) — `keep` is read but has no effect there.
+    nheads: an int, or (segmenter heads, tracker / refiner heads)."""
     images, img_size = preprocess(frames, sd["pixel_mean"].flatten(), sd["pixel_std"].flatten())
     pd, pr = _sub(sd, "sem_seg_head.pixel_decoder."), _sub(sd, "sem_seg_head.predictor.")
-    trk = Tracker(_sub(sd, "tracker."), nheads, tracker_layers)
+    nheads, nheads_t = (nheads, nheads) if isinstance(nheads, int) else nheads
+    trk = tracker if tracker is not None else Tracker(_sub(sd, "tracker."), nheads_t, tracker_layers)
     T = len(images)
     all_mf, all_fe_nn, all_inst, online_logits, online_masks = [], [], [], [], []
     for s in range(0, T, window_size):                                      # the reference's window loop
         feats = backbone(images[s:s + window_size])
         mf, _, ms = pixel_decoder_forward(pd, feats, nheads, enc_layers)
         out = decoder_forward(pr, ms, mf, nheads, dec_layers)
-        t_out = trk.forward(out["pred_embds"], mf.unsqueeze(0), resume=(s != 0),
+        t_out = trk.forward(out["pred_embds"], mf.unsqueeze(0), resume=(s != 0) or (bool(keep) and not offline),
                             frame_embeds_no_norm=out["pred_embds_without_norm"], with_masks=not offline)
         all_mf.append(mf)
         all_fe_nn.append(out["pred_embds_without_norm"])
@@ -461,14 +467,17 @@ def dvis_plus_forward(sd, backbone, frames, *, offline=True, nheads=8, enc_layer
     online_logits = torch.cat(online_logits, 1)
     if offline:
         ref = refiner_forward(_sub(sd, "refiner."), torch.cat(all_inst, 2), torch.cat(all_fe_nn, 2), mask_features,
-                              nheads, refiner_layers)
+                              nheads_t, refiner_layers)
         cls, aux = post_processing(ref["pred_logits"], online_logits)
         masks = ref["pred_masks"][0]
     else:
         cls, aux = post_processing(online_logits)
         masks = torch.cat(online_masks, 2)[0]
     if stages is not None:
-        stages.update(mask_features=mask_features, cls=cls, aux=aux, masks=masks, online_logits=online_logits)
+        stages.update(mask_features=mask_features, cls=cls, aux=aux, masks=masks, online_logits=online_logits,
+                      tracker=trk, instance_embds=torch.cat(all_inst, 2))
+        if offline:
+            stages.update(refiner_logits=ref["pred_logits"], refiner_embds=ref["pred_embds"])
     first = tuple(images.shape[-2:])
     out_hw = img_size if out_hw is None else out_hw
     if task == "vis":

@@ -33,6 +33,13 @@ def _np(t):
     return np.asarray(t)
 
 
+def _small_int(t):
+    """Integer maps (segment ids, class indices) as int16: values are tiny, fixtures stay small."""
+    a = _np(t)
+    assert a.min() >= -32768 and a.max() <= 32767
+    return a.astype(np.int16)
+
+
 def save(name, ins=None, outs=None, sd=None, **meta):
     d = {}
     for k, v in (ins or {}).items():
@@ -393,11 +400,181 @@ def g8_vit_adapter():
                   interaction_indexes=[[0, 0], [1, 1], [2, 2], [3, 3]], cffn_ratio=0.25, HW=[int(H), int(W)]))
 
 
+# --------------------------------------------------------------------------- G10
+class _ImageList:
+    """detectron2.structures.ImageList.from_tensors — un-vendored third-party semantics the reference relies on at
+    meta_architecture.py:1311: stack to the max H, W rounded UP to a multiple of size_divisibility,
+    zero padding bottom / right, image_sizes = the un-padded sizes."""
+
+    def __init__(self, tensor, image_sizes):
+        self.tensor, self.image_sizes = tensor, image_sizes
+
+    @staticmethod
+    def from_tensors(tensors, size_divisibility=0):
+        sizes = [tuple(t.shape[-2:]) for t in tensors]
+        H, W = max(s[0] for s in sizes), max(s[1] for s in sizes)
+        if size_divisibility > 1:
+            d = size_divisibility
+            H, W = (H + d - 1) // d * d, (W + d - 1) // d * d
+        out = tensors[0].new_zeros((len(tensors), tensors[0].shape[0], H, W))
+        for i, t in enumerate(tensors):
+            out[i, :, :t.shape[-2], :t.shape[-1]] = t
+        return _ImageList(out, sizes)
+
+
+def g10_window_loop():
+    """The a12 COMPOSITION through the reference's own methods, called unbound on a stub `self` that holds reference
+    sub-modules (MaskFormerHead with MSDeformAttnPixelDecoder + dvisPlus decoder, ReferringTracker_noiser,
+    TemporalRefiner) and a toy backbone:
+      DVIS_Plus_offline.forward eval branch (meta_architecture.py:1301-1317, 1376-1396) -> run_window_inference
+        (:1446-1500) -> post_processing (:758-772) -> inference_video_{vps,vis,vss};
+      DVIS_Plus_online.forward eval branch (:629-642, 687-706) -> run_window_inference (:774-816), incl. a second call
+        with `keep` (the demo's long-video hand-off; the OFFLINE window loop ignores `keep`: pinned too).
+    T = 7 frames of 70 x 100 (padded to 96 x 128), window 3 (ragged last window 3 + 3 + 1), output size 105 x 150."""
+    import importlib
+    sys.path.insert(0, os.path.dirname(OUT))
+    from toy_backbone import ToyBackbone, CHANS, STRIDES
+    ma = R.ref_meta()
+    sys.modules["detectron2.layers"].DeformConv = None            # un-vendored name imported by pixel_decoder/fpn.py:14
+    if "mask2former.modeling.meta_arch" not in sys.modules:
+        pkg = types.ModuleType("mask2former.modeling.meta_arch")
+        pkg.__path__ = [f"{R.REF}/mask2former/modeling/meta_arch"]
+        sys.modules[pkg.__name__] = pkg
+    head_mod = importlib.import_module("mask2former.modeling.meta_arch.mask_former_head")
+    pdm = R.ref("mask2former.modeling.pixel_decoder.msdeformattn")
+    dm = R.ref("dvis_Plus.video_mask2former_transformer_decoder")
+    tm, rm = R.ref("dvis_Plus.tracker"), R.ref("dvis_Plus.refiner")
+    SS = sys.modules["detectron2.layers"].ShapeSpec
+    ma.ImageList = _ImageList
+    torch.manual_seed(100)
+    K, Q, HID, MD, NH, NHT = 7, 6, 32, 16, 1, 2       # segmenter: 1 head of 32; tracker / refiner: 2 heads of 32
+    cfg = dict(K=K, Q=Q, hidden=HID, mask_dim=MD, nheads=NH, trk_heads=NHT, enc_layers=2, enc_ffn=64, dec_layers=3, dec_ffn=64,
+               tracker_layers=2, refiner_layers=2, trk_ffn=128, T=7, window=3, frame_hw=(70, 100), out_hw=(105, 150),
+               n_things=3, max_num=5, overlap_threshold=0.3)
+    backbone = ToyBackbone().eval()
+    inp = {k: SS(channels=CHANS[k], stride=STRIDES[k]) for k in CHANS}
+    pd = pdm.MSDeformAttnPixelDecoder(inp, transformer_dropout=0.0, transformer_nheads=NH, transformer_dim_feedforward=64,
+                                      transformer_enc_layers=2, conv_dim=HID, mask_dim=MD, norm="GN",
+                                      transformer_in_features=["res3", "res4", "res5"], common_stride=4)
+    with torch.no_grad():
+        for layer in pd.transformer.encoder.layers:
+            layer.self_attn.sampling_offsets.weight.normal_(0, 0.3)
+            layer.self_attn.attention_weights.weight.normal_(0, 0.5)
+    dec = dm.VideoMultiScaleMaskedTransformerDecoder_dvisPlus(
+        HID, True, num_classes=K, hidden_dim=HID, num_queries=Q, nheads=NH, dim_feedforward=64, dec_layers=3,
+        pre_norm=False, mask_dim=MD, enforce_input_project=False, num_frames=3, num_reid_head_layers=3,
+        reid_hidden_dim=HID)
+    head = head_mod.MaskFormerHead(inp, num_classes=K, pixel_decoder=pd, loss_weight=1.0, ignore_value=-1,
+                                   transformer_predictor=dec, transformer_in_feature="multi_scale_pixel_decoder").eval()
+    trk = tm.ReferringTracker_noiser(hidden_channel=2 * HID, feedforward_channel=128, num_head=NHT, decoder_layer_num=2,
+                                     noise_mode="wa", mask_dim=MD, class_num=K).eval()
+    ref = rm.TemporalRefiner(hidden_channel=2 * HID, feedforward_channel=128, num_head=NHT, decoder_layer_num=2,
+                             mask_dim=MD, class_num=K, windows=3).eval()
+    with torch.no_grad():                                 # decisive masks / class scores (random init ties everything)
+        for m_ in (dec.mask_embed, trk.mask_embed, ref.mask_embed):
+            m_.layers[-1].weight.mul_(30)
+        for m_ in (dec.class_embed, trk.class_embed, ref.class_embed):
+            m_.weight.mul_(8)
+    g = torch.Generator().manual_seed(101)
+    H, W = cfg["frame_hw"]
+    yy, xx = torch.meshgrid(torch.linspace(0, 6.28, H), torch.linspace(0, 6.28, W), indexing="ij")
+    frames = []
+    for t in range(cfg["T"]):
+        pat = 127 + 100 * torch.sin(xx * (1 + t % 2) + 0.3 * t) * torch.cos(yy * 2 + 0.2 * t)
+        frames.append((torch.randint(0, 256, (3, H, W), generator=g).float() * 0.4 + pat[None] * 0.6).to(torch.uint8))
+    frames = torch.stack(frames)
+    pixel_mean = torch.tensor([123.675, 116.280, 103.530]).view(-1, 1, 1)
+    pixel_std = torch.tensor([58.395, 57.120, 57.375]).view(-1, 1, 1)
+
+    def stub_for(cls, task, thr):
+        s_ = types.SimpleNamespace(
+            backbone=backbone, sem_seg_head=head, tracker=trk, refiner=ref, keep=False, device=torch.device("cpu"),
+            pixel_mean=pixel_mean, pixel_std=pixel_std, size_divisibility=32, training=False, window_inference=True,
+            window_size=cfg["window"], num_queries=Q, max_num=cfg["max_num"], task=task, object_mask_threshold=thr,
+            overlap_threshold=cfg["overlap_threshold"],
+            metadata=types.SimpleNamespace(thing_dataset_id_to_contiguous_id={i: i for i in range(cfg["n_things"])}))
+        for name in ("run_window_inference", "post_processing", "_get_instance_labels", "inference_video_vis",
+                     "inference_video_vps", "inference_video_vss"):
+            setattr(s_, name, types.MethodType(getattr(cls, name), s_))
+        s_.inference_video_task = getattr(s_, "inference_video_" + task)
+        return s_
+
+    def video(lo, hi, keep=None):
+        v = {"image": [f for f in frames[lo:hi]], "height": cfg["out_hw"][0], "width": cfg["out_hw"][1]}
+        if keep is not None:
+            v["keep"] = keep
+        return v
+
+    outs = {}
+
+    def put(tag, r, task):
+        if task == "vps":
+            outs[f"{tag}_masks"] = _small_int(r["pred_masks"])
+            outs[f"{tag}_ids"] = np.array([int(x) for x in r["pred_ids"]], dtype=np.int64)
+            outs[f"{tag}_seg_id"] = np.array([s_["id"] for s_ in r["segments_infos"]], dtype=np.int64)
+            outs[f"{tag}_seg_isthing"] = np.array([s_["isthing"] for s_ in r["segments_infos"]], dtype=np.bool_)
+            outs[f"{tag}_seg_cat"] = np.array([s_["category_id"] for s_ in r["segments_infos"]], dtype=np.int64)
+        elif task == "vis":
+            outs[f"{tag}_scores"] = np.array(r["pred_scores"], dtype=np.float32)
+            outs[f"{tag}_labels"] = np.array(r["pred_labels"], dtype=np.int64)
+            outs[f"{tag}_ids"] = np.array(r["pred_ids"], dtype=np.int64)
+            outs[f"{tag}_masks"] = torch.stack(r["pred_masks"])
+        else:
+            outs[f"{tag}_masks"] = _small_int(r["pred_masks"])
+
+    T = cfg["T"]
+    with torch.no_grad():
+        # ---- offline: the floats behind the decisions, straight from run_window_inference
+        st = stub_for(ma.DVIS_Plus_offline, "vps", 0.0)
+        images = _ImageList.from_tensors([(f.float() - pixel_mean) / pixel_std for f in frames], 32)
+        ro, online_logits = ma.DVIS_Plus_offline.run_window_inference(st, images.tensor, window_size=cfg["window"])
+        outs.update(off_refiner_logits=ro["pred_logits"], off_refiner_masks=ro["pred_masks"],
+                    off_refiner_embds=ro["pred_embds"], off_online_logits=online_logits)
+        # a threshold that keeps about half of the non-void queries
+        cls_, aux_ = ma.DVIS_Plus_offline.post_processing(st, dict(pred_logits=ro["pred_logits"].clone(),
+                                                                   pred_masks=ro["pred_masks"]), aux_logits=online_logits.clone())
+        pr = torch.softmax(cls_["pred_logits"][0], -1)
+        pr[:, :-1] = torch.maximum(pr[:, :-1], torch.softmax(aux_, -1)[:, :-1])
+        sc, lb = pr.max(-1)
+        live = sc[lb != K].sort(descending=True)[0]
+        keep_n = min(4, len(live) - 1)                                     # about 4 of the 6 queries become candidates
+        thr = float((live[keep_n - 1] + live[keep_n]) / 2) if keep_n > 0 else 0.0
+        cfg["object_mask_threshold"] = thr
+        for task in ("vps", "vis", "vss"):
+            st = stub_for(ma.DVIS_Plus_offline, task, thr)
+            put(f"off_{task}", ma.DVIS_Plus_offline.forward(st, [video(0, T)]), task)
+        # offline + keep: the window loop never resumes from `keep` (meta_architecture.py:1479-1486) — second half of the
+        # clip with keep=True must equal the second half run on its own
+        st = stub_for(ma.DVIS_Plus_offline, "vps", thr)
+        ma.DVIS_Plus_offline.forward(st, [video(0, 4)])
+        put("off_keep_vps", ma.DVIS_Plus_offline.forward(st, [video(4, T, keep=True)]), "vps")
+        # ---- online
+        st = stub_for(ma.DVIS_Plus_online, "vps", thr)
+        on = ma.DVIS_Plus_online.run_window_inference(st, images.tensor, window_size=cfg["window"])
+        outs.update(on_logits=on["pred_logits"], on_masks=on["pred_masks"], on_embds=on["pred_embds"])
+        for task in ("vps", "vis"):
+            st = stub_for(ma.DVIS_Plus_online, task, thr)
+            put(f"on_{task}", ma.DVIS_Plus_online.forward(st, [video(0, T)]), task)
+        # online + keep: frames 0..3, then 4..6 resuming the tracker state (demo_long_video.py:113-126)
+        st = stub_for(ma.DVIS_Plus_online, "vps", thr)
+        put("on_keep_a_vps", ma.DVIS_Plus_online.forward(st, [video(0, 4)]), "vps")
+        put("on_keep_b_vps", ma.DVIS_Plus_online.forward(st, [video(4, T, keep=True)]), "vps")
+    sd = {}
+    for prefix, mod in (("backbone.", backbone), ("sem_seg_head.pixel_decoder.", pd), ("sem_seg_head.predictor.", dec),
+                        ("tracker.", trk), ("refiner.", ref)):
+        sd.update({prefix + k: v for k, v in mod.state_dict().items()})
+    sd["pixel_mean"], sd["pixel_std"] = pixel_mean, pixel_std
+    print("  g10: threshold %.4f, offline vps segments %s, online vps segments %s, keep-b segments %s" % (
+        thr, outs["off_vps_seg_cat"].tolist(), outs["on_vps_seg_cat"].tolist(), outs["on_keep_b_vps_seg_cat"].tolist()))
+    save("g10_window_loop", ins=dict(frames=frames), outs=outs, sd=sd, seed=100, cfg=cfg)
+
+
+
 if __name__ == "__main__":
     import warnings
     warnings.filterwarnings("ignore")
     torch.set_num_threads(1)  # deterministic reduction order in the generating run
     only = sys.argv[1:]
-    for fn in (g1_msda, g2_pixel_decoder, g3_decoder, g4_tracker_refiner, g5_match, g6_postprocess, g7_head_dim_32, g8_vit_adapter, g9_minvis):
+    for fn in (g1_msda, g2_pixel_decoder, g3_decoder, g4_tracker_refiner, g5_match, g6_postprocess, g7_head_dim_32, g8_vit_adapter, g9_minvis, g10_window_loop):
         if not only or fn.__name__.split("_")[0] in only:
             fn()

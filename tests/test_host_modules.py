@@ -476,6 +476,7 @@ def _keep_worker(rank, world, port, out_dir):
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     m = _tiny_model("offline", "vps")
+    m.window_inference = False       # the reference's non-window branch, where `keep` resumes (meta_architecture.py:1329-1334)
     frames = _tiny_clip(8, seed=9)
     clips = [{"image": frames[:4], "height": 70, "width": 100},
              {"image": frames[4:], "height": 70, "width": 100, "keep": True}]     # second half resumes the tracker
@@ -491,6 +492,7 @@ def test_clip_stream_with_resumed_tracker_state_takes_the_replicated_path(oracle
     port = 35500 + (os.getpid() % 2000)
     mp.spawn(_keep_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     m = _tiny_model("offline", "vps")
+    m.window_inference = False       # the reference's non-window branch, where `keep` resumes (meta_architecture.py:1329-1334)
     frames = _tiny_clip(8, seed=9)
     first = m([{"image": frames[:4], "height": 70, "width": 100}])
     second = m([{"image": frames[4:], "height": 70, "width": 100, "keep": True}])
@@ -513,6 +515,7 @@ def _keep_after_round_worker(rank, world, port, out_dir):
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     m = _tiny_model("offline", "vps")
+    m.window_inference = False       # the reference's non-window branch, where `keep` resumes (meta_architecture.py:1329-1334)
     a, b = _tiny_clip(4, seed=20), _tiny_clip(8, seed=21)
     clips = [{"image": a, "height": 70, "width": 100},                              # round 1 (owner rounds): A on rank 0,
              {"image": b[:4], "height": 70, "width": 100},                          #                         B on rank 1
@@ -529,6 +532,7 @@ def test_keep_clip_after_an_owner_round_resumes_the_last_clips_state(oracle_ops,
     port = 36500 + (os.getpid() % 2000)
     mp.spawn(_keep_after_round_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     m = _tiny_model("offline", "vps")
+    m.window_inference = False       # the reference's non-window branch, where `keep` resumes (meta_architecture.py:1329-1334)
     a, b = _tiny_clip(4, seed=20), _tiny_clip(8, seed=21)
     want = [m([{"image": a, "height": 70, "width": 100}]), m([{"image": b[:4], "height": 70, "width": 100}]),
             m([{"image": b[4:], "height": 70, "width": 100, "keep": True}])]
@@ -606,3 +610,50 @@ def test_stream_8_ranks_ragged_T30_ten_clips_gloo(oracle_ops, tmp_path):
         assert sorted(f for p in parts for f in p["outs"][ci]["frame_ids"]) == list(range(T))
         assert torch.equal(torch.cat([parts[r]["outs"][ci]["masks"] for _, r in held], 0), single["pred_masks"]), ci
         assert all(p["outs"][ci]["segs"] == single["segments_infos"] for p in parts), ci
+
+
+# ---- a12 composition against the reference's OWN forward (golden g10_window_loop: DVIS_Plus_offline / _online forward
+# eval branches + run_window_inference + post_processing + inference_video_*, meta_architecture.py:1301-1317, 1376-1396,
+# 1446-1500, 629-642, 687-706, 774-816, 758-772)
+def _g10_check_vps(out, o, tag):
+    assert [s["id"] for s in out["segments_infos"]] == o[f"{tag}_seg_id"].tolist(), tag
+    assert [s["category_id"] for s in out["segments_infos"]] == o[f"{tag}_seg_cat"].tolist(), tag
+    assert [s["isthing"] for s in out["segments_infos"]] == o[f"{tag}_seg_isthing"].tolist(), tag
+    assert list(out["pred_ids"]) == o[f"{tag}_ids"].tolist(), tag
+    want = o[f"{tag}_masks"].to(torch.int64)
+    n = int((out["pred_masks"].cpu().to(torch.int64) != want).sum())
+    assert n == 0, f"{tag}: {n} of {want.numel()} panoptic pixels differ from the reference's forward"
+
+
+@pytest.mark.parametrize("task", ["vps", "vis", "vss"])
+def test_offline_meta_architecture_equals_reference_forward_g10(oracle_ops, task):
+    import g10_model as G
+    m, g, cfg, frames = G.build("offline", task)
+    o = g.outs
+    with torch.no_grad():
+        out = m([G.video(frames, cfg)])
+    if task == "vps":
+        _g10_check_vps(out, o, "off_vps")
+        # `keep` on the offline model: read, but the window loop never resumes from it (meta_architecture.py:1479-1486)
+        with torch.no_grad():
+            m([G.video(frames, cfg, 0, 4)])
+            _g10_check_vps(m([G.video(frames, cfg, 4, None, keep=True)]), o, "off_keep_vps")
+    elif task == "vis":
+        key_ref = o["off_vis_ids"] * 1000 + o["off_vis_labels"]
+        key_out = out["pred_ids"] * 1000 + out["pred_labels"]
+        a, b = key_ref.argsort(), key_out.argsort()
+        assert torch.equal(key_ref[a], key_out[b])
+        torch.testing.assert_close(out["pred_scores"][b], o["off_vis_scores"][a], rtol=1e-4, atol=1e-6)
+        assert torch.equal(out["pred_masks"][b], o["off_vis_masks"][a])
+    else:
+        assert torch.equal(out["pred_masks"], o["off_vss_masks"].to(out["pred_masks"].dtype))
+
+
+def test_online_meta_architecture_equals_reference_forward_g10(oracle_ops):
+    import g10_model as G
+    m, g, cfg, frames = G.build("online", "vps")
+    o = g.outs
+    with torch.no_grad():
+        _g10_check_vps(m([G.video(frames, cfg)]), o, "on_vps")
+        _g10_check_vps(m([G.video(frames, cfg, 0, 4)]), o, "on_keep_a_vps")
+        _g10_check_vps(m([G.video(frames, cfg, 4, None, keep=True)]), o, "on_keep_b_vps")     # resumes (:793)

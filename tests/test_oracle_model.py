@@ -114,3 +114,80 @@ def test_minvis_alignment_and_top10():
     np.testing.assert_allclose(s.numpy()[order], o["scores"].numpy()[order_ref], rtol=1e-6)
     assert np.array_equal(l.numpy()[order], o["labels"].numpy()[order_ref])
     assert torch.equal(m[order], o["masks"][order_ref])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# g10: the a12 COMPOSITION (window loop, state hand-off, which embeddings go where, mean logits, `keep`) — the reference's
+# own DVIS_Plus_offline / DVIS_Plus_online forward + run_window_inference + post_processing + inference_video_*, driven
+# with a stub `self` in the build container (tests/golden/gen_golden.py::g10_window_loop).
+# ---------------------------------------------------------------------------------------------------------------
+def _g10():
+    from toy_backbone import ToyBackbone
+    g = Golden("g10_window_loop")
+    cfg, sd = g.meta["cfg"], g.sd
+    bb = ToyBackbone().eval()
+    bb.load_state_dict({k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")}, strict=True)
+    frames = [f for f in g.ins["frames"]]
+    kw = dict(nheads=(cfg["nheads"], cfg["trk_heads"]), enc_layers=cfg["enc_layers"], dec_layers=cfg["dec_layers"],
+              tracker_layers=cfg["tracker_layers"], refiner_layers=cfg["refiner_layers"], window_size=cfg["window"],
+              num_classes=cfg["K"], n_things=cfg["n_things"], max_num=cfg["max_num"],
+              object_mask_threshold=cfg["object_mask_threshold"], overlap_threshold=cfg["overlap_threshold"],
+              out_hw=tuple(cfg["out_hw"]))
+    return g, cfg, sd, bb, frames, kw
+
+
+def _check_vps(got, o, tag):
+    pan, segs, ids = got
+    assert [s["id"] for s in segs] == o[f"{tag}_seg_id"].tolist(), tag
+    assert [s["category_id"] for s in segs] == o[f"{tag}_seg_cat"].tolist(), tag
+    assert [s["isthing"] for s in segs] == o[f"{tag}_seg_isthing"].tolist(), tag
+    assert list(ids) == o[f"{tag}_ids"].tolist(), tag
+    assert torch.equal(pan.to(torch.int64), o[f"{tag}_masks"].to(torch.int64)), tag
+
+
+def test_oracle_composition_offline_equals_reference_forward():
+    from oracle import dvis_torch as O
+    g, cfg, sd, bb, frames, kw = _g10()
+    o = g.outs
+    with torch.no_grad():
+        st = {}
+        got = O.dvis_plus_forward(sd, bb, frames, offline=True, task="vps", stages=st, **kw)
+        torch.testing.assert_close(st["refiner_logits"], o["off_refiner_logits"], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(st["masks"][None], o["off_refiner_masks"], rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(st["refiner_embds"], o["off_refiner_embds"], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(st["online_logits"], o["off_online_logits"], rtol=1e-4, atol=1e-5)
+        assert len(got[1]) >= 2                                            # non-degenerate: several segments survive
+        _check_vps(got, o, "off_vps")
+        scores, labels, qidx, masks = O.dvis_plus_forward(sd, bb, frames, offline=True, task="vis", **kw)
+        torch.testing.assert_close(scores, o["off_vis_scores"], rtol=1e-4, atol=1e-6)
+        assert torch.equal(labels, o["off_vis_labels"]) and torch.equal(qidx, o["off_vis_ids"])
+        assert torch.equal(masks, o["off_vis_masks"])
+        sem = O.dvis_plus_forward(sd, bb, frames, offline=True, task="vss", **kw)
+        assert torch.equal(sem, o["off_vss_masks"].to(sem.dtype))
+        # offline + keep: the window loop ignores it (meta_architecture.py:1479-1486)
+        st = {}
+        O.dvis_plus_forward(sd, bb, frames[:4], offline=True, task="vps", stages=st, **kw)
+        got = O.dvis_plus_forward(sd, bb, frames[4:], offline=True, task="vps", keep=True, tracker=st["tracker"], **kw)
+        _check_vps(got, o, "off_keep_vps")
+
+
+def test_oracle_composition_online_equals_reference_forward():
+    from oracle import dvis_torch as O
+    g, cfg, sd, bb, frames, kw = _g10()
+    o = g.outs
+    with torch.no_grad():
+        st = {}
+        got = O.dvis_plus_forward(sd, bb, frames, offline=False, task="vps", stages=st, **kw)
+        torch.testing.assert_close(st["online_logits"], o["on_logits"], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(st["masks"][None], o["on_masks"], rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(st["instance_embds"], o["on_embds"], rtol=1e-4, atol=1e-5)
+        _check_vps(got, o, "on_vps")
+        scores, labels, qidx, masks = O.dvis_plus_forward(sd, bb, frames, offline=False, task="vis", **kw)
+        torch.testing.assert_close(scores, o["on_vis_scores"], rtol=1e-4, atol=1e-6)
+        assert torch.equal(labels, o["on_vis_labels"]) and torch.equal(qidx, o["on_vis_ids"])
+        assert torch.equal(masks, o["on_vis_masks"])
+        # online + keep: frames 0..3, then 4..6 resuming the tracker (meta_architecture.py:793)
+        st = {}
+        _check_vps(O.dvis_plus_forward(sd, bb, frames[:4], offline=False, task="vps", stages=st, **kw), o, "on_keep_a_vps")
+        got = O.dvis_plus_forward(sd, bb, frames[4:], offline=False, task="vps", keep=True, tracker=st["tracker"], **kw)
+        _check_vps(got, o, "on_keep_b_vps")
