@@ -62,17 +62,21 @@ class FusedKV:
     allocated once per device and refreshed IN PLACE when a parameter changes (load_state_dict / optimizer step bump
     the parameters' version counters): a graph captured earlier keeps reading valid, current weights."""
 
-    def __init__(self):
+    def __init__(self, rows="kv"):
+        """rows: "kv" = the K and V rows [C, 3C) of every layer's in_proj (K / V of all layers: one GEMM over the memory);
+        "q" = the Q rows [0, C) (all layers' queries of ONE input: the tracker's per-frame reference, tracker.py:278)."""
         self._key, self._W, self._b = None, None, None
+        self._rows = rows
 
     def get(self, layers, C):
         ws = [l.multihead_attn.in_proj_weight for l in layers]
         bs = [l.multihead_attn.in_proj_bias for l in layers]
         ver = tuple(t._version for t in ws + bs) + tuple(t.data_ptr() for t in ws + bs)
         dev = ws[0].device
+        sl = slice(C, None) if self._rows == "kv" else slice(0, C)
         if self._key != (ver, dev):
-            W = torch.cat([w[C:].detach() for w in ws], 0)
-            b = torch.cat([x[C:].detach() for x in bs], 0)
+            W = torch.cat([w[sl].detach() for w in ws], 0)
+            b = torch.cat([x[sl].detach() for x in bs], 0)
             if self._W is not None and self._W.device == dev and self._W.shape == W.shape and self._W.dtype == W.dtype:
                 self._W.copy_(W)
                 self._b.copy_(b)

@@ -385,6 +385,8 @@ class DVIS_Plus_offline(_VideoBase):
             per_clip = [run(b) for b in batches]
         for m, (e, e_nn, lg, mf) in zip(metas, per_clip):
             m.update(embds=e, embds_nn=e_nn, logits=lg, mf=mf)
+            if self.debug_stages is not None:
+                self.debug_stages.update(mask_features=mf)
         return metas
 
     @property
@@ -402,6 +404,11 @@ class DVIS_Plus_offline(_VideoBase):
                              need_masks=False)
         ref = self.refiner(track["pred_embds"], to_bctq(embds_nn), None, need_masks=False)
         cls, aux = PP.mean_logits(ref["pred_logits"], track["pred_logits"])
+        if self.debug_stages is not None:      # tests / error budget: the floats of every stage, in the reference's layouts
+            self.debug_stages.update(frame_embds=to_bctq(embds), frame_embds_no_norm=to_bctq(embds_nn),
+                                     instance_embds=track["pred_embds"], online_logits=track["pred_logits"],
+                                     refiner_embds=ref["pred_embds"], refiner_logits=ref["pred_logits"],
+                                     refiner_mask_embed=ref["mask_embed"])
         return ref["mask_embed"], cls, aux
 
     def _finish_phase(self, st, mask_embed, cls, aux):
@@ -532,8 +539,11 @@ class DVIS_Plus_offline(_VideoBase):
         it, prev, n = iter(videos), None, 0
         while True:
             chunk = list(itertools.islice(it, per_round))
-            # rotate the ragged split (every rank gets the short blocks in turn); one segmenter batch per round
-            sts = self._segment_round(chunk, shift=n) if chunk else []
+            # Rounds of several clips: rotate the ragged split clip by clip (over a round every rank gets the short blocks
+            # in turn: equal merged batches).  One clip per round (tracker replicated): no rotation — a clip takes
+            # ceil(T / world) frames of segmenter time whoever holds the short block, and a fixed split means every rank
+            # keeps ONE batch shape (a new convolution shape costs a MIOpen solver search, seconds).
+            sts = self._segment_round(chunk, shift=n if per_round > 1 else 0) if chunk else []
             n += len(chunk)
             if overlap and sts:
                 done = torch.cuda.Event()

@@ -51,9 +51,13 @@ class ReferringCrossAttentionLayer(nn.Module):
         self.nhead = nhead
         _xavier_(self)
 
-    def attend(self, indentify, tgt, k_proj, v_proj):
-        C = tgt.shape[-1]
-        q = Fn.linear(tgt, self.multihead_attn.in_proj_weight[:C], self.multihead_attn.in_proj_bias[:C], own=self.own_gemm)
+    def attend(self, indentify, tgt, k_proj, v_proj, q_proj=None):
+        """q_proj: the already projected query (the tracker projects one reference for all its layers in one GEMM)."""
+        q = q_proj
+        if q is None:
+            C = tgt.shape[-1]
+            q = Fn.linear(tgt, self.multihead_attn.in_proj_weight[:C], self.multihead_attn.in_proj_bias[:C],
+                          own=self.own_gemm)
         att = Fn.attention(q, k_proj, v_proj, self.nhead)
         op = self.multihead_attn.out_proj
         return Fn.add_layer_norm(Fn.linear(att, op.weight, op.bias, own=self.own_gemm), indentify, self.norm)
@@ -119,6 +123,7 @@ class ReferringTracker_noiser(nn.Module):
         self.last_reference = None
         self.noise_mode, self.noise_ratio = noise_mode, noise_ratio   # training-only knobs (kept for the ctor surface)
         self._kv_cache = FusedKV()
+        self._q_cache = FusedKV("q")
         self.use_graphs = True
         self._graph = GraphRunner(self._recurrence_entry)
         use_own_gemm(self)
@@ -130,6 +135,9 @@ class ReferringTracker_noiser(nn.Module):
     def _kv_weights(self):
         return self._kv_cache.get(self.transformer_cross_attention_layers, self.decoder_norm.weight.shape[0])
 
+    def _q_weights(self):
+        return self._q_cache.get(self.transformer_cross_attention_layers, self.decoder_norm.weight.shape[0])
+
     def _recurrence_entry(self, fe_nn, idx_dev, last_outputs):
         return self._recurrence(fe_nn, idx_dev, last_outputs, self._rec_first)
 
@@ -140,18 +148,23 @@ class ReferringTracker_noiser(nn.Module):
         T, Q, B, C = fe_nn.shape
         W, b = self._kv_weights()
         kv = Fn.linear(fe_nn, W, b, own=True)                                  # (T, Q, 1, layers * 2C): one GEMM
+        Wq, bq = self._q_weights()
         outputs, refs = [], []
         for i in range(T):
             single_nn = fe_nn[i]                                               # (q, b, c)
             out = single_nn[idx_dev[i]]
             first = i == 0 and first_is_start
             if not first:
+                # the same reference feeds every layer's cross-attention (tracker.py:278, 293-318): its 6 query
+                # projections are ONE GEMM (N = layers * C) instead of six launches in the sequential chain
                 reference = self.ref_proj(last_outputs)
+                q_all = Fn.linear(reference, Wq, bq, own=True)
             for j in range(self.num_layers):
                 ref_j = self.ref_proj(single_nn if j == 0 else out) if first else reference
                 kj = kv[i, :, :, (2 * j) * C:(2 * j + 1) * C]
                 vj = kv[i, :, :, (2 * j + 1) * C:(2 * j + 2) * C]
-                out = self.transformer_cross_attention_layers[j].attend(out, ref_j, kj, vj)
+                qj = None if first else q_all[..., j * C:(j + 1) * C]
+                out = self.transformer_cross_attention_layers[j].attend(out, ref_j, kj, vj, q_proj=qj)
                 out = self.transformer_self_attention_layers[j](out)
                 out = self.transformer_ffn_layers[j](out)
             refs.append(self.ref_proj(single_nn) if first else reference)
@@ -179,9 +192,10 @@ class ReferringTracker_noiser(nn.Module):
         ref0 = cur[0] if first_is_start else self.last_frame_embeds[:, 0, :]
         indices = match_chain(cosine_costs(cur, ref0))                         # (T, Q) int64, host
         idx_dev = torch.from_numpy(indices).to(fe.device)
+        self.last_indices = indices                                            # (T, Q): this call's assignments (tests)
 
         # ---- 2 + 3. K / V of all layers for all frames (one GEMM) and the recurrence, replayed from a hipGraph
-        self._kv_weights()                                                     # build the cached weights outside capture
+        self._kv_weights(), self._q_weights()                                  # build the cached weights outside capture
         state = self.last_outputs if not first_is_start else torch.zeros_like(fe_nn[0])
         self._rec_first = first_is_start                                       # part of the graph key: fixes control flow
         self._graph.enabled = self.use_graphs

@@ -318,7 +318,7 @@ def refiner_forward(sd, instance_embeds, frame_embeds, mask_features, nheads, la
     act = linear(sd, p + "activation_proj", dec_b).softmax(dim=1)             # softmax over t (:203)
     pooled = (dec_b * act).sum(dim=1, keepdim=True).repeat(1, T, 1, 1)
     logits = linear(sd, p + "class_embed", pooled)                            # (b, t, q, K+1)
-    return dict(pred_logits=logits, pred_masks=masks, pred_embds=dec.permute(2, 3, 0, 1))
+    return dict(pred_logits=logits, pred_masks=masks, pred_embds=dec.permute(2, 3, 0, 1), mask_embed=emb)
 
 
 # ----------------------------------------------------------------------------- post-processing (a12, a13)
@@ -450,7 +450,7 @@ def dvis_plus_forward(sd, backbone, frames, *, offline=True, nheads=8, enc_layer
     nheads, nheads_t = (nheads, nheads) if isinstance(nheads, int) else nheads
     trk = tracker if tracker is not None else Tracker(_sub(sd, "tracker."), nheads_t, tracker_layers)
     T = len(images)
-    all_mf, all_fe_nn, all_inst, online_logits, online_masks = [], [], [], [], []
+    all_mf, all_fe_nn, all_inst, online_logits, online_masks, all_fe, all_ms0 = [], [], [], [], [], [], []
     for s in range(0, T, window_size):                                      # the reference's window loop
         feats = backbone(images[s:s + window_size])
         mf, _, ms = pixel_decoder_forward(pd, feats, nheads, enc_layers)
@@ -458,6 +458,8 @@ def dvis_plus_forward(sd, backbone, frames, *, offline=True, nheads=8, enc_layer
         t_out = trk.forward(out["pred_embds"], mf.unsqueeze(0), resume=(s != 0) or (bool(keep) and not offline),
                             frame_embeds_no_norm=out["pred_embds_without_norm"], with_masks=not offline)
         all_mf.append(mf)
+        all_fe.append(out["pred_embds"])
+        all_ms0.append(ms[-1])
         all_fe_nn.append(out["pred_embds_without_norm"])
         all_inst.append(t_out["pred_embds"])
         online_logits.append(t_out["pred_logits"])
@@ -475,9 +477,11 @@ def dvis_plus_forward(sd, backbone, frames, *, offline=True, nheads=8, enc_layer
         masks = torch.cat(online_masks, 2)[0]
     if stages is not None:
         stages.update(mask_features=mask_features, cls=cls, aux=aux, masks=masks, online_logits=online_logits,
-                      tracker=trk, instance_embds=torch.cat(all_inst, 2))
+                      tracker=trk, instance_embds=torch.cat(all_inst, 2), frame_embds=torch.cat(all_fe, 2),
+                      frame_embds_no_norm=torch.cat(all_fe_nn, 2), encoder_finest=torch.cat(all_ms0, 0))
         if offline:
-            stages.update(refiner_logits=ref["pred_logits"], refiner_embds=ref["pred_embds"])
+            stages.update(refiner_logits=ref["pred_logits"], refiner_embds=ref["pred_embds"],
+                          refiner_mask_embed=ref.get("mask_embed"))
     first = tuple(images.shape[-2:])
     out_hw = img_size if out_hw is None else out_hw
     if task == "vis":

@@ -131,3 +131,45 @@ def compare_vss(out, ref, stages, what, max_count=None):
     margin = intcmp.argmax_margin(stages["vss_sums"])
     return intcmp.near_boundary(out["pred_masks"].cpu(), ref, margin, TOL_PROB, f"{what}: semantic map vs oracle",
                                 max_count=max_count)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Error budget: where does the product-vs-oracle difference of the final mask logits come from?  Both sides expose the
+# same stage tensors (model.debug_stages / oracle `stages`, the reference's layouts); every row is max |product - oracle|,
+# the oracle's max |value| and their ratio.  Written to $DVIS_PARITY_REPORT like every other comparison.
+# ------------------------------------------------------------------------------------------------------------------
+STAGES = (("mask_features", "pixel decoder: mask_features (T,Cm,h,w)"),
+          ("frame_embds_no_norm", "decoder: per-frame queries, un-normed (1,2C,T,Q)"),
+          ("frame_embds", "decoder: per-frame queries, normed"),
+          ("instance_embds", "tracker: instance embeddings (1,2C,T,Q)"),
+          ("online_logits", "tracker: class logits (1,T,Q,K+1)"),
+          ("refiner_embds", "refiner: embeddings after decoder_norm (1,2C,T,Q)"),
+          ("refiner_logits", "refiner: class logits"),
+          ("refiner_mask_embed", "refiner: mask embeddings (1,T,Q,Cm)"))
+
+
+def error_budget(product, oracle, mask_logits_product, what, frames=(0, 10, 20, 29)):
+    """-> {stage: (max abs err, max |oracle|)}; reports one line per stage + the tracker's error at a few frames."""
+    rows = {}
+    _r = intcmp._report
+    _r(f"error budget, {what}: stage | max |product - oracle| | max |oracle| | ratio")
+    for key, title in STAGES:
+        if key not in product or key not in oracle or oracle[key] is None:
+            continue
+        a, b = product[key].detach().float().cpu(), oracle[key].detach().float().cpu()
+        if key == "mask_features" and b.dim() == 5:
+            b = b[0]
+        assert a.shape == b.shape, f"{key}: {tuple(a.shape)} vs {tuple(b.shape)}"
+        err, scale = float((a - b).abs().max()), float(b.abs().max())
+        rows[key] = (err, scale)
+        _r(f"  {title}: {err:.3e} | {scale:.3e} | {err / max(scale, 1e-30):.2e}")
+        if key == "instance_embds":
+            T = a.shape[2]
+            per_t = [(t, float((a[:, :, t] - b[:, :, t]).abs().max())) for t in frames if t < T]
+            _r("    tracker recurrence, per frame: " + ", ".join(f"t={t}: {e:.2e}" for t, e in per_t))
+    if mask_logits_product is not None:
+        a, b = mask_logits_product.detach().float().cpu(), oracle["masks"].float()
+        err, scale = float((a - b).abs().max()), float(b.abs().max())
+        rows["mask_logits"] = (err, scale)
+        _r(f"  final mask logits (Q,T,h,w): {err:.3e} | {scale:.3e} | {err / max(scale, 1e-30):.2e}")
+    return rows

@@ -278,7 +278,8 @@ def test_clip_stream_world_size_2_gloo(oracle_ops, tmp_path, world, owner_rounds
     """stream() under frame sharding: phase A has no collective, phase B issues them in the same order on every rank.
     owner_rounds=1: clips go in rounds of `world`, clip j of a round is tracked + refined by rank j only (3 clips on 2
     ranks -> rank 0 tracks two, rank 1 one; on 3 ranks one each) and the results are all-gathered; a rank's frames of a
-    round are one segmenter batch; the ragged split rotates clip by clip.  owner_rounds=0: every rank tracks every clip."""
+    round are one segmenter batch; the ragged split rotates clip by clip.  owner_rounds=0: every rank tracks every clip,
+    the split does not rotate."""
     import torch.multiprocessing as mp
     port = 33500 + (os.getpid() % 2000) + 10 * world + owner_rounds
     mp.spawn(_stream_worker, args=(world, port, str(tmp_path), owner_rounds), nprocs=world, join=True)
@@ -289,10 +290,12 @@ def test_clip_stream_world_size_2_gloo(oracle_ops, tmp_path, world, owner_rounds
     assert [p["tracked"] for p in parts] == want_tracked
     for ci, (T, seed) in enumerate(STREAM_CLIPS):
         single = m([{"image": _tiny_clip(T, seed=seed), "height": 70, "width": 100}])
-        # clip ci shards with the block -> rank assignment rotated by ci (the short block changes rank every clip)
+        # owner rounds: clip ci shards with the block -> rank assignment rotated by ci (the short block changes rank every
+        # clip, a round's merged batches are equal); one clip per round (replicated tracker): fixed split, one batch
+        # shape per rank
         per = (T + world - 1) // world
         blocks = [list(range(min(T, b * per), min(T, (b + 1) * per))) for b in range(world)]
-        order = [(r - ci) % world for r in range(world)]               # block held by rank r
+        order = [(r - (ci if owner_rounds else 0)) % world for r in range(world)]               # block held by rank r
         assert [p["outs"][ci]["frame_ids"] for p in parts] == [blocks[b] for b in order]
         by_block = sorted(range(world), key=lambda r: order[r])
         assert torch.equal(torch.cat([parts[r]["outs"][ci]["masks"] for r in by_block], 0), single["pred_masks"])

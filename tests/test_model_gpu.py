@@ -137,6 +137,37 @@ def test_image_mask2former_gpu_vs_oracle():
     torch.testing.assert_close(out["sem_seg"].cpu(), sem, rtol=1e-3, atol=1e-3)
 
 
+def test_image_mask2former_full_config_480x640_vs_oracle():
+    """BASELINE config #1 AT ITS OWN SIZE on the GPU: Mask2Former R50, one 480 x 640 frame, 100 queries, 6 encoder layers,
+    9 + 1 decoder layers, 133 classes (COCO panoptic head sizes) — semantic map and the decoder's logits / stride-4 masks
+    against oracle.maskformer_image_forward (the reference's CPU / torch MSDeformAttn path), from the backbone outputs on."""
+    from dvis_plus_amd.meta_architecture import build_mask2former_r50
+    from oracle import dvis_torch as O
+    m = build_mask2former_r50(semantic_on=True)                       # 133 classes, 100 queries, 6 enc, 10 dec layers
+    _perturb_msda(m.sem_seg_head.pixel_decoder)
+    img = torch.randint(0, 256, (3, 480, 640), dtype=torch.uint8, generator=torch.Generator().manual_seed(7))
+    sd = _cpu_sd(m)
+    sd["pixel_mean"], sd["pixel_std"] = m.pixel_mean.clone(), m.pixel_std.clone()
+    m = m.to(DEV)
+    with torch.no_grad():
+        out = m([{"image": img.to(DEV), "height": 480, "width": 640}])[0]
+        dec = m.sem_seg_head(m.backbone(((img.to(DEV).float() - m.pixel_mean) / m.pixel_std)[None]))
+
+    def backbone_from_gpu(images_cpu):
+        with torch.no_grad():
+            return {k: v.cpu() for k, v in m.backbone(images_cpu.to(DEV)).items()}
+    with torch.no_grad():
+        sem, logits, masks = O.maskformer_image_forward(sd, backbone_from_gpu, img, nheads=8, enc_layers=6, dec_layers=9,
+                                                        num_classes=133)
+    assert out["sem_seg"].shape == (133, 480, 640)
+    torch.testing.assert_close(dec["pred_logits"].cpu(), logits, rtol=1e-3, atol=1e-3)
+    err = float((dec["pred_masks"].cpu() - masks).abs().max())
+    print(f"config #1 480x640 full config: stride-4 mask logits max |product - oracle| {err:.2e} "
+          f"(max |logit| {float(masks.abs().max()):.2f})")
+    assert err <= 1e-3                                                # BASELINE.json's literal bound
+    torch.testing.assert_close(out["sem_seg"].cpu(), sem, rtol=1e-3, atol=1e-3)
+
+
 def test_minvis_gpu_vs_oracle():
     """MinVIS on the GPU: bit-exact alignment chain, same top-10 (query, class) pairs, masks equal away from 0."""
     from dvis_plus_amd.meta_architecture import build_dvis_plus_r50

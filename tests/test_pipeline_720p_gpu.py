@@ -22,11 +22,11 @@ DEV = "cuda:0"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def _model(mode, task, **kw):
+def _model(mode, task, gain=PPar.SHARPEN, **kw):
     from dvis_plus_amd.meta_architecture import build_dvis_plus_r50
     m = build_dvis_plus_r50(mode, task=task, object_mask_threshold=0.0, **kw)
     PPar.perturb_msda(m.sem_seg_head.pixel_decoder)
-    PPar.sharpen_masks(m, PPar.SHARPEN)
+    PPar.sharpen_masks(m, gain)
     return m, PPar.cpu_state(m)
 
 
@@ -79,14 +79,13 @@ def test_bench_workload_T30_vps_stream_vs_oracle():
     what = "config #3 offline vps T=30 720p through stream() (bench workload)"
     tol = PPar.logit_tolerance(float(stages["masks"][stages["vps_query_ids"]].abs().max()))
     PPar.compare_vps(outs[0], ref, stages, what, tol_logit=tol)
-    # (two runs of the same clip are not bit-identical at this size: some library GEMM / convolution kernels accumulate
-    # with atomics; a stream-ordering bug would garble whole regions, rounding noise moves a few boundary pixels)
+    # Round 3: the pipeline is bit-reproducible (phase A's library kernels measured reproducible run to run —
+    # tools/determinism_probe.py — and phase B runs on the own deterministic GEMM): stream() next to another clip's
+    # segmenter == forward() alone, EXACTLY.  (Rounds 1-2: 1.8 - 2.0 k pixels differed, excused as library noise.)
     again = m([videos[1]])
     assert again["segments_infos"] == outs[1]["segments_infos"] and again["pred_ids"] == outs[1]["pred_ids"]
-    n_diff = int((again["pred_masks"] != outs[1]["pred_masks"]).sum())
-    PPar.intcmp._report(f"config #3 clip 1: stream() vs forward() of the same clip: {n_diff} of "
-                        f"{again['pred_masks'].numel()} panoptic pixels differ (run-to-run library noise)")
-    assert n_diff <= 20000                 # 0.07 % of the map; observed 1.8 - 2.0 k
+    PPar.intcmp.exact(outs[1]["pred_masks"], again["pred_masks"],
+                      "config #3 clip 1: stream() vs forward() of the same clip, panoptic map")
     # Random masks overlap heavily, so the reference's 0.8 overlap rule keeps few segments.  Second comparison on the
     # same clip with the overlap rule off: every candidate that wins a pixel becomes a segment, i.e. the whole
     # 30 x 720 x 1280 arg-max map is compared.  (The oracle's post-processing is re-run on its stored class
@@ -109,7 +108,7 @@ def test_t64_clips_streamed_equal_clip_by_clip():
     """BASELINE config #4's clip length on one GPU: T = 64 at 720p through stream(), one 64-frame segmenter call per clip
     (4.7 GiB FFN activation) with phase B on the second stream — the schedule that stalled in rounds 1-2 and was capped
     (DESIGN.md section 9); phase B no longer issues library GEMMs, the caps are gone (tests/test_stream_gpu.py soaks it).
-    Streamed == clip by clip: segment lists equal, the maps up to phase A's run-to-run library noise."""
+    Streamed == clip by clip, bit for bit."""
     import bench
     from dvis_plus_amd.meta_architecture import segmenter_frames_per_call
     assert segmenter_frames_per_call(64, 736, 1280) == 64
@@ -123,7 +122,101 @@ def test_t64_clips_streamed_equal_clip_by_clip():
         want = m([v])
         assert o["pred_masks"].shape == (64, 720, 1280)
         assert o["segments_infos"] == want["segments_infos"] and o["pred_ids"] == want["pred_ids"]
-        n_diff = int((o["pred_masks"] != want["pred_masks"]).sum())
-        PPar.intcmp._report(f"config #4 clip length (T=64) streamed vs clip by clip: {n_diff} of {want['pred_masks'].numel()} "
-                            f"panoptic pixels differ (run-to-run noise of phase A's library kernels)")
-        assert n_diff <= 40000
+        PPar.intcmp.exact(o["pred_masks"], want["pred_masks"],
+                          "config #4 clip length (T=64) streamed vs clip by clip, panoptic map")
+
+
+def test_T30_natural_logit_scale_literal_1e3_and_error_budget():
+    """BASELINE.json: "mask logits within 1e-3 of reference" — asserted LITERALLY on the benchmarked configuration (#3,
+    T = 30, 720p, full R50 sizes) at a natural logit scale: mask heads scaled so that max |logit| is 4 - 10 (trained
+    DVIS++ masks live there; the x40 `sharpen_masks` of the other tests pushes |logit| beyond 100 to make every arg-max
+    decisive, which multiplies the absolute error by the same factor).  Also records the per-stage error budget
+    (encoder -> decoder -> 30-frame tracker recurrence -> refiner -> mask embeddings -> logits)."""
+    import bench
+    gain = 3.0
+    m, sd = _model("offline", "vps", gain=gain)
+    m = m.to(DEV)
+    clip = bench.synthetic_clip(30, torch.device(DEV), seed=1234)
+    video = {"image": clip, "height": 720, "width": 1280}
+    m.object_mask_threshold = bench.calibrate_threshold(m, [video], 20)
+    m.overlap_threshold = 0.0
+    m.debug_stages = {}
+    out = m([video])
+    ref, stages = PPar.run_oracle(m, sd, [f for f in clip.cpu()], offline=True, task="vps",
+                                  object_mask_threshold=m.object_mask_threshold, overlap_threshold=0.0, out_hw=(720, 1280))
+    what = f"config #3 offline vps T=30 720p, mask heads x{gain:g} (natural logit scale)"
+    with torch.no_grad():
+        all_logits = m.debug_stages["mask_fn"](None)                                    # (Q, T, h, w), all 100 queries
+    rows = PPar.error_budget(m.debug_stages, stages, all_logits, what)
+    err, scale = rows["mask_logits"]
+    assert 2.0 <= scale <= 16.0, f"the test's premise: natural logit scale (got max |logit| {scale:.1f})"
+    assert err <= 1e-3, f"mask logits: max |product - oracle| {err:.3e} exceeds BASELINE's literal 1e-3 at max |logit| {scale:.1f}"
+    for key in ("frame_embds", "instance_embds", "refiner_embds"):                      # embeddings of order 1-10
+        assert rows[key][0] <= 1e-3, f"{key}: {rows[key]}"
+    PPar.compare_vps(out, ref, stages, what, tol_logit=PPar.TOL_LOGIT)
+
+
+def test_config4_T64_vs_oracle_prefix_suffix_and_refiner():
+    """BASELINE config #4's clip (T = 64, 720p, full R50 sizes) on one GPU against the ORACLE, not against itself.  The
+    oracle's windowed CPU pipeline over 64 frames would take ~10 minutes, so the comparison uses the structure of the
+    path: (1) PREFIX — the segmenter is per-frame and the tracker causal, so frames 0..5 of the 64-frame run must equal
+    the oracle's run on those 6 frames (2 reference windows); (2) SUFFIX — the oracle's tracker, given the product's
+    state after frame 60 (last_outputs / last_frame_embeds / last_reference, tracker.py:175-185), run on the last
+    reference window (frames 61, 62, 63) with `resume`, must reproduce the product's instance embeddings / logits /
+    assignment indices there: 60 frames of recurrence have not drifted; (3) REFINER — the oracle's refiner over all 64
+    frames, fed the product's tracker outputs, must reproduce the product's refined embeddings, mask embeddings and class
+    logits (the refiner attends over the whole clip: no prefix property)."""
+    import bench
+    import numpy as np
+    from oracle import dvis_torch as O
+    m, sd = _model("offline", "vps", gain=3.0)
+    m = m.to(DEV)
+    T = 64
+    clip = bench.synthetic_clip(T, torch.device(DEV), seed=4242)
+    video = {"image": clip, "height": 720, "width": 1280}
+    m.object_mask_threshold = bench.calibrate_threshold(m, [video], 20)
+    m.debug_stages = {}
+    out = m([video])
+    assert out["pred_masks"].shape == (T, 720, 1280)
+    P = {k: (v.detach().float().cpu() if torch.is_tensor(v) else v) for k, v in m.debug_stages.items() if k != "mask_fn"}
+    idx_prod = np.array(m.tracker.last_indices)
+    rep = PPar.intcmp._report
+    # ---- (1) prefix
+    ref, st = PPar.run_oracle(m, sd, [f for f in clip[:6].cpu()], offline=True, task="vps",
+                              object_mask_threshold=m.object_mask_threshold, out_hw=(720, 1280))
+    for key in ("frame_embds", "frame_embds_no_norm", "instance_embds"):
+        e = float((P[key][:, :, :6] - st[key]).abs().max())
+        rep(f"config #4 T=64 prefix (frames 0-5) {key}: max |product - oracle| {e:.2e} at max |value| {float(st[key].abs().max()):.1f}")
+        assert e <= 1e-3
+    e = float((P["online_logits"][:, :6] - st["online_logits"]).abs().max())
+    rep(f"config #4 T=64 prefix tracker class logits: max |product - oracle| {e:.2e}")
+    assert e <= 1e-3
+    e = float((P["mask_features"][:6] - st["mask_features"][0]).abs().max())
+    rep(f"config #4 T=64 prefix mask_features: max |product - oracle| {e:.2e} at max |value| {float(st['mask_features'].abs().max()):.1f}")
+    assert e <= 1e-3
+    # ---- (2) suffix: frames 61..63 = the reference's last full window before the ragged end (64 = 21 * 3 + 1)
+    t0 = 61
+    trk = O.Tracker(O._sub(sd, "tracker."), 8, 6)
+    inst, fe = P["instance_embds"], P["frame_embds"]                       # (1, C, T, Q)
+    prev = t0 - 1
+    trk.last_outputs = inst[0, :, prev].t()[None, :, None, :]              # (1 layer kept, Q, 1, C): only [-1] is read
+    trk.last_frame_embeds = fe[0, :, prev].t()[torch.as_tensor(idx_prod[prev])][:, None, :]
+    with torch.no_grad():
+        t_out = trk.forward(fe[:, :, t0:], None, resume=True, frame_embeds_no_norm=P["frame_embds_no_norm"][:, :, t0:],
+                            with_masks=False)
+    assert np.array_equal(t_out["indices"], idx_prod[t0:]), "assignment indices of the last window differ"
+    e = float((t_out["pred_embds"] - inst[:, :, t0:]).abs().max())
+    rep(f"config #4 T=64 suffix (frames 61-63, oracle tracker resumed from the product's state at frame 60): instance "
+        f"embeddings max |product - oracle| {e:.2e} at max |value| {float(inst.abs().max()):.1f}")
+    assert e <= 1e-3
+    e = float((t_out["pred_logits"] - P["online_logits"][:, t0:]).abs().max())
+    rep(f"config #4 T=64 suffix tracker class logits: max |product - oracle| {e:.2e}")
+    assert e <= 1e-3
+    # ---- (3) refiner over all 64 frames on the product's tracker outputs
+    with torch.no_grad():
+        r = O.refiner_forward(O._sub(sd, "refiner."), inst, P["frame_embds_no_norm"],
+                              torch.zeros(1, T, 256, 1, 1), 8, 6)
+    for key, got in (("pred_embds", P["refiner_embds"]), ("pred_logits", P["refiner_logits"]), ("mask_embed", P["refiner_mask_embed"])):
+        e = float((r[key] - got).abs().max())
+        rep(f"config #4 T=64 refiner over 64 frames, {key}: max |product - oracle| {e:.2e} at max |value| {float(r[key].abs().max()):.1f}")
+        assert e <= 1e-3

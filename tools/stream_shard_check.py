@@ -94,6 +94,22 @@ def main():
                   f"segments={len(single['segments_infos'])} masks_equal={same} (differing pixels {diff:.2e}) "
                   f"segments_equal={segs}")
             bad += (not segs) or diff > 3e-3   # other batch sizes -> other conv / GEMM algorithms -> a few tie pixels flip
+        # ---- and against the ORACLE (not only against the unsharded product): the sharded ranks' concatenated panoptic
+        # map of clip 0 vs the CPU oracle's windowed pipeline on the same frames and weights (from the backbone outputs on)
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+        import pipeline_parity as PPar
+        sd = PPar.cpu_state(model)
+        clip0 = clips[0]
+        ref, stages = PPar.run_oracle(model, sd, [f for f in clip0["image"].cpu()], offline=True, task="vps",
+                                      object_mask_threshold=model.object_mask_threshold, out_hw=(args.height, args.width))
+        masks0 = torch.cat([p[0]["masks"] for p in sorted(parts, key=lambda p: (p[0]["fr"] or [1 << 30])[0])], 0)
+        sharded = {"pred_masks": masks0, "segments_infos": parts[0][0]["segs"], "pred_ids": parts[0][0]["ids"]}
+        try:
+            n = PPar.compare_vps(sharded, ref, stages, f"sharded stream() over {world} ranks, clip 0 vs ORACLE")
+            print(f"clip 0 vs oracle: segment lists equal, {n} differing pixels, all within the 1e-3 logit allowance")
+        except AssertionError as e:
+            print("clip 0 vs oracle FAILED:", str(e)[:500])
+            bad += 1
         print("SHARD_CHECK", "OK" if not bad else "FAILED", f"world={world}")
         sys.exit(1 if bad else 0)
 
