@@ -32,7 +32,7 @@ struct GemmArgs {
   float *C;
   long long lda, ldw, ldres, ldc;          // row strides in floats
   long long sA, sW, sRes, sC;              // batch strides in floats
-  int M, N, K, act, row_blocks, vec_store;
+  int M, N, K, act, row_blocks, col_blocks, vec_store, col_fastest;
 };
 
 template <int RT, int CT, int NW, int PF, bool K16>
@@ -43,7 +43,20 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GemmArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
-  const int rb = blockIdx.x % p.row_blocks, cb = blockIdx.x / p.row_blocks;
+  // Tile of this workgroup.  Skinny problems: row blocks fastest (workgroups that share a weight slab run together).
+  // Tall problems (A does not fit the caches): column blocks fastest AND XCD-aware — dispatch puts block b on XCD b % 8,
+  // so the logical tile id is remapped such that an XCD walks CONSECUTIVE logical tiles: the N / BN column blocks that
+  // re-read one row block of A then follow each other on one XCD's L2 instead of being spread over the launch (A would
+  // be re-fetched from HBM N / BN times) or over 8 L2s.
+  int rb, cb;
+  if (p.col_fastest) {
+    const unsigned tiles = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const unsigned q8 = tiles >> 3, r8 = tiles & 7u;                       // bijective also when tiles % 8 != 0
+    const unsigned logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    rb = (int)(logical / (unsigned)p.col_blocks), cb = (int)(logical % (unsigned)p.col_blocks);
+  } else {
+    rb = blockIdx.x % p.row_blocks, cb = blockIdx.x / p.row_blocks;
+  }
   const int row0 = rb * BM, col0 = cb * BN;
   const long long batch = blockIdx.y;
 
@@ -177,6 +190,9 @@ const Config kConfigs[] = {
     DVIS_GEMM_CFG(4, 4, 2, 2),   // 9
     DVIS_GEMM_CFG(7, 1, 8, 2),   // 10: 112 x 16 (all rows of a 100-query block)
     DVIS_GEMM_CFG(7, 2, 4, 2),   // 11: 112 x 32
+    DVIS_GEMM_CFG(4, 4, 1, 2),   // 12: 64 x 64, one wave, K not split (short K, tall M)
+    DVIS_GEMM_CFG(8, 4, 2, 2),   // 13: 128 x 64
+    DVIS_GEMM_CFG(8, 4, 1, 2),   // 14
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -224,11 +240,13 @@ DVIS_EXPORT int dvis_gemm_nt(const float *A, int64_t lda, int64_t strideA, const
   p.sA = strideA, p.sW = strideW, p.sRes = strideRes, p.sC = strideC;
   p.M = M, p.N = N, p.K = K, p.act = act;
   p.row_blocks = (M + BM - 1) / BM;
+  p.col_blocks = (N + BN - 1) / BN;
+  // A larger than what the caches keep between two passes over it (L2s 32 MB; the 256 MB MALL is shared with C and W)
+  p.col_fastest = (long long)M * K * 4 > (64ll << 20) && p.col_blocks > 1;
   p.vec_store = N % 4 == 0 && ldc % 4 == 0 && strideC % 4 == 0 && (uintptr_t)C % 16 == 0 &&
                 (!bias || (uintptr_t)bias % 16 == 0) &&
                 (!res || (ldres % 4 == 0 && strideRes % 4 == 0 && (uintptr_t)res % 16 == 0));
-  const long long col_blocks = (N + BN - 1) / BN;
-  const long long tiles = p.row_blocks * col_blocks;
+  const long long tiles = (long long)p.row_blocks * p.col_blocks;
   DVIS_REQUIRE(tiles < (1ll << 31), "gemm_nt: too many tiles");
   const size_t lds = (size_t)cf.nw * BM * BN * sizeof(float);
   auto kernel = K % 16 == 0 ? cf.kernel16 : cf.kernel4;

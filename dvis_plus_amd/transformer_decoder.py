@@ -172,6 +172,7 @@ class _MaskedDecoderBase(nn.Module):
         self.class_embed = nn.Linear(hidden_dim, num_classes + 1)
         self.mask_embed = MLP(hidden_dim, hidden_dim, mask_dim, 3)
         self._kv_cache = None
+        self.debug_masks = None      # tests: a list here receives every layer's effective attention mask (N, Q, hw) bool
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
                               error_msgs):
@@ -249,6 +250,8 @@ class _MaskedDecoderBase(nn.Module):
             lvl = i % self.num_feature_levels
             emb = self.mask_embed(self.decoder_norm(output).transpose(0, 1))                    # (N, Q, Cm)
             mask, allowed = Fn.attn_mask(emb.contiguous(), mask_features, size_list[lvl])
+            if self.debug_masks is not None:     # rows blocked everywhere attend everywhere (…decoder.py:297)
+                self.debug_masks.append(mask.bool() & (allowed > 0)[..., None])
             layer = self.transformer_cross_attention_layers[i]
             output = layer.attend(output, output + query_embed, kproj[i], vproj[i], mask, allowed)
             output = self.transformer_self_attention_layers[i](output, query_pos=query_embed)

@@ -458,6 +458,9 @@ def dvis_plus_forward(sd, backbone, frames, *, offline=True, nheads=8, enc_layer
         t_out = trk.forward(out["pred_embds"], mf.unsqueeze(0), resume=(s != 0) or (bool(keep) and not offline),
                             frame_embeds_no_norm=out["pred_embds_without_norm"], with_masks=not offline)
         all_mf.append(mf)
+        if stages is not None and stages.get("want_attn_masks"):
+            # effective attention masks (head 0 of each frame; fully blocked rows already reset), one list per layer
+            stages.setdefault("attn_masks", []).append([a[::nheads].clone() for a in out["attn_masks"]])
         all_fe.append(out["pred_embds"])
         all_ms0.append(ms[-1])
         all_fe_nn.append(out["pred_embds_without_norm"])

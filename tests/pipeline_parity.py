@@ -73,10 +73,10 @@ def gpu_backbone(m):
     return backbone_from_gpu
 
 
-def run_oracle(m, sd, frames_cpu, *, offline, task, **cfg):
+def run_oracle(m, sd, frames_cpu, *, offline, task, attn_masks=False, **cfg):
     """-> (task outputs of oracle.dvis_plus_forward, stages dict with the floats behind the integer decisions)."""
     from oracle import dvis_torch as O
-    stages = {}
+    stages = {"want_attn_masks": True} if attn_masks else {}
     with torch.no_grad():
         ref = O.dvis_plus_forward(sd, gpu_backbone(m), frames_cpu, offline=offline, task=task, stages=stages, **cfg)
     return ref, stages
@@ -173,3 +173,23 @@ def error_budget(product, oracle, mask_logits_product, what, frames=(0, 10, 20, 
         rows["mask_logits"] = (err, scale)
         _r(f"  final mask logits (Q,T,h,w): {err:.3e} | {scale:.3e} | {err / max(scale, 1e-30):.2e}")
     return rows
+
+
+def attention_mask_flips(product_masks, oracle_masks, T):
+    """Decoder attention masks are BOOLEANS derived from logits (sigmoid < 0.5): where a down-sized logit sits within the
+    two pipelines' rounding difference of 0, the bit differs, and that query then attends to a different key set — a
+    discrete event that moves its embedding by far more than rounding does.  product_masks: list over layers of
+    (T, Q, hw) bool (model.sem_seg_head.predictor.debug_masks); oracle_masks: list over windows of lists over layers of
+    (t_w, Q, hw).  -> (flips (layers, T, Q) int64, total bits per layer)."""
+    L = len(product_masks)
+    flips, bits = [], []
+    for l in range(L):
+        o = torch.cat([w[l] for w in oracle_masks], 0)
+        p = product_masks[l].cpu()
+        assert p.shape == o.shape, (p.shape, o.shape)
+        flips.append((p != o).sum(-1))
+        bits.append(o[0].numel() * T)
+    flips = torch.stack(flips)
+    intcmp._report("decoder attention masks, differing bits per layer (product vs oracle): "
+                   + ", ".join(f"L{l}: {int(flips[l].sum())}/{bits[l]}" for l in range(L)))
+    return flips, bits
