@@ -85,9 +85,9 @@ class ClipShard:
         return x
 
     def broadcast_from_rank0(self, tensors):
-        """Make small decision inputs (class logits) bit-identical on every rank.  Tracker + refiner are replicated and
-        deterministic, but library heuristics (MIOpen find) may pick different conv algorithms per rank; post-processing
-        takes keep/merge decisions and sizes a collective from these values, so they must agree exactly."""
+        """Make small decision inputs bit-identical on every rank.  (Rounds 1-2 broadcast the replicated tracker's class
+        logits because its library GEMMs could pick different algorithms per rank; since round 3 the tracker / refiner run
+        on the own deterministic GEMM and the pipeline no longer calls this.)"""
         if self.world > 1 or self.force:
             for t in tensors:
                 if t is not None:

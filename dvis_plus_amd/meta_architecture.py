@@ -430,13 +430,16 @@ class DVIS_Plus_offline(_VideoBase):
 
     @torch.no_grad()
     def _track_phase(self, st):
-        """Phase B on the current stream: all-gather of the per-frame queries, tracker, refiner (replicated on every
-        rank), masks of this rank's frames, post-processing."""
+        """Phase B on the current stream: ONE all-gather of the per-frame queries, tracker + refiner replicated on every
+        rank, masks of this rank's frames, post-processing (VPS: one tiny all-reduce of the segment areas)."""
         self.keep = bool(st["video"].get("keep", False))
         embds, embds_nn, _ = self.clip_shard.all_gather_frames([st["embds"], st["embds_nn"], st["logits"]], st["T"],
                                                                shift=st["shift"])
+        # Replicated tracker + refiner need NO broadcast: every rank holds the same gathered queries, the host assignment
+        # is deterministic, and since round 3 phase B runs no library kernel (own deterministic GEMM, attention, add+LN)
+        # — same bits on every rank, so the post-processing decisions agree.  north_star's "single all-gather" is
+        # literally that (+ the few-hundred-byte VPS area sum).
         mask_embed, cls, aux = self._track_core(embds, embds_nn)
-        cls, aux = self.clip_shard.broadcast_from_rank0([cls.contiguous(), aux.contiguous()])
         return self._finish_phase(st, mask_embed, cls, aux)
 
     @torch.no_grad()
@@ -641,7 +644,6 @@ class DVIS_Plus_offline(_VideoBase):
                  "pred_logits": cat([t["pred_logits"] for t in tracks], 1)}
         ref = self.refiner(track["pred_embds"], to_bctq(embds_nn), None, need_masks=False)
         cls, aux = PP.mean_logits(ref["pred_logits"], track["pred_logits"])
-        cls, aux = self.clip_shard.broadcast_from_rank0([cls.contiguous(), aux.contiguous()])
         if contiguous:
             emb_local = ref["mask_embed"][:, local_ids[0]:local_ids[0] + len(local_ids)] if local_ids \
                 else ref["mask_embed"][:, :0]                                       # (1, t_local, Q, Cm)

@@ -574,6 +574,48 @@ def test_reloaded_weights_reach_the_fused_kv_projection(oracle_ops):
 RAGGED8 = [30] * 9 + [5]        # the last clip leaves three of the eight ranks without a frame
 
 
+def _northstar_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import conftest as c
+    from dvis_plus_amd import functions as Fn
+    Fn.attention, Fn.attn_mask, Fn.mask_logits = c._o_attention, c._o_attn_mask, c._o_mask_logits
+    Fn.msda_fused_forward, Fn.MSDeformAttnFunction = c._o_msda_fused, c._OMSDAFunction
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _tiny_model("offline", "vps")
+    m.owner_rounds = False                        # north_star's split: what bench.py reports as the headline at N > 1
+    seen = []
+    for name in ("all_gather_into_tensor", "all_reduce", "broadcast", "all_gather", "all_to_all", "reduce_scatter_tensor"):
+        orig = getattr(dist, name)
+        setattr(dist, name, (lambda o, n: lambda *a, **k: (seen.append(n), o(*a, **k))[1])(orig, name))
+    clips = [{"image": _tiny_clip(5, seed=40 + i), "height": 70, "width": 100} for i in range(3)]
+    per_clip = []
+    for o in m.stream(clips):
+        per_clip.append((list(seen), o["frame_ids"], bool(o["segments_infos"])))
+        seen.clear()
+    torch.save(per_clip, os.path.join(out_dir, f"n{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_north_star_split_is_one_all_gather_per_clip(oracle_ops, tmp_path):
+    """BASELINE.json north_star: "a single RCCL all-gather ... of per-frame object queries before the temporal refiner".
+    With the tracker replicated (owner rounds off) a clip costs exactly ONE all-gather; the only other collective is the
+    VPS post-processing's sum of the per-segment areas (a few hundred bytes) — no broadcast (phase B is deterministic, every
+    rank computes identical tracker / refiner outputs) — and the fixed (non-rotating) ragged split 3 + 2."""
+    import torch.multiprocessing as mp
+    port = 38500 + (os.getpid() % 2000)
+    mp.spawn(_northstar_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    parts = [torch.load(tmp_path / f"n{r}.pt") for r in range(2)]
+    for r, part in enumerate(parts):
+        for names, frame_ids, has_segments in part:
+            assert names.count("all_gather_into_tensor") == 1 and "broadcast" not in names, names
+            assert set(names) <= {"all_gather_into_tensor", "all_reduce"} and names.count("all_reduce") <= 1, names
+            assert frame_ids == ([0, 1, 2] if r == 0 else [3, 4])
+
+
 def _ragged8_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
