@@ -3,12 +3,20 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--frames T]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
+`--gpus N` without a launcher (no WORLD_SIZE in the environment) re-executes itself as N ranks under torch.distributed.run
+on 127.0.0.1 (one rank per GPU, RCCL); under a launcher WORLD_SIZE must equal --gpus.
+
 A "step" is one pass of the whole hot path over one synthetic clip of T=30 uint8 720x1280 frames that is already
 resident in HBM (step i gets its own clip, seed 1234 + i): normalise/pad -> R50 backbone -> MSDeformAttn pixel decoder -> masked-attention decoder ->
 (all-gather of per-frame queries when N > 1) -> referring tracker (incl. host assignment) -> temporal refiner ->
-mask contraction -> panoptic post-processing to integer masks on the device.  With N GPUs the SAME clip is sharded by
+mask contraction -> panoptic post-processing to integer masks on the device.  With N GPUs the SAME clips are sharded by
 frame (strong scaling); value = T * K / max-over-ranks(wall time).  Weights: deterministic random init with the
-reference's init rules (no checkpoints offline).  fp32 throughout (the parity target is the fp32 path).
+reference's init rules (no checkpoints offline).  fp32 throughout (the parity target is the fp32 path).  The timed pass
+runs under DVIS_STRICT=1: a glue op that would quietly take a torch formulation on the GPU raises instead.
+
+N > 1: `value` is north_star's split (frames sharded, ONE all-gather of the per-frame queries per clip, tracker + refiner
+replicated); `owner_rounds` holds a second timed pass with stream()'s tracker-owner rounds; `dist` lists world size,
+backend and every rank's device.
 
 Also reported on the one JSON line:
   latency_ms    per-clip latency (first enqueue of the clip -> its outputs complete), p10 / p50 / p90 over the timed clips;
@@ -16,8 +24,9 @@ Also reported on the one JSON line:
   candidates_100  the same workload with every non-void query sent to the panoptic stage (short second timed pass);
   roofline      the dominant hand-written kernel of the path, MSDeformAttn forward: algorithmic bytes (61 824 000 B
                 per frame-layer) / its mean launch time (HIP events on the launch stream) vs 8 TB/s.
-  cpu_baseline  the oracle's C port of that kernel (OpenMP, all host cores) on a bounded sample, frames-layers/s
-                converted to the same unit, plus the oracle's torch pipeline on a small clip (rank 0, N=1 only).
+  cpu_baseline  the oracle's restatement of the reference pipeline (torch fp32 CPU ops, all host cores) on a bounded
+                sample of the same clip, in the metric's own unit, plus the oracle's C port of the MSDeformAttn kernel
+                (rank 0, N=1 only).
 """
 import argparse
 import json
@@ -419,7 +428,7 @@ def main():
         sec, nfr, nlaunch = timer.summary()
         achieved = MSDA_BYTES_PER_FRAME_LAYER * nfr / sec / 1e9
         traffic, traffic_src = None, None     # HBM bytes per launch from the committed rocprofv3 PMC passes (bench.py cannot read PMCs itself)
-        for name in ("r02_msda_traffic.json", "r01_msda_traffic.json"):
+        for name in ("r03_msda_traffic.json", "r02_msda_traffic.json", "r01_msda_traffic.json"):
             tj = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tj):
                 t = json.load(open(tj))

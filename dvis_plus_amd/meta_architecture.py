@@ -106,7 +106,7 @@ class _VideoBase(nn.Module):
                  pixel_std=(58.395, 57.120, 57.375), tracker=None, refiner=None, task="vis", max_num=20,
                  window_size=3, segmenter_chunk=0, metadata=None, criterion=None,
                  sem_seg_postprocess_before_inference=True, num_frames=1, window_inference=True, max_iter_num=0,
-                 use_cl=False):
+                 use_cl=False, reference_outputs=False):
         super().__init__()
         self.backbone, self.sem_seg_head, self.tracker, self.refiner = backbone, sem_seg_head, tracker, refiner
         self.num_queries = num_queries
@@ -120,6 +120,9 @@ class _VideoBase(nn.Module):
         self.register_buffer("pixel_std", torch.tensor(pixel_std, dtype=torch.float32).view(-1, 1, 1), False)
         assert task in ("vis", "vss", "vps")
         self.task, self.max_num = task, max_num
+        # True: forward() / stream() return the reference's output format (python lists, CPU tensors: what its evaluators
+        # consume, postprocess.to_reference_format); False: everything stays on the device.  `Cls(cfg)` sets True.
+        self.reference_outputs = bool(reference_outputs)
         self.window_size = window_size        # reference knob (TEST.WINDOW_SIZE); results do not depend on it
         self.segmenter_chunk = segmenter_chunk  # frames per segmenter call, 0 = whole (local) clip at once
         self.keep = False
@@ -164,6 +167,7 @@ class _VideoBase(nn.Module):
             "num_frames": cfg.INPUT.SAMPLING_FRAME_NUM, "window_inference": _get(test, "WINDOW_INFERENCE", False),
             "task": _get(test, "TASK", "vis"), "max_num": _get(test, "MAX_NUM", 20),
             "window_size": _get(test, "WINDOW_SIZE", 3),
+            "reference_outputs": True,            # built the detectron2 way: drop-in for train_net_video.py's evaluators
         }
 
     @staticmethod
@@ -284,8 +288,9 @@ class MinVIS(_VideoBase):
         masks = Fn.mask_logits(emb.contiguous(), mask_features).permute(1, 0, 2, 3)     # (k, T, h, w)
         out_hw = (video.get("height", img_size[0]), video.get("width", img_size[1]))
         masks = PP.resize2_gt0(masks, images.shape[-2:], img_size, out_hw)
-        return {"image_size": tuple(out_hw), "pred_scores": scores.tolist(), "pred_labels": labels.tolist(),
-                "pred_masks": [m for m in masks], "pred_ids": slot.tolist(), "aligned_indices": idx}
+        out = {"image_size": tuple(out_hw), "pred_scores": scores.tolist(), "pred_labels": labels.tolist(),
+               "pred_masks": [m for m in masks], "pred_ids": slot.tolist(), "aligned_indices": idx}
+        return PP.to_reference_format(out) if self.reference_outputs else out
 
 
 @META_ARCH_REGISTRY.register()
@@ -323,7 +328,8 @@ class DVIS_Plus_online(_VideoBase):
         if self.debug_stages is not None:
             self.debug_stages.update(mask_fn=mask_fn, cls=cls, aux=None)
         out_hw = (video.get("height", img_size[0]), video.get("width", img_size[1]))
-        return self._task_output(cls, None, mask_fn, img_size, out_hw, images.shape[-2:], len(images), video)
+        out = self._task_output(cls, None, mask_fn, img_size, out_hw, images.shape[-2:], len(images), video)
+        return PP.to_reference_format(out) if self.reference_outputs else out
 
 
 @META_ARCH_REGISTRY.register()
@@ -426,7 +432,7 @@ class DVIS_Plus_offline(_VideoBase):
         out = self._task_output(cls, aux, mask_fn, img_size, out_hw, st["padded"], hi - lo, video)
         out["frame_ids"] = list(range(lo, hi))
         out["frame_range"] = (lo, hi)
-        return out
+        return out        # (forward() / stream() convert to the reference's format when reference_outputs is set)
 
     @torch.no_grad()
     def _track_phase(self, st):
@@ -554,7 +560,8 @@ class DVIS_Plus_offline(_VideoBase):
                 for st in sts:
                     st["done"] = done
             if prev is not None:
-                yield from phase_b(prev)
+                for out in phase_b(prev):
+                    yield PP.to_reference_format(out) if self.reference_outputs else out
             prev = sts or None
             if not sts:
                 break
@@ -566,7 +573,8 @@ class DVIS_Plus_offline(_VideoBase):
         assert len(batched_inputs) == 1 and not self.training
         video = batched_inputs[0]
         if self.pipeline_rounds <= 1:
-            return self._track_phase(self._segment_phase(video))
+            out = self._track_phase(self._segment_phase(video))
+            return PP.to_reference_format(out) if self.reference_outputs else out
         self.keep = bool(video.get("keep", False))
         frames = video["image"]
         T = len(frames)
@@ -657,7 +665,7 @@ class DVIS_Plus_offline(_VideoBase):
         out = self._task_output(cls, aux, mask_fn, img_size, out_hw, padded, len(local_ids), video)
         out["frame_ids"] = local_ids                                                # which frames of the clip the masks are
         out["frame_range"] = (local_ids[0], local_ids[-1] + 1) if local_ids and contiguous else None
-        return out
+        return PP.to_reference_format(out) if self.reference_outputs else out
 
 
 def _slice_maps(maps, a, b):

@@ -120,6 +120,7 @@ def test_build_model_like_detectron2_from_the_references_offline_yaml(d2_stubs):
     assert model.thing_ids == frozenset(range(58)) and model.n_things == 58
     assert d2.thing_ids_from_metadata(model.metadata) == frozenset(VIPSEG_THING_IDS)       # image MaskFormer rule
     assert model.object_mask_threshold == 0.8 and model.overlap_threshold == 0.8
+    assert model.reference_outputs is True          # built from cfg: outputs in the evaluators' format (lists, CPU tensors)
     pred = model.sem_seg_head.predictor
     assert type(pred).__name__ == "VideoMultiScaleMaskedTransformerDecoder_dvisPlus" and pred.num_layers == 9
     assert len(model.sem_seg_head.pixel_decoder.transformer.encoder.layers) == 6

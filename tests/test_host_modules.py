@@ -702,3 +702,36 @@ def test_online_meta_architecture_equals_reference_forward_g10(oracle_ops):
         _g10_check_vps(m([G.video(frames, cfg)]), o, "on_vps")
         _g10_check_vps(m([G.video(frames, cfg, 0, 4)]), o, "on_keep_a_vps")
         _g10_check_vps(m([G.video(frames, cfg, 4, None, keep=True)]), o, "on_keep_b_vps")     # resumes (:793)
+
+
+@pytest.mark.parametrize("mode,task", [("offline", "vis"), ("offline", "vps"), ("offline", "vss"), ("online", "vis")])
+def test_reference_output_format_feeds_the_reference_evaluators(oracle_ops, mode, task):
+    """`reference_outputs=True` (what `Cls(cfg)` sets): the dict of meta_architecture.py:603-626 as the reference's evaluators
+    read it — ytvis_eval.py:268-295 zips python floats / ints with per-instance (T, H, W) masks it turns into numpy and
+    serialises to json; vps_eval.py:106-135 / vss_eval.py:92-93 call .numpy() on the maps.  Same values as the device dict."""
+    import json
+    m = _tiny_model(mode, task)
+    frames = _tiny_clip(4, seed=3)
+    video = {"image": frames, "height": 70, "width": 100}
+    dev_out = m([video])
+    m.reference_outputs = True
+    out = m([video])
+    streamed = list(m.stream([video])) if mode == "offline" else [out]
+    for o in (out, streamed[0]):
+        assert o["image_size"] == (70, 100) and o["task"] == task and "ready_event" not in o
+        if task == "vis":
+            assert isinstance(o["pred_scores"], list) and isinstance(o["pred_scores"][0], float)
+            assert isinstance(o["pred_labels"][0], int) and isinstance(o["pred_ids"][0], int)
+            json.dumps({"score": o["pred_scores"][0], "category_id": o["pred_labels"][0]})
+            assert isinstance(o["pred_masks"], list) and len(o["pred_masks"]) == len(o["pred_scores"])
+            m0 = o["pred_masks"][0]
+            assert m0.device.type == "cpu" and m0.dtype == torch.bool and m0.shape == (4, 70, 100)
+            np.array(m0[0][:, :, None], order="F", dtype="uint8")                  # what the evaluator feeds to RLE
+            assert o["pred_scores"] == dev_out["pred_scores"].tolist()
+            assert torch.equal(torch.stack(o["pred_masks"]), dev_out["pred_masks"].cpu())
+        elif task == "vps":
+            assert o["pred_masks"].device.type == "cpu" and o["pred_masks"].numpy().shape == (4, 70, 100)
+            assert all(isinstance(i, int) for i in o["pred_ids"]) and o["segments_infos"] == dev_out["segments_infos"]
+            assert torch.equal(o["pred_masks"], dev_out["pred_masks"].cpu())
+        else:
+            assert o["pred_masks"].numpy().astype(np.uint8).shape == (4, 70, 100)
