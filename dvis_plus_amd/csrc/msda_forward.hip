@@ -123,6 +123,11 @@ struct TileMap {
   int tile_start[kMaxLevels + 1];   // first block index of every level (prefix sums); [L] = number of blocks
   int tiles_x[kMaxLevels];          // 8-pixel tiles per row of every level
   int h[kMaxLevels], w[kMaxLevels], q0[kMaxLevels];   // map size and first query of every level
+  int tiled;                        // the 8 x 8 geometry above is valid (else: QB consecutive queries per workgroup)
+  // FUSED form: floats between two heads' parameters inside a projection row; 0 = the reference's layout (all heads'
+  // offsets, then all heads' logits: L*P*2 and L*P).  "Slots" = [head m: 2LP offsets | LP logits | pad]: a (query, head)
+  // pair then touches ONE contiguous run of its row instead of two (fewer 128-byte lines shared between the 8 XCDs).
+  int off_hs, logit_hs;
 };
 
 bool make_tile_map(const int64_t *shapes_host, int L, int Lq, TileMap *tm) {
@@ -141,7 +146,8 @@ bool make_tile_map(const int64_t *shapes_host, int L, int Lq, TileMap *tm) {
     total += H * W;
   }
   tm->tile_start[kMaxLevels] = tiles;
-  return total == Lq && tiles <= 65535;     // the queries are exactly the pixels of the maps
+  tm->tiled = total == Lq && tiles <= 65535;     // the queries are exactly the pixels of the maps
+  return tm->tiled != 0;
 }
 
 // QB queries per workgroup; WPS = register budget in waves/SIMD; B = samples per batch of corner loads.
@@ -222,8 +228,9 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile(
     float2 xy[L];
     float aw[L];
     if constexpr (FUSED) {
-      const float *orow = loc_or_off + ((size_t)n * Lq + qq) * off_stride + (size_t)m * (LP * 2);
-      const float *lrow = w_or_logit + ((size_t)n * Lq + qq) * logit_stride + (size_t)m * LP;
+      const int off_hs = tm.off_hs ? tm.off_hs : LP * 2, logit_hs = tm.logit_hs ? tm.logit_hs : LP;
+      const float *orow = loc_or_off + ((size_t)n * Lq + qq) * off_stride + (size_t)m * off_hs;
+      const float *lrow = w_or_logit + ((size_t)n * Lq + qq) * logit_stride + (size_t)m * logit_hs;
       float2 ro[L], rr[L];
       float4 rl[LP / 4];
 #pragma unroll
@@ -234,8 +241,8 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile(
 #pragma unroll
       for (int k = 0; k < LP / 4; ++k) rl[k] = *reinterpret_cast<const float4 *>(lrow + 4 * k);
       if (pos_off != nullptr) {     // + projection of the query's position embedding (same for all n)
-        const float *prow = pos_off + qq * pos_stride + (size_t)m * (LP * 2);
-        const float *plrow = pos_logit + qq * pos_stride + (size_t)m * LP;
+        const float *prow = pos_off + qq * pos_stride + (size_t)m * off_hs;
+        const float *plrow = pos_logit + qq * pos_stride + (size_t)m * logit_hs;
 #pragma unroll
         for (int l = 0; l < L; ++l) {
           const float2 pv = *reinterpret_cast<const float2 *>(prow + 2 * (l * P + p));
@@ -414,7 +421,7 @@ int launch_variant(const T *value, const int64_t *shapes, const int64_t *ls, con
                    const T *b, int64_t b_stride, const float *refp, int nref, int N, int S, int M, int Lq, T *out,
                    hipStream_t st, const float *pos_off, const float *pos_logit, int64_t pos_stride, const TileMap *tm) {
   if constexpr (QB == 64 && L <= kMaxLevels) {
-    if (tm != nullptr) {
+    if (tm != nullptr && tm->tiled) {
       if (N > 65535) {
         dvis_set_error("msda: grid too large (N must be <= 65535)");
         return DVIS_E_ARG;
@@ -432,7 +439,7 @@ int launch_variant(const T *value, const int64_t *shapes, const int64_t *ls, con
   }
   hipLaunchKernelGGL((msda_fwd_tile<T, D, L, P, FUSED, WPS, B, QB, false>), dim3(M, nchunks, N), dim3(256), 0, st, value,
                      shapes, ls, a, a_stride, b, b_stride, refp, nref, S, M, Lq, out, pos_off, pos_logit, pos_stride,
-                     TileMap{});
+                     tm ? *tm : TileMap{});
   return dvis_check_launch("msda_fwd_tile");
 }
 
@@ -518,16 +525,20 @@ DVIS_EXPORT int dvis_msda_forward(int dtype, const void *value, const int64_t *s
   return DVIS_E_ARG;
 }
 
-DVIS_EXPORT int dvis_msda_fused_forward_pos(const float *value, const int64_t *shapes, const int64_t *level_start,
-                                            const float *ref, int Nref, const float *offsets, int64_t off_stride,
-                                            const float *logits, int64_t logit_stride, const float *pos_offsets,
-                                            const float *pos_logits, int64_t pos_stride, int N, int S, int M, int D,
-                                            int L, int Lq, int P, float *out, const int64_t *shapes_host, void *stream) {
+DVIS_EXPORT int dvis_msda_fused_forward_slots(const float *value, const int64_t *shapes, const int64_t *level_start,
+                                              const float *ref, int Nref, const float *offsets, int64_t off_stride,
+                                              const float *logits, int64_t logit_stride, int off_head_stride,
+                                              int logit_head_stride, const float *pos_offsets, const float *pos_logits,
+                                              int64_t pos_stride, int N, int S, int M, int D, int L, int Lq, int P,
+                                              float *out, const int64_t *shapes_host, void *stream) {
   DVIS_REQUIRE(N >= 0 && S > 0 && M > 0 && D > 0 && L > 0 && Lq >= 0 && P > 0, "msda_fused_forward: bad sizes");
   if (N == 0 || Lq == 0) return DVIS_OK;
   DVIS_REQUIRE(value && shapes && level_start && ref && offsets && logits && out, "msda_fused_forward: null pointer");
   DVIS_REQUIRE(Nref == 1 || Nref == N, "msda_fused_forward: Nref must be 1 or N");
-  DVIS_REQUIRE(off_stride >= (int64_t)M * L * P * 2 && logit_stride >= (int64_t)M * L * P,
+  const int off_hs = off_head_stride ? off_head_stride : L * P * 2, logit_hs = logit_head_stride ? logit_head_stride : L * P;
+  DVIS_REQUIRE(off_hs >= L * P * 2 && logit_hs >= L * P && off_hs % 4 == 0 && logit_hs % 4 == 0,
+               "msda_fused_forward: head strides must cover a head's parameters and be multiples of 4 floats");
+  DVIS_REQUIRE(off_stride >= (int64_t)(M - 1) * off_hs + L * P * 2 && logit_stride >= (int64_t)(M - 1) * logit_hs + L * P,
                "msda_fused_forward: row strides too small");
   DVIS_REQUIRE(off_stride % 4 == 0 && logit_stride % 4 == 0 && aligned16(offsets) && aligned16(logits) &&
                    aligned16(value) && aligned16(out),
@@ -536,28 +547,33 @@ DVIS_EXPORT int dvis_msda_fused_forward_pos(const float *value, const int64_t *s
   bool handled = false;
   DVIS_REQUIRE((size_t)Lq * (size_t)(off_stride > logit_stride ? off_stride : logit_stride) * sizeof(float) < 0x7fffffffu,
                "msda_fused_forward: one frame of offsets/logits must stay below 2 GiB");
+  // Encoder self-attention geometry (queries = the pixels of the L maps, shapes known on the host): 8 x 8 query tiles
+  TileMap tm{};
   const bool has_pos = pos_offsets != nullptr || pos_logits != nullptr;
+  if (!has_pos) make_tile_map(shapes_host, L, Lq, &tm);
+  tm.off_hs = off_head_stride, tm.logit_hs = logit_head_stride;
   if (has_pos) {
-    DVIS_REQUIRE(pos_offsets && pos_logits && pos_stride >= (int64_t)M * L * P * 2 && pos_stride % 4 == 0 &&
+    DVIS_REQUIRE(pos_offsets && pos_logits && pos_stride >= (int64_t)(M - 1) * off_hs + L * P * 2 && pos_stride % 4 == 0 &&
                      aligned16(pos_offsets) && aligned16(pos_logits),
                  "msda_fused_forward: position rows need both pointers, 16-byte alignment and a row stride multiple of 4");
-    int rc2 = dispatch_tile<float, true>(D, L, P, value, shapes, level_start, offsets, off_stride, logits, logit_stride, ref, Nref,
-                                  N, S, M, Lq, out, (hipStream_t)stream, &handled, pos_offsets, pos_logits, pos_stride);
-    if (handled) return rc2;
-    dvis_set_error("msda_fused_forward: unsupported (D=%d, L=%d, P=%d)", D, L, P);
-    return DVIS_E_UNSUPPORTED;
+    tm.tiled = 0;
   }
-  // Encoder self-attention geometry (queries = the pixels of the L maps, shapes known on the host): 8 x 8 query tiles
-  TileMap tm;
-  const bool tiled2d = make_tile_map(shapes_host, L, Lq, &tm);
-  int rc;
-  rc = dispatch_tile<float, true>(D, L, P, value, shapes, level_start, offsets, off_stride, logits, logit_stride, ref,
-                                  Nref, N, S, M, Lq, out, (hipStream_t)stream, &handled, nullptr, nullptr, 0,
-                                  tiled2d ? &tm : nullptr);
+  const int rc = dispatch_tile<float, true>(D, L, P, value, shapes, level_start, offsets, off_stride, logits, logit_stride, ref,
+                                            Nref, N, S, M, Lq, out, (hipStream_t)stream, &handled, pos_offsets, pos_logits,
+                                            pos_stride, &tm);
   if (handled) return rc;
   dvis_set_error("msda_fused_forward: unsupported (D=%d, L=%d, P=%d); supported D in {32,64}, (L,P) in {(1,4),(3,4),(4,4)}",
                  D, L, P);
   return DVIS_E_UNSUPPORTED;
+}
+
+DVIS_EXPORT int dvis_msda_fused_forward_pos(const float *value, const int64_t *shapes, const int64_t *level_start,
+                                            const float *ref, int Nref, const float *offsets, int64_t off_stride,
+                                            const float *logits, int64_t logit_stride, const float *pos_offsets,
+                                            const float *pos_logits, int64_t pos_stride, int N, int S, int M, int D,
+                                            int L, int Lq, int P, float *out, const int64_t *shapes_host, void *stream) {
+  return dvis_msda_fused_forward_slots(value, shapes, level_start, ref, Nref, offsets, off_stride, logits, logit_stride, 0, 0,
+                                       pos_offsets, pos_logits, pos_stride, N, S, M, D, L, Lq, P, out, shapes_host, stream);
 }
 
 DVIS_EXPORT int dvis_msda_fused_forward(const float *value, const int64_t *shapes, const int64_t *level_start,

@@ -111,7 +111,7 @@ class MSDeformAttnFunction(Function):
 
 
 def msda_fused_forward(value, spatial_shapes, level_start_index, reference_points, offsets, logits, n_levels,
-                       n_points, shapes_host=None, pos_offsets=None, pos_logits=None):
+                       n_points, shapes_host=None, pos_offsets=None, pos_logits=None, head_stride=0):
     """Inference fast path of ``MSDeformAttn.forward`` (ops/modules/ms_deform_attn.py:101-117), fp32.
 
     value (N,S,M,D); reference_points (1|N, Lq, L, 2); ``offsets`` / ``logits`` are 2-D row views
@@ -121,6 +121,8 @@ def msda_fused_forward(value, spatial_shapes, level_start_index, reference_point
     pos_offsets / pos_logits: optional (Lq, >= M*L*P*2) / (Lq, >= M*L*P) row views with the SAME row stride: the
     bias-free projections of the queries' position embedding, added to the raw rows inside the kernel
     (linear(src + pos) = linear(src) + pos W^T), so the caller projects `src` and never forms `src + pos`.
+    head_stride: 0 = the reference's row layout (all heads' offsets, then all heads' logits); s > 0 = per-head SLOTS of s
+    floats [2LP offsets | LP logits | pad]: `offsets` then points at a row's first slot and `logits` 2LP floats further.
     """
     N, S, M, D = value.shape
     L, P = n_levels, n_points
@@ -132,7 +134,12 @@ def msda_fused_forward(value, spatial_shapes, level_start_index, reference_point
             raise RuntimeError(f"{name} must be a float32 GPU (N*Lq, width) row view with unit inner stride")
     if value.dtype != torch.float32 or reference_points.dtype != torch.float32:
         raise RuntimeError("msda_fused_forward is fp32 only")
-    if offsets.shape[1] < M * L * P * 2 or logits.shape[1] < M * L * P or reference_points.shape[2:] != (L, 2):
+    if head_stride:
+        if offsets.shape[1] < (M - 1) * head_stride + L * P * 2 or logits.shape[1] < (M - 1) * head_stride + L * P:
+            raise RuntimeError("msda_fused_forward: rows shorter than M slots")
+    elif offsets.shape[1] < M * L * P * 2 or logits.shape[1] < M * L * P:
+        raise RuntimeError("msda_fused_forward: inconsistent shapes")
+    if reference_points.shape[2:] != (L, 2):
         raise RuntimeError("msda_fused_forward: inconsistent shapes")
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
     hs = None
@@ -141,7 +148,9 @@ def msda_fused_forward(value, spatial_shapes, level_start_index, reference_point
     po = pl = None
     pstride = 0
     if pos_offsets is not None or pos_logits is not None:
-        for name, t, width in (("pos_offsets", pos_offsets, M * L * P * 2), ("pos_logits", pos_logits, M * L * P)):
+        wo = (M - 1) * head_stride + L * P * 2 if head_stride else M * L * P * 2
+        wl = (M - 1) * head_stride + L * P if head_stride else M * L * P
+        for name, t, width in (("pos_offsets", pos_offsets, wo), ("pos_logits", pos_logits, wl)):
             if t is None or not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 \
                     or t.shape[0] != Lq or t.shape[1] < width:
                 raise RuntimeError(f"{name} must be a float32 GPU (Lq, >= {width}) row view with unit inner stride")
@@ -149,12 +158,12 @@ def msda_fused_forward(value, spatial_shapes, level_start_index, reference_point
             raise RuntimeError("pos_offsets / pos_logits must share their row stride (slices of one projection)")
         po, pl, pstride = ctypes.c_void_p(pos_offsets.data_ptr()), ctypes.c_void_p(pos_logits.data_ptr()), pos_offsets.stride(0)
     with torch.cuda.device(value.device):
-        rc = native.lib().dvis_msda_fused_forward_pos(
+        rc = native.lib().dvis_msda_fused_forward_slots(
             native.dev_ptr(value, "value"), native.dev_ptr(spatial_shapes, "spatial_shapes"),
             native.dev_ptr(level_start_index, "level_start_index"), native.dev_ptr(reference_points, "ref"), nref,
             ctypes.c_void_p(offsets.data_ptr()), offsets.stride(0), ctypes.c_void_p(logits.data_ptr()),
-            logits.stride(0), po, pl, pstride, N, S, M, D, L, Lq, P, native.dev_ptr(out, "out"), hs,
-            native.stream_ptr(value.device))
+            logits.stride(0), int(head_stride), int(head_stride), po, pl, pstride, N, S, M, D, L, Lq, P,
+            native.dev_ptr(out, "out"), hs, native.stream_ptr(value.device))
     native.check(rc, "dvis_msda_fused_forward")
     return out
 

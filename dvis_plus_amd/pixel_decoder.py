@@ -35,6 +35,8 @@ from .registry import SEM_SEG_HEADS_REGISTRY, ShapeSpec
 # on MI355X (T=30, 720p): end to end 180.5 vs 179.1 frames/s (+0.8 %), but the MSDA launch itself 1168 vs 1059 us (its
 # set-up phase reads 22 MB more through scattered 16-byte loads) — a wash, so the plain form stays the default.
 _POS_IN_KERNEL = os.environ.get("DVIS_MSDA_POS", "0") == "1"
+# rows of the fused offsets | logits projection permuted into per-head slots (MSDeformAttn._fused_projection)
+_MSDA_SLOTS = os.environ.get("DVIS_MSDA_SLOTS", "0") == "1"
 
 
 def _is_power_of_2(n):
@@ -116,19 +118,36 @@ class MSDeformAttn(nn.Module):
                 proj.bias.zero_()
 
     def _fused_projection(self):
+        """-> (weight, bias, head_stride) of the ONE GEMM that produces offsets and logits.  head_stride 0: rows in the
+        reference's order [all offsets | all logits | zero rows up to a multiple of 64]; head_stride s: per-head slots
+        [head m: 2LP offset rows | LP logit rows | zero rows] of s = (padded width) / M output columns — the same GEMM
+        width (8 heads x 36 = 288 -> 320 = 8 x 40), but a (query, head) pair's parameters are one contiguous 160-byte run."""
         so, aw = self.sampling_offsets, self.attention_weights
-        key = (so.weight._version, so.bias._version, aw.weight._version, aw.bias._version, so.weight.device)
+        key = (so.weight._version, so.bias._version, aw.weight._version, aw.bias._version, so.weight.device, _MSDA_SLOTS)
         if self._fused is None or self._fused[0] != key:
-            w = torch.cat([so.weight.detach(), aw.weight.detach()], 0)
-            b = torch.cat([so.bias.detach(), aw.bias.detach()], 0)
+            M, LP = self.n_heads, self.n_levels * self.n_points
+            width = -(-(3 * M * LP) // 64) * 64
             # zero rows up to a multiple of 64 output columns: the library's GEMM for (579 600 x 256) x (256 x 288) runs
             # at 97 TFLOP/s, for 320 columns at 118 (974 -> 829 us per encoder layer at 30 frames of 720p)
-            pad = -w.shape[0] % 64
-            if pad:
-                w = torch.cat([w, w.new_zeros(pad, w.shape[1])], 0)
-                b = torch.cat([b, b.new_zeros(pad)], 0)
-            self._fused = (key, w.contiguous(), b.contiguous())
-        return self._fused[1], self._fused[2]
+            slot = width // M if _MSDA_SLOTS and width % M == 0 and (width // M) % 4 == 0 and width // M >= 3 * LP else 0
+            if slot:
+                C = so.weight.shape[1]
+                w = so.weight.new_zeros(M, slot, C)
+                b = so.bias.new_zeros(M, slot)
+                w[:, :2 * LP] = so.weight.detach().view(M, 2 * LP, C)
+                w[:, 2 * LP:3 * LP] = aw.weight.detach().view(M, LP, C)
+                b[:, :2 * LP] = so.bias.detach().view(M, 2 * LP)
+                b[:, 2 * LP:3 * LP] = aw.bias.detach().view(M, LP)
+                w, b = w.view(M * slot, C), b.view(M * slot)
+            else:
+                w = torch.cat([so.weight.detach(), aw.weight.detach()], 0)
+                b = torch.cat([so.bias.detach(), aw.bias.detach()], 0)
+                pad = width - w.shape[0]
+                if pad:
+                    w = torch.cat([w, w.new_zeros(pad, w.shape[1])], 0)
+                    b = torch.cat([b, b.new_zeros(pad)], 0)
+            self._fused = (key, w.contiguous(), b.contiguous(), slot)
+        return self._fused[1], self._fused[2], self._fused[3]
 
     def _fast_path_ok(self, query, reference_points, input_padding_mask):
         d = self.d_model // self.n_heads
@@ -152,20 +171,19 @@ class MSDeformAttn(nn.Module):
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(N, Len_in, M, self.d_model // M)
         if self._fast_path_ok(query, reference_points, input_padding_mask):
-            w, b = self._fused_projection()
-            n_off = M * L * P * 2
+            w, b, slot = self._fused_projection()
+            n_off = 2 * L * P if slot else M * L * P * 2        # where a row's logits start (slots: inside the head's slot)
             po = pl = None
             if query_pos is not None and query_pos.shape[0] == 1 and _POS_IN_KERNEL:
                 pp = F.linear(query_pos[0], w)                                     # (Lq, 3*M*L*P): tiny, once per call
-                po, pl = pp[:, :n_off], pp[:, n_off:n_off + M * L * P]
+                po, pl = pp, pp[:, n_off:]
             elif query_pos is not None:
                 query = query + query_pos
             proj = F.linear(query.reshape(N * Len_q, self.d_model), w, b)          # offsets | logits in one GEMM
             ref = reference_points if reference_points.is_contiguous() else reference_points.contiguous()
             output = Fn.msda_fused_forward(value, input_spatial_shapes, input_level_start_index, ref,
-                                           proj[:, :n_off], proj[:, n_off:n_off + M * L * P], L, P,
-                                           shapes_host=spatial_shapes_py,
-                                           pos_offsets=po, pos_logits=pl)
+                                           proj, proj[:, n_off:], L, P, shapes_host=spatial_shapes_py,
+                                           pos_offsets=po, pos_logits=pl, head_stride=slot)
             return self.output_proj(output)
         if query_pos is not None:
             query = query + query_pos

@@ -120,6 +120,20 @@ int dvis_msda_fused_forward_pos(const float *value, const int64_t *shapes, const
                                 int P, float *out, const int64_t *shapes_host, void *stream);
 
 /*
+ * Same, with the per-head layout of a projection row made explicit: head m's 2*L*P offsets start `off_head_stride` floats
+ * after head m-1's, its L*P logits `logit_head_stride` floats after head m-1's (0 = the reference's layout: L*P*2 and
+ * L*P, i.e. all heads' offsets, then all heads' logits).  With the rows of the fused projection permuted into per-head
+ * SLOTS [2LP offsets | LP logits | pad] (offsets = proj, logits = proj + 2LP, both head strides = the slot size) a
+ * (query, head) pair reads one contiguous run of its row: fewer 128-byte lines shared between the heads' XCDs.
+ */
+int dvis_msda_fused_forward_slots(const float *value, const int64_t *shapes, const int64_t *level_start,
+                                  const float *ref, int Nref, const float *offsets, int64_t off_stride,
+                                  const float *logits, int64_t logit_stride, int off_head_stride, int logit_head_stride,
+                                  const float *pos_offsets, const float *pos_logits, int64_t pos_stride, int N, int S,
+                                  int M, int D, int L, int Lq, int P, float *out, const int64_t *shapes_host,
+                                  void *stream);
+
+/*
  * Mask logits: out[b, q, p] = sum_c embed[b, q, c] * feat[b, c, p]     (fp32, exact-fp32 MFMA)
  *   embed (B, Q, C), feat (B, C, HW), out (B, Q, HW)
  */

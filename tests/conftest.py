@@ -121,16 +121,21 @@ def _o_mask_logits(mask_embed, mask_features):
 
 
 def _o_msda_fused(value, spatial_shapes, level_start_index, reference_points, offsets, logits, n_levels, n_points,
-                  shapes_host=None, pos_offsets=None, pos_logits=None):
+                  shapes_host=None, pos_offsets=None, pos_logits=None, head_stride=0):
     from oracle.msda import msda_forward_torch
     N, S, M, D = value.shape
     Lq = reference_points.shape[1]
     L, P = n_levels, n_points
-    off = offsets[:, :M * L * P * 2].reshape(N, Lq, M, L, P, 2)
-    lg = logits[:, :M * L * P].reshape(N, Lq, M, L * P)
+
+    def heads(rows, width):          # (rows, >= ...) -> (rows, M, width): head m's run starts m * head_stride floats in
+        if not head_stride:
+            return rows[:, :M * width].reshape(rows.shape[0], M, width)
+        return torch.stack([rows[:, m * head_stride:m * head_stride + width] for m in range(M)], 1)
+    off = heads(offsets, L * P * 2).reshape(N, Lq, M, L, P, 2)
+    lg = heads(logits, L * P).reshape(N, Lq, M, L * P)
     if pos_offsets is not None:
-        off = off + pos_offsets[:, :M * L * P * 2].reshape(1, Lq, M, L, P, 2)
-        lg = lg + pos_logits[:, :M * L * P].reshape(1, Lq, M, L * P)
+        off = off + heads(pos_offsets, L * P * 2).reshape(1, Lq, M, L, P, 2)
+        lg = lg + heads(pos_logits, L * P).reshape(1, Lq, M, L * P)
     w = torch.softmax(lg, -1).reshape(N, Lq, M, L, P)
     norm = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
     loc = reference_points[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]

@@ -19,9 +19,14 @@ def _dev(d):
     return {k: v.to(DEV) for k, v in d.items()}
 
 
-def test_pixel_decoder_vs_reference_outputs():
+@pytest.mark.parametrize("slots", [False, True])
+def test_pixel_decoder_vs_reference_outputs(slots, monkeypatch):
+    """slots: the fused offsets | logits projection with its rows permuted into per-head slots (dvis_msda_fused_forward_slots:
+    a (query, head) pair reads one contiguous run of its projection row) — same results as the reference's row order."""
+    from dvis_plus_amd import pixel_decoder as PD
     from dvis_plus_amd.pixel_decoder import MSDeformAttnPixelDecoder
     from dvis_plus_amd.registry import ShapeSpec
+    monkeypatch.setattr(PD, "_MSDA_SLOTS", slots)
     g = Golden("g7_pixel_decoder_d32")
     chans = g.meta["cfg"]["chans"]
     strides = dict(res2=4, res3=8, res4=16, res5=32)
@@ -39,6 +44,7 @@ def test_pixel_decoder_vs_reference_outputs():
         shapes = torch.tensor([(2, 3), (4, 6), (8, 12)], device=DEV)
         lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
         a = attn(i["attn_query"], i["attn_ref"], i["attn_src"], shapes, lsi, None)
+        assert (attn._fused_projection()[2] > 0) == slots            # 2 heads x 36 = 72 -> 128 columns = 2 slots of 64
     for got, key in ((mf, "mask_features"), (out0, "out0"), (ms[0], "ms0"), (ms[1], "ms1"), (ms[2], "ms2"),
                      (a, "attn_out")):
         torch.testing.assert_close(got.cpu(), g.outs[key], **TOL)
