@@ -405,7 +405,7 @@ def main():
         torch.distributed.all_gather_object(per_rank, mine)
         dist_info = {"world_size": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
                      "ranks": per_rank, "ranks_share_one_gpu": bool(one_device),
-                     "split": "frames sharded contiguously (rotating ragged split), one all-gather of per-frame queries "
+                     "split": "frames sharded contiguously (fixed split), one all-gather of per-frame queries "
                               "per clip, tracker + refiner replicated"}
 
     # second, short timed pass: every non-void query goes to the panoptic stage (the upper end of the work that the

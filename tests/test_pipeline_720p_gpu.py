@@ -189,24 +189,39 @@ def test_config4_T64_vs_oracle_prefix_suffix_and_refiner():
     video = {"image": clip, "height": 720, "width": 1280}
     m.object_mask_threshold = bench.calibrate_threshold(m, [video], 20)
     m.debug_stages = {}
+    m.sem_seg_head.predictor.debug_masks = []
     out = m([video])
+    pmasks, m.sem_seg_head.predictor.debug_masks = m.sem_seg_head.predictor.debug_masks, None
     assert out["pred_masks"].shape == (T, 720, 1280)
     P = {k: (v.detach().float().cpu() if torch.is_tensor(v) else v) for k, v in m.debug_stages.items() if k != "mask_fn"}
     idx_prod = np.array(m.tracker.last_indices)
     rep = PPar.intcmp._report
-    # ---- (1) prefix
-    ref, st = PPar.run_oracle(m, sd, [f for f in clip[:6].cpu()], offline=True, task="vps",
+    # ---- (1) prefix.  The decoder's attention masks are booleans: where a down-sized mask logit sits within the two
+    # pipelines' rounding distance of 0 the bit differs and that query attends to a different key set — a
+    # discrete event, O(1e-2) on the query.  Frames whose masks agree in all 9 layers must agree to rounding level; with a
+    # differing bit somewhere the bound is the loose one, and the tracker (it consumes the queries) inherits it.
+    ref, st = PPar.run_oracle(m, sd, [f for f in clip[:6].cpu()], offline=True, task="vps", attn_masks=True,
                               object_mask_threshold=m.object_mask_threshold, out_hw=(720, 1280))
-    for key in ("frame_embds", "frame_embds_no_norm", "instance_embds"):
-        e = float((P[key][:, :, :6] - st[key]).abs().max())
-        rep(f"config #4 T=64 prefix (frames 0-5) {key}: max |product - oracle| {e:.2e} at max |value| {float(st[key].abs().max()):.1f}")
-        assert e <= 1e-3
+    flips, _ = PPar.attention_mask_flips([pm[:6] for pm in pmasks], st["attn_masks"], 6)
+    clean = flips.sum((0, 2)) == 0                                                       # (6,) frames without a flip
+    for key in ("frame_embds", "frame_embds_no_norm"):
+        per_frame = (P[key][:, :, :6] - st[key]).abs().amax((0, 1, 3))
+        rep(f"config #4 T=64 prefix (frames 0-5) {key}: max |product - oracle| per frame "
+            f"{[float(f'{e:.1e}') for e in per_frame.tolist()]} (frames without a differing mask bit: {clean.tolist()})")
+        assert float(per_frame.max()) <= 5e-2
+        if clean.any():
+            assert float(per_frame[clean].max()) <= 1e-4
+    tight = 1e-3 if bool(clean.all()) else 5e-2
+    e = float((P["instance_embds"][:, :, :6] - st["instance_embds"]).abs().max())
+    rep(f"config #4 T=64 prefix (frames 0-5) instance_embds: max |product - oracle| {e:.2e} at max |value| "
+        f"{float(st['instance_embds'].abs().max()):.1f} (bound {tight:g})")
+    assert e <= tight
     e = float((P["online_logits"][:, :6] - st["online_logits"]).abs().max())
-    rep(f"config #4 T=64 prefix tracker class logits: max |product - oracle| {e:.2e}")
-    assert e <= 1e-3
+    rep(f"config #4 T=64 prefix tracker class logits: max |product - oracle| {e:.2e} (bound {tight:g})")
+    assert e <= tight
     e = float((P["mask_features"][:6] - st["mask_features"][0]).abs().max())
     rep(f"config #4 T=64 prefix mask_features: max |product - oracle| {e:.2e} at max |value| {float(st['mask_features'].abs().max()):.1f}")
-    assert e <= 1e-3
+    assert e <= 1e-4
     # ---- (2) suffix: frames 61..63 = the reference's last full window before the ragged end (64 = 21 * 3 + 1)
     t0 = 61
     trk = O.Tracker(O._sub(sd, "tracker."), 8, 6)
