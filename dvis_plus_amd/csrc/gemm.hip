@@ -35,8 +35,14 @@ struct GemmArgs {
   int M, N, K, act, row_blocks, col_blocks, vec_store, col_fastest;
 };
 
+// Register budget: the second __launch_bounds__ argument is the minimum number of waves per SIMD the allocator must leave
+// room for.  Without it hipcc spends 176 registers (80 VGPR + 96 AGPR) on the 64 x 64 tile where 64 accumulators + two
+// fragment slots need ~150: 2 instead of 3 waves per SIMD, and the prologue / epilogue of one wave is then covered by only
+// one other wave's MFMAs.
+template <int TILES> constexpr int kGemmMinWaves = TILES >= 32 ? 1 : (TILES >= 12 ? 3 : 4);
+
 template <int RT, int CT, int NW, int PF, bool K16>
-__global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(64 * NW, kGemmMinWaves<RT * CT>) void gemm_nt_kernel(const GemmArgs p) {
   extern __shared__ float lds[];   // [NW][16 RT][16 CT] partial tiles
   constexpr int BM = 16 * RT, BN = 16 * CT, T = 64 * NW;
 
@@ -97,24 +103,44 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(const GemmArgs p) {
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = dvis_f4{0.f, 0.f, 0.f, 0.f};
 
+  auto contract = [&](int s) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+          acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][rt][c], w[s][ct][c], acc[rt][ct], 0, 0, 0);
+  };
 #pragma unroll
   for (int s = 0; s < PF; ++s) load(s, g0 + s);
+  int grp = g0;
+  // Steady state: rounds of PF groups whose refills are all in range — ONE basic block, no branch between a slot's
+  // MFMAs and its refill, so the compiler's counted `s_waitcnt vmcnt(N)` leaves the other PF - 1 slots' loads in flight
+  // (with a branch around each refill it waited vmcnt(0) at the loop head: every round stalled for a full load latency).
 #pragma unroll 1
-  for (int grp = g0; grp < g1; grp += PF) {
+  for (; grp + 2 * PF <= g1; grp += PF) {
 #pragma unroll
     for (int s = 0; s < PF; ++s) {
-      if (grp + s < g1) {   // wave-uniform: the padding groups of the last round hold zeros, skip their MFMAs
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-              acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][rt][c], w[s][ct][c], acc[rt][ct], 0, 0, 0);
-      }
-      if (grp + s + PF < g1) load(s, grp + s + PF);   // uniform
+      contract(s);
+      // pin the order "slot's MFMAs, then ITS refill": left alone the scheduler sinks all refills to the end of the round,
+      // and the first slot's loads then have a fraction of a slot of MFMAs to arrive
+      __builtin_amdgcn_sched_barrier(0);
+      load(s, grp + s + PF);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
+  if (grp + PF <= g1) {   // last full round: refill only the slots the tail below still needs (wave-uniform branches)
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+      contract(s);
+      if (grp + s + PF < g1) load(s, grp + s + PF);
+    }
+    grp += PF;
+  }
+#pragma unroll
+  for (int s = 0; s < PF; ++s)
+    if (grp + s < g1) contract(s);   // tail: fewer than PF groups left (their slots were filled above / by the prologue)
 
   // ---- partial tiles meet in LDS.  Accumulator layout: column = lane & 15, row = (lane >> 4) * 4 + reg.
   float *mine = lds + wv * (BM * BN);
@@ -203,8 +229,12 @@ int pick_config(int M, int N, int K, int batch) {
     const long long cb = (N + 16 * kConfigs[c].ct - 1) / (16 * kConfigs[c].ct);
     return rb * cb * batch;
   };
-  // the largest tile that still gives every CU a workgroup; below that, smaller tiles with a deeper K split
-  if (wgs(8) >= 256) return 8;
+  // tall problems (A streams from HBM, tile order column-fastest): the 128 x 64 tile of ONE wave, K unsplit — no LDS
+  // reduction, every A row block read by N / 64 neighbouring workgroups (measured best at 579 600 rows, K = 256 ... 1024)
+  if ((long long)M * K * 4 > (64ll << 20) && N >= 64) return 14;
+  // the largest tile that still gives every CU a workgroup (half of them when a long K keeps each workgroup busy); below
+  // that, smaller tiles with a deeper K split
+  if (wgs(8) >= 256 || (K >= 1024 && wgs(8) >= 128)) return 8;
   if (wgs(6) >= 256) return 6;
   if (wgs(3) >= 192) return K >= 1024 ? 4 : 3;
   if (wgs(2) >= 96) return 2;

@@ -166,7 +166,7 @@ class MSDeformAttn(nn.Module):
         N, Len_q, _ = query.shape
         N, Len_in, _ = input_flatten.shape
         M, L, P = self.n_heads, self.n_levels, self.n_points
-        value = self.value_proj(input_flatten)
+        value = Fn.linear(input_flatten, self.value_proj.weight, self.value_proj.bias)     # library, or own (DVIS_DETERMINISTIC)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(N, Len_in, M, self.d_model // M)
@@ -175,16 +175,16 @@ class MSDeformAttn(nn.Module):
             n_off = 2 * L * P if slot else M * L * P * 2        # where a row's logits start (slots: inside the head's slot)
             po = pl = None
             if query_pos is not None and query_pos.shape[0] == 1 and _POS_IN_KERNEL:
-                pp = F.linear(query_pos[0], w)                                     # (Lq, 3*M*L*P): tiny, once per call
+                pp = Fn.linear(query_pos[0], w)                                    # (Lq, 3*M*L*P): tiny, once per call
                 po, pl = pp, pp[:, n_off:]
             elif query_pos is not None:
                 query = query + query_pos
-            proj = F.linear(query.reshape(N * Len_q, self.d_model), w, b)          # offsets | logits in one GEMM
+            proj = Fn.linear(query.reshape(N * Len_q, self.d_model), w, b)         # offsets | logits in one GEMM
             ref = reference_points if reference_points.is_contiguous() else reference_points.contiguous()
             output = Fn.msda_fused_forward(value, input_spatial_shapes, input_level_start_index, ref,
                                            proj, proj[:, n_off:], L, P, shapes_host=spatial_shapes_py,
                                            pos_offsets=po, pos_logits=pl, head_stride=slot)
-            return self.output_proj(output)
+            return Fn.linear(output, self.output_proj.weight, self.output_proj.bias)
         if query_pos is not None:
             query = query + query_pos
         sampling_offsets = self.sampling_offsets(query).view(N, Len_q, M, L, P, 2)
@@ -230,7 +230,7 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
             src2 = self.self_attn(src, reference_points, src, spatial_shapes, level_start_index, padding_mask,
                                   spatial_shapes_py=shapes_py, query_pos=pos)
         src = Fn.add_layer_norm(src2, src, self.norm1)
-        src2 = self.linear2(Fn.linear_relu(src, self.linear1))
+        src2 = Fn.linear(Fn.linear_relu(src, self.linear1), self.linear2.weight, self.linear2.bias)
         if emit_next_query and pos is not None and pos.shape[0] == 1:
             return Fn.add_layer_norm(src2, src, self.norm2, pos=pos)
         out = Fn.add_layer_norm(src2, src, self.norm2)

@@ -235,13 +235,13 @@ class _MaskedDecoderBase(nn.Module):
                 # V = (tok + level_embed) Wv^T + bv = tok Wv^T + (bv + Wv level_embed): no pass at all
                 tok = tokens[lvl]                                                               # (N, hw, C)
                 pos_t = self.pe_layer.compute(h, w, tok.device).flatten(2).transpose(1, 2)      # (1, hw, C)
-                kall = F.linear(tok + (pos_t + le), Wk, bk).transpose(0, 1)                     # (hw, N, n_l * C) view
-                vall = F.linear(tok, Wv, bv + F.linear(le, Wv)).transpose(0, 1)
+                kall = Fn.linear(tok + (pos_t + le), Wk, bk).transpose(0, 1)                    # (hw, N, n_l * C) view
+                vall = Fn.linear(tok, Wv, bv + F.linear(le, Wv)).transpose(0, 1)
             else:
                 src = (self.input_proj[lvl](x[lvl]).flatten(2) + le[None, :, None]).permute(2, 0, 1)
                 pos = self.pe_layer.compute(h, w, x[lvl].device).flatten(2).permute(2, 0, 1)   # (hw, 1, C)
-                kall = F.linear(src + pos, Wk, bk)                                              # (hw, N, n_l * C)
-                vall = F.linear(src, Wv, bv)
+                kall = Fn.linear(src + pos, Wk, bk)                                             # (hw, N, n_l * C)
+                vall = Fn.linear(src, Wv, bv)
             for n, i in enumerate(idx):
                 kproj[i], vproj[i] = kall[..., n * C:(n + 1) * C], vall[..., n * C:(n + 1) * C]
         query_embed = self.query_embed.weight.unsqueeze(1)                                      # (Q, 1, C) broadcasts
