@@ -39,7 +39,7 @@ struct GemmArgs {
 // room for.  Without it hipcc spends 176 registers (80 VGPR + 96 AGPR) on the 64 x 64 tile where 64 accumulators + two
 // fragment slots need ~150: 2 instead of 3 waves per SIMD, and the prologue / epilogue of one wave is then covered by only
 // one other wave's MFMAs.
-template <int TILES> constexpr int kGemmMinWaves = TILES >= 32 ? 1 : (TILES >= 12 ? 3 : 4);
+template <int TILES> constexpr int kGemmMinWaves = TILES >= 32 ? 1 : (TILES >= 20 ? 2 : (TILES >= 12 ? 3 : 4));
 
 template <int RT, int CT, int NW, int PF, bool K16>
 __global__ __launch_bounds__(64 * NW, kGemmMinWaves<RT * CT>) void gemm_nt_kernel(const GemmArgs p) {
@@ -219,6 +219,8 @@ const Config kConfigs[] = {
     DVIS_GEMM_CFG(4, 4, 1, 2),   // 12: 64 x 64, one wave, K not split (short K, tall M)
     DVIS_GEMM_CFG(8, 4, 2, 2),   // 13: 128 x 64
     DVIS_GEMM_CFG(8, 4, 1, 2),   // 14
+    DVIS_GEMM_CFG(6, 4, 1, 2),   // 15: 96 x 64, one wave: 96 accumulators + two fragment slots fit 2 waves per SIMD
+    DVIS_GEMM_CFG(5, 4, 1, 2),   // 16: 80 x 64
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -229,9 +231,10 @@ int pick_config(int M, int N, int K, int batch) {
     const long long cb = (N + 16 * kConfigs[c].ct - 1) / (16 * kConfigs[c].ct);
     return rb * cb * batch;
   };
-  // tall problems (A streams from HBM, tile order column-fastest): the 128 x 64 tile of ONE wave, K unsplit — no LDS
-  // reduction, every A row block read by N / 64 neighbouring workgroups (measured best at 579 600 rows, K = 256 ... 1024)
-  if ((long long)M * K * 4 > (64ll << 20) && N >= 64) return 14;
+  // tall problems (A streams from HBM, tile order column-fastest): ONE wave per tile, K unsplit — no LDS reduction, every
+  // A row block read by N / 64 neighbouring workgroups.  Measured at 579 600 rows: the 80 x 64 tile (2 waves per SIMD) for
+  // K = 256 (0.81 - 0.90 of hipBLASLt), the 128 x 64 tile for K = 1024 (0.88)
+  if ((long long)M * K * 4 > (64ll << 20) && N >= 64) return K >= 1024 ? 14 : 16;
   // the largest tile that still gives every CU a workgroup (half of them when a long K keeps each workgroup busy); below
   // that, smaller tiles with a deeper K split
   if (wgs(8) >= 256 || (K >= 1024 && wgs(8) >= 128)) return 8;
