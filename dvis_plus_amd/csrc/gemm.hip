@@ -248,6 +248,8 @@ int pick_config(int M, int N, int K, int batch) {
 
 DVIS_EXPORT int dvis_gemm_num_configs(void) { return kNumConfigs; }
 
+DVIS_EXPORT int dvis_gemm_pick_config(int M, int N, int K, int batch) { return pick_config(M, N, K, batch > 0 ? batch : 1); }
+
 DVIS_EXPORT int dvis_gemm_nt(const float *A, int64_t lda, int64_t strideA, const float *W, int64_t ldw, int64_t strideW,
                              const float *bias, const float *res, int64_t ldres, int64_t strideRes, float *C,
                              int64_t ldc, int64_t strideC, int M, int N, int K, int batch, int act, int config,

@@ -472,6 +472,29 @@ def upsample_add(lateral, top, lat_affine=None):
 OWN_GEMM_DEFAULT = os.environ.get("DVIS_DETERMINISTIC", "0") == "1"
 
 
+class gemm_sizes_as:
+    """Inside this context dvis_gemm_nt picks its tile configuration as if the problem had `rows` rows (and `batch` batch
+    entries), whatever the actual operand has.  A row's result depends on (N, K, configuration) only, so the tracker gets
+    the SAME bits for a clip whether its recurrence runs alone (Q rows per GEMM) or stacked with another clip's (2Q rows)."""
+    _rows, _batch = None, None
+
+    def __init__(self, rows=None, batch=None):
+        self.rows, self.batch = rows, batch
+
+    def __enter__(self):
+        self.prev = (gemm_sizes_as._rows, gemm_sizes_as._batch)
+        gemm_sizes_as._rows, gemm_sizes_as._batch = self.rows, self.batch
+
+    def __exit__(self, *exc):
+        gemm_sizes_as._rows, gemm_sizes_as._batch = self.prev
+
+
+def _gemm_config(M, N, K, batch, config):
+    if config >= 0 or (gemm_sizes_as._rows is None and gemm_sizes_as._batch is None):
+        return config
+    return native.lib().dvis_gemm_pick_config(gemm_sizes_as._rows or M, N, K, gemm_sizes_as._batch or batch)
+
+
 def _rows2d(x, K):
     """(..., K) tensor -> (2-D view (M, K) with unit inner stride, row stride in floats); copies only when the leading
     dims do not collapse into one stride."""
@@ -509,7 +532,7 @@ def gemm_nt(a, w, bias=None, relu=False, res=None, config=-1):
     with torch.cuda.device(a.device):
         rc = native.lib().dvis_gemm_nt(ctypes.c_void_p(a2.data_ptr()), lda, 0, ctypes.c_void_p(w.data_ptr()), w.stride(0), 0,
                                        bp, rp, ldres, 0, ctypes.c_void_p(out.data_ptr()), N, 0, M, N, K, 1,
-                                       1 if relu else 0, config, native.stream_ptr(a.device))
+                                       1 if relu else 0, _gemm_config(M, N, K, 1, config), native.stream_ptr(a.device))
     native.check(rc, "dvis_gemm_nt")
     return out
 
@@ -524,8 +547,8 @@ def bmm_nt(a, b, config=-1):
     out = torch.empty((B, M, N), dtype=torch.float32, device=a.device)
     with torch.cuda.device(a.device):
         rc = native.lib().dvis_gemm_nt(ctypes.c_void_p(a.data_ptr()), K, M * K, ctypes.c_void_p(b.data_ptr()), K, N * K, None,
-                                       None, 0, 0, ctypes.c_void_p(out.data_ptr()), N, M * N, M, N, K, B, 0, config,
-                                       native.stream_ptr(a.device))
+                                       None, 0, 0, ctypes.c_void_p(out.data_ptr()), N, M * N, M, N, K, B, 0,
+                                       _gemm_config(M, N, K, B, config), native.stream_ptr(a.device))
     native.check(rc, "dvis_gemm_nt")
     return out
 

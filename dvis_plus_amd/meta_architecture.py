@@ -133,6 +133,10 @@ class _VideoBase(nn.Module):
         # stream(): clips go in rounds of `world`, each clip's tracker + refiner on its own rank (DVIS_OWNER_ROUNDS=0:
         # one clip per round, tracker replicated on every rank)
         self.owner_rounds = os.environ.get("DVIS_OWNER_ROUNDS", "1") != "0"
+        # stream() with the tracker replicated (single GPU, or owner rounds off): clips per round whose tracker recurrences
+        # advance TOGETHER in one pass (same results per clip; the recurrence's ~65 launch-bound kernels per frame are paid
+        # once for the whole round).  Per-clip latency grows by (tracker_batch - 1) segmenter passes.
+        self.tracker_batch = max(1, int(os.environ.get("DVIS_TRACKER_BATCH", "1")))
         self.stream_timing = False            # stream(): make the per-clip "ready_event" a timing event (bench latency)
         # bench.py only: let a clip's input dict carry its own calibrated "object_mask_threshold" (random-init class
         # scores are near-uniform).  Off by default: the reference's input dicts have no such key.
@@ -375,7 +379,10 @@ class DVIS_Plus_offline(_VideoBase):
                               padded=tuple(images.shape[-2:])))
             batches.append(images if hi > lo else images[:0])
         mask_dim = self.sem_seg_head.predictor.mask_embed.layers[-1].out_features
-        merged = len(videos) > 1 and len({m["padded"] for m in metas}) == 1 and sum(len(b) for b in batches) > 0
+        # (one rank: every clip already is a full batch — separate calls keep a clip's segmenter bits independent of its
+        # round mates; DVIS_ROUND_CLIPS, a development aid, forces the merged batch on a single GPU)
+        merged = len(videos) > 1 and len({m["padded"] for m in metas}) == 1 and sum(len(b) for b in batches) > 0 \
+            and (self.clip_shard.world > 1 or self.clip_shard.force or "DVIS_ROUND_CLIPS" in os.environ)
 
         def run(images):
             if len(images):
@@ -448,6 +455,31 @@ class DVIS_Plus_offline(_VideoBase):
         mask_embed, cls, aux = self._track_core(embds, embds_nn)
         return self._finish_phase(st, mask_embed, cls, aux)
 
+    def _resume_of(self, st):
+        return bool(st["video"].get("keep", False)) and not self.window_inference
+
+    @torch.no_grad()
+    def _track_phase_batched(self, sts):
+        """Phase B of several clips of equal length with the tracker REPLICATED: one all-gather per clip as in
+        _track_phase, then ONE tracker pass in which the clips' recurrences advance together (ReferringTracker_noiser with
+        batch = number of clips: every op of the recurrence is row-wise or per (batch, head), the GEMMs' tile configuration is
+        pinned to a single clip's — same bits per clip as alone), then refiner, masks and post-processing clip by clip."""
+        to_bctq = lambda z: z.permute(2, 0, 1).unsqueeze(0)
+        self.keep = False
+        gathered = [self.clip_shard.all_gather_frames([st["embds"], st["embds_nn"], st["logits"]], st["T"], shift=st["shift"])
+                    for st in sts]
+        embds = torch.cat([to_bctq(g[0]) for g in gathered], 0)                      # (clips, 2C, T, Q)
+        embds_nn = torch.cat([to_bctq(g[1]) for g in gathered], 0)
+        track = self.tracker(embds, None, resume=False, frame_embeds_no_norm=embds_nn, need_masks=False)
+        outs = []
+        for j, st in enumerate(sts):
+            ref = self.refiner(track["pred_embds"][j:j + 1], embds_nn[j:j + 1], None, need_masks=False)
+            cls, aux = PP.mean_logits(ref["pred_logits"], track["pred_logits"][j:j + 1])
+            if self.debug_stages is not None:
+                self.debug_stages.update(instance_embds=track["pred_embds"][j:j + 1], refiner_embds=ref["pred_embds"])
+            outs.append(self._finish_phase(st, ref["mask_embed"], cls, aux))
+        return outs
+
     @torch.no_grad()
     def _track_round(self, sts):
         """Phase B of a round of up to `world` clips with ONE OWNER per clip: the tracker's recurrence and the refiner
@@ -463,6 +495,8 @@ class DVIS_Plus_offline(_VideoBase):
         m = len(sts)
         if not self.owner_rounds or (shard.world == 1 and not shard.force) \
                 or (not self.window_inference and any(bool(st["video"].get("keep", False)) for st in sts)):
+            if m > 1 and len({st["T"] for st in sts}) == 1 and not any(self._resume_of(st) for st in sts):
+                return self._track_phase_batched(sts)
             return [self._track_phase(st) for st in sts]
         assert m <= shard.world
         gathered = [shard.all_gather_frames([st["embds"], st["embds_nn"], st["logits"]], st["T"], shift=st["shift"])
@@ -515,7 +549,9 @@ class DVIS_Plus_offline(_VideoBase):
             self._tracker_stream = torch.cuda.Stream()
         side = self._tracker_stream if overlap else None
         # DVIS_ROUND_CLIPS: development aid — clips per round on a single GPU (exercises the merged segmenter batch)
-        per_round = int(os.environ.get("DVIS_ROUND_CLIPS", "0")) or (self.clip_shard.world if self.owner_rounds else 1)
+        sharded_owner = self.owner_rounds and (self.clip_shard.world > 1 or self.clip_shard.force)
+        per_round = int(os.environ.get("DVIS_ROUND_CLIPS", "0")) or (self.clip_shard.world if sharded_owner
+                                                                     else self.tracker_batch)
 
         def phase_b(sts):
             """Always next to the following round's phase A: everything phase B enqueues is own code that never waits for

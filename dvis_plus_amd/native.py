@@ -53,6 +53,7 @@ SIGNATURES = {
     "dvis_match_chain": (_i, [_p, _i, _i, _p]),
     "dvis_gemm_nt": (_i, [_p, _i64, _i64, _p, _i64, _i64, _p, _p, _i64, _i64, _p, _i64, _i64, _i, _i, _i, _i, _i, _i, _p]),
     "dvis_gemm_num_configs": (_i, []),
+    "dvis_gemm_pick_config": (_i, [_i, _i, _i, _i]),
 }
 
 _lib = None

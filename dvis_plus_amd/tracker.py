@@ -81,6 +81,17 @@ def match_chain(cost):
     return out
 
 
+def match_chains(costs):
+    """costs (B, T, Q, Q): the chains of B independent clips.  ONE device->host copy, B solver calls -> (B, T, Q)."""
+    c = costs.detach().to("cpu", torch.float32).contiguous().numpy()
+    B, T, Q, _ = c.shape
+    out = np.empty((B, T, Q), dtype=np.int64)
+    for b in range(B):
+        rc = native.lib().dvis_match_chain(c[b].ctypes.data_as(ctypes.c_void_p), T, Q, out[b].ctypes.data_as(ctypes.c_void_p))
+        native.check(rc, "dvis_match_chain")
+    return out
+
+
 def cosine_costs(cur, ref_first):
     """cur (T, Q, C) embeddings of the clip, ref_first (Q, C) what frame 0 is matched against.
     -> (T, Q, Q) with cost[i] = 1 - norm(cur_i) @ norm(ref_i)^T, ref_i = cur_{i-1} (un-permuted) for i > 0.
@@ -142,34 +153,39 @@ class ReferringTracker_noiser(nn.Module):
         return self._recurrence(fe_nn, idx_dev, last_outputs, self._rec_first)
 
     def _recurrence(self, fe_nn, idx_dev, last_outputs, first_is_start):
-        """The genuinely sequential part.  fe_nn (T,Q,1,C) un-normed frame queries, idx_dev (T,Q) assignments,
-        last_outputs (Q,1,C) carried state (ignored when the clip starts a video).
-        Returns (outputs (T,Q,1,C), references (T,Q,1,C), new last_outputs)."""
+        """The genuinely sequential part.  fe_nn (T,Q,B,C) un-normed frame queries, idx_dev (T,Q,B) assignments,
+        last_outputs (Q,B,C) carried state (ignored when the clip starts a video).  B > 1: B independent clips of equal
+        length advance together — every op below is row-wise or per (batch, head), so a clip's rows see the same arithmetic
+        as alone, and the ~65 launch-bound kernels per frame are paid once for all B clips.
+        Returns (outputs (T,Q,B,C), references (T,Q,B,C), new last_outputs)."""
         T, Q, B, C = fe_nn.shape
         W, b = self._kv_weights()
-        kv = Fn.linear(fe_nn, W, b, own=True)                                  # (T, Q, 1, layers * 2C): one GEMM
+        with Fn.gemm_sizes_as(rows=T * Q):
+            kv = Fn.linear(fe_nn, W, b, own=True)                              # (T, Q, B, layers * 2C): one GEMM
         Wq, bq = self._q_weights()
         outputs, refs = [], []
-        for i in range(T):
-            single_nn = fe_nn[i]                                               # (q, b, c)
-            out = single_nn[idx_dev[i]]
-            first = i == 0 and first_is_start
-            if not first:
-                # the same reference feeds every layer's cross-attention (tracker.py:278, 293-318): its 6 query
-                # projections are ONE GEMM (N = layers * C) instead of six launches in the sequential chain
-                reference = self.ref_proj(last_outputs)
-                q_all = Fn.linear(reference, Wq, bq, own=True)
-            for j in range(self.num_layers):
-                ref_j = self.ref_proj(single_nn if j == 0 else out) if first else reference
-                kj = kv[i, :, :, (2 * j) * C:(2 * j + 1) * C]
-                vj = kv[i, :, :, (2 * j + 1) * C:(2 * j + 2) * C]
-                qj = None if first else q_all[..., j * C:(j + 1) * C]
-                out = self.transformer_cross_attention_layers[j].attend(out, ref_j, kj, vj, q_proj=qj)
-                out = self.transformer_self_attention_layers[j](out)
-                out = self.transformer_ffn_layers[j](out)
-            refs.append(self.ref_proj(single_nn) if first else reference)
-            last_outputs = out
-            outputs.append(out)
+        gidx = idx_dev[..., None].expand(T, Q, B, C)
+        with Fn.gemm_sizes_as(rows=Q):                                         # tile configuration of ONE clip's Q rows
+            for i in range(T):
+                single_nn = fe_nn[i]                                           # (q, b, c)
+                out = torch.gather(single_nn, 0, gidx[i])                      # out[q, b] = single_nn[idx[q, b], b]
+                first = i == 0 and first_is_start
+                if not first:
+                    # the same reference feeds every layer's cross-attention (tracker.py:278, 293-318): its 6 query
+                    # projections are ONE GEMM (N = layers * C) instead of six launches in the sequential chain
+                    reference = self.ref_proj(last_outputs)
+                    q_all = Fn.linear(reference, Wq, bq, own=True)
+                for j in range(self.num_layers):
+                    ref_j = self.ref_proj(single_nn if j == 0 else out) if first else reference
+                    kj = kv[i, :, :, (2 * j) * C:(2 * j + 1) * C]
+                    vj = kv[i, :, :, (2 * j + 1) * C:(2 * j + 2) * C]
+                    qj = None if first else q_all[..., j * C:(j + 1) * C]
+                    out = self.transformer_cross_attention_layers[j].attend(out, ref_j, kj, vj, q_proj=qj)
+                    out = self.transformer_self_attention_layers[j](out)
+                    out = self.transformer_ffn_layers[j](out)
+                refs.append(self.ref_proj(single_nn) if first else reference)
+                last_outputs = out
+                outputs.append(out)
         return torch.stack(outputs, 0), torch.stack(refs, 0), last_outputs
 
     def forward(self, frame_embeds, mask_features, resume=False, return_indices=False, frame_classes=None,
@@ -182,17 +198,21 @@ class ReferringTracker_noiser(nn.Module):
         fe = frame_embeds.permute(2, 3, 0, 1)                                  # (t, q, b, c)
         fe_nn = fe if frame_embeds_no_norm is None else frame_embeds_no_norm.permute(2, 3, 0, 1)
         T, Q, B, C = fe.shape
-        assert B == 1, "inference runs one video at a time (the reference matches on batch entry 0 only)"
+        # The reference runs one video at a time (it matches on batch entry 0 only, noiser.py:43-56).  B > 1 here means B
+        # INDEPENDENT clips of equal length that each start a video, advanced together (stream() with tracker_batch > 1):
+        # same results per clip, the recurrence's launch-bound kernels paid once.
+        assert B == 1 or not resume, "only clips that start a video can share a tracker pass"
         first_is_start = not resume
         if first_is_start:
             self._clear_memory()
 
-        # ---- 1. every frame's assignment: batched cosine costs on the GPU, ONE sync, chain solved on the host
-        cur = fe[:, :, 0, :]
-        ref0 = cur[0] if first_is_start else self.last_frame_embeds[:, 0, :]
-        indices = match_chain(cosine_costs(cur, ref0))                         # (T, Q) int64, host
-        idx_dev = torch.from_numpy(indices).to(fe.device)
-        self.last_indices = indices                                            # (T, Q): this call's assignments (tests)
+        # ---- 1. every frame's assignment: batched cosine costs on the GPU, ONE sync, chains solved on the host
+        with Fn.gemm_sizes_as(batch=T):
+            costs = torch.stack([cosine_costs(fe[:, :, b, :], fe[0, :, b, :] if first_is_start
+                                              else self.last_frame_embeds[:, b, :]) for b in range(B)])
+        indices = match_chains(costs)                                          # (B, T, Q) int64, host
+        idx_dev = torch.from_numpy(indices).to(fe.device).permute(1, 2, 0).contiguous()    # (T, Q, B)
+        self.last_indices = indices[0] if B == 1 else indices                  # this call's assignments (tests)
 
         # ---- 2 + 3. K / V of all layers for all frames (one GEMM) and the recurrence, replayed from a hipGraph
         self._kv_weights(), self._q_weights()                                  # build the cached weights outside capture
@@ -200,14 +220,16 @@ class ReferringTracker_noiser(nn.Module):
         self._rec_first = first_is_start                                       # part of the graph key: fixes control flow
         self._graph.enabled = self.use_graphs
         outputs, refs, last = self._graph((T, first_is_start), fe_nn.contiguous(), idx_dev, state)
-        self.last_outputs = last.clone()
-        self.last_reference = refs[T - 1].clone()
-        self.last_frame_embeds = fe[T - 1][idx_dev[T - 1]]
+        # carried state = the LAST batch entry's (a later `resume` call continues that video)
+        self.last_outputs = last[:, B - 1:].clone()
+        self.last_reference = refs[T - 1][:, B - 1:].clone()
+        self.last_frame_embeds = torch.gather(fe[T - 1], 0, idx_dev[T - 1][..., None].expand(Q, B, C))[:, B - 1:].clone()
         outputs, refs = outputs.clone(), refs.clone()                          # static graph buffers -> owned tensors
 
         # ---- 4. heads
         dec = self.decoder_norm(outputs)
-        logits = Fn.linear(torch.cat([refs, dec], dim=-1), self.class_embed.weight, self.class_embed.bias, own=True)  # (t,q,b,K+1)
+        with Fn.gemm_sizes_as(rows=T * Q):
+            logits = Fn.linear(torch.cat([refs, dec], dim=-1), self.class_embed.weight, self.class_embed.bias, own=True)  # (t,q,b,K+1)
         out = {
             "pred_logits": logits.permute(2, 0, 1, 3),
             "pred_masks": None,
@@ -216,10 +238,11 @@ class ReferringTracker_noiser(nn.Module):
             "pred_references": refs.permute(2, 3, 0, 1),
         }
         if need_masks:
+            assert B == 1, "tracker masks (online mode) are produced one video at a time"
             b_, t_, cm, h, w = mask_features.shape
             mf = self.mask_feature_proj(mask_features.flatten(0, 1))           # (t, cm, h, w); online mode, main stream
             emb = self.mask_embed(dec[:, :, 0, :])                             # (t, q, cm)
             out["pred_masks"] = Fn.mask_logits(emb.contiguous(), mf).permute(1, 0, 2, 3).unsqueeze(0)
         if return_indices:
-            return out, [indices[i] for i in range(T)]
+            return out, [indices[0][i] for i in range(T)]
         return out

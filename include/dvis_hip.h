@@ -323,6 +323,10 @@ int dvis_gemm_nt(const float *A, int64_t lda, int64_t strideA, const float *W, i
                  const float *bias, const float *res, int64_t ldres, int64_t strideRes, float *C, int64_t ldc,
                  int64_t strideC, int M, int N, int K, int batch, int act, int config, void *stream);
 int dvis_gemm_num_configs(void);
+/* The configuration dvis_gemm_nt(config = -1) would choose for these sizes.  A row's result depends on (N, K, config) only,
+ * so a caller that wants the SAME bits for a row whether it is computed alone or stacked with other rows (the tracker run
+ * for one clip or for two clips at once) pins the configuration of the smaller problem. */
+int dvis_gemm_pick_config(int M, int N, int K, int batch);
 
 #ifdef __cplusplus
 }

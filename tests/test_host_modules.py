@@ -735,3 +735,20 @@ def test_reference_output_format_feeds_the_reference_evaluators(oracle_ops, mode
             assert torch.equal(o["pred_masks"], dev_out["pred_masks"].cpu())
         else:
             assert o["pred_masks"].numpy().astype(np.uint8).shape == (4, 70, 100)
+
+
+def test_tracker_batch_advances_two_clips_together_same_results(oracle_ops):
+    """stream() with tracker_batch = 2: the two clips of a round share ONE tracker pass (batch 2 through the recurrence) —
+    same outputs per clip as one by one; a clip of another length, and a single left-over clip, take the unbatched path."""
+    m = _tiny_model("offline", "vps")
+    clips = [{"image": _tiny_clip(T, seed=60 + i), "height": 70, "width": 100} for i, T in enumerate((5, 5, 4, 5, 5))]
+    want = [m([c]) for c in clips]
+    calls = []
+    fwd = m.tracker.forward
+    m.tracker.forward = lambda fe, *a, **k: (calls.append(fe.shape[0]), fwd(fe, *a, **k))[1]
+    m.tracker_batch = 2
+    got = list(m.stream(clips))
+    assert calls == [2, 1, 1, 1]          # (5, 5) together; (4, 5) differ in length -> one by one; the last clip alone
+    for g, w in zip(got, want):
+        assert g["segments_infos"] == w["segments_infos"] and g["pred_ids"] == w["pred_ids"]
+        assert torch.equal(g["pred_masks"], w["pred_masks"])

@@ -139,3 +139,25 @@ def test_soak_200_streamed_t64_clips_finish():
     tail = "\n".join((r.stdout + r.stderr).splitlines()[-12:])
     assert r.returncode == 0 and f"SOAK OK {n} clips" in r.stdout, tail
     print(tail)
+
+
+def test_tracker_batch_is_bit_identical_on_the_gpu():
+    """tracker_batch = 2: two clips' tracker recurrences advance together in one pass (batch 2 through every GEMM, attention
+    and add+LayerNorm of the recurrence, hipGraph-captured).  The GEMM tile configuration is pinned to one clip's rows and
+    the attention kernel works per (batch, head), so every clip's outputs equal the one-by-one run BIT FOR BIT."""
+    m = _model().to(DEV)
+    m.object_mask_threshold = 0.008
+    clips = [_clip(7, 20 + i) for i in range(5)] + [_clip(6, 30)]
+    with torch.no_grad():
+        want = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in m([c]).items()} for c in clips]
+        calls = []
+        fwd = m.tracker.forward
+        m.tracker.forward = lambda fe, *a, **k: (calls.append(fe.shape[0]), fwd(fe, *a, **k))[1]
+        m.tracker_batch = 2
+        got = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()} for o in m.stream(clips)]
+    torch.cuda.synchronize()
+    assert calls == [2, 2, 1, 1]                        # (7, 7) (7, 7) together; (7, 6) differ in length: one by one
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g["segments_infos"] == w["segments_infos"] and g["pred_ids"] == w["pred_ids"], i
+        assert torch.equal(g["pred_masks"], w["pred_masks"]), f"clip {i}: panoptic map differs from the unbatched run"
+    assert any(w["segments_infos"] for w in want), "degenerate test: no segment anywhere"
