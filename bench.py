@@ -140,19 +140,20 @@ def round_sizes(n_clips, per_round):
     return [min(per_round, n_clips - i) for i in range(0, n_clips, per_round)]
 
 
-def warmup_clip_count(warmup, steps, world, owner_rounds, streamed):
+def warmup_clip_count(warmup, steps, world, owner_rounds, streamed, tracker_batch=1):
     """Clips to run untimed so that EVERY segmenter batch shape of the timed pass has been seen (MIOpen searches its
     solvers, seconds per shape, the first time a convolution shape appears).  One clip per step on a single GPU.  With
-    several ranks stream() batches a rank's frames of a whole round of `world` clips into one segmenter call, so the shapes
-    are those of a full round and of the last, partial round (steps mod world clips, same rotation of the ragged split):
-    the warm-up replays exactly that round structure."""
-    if not (streamed and world > 1 and owner_rounds):
+    several ranks stream() batches a rank's frames of a whole ROUND of clips into one segmenter call — `world` clips with
+    tracker-owner rounds, `tracker_batch` clips with the replicated tracker — so the shapes are those of a full round and of
+    the last, partial round (steps mod round size clips): the warm-up replays exactly that round structure."""
+    size = world if owner_rounds else tracker_batch
+    if not (streamed and world > 1 and size > 1):
         return warmup
-    r, full = steps % world, steps >= world
-    k = max(1 if full else 0, -(-(warmup - r) // world))          # smallest k with k * world + r >= warmup
+    r, full = steps % size, steps >= size
+    k = max(1 if full else 0, -(-(warmup - r) // size))          # smallest k with k * size + r >= warmup
     if r == 0:
         k = max(k, 1)
-    return k * world + r
+    return k * size + r
 
 
 def calibrate_threshold(model, inputs, candidates):
@@ -359,7 +360,7 @@ def main():
         sides; max over ranks.  -> (seconds, outputs, latencies, MSDA timer, warm-up clips run)."""
         model.owner_rounds = owner_rounds
         model.stream_timing = False
-        warm = warmup_clip_count(args.warmup, args.steps, world, owner_rounds, streamed)
+        warm = warmup_clip_count(args.warmup, args.steps, world, owner_rounds, streamed, model.tracker_batch)
         run_pass([videos[i % len(videos)] for i in range(warm)])
         torch.cuda.synchronize()
         if dist_on:
@@ -384,6 +385,10 @@ def main():
     # segmenter) — and a second timed pass measures stream()'s tracker-owner rounds (clip j of a round of `world` clips is
     # tracked by rank j alone; one more all-gather per round) as an extra key.
     owner_default = model.owner_rounds
+    if world > 1 and streamed and "DVIS_TRACKER_BATCH" not in os.environ:
+        # replicated tracker: two clips per round advance through ONE tracker pass (same results per clip) and a rank's
+        # frames of both clips are one segmenter batch — at 8 ranks the replicated recurrence is otherwise the critical path
+        model.tracker_batch = 2
     dt, outs, lat, timer, warm_clips = timed(owner_rounds=False if world > 1 else owner_default)
     owner_line = None
     if world > 1 and streamed and owner_default:
@@ -406,7 +411,8 @@ def main():
         dist_info = {"world_size": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
                      "ranks": per_rank, "ranks_share_one_gpu": bool(one_device),
                      "split": "frames sharded contiguously (fixed split), one all-gather of per-frame queries "
-                              "per clip, tracker + refiner replicated"}
+                              "per clip, tracker + refiner replicated",
+                     "tracker_batch": model.tracker_batch}
 
     # second, short timed pass: every non-void query goes to the panoptic stage (the upper end of the work that the
     # candidate count controls).  Same protocol, up to 4 clips; single GPU only.

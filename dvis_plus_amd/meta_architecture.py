@@ -364,7 +364,7 @@ class DVIS_Plus_offline(_VideoBase):
         return self._segment_round([video], shift)[0]
 
     @torch.no_grad()
-    def _segment_round(self, videos, shift=0):
+    def _segment_round(self, videos, shift=0, rotate=True):
         """Phase A of a round of clips (clip j sharded with rotation shift + j).  The segmenter treats frames as a
         batch, so this rank's frames of ALL clips of the round go through it in ONE call when their padded sizes agree
         (8 ranks x 30-frame clips: one 30-frame batch per round instead of eight 4-frame calls — 158.7 vs 183 frames/s
@@ -373,9 +373,10 @@ class DVIS_Plus_offline(_VideoBase):
         for j, video in enumerate(videos):
             frames = video["image"]
             T = len(frames)
-            lo, hi = self.clip_shard.local_range(T, shift + j)
+            sh = shift + j if rotate else shift
+            lo, hi = self.clip_shard.local_range(T, sh)
             images, img_size = self.preprocess(frames[lo:hi] if hi > lo else frames[:1])
-            metas.append(dict(video=video, T=T, lo=lo, hi=hi, shift=shift + j, img_size=img_size,
+            metas.append(dict(video=video, T=T, lo=lo, hi=hi, shift=sh, img_size=img_size,
                               padded=tuple(images.shape[-2:])))
             batches.append(images if hi > lo else images[:0])
         mask_dim = self.sem_seg_head.predictor.mask_embed.layers[-1].out_features
@@ -584,11 +585,12 @@ class DVIS_Plus_offline(_VideoBase):
         it, prev, n = iter(videos), None, 0
         while True:
             chunk = list(itertools.islice(it, per_round))
-            # Rounds of several clips: rotate the ragged split clip by clip (over a round every rank gets the short blocks
-            # in turn: equal merged batches).  One clip per round (tracker replicated): no rotation — a clip takes
-            # ceil(T / world) frames of segmenter time whoever holds the short block, and a fixed split means every rank
-            # keeps ONE batch shape (a new convolution shape costs a MIOpen solver search, seconds).
-            sts = self._segment_round(chunk, shift=n if per_round > 1 else 0) if chunk else []
+            # Tracker-owner rounds: rotate the ragged split clip by clip (over a round of `world` clips every rank gets the
+            # short blocks in turn: equal merged batches).  Tracker replicated (one clip per round, or `tracker_batch`
+            # clips): no rotation — a clip takes ceil(T / world) frames of segmenter time whoever holds the short block,
+            # and a fixed split means every rank keeps ONE batch shape (a new convolution shape costs a MIOpen solver
+            # search, seconds).
+            sts = self._segment_round(chunk, shift=n if sharded_owner else 0, rotate=sharded_owner) if chunk else []
             n += len(chunk)
             if overlap and sts:
                 done = torch.cuda.Event()

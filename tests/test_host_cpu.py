@@ -53,3 +53,6 @@ def test_bench_warmup_replays_the_round_structure_of_the_timed_pass():
                 else:
                     assert w == warmup
     assert bench.warmup_clip_count(2, 10, 8, False, True) == 2 and bench.warmup_clip_count(2, 10, 8, True, False) == 2
+    # replicated tracker with two clips per round: a full round, plus the 1-clip round an odd step count ends with
+    assert bench.warmup_clip_count(2, 10, 8, False, True, tracker_batch=2) == 2
+    assert bench.warmup_clip_count(2, 5, 8, False, True, tracker_batch=2) == 3

@@ -587,6 +587,7 @@ def _northstar_worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     m = _tiny_model("offline", "vps")
     m.owner_rounds = False                        # north_star's split: what bench.py reports as the headline at N > 1
+    m.tracker_batch = int(os.environ.get("TEST_TRACKER_BATCH", "1"))
     seen = []
     for name in ("all_gather_into_tensor", "all_reduce", "broadcast", "all_gather", "all_to_all", "reduce_scatter_tensor"):
         orig = getattr(dist, name)
@@ -594,26 +595,36 @@ def _northstar_worker(rank, world, port, out_dir):
     clips = [{"image": _tiny_clip(5, seed=40 + i), "height": 70, "width": 100} for i in range(3)]
     per_clip = []
     for o in m.stream(clips):
-        per_clip.append((list(seen), o["frame_ids"], bool(o["segments_infos"])))
+        per_clip.append((list(seen), o["frame_ids"], o["segments_infos"], o["pred_masks"]))
         seen.clear()
     torch.save(per_clip, os.path.join(out_dir, f"n{rank}.pt"))
     dist.destroy_process_group()
 
 
-def test_north_star_split_is_one_all_gather_per_clip(oracle_ops, tmp_path):
+@pytest.mark.parametrize("tracker_batch", [1, 2])
+def test_north_star_split_is_one_all_gather_per_clip(oracle_ops, tmp_path, tracker_batch, monkeypatch):
     """BASELINE.json north_star: "a single RCCL all-gather ... of per-frame object queries before the temporal refiner".
     With the tracker replicated (owner rounds off) a clip costs exactly ONE all-gather; the only other collective is the
     VPS post-processing's sum of the per-segment areas (a few hundred bytes) — no broadcast (phase B is deterministic, every
     rank computes identical tracker / refiner outputs) — and the fixed (non-rotating) ragged split 3 + 2."""
     import torch.multiprocessing as mp
-    port = 38500 + (os.getpid() % 2000)
+    port = 38500 + (os.getpid() % 2000) + 7 * tracker_batch
+    monkeypatch.setenv("TEST_TRACKER_BATCH", str(tracker_batch))
     mp.spawn(_northstar_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     parts = [torch.load(tmp_path / f"n{r}.pt") for r in range(2)]
+    m = _tiny_model("offline", "vps")
+    singles = [m([{"image": _tiny_clip(5, seed=40 + i), "height": 70, "width": 100}]) for i in range(3)]
     for r, part in enumerate(parts):
-        for names, frame_ids, has_segments in part:
-            assert names.count("all_gather_into_tensor") == 1 and "broadcast" not in names, names
-            assert set(names) <= {"all_gather_into_tensor", "all_reduce"} and names.count("all_reduce") <= 1, names
-            assert frame_ids == ([0, 1, 2] if r == 0 else [3, 4])
+        names_all = [n for names, *_ in part for n in names]
+        # 3 clips: exactly one all-gather per clip, at most one (VPS area) all-reduce per clip, no broadcast — whether the
+        # clips' trackers run one by one or two clips of a round advance together (tracker_batch = 2: rounds of 2 + 1)
+        assert names_all.count("all_gather_into_tensor") == 3 and "broadcast" not in names_all, names_all
+        assert set(names_all) <= {"all_gather_into_tensor", "all_reduce"} and names_all.count("all_reduce") <= 3
+    for ci, single in enumerate(singles):            # stitched maps == the single-process result
+        held = sorted((p[ci][1][0], r) for r, p in enumerate(parts) if p[ci][1])
+        assert sorted(f for p in parts for f in p[ci][1]) == list(range(5))
+        assert torch.equal(torch.cat([parts[r][ci][3] for _, r in held], 0), single["pred_masks"]), ci
+        assert all(p[ci][2] == single["segments_infos"] for p in parts), ci
 
 
 def _ragged8_worker(rank, world, port, out_dir):
