@@ -97,8 +97,8 @@ def test_phase_b_is_bit_reproducible():
         m.tracker.use_graphs = m.refiner.use_graphs = True
         seg = m._segment_round
 
-        def replay_first(videos, shift=0):
-            sts = seg(videos, shift)
+        def replay_first(videos, shift=0, **kw):
+            sts = seg(videos, shift, **kw)
             if videos and videos[0] is video:
                 for k in ("embds", "embds_nn", "logits", "mf"):
                     sts[0][k] = st[k]                      # the SAME phase-A tensors as above
@@ -154,7 +154,7 @@ def test_tracker_batch_is_bit_identical_on_the_gpu():
         stored = {id(c): m._segment_phase(c) for c in clips}
         want = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in m._track_phase(dict(stored[id(c)])).items()}
                 for c in clips]
-        m._segment_round = lambda videos, shift=0: [dict(stored[id(v)]) for v in videos]
+        m._segment_round = lambda videos, shift=0, **kw: [dict(stored[id(v)]) for v in videos]
         calls = []
         fwd = m.tracker.forward
         m.tracker.forward = lambda fe, *a, **k: (calls.append(fe.shape[0]), fwd(fe, *a, **k))[1]
