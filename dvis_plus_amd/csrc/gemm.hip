@@ -195,14 +195,166 @@ __global__ __launch_bounds__(64 * NW, kGemmMinWaves<RT * CT>) void gemm_nt_kerne
   }
 }
 
+// Tall problems, one wave per tile (NW = 1): PERSISTENT form.  A wave walks tiles t = first, first + grid, ... and requests
+// the first fragment slots of its NEXT tile before the epilogue of the current one, so a tile's prologue latency (an HBM
+// round trip for the A rows) and the LDS transpose + stores of the epilogue overlap instead of adding up — at K = 256 a
+// tile is only 16 k-groups long and the two cost ~15 % of it.  Tile order as above: column-fastest and XCD-aware (the grid
+// is a multiple of 8: in every sweep an XCD's workgroups take consecutive logical tiles).
+template <int RT, int CT, int PF, bool K16>
+__global__ __launch_bounds__(64, kGemmMinWaves<RT * CT>) void gemm_nt_persist_kernel(const GemmArgs p) {
+  extern __shared__ float lds[];   // [16 RT][16 CT]: the epilogue's transpose buffer
+  constexpr int BM = 16 * RT, BN = 16 * CT, T = 64;
+  const int tid = threadIdx.x, lane = tid;
+  const int i = lane & 15, g = lane >> 4;
+  const long long total = (long long)p.row_blocks * p.col_blocks;
+  const unsigned gsz = gridDim.x;                                             // multiple of 8, <= total
+  long long t = (long long)(blockIdx.x & 7u) * (gsz >> 3) + (blockIdx.x >> 3);
+  const long long batch = blockIdx.y;
+  const float *A0 = p.A + batch * p.sA, *W0 = p.W + batch * p.sW;
+  unsigned aoff[RT], woff[CT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) aoff[rt] = (unsigned)((rt * 16 + i) * p.lda * 4 + g * 16);
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) woff[ct] = (unsigned)((ct * 16 + i) * p.ldw * 4 + g * 16);
+  const int g1 = (p.K + 15) >> 4;
+
+  int row0 = (int)(t / p.col_blocks) * BM, col0 = (int)(t % p.col_blocks) * BN;
+  auto desc_a = [&](int r0) {
+    const int rows = min(BM, p.M - r0);
+    return dvis_make_rsrc_uniform(A0 + (long long)r0 * p.lda, (unsigned)((((long long)rows - 1) * p.lda + p.K) * 4));
+  };
+  auto desc_w = [&](int c0) {
+    const int rows = min(BN, p.N - c0);
+    return dvis_make_rsrc_uniform(W0 + (long long)c0 * p.ldw, (unsigned)((((long long)rows - 1) * p.ldw + p.K) * 4));
+  };
+  __amdgpu_buffer_rsrc_t ra = desc_a(row0), rw = desc_w(col0);
+
+  dvis_f4 a[PF][RT], w[PF][CT];
+  auto load = [&](int slot, int grp) {
+    const bool in = grp < g1;
+    const unsigned so = in ? (unsigned)grp * 64u : 0u;
+    const bool kv = in && (K16 || grp * 16 + g * 4 < p.K);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+      a[slot][rt] = __builtin_bit_cast(dvis_f4, __builtin_amdgcn_raw_buffer_load_b128(ra, kv ? aoff[rt] : kOOB, so, 0));
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+      w[slot][ct] = __builtin_bit_cast(dvis_f4, __builtin_amdgcn_raw_buffer_load_b128(rw, kv ? woff[ct] : kOOB, so, 0));
+  };
+  dvis_f4 acc[RT][CT];
+  auto contract = [&](int s) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+          acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][rt][c], w[s][ct][c], acc[rt][ct], 0, 0, 0);
+  };
+#pragma unroll
+  for (int s = 0; s < PF; ++s) load(s, s);
+
+  float *Cb = p.C + batch * p.sC;
+  const float *Rb = p.res ? p.res + batch * p.sRes : nullptr;
+#pragma unroll 1
+  for (;;) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = dvis_f4{0.f, 0.f, 0.f, 0.f};
+    int grp = 0;
+#pragma unroll 1
+    for (; grp + 2 * PF <= g1; grp += PF) {
+#pragma unroll
+      for (int s = 0; s < PF; ++s) {
+        contract(s);
+        __builtin_amdgcn_sched_barrier(0);
+        load(s, grp + s + PF);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (grp + PF <= g1) {
+#pragma unroll
+      for (int s = 0; s < PF; ++s) {
+        contract(s);
+        if (grp + s + PF < g1) load(s, grp + s + PF);
+      }
+      grp += PF;
+    }
+#pragma unroll
+    for (int s = 0; s < PF; ++s)
+      if (grp + s < g1) contract(s);
+
+    // ---- the next tile's first slots go out BEFORE this tile's epilogue
+    const long long tn = t + gsz;
+    const bool more = tn < total;   // wave-uniform
+    const int row_e = row0, col_e = col0;
+    if (more) {
+      row0 = (int)(tn / p.col_blocks) * BM, col0 = (int)(tn % p.col_blocks) * BN;
+      ra = desc_a(row0), rw = desc_w(col0);
+#pragma unroll
+      for (int s = 0; s < PF; ++s) load(s, s);
+    }
+    // ---- epilogue of tile (row_e, col_e): transpose through LDS, bias / residual / ReLU, 16-byte stores
+    __syncthreads();   // the previous tile's reads of the buffer are done
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds[(rt * 16 + g * 4 + r) * BN + ct * 16 + i] = acc[rt][ct][r];
+    __syncthreads();
+    constexpr int U = BM * BN / 4, UR = BN / 4;
+#pragma unroll 4
+    for (int u = tid; u < U; u += T) {
+      const int row = u / UR, c4 = (u - row * UR) * 4;
+      dvis_f4 sv = *reinterpret_cast<const dvis_f4 *>(lds + row * BN + c4);
+      const int gr = row_e + row, gc = col_e + c4;
+      if (gr >= p.M || gc >= p.N) continue;
+      float *dst = Cb + (long long)gr * p.ldc + gc;
+      if (p.vec_store) {
+        if (p.bias) {
+          const dvis_f4 bq = *reinterpret_cast<const dvis_f4 *>(p.bias + gc);
+          sv = dvis_f4{sv[0] + bq[0], sv[1] + bq[1], sv[2] + bq[2], sv[3] + bq[3]};
+        }
+        if (Rb) {
+          const dvis_f4 tq = *reinterpret_cast<const dvis_f4 *>(Rb + (long long)gr * p.ldres + gc);
+          sv = dvis_f4{sv[0] + tq[0], sv[1] + tq[1], sv[2] + tq[2], sv[3] + tq[3]};
+        }
+        if (p.act) sv = dvis_f4{fmaxf(sv[0], 0.f), fmaxf(sv[1], 0.f), fmaxf(sv[2], 0.f), fmaxf(sv[3], 0.f)};
+        *reinterpret_cast<dvis_f4 *>(dst) = sv;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (gc + e >= p.N) break;
+          float v = sv[e];
+          if (p.bias) v += p.bias[gc + e];
+          if (Rb) v += Rb[(long long)gr * p.ldres + gc + e];
+          if (p.act) v = fmaxf(v, 0.f);
+          dst[e] = v;
+        }
+      }
+    }
+    if (!more) break;
+    t = tn;
+  }
+}
+
 struct Config {
   int rt, ct, nw;
   void (*kernel16)(const GemmArgs);
   void (*kernel4)(const GemmArgs);
+  void (*persist16)(const GemmArgs);   // NW == 1 only
+  void (*persist4)(const GemmArgs);
 };
+template <int RT, int CT, int NW, int PF, bool K16> constexpr auto persist_or_null() -> void (*)(const GemmArgs) {
+  if constexpr (NW == 1) return gemm_nt_persist_kernel<RT, CT, PF, K16>;
+  else return nullptr;
+}
 
-#define DVIS_GEMM_CFG(RT_, CT_, NW_, PF_) \
-  { RT_, CT_, NW_, gemm_nt_kernel<RT_, CT_, NW_, PF_, true>, gemm_nt_kernel<RT_, CT_, NW_, PF_, false> }
+#define DVIS_GEMM_CFG(RT_, CT_, NW_, PF_)                                                                      \
+  { RT_, CT_, NW_, gemm_nt_kernel<RT_, CT_, NW_, PF_, true>, gemm_nt_kernel<RT_, CT_, NW_, PF_, false>,            \
+    persist_or_null<RT_, CT_, NW_, PF_, true>(), persist_or_null<RT_, CT_, NW_, PF_, false>() }
 const Config kConfigs[] = {
     DVIS_GEMM_CFG(1, 1, 4, 4),   // 0: 16 x 16
     DVIS_GEMM_CFG(1, 1, 8, 4),   // 1
@@ -288,6 +440,29 @@ DVIS_EXPORT int dvis_gemm_nt(const float *A, int64_t lda, int64_t strideA, const
   static DvisLdsOptIn opted[kNumConfigs][2];
   if (const int rc = dvis_lds_opt_in(reinterpret_cast<const void *>(kernel), lds, &opted[c][K % 16 == 0 ? 0 : 1], "gemm_nt"))
     return rc;
+  // persistent form: one-wave tiles of a tall problem (see gemm_nt_persist_kernel); DVIS_GEMM_PERSIST=0 switches it off
+  static const bool persist_on = []() { const char *e = getenv("DVIS_GEMM_PERSIST"); return !(e && e[0] == '0'); }();
+  auto pk = K % 16 == 0 ? cf.persist16 : cf.persist4;
+  if (persist_on && pk != nullptr && p.col_fastest) {
+    static int cus = 0;
+    if (cus == 0) {
+      int dev = 0, n = 0;
+      hipGetDevice(&dev);
+      cus = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0 ? n : 256;
+    }
+    const int tiles_cnt = cf.rt * cf.ct;
+    const int occ = tiles_cnt >= 32 ? 1 : (tiles_cnt >= 20 ? 2 : (tiles_cnt >= 12 ? 3 : 4));   // = kGemmMinWaves
+    const size_t lds1 = (size_t)BM * BN * sizeof(float);
+    long long per_cu = 4ll * occ;
+    if ((long long)(160 * 1024 / lds1) < per_cu) per_cu = (long long)(160 * 1024 / lds1);
+    long long grid = (long long)cus * per_cu;
+    if (grid > tiles) grid = tiles;
+    grid &= ~7ll;
+    if (grid >= 8) {
+      hipLaunchKernelGGL(pk, dim3((unsigned)grid, (unsigned)batch), dim3(64), lds1, (hipStream_t)stream, p);
+      return dvis_check_launch("gemm_nt_persist_kernel");
+    }
+  }
   hipLaunchKernelGGL(kernel, dim3((unsigned)tiles, (unsigned)batch), dim3(64 * cf.nw), lds, (hipStream_t)stream, p);
   return dvis_check_launch("gemm_nt_kernel");
 }

@@ -121,3 +121,28 @@ def test_bit_reproducible_and_independent_of_neighbours():
     torch.cuda.synchronize()
     part = Fn.gemm_nt(a[:100], w, config=3)
     assert torch.equal(part, Fn.gemm_nt(a, w, config=3)[:100])
+
+
+@pytest.mark.parametrize("M,N,K", [(70001, 200, 256), (20000, 125, 1024)])
+def test_tall_problems_persistent_tiles_vs_fp64(M, N, K):
+    """A larger than the caches (M K 4 B > 64 MB): column-fastest XCD-aware tile order, and for the one-wave configurations
+    the PERSISTENT kernel (a wave walks several tiles, the next tile's fragments requested before the current epilogue);
+    ragged M and N, bias + ReLU epilogue, every configuration, checked on row samples incl. the first / last tiles."""
+    from dvis_plus_amd import functions as Fn
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g).to(DEV)
+    w = torch.randn(N, K, generator=g).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    rows = torch.cat([torch.arange(0, 300), torch.arange(M // 2, M // 2 + 300), torch.arange(M - 300, M),
+                      torch.randint(0, M, (600,), generator=g)]).to(DEV)
+    want = torch.relu(a[rows].double() @ w.double().t() + bias.double())
+    scale = float((a[rows].double().abs() @ w.double().abs().t()).max())
+    ref = None
+    for cfg in [-1] + list(range(_n_configs())):
+        got = Fn.gemm_nt(a, w, bias, relu=True, config=cfg)
+        err = float((got[rows].double() - want).abs().max())
+        assert err <= 4e-7 * scale, f"config {cfg}: max err {err:.3e}"
+        assert torch.isfinite(got).all()
+        if cfg == -1:
+            ref = got
+    assert torch.equal(Fn.gemm_nt(a, w, bias, relu=True), ref)          # and the same bits again
