@@ -256,6 +256,7 @@ __global__ __launch_bounds__(64, kGemmMinWaves<RT * CT>) void gemm_nt_persist_ke
 
   float *Cb = p.C + batch * p.sC;
   const float *Rb = p.res ? p.res + batch * p.sRes : nullptr;
+  const __amdgpu_buffer_rsrc_t rbias = dvis_make_rsrc_uniform(p.bias ? p.bias : p.A, p.bias ? (unsigned)p.N * 4u : 0u);
 #pragma unroll 1
   for (;;) {
 #pragma unroll
@@ -263,8 +264,7 @@ __global__ __launch_bounds__(64, kGemmMinWaves<RT * CT>) void gemm_nt_persist_ke
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = dvis_f4{0.f, 0.f, 0.f, 0.f};
     int grp = 0;
-#pragma unroll 1
-    for (; grp + 2 * PF <= g1; grp += PF) {
+    auto round = [&]() {
 #pragma unroll
       for (int s = 0; s < PF; ++s) {
         contract(s);
@@ -272,7 +272,15 @@ __global__ __launch_bounds__(64, kGemmMinWaves<RT * CT>) void gemm_nt_persist_ke
         load(s, grp + s + PF);
         __builtin_amdgcn_sched_barrier(0);
       }
-    }
+      grp += PF;
+    };
+    // The FIRST round of a tile is peeled out of the loop: on gfx950 loads and stores share the vmcnt counter and may
+    // complete out of order with respect to each other, so with the previous tile's epilogue stores possibly pending the
+    // compiler must wait vmcnt(0) — once, here.  Were this round inside the loop, the loop header would inherit "stores
+    // may be pending" from its entry edge and wait vmcnt(0) in EVERY round (seen in the ISA: the 80 x 64 tile lost 12 %).
+    if (grp + 2 * PF <= g1) round();
+#pragma unroll 1
+    while (grp + 2 * PF <= g1) round();
     if (grp + PF <= g1) {
 #pragma unroll
       for (int s = 0; s < PF; ++s) {
@@ -285,10 +293,19 @@ __global__ __launch_bounds__(64, kGemmMinWaves<RT * CT>) void gemm_nt_persist_ke
     for (int s = 0; s < PF; ++s)
       if (grp + s < g1) contract(s);
 
-    // ---- the next tile's first slots go out BEFORE this tile's epilogue
+    // ---- the next tile's first slots go out BEFORE this tile's epilogue.  The epilogue's only load — the thread's four
+    // bias values (its column quad is the same in every round: T is a multiple of BN / 4) — goes out before them: loads
+    // return in order, and waiting for a bias requested behind the prefetch would drain the prefetch.
     const long long tn = t + gsz;
     const bool more = tn < total;   // wave-uniform
     const int row_e = row0, col_e = col0;
+    static_assert(T % (BN / 4) == 0, "a thread keeps its column quad over the epilogue's rounds");
+    const int c4_mine = (tid % (BN / 4)) * 4;
+    // (through a descriptor over exactly the N bias values — none: zero records —, UNCONDITIONALLY and consumed on every
+    // path below: a load that some path leaves un-waited would be "possibly pending" at the loop head and cost every round
+    // of the main loop a vmcnt(0) before it may touch that register)
+    const dvis_f4 bias4 = __builtin_bit_cast(
+        dvis_f4, __builtin_amdgcn_raw_buffer_load_b128(rbias, (unsigned)(col_e + c4_mine) * 4u, 0, 0));
     if (more) {
       row0 = (int)(tn / p.col_blocks) * BM, col0 = (int)(tn % p.col_blocks) * BN;
       ra = desc_a(row0), rw = desc_w(col0);
@@ -313,10 +330,7 @@ __global__ __launch_bounds__(64, kGemmMinWaves<RT * CT>) void gemm_nt_persist_ke
       if (gr >= p.M || gc >= p.N) continue;
       float *dst = Cb + (long long)gr * p.ldc + gc;
       if (p.vec_store) {
-        if (p.bias) {
-          const dvis_f4 bq = *reinterpret_cast<const dvis_f4 *>(p.bias + gc);
-          sv = dvis_f4{sv[0] + bq[0], sv[1] + bq[1], sv[2] + bq[2], sv[3] + bq[3]};
-        }
+        sv = dvis_f4{sv[0] + bias4[0], sv[1] + bias4[1], sv[2] + bias4[2], sv[3] + bias4[3]};
         if (Rb) {
           const dvis_f4 tq = *reinterpret_cast<const dvis_f4 *>(Rb + (long long)gr * p.ldres + gc);
           sv = dvis_f4{sv[0] + tq[0], sv[1] + tq[1], sv[2] + tq[2], sv[3] + tq[3]};
@@ -327,8 +341,7 @@ __global__ __launch_bounds__(64, kGemmMinWaves<RT * CT>) void gemm_nt_persist_ke
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if (gc + e >= p.N) break;
-          float v = sv[e];
-          if (p.bias) v += p.bias[gc + e];
+          float v = sv[e] + bias4[e];
           if (Rb) v += Rb[(long long)gr * p.ldres + gc + e];
           if (p.act) v = fmaxf(v, 0.f);
           dst[e] = v;
@@ -383,10 +396,10 @@ int pick_config(int M, int N, int K, int batch) {
     const long long cb = (N + 16 * kConfigs[c].ct - 1) / (16 * kConfigs[c].ct);
     return rb * cb * batch;
   };
-  // tall problems (A streams from HBM, tile order column-fastest): ONE wave per tile, K unsplit — no LDS reduction, every
-  // A row block read by N / 64 neighbouring workgroups.  Measured at 579 600 rows: the 80 x 64 tile (2 waves per SIMD) for
-  // K = 256 (0.81 - 0.90 of hipBLASLt), the 128 x 64 tile for K = 1024 (0.88)
-  if ((long long)M * K * 4 > (64ll << 20) && N >= 64) return K >= 1024 ? 14 : 16;
+  // tall problems (A streams from HBM, tile order column-fastest): ONE wave per 128 x 64 tile, K unsplit — no LDS reduction,
+  // every A row block read by N / 64 neighbouring workgroups — in the PERSISTENT form (gemm_nt_persist_kernel).  Measured at
+  // 579 600 rows: 0.85 - 0.96 of hipBLASLt (the 80 x 64 / 64 x 64 tiles lose in that form: 0.80 / 0.53)
+  if ((long long)M * K * 4 > (64ll << 20) && N >= 64) return 14;
   // the largest tile that still gives every CU a workgroup (half of them when a long K keeps each workgroup busy); below
   // that, smaller tiles with a deeper K split
   if (wgs(8) >= 256 || (K >= 1024 && wgs(8) >= 128)) return 8;
