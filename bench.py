@@ -70,7 +70,7 @@ class MsdaTimer:
             e0.record(st)
             out = self.orig(value, *a, **k)
             e1.record(st)
-            self.events.append((e0, e1, value.shape[0]))
+            self.events.append((e0, e1, out.shape[0]))          # frames of this launch (the output is (N, Lq, M * D))
             return out
         self.Fn.msda_fused_forward = timed
         return self

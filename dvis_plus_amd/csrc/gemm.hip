@@ -33,6 +33,11 @@ struct GemmArgs {
   long long lda, ldw, ldres, ldc;          // row strides in floats
   long long sA, sW, sRes, sC;              // batch strides in floats
   int M, N, K, act, row_blocks, col_blocks, vec_store, col_fastest;
+  // head-major output: column n of row m goes to C[(n / head_d) * head_stride + m * head_d + n % head_d] — the (heads, M, d)
+  // layout MSDeformAttn gathers from (a pixel's d channels of ONE head are a contiguous line, neighbouring pixels adjacent);
+  // head_d == 0: plain row-major C with row stride ldc
+  int head_d;
+  long long head_stride;
 };
 
 // Register budget: the second __launch_bounds__ argument is the minimum number of waves per SIMD the allocator must leave
@@ -169,7 +174,8 @@ __global__ __launch_bounds__(64 * NW, kGemmMinWaves<RT * CT>) void gemm_nt_kerne
     }
     const int gr = row0 + row, gc = col0 + c4;
     if (gr >= p.M || gc >= p.N) continue;
-    float *dst = Cb + (long long)gr * p.ldc + gc;
+    float *dst = p.head_d ? Cb + (long long)(gc / p.head_d) * p.head_stride + (long long)gr * p.head_d + gc % p.head_d
+                          : Cb + (long long)gr * p.ldc + gc;
     if (p.vec_store) {   // N % 4 == 0, 16-byte aligned rows of C / bias / res
       if (p.bias) {
         const dvis_f4 b = *reinterpret_cast<const dvis_f4 *>(p.bias + gc);
@@ -328,7 +334,8 @@ __global__ __launch_bounds__(64, kGemmMinWaves<RT * CT>) void gemm_nt_persist_ke
       dvis_f4 sv = *reinterpret_cast<const dvis_f4 *>(lds + row * BN + c4);
       const int gr = row_e + row, gc = col_e + c4;
       if (gr >= p.M || gc >= p.N) continue;
-      float *dst = Cb + (long long)gr * p.ldc + gc;
+      float *dst = p.head_d ? Cb + (long long)(gc / p.head_d) * p.head_stride + (long long)gr * p.head_d + gc % p.head_d
+                            : Cb + (long long)gr * p.ldc + gc;
       if (p.vec_store) {
         sv = dvis_f4{sv[0] + bias4[0], sv[1] + bias4[1], sv[2] + bias4[2], sv[3] + bias4[3]};
         if (Rb) {
@@ -415,10 +422,10 @@ DVIS_EXPORT int dvis_gemm_num_configs(void) { return kNumConfigs; }
 
 DVIS_EXPORT int dvis_gemm_pick_config(int M, int N, int K, int batch) { return pick_config(M, N, K, batch > 0 ? batch : 1); }
 
-DVIS_EXPORT int dvis_gemm_nt(const float *A, int64_t lda, int64_t strideA, const float *W, int64_t ldw, int64_t strideW,
-                             const float *bias, const float *res, int64_t ldres, int64_t strideRes, float *C,
-                             int64_t ldc, int64_t strideC, int M, int N, int K, int batch, int act, int config,
-                             void *stream) {
+DVIS_EXPORT int dvis_gemm_nt_hm(const float *A, int64_t lda, int64_t strideA, const float *W, int64_t ldw, int64_t strideW,
+                                const float *bias, const float *res, int64_t ldres, int64_t strideRes, float *C,
+                                int64_t ldc, int64_t strideC, int M, int N, int K, int batch, int act, int config,
+                                int head_d, int64_t head_stride, void *stream) {
   DVIS_REQUIRE(M >= 0 && N >= 0 && K > 0 && batch >= 0, "gemm_nt: bad sizes (M=%d N=%d K=%d batch=%d)", M, N, K, batch);
   if (M == 0 || N == 0 || batch == 0) return DVIS_OK;
   DVIS_REQUIRE(A && W && C, "gemm_nt: null pointer");
@@ -426,7 +433,8 @@ DVIS_EXPORT int dvis_gemm_nt(const float *A, int64_t lda, int64_t strideA, const
                    ((uintptr_t)A | (uintptr_t)W) % 16 == 0,
                "gemm_nt: needs K, lda, ldw, batch strides %% 4 == 0 and 16-byte aligned A / W (K=%d lda=%lld ldw=%lld)", K,
                (long long)lda, (long long)ldw);
-  DVIS_REQUIRE(lda >= K && ldw >= K && ldc >= N && (!res || ldres >= N), "gemm_nt: row strides shorter than the rows");
+  DVIS_REQUIRE(lda >= K && ldw >= K && (head_d || ldc >= N) && (!res || ldres >= N),
+               "gemm_nt: row strides shorter than the rows");
   DVIS_REQUIRE(batch <= 65535, "gemm_nt: batch <= 65535");
   const int c = config >= 0 ? config : pick_config(M, N, K, batch);
   DVIS_REQUIRE(c < kNumConfigs, "gemm_nt: configuration %d does not exist", c);
@@ -439,6 +447,10 @@ DVIS_EXPORT int dvis_gemm_nt(const float *A, int64_t lda, int64_t strideA, const
   p.lda = lda, p.ldw = ldw, p.ldres = ldres, p.ldc = ldc;
   p.sA = strideA, p.sW = strideW, p.sRes = strideRes, p.sC = strideC;
   p.M = M, p.N = N, p.K = K, p.act = act;
+  DVIS_REQUIRE(head_d == 0 || (head_d % 4 == 0 && N % head_d == 0 && !res && batch == 1 && head_stride >= (int64_t)M * head_d &&
+                               head_stride % 4 == 0),
+               "gemm_nt: head-major output needs head_d %% 4 == 0, N %% head_d == 0, no residual, batch 1");
+  p.head_d = head_d, p.head_stride = head_stride;
   p.row_blocks = (M + BM - 1) / BM;
   p.col_blocks = (N + BN - 1) / BN;
   // A larger than what the caches keep between two passes over it (L2s 32 MB; the 256 MB MALL is shared with C and W)
@@ -478,4 +490,12 @@ DVIS_EXPORT int dvis_gemm_nt(const float *A, int64_t lda, int64_t strideA, const
   }
   hipLaunchKernelGGL(kernel, dim3((unsigned)tiles, (unsigned)batch), dim3(64 * cf.nw), lds, (hipStream_t)stream, p);
   return dvis_check_launch("gemm_nt_kernel");
+}
+
+DVIS_EXPORT int dvis_gemm_nt(const float *A, int64_t lda, int64_t strideA, const float *W, int64_t ldw, int64_t strideW,
+                             const float *bias, const float *res, int64_t ldres, int64_t strideRes, float *C,
+                             int64_t ldc, int64_t strideC, int M, int N, int K, int batch, int act, int config,
+                             void *stream) {
+  return dvis_gemm_nt_hm(A, lda, strideA, W, ldw, strideW, bias, res, ldres, strideRes, C, ldc, strideC, M, N, K, batch, act,
+                         config, 0, 0, stream);
 }

@@ -128,6 +128,10 @@ struct TileMap {
   // offsets, then all heads' logits: L*P*2 and L*P).  "Slots" = [head m: 2LP offsets | LP logits | pad]: a (query, head)
   // pair then touches ONE contiguous run of its row instead of two (fewer 128-byte lines shared between the 8 XCDs).
   int off_hs, logit_hs;
+  // `value` is HEAD-MAJOR (M, N, S, D) instead of the reference's (N, S, M, D): a pixel's D channels of one head are
+  // still one 128-byte line, but neighbouring pixels of the head are ADJACENT lines (two x-neighbouring corners = 256
+  // contiguous bytes) instead of M * D * 4 = 1 KB apart — what the value projection writes through dvis_gemm_nt_hm.
+  int value_hm;
 };
 
 bool make_tile_map(const int64_t *shapes_host, int L, int Lq, TileMap *tm) {
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile(
   // then softmax, loc = ref + off / (W_l, H_l) and the taps, and ONE barrier.  (The first form staged the rows in LDS,
   // synchronised, loaded the reference points, computed, synchronised again: with the gather switched off that set-up
   // alone took 12.7-15.5 us per 720p frame-layer, and with the loads switched off the kernel still took 23.5 of 35 us.)
-  const unsigned pix_bytes = (unsigned)MD * (unsigned)sizeof(T);
+  const unsigned pix_bytes = (unsigned)(tm.value_hm ? D : MD) * (unsigned)sizeof(T);
   static_assert(QB * P <= 256, "one set-up thread per (query, point)");
   if (tid < QB * P) {
     const int ql = tid / P, p = tid - ql * P;
@@ -298,8 +302,11 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile(
   __amdgpu_buffer_rsrc_t rs[L];
 #pragma unroll
   for (int l = 0; l < L; ++l) {
-    const T *base = value + (((size_t)n * S + (size_t)level_start[l]) * M + m) * D;
-    rs[l] = dvis_make_rsrc_uniform(base, (unsigned)(((size_t)(Hs[l] * Ws[l] - 1) * MD + D) * sizeof(T)));
+    const T *base = tm.value_hm
+                        ? value + (((size_t)m * gridDim.z + n) * S + (size_t)level_start[l]) * D
+                        : value + (((size_t)n * S + (size_t)level_start[l]) * M + m) * D;
+    rs[l] = dvis_make_rsrc_uniform(
+        base, (unsigned)(((size_t)(Hs[l] * Ws[l] - 1) * (tm.value_hm ? D : MD) + D) * sizeof(T)));
   }
 
   const int lane = tid & 63, wv = tid >> 6;
@@ -528,9 +535,10 @@ DVIS_EXPORT int dvis_msda_forward(int dtype, const void *value, const int64_t *s
 DVIS_EXPORT int dvis_msda_fused_forward_slots(const float *value, const int64_t *shapes, const int64_t *level_start,
                                               const float *ref, int Nref, const float *offsets, int64_t off_stride,
                                               const float *logits, int64_t logit_stride, int off_head_stride,
-                                              int logit_head_stride, const float *pos_offsets, const float *pos_logits,
-                                              int64_t pos_stride, int N, int S, int M, int D, int L, int Lq, int P,
-                                              float *out, const int64_t *shapes_host, void *stream) {
+                                              int logit_head_stride, int value_head_major, const float *pos_offsets,
+                                              const float *pos_logits, int64_t pos_stride, int N, int S, int M, int D,
+                                              int L, int Lq, int P, float *out, const int64_t *shapes_host,
+                                              void *stream) {
   DVIS_REQUIRE(N >= 0 && S > 0 && M > 0 && D > 0 && L > 0 && Lq >= 0 && P > 0, "msda_fused_forward: bad sizes");
   if (N == 0 || Lq == 0) return DVIS_OK;
   DVIS_REQUIRE(value && shapes && level_start && ref && offsets && logits && out, "msda_fused_forward: null pointer");
@@ -552,6 +560,7 @@ DVIS_EXPORT int dvis_msda_fused_forward_slots(const float *value, const int64_t 
   const bool has_pos = pos_offsets != nullptr || pos_logits != nullptr;
   if (!has_pos) make_tile_map(shapes_host, L, Lq, &tm);
   tm.off_hs = off_head_stride, tm.logit_hs = logit_head_stride;
+  tm.value_hm = value_head_major ? 1 : 0;
   if (has_pos) {
     DVIS_REQUIRE(pos_offsets && pos_logits && pos_stride >= (int64_t)(M - 1) * off_hs + L * P * 2 && pos_stride % 4 == 0 &&
                      aligned16(pos_offsets) && aligned16(pos_logits),
@@ -573,7 +582,7 @@ DVIS_EXPORT int dvis_msda_fused_forward_pos(const float *value, const int64_t *s
                                             const float *pos_logits, int64_t pos_stride, int N, int S, int M, int D,
                                             int L, int Lq, int P, float *out, const int64_t *shapes_host, void *stream) {
   return dvis_msda_fused_forward_slots(value, shapes, level_start, ref, Nref, offsets, off_stride, logits, logit_stride, 0, 0,
-                                       pos_offsets, pos_logits, pos_stride, N, S, M, D, L, Lq, P, out, shapes_host, stream);
+                                       0, pos_offsets, pos_logits, pos_stride, N, S, M, D, L, Lq, P, out, shapes_host, stream);
 }
 
 DVIS_EXPORT int dvis_msda_fused_forward(const float *value, const int64_t *shapes, const int64_t *level_start,

@@ -111,7 +111,8 @@ class MSDeformAttnFunction(Function):
 
 
 def msda_fused_forward(value, spatial_shapes, level_start_index, reference_points, offsets, logits, n_levels,
-                       n_points, shapes_host=None, pos_offsets=None, pos_logits=None, head_stride=0):
+                       n_points, shapes_host=None, pos_offsets=None, pos_logits=None, head_stride=0,
+                       value_head_major=False):
     """Inference fast path of ``MSDeformAttn.forward`` (ops/modules/ms_deform_attn.py:101-117), fp32.
 
     value (N,S,M,D); reference_points (1|N, Lq, L, 2); ``offsets`` / ``logits`` are 2-D row views
@@ -123,8 +124,12 @@ def msda_fused_forward(value, spatial_shapes, level_start_index, reference_point
     (linear(src + pos) = linear(src) + pos W^T), so the caller projects `src` and never forms `src + pos`.
     head_stride: 0 = the reference's row layout (all heads' offsets, then all heads' logits); s > 0 = per-head SLOTS of s
     floats [2LP offsets | LP logits | pad]: `offsets` then points at a row's first slot and `logits` 2LP floats further.
+    value_head_major: `value` is (M, N, S, D) — head outermost — instead of (N, S, M, D).
     """
-    N, S, M, D = value.shape
+    if value_head_major:            # (M, N, S, D): head outermost (gemm_nt(head_major=D) of the value projection)
+        M, N, S, D = value.shape
+    else:
+        N, S, M, D = value.shape
     L, P = n_levels, n_points
     nref, Lq = reference_points.shape[0], reference_points.shape[1]
     for name, t in (("value", value), ("reference_points", reference_points)):
@@ -162,7 +167,8 @@ def msda_fused_forward(value, spatial_shapes, level_start_index, reference_point
             native.dev_ptr(value, "value"), native.dev_ptr(spatial_shapes, "spatial_shapes"),
             native.dev_ptr(level_start_index, "level_start_index"), native.dev_ptr(reference_points, "ref"), nref,
             ctypes.c_void_p(offsets.data_ptr()), offsets.stride(0), ctypes.c_void_p(logits.data_ptr()),
-            logits.stride(0), int(head_stride), int(head_stride), po, pl, pstride, N, S, M, D, L, Lq, P,
+            logits.stride(0), int(head_stride), int(head_stride), 1 if value_head_major else 0, po, pl, pstride,
+            N, S, M, D, L, Lq, P,
             native.dev_ptr(out, "out"), hs, native.stream_ptr(value.device))
     native.check(rc, "dvis_msda_fused_forward")
     return out
@@ -505,11 +511,13 @@ def _rows2d(x, K):
     return x.view(-1, K), K
 
 
-def gemm_nt(a, w, bias=None, relu=False, res=None, config=-1):
+def gemm_nt(a, w, bias=None, relu=False, res=None, config=-1, head_major=0):
     """``relu?(a @ w.T + bias + res)`` on the deterministic exact-fp32 MFMA kernel (dvis_gemm_nt).  a (..., K) float32 GPU
     tensor (rows with unit inner stride; a row-sliced 2-D view keeps its row stride), w (N, K) in F.linear's layout (row
     stride >= K allowed), bias (N) or None, res (..., N) or None.  Returns (..., N).  Raises when the kernel cannot serve
-    the operands (K or a row stride not a multiple of 4, unaligned base) — there is no silent library fallback here."""
+    the operands (K or a row stride not a multiple of 4, unaligned base) — there is no silent library fallback here.
+    head_major = d > 0: the output is written as (N / d, M, d) — N / d matrices of M rows, d columns each (the head-major
+    value layout of MSDeformAttn) — and returned with that shape (M = all leading dims of `a` flattened)."""
     K = a.shape[-1]
     N = w.shape[0]
     if not (a.is_cuda and a.dtype == torch.float32 and w.dtype == torch.float32 and w.dim() == 2 and w.shape[1] == K
@@ -517,7 +525,12 @@ def gemm_nt(a, w, bias=None, relu=False, res=None, config=-1):
         raise RuntimeError("gemm_nt: needs float32 GPU operands a (..., K), w (N, K) with unit inner strides")
     a2, lda = _rows2d(a, K)
     M = a2.shape[0]
-    out = torch.empty((*a.shape[:-1], N), dtype=torch.float32, device=a.device)
+    if head_major:
+        if N % head_major or head_major % 4 or res is not None:
+            raise RuntimeError("gemm_nt: head_major needs N % d == 0, d % 4 == 0 and no residual")
+        out = torch.empty((N // head_major, M, head_major), dtype=torch.float32, device=a.device)
+    else:
+        out = torch.empty((*a.shape[:-1], N), dtype=torch.float32, device=a.device)
     rp, ldres = None, 0
     if res is not None:
         if res.shape != out.shape or res.dtype != torch.float32 or not res.is_cuda:
@@ -530,9 +543,10 @@ def gemm_nt(a, w, bias=None, relu=False, res=None, config=-1):
             raise RuntimeError("gemm_nt: bias must be a contiguous float32 (N,) tensor")
         bp = ctypes.c_void_p(bias.data_ptr())
     with torch.cuda.device(a.device):
-        rc = native.lib().dvis_gemm_nt(ctypes.c_void_p(a2.data_ptr()), lda, 0, ctypes.c_void_p(w.data_ptr()), w.stride(0), 0,
-                                       bp, rp, ldres, 0, ctypes.c_void_p(out.data_ptr()), N, 0, M, N, K, 1,
-                                       1 if relu else 0, _gemm_config(M, N, K, 1, config), native.stream_ptr(a.device))
+        rc = native.lib().dvis_gemm_nt_hm(ctypes.c_void_p(a2.data_ptr()), lda, 0, ctypes.c_void_p(w.data_ptr()), w.stride(0), 0,
+                                          bp, rp, ldres, 0, ctypes.c_void_p(out.data_ptr()), head_major or N, 0, M, N, K, 1,
+                                          1 if relu else 0, _gemm_config(M, N, K, 1, config), int(head_major),
+                                          M * head_major, native.stream_ptr(a.device))
     native.check(rc, "dvis_gemm_nt")
     return out
 

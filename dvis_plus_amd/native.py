@@ -27,8 +27,8 @@ SIGNATURES = {
     "dvis_msda_fused_forward": (_i, [_p, _p, _p, _p, _i, _p, _i64, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "dvis_msda_fused_forward_pos": (_i, [_p, _p, _p, _p, _i, _p, _i64, _p, _i64, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _i,
                                          _p, _p, _p]),
-    "dvis_msda_fused_forward_slots": (_i, [_p, _p, _p, _p, _i, _p, _i64, _p, _i64, _i, _i, _p, _p, _i64, _i, _i, _i, _i, _i,
-                                           _i, _i, _p, _p, _p]),
+    "dvis_msda_fused_forward_slots": (_i, [_p, _p, _p, _p, _i, _p, _i64, _p, _i64, _i, _i, _i, _p, _p, _i64, _i, _i, _i, _i,
+                                           _i, _i, _i, _p, _p, _p]),
     "dvis_nchw_to_tokens": (_i, [_p, _p, _i64, _i, _i64, _i64, _i64, _p]),
     "dvis_nchw_to_tokens_affine": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i64, _i64, _i64, _p]),
     "dvis_mask_logits": (_i, [_p, _p, _i, _i, _i, _i64, _p, _p]),
@@ -52,6 +52,8 @@ SIGNATURES = {
     "dvis_lsap_solve": (_i, [_p, _i, _i, _p]),
     "dvis_match_chain": (_i, [_p, _i, _i, _p]),
     "dvis_gemm_nt": (_i, [_p, _i64, _i64, _p, _i64, _i64, _p, _p, _i64, _i64, _p, _i64, _i64, _i, _i, _i, _i, _i, _i, _p]),
+    "dvis_gemm_nt_hm": (_i, [_p, _i64, _i64, _p, _i64, _i64, _p, _p, _i64, _i64, _p, _i64, _i64, _i, _i, _i, _i, _i, _i, _i,
+                             _i64, _p]),
     "dvis_gemm_num_configs": (_i, []),
     "dvis_gemm_pick_config": (_i, [_i, _i, _i, _i]),
 }

@@ -37,6 +37,8 @@ from .registry import SEM_SEG_HEADS_REGISTRY, ShapeSpec
 _POS_IN_KERNEL = os.environ.get("DVIS_MSDA_POS", "0") == "1"
 # rows of the fused offsets | logits projection permuted into per-head slots (MSDeformAttn._fused_projection)
 _MSDA_SLOTS = os.environ.get("DVIS_MSDA_SLOTS", "0") == "1"
+# the value projection written HEAD-MAJOR (M, N, S, D) by the own GEMM's epilogue and gathered from that layout
+_MSDA_HM = os.environ.get("DVIS_MSDA_HM", "0") == "1"
 
 
 def _is_power_of_2(n):
@@ -166,11 +168,18 @@ class MSDeformAttn(nn.Module):
         N, Len_q, _ = query.shape
         N, Len_in, _ = input_flatten.shape
         M, L, P = self.n_heads, self.n_levels, self.n_points
-        value = Fn.linear(input_flatten, self.value_proj.weight, self.value_proj.bias)     # library, or own (DVIS_DETERMINISTIC)
-        if input_padding_mask is not None:
-            value = value.masked_fill(input_padding_mask[..., None], float(0))
-        value = value.view(N, Len_in, M, self.d_model // M)
-        if self._fast_path_ok(query, reference_points, input_padding_mask):
+        fast = self._fast_path_ok(query, reference_points, input_padding_mask)
+        hm = fast and _MSDA_HM and input_flatten.is_contiguous()
+        if hm:
+            # own GEMM with a head-major epilogue: value[m, n, s, :] — neighbouring pixels of a head are adjacent lines
+            value = Fn.gemm_nt(input_flatten.view(N * Len_in, self.d_model), self.value_proj.weight.detach(),
+                               self.value_proj.bias.detach(), head_major=self.d_model // M).view(M, N, Len_in, -1)
+        else:
+            value = Fn.linear(input_flatten, self.value_proj.weight, self.value_proj.bias)  # library, or own (DVIS_DETERMINISTIC)
+            if input_padding_mask is not None:
+                value = value.masked_fill(input_padding_mask[..., None], float(0))
+            value = value.view(N, Len_in, M, self.d_model // M)
+        if fast:
             w, b, slot = self._fused_projection()
             n_off = 2 * L * P if slot else M * L * P * 2        # where a row's logits start (slots: inside the head's slot)
             po = pl = None
@@ -183,7 +192,7 @@ class MSDeformAttn(nn.Module):
             ref = reference_points if reference_points.is_contiguous() else reference_points.contiguous()
             output = Fn.msda_fused_forward(value, input_spatial_shapes, input_level_start_index, ref,
                                            proj, proj[:, n_off:], L, P, shapes_host=spatial_shapes_py,
-                                           pos_offsets=po, pos_logits=pl, head_stride=slot)
+                                           pos_offsets=po, pos_logits=pl, head_stride=slot, value_head_major=hm)
             return Fn.linear(output, self.output_proj.weight, self.output_proj.bias)
         if query_pos is not None:
             query = query + query_pos

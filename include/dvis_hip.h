@@ -125,11 +125,13 @@ int dvis_msda_fused_forward_pos(const float *value, const int64_t *shapes, const
  * L*P, i.e. all heads' offsets, then all heads' logits).  With the rows of the fused projection permuted into per-head
  * SLOTS [2LP offsets | LP logits | pad] (offsets = proj, logits = proj + 2LP, both head strides = the slot size) a
  * (query, head) pair reads one contiguous run of its row: fewer 128-byte lines shared between the heads' XCDs.
+ * value_head_major != 0: `value` is laid out (M, N, S, D) — head outermost, as dvis_gemm_nt_hm writes the value projection —
+ * instead of the reference's (N, S, M, D): neighbouring pixels of a head are adjacent 128-byte lines.
  */
 int dvis_msda_fused_forward_slots(const float *value, const int64_t *shapes, const int64_t *level_start,
                                   const float *ref, int Nref, const float *offsets, int64_t off_stride,
                                   const float *logits, int64_t logit_stride, int off_head_stride, int logit_head_stride,
-                                  const float *pos_offsets, const float *pos_logits, int64_t pos_stride, int N, int S,
+                                  int value_head_major, const float *pos_offsets, const float *pos_logits, int64_t pos_stride, int N, int S,
                                   int M, int D, int L, int Lq, int P, float *out, const int64_t *shapes_host,
                                   void *stream);
 
@@ -322,6 +324,14 @@ int dvis_match_chain(const float *cost, int T, int Q, int64_t *indices);
 int dvis_gemm_nt(const float *A, int64_t lda, int64_t strideA, const float *W, int64_t ldw, int64_t strideW,
                  const float *bias, const float *res, int64_t ldres, int64_t strideRes, float *C, int64_t ldc,
                  int64_t strideC, int M, int N, int K, int batch, int act, int config, void *stream);
+/* Same with a HEAD-MAJOR output: column n of row m is stored at C[(n / head_d) * head_stride + m * head_d + n % head_d], i.e. C
+ * is (N / head_d) matrices of M x head_d — the value layout dvis_msda_fused_forward_slots(value_head_major = 1) gathers from
+ * (the value projection of MSDeformAttn, ops/modules/ms_deform_attn.py:97-100, written in the layout its consumer wants).
+ * head_d == 0: dvis_gemm_nt.  Needs batch == 1, no residual. */
+int dvis_gemm_nt_hm(const float *A, int64_t lda, int64_t strideA, const float *W, int64_t ldw, int64_t strideW,
+                    const float *bias, const float *res, int64_t ldres, int64_t strideRes, float *C, int64_t ldc,
+                    int64_t strideC, int M, int N, int K, int batch, int act, int config, int head_d, int64_t head_stride,
+                    void *stream);
 int dvis_gemm_num_configs(void);
 /* The configuration dvis_gemm_nt(config = -1) would choose for these sizes.  A row's result depends on (N, K, config) only,
  * so a caller that wants the SAME bits for a row whether it is computed alone or stacked with other rows (the tracker run

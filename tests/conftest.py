@@ -121,8 +121,10 @@ def _o_mask_logits(mask_embed, mask_features):
 
 
 def _o_msda_fused(value, spatial_shapes, level_start_index, reference_points, offsets, logits, n_levels, n_points,
-                  shapes_host=None, pos_offsets=None, pos_logits=None, head_stride=0):
+                  shapes_host=None, pos_offsets=None, pos_logits=None, head_stride=0, value_head_major=False):
     from oracle.msda import msda_forward_torch
+    if value_head_major:
+        value = value.permute(1, 2, 0, 3).contiguous()
     N, S, M, D = value.shape
     Lq = reference_points.shape[1]
     L, P = n_levels, n_points

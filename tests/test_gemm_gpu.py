@@ -146,3 +146,18 @@ def test_tall_problems_persistent_tiles_vs_fp64(M, N, K):
         if cfg == -1:
             ref = got
     assert torch.equal(Fn.gemm_nt(a, w, bias, relu=True), ref)          # and the same bits again
+
+
+def test_head_major_output():
+    """dvis_gemm_nt_hm: C written as (N / d, M, d) — the head-major value layout of MSDeformAttn — equals the row-major
+    result re-laid, bit for bit (same tiles, same summation order; only the store address differs), small and tall."""
+    from dvis_plus_amd import functions as Fn
+    g = torch.Generator().manual_seed(3)
+    for M in (300, 70001):
+        a = torch.randn(M, 256, generator=g).to(DEV)
+        w = torch.randn(256, 256, generator=g).to(DEV)
+        b = torch.randn(256, generator=g).to(DEV)
+        plain = Fn.gemm_nt(a, w, b)
+        hm = Fn.gemm_nt(a, w, b, head_major=32)
+        assert hm.shape == (8, M, 32)
+        assert torch.equal(hm, plain.view(M, 8, 32).permute(1, 0, 2))

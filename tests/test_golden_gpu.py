@@ -19,14 +19,15 @@ def _dev(d):
     return {k: v.to(DEV) for k, v in d.items()}
 
 
-@pytest.mark.parametrize("slots", [False, True])
-def test_pixel_decoder_vs_reference_outputs(slots, monkeypatch):
+@pytest.mark.parametrize("slots,hm", [(False, False), (True, False), (False, True), (True, True)])
+def test_pixel_decoder_vs_reference_outputs(slots, hm, monkeypatch):
     """slots: the fused offsets | logits projection with its rows permuted into per-head slots (dvis_msda_fused_forward_slots:
     a (query, head) pair reads one contiguous run of its projection row) — same results as the reference's row order."""
     from dvis_plus_amd import pixel_decoder as PD
     from dvis_plus_amd.pixel_decoder import MSDeformAttnPixelDecoder
     from dvis_plus_amd.registry import ShapeSpec
     monkeypatch.setattr(PD, "_MSDA_SLOTS", slots)
+    monkeypatch.setattr(PD, "_MSDA_HM", hm)        # value projection written head-major by the own GEMM, gathered from there
     g = Golden("g7_pixel_decoder_d32")
     chans = g.meta["cfg"]["chans"]
     strides = dict(res2=4, res3=8, res4=16, res5=32)
