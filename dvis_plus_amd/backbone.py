@@ -58,7 +58,14 @@ class ConvBN(nn.Conv2d):
         w, b = self.folded()
         if self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0):
             return Fn.conv1x1_bias_act(x, w, b, res, relu)
+        if self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) and res is None and x.is_cuda \
+                and not key_is_channels_last(w):
+            return Fn.conv3x3_bias_act(x, w, b, relu)            # own Winograd kernel where the shape is served
         return Fn.bias_act_(F.conv2d(x, w, None, self.stride, self.padding), b, res, relu)
+
+
+def key_is_channels_last(w):
+    return w.dim() == 4 and not w.is_contiguous() and w.is_contiguous(memory_format=torch.channels_last)
 
 
 class BasicStem(nn.Module):

@@ -94,3 +94,37 @@ class ClipShard:
                     dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
                                    group=self.group)
         return tensors
+
+
+class EmulatedShard(ClipShard):
+    """Measuring aid (tools/rank_emulation.py), not a product path: ONE process does exactly the work of rank `rank` of a
+    `world`-rank job — its block of every clip's frames, the same packing, buffers and kernels — with every collective
+    replaced by a device-local stand-in of the same size: the other ranks' slots of an all-gather are filled with copies of
+    this rank's slot, an all-reduce leaves the tensor as it is.  The per-rank time of a schedule can so be measured on a
+    1-GPU box; what it leaves out is the collective itself (RCCL latency + 15 - 30 MB over xGMI per clip) and the skew
+    between ranks.  The outputs are NOT those of the real job (the other frames' queries are made up)."""
+
+    def __init__(self, world, rank=0):
+        self.group, self.world, self.rank, self.force = None, int(world), int(rank), False
+
+    def all_gather_frames(self, parts, T, per=None, async_op=False, shift=0):
+        per = per or self.frames_per_rank(T)
+        widths = [p.shape[-1] for p in parts]
+        Q = parts[0].shape[1]
+        packed = torch.zeros((per, Q, sum(widths)), dtype=parts[0].dtype, device=parts[0].device)
+        t_local = parts[0].shape[0]
+        if t_local:
+            packed[:t_local] = torch.cat(parts, dim=-1)
+            packed[t_local:] = packed[:1]                                   # (a short block: made-up but finite rows)
+        gathered = packed.unsqueeze(0).expand(self.world, -1, -1, -1).reshape(self.world * per, Q, -1).contiguous()[:T]
+        out = list(gathered.split(widths, dim=-1))
+        return (out, None) if async_op else out
+
+    def all_gather_rows(self, row):
+        return row.unsqueeze(0).expand(self.world, -1).contiguous()
+
+    def all_reduce_sum(self, x):
+        return x
+
+    def broadcast_from_rank0(self, tensors):
+        return tensors

@@ -1,0 +1,370 @@
+// 3x3 / stride 1 / pad 1 convolution, NCHW fp32, as Winograd F(2x2, 3x3) on the fp32 matrix cores (round 3).
+//
+// What it replaces: the library's kernels for the 3x3 convolutions of the path — the pixel decoder's FPN output
+// convolution (mask2former/modeling/pixel_decoder/msdeformattn.py:262-270 `output_conv`, 256 -> 256 at stride 4: 2.08 TFLOP per
+// 30-frame clip, 16.8 ms in MIOpen's implicit-GEMM kernel = the fp32-MFMA peak for 9 multiplies per output) and conv2 of
+// the R50 bottlenecks (detectron2 BottleneckBlock; MIOpen runs those as a VALU Winograd).  F(2x2, 3x3)
+// needs 4 multiplies per output instead of 9 and the 16 transform-domain products are plain GEMMs
+//     M_xi[k][tile] = sum_c U_xi[k][c] V_xi[c][tile],   xi = 0..15,
+// which v_mfma_f32_16x16x4_f32 does exactly in fp32: 2.25x fewer matrix-core cycles than any direct formulation.
+//
+// Workgroup = 64 consecutive 2x2-output tiles (in (n, ty, tx) order — no spatial blocking, so no padding waste at
+// 23 x 40) x 64 output channels, 8 waves.  Wave w owns the 16 output channels kb16 = w & 3, ALL 64 tiles and HALF of the
+// transform positions (xi in [8 half, 8 half + 8), half = w >> 2): 8 x 4 accumulator tiles = 128 VGPRs, two waves per SIMD.
+//   * U (the transformed weights, packed once by dvis_conv3x3_winograd_pack) goes from L2 straight into the MFMA A layout:
+//     each wave reads only ITS channels and positions, 4 KB per 8-channel stage in four fully coalesced 16-byte loads — no
+//     LDS, no redundancy between the waves.
+//   * V (the transformed input) is made in the workgroup: wave w loads the 4x4 input patches of channel w of the stage for
+//     the 64 tiles (lane = tile; out-of-image elements carry an out-of-range buffer offset and read 0: exact zero padding,
+//     no branches), applies B^T d B (32 adds) and writes the 16 positions to LDS; the B operands of 4 MFMAs are one
+//     ds_read_b128 (a row keeps tile t at 4 (t & 15) + (t >> 4); rows are padded to 80 floats so that the 4 lane groups of a
+//     wave start in 4 different bank quarters).
+//   * LDS is double-buffered (2 x 40 KB): one barrier per stage of 8 input channels = per 64 MFMAs of a wave.  The waves
+//     with half == 1 transform BEFORE their MFMAs, the others after: the two waves of a SIMD are never both in the
+//     VALU / LDS-write phase, so the matrix pipe always has a wave feeding it (8 waves in lock-step behind a barrier that
+//     use the units one after the other was the failure of round 1's msda_forward_pipe).
+//   * Output transform A^T M A is linear, so each half reduces ITS 8 positions to a partial 2x2 block in registers and the
+//     halves exchange only those (64 KB through the LDS that the stages no longer need) — not the 16 M tiles.
+// Accumulation order over input channels is fixed (stages in order, no split-K, no atomics): bit-reproducible.
+#include "dvis_common.h"
+
+#include <type_traits>
+
+namespace {
+
+constexpr int kTiles = 64;                 // tiles per workgroup
+constexpr int kKw = 64;                    // output channels per workgroup
+constexpr int kCc = 8;                     // input channels per stage (two MFMA k-steps)
+constexpr int kRow = 80;                   // floats per channel row of V in LDS
+constexpr int kPos = kCc * kRow;           // floats per transform position in a stage
+constexpr int kStage = 16 * kPos;          // floats per stage (40 KB)
+constexpr unsigned kOOB = 0x80000000u;
+
+struct WinoArgs {
+  const float *x, *uf, *bias;
+  float *y;
+  int N, C, K, H, W, TY, TX, relu, nsp;
+  long long tiles;
+};
+
+__global__ __launch_bounds__(512, 2) void winograd_f2x3_kernel(const WinoArgs a) {
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // (provably wave-uniform: scalar offsets, no waterfall loops)
+  const int j = lane & 15, g = lane >> 4;
+  const int kb16 = wv & 3, half = wv >> 2;
+  // blocks that share input tiles (the K / 64 channel blocks of one tile group) run on the SAME XCD, back to back: block
+  // b lands on XCD b % 8, so the tile group takes the low 3 bits and the channel block the next ones.
+  const int KB = a.K / kKw;
+  const int grp = blockIdx.x / (8 * KB), rem = blockIdx.x - grp * 8 * KB;
+  const int kb = rem >> 3, sp = grp * 8 + (rem & 7);
+  if (sp >= a.nsp) return;
+  const long long p0 = (long long)sp * kTiles;
+  const int per_img = a.TY * a.TX;
+  const int n0 = (int)(p0 / per_img);   // per_img >= 64: the workgroup's tiles lie in images n0 and n0 + 1
+  const long long plane = (long long)a.H * a.W, img = plane * a.C;
+  const int nch = a.C / kCc;
+
+  // ---- transform role: lane = tile, wave = channel of the stage.  Patch element (i, jj) = input (2 ty - 1 + i, 2 tx - 1 + jj):
+  // one byte offset per patch ROW (at column jj = 1, always inside the image; kOOB for a row outside the image or a tile past
+  // the end) and one lane mask per column that can leave the image — 4 VGPRs instead of 16 offsets.
+  unsigned rowbase[4];
+  bool col0, col2, col3;
+  {
+    const long long p = p0 + lane;
+    const bool pv = p < a.tiles;
+    const int pi = pv ? (int)(p - (long long)n0 * per_img) : 0;
+    const int nn = pi / per_img, r = pi - nn * per_img;
+    const int ty = r / a.TX, tx = r - ty * a.TX;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int yy = 2 * ty - 1 + i;
+      const bool ok = pv && yy >= 0 && yy < a.H;
+      rowbase[i] = ok ? (unsigned)(((long long)nn * img + (long long)yy * a.W + 2 * tx) * 4) : kOOB;
+    }
+    col0 = tx > 0, col2 = 2 * tx + 1 < a.W, col3 = 2 * tx + 2 < a.W;
+  }
+  const int n_here = min(2, a.N - n0);
+  const __amdgpu_buffer_rsrc_t rx = dvis_make_rsrc_uniform(a.x + (long long)n0 * img, (unsigned)(n_here * img * 4));
+  const __amdgpu_buffer_rsrc_t ru = dvis_make_rsrc_uniform(a.uf, (unsigned)(16ll * a.K * a.C * 4));
+  const unsigned plane_bytes = (unsigned)(plane * 4);
+  const unsigned u_lane = (unsigned)lane * 16u;
+  const unsigned u_blk = (unsigned)((kb * 4 + kb16) * nch);
+
+  auto load_d = [&](int ch, float (&d)[16]) {
+    const unsigned so = (unsigned)(ch * kCc + wv) * plane_bytes;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // (kOOB - 4 and kOOB + 8 are out of range too: num_records < 2^31)
+      d[4 * i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, col0 ? rowbase[i] - 4u : kOOB, so, 0));
+      d[4 * i + 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, rowbase[i], so, 0));
+      d[4 * i + 2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, col2 ? rowbase[i] + 4u : kOOB, so, 0));
+      d[4 * i + 3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, col3 ? rowbase[i] + 8u : kOOB, so, 0));
+    }
+  };
+  auto load_u = [&](int ch, dvis_f4 (&u)[4]) {
+    const unsigned so = ((u_blk + (unsigned)ch) * 2u + (unsigned)half) * 4096u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      u[q] = __builtin_bit_cast(dvis_f4, __builtin_amdgcn_raw_buffer_load_b128(ru, u_lane + 1024u * q, so, 0));
+  };
+  // V = B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1], position xi = 4 i + jj, to row (xi, channel wv)
+  auto transform_store = [&](const float (&d)[16], float *stage) {
+    float *vw = stage + wv * kRow + (lane & 15) * 4 + (lane >> 4);   // tile t at 4 (t & 15) + (t >> 4): a reader's 4 tile blocks are adjacent
+    float t[16];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      t[jj] = d[jj] - d[8 + jj];
+      t[4 + jj] = d[4 + jj] + d[8 + jj];
+      t[8 + jj] = d[8 + jj] - d[4 + jj];
+      t[12 + jj] = d[4 + jj] - d[12 + jj];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      vw[(4 * i) * kPos] = t[4 * i] - t[4 * i + 2];
+      vw[(4 * i + 1) * kPos] = t[4 * i + 1] + t[4 * i + 2];
+      vw[(4 * i + 2) * kPos] = t[4 * i + 2] - t[4 * i + 1];
+      vw[(4 * i + 3) * kPos] = t[4 * i + 1] - t[4 * i + 3];
+    }
+  };
+
+  dvis_f4 acc[8][4];
+#pragma unroll
+  for (int x8 = 0; x8 < 8; ++x8)
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) acc[x8][tb] = dvis_f4{0.f, 0.f, 0.f, 0.f};
+  // u[q] = {U(xi0, s0), U(xi0, s1), U(xi0 + 1, s0), U(xi0 + 1, s1)}, xi0 = 8 half + 2 q; k-step s = channels 4 s + g
+  // B operands: one ds_read_b128 per (position, k-step) = the lane's tile in each of the 4 tile blocks; the reads of position
+  // x8 + 1 are issued before the 8 MFMAs of position x8 (hipcc otherwise reads each operand right in front of its MFMA and
+  // waits for it: lgkmcnt(0) every second instruction)
+  auto contract = [&](const float *stage, const dvis_f4 (&u)[4]) {
+    const dvis_f4 *vr = reinterpret_cast<const dvis_f4 *>(stage + (half * 8) * kPos + g * kRow + 4 * j);
+    dvis_f4 b[2][2];
+    b[0][0] = vr[0];
+    b[0][1] = vr[(4 * kRow) / 4];
+#pragma unroll
+    for (int x8 = 0; x8 < 8; ++x8) {
+      if (x8 + 1 < 8) {
+        b[(x8 + 1) & 1][0] = vr[((x8 + 1) * kPos) / 4];
+        b[(x8 + 1) & 1][1] = vr[((x8 + 1) * kPos + 4 * kRow) / 4];
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const float av = u[x8 >> 1][(x8 & 1) * 2 + s];
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+          acc[x8][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[x8 & 1][s][tb], acc[x8][tb], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  float *s0 = lds, *s1 = lds + kStage;
+  float d[16];
+  dvis_f4 ua[4], ub[4];
+  load_u(0, ua);
+  load_d(0, d);
+  transform_store(d, s0);
+  // nch is even (C % 16 == 0): stages in pairs, even ones in s0 / ua, odd ones in s1 / ub.  One pair is straight-line code
+  // for a given wave role: with the role, or a "more stages?" test, as run-time branches inside, the join points make hipcc's
+  // s_waitcnt insertion assume the fewest loads in flight on any path, and the waves that had just requested the next
+  // patches waited for them in front of their MFMAs (vmcnt(3) with 16 younger loads outstanding).  So the last pair is NOT
+  // special: it re-requests the last stage (clamped index) and transforms it into a buffer nobody reads any more — 3 % more
+  // loads at C = 256 — and a peeled copy of the pair in front of the epilogue made hipcc spill 300-600 registers.
+  auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
+  auto pair = [&](auto first_c, int ch) {
+    constexpr bool kFirst = decltype(first_c)::value;
+    const int c2 = min(ch + 2, nch - 1), c3 = min(ch + 3, nch - 1);
+    __syncthreads();   // s0 holds stage ch; nobody reads s1 (stage ch - 1) any more
+    if constexpr (kFirst) {
+      transform_store(d, s1);
+      fence();
+      load_d(c2, d);
+      fence();
+    }
+    contract(s0, ua);
+    load_u(c2, ua);
+    fence();
+    if constexpr (!kFirst) {
+      transform_store(d, s1);
+      fence();
+      load_d(c2, d);
+      fence();
+    }
+    __syncthreads();   // s1 holds stage ch + 1; nobody reads s0 any more
+    if constexpr (kFirst) {
+      transform_store(d, s0);
+      fence();
+      load_d(c3, d);
+      fence();
+    }
+    contract(s1, ub);
+    load_u(c3, ub);
+    fence();
+    if constexpr (!kFirst) {
+      transform_store(d, s0);
+      fence();
+      load_d(c3, d);
+      fence();
+    }
+  };
+  // (the loads of stage 1 are requested in the order the pair's back edge leaves them in: the s_waitcnt counts at the loop
+  // head are the merge of both ways in)
+  if (half) {   // wave-uniform
+    load_d(1, d);
+    fence();
+    load_u(1, ub);
+    fence();
+#pragma unroll 1
+    for (int ch = 0; ch < nch; ch += 2) pair(std::true_type{}, ch);
+  } else {
+    load_u(1, ub);
+    fence();
+    load_d(1, d);
+    fence();
+#pragma unroll 1
+    for (int ch = 0; ch < nch; ch += 2) pair(std::false_type{}, ch);
+  }
+
+  // ---- output transform.  Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1].  Rows first, over THIS half's two rows of M (half 0:
+  // i = 0, 1; half 1: i = 2, 3), then columns: a partial 2x2 block yp[a][b] per (channel row r, tile block tb).
+  float yp[4][4][4];   // [tb][r][2 a + b]
+#pragma unroll
+  for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float R0[4], R1[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const float m_lo = acc[jj][tb][r], m_hi = acc[4 + jj][tb][r];
+        R0[jj] = half ? m_lo : m_lo + m_hi;
+        R1[jj] = half ? -m_lo - m_hi : m_hi;
+      }
+      yp[tb][r][0] = R0[0] + R0[1] + R0[2];
+      yp[tb][r][1] = R0[1] - R0[2] - R0[3];
+      yp[tb][r][2] = R1[0] + R1[1] + R1[2];
+      yp[tb][r][3] = R1[1] - R1[2] - R1[3];
+    }
+  // half h stores tile blocks 2 h, 2 h + 1; the partials of the other two go to the partner wave through LDS
+  __syncthreads();   // the stages are dead
+  {
+    float *ex = lds + (((1 - half) * 4 + kb16) * 2) * 16 * 64 + lane;   // [dst half][kb16][tb & 1][r][ab][lane]
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) ex[((t2 * 4 + r) * 4 + ab) * 64] = half ? yp[t2][r][ab] : yp[2 + t2][r][ab];
+  }
+  __syncthreads();
+  const float *ex = lds + ((half * 4 + kb16) * 2) * 16 * 64 + lane;
+  const int k0 = kb * kKw + kb16 * 16 + 4 * g;
+  const bool w_even = (a.W & 1) == 0;
+#pragma unroll
+  for (int t2 = 0; t2 < 2; ++t2) {
+    const int tb = 2 * half + t2;
+    const long long p = p0 + tb * 16 + j;
+    if (p >= a.tiles) continue;
+    const int n = (int)(p / per_img), rr = (int)(p - (long long)n * per_img);
+    const int ty = rr / a.TX, tx = rr - ty * a.TX;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float o[4];
+#pragma unroll
+      for (int ab = 0; ab < 4; ++ab) {
+        const float mine = half ? yp[2 + t2][r][ab] : yp[t2][r][ab];
+        const float other = ex[((t2 * 4 + r) * 4 + ab) * 64];
+        float v = half ? other + mine : mine + other;   // (half 0's partial) + (half 1's partial)
+        if (a.bias) v += a.bias[k0 + r];
+        o[ab] = a.relu ? fmaxf(v, 0.f) : v;
+      }
+      float *yrow = a.y + (((long long)n * a.K + k0 + r) * a.H + 2 * ty) * a.W + 2 * tx;
+      const bool x1 = 2 * tx + 1 < a.W, y1 = 2 * ty + 1 < a.H;
+      if (w_even) {
+        *reinterpret_cast<float2 *>(yrow) = make_float2(o[0], o[1]);
+        if (y1) *reinterpret_cast<float2 *>(yrow + a.W) = make_float2(o[2], o[3]);
+      } else {
+        yrow[0] = o[0];
+        if (x1) yrow[1] = o[1];
+        if (y1) {
+          yrow[a.W] = o[2];
+          if (x1) yrow[a.W + 1] = o[3];
+        }
+      }
+    }
+  }
+}
+
+// U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], packed for the kernel's A-operand loads:
+//   uf[kb16][stage][half][q][lane = 16 g + i][e = 2 xo + s] = U_xi[k = 16 kb16 + i][c = 8 stage + 4 s + g],  xi = 8 half + 2 q + xo
+__global__ void winograd_pack_kernel(const float *__restrict__ w, float *__restrict__ uf, int K, int C) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= K * C) return;
+  const int k = idx / C, c = idx - k * C;
+  double gk[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) gk[i][jj] = (double)w[(long long)idx * 9 + i * 3 + jj];
+  double t[4][3];
+#pragma unroll
+  for (int jj = 0; jj < 3; ++jj) {
+    t[0][jj] = gk[0][jj];
+    t[1][jj] = 0.5 * (gk[0][jj] + gk[1][jj] + gk[2][jj]);
+    t[2][jj] = 0.5 * (gk[0][jj] - gk[1][jj] + gk[2][jj]);
+    t[3][jj] = gk[2][jj];
+  }
+  const int kb16 = k >> 4, i16 = k & 15, st = c >> 3, s = (c >> 2) & 1, g = c & 3, nch = C / kCc;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double u4[4] = {t[i][0], 0.5 * (t[i][0] + t[i][1] + t[i][2]), 0.5 * (t[i][0] - t[i][1] + t[i][2]), t[i][2]};
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int xi = 4 * i + jj, half = xi >> 3, q = (xi >> 1) & 3, xo = xi & 1;
+      const long long o = ((((long long)(kb16 * nch + st) * 2 + half) * 4 + q) * 64 + 16 * g + i16) * 4 + 2 * xo + s;
+      uf[o] = (float)u4[jj];
+    }
+  }
+}
+
+DvisLdsOptIn g_opted;
+
+}  // namespace
+
+DVIS_EXPORT int dvis_conv3x3_winograd_supported(int C, int K, int H, int W) {
+  if (C <= 0 || K <= 0 || H <= 0 || W <= 0 || C % 16 != 0 || K % kKw != 0) return 0;
+  const long long tiles_per_img = (long long)((H + 1) / 2) * ((W + 1) / 2);
+  if (tiles_per_img < kTiles) return 0;
+  if (2ll * C * H * W * 4 >= (1ll << 31) || 16ll * K * C * 4 >= (1ll << 31)) return 0;
+  return 1;
+}
+
+DVIS_EXPORT int dvis_conv3x3_winograd_pack(const float *w, float *uf, int K, int C, void *stream) {
+  DVIS_REQUIRE(w && uf && K > 0 && C > 0 && C % 16 == 0 && K % kKw == 0, "conv3x3_winograd_pack: K %% 64 == 0 and C %% 16 == 0");
+  const int n = K * C;
+  hipLaunchKernelGGL(winograd_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, uf, K, C);
+  return dvis_check_launch("dvis_conv3x3_winograd_pack");
+}
+
+DVIS_EXPORT int dvis_conv3x3_winograd(const float *x, const float *uf, const float *bias, float *y, int N, int C, int K, int H,
+                                      int W, int relu, void *stream) {
+  DVIS_REQUIRE(N >= 0, "conv3x3_winograd: bad batch");
+  if (N == 0) return DVIS_OK;
+  DVIS_REQUIRE(x && uf && y, "conv3x3_winograd: null pointer");
+  DVIS_REQUIRE(dvis_conv3x3_winograd_supported(C, K, H, W),
+               "conv3x3_winograd: unsupported shape C=%d K=%d H=%d W=%d (dvis_conv3x3_winograd_supported)", C, K, H, W);
+  DVIS_REQUIRE((((uintptr_t)x | (uintptr_t)uf | (uintptr_t)y) & 15) == 0, "conv3x3_winograd: 16-byte aligned tensors");
+  WinoArgs a;
+  a.x = x, a.uf = uf, a.bias = bias, a.y = y;
+  a.N = N, a.C = C, a.K = K, a.H = H, a.W = W, a.relu = relu;
+  a.TY = (H + 1) / 2, a.TX = (W + 1) / 2;
+  a.tiles = (long long)N * a.TY * a.TX;
+  const long long nsp = (a.tiles + kTiles - 1) / kTiles;
+  DVIS_REQUIRE(nsp * (K / kKw) + 8 * (K / kKw) < (1ll << 31), "conv3x3_winograd: grid too large");
+  a.nsp = (int)nsp;
+  const size_t lds_bytes = 2 * kStage * sizeof(float);
+  const int rc = dvis_lds_opt_in((const void *)winograd_f2x3_kernel, lds_bytes, &g_opted, "dvis_conv3x3_winograd");
+  if (rc != DVIS_OK) return rc;
+  const unsigned grid = (unsigned)(((nsp + 7) / 8) * 8 * (K / kKw));
+  hipLaunchKernelGGL(winograd_f2x3_kernel, dim3(grid), dim3(512), lds_bytes, (hipStream_t)stream, a);
+  return dvis_check_launch("dvis_conv3x3_winograd");
+}

@@ -671,6 +671,52 @@ def conv1x1_bias_act(x, weight, bias=None, res=None, relu=False):
     return bias_act_(conv1x1(x, weight), None if bias is None else bias.detach(), res, relu)
 
 
+WINOGRAD_DEFAULT = os.environ.get("DVIS_WINOGRAD", "1") != "0"
+_WINOGRAD_PACKED = {}     # id(weight) -> ((version, data_ptr, device), packed): transformed weights, made once per weight
+
+
+def _winograd_weights(weight):
+    key = (weight._version, weight.data_ptr(), weight.device)
+    ent = _WINOGRAD_PACKED.get(id(weight))
+    if ent is None or ent[0] != key:
+        K, C = weight.shape[:2]
+        w = weight.detach().contiguous()
+        uf = ent[1] if ent is not None and ent[1].device == w.device and ent[1].numel() == 16 * K * C else \
+            torch.empty(16 * K * C, dtype=torch.float32, device=w.device)       # refreshed in place (captured graphs)
+        with torch.cuda.device(w.device):
+            native.check(native.lib().dvis_conv3x3_winograd_pack(native.dev_ptr(w, "weight"), native.dev_ptr(uf, "uf"), K, C,
+                                                                 native.stream_ptr(w.device)), "dvis_conv3x3_winograd_pack")
+        _WINOGRAD_PACKED[id(weight)] = ent = (key, uf, weight)     # (holds the weight: id() stays unique)
+    return ent[1]
+
+
+def conv3x3_bias_act(x, weight, bias=None, relu=False, winograd=None):
+    """relu?(conv2d(x, weight (K, C, 3, 3), stride 1, padding 1) + bias[k]) on NCHW.  Shapes dvis_conv3x3_winograd serves run
+    as ONE own kernel — Winograd F(2x2, 3x3) on the fp32 matrix cores, bias / ReLU in its epilogue (csrc/winograd_conv.hip:
+    the FPN output convolution and conv2 of the R50 bottlenecks); other shapes, and `winograd=False` / DVIS_WINOGRAD=0, are
+    the library convolution followed by the in-place ``bias_act_`` pass."""
+    use = WINOGRAD_DEFAULT if winograd is None else winograd
+    if use and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and weight.dtype == torch.float32 \
+            and tuple(weight.shape[2:]) == (3, 3) and not torch.is_grad_enabled():
+        N, C, H, W = x.shape
+        K = weight.shape[0]
+        if weight.shape[1] == C and native.lib().dvis_conv3x3_winograd_supported(C, K, H, W):
+            x = x if x.is_contiguous() else x.contiguous()
+            uf = _winograd_weights(weight)
+            out = torch.empty((N, K, H, W), dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device):
+                rc = native.lib().dvis_conv3x3_winograd(
+                    native.dev_ptr(x, "x"), native.dev_ptr(uf, "uf"),
+                    None if bias is None else native.dev_ptr(bias.detach(), "bias"), native.dev_ptr(out, "out"), N, C, K, H, W,
+                    1 if relu else 0, native.stream_ptr(x.device))
+            native.check(rc, "dvis_conv3x3_winograd")
+            return out
+    y = torch.nn.functional.conv2d(x, weight, None, 1, 1)
+    if bias is None and not relu:
+        return y
+    return bias_act_(y, None if bias is None else bias.detach(), None, relu)
+
+
 def bias_act_(x, bias=None, res=None, relu=True):
     """In place: x = relu?(x + bias[c] + res) on an NCHW float32 tensor — one pass instead of torch's three kernels
     (conv bias add, residual add, ReLU).  Non-GPU / odd shapes use the torch ops."""

@@ -24,7 +24,7 @@ from torch import nn
 
 from . import d2
 from . import postprocess as PP
-from .clip_shard import ClipShard
+from .clip_shard import ClipShard, EmulatedShard
 from .d2 import configurable
 from .registry import META_ARCH_REGISTRY, SEM_SEG_HEADS_REGISTRY
 
@@ -189,6 +189,8 @@ class _VideoBase(nn.Module):
     @property
     def clip_shard(self):
         """Frame sharding follows the default process group of the moment (none -> single GPU)."""
+        if isinstance(self._clip_shard, EmulatedShard):        # tools/rank_emulation.py
+            return self._clip_shard
         world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
         if self._clip_shard is None or self._clip_shard.world != world:
             self._clip_shard = ClipShard()

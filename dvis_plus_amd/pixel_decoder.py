@@ -348,6 +348,9 @@ class ConvNorm(nn.Conv2d):
     def conv(self, x):
         if self.kernel_size == (1, 1) and self.stride == (1, 1) and self.groups == 1 and self.padding == (0, 0):
             return Fn.conv1x1(x, self.weight, self.bias)
+        if self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) and self.dilation == (1, 1) \
+                and self.groups == 1 and x.is_cuda and not torch.is_grad_enabled():
+            return Fn.conv3x3_bias_act(x, self.weight, self.bias)   # own Winograd kernel where the shape is served
         return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
 
     def conv_and_affine(self, x):

@@ -26,6 +26,9 @@
  *   dvis_nchw_to_tokens      <- src.flatten(2).transpose(1, 2) + torch.cat over levels, msdeformattn.py:64-79
  *   dvis_bias_act            <- FrozenBN shift + shortcut add + ReLU after each backbone convolution (detectron2 BottleneckBlock)
  *   dvis_conv1x1_bias_act    <- 1x1 convolution + that epilogue in one pass (conv1 / conv3 / stride-1 shortcut of the bottleneck)
+ *   dvis_conv3x3_winograd    <- 3x3 / stride 1 / pad 1 convolution (+ bias + ReLU): the FPN output convolution of the pixel decoder,
+ *                               mask2former/modeling/pixel_decoder/msdeformattn.py:262-270 (built), :343-349 (applied), and conv2 of
+ *                               the R50 bottlenecks (detectron2 BottleneckBlock)
  *   dvis_bias_relu_maxpool   <- FrozenBN shift + ReLU + max_pool2d(3, stride 2, padding 1) of the ResNet stem (detectron2 BasicStem)
  *   dvis_upsample_add        <- `cur_fpn + F.interpolate(out[-1], size=..., mode="bilinear")`, msdeformattn.py:347
  *   dvis_group_norm_affine / dvis_scale_shift_act / dvis_upsample_add_affine
@@ -222,6 +225,20 @@ int dvis_nchw_to_tokens_affine(const float *x, const float *scale, const float *
 int dvis_conv1x1_supported(int K, int M, int64_t HW);
 int dvis_conv1x1_bias_act(const float *x, const float *w, const float *bias, const float *res, float *out,
                           int N, int K, int M, int64_t HW, int relu, void *stream);
+
+/*
+ * y (N, K, H, W) = relu?(conv2d(x (N, C, H, W), w (K, C, 3, 3), stride 1, padding 1) + bias[k]) as Winograd F(2x2, 3x3) on the fp32
+ * matrix cores: 4 multiplies per output instead of 9, accumulated in a fixed order (bit-reproducible).  `uf` = the transformed
+ * weights (16 * K * C floats), written once per weight by dvis_conv3x3_winograd_pack(w, uf, K, C).  bias (K) or NULL.  fp32, NCHW
+ * contiguous, 16-byte aligned.  dvis_conv3x3_winograd_supported(C, K, H, W) != 0 tells whether the shape is served (C % 16 == 0,
+ * K % 64 == 0, at least 64 2x2 tiles per image, 2 images < 2 GiB); other shapes return DVIS_E_ARG — the caller keeps the library
+ * convolution for them.  Rounding differs from a direct convolution by the usual F(2x2, 3x3) factor (a few fp32 ulps of the
+ * accumulated magnitude; tests/test_winograd_gpu.py bounds it against fp64).
+ */
+int dvis_conv3x3_winograd_supported(int C, int K, int H, int W);
+int dvis_conv3x3_winograd_pack(const float *w, float *uf, int K, int C, void *stream);
+int dvis_conv3x3_winograd(const float *x, const float *uf, const float *bias, float *y, int N, int C, int K, int H, int W,
+                          int relu, void *stream);
 
 /*
  * In place on `planes` = N*C contiguous planes of HW floats (NCHW): x = relu?(x + bias[c] + res).  bias (C,) or NULL,

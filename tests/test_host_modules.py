@@ -763,3 +763,29 @@ def test_tracker_batch_advances_two_clips_together_same_results(oracle_ops):
     for g, w in zip(got, want):
         assert g["segments_infos"] == w["segments_infos"] and g["pred_ids"] == w["pred_ids"]
         assert torch.equal(g["pred_masks"], w["pred_masks"])
+
+
+@pytest.mark.parametrize("owner_rounds", [False, True])
+def test_emulated_rank_does_one_ranks_work(oracle_ops, owner_rounds):
+    """clip_shard.EmulatedShard (tools/rank_emulation.py): one process, the work of rank 0 of 4 — its block of every clip's
+    frames through the segmenter, gathered buffers of the real size, the tracker over all T frames (replicated) or over
+    the clip it owns (owner rounds), outputs for its own frames only."""
+    from dvis_plus_amd.clip_shard import EmulatedShard
+    m = _tiny_model("offline", "vps")
+    m.owner_rounds = owner_rounds
+    m._clip_shard = EmulatedShard(4)
+    seg_frames, trk_frames = [], []
+    seg, trk = m.segment, m.tracker.forward
+    m.segment = lambda images: (seg_frames.append(len(images)), seg(images))[1]
+    m.tracker.forward = lambda fe, *a, **k: (trk_frames.append(tuple(fe.shape)), trk(fe, *a, **k))[1]
+    clips = [{"image": _tiny_clip(6, seed=s), "height": 70, "width": 100} for s in range(4)]
+    outs = list(m.stream(clips))
+    assert len(outs) == 4
+    if owner_rounds:     # one merged call for the round; the rotation hands rank 0 blocks 0, 3, 2, 1 of (2, 2, 2, 0) frames
+        assert seg_frames == [6] and len(trk_frames) == 1 and trk_frames[0][2] == 6
+        assert sorted(len(o["frame_ids"]) for o in outs) == [0, 2, 2, 2]
+    else:                # four clips, 2 of 6 frames each; the tracker sees all 6 frames of every clip
+        assert seg_frames == [2, 2, 2, 2] and [t[2] for t in trk_frames] == [6, 6, 6, 6]
+        assert all(o["frame_ids"] == [0, 1] and o["pred_masks"].shape[0] == 2 for o in outs)
+    m._clip_shard = None
+    assert m.clip_shard.world == 1

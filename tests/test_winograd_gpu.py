@@ -1,0 +1,84 @@
+"""dvis_conv3x3_winograd (csrc/winograd_conv.hip) against the fp64 convolution — the 3x3 convolutions of the path: the pixel
+decoder's FPN output convolution (msdeformattn.py:262-270, :343-349) and conv2 of the R50 bottlenecks."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(N, C, K, H, W, bias, relu, seed=0, scale=1.0):
+    from dvis_plus_amd import functions as Fn
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.randn(N, C, H, W, device="cuda", generator=g) * scale
+    w = torch.randn(K, C, 3, 3, device="cuda", generator=g) * (2.0 / (9 * C)) ** 0.5
+    b = torch.randn(K, device="cuda", generator=g) if bias else None
+    got = Fn.conv3x3_bias_act(x, w, b, relu, winograd=True)
+    want = F.conv2d(x.double(), w.double(), None if b is None else b.double(), 1, 1)
+    want = want.relu() if relu else want
+    lib = F.conv2d(x, w, b, 1, 1)
+    lib = lib.relu() if relu else lib
+    mag = float(F.conv2d(x.double().abs(), w.double().abs(), None, 1, 1).max())     # accumulated magnitude
+    return float((got.double() - want).abs().max()), float((lib.double() - want).abs().max()), mag, got
+
+
+@pytest.mark.parametrize("N,C,K,H,W", [
+    (2, 64, 64, 32, 48),          # one channel block, even sizes
+    (3, 64, 128, 23, 40),         # odd height (stride-32 map of a 736 x 1280 frame): half-used last tile row
+    (2, 128, 64, 17, 33),         # odd width: scalar stores, column masks on both sides
+    (5, 16, 64, 16, 18),          # 72 tiles per image: workgroups straddle two images; a single pair of stages
+    (1, 256, 256, 46, 80),        # the stride-16 map
+])
+@pytest.mark.parametrize("bias,relu", [(False, False), (True, True)])
+def test_winograd_equals_fp64_convolution(N, C, K, H, W, bias, relu):
+    from dvis_plus_amd import native
+    assert native.lib().dvis_conv3x3_winograd_supported(C, K, H, W)
+    err, lib_err, mag, _ = _case(N, C, K, H, W, bias, relu)
+    # F(2x2, 3x3) in fp32: a few ulps of the accumulated magnitude (the direct library kernel sits at ~1 ulp of it)
+    assert err <= 8 * 2.0 ** -24 * mag, (err, lib_err, mag)
+
+
+def test_winograd_fpn_output_convolution_full_size():
+    """256 -> 256 at 184 x 320 (stride 4 of a 720p frame), 4 frames: error against fp64 next to the library's."""
+    err, lib_err, mag, _ = _case(4, 256, 256, 184, 320, False, False, seed=3)
+    assert err <= 8 * 2.0 ** -24 * mag, (err, lib_err, mag)
+    print(f"winograd max err {err:.3e}, library {lib_err:.3e}, accumulated magnitude {mag:.1f}")
+
+
+def test_winograd_is_bit_reproducible_and_batch_independent():
+    """Fixed accumulation order: the same bits run to run, and a frame's result does not depend on its batch mates."""
+    from dvis_plus_amd import functions as Fn
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(6, 128, 46, 80, device="cuda", generator=g)
+    w = torch.randn(128, 128, 3, 3, device="cuda", generator=g) * 0.03
+    a = Fn.conv3x3_bias_act(x, w, None, False, winograd=True)
+    b = Fn.conv3x3_bias_act(x, w, None, False, winograd=True)
+    assert torch.equal(a, b)
+    c = Fn.conv3x3_bias_act(x[2:5].contiguous(), w, None, False, winograd=True)
+    assert torch.equal(a[2:5], c)
+
+
+def test_winograd_weights_follow_the_parameter():
+    """The packed weights are cached per parameter and refreshed when it changes (in place: captured graphs)."""
+    from dvis_plus_amd import functions as Fn
+    x = torch.randn(1, 64, 16, 16, device="cuda")
+    w = torch.nn.Parameter(torch.randn(64, 64, 3, 3, device="cuda") * 0.05)
+    a = Fn.conv3x3_bias_act(x, w, None, False, winograd=True)
+    with torch.no_grad():
+        w.mul_(2.0)
+    b = Fn.conv3x3_bias_act(x, w, None, False, winograd=True)
+    assert torch.allclose(b, 2 * a, rtol=1e-5, atol=1e-6)
+
+
+def test_winograd_refuses_shapes_it_does_not_serve():
+    from dvis_plus_amd import native
+    lib = native.lib()
+    assert not lib.dvis_conv3x3_winograd_supported(3, 64, 64, 64)        # stem: 3 input channels
+    assert not lib.dvis_conv3x3_winograd_supported(64, 32, 64, 64)       # 32 output channels
+    assert not lib.dvis_conv3x3_winograd_supported(64, 64, 8, 8)         # 16 tiles per image
+    x = torch.zeros(1, 3, 64, 64, device="cuda")
+    uf = torch.zeros(16 * 64 * 3, device="cuda")
+    y = torch.zeros(1, 64, 64, 64, device="cuda")
+    rc = lib.dvis_conv3x3_winograd(native.dev_ptr(x, "x"), native.dev_ptr(uf, "uf"), None, native.dev_ptr(y, "y"), 1, 3, 64, 64, 64,
+                                   0, native.stream_ptr(x.device))
+    assert rc != 0 and "unsupported shape" in lib.dvis_last_error().decode()

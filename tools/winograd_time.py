@@ -1,0 +1,46 @@
+"""Own Winograd F(2x2, 3x3) fp32-MFMA convolution against the library's kernels at the shapes of the path (dev tool, GPU box):
+    python tools/winograd_time.py [frames]"""
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dvis_plus_amd import functions as Fn  # noqa: E402
+
+dev = torch.device("cuda", 0)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+
+
+def timeit(fn, iters=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+CASES = [("FPN output conv 256->256 @184x320", 256, 256, 184, 320),
+         ("res2 conv2 64->64 @184x320", 64, 64, 184, 320),
+         ("res3 conv2 128->128 @92x160", 128, 128, 92, 160),
+         ("res4 conv2 256->256 @46x80", 256, 256, 46, 80),
+         ("res5 conv2 512->512 @23x40", 512, 512, 23, 40)]
+print(f"{N} frames; direct FLOPs = 2*9*C*K*H*W*N, Winograd F(2x2,3x3) multiplies = /2.25; MFMA peak 157.3 TF (137.6 at 2.1 GHz)")
+for name, C, K, H, W in CASES:
+    x = torch.randn(N, C, H, W, device=dev)
+    w = torch.randn(K, C, 3, 3, device=dev) * 0.02
+    b = torch.randn(K, device=dev)
+    t_lib = timeit(lambda: Fn.bias_act_(F.conv2d(x, w, None, 1, 1), b, None, True))
+    t_own = timeit(lambda: Fn.conv3x3_bias_act(x, w, b, True, winograd=True))
+    fl = 2.0 * 9 * C * K * H * W * N
+    err = float((Fn.conv3x3_bias_act(x, w, b, True, winograd=True) - Fn.bias_act_(F.conv2d(x, w, None, 1, 1), b, None, True)).abs().max())
+    print(f"{name:36s} library + bias_act {t_lib:8.1f} us   own {t_own:8.1f} us  ({t_lib / t_own:4.2f}x)   "
+          f"own = {fl / t_own / 1e6:6.1f} direct-equivalent TFLOP/s, {fl / 2.25 / t_own / 1e6 / 157.3:.2f} of the MFMA peak on its own "
+          f"multiplies; |own - library| max {err:.2e}")
