@@ -697,10 +697,14 @@ def conv3x3_bias_act(x, weight, bias=None, relu=False, winograd=None):
     the library convolution followed by the in-place ``bias_act_`` pass."""
     use = WINOGRAD_DEFAULT if winograd is None else winograd
     if use and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and weight.dtype == torch.float32 \
-            and tuple(weight.shape[2:]) == (3, 3) and not torch.is_grad_enabled():
+            and tuple(weight.shape[2:]) == (3, 3) and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)):
         N, C, H, W = x.shape
         K = weight.shape[0]
-        if weight.shape[1] == C and native.lib().dvis_conv3x3_winograd_supported(C, K, H, W):
+        served = weight.shape[1] == C and native.lib().dvis_conv3x3_winograd_supported(C, K, H, W)
+        if winograd and not served:
+            raise RuntimeError(f"conv3x3_bias_act(winograd=True): shape C={C} K={K} H={H} W={W} is not served "
+                               "(dvis_conv3x3_winograd_supported)")
+        if served:
             x = x if x.is_contiguous() else x.contiguous()
             uf = _winograd_weights(weight)
             out = torch.empty((N, K, H, W), dtype=torch.float32, device=x.device)

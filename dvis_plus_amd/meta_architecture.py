@@ -137,6 +137,8 @@ class _VideoBase(nn.Module):
         # advance TOGETHER in one pass (same results per clip; the recurrence's ~65 launch-bound kernels per frame are paid
         # once for the whole round).  Per-clip latency grows by (tracker_batch - 1) segmenter passes.
         self.tracker_batch = max(1, int(os.environ.get("DVIS_TRACKER_BATCH", "1")))
+        # stream(): phase B on its own host thread (matters when a rank's phase A is shorter than phase B: N >= 4 GPUs)
+        self.stream_thread = os.environ.get("DVIS_STREAM_THREAD", "1") != "0"
         self.stream_timing = False            # stream(): make the per-clip "ready_event" a timing event (bench latency)
         # bench.py only: let a clip's input dict carry its own calibrated "object_mask_threshold" (random-init class
         # scores are near-uniform).  Off by default: the reference's input dicts have no such key.
@@ -573,16 +575,24 @@ class DVIS_Plus_offline(_VideoBase):
                 outs = self._track_round(sts)
                 ready = torch.cuda.Event(enable_timing=self.stream_timing)
                 ready.record(side)
-            # The outputs were produced (and allocated) on the side stream; the caller consumes them on ITS stream.
-            # Phase A of the next round is already enqueued, so waiting here costs no overlap: the consumer's stream is
-            # ordered behind phase B of this round, and the allocator is told about the second stream.
-            main.wait_event(ready)
             for out in outs:
-                for v in out.values():
-                    if torch.is_tensor(v) and v.is_cuda:
-                        v.record_stream(main)
                 out["ready_event"] = ready
             return outs
+
+        def hand_over(outs):
+            """(consumer's thread) The outputs were produced (and allocated) on the side stream; the caller consumes them on
+            ITS stream: order it behind phase B of the round and tell the allocator about the second stream."""
+            if overlap:
+                main.wait_event(outs[0]["ready_event"])
+                for out in outs:
+                    for v in out.values():
+                        if torch.is_tensor(v) and v.is_cuda:
+                            v.record_stream(main)
+            return [PP.to_reference_format(out) if self.reference_outputs else out for out in outs]
+
+        if overlap and self.stream_thread:
+            yield from self._stream_threaded(videos, per_round, sharded_owner, main, phase_b, hand_over)
+            return
 
         it, prev, n = iter(videos), None, 0
         while True:
@@ -600,13 +610,88 @@ class DVIS_Plus_offline(_VideoBase):
                 for st in sts:
                     st["done"] = done
             if prev is not None:
-                for out in phase_b(prev):
-                    yield PP.to_reference_format(out) if self.reference_outputs else out
+                yield from hand_over(phase_b(prev))
             prev = sts or None
             if not sts:
                 break
         if overlap:
             main.wait_stream(side)
+
+    def _stream_threaded(self, videos, per_round, sharded_owner, main, phase_b, hand_over):
+        """stream() with phase B on its own HOST thread.  Phase B blocks the host for as long as the tracker's chain of
+        small kernels and host-side assignments runs (~24 ms per 30-frame clip); with one host thread the next round's
+        phase A can only be enqueued after that, so a rank whose phase A is SHORTER than phase B — 4 frames of a clip on 8
+        GPUs: ~21 ms — alternates between the two instead of overlapping them (measured per rank with
+        tools/rank_emulation.py: 40 ms per clip at 8 ranks = the sum; profiles/r03_rank_emulation_serial_host.txt).  Here
+        this thread only enqueues phase A (bounded: two rounds ahead) and hands finished rounds to the consumer; the worker
+        runs phase B round by round in order — every collective of the pipeline is issued by it, in the same order on
+        every rank.  The waits of phase B (event / stream synchronisation, the C assignment chain through ctypes) release
+        the GIL.  Results are those of the single-threaded schedule: same kernels, same order per stream."""
+        import itertools
+        import queue
+        import threading
+        q_in, q_out = queue.Queue(maxsize=2), queue.Queue()
+        device = self.device
+
+        def worker():
+            torch.cuda.set_device(device)
+            with torch.no_grad():
+                while True:
+                    sts = q_in.get()
+                    if sts is None:
+                        return
+                    try:
+                        q_out.put(("ok", phase_b(sts)))
+                    except BaseException as e:      # noqa: BLE001 — re-raised in the consumer's thread
+                        q_out.put(("err", e))
+                        return
+        th = threading.Thread(target=worker, name="dvis-phase-b", daemon=True)
+        th.start()
+        pending = 0
+
+        def take(block):
+            nonlocal pending
+            kind, val = q_out.get(block=block)
+            pending -= 1
+            if kind == "err":
+                pending = 0
+                raise val
+            return hand_over(val)
+        try:
+            it, n = iter(videos), 0
+            while True:
+                chunk = list(itertools.islice(it, per_round))
+                if not chunk:
+                    break
+                sts = self._segment_round(chunk, shift=n if sharded_owner else 0, rotate=sharded_owner)
+                n += len(chunk)
+                done = torch.cuda.Event()
+                done.record(main)
+                for st in sts:
+                    st["done"] = done
+                while True:                         # hand the round to the worker; meanwhile pass finished rounds on
+                    try:
+                        q_in.put(sts, timeout=0.002)
+                        pending += 1
+                        break
+                    except queue.Full:
+                        if not th.is_alive() and q_out.empty():
+                            raise RuntimeError("stream(): the phase-B thread died")
+                    while not q_out.empty():
+                        yield from take(False)
+                while not q_out.empty():
+                    yield from take(False)
+            while pending:
+                yield from take(True)
+        finally:
+            try:
+                while True:                         # (consumer stopped early / error: drop what is queued)
+                    q_in.get_nowait()
+            except queue.Empty:
+                pass
+            q_in.put(None)
+            th.join()
+            main.wait_stream(self._tracker_stream)
 
     @torch.no_grad()
     def forward(self, batched_inputs):

@@ -7,13 +7,33 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
+def _count_kernel_calls():
+    """Counts dvis_conv3x3_winograd launches from here on (the wrapper must not fall back to the library quietly)."""
+    from dvis_plus_amd import native
+    lib = native.lib()
+    real, n = lib.dvis_conv3x3_winograd, [0]
+
+    class Spy:
+        def __call__(self, *a):
+            n[0] += 1
+            return real(*a)
+    lib.dvis_conv3x3_winograd = Spy()
+
+    def done():
+        lib.dvis_conv3x3_winograd = real
+        return n[0]
+    return done
+
+
 def _case(N, C, K, H, W, bias, relu, seed=0, scale=1.0):
     from dvis_plus_amd import functions as Fn
     g = torch.Generator(device="cuda").manual_seed(seed)
     x = torch.randn(N, C, H, W, device="cuda", generator=g) * scale
     w = torch.randn(K, C, 3, 3, device="cuda", generator=g) * (2.0 / (9 * C)) ** 0.5
     b = torch.randn(K, device="cuda", generator=g) if bias else None
+    calls = _count_kernel_calls()
     got = Fn.conv3x3_bias_act(x, w, b, relu, winograd=True)
+    assert calls() == 1, "the own kernel did not run"
     want = F.conv2d(x.double(), w.double(), None if b is None else b.double(), 1, 1)
     want = want.relu() if relu else want
     lib = F.conv2d(x, w, b, 1, 1)
@@ -63,10 +83,10 @@ def test_winograd_weights_follow_the_parameter():
     from dvis_plus_amd import functions as Fn
     x = torch.randn(1, 64, 16, 16, device="cuda")
     w = torch.nn.Parameter(torch.randn(64, 64, 3, 3, device="cuda") * 0.05)
-    a = Fn.conv3x3_bias_act(x, w, None, False, winograd=True)
     with torch.no_grad():
+        a = Fn.conv3x3_bias_act(x, w, None, False, winograd=True)
         w.mul_(2.0)
-    b = Fn.conv3x3_bias_act(x, w, None, False, winograd=True)
+        b = Fn.conv3x3_bias_act(x, w, None, False, winograd=True)
     assert torch.allclose(b, 2 * a, rtol=1e-5, atol=1e-6)
 
 
