@@ -386,9 +386,11 @@ def main():
     # tracked by rank j alone; one more all-gather per round) as an extra key.
     owner_default = model.owner_rounds
     if world > 1 and streamed and "DVIS_TRACKER_BATCH" not in os.environ:
-        # replicated tracker: two clips per round advance through ONE tracker pass (same results per clip) and a rank's
-        # frames of both clips are one segmenter batch — at 8 ranks the replicated recurrence is otherwise the critical path
-        model.tracker_batch = 2
+        # replicated tracker: several clips per round advance through ONE tracker pass (same results per clip) and a rank's
+        # frames of those clips are one segmenter batch — the replicated recurrence is otherwise the critical path.  Per rank,
+        # measured on one GPU with the collective replaced by a copy (tools/rank_emulation.py, profiles/r03_rank_emulation*):
+        # 4 ranks 0.65 / 0.72 / 0.77 of linear at 1 / 2 / 4 clips per round, 8 ranks 0.47 / 0.56 / 0.61; 2 ranks 0.86 / 0.92 / 0.92
+        model.tracker_batch = 4 if world >= 4 else 2
     dt, outs, lat, timer, warm_clips = timed(owner_rounds=False if world > 1 else owner_default)
     owner_line = None
     if world > 1 and streamed and owner_default:

@@ -137,8 +137,9 @@ class _VideoBase(nn.Module):
         # advance TOGETHER in one pass (same results per clip; the recurrence's ~65 launch-bound kernels per frame are paid
         # once for the whole round).  Per-clip latency grows by (tracker_batch - 1) segmenter passes.
         self.tracker_batch = max(1, int(os.environ.get("DVIS_TRACKER_BATCH", "1")))
-        # stream(): phase B on its own host thread (matters when a rank's phase A is shorter than phase B: N >= 4 GPUs)
-        self.stream_thread = os.environ.get("DVIS_STREAM_THREAD", "1") != "0"
+        # stream(): phase B on its own host thread (DVIS_STREAM_THREAD=1).  Off by default: measured per rank with
+        # tools/rank_emulation.py it buys 0 - 3 % — the serial host is not what keeps the two phases from overlapping
+        self.stream_thread = os.environ.get("DVIS_STREAM_THREAD", "0") == "1"
         self.stream_timing = False            # stream(): make the per-clip "ready_event" a timing event (bench latency)
         # bench.py only: let a clip's input dict carry its own calibrated "object_mask_threshold" (random-init class
         # scores are near-uniform).  Off by default: the reference's input dicts have no such key.
@@ -187,6 +188,17 @@ class _VideoBase(nn.Module):
                                        noise_mode=_get(trk, "NOISE_MODE", "none"),
                                        noise_ratio=_get(trk, "NOISE_RATIO", 0.5), mask_dim=mf.HIDDEN_DIM,
                                        class_num=cfg.MODEL.SEM_SEG_HEAD.NUM_CLASSES), hidden
+
+    @staticmethod
+    def _new_tracker_stream():
+        """The stream phase B runs on.  Its kernels are few-workgroup links of a strictly sequential chain; next to phase A's
+        device-filling kernels each of them takes 4-6x its stand-alone time (profiles/r03_bench_kernel_stats.csv) — invisible
+        while phase A is 140 ms long, the critical path when it is 20 ms (a rank of an 8-GPU job).  Measured and NOT the
+        answer (profiles/r03_rank_emulation_matrix.txt): a high-priority stream (DVIS_SIDE_PRIORITY=-1:
+        140 -> 162 ms per clip on one GPU) and disjoint compute-unit masks for the two streams (hipExtStreamCreateWithCUMask,
+        16 / 32 / 64 CUs for phase B: 219 - 232 ms)."""
+        pr = int(os.environ.get("DVIS_SIDE_PRIORITY", "0"))
+        return torch.cuda.Stream(priority=pr)
 
     @property
     def clip_shard(self):
@@ -551,7 +563,7 @@ class DVIS_Plus_offline(_VideoBase):
         overlap = self.device.type == "cuda"
         main = torch.cuda.current_stream() if overlap else None
         if overlap and self._tracker_stream is None:
-            self._tracker_stream = torch.cuda.Stream()
+            self._tracker_stream = self._new_tracker_stream()
         side = self._tracker_stream if overlap else None
         # DVIS_ROUND_CLIPS: development aid — clips per round on a single GPU (exercises the merged segmenter batch)
         sharded_owner = self.owner_rounds and (self.clip_shard.world > 1 or self.clip_shard.force)
@@ -618,15 +630,15 @@ class DVIS_Plus_offline(_VideoBase):
             main.wait_stream(side)
 
     def _stream_threaded(self, videos, per_round, sharded_owner, main, phase_b, hand_over):
-        """stream() with phase B on its own HOST thread.  Phase B blocks the host for as long as the tracker's chain of
-        small kernels and host-side assignments runs (~24 ms per 30-frame clip); with one host thread the next round's
-        phase A can only be enqueued after that, so a rank whose phase A is SHORTER than phase B — 4 frames of a clip on 8
-        GPUs: ~21 ms — alternates between the two instead of overlapping them (measured per rank with
-        tools/rank_emulation.py: 40 ms per clip at 8 ranks = the sum; profiles/r03_rank_emulation_serial_host.txt).  Here
-        this thread only enqueues phase A (bounded: two rounds ahead) and hands finished rounds to the consumer; the worker
-        runs phase B round by round in order — every collective of the pipeline is issued by it, in the same order on
-        every rank.  The waits of phase B (event / stream synchronisation, the C assignment chain through ctypes) release
-        the GIL.  Results are those of the single-threaded schedule: same kernels, same order per stream."""
+        """stream() with phase B on its own HOST thread (opt-in: `stream_thread`).  Phase B blocks the host for as long as
+        the tracker's chain of small kernels and host-side assignments runs (~24 ms per 30-frame clip); with one host thread
+        the next round's phase A can only be enqueued after that.  Here this thread only enqueues phase A (bounded: two rounds
+        ahead) and hands finished rounds to the consumer; the worker runs phase B round by round in order — every collective
+        of the pipeline is issued by it, in the same order on every rank.  The waits of phase B (event / stream
+        synchronisation, the C assignment chain through ctypes) release the GIL.  Results are those of the single-threaded
+        schedule: same kernels, same order per stream.  Measured (tools/rank_emulation.py, one rank of 8: 38.5 -> 37.4 ms per
+        clip; owner rounds 19.2 -> 19.2): the host was not the limiter — phase B's kernels run 4-6x slower NEXT to phase A's
+        than alone, whoever enqueues them — so this stays off."""
         import itertools
         import queue
         import threading
@@ -709,7 +721,7 @@ class DVIS_Plus_offline(_VideoBase):
         overlap = len(plan) > 1 and self.device.type == "cuda"
         main = torch.cuda.current_stream() if overlap else None
         if overlap and self._tracker_stream is None:
-            self._tracker_stream = torch.cuda.Stream()
+            self._tracker_stream = self._new_tracker_stream()
 
         # backbone + pixel decoder once over all of this rank's frames (span-major order), at full batch efficiency;
         # only the decoder (cheap, batch-insensitive) is cut into spans

@@ -107,6 +107,22 @@ def test_phase_b_is_bit_reproducible():
         outs = list(m.stream([video, _clip(7, 4), _clip(7, 5)]))
         torch.cuda.synchronize()
         assert torch.equal(outs[0]["pred_masks"], ref[0]) and outs[0]["segments_infos"] == ref[1]
+        # ... and with phase B on its own host thread (opt-in schedule): the same bits, clips in order, errors re-raised
+        m.stream_thread = True
+        clips = [video, _clip(7, 4), _clip(7, 5), _clip(7, 6), _clip(7, 7)]
+        outs_t = list(m.stream(clips))
+        torch.cuda.synchronize()
+        assert len(outs_t) == 5 and torch.equal(outs_t[0]["pred_masks"], ref[0]) and outs_t[0]["segments_infos"] == ref[1]
+        assert torch.equal(outs_t[1]["pred_masks"], outs[1]["pred_masks"])
+        assert torch.equal(outs_t[2]["pred_masks"], outs[2]["pred_masks"])
+
+        def boom(sts):
+            raise RuntimeError("phase B failed")
+        good, m._track_round = m._track_round, boom
+        with pytest.raises(RuntimeError, match="phase B failed"):
+            list(m.stream(clips))
+        m._track_round = good
+        assert len(list(m.stream(clips[:2]))) == 2      # the model is usable afterwards
 
 
 SOAK = r"""
