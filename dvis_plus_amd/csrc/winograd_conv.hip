@@ -16,10 +16,9 @@
 //     LDS, no redundancy between the waves.
 //   * V (the transformed input) is made in the workgroup: wave w loads the 4x4 input patches of channel w of the stage for
 //     the 64 tiles (lane = tile; out-of-image elements carry an out-of-range buffer offset and read 0: exact zero padding,
-//     no branches), applies B^T d B (32 adds) and writes the 16 positions to LDS; the B operands of 4 MFMAs are one
-//     ds_read_b128 (a row keeps tile t at 4 (t & 15) + (t >> 4); rows are padded to 80 floats so that the 4 lane groups of a
-//     wave start in 4 different bank quarters).
-//   * LDS is double-buffered (2 x 40 KB): one barrier per stage of 8 input channels = per 64 MFMAs of a wave.  The waves
+//     no branches), applies B^T d B (32 adds) and writes the 16 positions to LDS, 64 consecutive dwords per row; the B
+//     operands of 4 MFMAs are one ds_read_b128 (accumulator tile tb of lane column j = tile 4 j + tb).
+//   * LDS is double-buffered (2 x 32 KB): one barrier per stage of 8 input channels = per 64 MFMAs of a wave.  The waves
 //     with half == 1 transform BEFORE their MFMAs, the others after: the two waves of a SIMD are never both in the
 //     VALU / LDS-write phase, so the matrix pipe always has a wave feeding it (8 waves in lock-step behind a barrier that
 //     use the units one after the other was the failure of round 1's msda_forward_pipe).
@@ -28,6 +27,7 @@
 // Accumulation order over input channels is fixed (stages in order, no split-K, no atomics): bit-reproducible.
 #include "dvis_common.h"
 
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -35,9 +35,9 @@ namespace {
 constexpr int kTiles = 64;                 // tiles per workgroup
 constexpr int kKw = 64;                    // output channels per workgroup
 constexpr int kCc = 8;                     // input channels per stage (two MFMA k-steps)
-constexpr int kRow = 80;                   // floats per channel row of V in LDS
+constexpr int kRow = 64;                   // floats per channel row of V in LDS: tile t at dword t
 constexpr int kPos = kCc * kRow;           // floats per transform position in a stage
-constexpr int kStage = 16 * kPos;          // floats per stage (40 KB)
+constexpr int kStage = 16 * kPos;          // floats per stage (32 KB)
 constexpr unsigned kOOB = 0x80000000u;
 
 struct WinoArgs {
@@ -47,6 +47,7 @@ struct WinoArgs {
   long long tiles;
 };
 
+template <int ABL>   // ABL != 0: timing experiments only (tools/exp): 1 no patch loads, 2 no transform, 4 no U loads, 8 no MFMAs
 __global__ __launch_bounds__(512, 2) void winograd_f2x3_kernel(const WinoArgs a) {
   extern __shared__ float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -65,24 +66,28 @@ __global__ __launch_bounds__(512, 2) void winograd_f2x3_kernel(const WinoArgs a)
   const long long plane = (long long)a.H * a.W, img = plane * a.C;
   const int nch = a.C / kCc;
 
-  // ---- transform role: lane = tile, wave = channel of the stage.  Patch element (i, jj) = input (2 ty - 1 + i, 2 tx - 1 + jj):
-  // one byte offset per patch ROW (at column jj = 1, always inside the image; kOOB for a row outside the image or a tile past
-  // the end) and one lane mask per column that can leave the image — 4 VGPRs instead of 16 offsets.
-  unsigned rowbase[4];
-  bool col0, col2, col3;
+  // ---- transform role: lane = tile, wave = channel of the stage.  Patch element (i, jj) = input (2 ty - 1 + i, 2 tx - 1 + jj).
+  // A patch row is ONE 16-byte load (4-byte aligned): 16 dword loads per lane and stage kept the texture-address unit busy
+  // for 2500 of a stage's 6100 cycles and were not hidden (timing ablation: 10.4 ms -> 7.0 without them; profiles/
+  // r03_winograd_ablation.txt).  A row outside the image (or a tile past the end) carries an out-of-range offset and reads
+  // 0.  The leftmost tile of a row would start at column -1 and the rightmost (W even) end at column W: they load columns
+  // 0..3 resp. W-4..W-1 instead and shift in registers (`left`, `right`), so no load ever leaves its image row.
+  unsigned rowq[4];
+  bool left, right;
   {
     const long long p = p0 + lane;
     const bool pv = p < a.tiles;
     const int pi = pv ? (int)(p - (long long)n0 * per_img) : 0;
     const int nn = pi / per_img, r = pi - nn * per_img;
     const int ty = r / a.TX, tx = r - ty * a.TX;
+    left = tx == 0, right = 2 * tx + 2 >= a.W;
+    const int x0 = left ? 0 : (right ? a.W - 4 : 2 * tx - 1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int yy = 2 * ty - 1 + i;
       const bool ok = pv && yy >= 0 && yy < a.H;
-      rowbase[i] = ok ? (unsigned)(((long long)nn * img + (long long)yy * a.W + 2 * tx) * 4) : kOOB;
+      rowq[i] = ok ? (unsigned)(((long long)nn * img + (long long)yy * a.W + x0) * 4) : kOOB;
     }
-    col0 = tx > 0, col2 = 2 * tx + 1 < a.W, col3 = 2 * tx + 2 < a.W;
   }
   const int n_here = min(2, a.N - n0);
   const __amdgpu_buffer_rsrc_t rx = dvis_make_rsrc_uniform(a.x + (long long)n0 * img, (unsigned)(n_here * img * 4));
@@ -91,26 +96,31 @@ __global__ __launch_bounds__(512, 2) void winograd_f2x3_kernel(const WinoArgs a)
   const unsigned u_lane = (unsigned)lane * 16u;
   const unsigned u_blk = (unsigned)((kb * 4 + kb16) * nch);
 
-  auto load_d = [&](int ch, float (&d)[16]) {
+  auto load_d = [&](int ch, dvis_f4 (&d)[4]) {
+    if constexpr (ABL & 1) return;
     const unsigned so = (unsigned)(ch * kCc + wv) * plane_bytes;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {   // (kOOB - 4 and kOOB + 8 are out of range too: num_records < 2^31)
-      d[4 * i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, col0 ? rowbase[i] - 4u : kOOB, so, 0));
-      d[4 * i + 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, rowbase[i], so, 0));
-      d[4 * i + 2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, col2 ? rowbase[i] + 4u : kOOB, so, 0));
-      d[4 * i + 3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, col3 ? rowbase[i] + 8u : kOOB, so, 0));
-    }
+    for (int i = 0; i < 4; ++i) d[i] = __builtin_bit_cast(dvis_f4, __builtin_amdgcn_raw_buffer_load_b128(rx, rowq[i], so, 0));
   };
   auto load_u = [&](int ch, dvis_f4 (&u)[4]) {
+    if constexpr (ABL & 4) return;
     const unsigned so = ((u_blk + (unsigned)ch) * 2u + (unsigned)half) * 4096u;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       u[q] = __builtin_bit_cast(dvis_f4, __builtin_amdgcn_raw_buffer_load_b128(ru, u_lane + 1024u * q, so, 0));
   };
   // V = B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1], position xi = 4 i + jj, to row (xi, channel wv)
-  auto transform_store = [&](const float (&d)[16], float *stage) {
-    float *vw = stage + wv * kRow + (lane & 15) * 4 + (lane >> 4);   // tile t at 4 (t & 15) + (t >> 4): a reader's 4 tile blocks are adjacent
-    float t[16];
+  auto transform_store = [&](const dvis_f4 (&q)[4], float *stage) {
+    if constexpr (ABL & 2) return;
+    float *vw = stage + wv * kRow + lane;   // 64 lanes, 64 consecutive dwords: conflict-free under the (a/4) % 32 write banking
+    float d[16], t[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // edge tiles: the row was loaded one column to the right / left of the patch
+      d[4 * i] = left ? 0.f : (right ? q[i][1] : q[i][0]);
+      d[4 * i + 1] = left ? q[i][0] : (right ? q[i][2] : q[i][1]);
+      d[4 * i + 2] = left ? q[i][1] : (right ? q[i][3] : q[i][2]);
+      d[4 * i + 3] = left ? q[i][2] : (right ? 0.f : q[i][3]);
+    }
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       t[jj] = d[jj] - d[8 + jj];
@@ -133,10 +143,15 @@ __global__ __launch_bounds__(512, 2) void winograd_f2x3_kernel(const WinoArgs a)
 #pragma unroll
     for (int tb = 0; tb < 4; ++tb) acc[x8][tb] = dvis_f4{0.f, 0.f, 0.f, 0.f};
   // u[q] = {U(xi0, s0), U(xi0, s1), U(xi0 + 1, s0), U(xi0 + 1, s1)}, xi0 = 8 half + 2 q; k-step s = channels 4 s + g
-  // B operands: one ds_read_b128 per (position, k-step) = the lane's tile in each of the 4 tile blocks; the reads of position
+  // B operands: one ds_read_b128 per (position, k-step) = tiles 4 j .. 4 j + 3 of the row: accumulator tile tb holds the 16
+  // tiles {4 j + tb}.  Rows are NOT padded: ds_read_b128 is serviced in four 16-lane groups that each take j = 0..15 once
+  // (from two different lane groups g), so equal bank alignment of the rows is what makes it conflict-free — padded to 80
+  // floats the groups collided 2-way (SQ_LDS_BANK_CONFLICT 12 % of the CU cycles), and the tile-block-major row needed for
+  // "tile 16 tb + j" made every ds_write_b32 2-way ((a/4) % 32 banking over 32-lane halves).  The reads of position
   // x8 + 1 are issued before the 8 MFMAs of position x8 (hipcc otherwise reads each operand right in front of its MFMA and
   // waits for it: lgkmcnt(0) every second instruction)
   auto contract = [&](const float *stage, const dvis_f4 (&u)[4]) {
+    if constexpr (ABL & 8) return;
     const dvis_f4 *vr = reinterpret_cast<const dvis_f4 *>(stage + (half * 8) * kPos + g * kRow + 4 * j);
     dvis_f4 b[2][2];
     b[0][0] = vr[0];
@@ -159,8 +174,7 @@ __global__ __launch_bounds__(512, 2) void winograd_f2x3_kernel(const WinoArgs a)
   };
 
   float *s0 = lds, *s1 = lds + kStage;
-  float d[16];
-  dvis_f4 ua[4], ub[4];
+  dvis_f4 d[4] = {}, ua[4] = {}, ub[4] = {};
   load_u(0, ua);
   load_d(0, d);
   transform_store(d, s0);
@@ -244,7 +258,8 @@ __global__ __launch_bounds__(512, 2) void winograd_f2x3_kernel(const WinoArgs a)
       yp[tb][r][2] = R1[0] + R1[1] + R1[2];
       yp[tb][r][3] = R1[1] - R1[2] - R1[3];
     }
-  // half h stores tile blocks 2 h, 2 h + 1; the partials of the other two go to the partner wave through LDS
+  // half h stores accumulator tiles tb = 2 h, 2 h + 1 (tiles 4 j + tb); the partials of the other two go to the partner wave
+  // through LDS
   __syncthreads();   // the stages are dead
   {
     float *ex = lds + (((1 - half) * 4 + kb16) * 2) * 16 * 64 + lane;   // [dst half][kb16][tb & 1][r][ab][lane]
@@ -258,36 +273,51 @@ __global__ __launch_bounds__(512, 2) void winograd_f2x3_kernel(const WinoArgs a)
   __syncthreads();
   const float *ex = lds + ((half * 4 + kb16) * 2) * 16 * 64 + lane;
   const int k0 = kb * kKw + kb16 * 16 + 4 * g;
-  const bool w_even = (a.W & 1) == 0;
+  float bias4[4];
 #pragma unroll
-  for (int t2 = 0; t2 < 2; ++t2) {
-    const int tb = 2 * half + t2;
-    const long long p = p0 + tb * 16 + j;
-    if (p >= a.tiles) continue;
-    const int n = (int)(p / per_img), rr = (int)(p - (long long)n * per_img);
-    const int ty = rr / a.TX, tx = rr - ty * a.TX;
+  for (int r = 0; r < 4; ++r) bias4[r] = a.bias ? a.bias[k0 + r] : 0.f;
+  // this wave's two tiles of the lane: 4 j + 2 half and the next one = 4 adjacent output columns (2 rows)
+  float o[2][4][4];   // [t2][r][2 a + b]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float o[4];
+  for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int ab = 0; ab < 4; ++ab) {
         const float mine = half ? yp[2 + t2][r][ab] : yp[t2][r][ab];
         const float other = ex[((t2 * 4 + r) * 4 + ab) * 64];
-        float v = half ? other + mine : mine + other;   // (half 0's partial) + (half 1's partial)
-        if (a.bias) v += a.bias[k0 + r];
-        o[ab] = a.relu ? fmaxf(v, 0.f) : v;
+        const float v = (half ? other + mine : mine + other) + bias4[r];   // (half 0's partial) + (half 1's partial)
+        o[t2][r][ab] = a.relu ? fmaxf(v, 0.f) : v;
       }
-      float *yrow = a.y + (((long long)n * a.K + k0 + r) * a.H + 2 * ty) * a.W + 2 * tx;
+  const long long pa = p0 + 4 * j + 2 * half;
+  if (((a.TX & 1) | (a.W & 3)) == 0) {   // the pair lies in one tile row, 16-byte aligned: one float4 per output row
+    if (pa < a.tiles) {
+      const int n = (int)(pa / per_img), rr = (int)(pa - (long long)n * per_img);
+      const int ty = rr / a.TX, tx = rr - ty * a.TX;
+      const bool y1 = 2 * ty + 1 < a.H;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float *yrow = a.y + (((long long)n * a.K + k0 + r) * a.H + 2 * ty) * a.W + 2 * tx;
+        *reinterpret_cast<float4 *>(yrow) = make_float4(o[0][r][0], o[0][r][1], o[1][r][0], o[1][r][1]);
+        if (y1) *reinterpret_cast<float4 *>(yrow + a.W) = make_float4(o[0][r][2], o[0][r][3], o[1][r][2], o[1][r][3]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      const long long p = pa + t2;
+      if (p >= a.tiles) continue;
+      const int n = (int)(p / per_img), rr = (int)(p - (long long)n * per_img);
+      const int ty = rr / a.TX, tx = rr - ty * a.TX;
       const bool x1 = 2 * tx + 1 < a.W, y1 = 2 * ty + 1 < a.H;
-      if (w_even) {
-        *reinterpret_cast<float2 *>(yrow) = make_float2(o[0], o[1]);
-        if (y1) *reinterpret_cast<float2 *>(yrow + a.W) = make_float2(o[2], o[3]);
-      } else {
-        yrow[0] = o[0];
-        if (x1) yrow[1] = o[1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float *yrow = a.y + (((long long)n * a.K + k0 + r) * a.H + 2 * ty) * a.W + 2 * tx;
+        yrow[0] = o[t2][r][0];
+        if (x1) yrow[1] = o[t2][r][1];
         if (y1) {
-          yrow[a.W] = o[2];
-          if (x1) yrow[a.W + 1] = o[3];
+          yrow[a.W] = o[t2][r][2];
+          if (x1) yrow[a.W + 1] = o[t2][r][3];
         }
       }
     }
@@ -326,12 +356,10 @@ __global__ void winograd_pack_kernel(const float *__restrict__ w, float *__restr
   }
 }
 
-DvisLdsOptIn g_opted;
-
 }  // namespace
 
 DVIS_EXPORT int dvis_conv3x3_winograd_supported(int C, int K, int H, int W) {
-  if (C <= 0 || K <= 0 || H <= 0 || W <= 0 || C % 16 != 0 || K % kKw != 0) return 0;
+  if (C <= 0 || K <= 0 || H <= 0 || W < 4 || (W & 1) || C % 16 != 0 || K % kKw != 0) return 0;   // (W even: 16-byte patch rows)
   const long long tiles_per_img = (long long)((H + 1) / 2) * ((W + 1) / 2);
   if (tiles_per_img < kTiles) return 0;
   if (2ll * C * H * W * 4 >= (1ll << 31) || 16ll * K * C * 4 >= (1ll << 31)) return 0;
@@ -362,9 +390,17 @@ DVIS_EXPORT int dvis_conv3x3_winograd(const float *x, const float *uf, const flo
   DVIS_REQUIRE(nsp * (K / kKw) + 8 * (K / kKw) < (1ll << 31), "conv3x3_winograd: grid too large");
   a.nsp = (int)nsp;
   const size_t lds_bytes = 2 * kStage * sizeof(float);
-  const int rc = dvis_lds_opt_in((const void *)winograd_f2x3_kernel, lds_bytes, &g_opted, "dvis_conv3x3_winograd");
-  if (rc != DVIS_OK) return rc;
   const unsigned grid = (unsigned)(((nsp + 7) / 8) * 8 * (K / kKw));
-  hipLaunchKernelGGL(winograd_f2x3_kernel, dim3(grid), dim3(512), lds_bytes, (hipStream_t)stream, a);
+  static const int abl = getenv("DVIS_WINO_ABL") ? atoi(getenv("DVIS_WINO_ABL")) : 0;   // timing experiments (wrong results)
+  switch (abl) {
+#define DVIS_WINO_CASE(V)                                                                                          \
+  case V:                                                                                                          \
+    hipLaunchKernelGGL(winograd_f2x3_kernel<V>, dim3(grid), dim3(512), lds_bytes, (hipStream_t)stream, a);          \
+    break;
+    DVIS_WINO_CASE(1) DVIS_WINO_CASE(2) DVIS_WINO_CASE(3) DVIS_WINO_CASE(4) DVIS_WINO_CASE(7) DVIS_WINO_CASE(8) DVIS_WINO_CASE(11)
+#undef DVIS_WINO_CASE
+  default:
+    hipLaunchKernelGGL(winograd_f2x3_kernel<0>, dim3(grid), dim3(512), lds_bytes, (hipStream_t)stream, a);
+  }
   return dvis_check_launch("dvis_conv3x3_winograd");
 }

@@ -231,7 +231,7 @@ int dvis_conv1x1_bias_act(const float *x, const float *w, const float *bias, con
  * matrix cores: 4 multiplies per output instead of 9, accumulated in a fixed order (bit-reproducible).  `uf` = the transformed
  * weights (16 * K * C floats), written once per weight by dvis_conv3x3_winograd_pack(w, uf, K, C).  bias (K) or NULL.  fp32, NCHW
  * contiguous, 16-byte aligned.  dvis_conv3x3_winograd_supported(C, K, H, W) != 0 tells whether the shape is served (C % 16 == 0,
- * K % 64 == 0, at least 64 2x2 tiles per image, 2 images < 2 GiB); other shapes return DVIS_E_ARG — the caller keeps the library
+ * K % 64 == 0, W even, at least 64 2x2 tiles per image, 2 images < 2 GiB); other shapes return DVIS_E_ARG — the caller keeps the library
  * convolution for them.  Rounding differs from a direct convolution by the usual F(2x2, 3x3) factor (a few fp32 ulps of the
  * accumulated magnitude; tests/test_winograd_gpu.py bounds it against fp64).
  */

@@ -45,7 +45,7 @@ def _case(N, C, K, H, W, bias, relu, seed=0, scale=1.0):
 @pytest.mark.parametrize("N,C,K,H,W", [
     (2, 64, 64, 32, 48),          # one channel block, even sizes
     (3, 64, 128, 23, 40),         # odd height (stride-32 map of a 736 x 1280 frame): half-used last tile row
-    (2, 128, 64, 17, 33),         # odd width: scalar stores, column masks on both sides
+    (2, 128, 64, 17, 34),         # odd height, 17 tiles per row: the two tiles of a lane straddle tile rows (scalar stores)
     (5, 16, 64, 16, 18),          # 72 tiles per image: workgroups straddle two images; a single pair of stages
     (1, 256, 256, 46, 80),        # the stride-16 map
 ])
@@ -96,6 +96,7 @@ def test_winograd_refuses_shapes_it_does_not_serve():
     assert not lib.dvis_conv3x3_winograd_supported(3, 64, 64, 64)        # stem: 3 input channels
     assert not lib.dvis_conv3x3_winograd_supported(64, 32, 64, 64)       # 32 output channels
     assert not lib.dvis_conv3x3_winograd_supported(64, 64, 8, 8)         # 16 tiles per image
+    assert not lib.dvis_conv3x3_winograd_supported(64, 64, 64, 63)       # odd width (16-byte patch rows)
     x = torch.zeros(1, 3, 64, 64, device="cuda")
     uf = torch.zeros(16 * 64 * 3, device="cuda")
     y = torch.zeros(1, 64, 64, 64, device="cuda")
