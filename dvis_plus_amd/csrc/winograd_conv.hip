@@ -18,10 +18,15 @@
 //     the 64 tiles (lane = tile; out-of-image elements carry an out-of-range buffer offset and read 0: exact zero padding,
 //     no branches), applies B^T d B (32 adds) and writes the 16 positions to LDS, 64 consecutive dwords per row; the B
 //     operands of 4 MFMAs are one ds_read_b128 (accumulator tile tb of lane column j = tile 4 j + tb).
-//   * LDS is double-buffered (2 x 32 KB): one barrier per stage of 8 input channels = per 64 MFMAs of a wave.  The waves
-//     with half == 1 transform BEFORE their MFMAs, the others after: the two waves of a SIMD are never both in the
-//     VALU / LDS-write phase, so the matrix pipe always has a wave feeding it (8 waves in lock-step behind a barrier that
-//     use the units one after the other was the failure of round 1's msda_forward_pipe).
+//   * LDS is double-buffered (2 x 32 KB): one barrier per stage of 8 input channels = per 64 MFMAs of a wave.  The transform
+//     of the NEXT stage's patch is threaded through the stage's MFMAs in 32 micro-slices (see `stage`); patches are requested
+//     two stages ahead, U one stage ahead.
+//   * What bounds it (timing ablations, profiles/r03_winograd_ablation*.txt): MFMAs alone 6.4 ms at the FPN shape = the matrix
+//     pipe at 100 %; everything else alone 1.8 ms; together 8.4 ms — the SUM, whatever the schedule (separate phases with the
+//     two waves of a SIMD in opposite order, 6 slices, 32 micro-slices, patches one or two stages ahead: 8.39 - 8.47 ms).  The
+//     fp32 MFMA and the fp32 VALU do not overlap on a SIMD here, so every VALU instruction of the transform (~80 per wave and
+//     stage, half of them the edge-tile shift) is paid in full; a structured-buffer load does not range-check the column
+//     (tools/exp/struct_probe), so the shift cannot be left to the hardware.
 //   * Output transform A^T M A is linear, so each half reduces ITS 8 positions to a partial 2x2 block in registers and the
 //     halves exchange only those (64 KB through the LDS that the stages no longer need) — not the 16 M tiles.
 // Accumulation order over input channels is fixed (stages in order, no split-K, no atomics): bit-reproducible.
@@ -109,18 +114,26 @@ __global__ __launch_bounds__(512, 2) void winograd_f2x3_kernel(const WinoArgs a)
     for (int q = 0; q < 4; ++q)
       u[q] = __builtin_bit_cast(dvis_f4, __builtin_amdgcn_raw_buffer_load_b128(ru, u_lane + 1024u * q, so, 0));
   };
+  // edge tiles loaded their rows one column to the right (`left`) / left (`right`) of the patch: shift, zero the column
+  // outside the image.  Bit masks, not `c ? a : b`: hipcc turned the nested selects into exec-masked branches.
+  const unsigned lm = left ? ~0u : 0u, rm = right ? ~0u : 0u, nm = ~(lm | rm);
+  auto shift_row = [&](const dvis_f4 &q, float &e0, float &e1, float &e2, float &e3) {
+    // (by value through __float_as_uint: __builtin_bit_cast applied to the element lvalue q[k] reads element 0 for every k
+    // with this hipcc — the whole row collapsed to its first float)
+    const unsigned q0 = __float_as_uint(q[0]), q1 = __float_as_uint(q[1]), q2 = __float_as_uint(q[2]),
+                   q3 = __float_as_uint(q[3]);
+    e0 = __uint_as_float((q0 & nm) | (q1 & rm));
+    e1 = __uint_as_float((q0 & lm) | (q1 & nm) | (q2 & rm));
+    e2 = __uint_as_float((q1 & lm) | (q2 & nm) | (q3 & rm));
+    e3 = __uint_as_float((q2 & lm) | (q3 & nm));
+  };
   // V = B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1], position xi = 4 i + jj, to row (xi, channel wv)
   auto transform_store = [&](const dvis_f4 (&q)[4], float *stage) {
     if constexpr (ABL & 2) return;
     float *vw = stage + wv * kRow + lane;   // 64 lanes, 64 consecutive dwords: conflict-free under the (a/4) % 32 write banking
     float d[16], t[16];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {   // edge tiles: the row was loaded one column to the right / left of the patch
-      d[4 * i] = left ? 0.f : (right ? q[i][1] : q[i][0]);
-      d[4 * i + 1] = left ? q[i][0] : (right ? q[i][2] : q[i][1]);
-      d[4 * i + 2] = left ? q[i][1] : (right ? q[i][3] : q[i][2]);
-      d[4 * i + 3] = left ? q[i][2] : (right ? 0.f : q[i][3]);
-    }
+    for (int i = 0; i < 4; ++i) shift_row(q[i], d[4 * i], d[4 * i + 1], d[4 * i + 2], d[4 * i + 3]);
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       t[jj] = d[jj] - d[8 + jj];
@@ -146,97 +159,112 @@ __global__ __launch_bounds__(512, 2) void winograd_f2x3_kernel(const WinoArgs a)
   // B operands: one ds_read_b128 per (position, k-step) = tiles 4 j .. 4 j + 3 of the row: accumulator tile tb holds the 16
   // tiles {4 j + tb}.  Rows are NOT padded: ds_read_b128 is serviced in four 16-lane groups that each take j = 0..15 once
   // (from two different lane groups g), so equal bank alignment of the rows is what makes it conflict-free — padded to 80
-  // floats the groups collided 2-way (SQ_LDS_BANK_CONFLICT 12 % of the CU cycles), and the tile-block-major row needed for
-  // "tile 16 tb + j" made every ds_write_b32 2-way ((a/4) % 32 banking over 32-lane halves).  The reads of position
-  // x8 + 1 are issued before the 8 MFMAs of position x8 (hipcc otherwise reads each operand right in front of its MFMA and
-  // waits for it: lgkmcnt(0) every second instruction)
-  auto contract = [&](const float *stage, const dvis_f4 (&u)[4]) {
-    if constexpr (ABL & 8) return;
-    const dvis_f4 *vr = reinterpret_cast<const dvis_f4 *>(stage + (half * 8) * kPos + g * kRow + 4 * j);
-    dvis_f4 b[2][2];
-    b[0][0] = vr[0];
-    b[0][1] = vr[(4 * kRow) / 4];
-#pragma unroll
-    for (int x8 = 0; x8 < 8; ++x8) {
-      if (x8 + 1 < 8) {
-        b[(x8 + 1) & 1][0] = vr[((x8 + 1) * kPos) / 4];
-        b[(x8 + 1) & 1][1] = vr[((x8 + 1) * kPos + 4 * kRow) / 4];
-      }
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const float av = u[x8 >> 1][(x8 & 1) * 2 + s];
-#pragma unroll
-        for (int tb = 0; tb < 4; ++tb)
-          acc[x8][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[x8 & 1][s][tb], acc[x8][tb], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
+  // floats the groups collided 2-way (SQ_LDS_BANK_CONFLICT 12 % of the CU cycles), and a tile-block-major row ("tile
+  // 16 tb + j") made every ds_write_b32 2-way ((a/4) % 32 banking over 32-lane halves).  The reads of position x8 + 1 are
+  // issued before the 8 MFMAs of position x8 (hipcc otherwise reads each operand right in front of its MFMA and waits).
   float *s0 = lds, *s1 = lds + kStage;
   dvis_f4 d[4] = {}, ua[4] = {}, ub[4] = {};
   load_u(0, ua);
   load_d(0, d);
   transform_store(d, s0);
-  // nch is even (C % 16 == 0): stages in pairs, even ones in s0 / ua, odd ones in s1 / ub.  One pair is straight-line code
-  // for a given wave role: with the role, or a "more stages?" test, as run-time branches inside, the join points make hipcc's
-  // s_waitcnt insertion assume the fewest loads in flight on any path, and the waves that had just requested the next
-  // patches waited for them in front of their MFMAs (vmcnt(3) with 16 younger loads outstanding).  So the last pair is NOT
-  // special: it re-requests the last stage (clamped index) and transforms it into a buffer nobody reads any more — 3 % more
-  // loads at C = 256 — and a peeled copy of the pair in front of the epilogue made hipcc spill 300-600 registers.
+  // One stage = the 64 MFMAs of the wave on the current buffer WITH the transform of the next stage's patch threaded through
+  // them in 32 micro-slices: after every PAIR of MFMAs at most 7 other instructions (one work item of <= 6 VALU / LDS-write /
+  // VMEM instructions, sometimes a B-operand read).  Why that fine: the matrix pipe of a SIMD is fed in order by its two
+  // waves, and a wave hides only ~7 single-issue instructions behind one of its MFMAs (32 cycles); a longer run of VALU is a
+  // hole in ITS MFMA stream, and the partner — same code, released by the same barrier — has its hole at the same time.
+  // Measured: separate phases (MFMAs, then transform; the two waves of a SIMD in opposite order) ran at the SUM of the parts
+  // (MFMAs alone 6.4 ms, loads + transform alone 2.1 ms, together 8.4 ms), and so did 6 slices of ~28 VALU each.
+  // Items, in dependency order:  S(i, h) shift half of patch row i (5) x 8;  T(jj) column jj of B^T d (4) x 4;  V(i) row i of
+  // (B^T d) B + its 4 positions to LDS (4 + 2 write2) x 4;  L(i) request row i of the patch two stages ahead x 4.
   auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
-  auto pair = [&](auto first_c, int ch) {
-    constexpr bool kFirst = decltype(first_c)::value;
-    const int c2 = min(ch + 2, nch - 1), c3 = min(ch + 3, nch - 1);
+  auto stage = [&](const float *cur, const dvis_f4 (&u)[4], float *nxt, dvis_f4 (&d)[4], int ch_load) {
+    const dvis_f4 *vr = reinterpret_cast<const dvis_f4 *>(cur + (half * 8) * kPos + g * kRow + 4 * j);
+    float *vw = nxt + wv * kRow + lane;
+    const unsigned so_load = (unsigned)(ch_load * kCc + wv) * plane_bytes;
+    dvis_f4 b[2][2];
+    float e[16], t[16];
+    auto S = [&](int i, int h) {
+      const unsigned q0 = __float_as_uint(d[i][0]), q1 = __float_as_uint(d[i][1]), q2 = __float_as_uint(d[i][2]),
+                     q3 = __float_as_uint(d[i][3]);
+      if (h == 0) {
+        e[4 * i] = __uint_as_float((q0 & nm) | (q1 & rm));
+        e[4 * i + 1] = __uint_as_float((q0 & lm) | (q1 & nm) | (q2 & rm));
+      } else {
+        e[4 * i + 2] = __uint_as_float((q1 & lm) | (q2 & nm) | (q3 & rm));
+        e[4 * i + 3] = __uint_as_float((q2 & lm) | (q3 & nm));
+      }
+    };
+    auto T = [&](int jj) {
+      t[jj] = e[jj] - e[8 + jj];
+      t[4 + jj] = e[4 + jj] + e[8 + jj];
+      t[8 + jj] = e[8 + jj] - e[4 + jj];
+      t[12 + jj] = e[4 + jj] - e[12 + jj];
+    };
+    auto V = [&](int i) {
+      vw[(4 * i) * kPos] = t[4 * i] - t[4 * i + 2];
+      vw[(4 * i + 1) * kPos] = t[4 * i + 1] + t[4 * i + 2];
+      vw[(4 * i + 2) * kPos] = t[4 * i + 2] - t[4 * i + 1];
+      vw[(4 * i + 3) * kPos] = t[4 * i + 1] - t[4 * i + 3];
+    };
+    auto L = [&](int i) {
+      if constexpr (!(ABL & 1)) d[i] = __builtin_bit_cast(dvis_f4, __builtin_amdgcn_raw_buffer_load_b128(rx, rowq[i], so_load, 0));
+    };
+    auto item = [&](int m) {   // m = 0..31, after MFMA pair m
+      if constexpr (ABL & 2) return;
+      if (m < 4) S(m, 0);
+      else if (m < 6) T(m - 4);
+      else if (m < 10) S(m - 6, 1);
+      else if (m < 12) T(m - 8);
+      else if (m < 16) { V(m - 12); L(m - 12); }
+    };
+    b[0][0] = vr[0];
+    b[0][1] = vr[(4 * kRow) / 4];
+#pragma unroll
+    for (int x8 = 0; x8 < 8; ++x8)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const int m = (x8 * 2 + s) * 2 + h2;
+          if constexpr (!(ABL & 8)) {
+            const float av = u[x8 >> 1][(x8 & 1) * 2 + s];
+#pragma unroll
+            for (int tb = 2 * h2; tb < 2 * h2 + 2; ++tb)
+              acc[x8][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[x8 & 1][s][tb], acc[x8][tb], 0, 0, 0);
+          }
+          if (x8 + 1 < 8 && s == 1) b[(x8 + 1) & 1][h2] = vr[((x8 + 1) * kPos + h2 * 4 * kRow) / 4];   // next position's operands
+          item(m);
+          fence();
+        }
+  };
+  // V = B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1], position xi = 4 i + jj, to row (xi, channel wv).
+  // nch is even (C % 16 == 0): stages in pairs, even ones in s0 / ua, odd ones in s1 / ub, straight-line code (run-time
+  // branches inside make hipcc's s_waitcnt insertion assume the fewest loads in flight on any path: it waited for loads it
+  // had just issued).  The last pair is not special: it re-requests the last stage (clamped index) and transforms it into a
+  // buffer nobody reads any more — 3 % more loads at C = 256; a peeled copy in front of the epilogue made hipcc spill 300-600
+  // registers.
+  // Patches are requested TWO stages ahead (two register sets): one stage (~1.5 us) is about the HBM latency under load, and
+  // the input streams from HBM — with one set the wave waited for its patch at the head of every stage (1.5 of 8.4 ms).
+  // (The prologue requests in the order the loop's back edge leaves the loads in — older patch, younger patch, operands: the
+  // s_waitcnt counts at the loop head are the merge of both ways in.)
+  dvis_f4 d2[4] = {};
+  load_d(1, d);
+  fence();
+  load_d(min(2, nch - 1), d2);
+  fence();
+  load_u(1, ub);
+  fence();
+#pragma unroll 1
+  for (int ch = 0; ch < nch; ch += 2) {
+    const int c2 = min(ch + 2, nch - 1), c3 = min(ch + 3, nch - 1), c4 = min(ch + 4, nch - 1);
     __syncthreads();   // s0 holds stage ch; nobody reads s1 (stage ch - 1) any more
-    if constexpr (kFirst) {
-      transform_store(d, s1);
-      fence();
-      load_d(c2, d);
-      fence();
-    }
-    contract(s0, ua);
+    stage(s0, ua, s1, d, c3);    // ... transforms stage ch + 1 (in d) into s1, then requests the patch of stage ch + 3 into d
     load_u(c2, ua);
     fence();
-    if constexpr (!kFirst) {
-      transform_store(d, s1);
-      fence();
-      load_d(c2, d);
-      fence();
-    }
     __syncthreads();   // s1 holds stage ch + 1; nobody reads s0 any more
-    if constexpr (kFirst) {
-      transform_store(d, s0);
-      fence();
-      load_d(c3, d);
-      fence();
-    }
-    contract(s1, ub);
+    stage(s1, ub, s0, d2, c4);   // ... stage ch + 2 (in d2) into s0, the patch of stage ch + 4 into d2
     load_u(c3, ub);
     fence();
-    if constexpr (!kFirst) {
-      transform_store(d, s0);
-      fence();
-      load_d(c3, d);
-      fence();
-    }
-  };
-  // (the loads of stage 1 are requested in the order the pair's back edge leaves them in: the s_waitcnt counts at the loop
-  // head are the merge of both ways in)
-  if (half) {   // wave-uniform
-    load_d(1, d);
-    fence();
-    load_u(1, ub);
-    fence();
-#pragma unroll 1
-    for (int ch = 0; ch < nch; ch += 2) pair(std::true_type{}, ch);
-  } else {
-    load_u(1, ub);
-    fence();
-    load_d(1, d);
-    fence();
-#pragma unroll 1
-    for (int ch = 0; ch < nch; ch += 2) pair(std::false_type{}, ch);
   }
 
   // ---- output transform.  Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1].  Rows first, over THIS half's two rows of M (half 0:
