@@ -497,7 +497,7 @@ def dvis_plus_forward(sd, backbone, frames, *, offline=True, nheads=8, enc_layer
 
 # ----------------------------------------------------------------------------- image Mask2Former (BASELINE config #1)
 def maskformer_image_forward(sd, backbone, image, *, nheads=8, enc_layers=6, dec_layers=9, num_classes=133,
-                             out_hw=None):
+                             out_hw=None, stages=None):
     """MaskFormer.forward eval (mask2former/maskformer_model.py:194-262) for one image with semantic inference
     (:280-284): backbone -> pixel decoder -> image decoder -> upsample to the padded size -> crop + resize
     (sem_seg_postprocess, un-vendored detectron2: "parity unpinned") -> einsum(softmax(cls)[:-1], sigmoid(mask)).
@@ -506,6 +506,8 @@ def maskformer_image_forward(sd, backbone, image, *, nheads=8, enc_layers=6, dec
     feats = backbone(images)
     mf, _, ms = pixel_decoder_forward(_sub(sd, "sem_seg_head.pixel_decoder."), feats, nheads, enc_layers)
     out = decoder_forward(_sub(sd, "sem_seg_head.predictor."), ms, mf, nheads, dec_layers, dvis_plus=False)
+    if stages is not None:      # parity tests: mask_features and every layer's effective attention mask (head 0)
+        stages.update(mask_features=mf, attn_masks=[a[::nheads].clone() for a in out["attn_masks"]])
     masks = F.interpolate(out["pred_masks"], size=tuple(images.shape[-2:]), mode="bilinear", align_corners=False)[0]
     out_hw = img_size if out_hw is None else out_hw
     masks = F.interpolate(masks[:, :img_size[0], :img_size[1]][None], size=tuple(out_hw), mode="bilinear",

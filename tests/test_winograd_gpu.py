@@ -48,6 +48,8 @@ def _case(N, C, K, H, W, bias, relu, seed=0, scale=1.0):
     (2, 128, 64, 17, 34),         # odd height, 17 tiles per row: the two tiles of a lane straddle tile rows (scalar stores)
     (5, 16, 64, 16, 18),          # 72 tiles per image: workgroups straddle two images; a single pair of stages
     (1, 256, 256, 46, 80),        # the stride-16 map
+    (1, 512, 512, 15, 20),        # stride 32 of a 480 x 640 frame: 80 tiles, the second workgroup is mostly past the end
+    (1, 256, 256, 120, 160),      # FPN output convolution of a 480 x 640 frame
 ])
 @pytest.mark.parametrize("bias,relu", [(False, False), (True, True)])
 def test_winograd_equals_fp64_convolution(N, C, K, H, W, bias, relu):
