@@ -201,7 +201,7 @@ def decoder_forward(sd, x, mask_features, nheads, dec_layers, p="", dvis_plus=Tr
         c, m, attn = prediction_heads(sd, p, output, mask_features, sizes[(i + 1) % 3], nheads)
         pred_cls.append(c), pred_mask.append(m)
     if not dvis_plus:
-        return dict(pred_logits=pred_cls[-1], pred_masks=pred_mask[-1])
+        return dict(pred_logits=pred_cls[-1], pred_masks=pred_mask[-1], attn_masks=attn_masks)
     t = pred_mask[-1].shape[0]                                    # eval: bs = 1, all frames are one clip
     normed = layer_norm(sd, p + "decoder_norm", output)
     reid = mlp(sd, p + "reid_embed", normed, reid_layers) if reid_layers > 0 else normed
