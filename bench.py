@@ -41,6 +41,7 @@ sys.path.insert(0, ROOT)
 
 MSDA_BYTES_PER_FRAME_LAYER = 4 * (19320 * 8 * 32 + 19320 * 8 * 3 * 4 * 2 + 19320 * 8 * 3 * 4 + 19320 * 8 * 32)  # 61 824 000
 HBM_PEAK_GBS = 8000.0
+MFMA_F32_PEAK_TF = 157.3      # dense fp32 matrix peak (MI355X_MICROARCH.md)
 
 
 def synthetic_clip(T, device, seed=1234):
@@ -83,6 +84,38 @@ class MsdaTimer:
         secs = [e0.elapsed_time(e1) / 1e3 for e0, e1, _ in self.events]
         frames = [n for _, _, n in self.events]
         return sum(secs) / max(1, len(secs)), sum(frames) / max(1, len(frames)), len(secs)
+
+
+class ConvTimer:
+    """Times every launch of the own 3x3 convolution (csrc/winograd_conv.hip) in the timed region the same way — the largest
+    MFMA-bound own kernel of a clip (the FPN output convolution and the R50 conv2 layers)."""
+
+    def __init__(self):
+        from dvis_plus_amd import native
+        self.native, self.events = native, []
+
+    def __enter__(self):
+        lib = self.native.lib()
+        self.lib, self.orig = lib, lib.dvis_conv3x3_winograd
+
+        def timed(x, uf, bias, y, N, C, K, H, W, relu, stream):
+            st = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            rc = self.orig(x, uf, bias, y, N, C, K, H, W, relu, stream)
+            e1.record(st)
+            self.events.append((e0, e1, 2.0 * 9 * N * C * K * H * W))      # direct-convolution FLOPs of the launch
+            return rc
+        lib.dvis_conv3x3_winograd = timed
+        return self
+
+    def __exit__(self, *exc):
+        self.lib.dvis_conv3x3_winograd = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        secs = sum(e0.elapsed_time(e1) / 1e3 for e0, e1, _ in self.events)
+        return secs, sum(f for _, _, f in self.events), len(self.events)
 
 
 def cpu_baseline_msda(budget_s=8.0):
@@ -367,8 +400,9 @@ def main():
             torch.distributed.barrier()
         model.stream_timing = True
         tm, lt = MsdaTimer(), []
+        tm.conv = ConvTimer()
         t0 = time.perf_counter()
-        with tm:
+        with tm, tm.conv:
             res_ = run_pass(videos[:args.steps], lt)
         torch.cuda.synchronize()
         if dist_on:
@@ -443,6 +477,17 @@ def main():
                 traffic = round(t["hbm_bytes_per_launch"] * nfr / t["frames_per_launch"])
                 traffic_src = f"profiles/{name} (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE)"
                 break
+        csec, cflops, claunch = timer.conv.summary()
+        conv_roof = None
+        if claunch:
+            # the kernel's own arithmetic: F(2x2, 3x3) does 4 multiply-adds per output where the direct form does 9
+            tf = cflops / 2.25 / csec / 1e12
+            conv_roof = {"bound": "mfma", "kernel": "winograd_f2x3 (3x3 convolutions: FPN output conv + R50 conv2)",
+                         "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
+                         "direct_equivalent_tflops": round(cflops / csec / 1e12, 1), "launches_timed": claunch,
+                         "ms_per_clip": round(csec / args.steps * 1e3, 2), "traffic": None,
+                         "note": "flops = 2 * 4 * N*C*K*H*W per launch (Winograd multiplies), summed over the timed launches / "
+                                 "their summed HIP-event durations"}
         ms = sorted(e0.elapsed_time(e1) for e0, e1 in lat)
         pct = lambda q: round(ms[min(len(ms) - 1, int(q * len(ms)))], 2) if ms else None
         res = {
@@ -473,6 +518,8 @@ def main():
         }
         if dist_info is not None:
             res["dist"] = dist_info
+        if conv_roof is not None:
+            res["roofline_conv3x3"] = conv_roof
         if owner_line is not None:
             res["owner_rounds"] = owner_line
         if cand100 is not None:
