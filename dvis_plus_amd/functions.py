@@ -686,6 +686,8 @@ def _winograd_weights(weight):
         with torch.cuda.device(w.device):
             native.check(native.lib().dvis_conv3x3_winograd_pack(native.dev_ptr(w, "weight"), native.dev_ptr(uf, "uf"), K, C,
                                                                  native.stream_ptr(w.device)), "dvis_conv3x3_winograd_pack")
+        if len(_WINOGRAD_PACKED) > 512:       # (weights that were replaced, e.g. re-folded FrozenBN: drop their packs)
+            _WINOGRAD_PACKED.clear()
         _WINOGRAD_PACKED[id(weight)] = ent = (key, uf, weight)     # (holds the weight: id() stays unique)
     return ent[1]
 
