@@ -24,9 +24,9 @@
 //   * What bounds it (timing ablations, profiles/r03_winograd_ablation*.txt): MFMAs alone 6.4 ms at the FPN shape = the matrix
 //     pipe at 100 %; everything else alone 1.8 ms; together 8.4 ms — the SUM, whatever the schedule (separate phases with the
 //     two waves of a SIMD in opposite order, 6 slices, 32 micro-slices, patches one or two stages ahead: 8.39 - 8.47 ms).  The
-//     fp32 MFMA and the fp32 VALU do not overlap on a SIMD here, so every VALU instruction of the transform (~80 per wave and
-//     stage, half of them the edge-tile shift) is paid in full; a structured-buffer load does not range-check the column
-//     (tools/exp/struct_probe), so the shift cannot be left to the hardware.
+//     fp32 MFMA and the fp32 VALU do not overlap on a SIMD here, so every VALU instruction of the transform is paid in full —
+//     which is why the edge tiles are no longer shifted in registers (40 of ~80 VALU per wave and stage) but loaded as they lie
+//     and masked (8): 8.4 -> 7.95 ms.
 //   * Output transform A^T M A is linear, so each half reduces ITS 8 positions to a partial 2x2 block in registers and the
 //     halves exchange only those (64 KB through the LDS that the stages no longer need) — not the 16 M tiles.
 // Accumulation order over input channels is fixed (stages in order, no split-K, no atomics): bit-reproducible.
@@ -75,9 +75,14 @@ __global__ __launch_bounds__(512, 2) void winograd_f2x3_kernel(const WinoArgs a)
   // A patch row is ONE 16-byte load (4-byte aligned): 16 dword loads per lane and stage kept the texture-address unit busy
   // for 2500 of a stage's 6100 cycles and were not hidden (timing ablation: 10.4 ms -> 7.0 without them; profiles/
   // r03_winograd_ablation.txt).  A row outside the image (or a tile past the end) carries an out-of-range offset and reads
-  // 0.  The leftmost tile of a row would start at column -1 and the rightmost (W even) end at column W: they load columns
-  // 0..3 resp. W-4..W-1 instead and shift in registers (`left`, `right`), so no load ever leaves its image row.
-  unsigned rowq[4];
+  // 0.  The leftmost tile of a row starts at column -1 and the rightmost (W even) ends at column W.  The main loop loads
+  // exactly those 16 bytes — the stray element is the neighbouring row's pixel, or lies past the tensor's end where the
+  // descriptor's per-dword range check returns 0 — and clears it with one AND per row end (2 VALU per row; shifting edge
+  // tiles in registers cost 10).  Its offsets are biased by +4 against a base 4 bytes in front of the window, because a
+  // NEGATIVE buffer offset zeroes the whole load (tools/exp/struct_probe/raw_probe.hip).  The one load that would start 4
+  // bytes in front of the TENSOR (tile 0 of image 0 in channel 0) belongs to stage 0, which the prologue handles with loads
+  // that stay inside the image row (edge tiles load columns 0..3 resp. W-4..W-1 and shift in registers: `rowq0`, `rx0`).
+  unsigned rowq[4], rowq0[4];
   bool left, right;
   {
     const long long p = p0 + lane;
@@ -91,11 +96,15 @@ __global__ __launch_bounds__(512, 2) void winograd_f2x3_kernel(const WinoArgs a)
     for (int i = 0; i < 4; ++i) {
       const int yy = 2 * ty - 1 + i;
       const bool ok = pv && yy >= 0 && yy < a.H;
-      rowq[i] = ok ? (unsigned)(((long long)nn * img + (long long)yy * a.W + x0) * 4) : kOOB;
+      const long long row = (long long)nn * img + (long long)yy * a.W;
+      rowq0[i] = ok ? (unsigned)((row + x0) * 4) : kOOB;
+      rowq[i] = ok ? (unsigned)((row + 2 * tx - 1) * 4 + 4) : kOOB;
     }
   }
   const int n_here = min(2, a.N - n0);
-  const __amdgpu_buffer_rsrc_t rx = dvis_make_rsrc_uniform(a.x + (long long)n0 * img, (unsigned)(n_here * img * 4));
+  const __amdgpu_buffer_rsrc_t rx0 = dvis_make_rsrc_uniform(a.x + (long long)n0 * img, (unsigned)(n_here * img * 4));
+  const __amdgpu_buffer_rsrc_t rx = dvis_make_rsrc_uniform(reinterpret_cast<const char *>(a.x + (long long)n0 * img) - 4,
+                                                           (unsigned)(n_here * img * 4 + 4));
   const __amdgpu_buffer_rsrc_t ru = dvis_make_rsrc_uniform(a.uf, (unsigned)(16ll * a.K * a.C * 4));
   const unsigned plane_bytes = (unsigned)(plane * 4);
   const unsigned u_lane = (unsigned)lane * 16u;
@@ -165,7 +174,11 @@ __global__ __launch_bounds__(512, 2) void winograd_f2x3_kernel(const WinoArgs a)
   float *s0 = lds, *s1 = lds + kStage;
   dvis_f4 d[4] = {}, ua[4] = {}, ub[4] = {};
   load_u(0, ua);
-  load_d(0, d);
+  {   // stage 0 (channel wv of the image): loads that stay inside the image row, edge tiles shifted in registers
+    const unsigned so = (unsigned)wv * plane_bytes;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = __builtin_bit_cast(dvis_f4, __builtin_amdgcn_raw_buffer_load_b128(rx0, rowq0[i], so, 0));
+  }
   transform_store(d, s0);
   // One stage = the 64 MFMAs of the wave on the current buffer WITH the transform of the next stage's patch threaded through
   // them in 32 micro-slices: after every PAIR of MFMAs at most 7 other instructions (one work item of <= 6 VALU / LDS-write /
@@ -174,7 +187,7 @@ __global__ __launch_bounds__(512, 2) void winograd_f2x3_kernel(const WinoArgs a)
   // hole in ITS MFMA stream, and the partner — same code, released by the same barrier — has its hole at the same time.
   // Measured: separate phases (MFMAs, then transform; the two waves of a SIMD in opposite order) ran at the SUM of the parts
   // (MFMAs alone 6.4 ms, loads + transform alone 2.1 ms, together 8.4 ms), and so did 6 slices of ~28 VALU each.
-  // Items, in dependency order:  S(i, h) shift half of patch row i (5) x 8;  T(jj) column jj of B^T d (4) x 4;  V(i) row i of
+  // Items, in dependency order:  S(i, h) half of patch row i, its out-of-image end cleared (1) x 8;  T(jj) column jj of B^T d (4) x 4;  V(i) row i of
   // (B^T d) B + its 4 positions to LDS (4 + 2 write2) x 4;  L(i) request row i of the patch two stages ahead x 4.
   auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
   auto stage = [&](const float *cur, const dvis_f4 (&u)[4], float *nxt, dvis_f4 (&d)[4], int ch_load) {
@@ -186,13 +199,9 @@ __global__ __launch_bounds__(512, 2) void winograd_f2x3_kernel(const WinoArgs a)
     auto S = [&](int i, int h) {
       const unsigned q0 = __float_as_uint(d[i][0]), q1 = __float_as_uint(d[i][1]), q2 = __float_as_uint(d[i][2]),
                      q3 = __float_as_uint(d[i][3]);
-      if (h == 0) {
-        e[4 * i] = __uint_as_float((q0 & nm) | (q1 & rm));
-        e[4 * i + 1] = __uint_as_float((q0 & lm) | (q1 & nm) | (q2 & rm));
-      } else {
-        e[4 * i + 2] = __uint_as_float((q1 & lm) | (q2 & nm) | (q3 & rm));
-        e[4 * i + 3] = __uint_as_float((q2 & lm) | (q3 & nm));
-      }
+      if (h == 0) e[4 * i] = __uint_as_float(q0 & ~lm), e[4 * i + 1] = d[i][1];     // column -1 of the leftmost tile
+      else e[4 * i + 2] = d[i][2], e[4 * i + 3] = __uint_as_float(q3 & ~rm);       // column W of the rightmost tile
+      (void)q1, (void)q2;
     };
     auto T = [&](int jj) {
       t[jj] = e[jj] - e[8 + jj];
