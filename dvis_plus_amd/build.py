@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libdvis_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fno-gpu-rdc",
-         "-Wno-unused-result"]
+         "-Wno-unused-result", *os.environ.get("DVIS_HIPCC_FLAGS", "").split()]    # (development: e.g. -DDVIS_WINO_ABLATION)
 
 
 def sources():

@@ -52,7 +52,7 @@ struct WinoArgs {
   long long tiles;
 };
 
-template <int ABL>   // ABL != 0: timing experiments only (tools/exp): 1 no patch loads, 2 no transform, 4 no U loads, 8 no MFMAs
+template <int ABL>   // ABL != 0 (-DDVIS_WINO_ABLATION builds, tools/exp/wino_abl.sh): 1 no patch loads, 2 no transform, 4 no U loads, 8 no MFMAs
 __global__ __launch_bounds__(512, 2) void winograd_f2x3_kernel(const WinoArgs a) {
   extern __shared__ float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -428,16 +428,19 @@ DVIS_EXPORT int dvis_conv3x3_winograd(const float *x, const float *uf, const flo
   a.nsp = (int)nsp;
   const size_t lds_bytes = 2 * kStage * sizeof(float);
   const unsigned grid = (unsigned)(((nsp + 7) / 8) * 8 * (K / kKw));
-  static const int abl = getenv("DVIS_WINO_ABL") ? atoi(getenv("DVIS_WINO_ABL")) : 0;   // timing experiments (wrong results)
+#ifdef DVIS_WINO_ABLATION   // development builds only (tools/exp/wino_abl.sh): the kernel with parts switched off — WRONG results
+  static const int abl = getenv("DVIS_WINO_ABL") ? atoi(getenv("DVIS_WINO_ABL")) : 0;
   switch (abl) {
 #define DVIS_WINO_CASE(V)                                                                                          \
   case V:                                                                                                          \
     hipLaunchKernelGGL(winograd_f2x3_kernel<V>, dim3(grid), dim3(512), lds_bytes, (hipStream_t)stream, a);          \
-    break;
+    return dvis_check_launch("dvis_conv3x3_winograd");
     DVIS_WINO_CASE(1) DVIS_WINO_CASE(2) DVIS_WINO_CASE(3) DVIS_WINO_CASE(4) DVIS_WINO_CASE(7) DVIS_WINO_CASE(8) DVIS_WINO_CASE(11)
 #undef DVIS_WINO_CASE
   default:
-    hipLaunchKernelGGL(winograd_f2x3_kernel<0>, dim3(grid), dim3(512), lds_bytes, (hipStream_t)stream, a);
+    break;
   }
+#endif
+  hipLaunchKernelGGL(winograd_f2x3_kernel<0>, dim3(grid), dim3(512), lds_bytes, (hipStream_t)stream, a);
   return dvis_check_launch("dvis_conv3x3_winograd");
 }
