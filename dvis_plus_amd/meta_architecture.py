@@ -480,7 +480,8 @@ class DVIS_Plus_offline(_VideoBase):
         """Phase B of several clips of equal length with the tracker REPLICATED: one all-gather per clip as in
         _track_phase, then ONE tracker pass in which the clips' recurrences advance together (ReferringTracker_noiser with
         batch = number of clips: every op of the recurrence is row-wise or per (batch, head), the GEMMs' tile configuration is
-        pinned to a single clip's — same bits per clip as alone), then refiner, masks and post-processing clip by clip."""
+        pinned to a single clip's — same bits per clip as alone), ONE refiner pass over the clips of the round (same argument),
+        then masks and post-processing clip by clip."""
         to_bctq = lambda z: z.permute(2, 0, 1).unsqueeze(0)
         self.keep = False
         gathered = [self.clip_shard.all_gather_frames([st["embds"], st["embds_nn"], st["logits"]], st["T"], shift=st["shift"])
@@ -488,13 +489,14 @@ class DVIS_Plus_offline(_VideoBase):
         embds = torch.cat([to_bctq(g[0]) for g in gathered], 0)                      # (clips, 2C, T, Q)
         embds_nn = torch.cat([to_bctq(g[1]) for g in gathered], 0)
         track = self.tracker(embds, None, resume=False, frame_embeds_no_norm=embds_nn, need_masks=False)
+        ref = self.refiner(track["pred_embds"], embds_nn, None, need_masks=False)      # ... and ONE refiner pass
         outs = []
         for j, st in enumerate(sts):
-            ref = self.refiner(track["pred_embds"][j:j + 1], embds_nn[j:j + 1], None, need_masks=False)
-            cls, aux = PP.mean_logits(ref["pred_logits"], track["pred_logits"][j:j + 1])
+            cls, aux = PP.mean_logits(ref["pred_logits"][j:j + 1], track["pred_logits"][j:j + 1])
             if self.debug_stages is not None:
-                self.debug_stages.update(instance_embds=track["pred_embds"][j:j + 1], refiner_embds=ref["pred_embds"])
-            outs.append(self._finish_phase(st, ref["mask_embed"], cls, aux))
+                self.debug_stages.update(instance_embds=track["pred_embds"][j:j + 1],
+                                         refiner_embds=ref["pred_embds"][j:j + 1])
+            outs.append(self._finish_phase(st, ref["mask_embed"][j:j + 1], cls, aux))
         return outs
 
     @torch.no_grad()

@@ -66,20 +66,24 @@ class TemporalRefiner(nn.Module):
     def _kv_weights(self):
         return self._kv_cache.get(self.transformer_cross_attention_layers, self.decoder_norm.weight.shape[0])
 
-    def _attention(self, q, k, v, over_time):
-        """q / k / v: (T, Q, C) views with unit inner stride.  over_time: sequences run over T (one per query slot),
-        otherwise over Q (one per frame).  -> (T, Q, C) contiguous.  The attention kernel takes row / batch strides, so
-        the reference's permute + flatten copies between its three layouts (refiner.py:104-139) never happen."""
+    def _attention(self, q, k, v, over_time, clips=1):
+        """q / k / v: (T, clips * Q, C) views with unit inner stride.  over_time: sequences run over T (one per query slot
+        of every clip), otherwise over the Q queries of one frame of one clip.  -> (T, clips * Q, C) contiguous.  The
+        attention kernel takes row / batch strides, so the reference's permute + flatten copies between its three layouts
+        (refiner.py:104-139) never happen; several clips are more batch entries ((T, clips, Q, C) memory order: a frame of a
+        clip is a contiguous (Q, C) block)."""
         out = torch.empty(q.shape, dtype=q.dtype, device=q.device)
         if over_time:
             return Fn.attention(q, k, v, self.num_heads, out=out)
-        Fn.attention(q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1), self.num_heads, out=out.transpose(0, 1))
+        T, QB, C = q.shape
+        per_frame = lambda z: z.view(T * clips, QB // clips, C).transpose(0, 1)    # (Q, T * clips, C): batch = (frame, clip)
+        Fn.attention(per_frame(q), per_frame(k), per_frame(v), self.num_heads, out=per_frame(out))
         return out
 
-    def _self_attention(self, layer, x, over_time):
+    def _self_attention(self, layer, x, over_time, clips=1):
         C = x.shape[-1]
         qkv = Fn.linear(x, layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias, own=True)
-        att = self._attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], over_time)
+        att = self._attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], over_time, clips)
         op = layer.self_attn.out_proj
         return Fn.add_layer_norm(Fn.linear(att, op.weight, op.bias, own=True), x, layer.norm)
 
@@ -95,24 +99,27 @@ class TemporalRefiner(nn.Module):
         return x
 
     def refine(self, instance_embeds, frame_embeds):
-        """The 6 refinement layers.  (b, c, t, q) x2 -> last layer's queries (t, q, b, c), un-normed.  b = 1."""
+        """The 6 refinement layers.  (b, c, t, q) x2 -> last layer's queries (t, q, b, c), un-normed.  b = the clips of a
+        round (the reference runs one video at a time): every op is row-wise, per (clip, query slot) over time or per (clip,
+        frame) over queries, and the GEMMs' tile configuration is pinned to ONE clip's rows — a clip's bits do not depend on
+        its round mates."""
         B, C, T, Q = instance_embeds.shape
-        assert B == 1, "inference runs one video at a time"
-        x = instance_embeds[0].permute(1, 2, 0).contiguous()                       # (T, Q, C): the one layout used below
-        fe = frame_embeds[0].permute(1, 2, 0).contiguous()
+        x = instance_embeds.permute(2, 0, 3, 1).reshape(T, B * Q, C)               # (T, clips * Q, C): the one layout used below
+        fe = frame_embeds.permute(2, 0, 3, 1).reshape(T, B * Q, C)
         W, b = self._kv_weights()
-        kv = Fn.linear(fe, W, b, own=True)                                         # (T, Q, layers * 2C): one GEMM
-        for i in range(self.num_layers):
-            x = self._self_attention(self.transformer_time_self_attention_layers[i], x, over_time=True)
-            x = Fn.add_layer_norm(self._short_aggregate(i, x), x, self.conv_norms[i])
-            x = self._self_attention(self.transformer_obj_self_attention_layers[i], x, over_time=False)
-            layer = self.transformer_cross_attention_layers[i]
-            att = self._attention(layer.project_q(x), kv[..., (2 * i) * C:(2 * i + 1) * C],
-                                  kv[..., (2 * i + 1) * C:(2 * i + 2) * C], over_time=False)
-            op = layer.multihead_attn.out_proj
-            x = Fn.add_layer_norm(Fn.linear(att, op.weight, op.bias, own=True), x, layer.norm)
-            x = self.transformer_ffn_layers[i](x)
-        return x.unsqueeze(2)                                                      # (t, q, b, c)
+        with Fn.gemm_sizes_as(rows=T * Q):
+            kv = Fn.linear(fe, W, b, own=True)                                     # (T, clips * Q, layers * 2C): one GEMM
+            for i in range(self.num_layers):
+                x = self._self_attention(self.transformer_time_self_attention_layers[i], x, over_time=True)
+                x = Fn.add_layer_norm(self._short_aggregate(i, x), x, self.conv_norms[i])
+                x = self._self_attention(self.transformer_obj_self_attention_layers[i], x, over_time=False, clips=B)
+                layer = self.transformer_cross_attention_layers[i]
+                att = self._attention(layer.project_q(x), kv[..., (2 * i) * C:(2 * i + 1) * C],
+                                      kv[..., (2 * i + 1) * C:(2 * i + 2) * C], over_time=False, clips=B)
+                op = layer.multihead_attn.out_proj
+                x = Fn.add_layer_norm(Fn.linear(att, op.weight, op.bias, own=True), x, layer.norm)
+                x = self.transformer_ffn_layers[i](x)
+        return x.view(T, B, Q, C).transpose(1, 2)                                  # (t, q, b, c)
 
     def pred_class(self, decoder_output):
         """(l, b, t, q, c): softmax-over-time pooled class logits, repeated T times (refiner.py:196-210)."""
@@ -135,8 +142,9 @@ class TemporalRefiner(nn.Module):
         last = self._graph("refine", instance_embeds.contiguous(), frame_embeds.contiguous()).clone()   # (t, q, b, c)
         dec = self.decoder_norm(last)
         dec_b = dec.permute(2, 0, 1, 3)                                            # (b, t, q, c)
-        emb = self.mask_embed(dec_b)                                               # (b, t, q, Cm)
-        logits = self.pred_class(dec_b[None])[0].transpose(1, 2)                   # (b, t, q, K+1)
+        with Fn.gemm_sizes_as(rows=dec_b.shape[1] * dec_b.shape[2]):               # (one clip's rows: see refine)
+            emb = self.mask_embed(dec_b)                                           # (b, t, q, Cm)
+            logits = self.pred_class(dec_b[None])[0].transpose(1, 2)               # (b, t, q, K+1)
         out = {"pred_logits": logits, "pred_masks": None, "aux_outputs": [],
                "pred_embds": dec.permute(2, 3, 0, 1), "mask_embed": emb}
         if need_masks:
