@@ -61,6 +61,9 @@ class ConvBN(nn.Conv2d):
         if self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) and res is None and x.is_cuda \
                 and not key_is_channels_last(w):
             return Fn.conv3x3_bias_act(x, w, b, relu)            # own Winograd kernel where the shape is served
+        if self.kernel_size == (3, 3) and self.stride == (2, 2) and self.padding == (1, 1) and res is None and x.is_cuda \
+                and not key_is_channels_last(w):
+            return Fn.conv3x3s2_bias_act(x, w, b, relu)          # own direct kernel where it beats the library
         return Fn.bias_act_(F.conv2d(x, w, None, self.stride, self.padding), b, res, relu)
 
 

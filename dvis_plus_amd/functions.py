@@ -692,6 +692,55 @@ def _winograd_weights(weight):
     return ent[1]
 
 
+_S2_PACKED = {}
+S2_DEFAULT = os.environ.get("DVIS_CONV3X3S2", "1") != "0"
+
+
+def _s2_weights(weight):
+    key = (weight._version, weight.data_ptr(), weight.device)
+    ent = _S2_PACKED.get(id(weight))
+    if ent is None or ent[0] != key:
+        K, C = weight.shape[:2]
+        w = weight.detach().contiguous()
+        uf = ent[1] if ent is not None and ent[1].device == w.device and ent[1].numel() == 12 * K * C else \
+            torch.empty(12 * K * C, dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            native.check(native.lib().dvis_conv3x3s2_pack(native.dev_ptr(w, "weight"), native.dev_ptr(uf, "uf"), K, C,
+                                                          native.stream_ptr(w.device)), "dvis_conv3x3s2_pack")
+        if len(_S2_PACKED) > 512:
+            _S2_PACKED.clear()
+        _S2_PACKED[id(weight)] = ent = (key, uf, weight)
+    return ent[1]
+
+
+def conv3x3s2_bias_act(x, weight, bias=None, relu=False, own=None):
+    """relu?(conv2d(x, weight (K, C, 3, 3), stride 2, padding 1) + bias[k]) on NCHW.  own=True: the direct fp32-MFMA kernel
+    (csrc/conv3x3s2.hip: 119 - 131 TFLOP/s at the R50 shapes, 1.4 - 1.65x the library + epilogue pass), raising when the
+    shape is not served; own=None: that kernel where the shape is served; otherwise the library convolution followed by the
+    in-place ``bias_act_`` pass."""
+    N, C, H, W = x.shape
+    K = weight.shape[0]
+    ok = x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and tuple(weight.shape[1:]) == (C, 3, 3) \
+        and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)) \
+        and bool(native.lib().dvis_conv3x3s2_supported(C, K, H, W))
+    if own and not ok:
+        raise RuntimeError(f"conv3x3s2_bias_act(own=True): C={C} K={K} H={H} W={W} is not served (dvis_conv3x3s2_supported)")
+    if ok and (own or (own is None and WINOGRAD_DEFAULT and S2_DEFAULT)):
+        x = x if x.is_contiguous() else x.contiguous()
+        uf = _s2_weights(weight)
+        out = torch.empty((N, K, (H + 1) // 2, W // 2), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = native.lib().dvis_conv3x3s2(
+                native.dev_ptr(x, "x"), native.dev_ptr(uf, "uf"), None if bias is None else native.dev_ptr(bias.detach(), "bias"),
+                native.dev_ptr(out, "out"), N, C, K, H, W, 1 if relu else 0, native.stream_ptr(x.device))
+        native.check(rc, "dvis_conv3x3s2")
+        return out
+    y = torch.nn.functional.conv2d(x, weight, None, 2, 1)
+    if bias is None and not relu:
+        return y
+    return bias_act_(y, None if bias is None else bias.detach(), None, relu)
+
+
 def conv3x3_bias_act(x, weight, bias=None, relu=False, winograd=None):
     """relu?(conv2d(x, weight (K, C, 3, 3), stride 1, padding 1) + bias[k]) on NCHW.  Shapes dvis_conv3x3_winograd serves run
     as ONE own kernel — Winograd F(2x2, 3x3) on the fp32 matrix cores, bias / ReLU in its epilogue (csrc/winograd_conv.hip:

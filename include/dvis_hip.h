@@ -29,6 +29,7 @@
  *   dvis_conv3x3_winograd    <- 3x3 / stride 1 / pad 1 convolution (+ bias + ReLU): the FPN output convolution of the pixel decoder,
  *                               mask2former/modeling/pixel_decoder/msdeformattn.py:262-270 (built), :343-349 (applied), and conv2 of
  *                               the R50 bottlenecks (detectron2 BottleneckBlock)
+ *   dvis_conv3x3s2           <- the stride-2 3x3 convolutions of the R50 (conv2 of the first res3 / res4 / res5 bottleneck)
  *   dvis_bias_relu_maxpool   <- FrozenBN shift + ReLU + max_pool2d(3, stride 2, padding 1) of the ResNet stem (detectron2 BasicStem)
  *   dvis_upsample_add        <- `cur_fpn + F.interpolate(out[-1], size=..., mode="bilinear")`, msdeformattn.py:347
  *   dvis_group_norm_affine / dvis_scale_shift_act / dvis_upsample_add_affine
@@ -236,6 +237,15 @@ int dvis_conv1x1_bias_act(const float *x, const float *w, const float *bias, con
  * accumulated magnitude; tests/test_winograd_gpu.py bounds it against fp64).
  */
 int dvis_conv3x3_winograd_supported(int C, int K, int H, int W);
+/*
+ * The same for stride 2 (padding 1): y (N, K, ceil(H/2), W/2) = relu?(conv2d(x, w, stride 2, padding 1) + bias[k]), direct on the fp32
+ * matrix cores (conv2 of the first bottleneck of res3 / res4 / res5 in detectron2's ResNet with STRIDE_IN_1X1 = False).  `uf` =
+ * the weights in the MFMA operand layout (12 * K * C floats), written by dvis_conv3x3s2_pack.  Same shape rules (W even).
+ */
+int dvis_conv3x3s2_supported(int C, int K, int H, int W);
+int dvis_conv3x3s2_pack(const float *w, float *uf, int K, int C, void *stream);
+int dvis_conv3x3s2(const float *x, const float *uf, const float *bias, float *y, int N, int C, int K, int H, int W, int relu,
+                   void *stream);
 int dvis_conv3x3_winograd_pack(const float *w, float *uf, int K, int C, void *stream);
 int dvis_conv3x3_winograd(const float *x, const float *uf, const float *bias, float *y, int N, int C, int K, int H, int W,
                           int relu, void *stream);

@@ -105,3 +105,45 @@ def test_winograd_refuses_shapes_it_does_not_serve():
     rc = lib.dvis_conv3x3_winograd(native.dev_ptr(x, "x"), native.dev_ptr(uf, "uf"), None, native.dev_ptr(y, "y"), 1, 3, 64, 64, 64,
                                    0, native.stream_ptr(x.device))
     assert rc != 0 and "unsupported shape" in lib.dvis_last_error().decode()
+
+
+# ---- the stride-2 sibling (csrc/conv3x3s2.hip): conv2 of the first bottleneck of res3 / res4 / res5
+@pytest.mark.parametrize("N,C,K,H,W", [
+    (2, 64, 64, 32, 48),          # even sizes, one channel block
+    (3, 128, 128, 23, 40),        # odd height: the last output row reads one row past the image (zero)
+    (2, 16, 64, 30, 34),          # 17 output pixels per row: a lane's two pixels straddle output rows; a single stage pair
+    (1, 256, 256, 46, 80),
+    (5, 32, 64, 16, 18),          # 72 pixels per image: workgroups straddle two images
+])
+@pytest.mark.parametrize("bias,relu", [(False, False), (True, True)])
+def test_conv3x3_stride2_equals_fp64_convolution(N, C, K, H, W, bias, relu):
+    from dvis_plus_amd import functions as Fn
+    g = torch.Generator(device="cuda").manual_seed(2)
+    x = torch.randn(N, C, H, W, device="cuda", generator=g)
+    w = torch.randn(K, C, 3, 3, device="cuda", generator=g) * (2.0 / (9 * C)) ** 0.5
+    b = torch.randn(K, device="cuda", generator=g) if bias else None
+    got = Fn.conv3x3s2_bias_act(x, w, b, relu, own=True)
+    want = F.conv2d(x.double(), w.double(), None if b is None else b.double(), 2, 1)
+    want = want.relu() if relu else want
+    assert got.shape == want.shape
+    mag = float(F.conv2d(x.double().abs(), w.double().abs(), None, 2, 1).max())
+    err = float((got.double() - want).abs().max())
+    assert err <= 4 * 2.0 ** -24 * mag, (err, mag)        # a direct fp32 contraction: ~1 ulp of the accumulated magnitude
+    assert torch.equal(got, Fn.conv3x3s2_bias_act(x, w, b, relu, own=True))          # fixed accumulation order
+    if N > 1:
+        assert torch.equal(got[1:2], Fn.conv3x3s2_bias_act(x[1:2].contiguous(), w, b, relu, own=True))
+
+
+def test_conv3x3_stride2_res3_shape_and_refusals():
+    from dvis_plus_amd import functions as Fn, native
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.randn(4, 128, 184, 320, device="cuda", generator=g)
+    w = torch.randn(128, 128, 3, 3, device="cuda", generator=g) * 0.03
+    got = Fn.conv3x3s2_bias_act(x, w, None, False, own=True)
+    want = F.conv2d(x.double(), w.double(), None, 2, 1)
+    mag = float(F.conv2d(x.double().abs(), w.double().abs(), None, 2, 1).max())
+    assert float((got.double() - want).abs().max()) <= 4 * 2.0 ** -24 * mag
+    lib = native.lib()
+    assert not lib.dvis_conv3x3s2_supported(3, 64, 64, 64) and not lib.dvis_conv3x3s2_supported(64, 64, 64, 63)
+    with pytest.raises(RuntimeError, match="not served"):
+        Fn.conv3x3s2_bias_act(torch.zeros(1, 3, 64, 64, device="cuda"), torch.zeros(64, 3, 3, 3, device="cuda"), own=True)

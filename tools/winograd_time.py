@@ -44,3 +44,16 @@ for name, C, K, H, W in CASES:
     print(f"{name:36s} library + bias_act {t_lib:8.1f} us   own {t_own:8.1f} us  ({t_lib / t_own:4.2f}x)   "
           f"own = {fl / t_own / 1e6:6.1f} direct-equivalent TFLOP/s, {fl / 2.25 / t_own / 1e6 / 157.3:.2f} of the MFMA peak on its own "
           f"multiplies; |own - library| max {err:.2e}")
+
+print("stride 2 (csrc/conv3x3s2.hip, direct fp32 MFMA):")
+for name, C, K, H, W in [("res3 first conv2 128->128 @184x320 -> 92x160", 128, 128, 184, 320),
+                         ("res4 first conv2 256->256 @92x160 -> 46x80", 256, 256, 92, 160),
+                         ("res5 first conv2 512->512 @46x80 -> 23x40", 512, 512, 46, 80)]:
+    x = torch.randn(N, C, H, W, device=dev)
+    w = torch.randn(K, C, 3, 3, device=dev) * 0.02
+    b = torch.randn(K, device=dev)
+    t_lib = timeit(lambda: Fn.bias_act_(F.conv2d(x, w, None, 2, 1), b, None, True))
+    t_own = timeit(lambda: Fn.conv3x3s2_bias_act(x, w, b, True, own=True))
+    fl = 2.0 * 9 * C * K * (H // 2) * (W // 2) * N
+    print(f"{name:48s} library + bias_act {t_lib:8.1f} us   own {t_own:8.1f} us  ({t_lib / t_own:4.2f}x)   own = {fl / t_own / 1e6:6.1f} TFLOP/s = "
+          f"{fl / t_own / 1e6 / 157.3:.2f} of the MFMA peak")
