@@ -77,9 +77,11 @@ class BasicStem(nn.Module):
         self.conv1 = ConvBN(in_channels, out_channels, 7, stride=2, padding=3)
 
     def forward(self, x):
-        """conv (MIOpen) then ONE pass: folded-BN shift + ReLU + 3x3/2 max-pool (the 1.8 GB stem output is read once)."""
+        """conv then ONE pass: folded-BN shift + ReLU + 3x3/2 max-pool (the 1.8 GB stem output is read once)."""
         c = self.conv1
         w, b = c.folded()
+        if c.kernel_size == (7, 7) and c.stride == (2, 2) and c.padding == (3, 3) and x.is_cuda and not key_is_channels_last(w):
+            return Fn.bias_relu_maxpool(Fn.conv7x7s2_stem(x, w), b)          # own direct kernel where the shape is served
         return Fn.bias_relu_maxpool(F.conv2d(x, w, None, c.stride, c.padding), b)
 
 

@@ -741,6 +741,45 @@ def conv3x3s2_bias_act(x, weight, bias=None, relu=False, own=None):
     return bias_act_(y, None if bias is None else bias.detach(), None, relu)
 
 
+_STEM_PACKED = {}
+
+
+def conv7x7s2_stem(x, weight, bias=None, relu=False, own=None):
+    """relu?(conv2d(x (N, 3, H, W), weight (64, 3, 7, 7), stride 2, padding 3) + bias[k]): the ResNet stem convolution on the
+    direct fp32-MFMA kernel (csrc/conv7x7s2.hip) where the shape is served (own=True: raise otherwise), else the library."""
+    N, C, H, W = x.shape
+    K = weight.shape[0]
+    ok = x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and tuple(weight.shape) == (64, 3, 7, 7) \
+        and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)) \
+        and bool(native.lib().dvis_conv7x7s2_supported(C, K, H, W))
+    if own and not ok:
+        raise RuntimeError(f"conv7x7s2_stem(own=True): C={C} K={K} H={H} W={W} is not served (dvis_conv7x7s2_supported)")
+    if ok and (own or (own is None and WINOGRAD_DEFAULT and S2_DEFAULT)):
+        key = (weight._version, weight.data_ptr(), weight.device)
+        ent = _STEM_PACKED.get(id(weight))
+        if ent is None or ent[0] != key:
+            w = weight.detach().contiguous()
+            uf = ent[1] if ent is not None and ent[1].device == w.device else torch.empty(10240, dtype=torch.float32, device=w.device)
+            with torch.cuda.device(w.device):
+                native.check(native.lib().dvis_conv7x7s2_pack(native.dev_ptr(w, "weight"), native.dev_ptr(uf, "uf"),
+                                                              native.stream_ptr(w.device)), "dvis_conv7x7s2_pack")
+            if len(_STEM_PACKED) > 64:
+                _STEM_PACKED.clear()
+            _STEM_PACKED[id(weight)] = ent = (key, uf, weight)
+        x = x if x.is_contiguous() else x.contiguous()
+        out = torch.empty((N, 64, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = native.lib().dvis_conv7x7s2(native.dev_ptr(x, "x"), native.dev_ptr(ent[1], "uf"),
+                                             None if bias is None else native.dev_ptr(bias.detach(), "bias"),
+                                             native.dev_ptr(out, "out"), N, H, W, 1 if relu else 0, native.stream_ptr(x.device))
+        native.check(rc, "dvis_conv7x7s2")
+        return out
+    y = torch.nn.functional.conv2d(x, weight, None, 2, 3)
+    if bias is None and not relu:
+        return y
+    return bias_act_(y, None if bias is None else bias.detach(), None, relu)
+
+
 def conv3x3_bias_act(x, weight, bias=None, relu=False, winograd=None):
     """relu?(conv2d(x, weight (K, C, 3, 3), stride 1, padding 1) + bias[k]) on NCHW.  Shapes dvis_conv3x3_winograd serves run
     as ONE own kernel — Winograd F(2x2, 3x3) on the fp32 matrix cores, bias / ReLU in its epilogue (csrc/winograd_conv.hip:

@@ -30,6 +30,7 @@
  *                               mask2former/modeling/pixel_decoder/msdeformattn.py:262-270 (built), :343-349 (applied), and conv2 of
  *                               the R50 bottlenecks (detectron2 BottleneckBlock)
  *   dvis_conv3x3s2           <- the stride-2 3x3 convolutions of the R50 (conv2 of the first res3 / res4 / res5 bottleneck)
+ *   dvis_conv7x7s2           <- the 7x7 / stride 2 stem convolution of the R50 (detectron2 BasicStem.conv1)
  *   dvis_bias_relu_maxpool   <- FrozenBN shift + ReLU + max_pool2d(3, stride 2, padding 1) of the ResNet stem (detectron2 BasicStem)
  *   dvis_upsample_add        <- `cur_fpn + F.interpolate(out[-1], size=..., mode="bilinear")`, msdeformattn.py:347
  *   dvis_group_norm_affine / dvis_scale_shift_act / dvis_upsample_add_affine
@@ -243,6 +244,13 @@ int dvis_conv3x3_winograd_supported(int C, int K, int H, int W);
  * the weights in the MFMA operand layout (12 * K * C floats), written by dvis_conv3x3s2_pack.  Same shape rules (W even).
  */
 int dvis_conv3x3s2_supported(int C, int K, int H, int W);
+/*
+ * The ResNet stem: y (N, 64, H/2, W/2) = relu?(conv2d(x (N, 3, H, W), w (64, 3, 7, 7), stride 2, padding 3) + bias[k]), direct on
+ * the fp32 matrix cores (detectron2 BasicStem.conv1).  `uf` = 10 240 floats written by dvis_conv7x7s2_pack(w, uf).  H, W even.
+ */
+int dvis_conv7x7s2_supported(int C, int K, int H, int W);
+int dvis_conv7x7s2_pack(const float *w, float *uf, void *stream);
+int dvis_conv7x7s2(const float *x, const float *uf, const float *bias, float *y, int N, int H, int W, int relu, void *stream);
 int dvis_conv3x3s2_pack(const float *w, float *uf, int K, int C, void *stream);
 int dvis_conv3x3s2(const float *x, const float *uf, const float *bias, float *y, int N, int C, int K, int H, int W, int relu,
                    void *stream);

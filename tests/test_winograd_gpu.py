@@ -147,3 +147,25 @@ def test_conv3x3_stride2_res3_shape_and_refusals():
     assert not lib.dvis_conv3x3s2_supported(3, 64, 64, 64) and not lib.dvis_conv3x3s2_supported(64, 64, 64, 63)
     with pytest.raises(RuntimeError, match="not served"):
         Fn.conv3x3s2_bias_act(torch.zeros(1, 3, 64, 64, device="cuda"), torch.zeros(64, 3, 3, 3, device="cuda"), own=True)
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 64, 96), (1, 96, 160), (3, 16, 32), (2, 736, 1280)])
+@pytest.mark.parametrize("bias,relu", [(False, False), (True, True)])
+def test_stem_conv7x7_stride2_equals_fp64_convolution(N, H, W, bias, relu):
+    """csrc/conv7x7s2.hip (detectron2 BasicStem.conv1): all four borders (3 columns / rows of padding), workgroups that straddle
+    images, the 720p frame."""
+    from dvis_plus_amd import functions as Fn
+    g = torch.Generator(device="cuda").manual_seed(6)
+    x = torch.randn(N, 3, H, W, device="cuda", generator=g)
+    w = torch.randn(64, 3, 7, 7, device="cuda", generator=g) * 0.1
+    b = torch.randn(64, device="cuda", generator=g) if bias else None
+    got = Fn.conv7x7s2_stem(x, w, b, relu, own=True)
+    want = F.conv2d(x.double(), w.double(), None if b is None else b.double(), 2, 3)
+    want = want.relu() if relu else want
+    assert got.shape == want.shape
+    mag = float(F.conv2d(x.double().abs(), w.double().abs(), None, 2, 3).max())
+    err = float((got.double() - want).abs().max())
+    assert err <= 4 * 2.0 ** -24 * mag, (err, mag)
+    assert torch.equal(got, Fn.conv7x7s2_stem(x, w, b, relu, own=True))
+    with pytest.raises(RuntimeError, match="not served"):
+        Fn.conv7x7s2_stem(torch.zeros(1, 3, 33, 64, device="cuda"), w, own=True)

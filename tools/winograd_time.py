@@ -57,3 +57,11 @@ for name, C, K, H, W in [("res3 first conv2 128->128 @184x320 -> 92x160", 128, 1
     fl = 2.0 * 9 * C * K * (H // 2) * (W // 2) * N
     print(f"{name:48s} library + bias_act {t_lib:8.1f} us   own {t_own:8.1f} us  ({t_lib / t_own:4.2f}x)   own = {fl / t_own / 1e6:6.1f} TFLOP/s = "
           f"{fl / t_own / 1e6 / 157.3:.2f} of the MFMA peak")
+
+x = torch.randn(N, 3, 736, 1280, device=dev)
+w = torch.randn(64, 3, 7, 7, device=dev) * 0.1
+t_lib = timeit(lambda: F.conv2d(x, w, None, 2, 3))
+t_own = timeit(lambda: Fn.conv7x7s2_stem(x, w, own=True))
+fl = 2.0 * 147 * 64 * 368 * 640 * N
+print(f"stem 7x7 / 2, 3 -> 64 @736x1280 (csrc/conv7x7s2.hip)      library {t_lib:8.1f} us   own {t_own:8.1f} us  ({t_lib / t_own:4.2f}x)   own = {fl / t_own / 1e6:6.1f} TFLOP/s = "
+      f"{fl / t_own / 1e6 / 157.3:.2f} of the MFMA peak")
