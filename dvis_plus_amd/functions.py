@@ -668,7 +668,39 @@ def conv1x1_bias_act(x, weight, bias=None, res=None, relu=False):
                     1 if relu else 0, native.stream_ptr(x.device))
             native.check(rc, "dvis_conv1x1_bias_act")
             return out
+        if CONV1X1_MFMA and native.lib().dvis_conv1x1_mfma_supported(Ci, Co, H * W) and (res is None or res.shape == (N, Co, H, W)):
+            return conv1x1_mfma(x, weight, bias, res, relu)
     return bias_act_(conv1x1(x, weight), None if bias is None else bias.detach(), res, relu)
+
+
+CONV1X1_MFMA = os.environ.get("DVIS_CONV1X1_MFMA", "1") != "0"
+_C1_PACKED = {}
+
+
+def conv1x1_mfma(x, weight, bias=None, res=None, relu=False):
+    """relu?(conv1x1(x, weight) + bias[c] + res) for the compute-bound 1x1 layers (csrc/conv1x1_mfma.hip: C % 128 == 0, K % 64 == 0):
+    contraction, folded-BN shift, shortcut add and ReLU in one kernel instead of the library's batched GEMM + ``bias_act_``."""
+    N, Ci, H, W = x.shape
+    Co = weight.shape[0]
+    key = (weight._version, weight.data_ptr(), weight.device)
+    ent = _C1_PACKED.get(id(weight))
+    if ent is None or ent[0] != key:
+        w2 = weight.detach().reshape(Co, Ci).contiguous()
+        uf = ent[1] if ent is not None and ent[1].device == w2.device and ent[1].numel() == Co * Ci else torch.empty_like(w2)
+        with torch.cuda.device(w2.device):
+            native.check(native.lib().dvis_conv1x1_mfma_pack(native.dev_ptr(w2, "weight"), native.dev_ptr(uf, "uf"), Co, Ci,
+                                                             native.stream_ptr(w2.device)), "dvis_conv1x1_mfma_pack")
+        if len(_C1_PACKED) > 512:
+            _C1_PACKED.clear()
+        _C1_PACKED[id(weight)] = ent = (key, uf, weight)
+    out = torch.empty((N, Co, H, W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = native.lib().dvis_conv1x1_mfma(
+            native.dev_ptr(x, "x"), native.dev_ptr(ent[1], "uf"), None if bias is None else native.dev_ptr(bias.detach(), "bias"),
+            None if res is None else native.dev_ptr(res, "res"), native.dev_ptr(out, "out"), N, Ci, Co, H * W, 1 if relu else 0,
+            native.stream_ptr(x.device))
+    native.check(rc, "dvis_conv1x1_mfma")
+    return out
 
 
 WINOGRAD_DEFAULT = os.environ.get("DVIS_WINOGRAD", "1") != "0"

@@ -225,6 +225,15 @@ int dvis_nchw_to_tokens_affine(const float *x, const float *scale, const float *
  *   wider: K <= 128); other shapes return DVIS_E_ARG — the caller keeps the library contraction for them.
  */
 int dvis_conv1x1_supported(int K, int M, int64_t HW);
+/*
+ * The same operation for the COMPUTE-bound 1x1 layers (many input channels: C % 128 == 0, K % 64 == 0, HW even and >= 64): weights
+ * streamed through the MFMA operand layout `uf` (K * C floats, written by dvis_conv1x1_mfma_pack), 64 pixels x 64 output channels
+ * per workgroup.  y (N, K, HW) = relu?(w (K, C) x (N, C, HW) + bias[k] + res).
+ */
+int dvis_conv1x1_mfma_supported(int C, int K, int64_t HW);
+int dvis_conv1x1_mfma_pack(const float *w, float *uf, int K, int C, void *stream);
+int dvis_conv1x1_mfma(const float *x, const float *uf, const float *bias, const float *res, float *y, int N, int C, int K, int64_t HW,
+                      int relu, void *stream);
 int dvis_conv1x1_bias_act(const float *x, const float *w, const float *bias, const float *res, float *out,
                           int N, int K, int M, int64_t HW, int relu, void *stream);
 

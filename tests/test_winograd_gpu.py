@@ -169,3 +169,32 @@ def test_stem_conv7x7_stride2_equals_fp64_convolution(N, H, W, bias, relu):
     assert torch.equal(got, Fn.conv7x7s2_stem(x, w, b, relu, own=True))
     with pytest.raises(RuntimeError, match="not served"):
         Fn.conv7x7s2_stem(torch.zeros(1, 3, 33, 64, device="cuda"), w, own=True)
+
+
+@pytest.mark.parametrize("N,C,K,H,W", [
+    (2, 128, 64, 8, 8),           # one stage pair, 64 pixels per image
+    (3, 256, 128, 23, 40),        # workgroups straddle images (920 pixels each)
+    (2, 1024, 256, 46, 80),       # conv1 of a res4 bottleneck
+    (1, 512, 2048, 23, 40),       # conv3 of a res5 bottleneck (with the shortcut)
+])
+@pytest.mark.parametrize("bias,res,relu", [(False, False, False), (True, True, True)])
+def test_conv1x1_mfma_equals_fp64(N, C, K, H, W, bias, res, relu):
+    """csrc/conv1x1_mfma.hip: the compute-bound 1x1 layers + folded-BN shift + shortcut + ReLU in one kernel."""
+    from dvis_plus_amd import functions as Fn
+    g = torch.Generator(device="cuda").manual_seed(8)
+    x = torch.randn(N, C, H, W, device="cuda", generator=g)
+    w = torch.randn(K, C, 1, 1, device="cuda", generator=g) * (1.0 / C) ** 0.5
+    b = torch.randn(K, device="cuda", generator=g) if bias else None
+    r = torch.randn(N, K, H, W, device="cuda", generator=g) if res else None
+    got = Fn.conv1x1_mfma(x, w, b, r, relu)
+    want = F.conv2d(x.double(), w.double(), None if b is None else b.double())
+    want = want if r is None else want + r.double()
+    want = want.relu() if relu else want
+    mag = float(F.conv2d(x.double().abs(), w.double().abs()).max())
+    assert float((got.double() - want).abs().max()) <= 4 * 2.0 ** -24 * mag
+    assert torch.equal(got, Fn.conv1x1_mfma(x, w, b, r, relu))
+    # the dispatcher picks it for these shapes (conv1x1.hip does not serve them), and refuses what it cannot do
+    from dvis_plus_amd import native
+    assert native.lib().dvis_conv1x1_mfma_supported(C, K, H * W) and not native.lib().dvis_conv1x1_mfma_supported(64, 64, H * W)
+    with torch.no_grad():
+        assert torch.equal(Fn.conv1x1_bias_act(x, w, b, r, relu), got) or native.lib().dvis_conv1x1_supported(C, K, H * W)

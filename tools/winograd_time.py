@@ -65,3 +65,29 @@ t_own = timeit(lambda: Fn.conv7x7s2_stem(x, w, own=True))
 fl = 2.0 * 147 * 64 * 368 * 640 * N
 print(f"stem 7x7 / 2, 3 -> 64 @736x1280 (csrc/conv7x7s2.hip)      library {t_lib:8.1f} us   own {t_own:8.1f} us  ({t_lib / t_own:4.2f}x)   own = {fl / t_own / 1e6:6.1f} TFLOP/s = "
       f"{fl / t_own / 1e6 / 157.3:.2f} of the MFMA peak")
+
+print("compute-bound 1x1 layers (csrc/conv1x1_mfma.hip) against the library's batched GEMM + bias_act:")
+for name, C, K, H, W, with_res in [("res3 conv1 512->128 @92x160", 512, 128, 92, 160, False), ("res4 conv1 1024->256 @46x80", 1024, 256, 46, 80, False),
+                                   ("res4 conv3 256->1024 @46x80 (+shortcut)", 256, 1024, 46, 80, True), ("res5 conv1 2048->512 @23x40", 2048, 512, 23, 40, False),
+                                   ("res5 conv3 512->2048 @23x40 (+shortcut)", 512, 2048, 23, 40, True), ("res3 first conv1 256->128 @184x320", 256, 128, 184, 320, False)]:
+    x = torch.randn(N, C, H, W, device=dev)
+    w = torch.randn(K, C, 1, 1, device=dev) * 0.02
+    b = torch.randn(K, device=dev)
+    r = torch.randn(N, K, H, W, device=dev) if with_res else None
+    with torch.no_grad():
+        t_lib = timeit(lambda: Fn.bias_act_(Fn.conv1x1(x, w), b, r, True))
+        t_own = timeit(lambda: Fn.conv1x1_mfma(x, w, b, r, True))
+    fl = 2.0 * C * K * H * W * N
+    print(f"{name:44s} library + bias_act {t_lib:8.1f} us   own {t_own:8.1f} us  ({t_lib / t_own:4.2f}x)   own = {fl / t_own / 1e6:6.1f} TFLOP/s")
+
+print("memory-bound 1x1 layers: csrc/conv1x1.hip (weights on chip) against the streaming MFMA kernel:")
+for name, C, K, H, W, with_res in [("res2 conv1 256->64 @184x320", 256, 64, 184, 320, False), ("res3 conv1 (first) 256->128 @184x320", 256, 128, 184, 320, False),
+                                   ("res3 conv3 128->512 @92x160 (+shortcut)", 128, 512, 92, 160, True)]:
+    x = torch.randn(N, C, H, W, device=dev)
+    w = torch.randn(K, C, 1, 1, device=dev) * 0.02
+    b = torch.randn(K, device=dev)
+    r = torch.randn(N, K, H, W, device=dev) if with_res else None
+    with torch.no_grad():
+        t_a = timeit(lambda: Fn.conv1x1_bias_act(x, w, b, r, True))
+        t_b = timeit(lambda: Fn.conv1x1_mfma(x, w, b, r, True))
+    print(f"{name:44s} conv1x1_bias_act {t_a:8.1f} us   conv1x1_mfma {t_b:8.1f} us")
