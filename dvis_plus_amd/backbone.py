@@ -58,6 +58,9 @@ class ConvBN(nn.Conv2d):
         w, b = self.folded()
         if self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0):
             return Fn.conv1x1_bias_act(x, w, b, res, relu)
+        if self.kernel_size == (1, 1) and self.stride == (2, 2) and self.padding == (0, 0) and not key_is_channels_last(w) \
+                and Fn.conv1x1s2_supported(x, w) and (res is None or res.is_contiguous()):
+            return Fn.conv1x1_mfma(x, w, b, res, relu, stride=2)     # the down-sampling shortcut, read in place
         if self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) and res is None and x.is_cuda \
                 and not key_is_channels_last(w):
             return Fn.conv3x3_bias_act(x, w, b, relu)            # own Winograd kernel where the shape is served

@@ -22,7 +22,9 @@ struct C1Args {
   const float *x, *uf, *bias, *res;
   float *y;
   int N, C, K, relu, nsp;
-  long long HW, pixels;
+  int stride, W_in, OW;       // stride 2 (the shortcut of the first res3 / res4 / res5 bottleneck): output pixel (oy, ox) reads (2 oy, 2 ox)
+  long long HW, pixels;       // OUTPUT pixels per image / in total
+  long long HW_in;            // input pixels per image
 };
 
 __global__ __launch_bounds__(512, 2) void conv1x1_mfma_kernel(const C1Args a) {
@@ -37,7 +39,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_mfma_kernel(const C1Args a) {
   if (sp >= a.nsp) return;
   const long long p0 = (long long)sp * kPix;
   const int n0 = (int)(p0 / a.HW);
-  const long long img = a.HW * a.C;
+  const long long img = a.HW_in * a.C;
   const int nch = a.C / kCc;
 
   // load role: lane = pixel; the workgroup's pixels lie in images n0 and n0 + 1 (HW >= 64)
@@ -46,12 +48,17 @@ __global__ __launch_bounds__(512, 2) void conv1x1_mfma_kernel(const C1Args a) {
     const long long p = p0 + lane;
     const long long pi = p - (long long)n0 * a.HW;
     const int nn = (int)(pi / a.HW);
-    off = p < a.pixels ? (unsigned)(((long long)nn * img + (pi - (long long)nn * a.HW)) * 4) : kOOB;
+    long long in_pix = pi - (long long)nn * a.HW;
+    if (a.stride == 2) {   // (wave-uniform)
+      const int oy = (int)(in_pix / a.OW), ox = (int)(in_pix - (long long)oy * a.OW);
+      in_pix = 2ll * oy * a.W_in + 2 * ox;
+    }
+    off = p < a.pixels ? (unsigned)(((long long)nn * img + in_pix) * 4) : kOOB;
   }
   const int n_here = min(2, a.N - n0);
   const __amdgpu_buffer_rsrc_t rx = dvis_make_rsrc_uniform(a.x + (long long)n0 * img, (unsigned)(n_here * img * 4));
   const __amdgpu_buffer_rsrc_t ru = dvis_make_rsrc_uniform(a.uf, (unsigned)((long long)a.K * a.C * 4));
-  const unsigned plane_bytes = (unsigned)(a.HW * 4);
+  const unsigned plane_bytes = (unsigned)(a.HW_in * 4);
   const unsigned u_lane = (unsigned)lane * 16u;
   const unsigned u_blk = (unsigned)((kb * 4 + kb16) * nch);
 
@@ -183,6 +190,10 @@ DVIS_EXPORT int dvis_conv1x1_mfma_pack(const float *w, float *uf, int K, int C, 
   return dvis_check_launch("dvis_conv1x1_mfma_pack");
 }
 
+namespace {
+int launch_c1(C1Args a, void *stream);
+}
+
 DVIS_EXPORT int dvis_conv1x1_mfma(const float *x, const float *uf, const float *bias, const float *res, float *y, int N, int C, int K,
                                   int64_t HW, int relu, void *stream) {
   DVIS_REQUIRE(N >= 0, "conv1x1_mfma: bad batch");
@@ -193,7 +204,31 @@ DVIS_EXPORT int dvis_conv1x1_mfma(const float *x, const float *uf, const float *
   DVIS_REQUIRE((((uintptr_t)x | (uintptr_t)uf | (uintptr_t)y | (uintptr_t)res) & 15) == 0, "conv1x1_mfma: 16-byte aligned tensors");
   C1Args a;
   a.x = x, a.uf = uf, a.bias = bias, a.res = res, a.y = y;
-  a.N = N, a.C = C, a.K = K, a.relu = relu, a.HW = HW;
+  a.N = N, a.C = C, a.K = K, a.relu = relu, a.HW = HW, a.HW_in = HW, a.stride = 1, a.W_in = 0, a.OW = 0;
+  return launch_c1(a, stream);
+}
+
+// stride 2: y (N, K, ceil(H/2), ceil(W/2)) = relu?(w (K, C) x[:, :, ::2, ::2] + bias[k] + res)
+DVIS_EXPORT int dvis_conv1x1s2_mfma(const float *x, const float *uf, const float *bias, const float *res, float *y, int N, int C, int K,
+                                    int H, int W, int relu, void *stream) {
+  DVIS_REQUIRE(N >= 0 && H > 0 && W > 0, "conv1x1s2_mfma: bad sizes");
+  if (N == 0) return DVIS_OK;
+  DVIS_REQUIRE(x && uf && y, "conv1x1s2_mfma: null pointer");
+  const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+  DVIS_REQUIRE(dvis_conv1x1_mfma_supported(C, K, (int64_t)OH * OW) && 2ll * C * H * W * 4 < (1ll << 31),
+               "conv1x1s2_mfma: unsupported shape C=%d K=%d H=%d W=%d (dvis_conv1x1_mfma_supported on the output size)", C, K, H, W);
+  DVIS_REQUIRE((((uintptr_t)x | (uintptr_t)uf | (uintptr_t)y | (uintptr_t)res) & 15) == 0, "conv1x1s2_mfma: 16-byte aligned tensors");
+  C1Args a;
+  a.x = x, a.uf = uf, a.bias = bias, a.res = res, a.y = y;
+  a.N = N, a.C = C, a.K = K, a.relu = relu, a.HW = (long long)OH * OW, a.HW_in = (long long)H * W, a.stride = 2, a.W_in = W, a.OW = OW;
+  return launch_c1(a, stream);
+}
+
+namespace {
+int launch_c1(C1Args a, void *stream) {
+  const int K = a.K;
+  const long long HW = a.HW;
+  const int N = a.N;
   a.pixels = (long long)N * HW;
   const long long nsp = (a.pixels + kPix - 1) / kPix;
   DVIS_REQUIRE(nsp * (K / kKw) + 8 * (K / kKw) < (1ll << 31), "conv1x1_mfma: grid too large");
@@ -202,3 +237,4 @@ DVIS_EXPORT int dvis_conv1x1_mfma(const float *x, const float *uf, const float *
   hipLaunchKernelGGL(conv1x1_mfma_kernel, dim3(grid), dim3(512), 2 * kStage * sizeof(float), (hipStream_t)stream, a);
   return dvis_check_launch("dvis_conv1x1_mfma");
 }
+}  // namespace

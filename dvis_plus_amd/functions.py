@@ -677,9 +677,18 @@ CONV1X1_MFMA = os.environ.get("DVIS_CONV1X1_MFMA", "1") != "0"
 _C1_PACKED = {}
 
 
-def conv1x1_mfma(x, weight, bias=None, res=None, relu=False):
+def conv1x1s2_supported(x, weight):
+    """Is the stride-2 1x1 convolution of x (the shortcut of a down-sampling bottleneck) served by csrc/conv1x1_mfma.hip?"""
+    N, Ci, H, W = x.shape
+    return CONV1X1_MFMA and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and not torch.is_grad_enabled() \
+        and bool(native.lib().dvis_conv1x1_mfma_supported(Ci, weight.shape[0], ((H + 1) // 2) * ((W + 1) // 2))) \
+        and 2 * Ci * H * W * 4 < 2 ** 31
+
+
+def conv1x1_mfma(x, weight, bias=None, res=None, relu=False, stride=1):
     """relu?(conv1x1(x, weight) + bias[c] + res) for the compute-bound 1x1 layers (csrc/conv1x1_mfma.hip: C % 128 == 0, K % 64 == 0):
-    contraction, folded-BN shift, shortcut add and ReLU in one kernel instead of the library's batched GEMM + ``bias_act_``."""
+    contraction, folded-BN shift, shortcut add and ReLU in one kernel instead of the library's batched GEMM + ``bias_act_``.
+    stride=2: the same on x[:, :, ::2, ::2] (read in place)."""
     N, Ci, H, W = x.shape
     Co = weight.shape[0]
     key = (weight._version, weight.data_ptr(), weight.device)
@@ -693,6 +702,15 @@ def conv1x1_mfma(x, weight, bias=None, res=None, relu=False):
         if len(_C1_PACKED) > 512:
             _C1_PACKED.clear()
         _C1_PACKED[id(weight)] = ent = (key, uf, weight)
+    if stride == 2:
+        out = torch.empty((N, Co, (H + 1) // 2, (W + 1) // 2), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = native.lib().dvis_conv1x1s2_mfma(
+                native.dev_ptr(x, "x"), native.dev_ptr(ent[1], "uf"), None if bias is None else native.dev_ptr(bias.detach(), "bias"),
+                None if res is None else native.dev_ptr(res, "res"), native.dev_ptr(out, "out"), N, Ci, Co, H, W, 1 if relu else 0,
+                native.stream_ptr(x.device))
+        native.check(rc, "dvis_conv1x1s2_mfma")
+        return out
     out = torch.empty((N, Co, H, W), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         rc = native.lib().dvis_conv1x1_mfma(

@@ -50,6 +50,7 @@ SIGNATURES = {
     "dvis_conv1x1_mfma_supported": (_i, [_i, _i, _i64]),
     "dvis_conv1x1_mfma_pack": (_i, [_p, _p, _i, _i, _p]),
     "dvis_conv1x1_mfma": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i64, _i, _p]),
+    "dvis_conv1x1s2_mfma": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "dvis_conv1x1_supported": (_i, [_i, _i, _i64]),
     "dvis_conv1x1_bias_act": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i64, _i, _p]),
     "dvis_bias_relu_maxpool": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p]),

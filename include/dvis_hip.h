@@ -234,6 +234,10 @@ int dvis_conv1x1_mfma_supported(int C, int K, int64_t HW);
 int dvis_conv1x1_mfma_pack(const float *w, float *uf, int K, int C, void *stream);
 int dvis_conv1x1_mfma(const float *x, const float *uf, const float *bias, const float *res, float *y, int N, int C, int K, int64_t HW,
                       int relu, void *stream);
+/* stride 2 (the 1x1 shortcut of the first res3 / res4 / res5 bottleneck): y (N, K, ceil(H/2), ceil(W/2)) = relu?(w x[:, :, ::2, ::2] + bias + res);
+ * served when dvis_conv1x1_mfma_supported(C, K, ceil(H/2) * ceil(W/2)) and 2 input images stay below 2 GiB. */
+int dvis_conv1x1s2_mfma(const float *x, const float *uf, const float *bias, const float *res, float *y, int N, int C, int K, int H, int W,
+                        int relu, void *stream);
 int dvis_conv1x1_bias_act(const float *x, const float *w, const float *bias, const float *res, float *out,
                           int N, int K, int M, int64_t HW, int relu, void *stream);
 

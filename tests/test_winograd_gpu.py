@@ -198,3 +198,21 @@ def test_conv1x1_mfma_equals_fp64(N, C, K, H, W, bias, res, relu):
     assert native.lib().dvis_conv1x1_mfma_supported(C, K, H * W) and not native.lib().dvis_conv1x1_mfma_supported(64, 64, H * W)
     with torch.no_grad():
         assert torch.equal(Fn.conv1x1_bias_act(x, w, b, r, relu), got) or native.lib().dvis_conv1x1_supported(C, K, H * W)
+
+
+@pytest.mark.parametrize("N,C,K,H,W", [(2, 256, 512, 46, 80), (3, 128, 64, 17, 22), (1, 1024, 2048, 46, 80)])
+def test_conv1x1_stride2_mfma_equals_fp64(N, C, K, H, W):
+    """The down-sampling 1x1 shortcut (stride 2) read in place by csrc/conv1x1_mfma.hip."""
+    from dvis_plus_amd import functions as Fn
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randn(N, C, H, W, device="cuda", generator=g)
+    w = torch.randn(K, C, 1, 1, device="cuda", generator=g) * (1.0 / C) ** 0.5
+    b = torch.randn(K, device="cuda", generator=g)
+    with torch.no_grad():
+        if not Fn.conv1x1s2_supported(x, w):
+            pytest.skip("odd output pixel count")
+        got = Fn.conv1x1_mfma(x, w, b, None, False, stride=2)
+    want = F.conv2d(x.double(), w.double(), b.double(), 2)
+    assert got.shape == want.shape
+    mag = float(F.conv2d(x.double().abs(), w.double().abs(), None, 2).max())
+    assert float((got.double() - want).abs().max()) <= 4 * 2.0 ** -24 * mag
