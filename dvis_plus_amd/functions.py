@@ -636,6 +636,10 @@ def conv1x1(x, weight, bias=None):
     MI355X at the R50 / pixel-decoder shapes (tools/conv1x1_probe.py): 256->64 @184x320 1.10 -> 0.56 ms, 64->64
     0.55 -> 0.24 ms, 2048->256 0.32 -> 0.25 ms; channel-expanding ones are faster through MIOpen and stay there."""
     Co, Ci = weight.shape[:2]
+    if bias is not None and CONV1X1_MFMA and x.is_cuda and x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32 \
+            and weight.dtype == torch.float32 and not torch.is_grad_enabled() \
+            and native.lib().dvis_conv1x1_mfma_supported(Ci, Co, x.shape[2] * x.shape[3]):
+        return conv1x1_mfma(x, weight, bias)          # contraction + bias in one kernel (the pixel decoder's input projections)
     if x.is_cuda and Ci >= Co and x.is_contiguous() and x.dim() == 4 and x.dtype == weight.dtype \
             and not torch.is_grad_enabled():
         N, _, H, W = x.shape
