@@ -27,13 +27,14 @@ struct C1Args {
   long long HW_in;            // input pixels per image
 };
 
+template <int KW>   // 16-channel blocks per wave: a workgroup covers 64 * KW output channels
 __global__ __launch_bounds__(512, 2) void conv1x1_mfma_kernel(const C1Args a) {
   extern __shared__ float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4;
   const int kb16 = wv & 3, half = wv >> 2;
-  const int KB = a.K / kKw;
+  const int KB = a.K / (kKw * KW);
   const int grp = blockIdx.x / (8 * KB), rem = blockIdx.x - grp * 8 * KB;   // channel blocks of one pixel group: same XCD
   const int kb = rem >> 3, sp = grp * 8 + (rem & 7);
   if (sp >= a.nsp) return;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_mfma_kernel(const C1Args a) {
   const __amdgpu_buffer_rsrc_t ru = dvis_make_rsrc_uniform(a.uf, (unsigned)((long long)a.K * a.C * 4));
   const unsigned plane_bytes = (unsigned)(a.HW_in * 4);
   const unsigned u_lane = (unsigned)lane * 16u;
-  const unsigned u_blk = (unsigned)((kb * 4 + kb16) * nch);
+  const unsigned u_blk = (unsigned)((kb * 4 * KW + kb16) * nch);   // (+ 4 nch per further block of the wave)
 
   auto load_d = [&](int ch, float (&d)[8]) {
     const unsigned so = (unsigned)(ch * kCc + wv * 8) * plane_bytes;
@@ -68,11 +69,14 @@ __global__ __launch_bounds__(512, 2) void conv1x1_mfma_kernel(const C1Args a) {
     for (int i = 0; i < 8; ++i)
       d[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, so + (unsigned)i * plane_bytes, 0));
   };
-  auto load_u = [&](int ch, dvis_f4 (&u)[2]) {
-    const unsigned so = ((u_blk + (unsigned)ch) * 2u + (unsigned)half) * 2048u;
+  auto load_u = [&](int ch, dvis_f4 (&u)[KW][2]) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
-      u[q] = __builtin_bit_cast(dvis_f4, __builtin_amdgcn_raw_buffer_load_b128(ru, u_lane + 1024u * q, so, 0));
+    for (int w = 0; w < KW; ++w) {
+      const unsigned so = ((u_blk + (unsigned)(4 * w * nch) + (unsigned)ch) * 2u + (unsigned)half) * 2048u;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        u[w][q] = __builtin_bit_cast(dvis_f4, __builtin_amdgcn_raw_buffer_load_b128(ru, u_lane + 1024u * q, so, 0));
+    }
   };
   auto store_rows = [&](const float (&d)[8], float *stage) {
     float *vw = stage + (wv * 8) * kPix + lane;
@@ -80,20 +84,25 @@ __global__ __launch_bounds__(512, 2) void conv1x1_mfma_kernel(const C1Args a) {
     for (int i = 0; i < 8; ++i) vw[i * kPix] = d[i];
   };
 
-  dvis_f4 acc[4];
+  dvis_f4 acc[KW][4];
 #pragma unroll
-  for (int tb = 0; tb < 4; ++tb) acc[tb] = dvis_f4{0.f, 0.f, 0.f, 0.f};
+  for (int w = 0; w < KW; ++w)
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) acc[w][tb] = dvis_f4{0.f, 0.f, 0.f, 0.f};
   auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
-  auto stage = [&](const float *cur, const dvis_f4 (&u)[2], float *nxt, float (&d)[8], int ch_load) {
+  auto stage = [&](const float *cur, const dvis_f4 (&u)[KW][2], float *nxt, float (&d)[8], int ch_load) {
     const dvis_f4 *vr = reinterpret_cast<const dvis_f4 *>(cur + (half * 32 + g) * kPix + 4 * j);
     dvis_f4 b[2];
     b[0] = vr[0];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       if (s + 1 < 8) b[(s + 1) & 1] = vr[(s + 1) * kPix];
-      const float av = u[s >> 2][s & 3];
 #pragma unroll
-      for (int tb = 0; tb < 4; ++tb) acc[tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[s & 1][tb], acc[tb], 0, 0, 0);
+      for (int w = 0; w < KW; ++w) {
+        const float av = u[w][s >> 2][s & 3];
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) acc[w][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[s & 1][tb], acc[w][tb], 0, 0, 0);
+      }
       if (s == 2) {
         store_rows(d, nxt);
         load_d(ch_load, d);
@@ -104,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_mfma_kernel(const C1Args a) {
 
   float *s0 = lds, *s1 = lds + kStage;
   float d[8], d2[8];
-  dvis_f4 ua[2], ub[2];
+  dvis_f4 ua[KW][2], ub[KW][2];
   load_u(0, ua);
   load_d(0, d);
   store_rows(d, s0);
@@ -130,33 +139,38 @@ __global__ __launch_bounds__(512, 2) void conv1x1_mfma_kernel(const C1Args a) {
   // ---- the halves' partial sums through LDS; half h stores accumulator tiles 2 h, 2 h + 1 (pixels 4 j + tb)
   __syncthreads();
   {
-    float *ex = lds + (((1 - half) * 4 + kb16) * 2) * 4 * 64 + lane;
+    float *ex = lds + (((1 - half) * 4 * KW + kb16 * KW) * 2) * 4 * 64 + lane;   // [dst half][kb16][w][t2][r][lane]
 #pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2)
+    for (int w = 0; w < KW; ++w)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ex[(t2 * 4 + r) * 64] = half ? acc[t2][r] : acc[2 + t2][r];
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ex[((w * 2 + t2) * 4 + r) * 64] = half ? acc[w][t2][r] : acc[w][2 + t2][r];
   }
   __syncthreads();
-  const float *ex = lds + ((half * 4 + kb16) * 2) * 4 * 64 + lane;
-  const int k0 = kb * kKw + kb16 * 16 + 4 * g;
+  const float *ex = lds + ((half * 4 * KW + kb16 * KW) * 2) * 4 * 64 + lane;
   const long long pa = p0 + 4 * j + 2 * half;
   if (pa >= a.pixels) return;   // (pixels even: HW even)
   const int n = (int)(pa / a.HW);
   const long long rr = pa - (long long)n * a.HW;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const long long o_idx = ((long long)n * a.K + k0 + r) * a.HW + rr;
-    float2 rv = make_float2(0.f, 0.f);
-    if (a.res) rv = *reinterpret_cast<const float2 *>(a.res + o_idx);
-    const float bv = a.bias ? a.bias[k0 + r] : 0.f;
-    float o[2];
+  for (int w = 0; w < KW; ++w) {
+    const int k0 = kb * kKw * KW + (4 * w + kb16) * 16 + 4 * g;
 #pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2) {
-      const float mine = half ? acc[2 + t2][r] : acc[t2][r], other = ex[(t2 * 4 + r) * 64];
-      const float v = (half ? other + mine : mine + other) + bv + (t2 ? rv.y : rv.x);
-      o[t2] = a.relu ? fmaxf(v, 0.f) : v;
+    for (int r = 0; r < 4; ++r) {
+      const long long o_idx = ((long long)n * a.K + k0 + r) * a.HW + rr;
+      float2 rv = make_float2(0.f, 0.f);
+      if (a.res) rv = *reinterpret_cast<const float2 *>(a.res + o_idx);
+      const float bv = a.bias ? a.bias[k0 + r] : 0.f;
+      float o[2];
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const float mine = half ? acc[w][2 + t2][r] : acc[w][t2][r], other = ex[((w * 2 + t2) * 4 + r) * 64];
+        const float v = (half ? other + mine : mine + other) + bv + (t2 ? rv.y : rv.x);
+        o[t2] = a.relu ? fmaxf(v, 0.f) : v;
+      }
+      *reinterpret_cast<float2 *>(a.y + o_idx) = make_float2(o[0], o[1]);
     }
-    *reinterpret_cast<float2 *>(a.y + o_idx) = make_float2(o[0], o[1]);
   }
 }
 
@@ -233,8 +247,15 @@ int launch_c1(C1Args a, void *stream) {
   const long long nsp = (a.pixels + kPix - 1) / kPix;
   DVIS_REQUIRE(nsp * (K / kKw) + 8 * (K / kKw) < (1ll << 31), "conv1x1_mfma: grid too large");
   a.nsp = (int)nsp;
-  const unsigned grid = (unsigned)(((nsp + 7) / 8) * 8 * (K / kKw));
-  hipLaunchKernelGGL(conv1x1_mfma_kernel, dim3(grid), dim3(512), 2 * kStage * sizeof(float), (hipStream_t)stream, a);
+  // 128 output channels per workgroup for the long contractions: an input stage is fetched and staged once per 128 instead of 64
+  // channels (measured: 512 -> 2048 523 -> 491 us, 2048 -> 512 436 -> 425; at C = 256 the two-pair loop is too short for it: 591 -> 614)
+  if (K % (2 * kKw) == 0 && a.C >= 512) {
+    const unsigned grid = (unsigned)(((nsp + 7) / 8) * 8 * (K / (2 * kKw)));
+    hipLaunchKernelGGL(conv1x1_mfma_kernel<2>, dim3(grid), dim3(512), 2 * kStage * sizeof(float), (hipStream_t)stream, a);
+  } else {
+    const unsigned grid = (unsigned)(((nsp + 7) / 8) * 8 * (K / kKw));
+    hipLaunchKernelGGL(conv1x1_mfma_kernel<1>, dim3(grid), dim3(512), 2 * kStage * sizeof(float), (hipStream_t)stream, a);
+  }
   return dvis_check_launch("dvis_conv1x1_mfma");
 }
 }  // namespace
