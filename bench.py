@@ -424,7 +424,7 @@ def main():
         # frames of those clips are one segmenter batch — the replicated recurrence is otherwise the critical path.  Per rank,
         # measured on one GPU with the collective replaced by a copy (tools/rank_emulation.py, profiles/r03_rank_emulation*):
         # 4 ranks 0.65 / 0.72 / 0.77 of linear at 1 / 2 / 4 clips per round, 8 ranks 0.47 / 0.56 / 0.61; 2 ranks 0.86 / 0.92 / 0.92
-        model.tracker_batch = 4 if world >= 4 else 2
+        model.tracker_batch = 4      # (final commit: 2 ranks 0.81 / 0.90 / 0.92, 4 ranks 0.61 / 0.71 / 0.77, 8 ranks 0.44 / 0.55 / 0.62)
     dt, outs, lat, timer, warm_clips = timed(owner_rounds=False if world > 1 else owner_default)
     owner_line = None
     if world > 1 and streamed and owner_default:
