@@ -56,3 +56,21 @@ def test_bench_warmup_replays_the_round_structure_of_the_timed_pass():
     # replicated tracker with two clips per round: a full round, plus the 1-clip round an odd step count ends with
     assert bench.warmup_clip_count(2, 10, 8, False, True, tracker_batch=2) == 2
     assert bench.warmup_clip_count(2, 5, 8, False, True, tracker_batch=2) == 3
+
+
+def test_convolution_wrappers_keep_torch_semantics_on_cpu_tensors():
+    """The own convolution kernels are GPU-only; the wrappers around them (functions.conv3x3_bias_act, conv3x3s2_bias_act,
+    conv7x7s2_stem) give CPU tensors to torch's convolution + the same epilogue, and `own=True` refuses instead of falling back."""
+    import pytest
+    import torch
+    import torch.nn.functional as F
+    from dvis_plus_amd import functions as Fn
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 16, 12, 14, generator=g)
+    w = torch.randn(64, 16, 3, 3, generator=g) * 0.1
+    b = torch.randn(64, generator=g)
+    torch.testing.assert_close(Fn.conv3x3_bias_act(x, w, b, True), F.relu(F.conv2d(x, w, b, 1, 1)))
+    torch.testing.assert_close(Fn.conv3x3s2_bias_act(x, w, b, True), F.relu(F.conv2d(x, w, b, 2, 1)))
+    xs = torch.randn(1, 3, 16, 20, generator=g)
+    ws = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    torch.testing.assert_close(Fn.conv7x7s2_stem(xs, ws), F.conv2d(xs, ws, None, 2, 3))
