@@ -12,7 +12,7 @@ resident in HBM (step i gets its own clip, seed 1234 + i)
 mask contraction -> panoptic post-processing to integer masks on the device.  With N GPUs the SAME clips are sharded by
 frame (strong scaling); value = T * K / max-over-ranks(wall time).  Weights: deterministic random init with the
 reference's init rules (no checkpoints offline).  fp32 throughout (the parity target is the fp32 path).  The timed pass
-runs under DVIS_STRICT=1: a glue op that would quietly take a torch formulation on the GPU raises instead.
+runs in the product's default strict mode: a glue op that would quietly take a torch formulation on the GPU raises instead.
 
 N > 1: `value` is north_star's split (frames sharded, ONE all-gather of the per-frame queries per clip, tracker + refiner
 replicated); `owner_rounds` holds a second timed pass with stream()'s tracker-owner rounds; `dist` lists world size,
@@ -301,7 +301,6 @@ def main():
     # a hung collective must not hang the box: dump every thread's Python stack and exit after this many seconds
     import faulthandler
     faulthandler.dump_traceback_later(int(os.environ.get("DVIS_BENCH_WATCHDOG", "1500")), exit=True)
-    os.environ.setdefault("DVIS_STRICT", "1")      # a glue op that would quietly run torch ops on the GPU raises instead
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist_on = world > 1 or os.environ.get("DVIS_FORCE_COLLECTIVES") == "1"   # dev aid: RCCL calls on a single rank

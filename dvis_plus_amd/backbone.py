@@ -56,18 +56,28 @@ class ConvBN(nn.Conv2d):
     def forward(self, x, res=None, relu=False):
         """conv (MIOpen, no bias) then ONE fused pass: + folded-BN shift (+ residual) (+ ReLU)."""
         w, b = self.folded()
-        if self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0):
+        plain = self.dilation == (1, 1) and self.groups == 1      # the own kernels (and their library fallbacks) are dense, un-dilated
+        if plain and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0):
             return Fn.conv1x1_bias_act(x, w, b, res, relu)
-        if self.kernel_size == (1, 1) and self.stride == (2, 2) and self.padding == (0, 0) and not key_is_channels_last(w) \
-                and Fn.conv1x1s2_supported(x, w) and (res is None or res.is_contiguous()):
+        if plain and self.kernel_size == (1, 1) and self.stride == (2, 2) and self.padding == (0, 0) and not key_is_channels_last(w) \
+                and Fn.conv1x1s2_supported(x, w) and _res_ok(res, x, w.shape[0], 2):
             return Fn.conv1x1_mfma(x, w, b, res, relu, stride=2)     # the down-sampling shortcut, read in place
-        if self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) and res is None and x.is_cuda \
+        if plain and self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) and res is None and x.is_cuda \
                 and not key_is_channels_last(w):
             return Fn.conv3x3_bias_act(x, w, b, relu)            # own Winograd kernel where the shape is served
-        if self.kernel_size == (3, 3) and self.stride == (2, 2) and self.padding == (1, 1) and res is None and x.is_cuda \
+        if plain and self.kernel_size == (3, 3) and self.stride == (2, 2) and self.padding == (1, 1) and res is None and x.is_cuda \
                 and not key_is_channels_last(w):
             return Fn.conv3x3s2_bias_act(x, w, b, relu)          # own direct kernel where it beats the library
-        return Fn.bias_act_(F.conv2d(x, w, None, self.stride, self.padding), b, res, relu)
+        return Fn.bias_act_(F.conv2d(x, w, None, self.stride, self.padding, self.dilation, self.groups), b, res, relu)
+
+
+def _res_ok(res, x, Co, stride):
+    """None, or a contiguous float32 residual of exactly the strided convolution's output shape."""
+    if res is None:
+        return True
+    N, _, H, W = x.shape
+    return res.is_contiguous() and res.dtype == torch.float32 and \
+        tuple(res.shape) == (N, Co, (H + stride - 1) // stride, (W + stride - 1) // stride)
 
 
 def key_is_channels_last(w):

@@ -84,6 +84,19 @@ class ClipShard:
             dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
         return x
 
+    def check_replicas(self, tensors, what):
+        """Debug guard for REPLICATED results (DVIS_CHECK_REPLICAS=1; off by default: it adds a collective and a host
+        sync per clip): the replicated tracker + refiner must produce the same BITS on every rank — the post-processing
+        collectives are sized from decisions taken on them, so a divergence would surface as an RCCL hang, not an error.
+        All-gathers a per-tensor checksum of the raw bit patterns and raises on the first rank that disagrees."""
+        if not ((self.world > 1 or self.force) and os.environ.get("DVIS_CHECK_REPLICAS") == "1"):
+            return
+        sums = torch.stack([t.detach().contiguous().view(torch.int32).to(torch.int64).sum() for t in tensors if t is not None])
+        rows = self.all_gather_rows(sums).cpu()
+        bad = (rows != rows[0:1]).any(1).nonzero().flatten().tolist()
+        if bad:
+            raise RuntimeError(f"replicated {what} differ between rank 0 and rank(s) {bad}: checksums {rows.tolist()}")
+
     def broadcast_from_rank0(self, tensors):
         """Make small decision inputs bit-identical on every rank.  (Rounds 1-2 broadcast the replicated tracker's class
         logits because its library GEMMs could pick different algorithms per rank; since round 3 the tracker / refiner run
@@ -125,6 +138,9 @@ class EmulatedShard(ClipShard):
 
     def all_reduce_sum(self, x):
         return x
+
+    def check_replicas(self, tensors, what):
+        return
 
     def broadcast_from_rank0(self, tensors):
         return tensors

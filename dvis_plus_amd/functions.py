@@ -11,6 +11,7 @@ unchanged.  Differences, all deliberate:
 """
 import ctypes
 import os
+import threading
 
 import torch
 from torch.autograd import Function
@@ -22,10 +23,10 @@ from . import native
 def _torch_path(op, x, why):
     """Called where a fused glue op is about to take its torch formulation instead of the HIP kernel.  That is the right
     thing for CPU tensors (host-logic tests) and under autograd (the kernels are inference-only), and otherwise a shape /
-    layout the kernel does not serve.  With DVIS_STRICT=1 the latter raises instead of silently running torch ops on the
-    GPU — the invisible dual path the reference has in ops/modules/ms_deform_attn.py:116-121.  The GPU test suite runs
-    with it (tests/conftest.py)."""
-    if os.environ.get("DVIS_STRICT", "0") == "1" and x.is_cuda and not torch.is_grad_enabled():
+    layout the kernel does not serve.  The latter RAISES (the default) instead of silently running torch ops on the GPU —
+    the invisible dual path the reference has in ops/modules/ms_deform_attn.py:116-121.  DVIS_STRICT=0 is the explicit
+    opt-out (odd research shapes: the torch formulation then runs, on the GPU)."""
+    if os.environ.get("DVIS_STRICT", "1") != "0" and x.is_cuda and not torch.is_grad_enabled():
         raise RuntimeError(f"DVIS_STRICT: {op} would run its torch formulation on a GPU tensor ({why}; shape "
                            f"{tuple(x.shape)}, dtype {x.dtype}, contiguous {x.is_contiguous()})")
 
@@ -482,23 +483,28 @@ class gemm_sizes_as:
     """Inside this context dvis_gemm_nt picks its tile configuration as if the problem had `rows` rows (and `batch` batch
     entries), whatever the actual operand has.  A row's result depends on (N, K, configuration) only, so the tracker gets
     the SAME bits for a clip whether its recurrence runs alone (Q rows per GEMM) or stacked with another clip's (2Q rows)."""
-    _rows, _batch = None, None
+    _tls = threading.local()      # per thread: stream()'s phase-B worker thread must not re-size the main thread's GEMMs
 
     def __init__(self, rows=None, batch=None):
         self.rows, self.batch = rows, batch
 
+    @staticmethod
+    def current():
+        return getattr(gemm_sizes_as._tls, "pin", (None, None))
+
     def __enter__(self):
-        self.prev = (gemm_sizes_as._rows, gemm_sizes_as._batch)
-        gemm_sizes_as._rows, gemm_sizes_as._batch = self.rows, self.batch
+        self.prev = gemm_sizes_as.current()
+        gemm_sizes_as._tls.pin = (self.rows, self.batch)
 
     def __exit__(self, *exc):
-        gemm_sizes_as._rows, gemm_sizes_as._batch = self.prev
+        gemm_sizes_as._tls.pin = self.prev
 
 
 def _gemm_config(M, N, K, batch, config):
-    if config >= 0 or (gemm_sizes_as._rows is None and gemm_sizes_as._batch is None):
+    rows, b = gemm_sizes_as.current()
+    if config >= 0 or (rows is None and b is None):
         return config
-    return native.lib().dvis_gemm_pick_config(gemm_sizes_as._rows or M, N, K, gemm_sizes_as._batch or batch)
+    return native.lib().dvis_gemm_pick_config(rows or M, N, K, b or batch)
 
 
 def _rows2d(x, K):
@@ -577,10 +583,17 @@ def linear(x, weight, bias=None, relu=False, own=None):
     """``F.linear`` (+ optional ReLU).  own=True: the deterministic own kernel (tracker / refiner call sites); own=None:
     OWN_GEMM_DEFAULT decides; otherwise the library GEMM — with a bias the ReLU then runs as the GEMM's epilogue
     (hipBLASLt via torch._addmm_activation) instead of a second pass.  CPU tensors / autograd always take torch ops."""
+    forced = own is True
     own = OWN_GEMM_DEFAULT if own is None else own
     if own and x.is_cuda and not torch.is_grad_enabled():
         if _own_gemm_ok(x, weight):
             return gemm_nt(x, weight.detach(), None if bias is None else bias.detach(), relu=relu)
+        if forced:
+            # tracker / refiner call sites: their stream must NEVER carry a library (stream-K) GEMM and every rank must
+            # compute the same bits — a refused operand is an error whatever DVIS_STRICT says (as in gemm_nt itself)
+            raise RuntimeError(f"linear(own=True): the own GEMM cannot serve these operands (needs fp32, K % 4 == 0, 16-byte "
+                               f"aligned operands, weight row stride % 4 == 0; x {tuple(x.shape)} {x.dtype}, weight "
+                               f"{tuple(weight.shape)} {weight.dtype} stride {tuple(weight.stride())})")
         _torch_path("linear(own GEMM)", x, "needs fp32, K % 4 == 0 and 16-byte aligned operands")
     if relu and bias is not None and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled():
         K = x.shape[-1]

@@ -470,6 +470,7 @@ class DVIS_Plus_offline(_VideoBase):
         # — same bits on every rank, so the post-processing decisions agree.  north_star's "single all-gather" is
         # literally that (+ the few-hundred-byte VPS area sum).
         mask_embed, cls, aux = self._track_core(embds, embds_nn)
+        self.clip_shard.check_replicas([mask_embed, cls, aux], "tracker / refiner results")   # DVIS_CHECK_REPLICAS=1 only
         return self._finish_phase(st, mask_embed, cls, aux)
 
     def _resume_of(self, st):
@@ -490,6 +491,8 @@ class DVIS_Plus_offline(_VideoBase):
         embds_nn = torch.cat([to_bctq(g[1]) for g in gathered], 0)
         track = self.tracker(embds, None, resume=False, frame_embeds_no_norm=embds_nn, need_masks=False)
         ref = self.refiner(track["pred_embds"], embds_nn, None, need_masks=False)      # ... and ONE refiner pass
+        self.clip_shard.check_replicas([ref["mask_embed"], ref["pred_logits"], track["pred_logits"]],
+                                       "tracker / refiner results (batched pass)")
         outs = []
         for j, st in enumerate(sts):
             cls, aux = PP.mean_logits(ref["pred_logits"][j:j + 1], track["pred_logits"][j:j + 1])

@@ -150,9 +150,24 @@ def inference_video_vss(pred_cls, mask_fn, img_size, out_hw, first_resize_size, 
         sem = Fn.vss_argmax(masks, mask_cls, first_resize_size, img_size, out_hw)             # one pass, no (C,T,H,W)
         return {"image_size": tuple(out_hw), "pred_masks": sem, "task": "vss"}
     outs = []
+    own = masks.is_cuda and masks.dtype == torch.float32 and not torch.is_grad_enabled()
+    if own:
+        # > 128 classes (the one-pass kernel's limit): the class contraction still must not be a library GEMM — phase B of
+        # stream() runs next to the segmenter's stream-K kernels (csrc/gemm.hip) — so it goes through dvis_gemm_nt as
+        # scores (pixels, classes) = cur^T (pixels, Q) @ cls^T (classes, Q)^T, Q zero-padded to a multiple of 4
+        from . import functions as Fn
+        Q, C = mask_cls.shape
+        Qp = (Q + 3) // 4 * 4
+        w = torch.zeros((C, Qp), dtype=torch.float32, device=masks.device)
+        w[:, :Q] = mask_cls.t()
     for s in range(0, masks.shape[1], frame_chunk):                                           # bound the 720p blow-up
         cur = _resize2(masks[:, s:s + frame_chunk], first_resize_size, img_size, out_hw, sigmoid=True)
-        outs.append(torch.einsum("qc,qthw->cthw", mask_cls, cur).max(0)[1])
+        if own:
+            a = torch.zeros((cur[0].numel(), Qp), dtype=torch.float32, device=cur.device)
+            a[:, :Q] = cur.flatten(1).t()
+            outs.append(Fn.gemm_nt(a, w).max(1)[1].view(cur.shape[1:]))
+        else:
+            outs.append(torch.einsum("qc,qthw->cthw", mask_cls, cur).max(0)[1])
     return {"image_size": tuple(out_hw), "pred_masks": torch.cat(outs, 0), "task": "vss"}
 
 

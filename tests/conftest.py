@@ -17,11 +17,10 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
-    """`-m gpu` tests are skipped automatically when no GPU is visible (never silently passed).  On a GPU box the suite
-    runs in strict mode: a fused glue op that would quietly take its torch formulation on a GPU tensor raises
-    (dvis_plus_amd.functions._torch_path), so every GPU test proves the HIP path is the one that ran."""
+    """`-m gpu` tests are skipped automatically when no GPU is visible (never silently passed).  The product is strict by
+    default (dvis_plus_amd.functions._torch_path: a fused glue op that would quietly take its torch formulation on a GPU
+    tensor raises unless DVIS_STRICT=0), so every GPU test proves the HIP path is the one that ran — nothing to set here."""
     if torch.cuda.is_available():
-        os.environ.setdefault("DVIS_STRICT", "1")
         return
     skip = pytest.mark.skip(reason="no GPU visible")
     for item in items:

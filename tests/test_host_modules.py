@@ -302,6 +302,54 @@ def test_clip_stream_world_size_2_gloo(oracle_ops, tmp_path, world, owner_rounds
         assert all(p["outs"][ci]["segs"] == single["segments_infos"] for p in parts)
 
 
+def _replica_worker(rank, world, port, out_dir, perturb):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      DVIS_OWNER_ROUNDS="0", DVIS_CHECK_REPLICAS="1")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import conftest as c
+    from dvis_plus_amd import functions as Fn
+    Fn.attention, Fn.attn_mask, Fn.mask_logits = c._o_attention, c._o_attn_mask, c._o_mask_logits
+    Fn.msda_fused_forward, Fn.MSDeformAttnFunction = c._o_msda_fused, c._OMSDAFunction
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _tiny_model("offline", "vps")
+    m.debug_stages = {}
+    core = m._track_core
+    if perturb and rank == 1:          # one ulp-sized disagreement on one rank: what a non-deterministic kernel would do
+        def core_off(*a):
+            emb, cls, aux = core(*a)
+            cls = cls.clone()
+            cls.view(-1)[3] = torch.nextafter(cls.view(-1)[3], cls.new_tensor(float("inf")))
+            return emb, cls, aux
+        m._track_core = core_off
+    err = None
+    try:
+        m([{"image": _tiny_clip(5), "height": 70, "width": 100}])
+    except RuntimeError as e:
+        err = str(e)
+    torch.save({"err": err, "cls": m.debug_stages.get("cls"), "aux": m.debug_stages.get("aux")},
+               os.path.join(out_dir, f"c{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("perturb", [False, True])
+def test_replicated_tracker_agrees_across_ranks_gloo(oracle_ops, tmp_path, perturb):
+    """north_star's split runs tracker + refiner REPLICATED and relies on every rank computing the same bits (no
+    broadcast): the class logits of both ranks are torch.equal, and the DVIS_CHECK_REPLICAS=1 guard (an all-gathered
+    checksum before post-processing) turns a one-ulp disagreement into an error on every rank instead of a hang."""
+    import torch.multiprocessing as mp
+    port = 31500 + (os.getpid() % 2000) + int(perturb)
+    mp.spawn(_replica_worker, args=(2, port, str(tmp_path), perturb), nprocs=2, join=True)
+    parts = [torch.load(tmp_path / f"c{r}.pt") for r in range(2)]
+    if perturb:
+        assert all(p["err"] is not None and "differ between rank 0" in p["err"] for p in parts), [p["err"] for p in parts]
+    else:
+        assert all(p["err"] is None for p in parts), [p["err"] for p in parts]
+        assert torch.equal(parts[0]["cls"], parts[1]["cls"]) and torch.equal(parts[0]["aux"], parts[1]["aux"])
+
+
 def _shard_worker(rank, world, port, out_dir, rounds=1, T=5):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)

@@ -28,9 +28,9 @@ LIBRARY_OPS = ("mm", "addmm", "bmm", "baddbmm", "matmul", "linear", "_addmm_acti
                "einsum", "tensordot")
 
 
-def _model(**kw):
+def _model(task="vps", **kw):
     from dvis_plus_amd.meta_architecture import build_dvis_plus_r50
-    return build_dvis_plus_r50("offline", task="vps", object_mask_threshold=0.0, **kw)
+    return build_dvis_plus_r50("offline", task=task, object_mask_threshold=0.0, **kw)
 
 
 def _clip(T, seed, h=360, w=640):
@@ -38,7 +38,9 @@ def _clip(T, seed, h=360, w=640):
     return {"image": torch.randint(0, 256, (T, 3, h, w), generator=g, dtype=torch.uint8).to(DEV), "height": h, "width": w}
 
 
-def test_phase_b_dispatches_no_library_gemm_or_convolution():
+@pytest.mark.parametrize("task,kw", [("vps", {}), ("vis", {}), ("vss", {}), ("vss", {"num_classes": 150})])
+def test_phase_b_dispatches_no_library_gemm_or_convolution(task, kw):
+    """vss with 150 classes: past the one-pass kernel's 128-class limit — the class contraction must still be the own GEMM."""
     from torch.utils._python_dispatch import TorchDispatchMode
     seen, offenders = [], []
 
@@ -50,7 +52,7 @@ def test_phase_b_dispatches_no_library_gemm_or_convolution():
                 offenders.append(name)
             return func(*args, **(kwargs or {}))
 
-    m = _model().to(DEV)
+    m = _model(task=task, **kw).to(DEV)
     m.object_mask_threshold = 0.008                 # some queries reach the panoptic stage
     inner = m._track_round
 
@@ -63,7 +65,7 @@ def test_phase_b_dispatches_no_library_gemm_or_convolution():
         seen.clear()
         outs = list(m.stream([_clip(4, 1), _clip(5, 2)]))
         torch.cuda.synchronize()
-        assert len(outs) == 2 and outs[1]["pred_masks"].shape[0] == 5
+        assert len(outs) == 2 and outs[1]["pred_masks"].shape[1 if task == "vis" else 0] == 5
         assert seen, "the dispatch watch saw no op: phase B did not run under it"
         assert not offenders, f"phase B dispatched library GEMM / convolution ops: {sorted(set(offenders))}"
 
