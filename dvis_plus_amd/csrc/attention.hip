@@ -593,28 +593,54 @@ __global__ __launch_bounds__(256) void attn_short_kernel(
   const bool q_ok = myq < Lq;
 
   float qf[DQ];
+  float4 qraw[DQ / 4];
   {
     const float *qrow = q + (size_t)bi * qs.b + (size_t)hi * qs.h + (size_t)(q_ok ? myq : 0) * qs.r + g * DQ;
 #pragma unroll
-    for (int c = 0; c < DQ / 4; ++c) {
-      const float4 t = *reinterpret_cast<const float4 *>(qrow + 4 * c);
-      qf[4 * c] = q_ok ? t.x * (scale * kLog2e) : 0.f;
-      qf[4 * c + 1] = q_ok ? t.y * (scale * kLog2e) : 0.f;
-      qf[4 * c + 2] = q_ok ? t.z * (scale * kLog2e) : 0.f;
-      qf[4 * c + 3] = q_ok ? t.w * (scale * kLog2e) : 0.f;
-    }
+    for (int c = 0; c < DQ / 4; ++c) qraw[c] = *reinterpret_cast<const float4 *>(qrow + 4 * c);
   }
   const float *kb = k + (size_t)bi * ks_.b + (size_t)hi * ks_.h;
   const float *vb = v + (size_t)bi * vs.b + (size_t)hi * vs.h;
-  for (int e = tid; e < nrows * (DH / 4); e += 256) {
-    const int row = e / (DH / 4), c4 = e - row * (DH / 4);
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-    if (row < Lk) {
-      a = *reinterpret_cast<const float4 *>(kb + (size_t)row * ks_.r + 4 * c4);
-      b = *reinterpret_cast<const float4 *>(vb + (size_t)row * vs.r + 4 * c4);
+  // K / V -> LDS.  A link of a launch-bound chain can afford ONE memory round trip: every 16-byte piece of K and V this
+  // thread stages is requested before the first one is written to LDS (a load -> store loop serialises into one round trip
+  // per iteration: 7 of them at 100 keys).
+  // Through buffer descriptors over this head's Lk rows (rows past Lk read zeros in hardware): no branch around a load —
+  // with conditional loads hipcc merges the "zero" and "loaded" values through register copies that wait for the load.
+  constexpr int NIT = 128 * (DH / 4) / 256;   // Lk <= 128
+  dvis_f4 kr[NIT], vr[NIT];
+  {
+    const __amdgpu_buffer_rsrc_t rk = dvis_make_rsrc_uniform(kb, (unsigned)(((size_t)(Lk - 1) * ks_.r + DH) * 4));
+    const __amdgpu_buffer_rsrc_t rv = dvis_make_rsrc_uniform(vb, (unsigned)(((size_t)(Lk - 1) * vs.r + DH) * 4));
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = tid + 256 * it;
+      const int row = e / (DH / 4), c4 = e - row * (DH / 4);
+      const bool in = row < Lk;
+      kr[it] = __builtin_bit_cast(dvis_f4, __builtin_amdgcn_raw_buffer_load_b128(
+                                               rk, in ? (unsigned)(((size_t)row * ks_.r + 4 * c4) * 4) : 0x80000000u, 0, 0));
+      vr[it] = __builtin_bit_cast(dvis_f4, __builtin_amdgcn_raw_buffer_load_b128(
+                                               rv, in ? (unsigned)(((size_t)row * vs.r + 4 * c4) * 4) : 0x80000000u, 0, 0));
     }
-    *reinterpret_cast<float4 *>(&k_lds[row * LS + 4 * c4]) = a;
-    *reinterpret_cast<float4 *>(&v_lds[row * LS + 4 * c4]) = b;
+  }
+  // (scheduling fence: left alone hipcc hoists the q scaling between the K / V requests and waits for the q rows there —
+  // the second half of the requests then leaves one round trip late)
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int c = 0; c < DQ / 4; ++c) {
+    const float4 t = qraw[c];
+    qf[4 * c] = q_ok ? t.x * (scale * kLog2e) : 0.f;
+    qf[4 * c + 1] = q_ok ? t.y * (scale * kLog2e) : 0.f;
+    qf[4 * c + 2] = q_ok ? t.z * (scale * kLog2e) : 0.f;
+    qf[4 * c + 3] = q_ok ? t.w * (scale * kLog2e) : 0.f;
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e = tid + 256 * it;
+    const int row = e / (DH / 4), c4 = e - row * (DH / 4);
+    if (row < nrows) {
+      *reinterpret_cast<dvis_f4 *>(&k_lds[row * LS + 4 * c4]) = kr[it];
+      *reinterpret_cast<dvis_f4 *>(&v_lds[row * LS + 4 * c4]) = vr[it];
+    }
   }
   const bool use_mask = mask != nullptr && q_ok && (allowed == nullptr || allowed[(size_t)bi * Lq + myq] != 0);
   const uint8_t *mrow = mask ? mask + ((size_t)bi * Lq + (q_ok ? myq : 0)) * Lk : nullptr;
@@ -763,10 +789,10 @@ DVIS_EXPORT int64_t dvis_attention_ws_bytes(int BH, int Lq, int Lk, int d) {
   return (int64_t)BH * ns * Lq * (d + 2) * (int64_t)sizeof(float);
 }
 
-DVIS_EXPORT int dvis_attention_forward(const float *q, const int64_t *q_strides, const float *k, const int64_t *k_strides,
-                                       const float *v, const int64_t *v_strides, float *out, const int64_t *o_strides,
-                                       const uint8_t *mask, const int32_t *allowed_count, int B, int heads, int Lq,
-                                       int Lk, int d, float scale, void *ws, void *stream) {
+static int attention_launch(const float *q, const int64_t *q_strides, const float *k, const int64_t *k_strides,
+                            const float *v, const int64_t *v_strides, float *out, const int64_t *o_strides,
+                            const uint8_t *mask, const int32_t *allowed_count, int B, int heads, int Lq, int Lk, int d,
+                            float scale, void *ws, void *stream, int kernel) {
   DVIS_REQUIRE(B >= 0 && heads > 0 && Lq >= 0 && Lk > 0, "attention: bad sizes");
   if (B == 0 || Lq == 0) return DVIS_OK;
   DVIS_REQUIRE(q && k && v && out && q_strides && k_strides && v_strides && o_strides, "attention: null pointer");
@@ -780,7 +806,8 @@ DVIS_EXPORT int dvis_attention_forward(const float *q, const int64_t *q_strides,
                "attention: q/k/v must be 16-byte aligned with strides that are multiples of 4 floats");
   DVIS_REQUIRE(mask == nullptr || ((uintptr_t)mask & 3) == 0, "attention: mask must be 4-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  if (keysplit_applies(Lq, Lk, d, mask != nullptr, ks.r, vs.r)) {
+  DVIS_REQUIRE(kernel == 0 || (kernel == 1 && Lk <= 128), "attention: kernel 1 (short keys) needs Lk <= 128 (Lk=%d)", Lk);
+  if (kernel == 0 && keysplit_applies(Lq, Lk, d, mask != nullptr, ks.r, vs.r)) {
     const KeySplitPlan kp = plan_keysplit(BH, Lq, Lk);
     DVIS_REQUIRE(kp.nsplit == 1 || ws, "attention: workspace required (dvis_attention_ws_bytes)");
     float *kws_o = (float *)ws;
@@ -803,7 +830,10 @@ DVIS_EXPORT int dvis_attention_forward(const float *q, const int64_t *q_strides,
   const dim3 grid(p.nsplit, BH, p.qchunks), block(512);
 // few workgroups: one per (batch, head, 16-query tile) with the keys split over 4 waves (8.0 vs 14.8 us for the tracker's
   // batch-1 call); with many (batch, head) pairs the per-tile K/V restaging costs more than it saves (17 vs 11 us at B=30).
-  if (Lk <= 128 && p.nsplit == 1 && (long long)BH * ((Lq + 15) / 16) <= 256) {
+  // (384: also the tracker's hoisted cross-attention call — 6 layers x 8 heads x 7 query tiles = 336 workgroups, 10.3 us
+  // here against 14.8 us on the one-workgroup-per-(batch, head) kernel, measured inside the tracker's hipGraph)
+  static const long long short_max = []() { const char *e = getenv("DVIS_ATTN_SHORT_MAX"); return e ? atoll(e) : 384ll; }();
+  if (kernel == 1 || (Lk <= 128 && p.nsplit == 1 && (long long)BH * ((Lq + 15) / 16) <= short_max)) {
     const dim3 sgrid((Lq + 15) / 16, BH);
     const int nrows = (Lk + 15) / 16 * 16, ls = d + 4;
     const size_t lds = sizeof(float) * ((size_t)std::max(nrows * ls, 64 * d) + (size_t)nrows * ls + 128);
@@ -830,4 +860,20 @@ DVIS_EXPORT int dvis_attention_forward(const float *q, const int64_t *q_strides,
   hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws_o, ws_ml, p.nsplit,
                      Lq, d, heads, total, out, os);
   return dvis_check_launch("attn_combine_kernel");
+}
+
+DVIS_EXPORT int dvis_attention_forward(const float *q, const int64_t *q_strides, const float *k, const int64_t *k_strides,
+                                       const float *v, const int64_t *v_strides, float *out, const int64_t *o_strides,
+                                       const uint8_t *mask, const int32_t *allowed_count, int B, int heads, int Lq,
+                                       int Lk, int d, float scale, void *ws, void *stream) {
+  return attention_launch(q, q_strides, k, k_strides, v, v_strides, out, o_strides, mask, allowed_count, B, heads, Lq, Lk, d,
+                          scale, ws, stream, 0);
+}
+
+DVIS_EXPORT int dvis_attention_forward_k(const float *q, const int64_t *q_strides, const float *k, const int64_t *k_strides,
+                                         const float *v, const int64_t *v_strides, float *out, const int64_t *o_strides,
+                                         const uint8_t *mask, const int32_t *allowed_count, int B, int heads, int Lq,
+                                         int Lk, int d, float scale, void *ws, void *stream, int kernel) {
+  return attention_launch(q, q_strides, k, k_strides, v, v_strides, out, o_strides, mask, allowed_count, B, heads, Lq, Lk, d,
+                          scale, ws, stream, kernel);
 }

@@ -31,7 +31,7 @@ struct GemmArgs {
   const float *A, *W, *bias, *res;
   float *C;
   long long lda, ldw, ldres, ldc;          // row strides in floats
-  long long sA, sW, sRes, sC;              // batch strides in floats
+  long long sA, sW, sRes, sC, sBias;       // batch strides in floats (sBias: 0 = one bias for the whole batch)
   int M, N, K, act, row_blocks, col_blocks, vec_store, col_fastest;
   // head-major output: column n of row m goes to C[(n / head_d) * head_stride + m * head_d + n % head_d] — the (heads, M, d)
   // layout MSDeformAttn gathers from (a pixel's d channels of ONE head are a contiguous line, neighbouring pixels adjacent);
@@ -161,6 +161,7 @@ __global__ __launch_bounds__(64 * NW, kGemmMinWaves<RT * CT>) void gemm_nt_kerne
   constexpr int U = BM * BN / 4, UR = BN / 4;
   float *Cb = p.C + batch * p.sC;
   const float *Rb = p.res ? p.res + batch * p.sRes : nullptr;
+  const float *Bb = p.bias ? p.bias + batch * p.sBias : nullptr;
 #pragma unroll
   for (int u0 = 0; u0 < U; u0 += T) {
     const int u = u0 + tid;
@@ -177,8 +178,8 @@ __global__ __launch_bounds__(64 * NW, kGemmMinWaves<RT * CT>) void gemm_nt_kerne
     float *dst = p.head_d ? Cb + (long long)(gc / p.head_d) * p.head_stride + (long long)gr * p.head_d + gc % p.head_d
                           : Cb + (long long)gr * p.ldc + gc;
     if (p.vec_store) {   // N % 4 == 0, 16-byte aligned rows of C / bias / res
-      if (p.bias) {
-        const dvis_f4 b = *reinterpret_cast<const dvis_f4 *>(p.bias + gc);
+      if (Bb) {
+        const dvis_f4 b = *reinterpret_cast<const dvis_f4 *>(Bb + gc);
         s = dvis_f4{s[0] + b[0], s[1] + b[1], s[2] + b[2], s[3] + b[3]};
       }
       if (Rb) {
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(64 * NW, kGemmMinWaves<RT * CT>) void gemm_nt_kerne
       for (int e = 0; e < 4; ++e) {
         if (gc + e >= p.N) break;
         float v = s[e];
-        if (p.bias) v += p.bias[gc + e];
+        if (Bb) v += Bb[gc + e];
         if (Rb) v += Rb[(long long)gr * p.ldres + gc + e];
         if (p.act) v = fmaxf(v, 0.f);
         dst[e] = v;
@@ -262,7 +263,8 @@ __global__ __launch_bounds__(64, kGemmMinWaves<RT * CT>) void gemm_nt_persist_ke
 
   float *Cb = p.C + batch * p.sC;
   const float *Rb = p.res ? p.res + batch * p.sRes : nullptr;
-  const __amdgpu_buffer_rsrc_t rbias = dvis_make_rsrc_uniform(p.bias ? p.bias : p.A, p.bias ? (unsigned)p.N * 4u : 0u);
+  const __amdgpu_buffer_rsrc_t rbias =
+      dvis_make_rsrc_uniform(p.bias ? p.bias + batch * p.sBias : p.A, p.bias ? (unsigned)p.N * 4u : 0u);
 #pragma unroll 1
   for (;;) {
 #pragma unroll
@@ -422,10 +424,10 @@ DVIS_EXPORT int dvis_gemm_num_configs(void) { return kNumConfigs; }
 
 DVIS_EXPORT int dvis_gemm_pick_config(int M, int N, int K, int batch) { return pick_config(M, N, K, batch > 0 ? batch : 1); }
 
-DVIS_EXPORT int dvis_gemm_nt_hm(const float *A, int64_t lda, int64_t strideA, const float *W, int64_t ldw, int64_t strideW,
-                                const float *bias, const float *res, int64_t ldres, int64_t strideRes, float *C,
-                                int64_t ldc, int64_t strideC, int M, int N, int K, int batch, int act, int config,
-                                int head_d, int64_t head_stride, void *stream) {
+static int gemm_launch(const float *A, int64_t lda, int64_t strideA, const float *W, int64_t ldw, int64_t strideW,
+                       const float *bias, int64_t strideBias, const float *res, int64_t ldres, int64_t strideRes, float *C,
+                       int64_t ldc, int64_t strideC, int M, int N, int K, int batch, int act, int config, int head_d,
+                       int64_t head_stride, void *stream) {
   DVIS_REQUIRE(M >= 0 && N >= 0 && K > 0 && batch >= 0, "gemm_nt: bad sizes (M=%d N=%d K=%d batch=%d)", M, N, K, batch);
   if (M == 0 || N == 0 || batch == 0) return DVIS_OK;
   DVIS_REQUIRE(A && W && C, "gemm_nt: null pointer");
@@ -445,7 +447,7 @@ DVIS_EXPORT int dvis_gemm_nt_hm(const float *A, int64_t lda, int64_t strideA, co
   GemmArgs p;
   p.A = A, p.W = W, p.bias = bias, p.res = res, p.C = C;
   p.lda = lda, p.ldw = ldw, p.ldres = ldres, p.ldc = ldc;
-  p.sA = strideA, p.sW = strideW, p.sRes = strideRes, p.sC = strideC;
+  p.sA = strideA, p.sW = strideW, p.sRes = strideRes, p.sC = strideC, p.sBias = strideBias;
   p.M = M, p.N = N, p.K = K, p.act = act;
   DVIS_REQUIRE(head_d == 0 || (head_d % 4 == 0 && N % head_d == 0 && !res && batch == 1 && head_stride >= (int64_t)M * head_d &&
                                head_stride % 4 == 0),
@@ -456,7 +458,7 @@ DVIS_EXPORT int dvis_gemm_nt_hm(const float *A, int64_t lda, int64_t strideA, co
   // A larger than what the caches keep between two passes over it (L2s 32 MB; the 256 MB MALL is shared with C and W)
   p.col_fastest = (long long)M * K * 4 > (64ll << 20) && p.col_blocks > 1;
   p.vec_store = N % 4 == 0 && ldc % 4 == 0 && strideC % 4 == 0 && (uintptr_t)C % 16 == 0 &&
-                (!bias || (uintptr_t)bias % 16 == 0) &&
+                (!bias || ((uintptr_t)bias % 16 == 0 && strideBias % 4 == 0)) &&
                 (!res || (ldres % 4 == 0 && strideRes % 4 == 0 && (uintptr_t)res % 16 == 0));
   const long long tiles = (long long)p.row_blocks * p.col_blocks;
   DVIS_REQUIRE(tiles < (1ll << 31), "gemm_nt: too many tiles");
@@ -492,10 +494,26 @@ DVIS_EXPORT int dvis_gemm_nt_hm(const float *A, int64_t lda, int64_t strideA, co
   return dvis_check_launch("gemm_nt_kernel");
 }
 
+DVIS_EXPORT int dvis_gemm_nt_hm(const float *A, int64_t lda, int64_t strideA, const float *W, int64_t ldw, int64_t strideW,
+                                const float *bias, const float *res, int64_t ldres, int64_t strideRes, float *C,
+                                int64_t ldc, int64_t strideC, int M, int N, int K, int batch, int act, int config,
+                                int head_d, int64_t head_stride, void *stream) {
+  return gemm_launch(A, lda, strideA, W, ldw, strideW, bias, 0, res, ldres, strideRes, C, ldc, strideC, M, N, K, batch, act,
+                     config, head_d, head_stride, stream);
+}
+
 DVIS_EXPORT int dvis_gemm_nt(const float *A, int64_t lda, int64_t strideA, const float *W, int64_t ldw, int64_t strideW,
                              const float *bias, const float *res, int64_t ldres, int64_t strideRes, float *C,
                              int64_t ldc, int64_t strideC, int M, int N, int K, int batch, int act, int config,
                              void *stream) {
-  return dvis_gemm_nt_hm(A, lda, strideA, W, ldw, strideW, bias, res, ldres, strideRes, C, ldc, strideC, M, N, K, batch, act,
-                         config, 0, 0, stream);
+  return gemm_launch(A, lda, strideA, W, ldw, strideW, bias, 0, res, ldres, strideRes, C, ldc, strideC, M, N, K, batch, act,
+                     config, 0, 0, stream);
+}
+
+DVIS_EXPORT int dvis_gemm_nt_bb(const float *A, int64_t lda, int64_t strideA, const float *W, int64_t ldw, int64_t strideW,
+                                const float *bias, int64_t strideBias, const float *res, int64_t ldres, int64_t strideRes,
+                                float *C, int64_t ldc, int64_t strideC, int M, int N, int K, int batch, int act, int config,
+                                void *stream) {
+  return gemm_launch(A, lda, strideA, W, ldw, strideW, bias, strideBias, res, ldres, strideRes, C, ldc, strideC, M, N, K,
+                     batch, act, config, 0, 0, stream);
 }

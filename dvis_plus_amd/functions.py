@@ -222,7 +222,7 @@ def _strides3(t, B, C, d):
     return (ctypes.c_int64 * 3)(t.stride(1) if B > 1 else C, d, t.stride(0))
 
 
-def attention(q, k, v, nheads, mask=None, allowed_count=None, out=None):
+def attention(q, k, v, nheads, mask=None, allowed_count=None, out=None, short=False):
     """Multi-head softmax(q k^T / sqrt(d)) v on projected, sequence-first tensors (what
     nn.MultiheadAttention computes between its in- and out-projection).
 
@@ -231,6 +231,8 @@ def attention(q, k, v, nheads, mask=None, allowed_count=None, out=None):
     d in {32, 64}.  mask: uint8 / bool (B, Lq, Lk), 1 = blocked, shared by all heads of a batch entry;
     allowed_count int32 (B, Lq) from ``attn_mask`` (rows with 0 ignore the mask).
     Returns (Lq, B, C) ready for the out-projection.
+    short=True pins the short-key latency kernel (Lk <= 128) whatever the batch size: same bits per (batch, head) for a clip
+    alone or stacked with others (the tracker's recurrence).
     """
     Lq, B, C = q.shape
     Lk = k.shape[0]
@@ -257,11 +259,11 @@ def attention(q, k, v, nheads, mask=None, allowed_count=None, out=None):
     nbytes = lib.dvis_attention_ws_bytes(B * nheads, Lq, Lk, d)
     ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=q.device) if nbytes else None
     with torch.cuda.device(q.device):
-        rc = lib.dvis_attention_forward(
+        rc = lib.dvis_attention_forward_k(
             ctypes.c_void_p(q.data_ptr()), _strides3(q, B, C, d), ctypes.c_void_p(k.data_ptr()), _strides3(k, B, C, d),
             ctypes.c_void_p(v.data_ptr()), _strides3(v, B, C, d), ctypes.c_void_p(out.data_ptr()),
             _strides3(out, B, C, d), mptr, aptr, B, nheads, Lq, Lk, d, 1.0 / (d ** 0.5),
-            ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, native.stream_ptr(q.device))
+            ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, native.stream_ptr(q.device), 1 if short else 0)
     native.check(rc, "dvis_attention_forward")
     return out
 
@@ -517,7 +519,7 @@ def _rows2d(x, K):
     return x.view(-1, K), K
 
 
-def gemm_nt(a, w, bias=None, relu=False, res=None, config=-1, head_major=0):
+def gemm_nt(a, w, bias=None, relu=False, res=None, config=-1, head_major=0, out=None):
     """``relu?(a @ w.T + bias + res)`` on the deterministic exact-fp32 MFMA kernel (dvis_gemm_nt).  a (..., K) float32 GPU
     tensor (rows with unit inner stride; a row-sliced 2-D view keeps its row stride), w (N, K) in F.linear's layout (row
     stride >= K allowed), bias (N) or None, res (..., N) or None.  Returns (..., N).  Raises when the kernel cannot serve
@@ -535,11 +537,13 @@ def gemm_nt(a, w, bias=None, relu=False, res=None, config=-1, head_major=0):
         if N % head_major or head_major % 4 or res is not None:
             raise RuntimeError("gemm_nt: head_major needs N % d == 0, d % 4 == 0 and no residual")
         out = torch.empty((N // head_major, M, head_major), dtype=torch.float32, device=a.device)
-    else:
+    elif out is None:
         out = torch.empty((*a.shape[:-1], N), dtype=torch.float32, device=a.device)
+    elif not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == M * N):
+        raise RuntimeError("gemm_nt: out must be a contiguous float32 GPU tensor of M * N elements")
     rp, ldres = None, 0
     if res is not None:
-        if res.shape != out.shape or res.dtype != torch.float32 or not res.is_cuda:
+        if res.numel() != out.numel() or res.shape[-1] != N or res.dtype != torch.float32 or not res.is_cuda:
             raise RuntimeError("gemm_nt: res must be a float32 GPU tensor of the output's shape")
         r2, ldres = _rows2d(res, N)
         rp = ctypes.c_void_p(r2.data_ptr())
@@ -555,6 +559,92 @@ def gemm_nt(a, w, bias=None, relu=False, res=None, config=-1, head_major=0):
                                           M * head_major, native.stream_ptr(a.device))
     native.check(rc, "dvis_gemm_nt")
     return out
+
+
+def gemm_nt_stacked(a, w, bias=None, config=-1):
+    """`L` projections of one activation matrix as ONE launch: a (M, L * K) holds L operands side by side (operand l =
+    columns [l K, (l + 1) K)), w (L, N, K) / bias (L, N) the L layers' ``nn.Linear`` parameters -> (L, M, N) with
+    out[l] = a[:, l K:(l + 1) K] @ w[l].T + bias[l] (dvis_gemm_nt_bb: a batched GEMM with a bias per batch entry)."""
+    L, N, K = w.shape
+    if not (a.is_cuda and a.dtype == torch.float32 and w.dtype == torch.float32 and a.dim() == 2 and a.stride(1) == 1
+            and a.shape[1] == L * K and w.is_contiguous()):
+        raise RuntimeError("gemm_nt_stacked: needs float32 GPU operands a (M, L * K) with unit inner stride, contiguous w (L, N, K)")
+    if bias is not None and not (bias.dtype == torch.float32 and bias.shape == (L, N) and bias.is_contiguous()):
+        raise RuntimeError("gemm_nt_stacked: bias must be a contiguous float32 (L, N) tensor")
+    M = a.shape[0]
+    out = torch.empty((L, M, N), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        rc = native.lib().dvis_gemm_nt_bb(ctypes.c_void_p(a.data_ptr()), a.stride(0), K, ctypes.c_void_p(w.data_ptr()), K, N * K,
+                                          None if bias is None else ctypes.c_void_p(bias.data_ptr()), N, None, 0, 0,
+                                          ctypes.c_void_p(out.data_ptr()), N, M * N, M, N, K, L, 0,
+                                          _gemm_config(M, N, K, L, config), native.stream_ptr(a.device))
+    native.check(rc, "dvis_gemm_nt_bb")
+    return out
+
+
+def gemm_ln_ok(a, w, norms=True):
+    """Can dvis_gemm_ln serve ``a (..., K) @ w (N, K).T``?  (fp32 GPU inference tensors, K % 16 == 0, K <= 512 — 2048 for a
+    call without norms —, N % 4 == 0)"""
+    return (a.is_cuda and a.dtype == torch.float32 and w.dtype == torch.float32 and not torch.is_grad_enabled()
+            and w.dim() == 2 and w.stride(1) == 1 and w.stride(0) % 4 == 0
+            and bool(native.lib().dvis_gemm_ln_supported(max(1, a.numel() // a.shape[-1]), w.shape[0], a.shape[-1],
+                                                         1 if norms else 0)))
+
+
+def gemm_ln(a, w, bias=None, norm1=None, add=None, norm2=None, relu=False, res=None, a_out=None, out=None, config=-1):
+    """``x = norm2(norm1(a) + add)``; returns ``(relu?(x @ w.T + bias + res), x)`` — the LayerNorm seam of a post-norm
+    transformer block folded into the prologue of the projection that consumes it (csrc/gemm_ln.hip).  Without norms it
+    is the latency form of ``gemm_nt`` for launch-bound chains (every operand requested up front, K <= 2048; x is None).  a (..., K) float32
+    GPU rows (the producer's RAW residual sum), norm1 / norm2 ``nn.LayerNorm`` modules or None, add (..., K) or None,
+    w (N, K), res (..., N) or None.  a_out / out: optional preallocated destinations ((..., K) / (..., N) row views).
+    Raises when the kernel cannot serve the operands — no fallback."""
+    K = a.shape[-1]
+    N = w.shape[0]
+    if (add is None) != (norm2 is None):
+        raise RuntimeError("gemm_ln: the forms are norm1, add + norm2, norm1 + add + norm2 or none")
+    if not gemm_ln_ok(a, w, norm1 is not None or norm2 is not None) or w.shape[1] != K:
+        raise RuntimeError(f"gemm_ln: operands not served (a {tuple(a.shape)} {a.dtype}, w {tuple(w.shape)}; needs fp32 GPU, "
+                           "K % 16 == 0, K <= 512, N % 4 == 0, no autograd)")
+    a2, lda = _rows2d(a, K)
+    M = a2.shape[0]
+    lead = a.shape[:-1]
+
+    def rows(t, width, name):
+        if t is None:
+            return None, 0
+        if t.dtype != torch.float32 or not t.is_cuda or t.shape[-1] != width or t.numel() != M * width:
+            raise RuntimeError(f"gemm_ln: {name} must be a float32 GPU tensor of {M} rows x {width}")
+        t2, ld = _rows2d(t, width)
+        return t2, ld
+    add2, ldadd = rows(add, K, "add")
+    res2, ldres = rows(res, N, "res")
+    if a_out is None and (norm1 is not None or norm2 is not None):
+        a_out = torch.empty((*lead, K), dtype=torch.float32, device=a.device)
+    if out is None:
+        out = torch.empty((*lead, N), dtype=torch.float32, device=a.device)
+    ao2, ldao = rows(a_out, K, "a_out")
+    o2, ldc = rows(out, N, "out")
+    if (ao2 is not None and ao2.data_ptr() != a_out.data_ptr()) or o2.data_ptr() != out.data_ptr():
+        raise RuntimeError("gemm_ln: a_out / out must be row views (unit inner stride, one row stride)")
+
+    def affine(n):
+        if n is None:
+            return None, None, 0.0
+        if n.weight is None or n.weight.numel() != K or n.weight.dtype != torch.float32:
+            raise RuntimeError("gemm_ln: needs an affine float32 LayerNorm over the K columns")
+        return ctypes.c_void_p(n.weight.data_ptr()), ctypes.c_void_p(n.bias.data_ptr()), float(n.eps)
+    g1, b1, e1 = affine(norm1)
+    g2, b2, e2 = affine(norm2)
+    rows_pin, _ = gemm_sizes_as.current()
+    cfg = config if config >= 0 or rows_pin is None else native.lib().dvis_gemm_ln_pick_config(rows_pin, N, K)
+    ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    with torch.cuda.device(a.device):
+        rc = native.lib().dvis_gemm_ln(ptr(a2), lda, ptr(add2), ldadd, g1, b1, e1, g2, b2, e2, ptr(ao2), ldao,
+                                       ctypes.c_void_p(w.data_ptr()), w.stride(0), None if bias is None else ptr(bias.detach()),
+                                       ptr(res2), ldres, ptr(o2), ldc, M, N, K, 1 if relu else 0, cfg,
+                                       native.stream_ptr(a.device))
+    native.check(rc, "dvis_gemm_ln")
+    return out, a_out
 
 
 def bmm_nt(a, b, config=-1):

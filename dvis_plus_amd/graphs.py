@@ -63,20 +63,35 @@ class FusedKV:
     the parameters' version counters): a graph captured earlier keeps reading valid, current weights."""
 
     def __init__(self, rows="kv"):
-        """rows: "kv" = the K and V rows [C, 3C) of every layer's in_proj (K / V of all layers: one GEMM over the memory);
-        "q" = the Q rows [0, C) (all layers' queries of ONE input: the tracker's per-frame reference, tracker.py:278)."""
+        """rows: "kv" = the K and V rows [C, 3C) of every layer's in_proj, layer by layer (K0 V0 K1 V1 ...: K / V of all
+        layers, one GEMM over the memory);
+        "k_v" = the same rows as ALL layers' K, then all layers' V (K0 .. K5 V0 .. V5): layer l's head h is then head
+        8 l + h of ONE attention call over layers x heads (the tracker's per-frame cross-attentions, tracker.py:293-318);
+        "q" = the Q rows [0, C) (all layers' queries of ONE input: the tracker's per-frame reference, tracker.py:278);
+        "out" = the out_proj weights stacked (layers, C, C) / biases (layers, C) — one batched GEMM (dvis_gemm_nt_bb)."""
         self._key, self._W, self._b = None, None, None
         self._rows = rows
 
     def get(self, layers, C):
-        ws = [l.multihead_attn.in_proj_weight for l in layers]
-        bs = [l.multihead_attn.in_proj_bias for l in layers]
+        if self._rows == "out":
+            ws = [l.multihead_attn.out_proj.weight for l in layers]
+            bs = [l.multihead_attn.out_proj.bias for l in layers]
+        else:
+            ws = [l.multihead_attn.in_proj_weight for l in layers]
+            bs = [l.multihead_attn.in_proj_bias for l in layers]
         ver = tuple(t._version for t in ws + bs) + tuple(t.data_ptr() for t in ws + bs)
         dev = ws[0].device
         sl = slice(C, None) if self._rows == "kv" else slice(0, C)
         if self._key != (ver, dev):
-            W = torch.cat([w[sl].detach() for w in ws], 0)
-            b = torch.cat([x[sl].detach() for x in bs], 0)
+            if self._rows == "out":
+                W = torch.stack([w.detach() for w in ws], 0)
+                b = torch.stack([x.detach() for x in bs], 0)
+            elif self._rows == "k_v":
+                W = torch.cat([w[C:2 * C].detach() for w in ws] + [w[2 * C:].detach() for w in ws], 0)
+                b = torch.cat([x[C:2 * C].detach() for x in bs] + [x[2 * C:].detach() for x in bs], 0)
+            else:
+                W = torch.cat([w[sl].detach() for w in ws], 0)
+                b = torch.cat([x[sl].detach() for x in bs], 0)
             if self._W is not None and self._W.device == dev and self._W.shape == W.shape and self._W.dtype == W.dtype:
                 self._W.copy_(W)
                 self._b.copy_(b)

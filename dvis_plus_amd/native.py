@@ -35,6 +35,7 @@ SIGNATURES = {
     "dvis_attn_mask": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "dvis_attention_ws_bytes": (_i64, [_i, _i, _i, _i]),
     "dvis_attention_forward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p]),
+    "dvis_attention_forward_k": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p, _i]),
     "dvis_add_layernorm": (_i, [_p, _p, _i64, _p, _p, _p, _i64, _i, _f, _p]),
     "dvis_add_layernorm_pos": (_i, [_p, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _i, _f, _p]),
     "dvis_bias_act": (_i, [_p, _p, _p, _i64, _i, _i64, _i, _p]),
@@ -67,6 +68,13 @@ SIGNATURES = {
     "dvis_gemm_nt": (_i, [_p, _i64, _i64, _p, _i64, _i64, _p, _p, _i64, _i64, _p, _i64, _i64, _i, _i, _i, _i, _i, _i, _p]),
     "dvis_gemm_nt_hm": (_i, [_p, _i64, _i64, _p, _i64, _i64, _p, _p, _i64, _i64, _p, _i64, _i64, _i, _i, _i, _i, _i, _i, _i,
                              _i64, _p]),
+    "dvis_gemm_nt_bb": (_i, [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _i64, _i64, _i, _i, _i, _i, _i, _i,
+                             _p]),
+    "dvis_gemm_ln": (_i, [_p, _i64, _p, _i64, _p, _p, _f, _p, _p, _f, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _i, _i, _i,
+                          _i, _i, _p]),
+    "dvis_gemm_ln_supported": (_i, [_i, _i, _i, _i]),
+    "dvis_gemm_ln_num_configs": (_i, []),
+    "dvis_gemm_ln_pick_config": (_i, [_i, _i, _i]),
     "dvis_gemm_num_configs": (_i, []),
     "dvis_gemm_pick_config": (_i, [_i, _i, _i, _i]),
 }

@@ -16,6 +16,7 @@ six K/V projections and (offline) a mask einsum whose result is thrown away.  He
     (dvis_Plus/meta_architecture.py:1486 deletes them).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -133,9 +134,15 @@ class ReferringTracker_noiser(nn.Module):
         self.last_frame_embeds = None
         self.last_reference = None
         self.noise_mode, self.noise_ratio = noise_mode, noise_ratio   # training-only knobs (kept for the ctor surface)
-        self._kv_cache = FusedKV()
+        self._kv_cache = FusedKV("k_v")
         self._q_cache = FusedKV("q")
+        self._o_cache = FusedKV("out")
         self.use_graphs = True
+        # The chain with its LayerNorm seams folded into the consuming projections (csrc/gemm_ln.hip) and the layer-independent
+        # cross-attentions hoisted out of the layer loop: 35 instead of ~65 dependent launches per frame.  False (or
+        # DVIS_TRACKER_FUSED=0): the layer-by-layer form (one launch per GEMM / attention / add+LayerNorm) — same results to
+        # fp32 rounding; kept as the cross-check of the fused form (tests/test_golden_gpu.py runs both).
+        self.fused_chain = os.environ.get("DVIS_TRACKER_FUSED", "1") != "0"
         self._graph = GraphRunner(self._recurrence_entry)
         use_own_gemm(self)
 
@@ -149,44 +156,97 @@ class ReferringTracker_noiser(nn.Module):
     def _q_weights(self):
         return self._q_cache.get(self.transformer_cross_attention_layers, self.decoder_norm.weight.shape[0])
 
+    def _o_weights(self):
+        return self._o_cache.get(self.transformer_cross_attention_layers, self.decoder_norm.weight.shape[0])
+
     def _recurrence_entry(self, fe_nn, idx_dev, last_outputs):
         return self._recurrence(fe_nn, idx_dev, last_outputs, self._rec_first)
+
+    def _first_frame(self, single_nn, out, kv_i):
+        """Frame 0 of a video (tracker.py:221-275): every layer's reference is ref_proj of the layer's own input, so nothing
+        hoists; layer by layer, once per video."""
+        C, L = single_nn.shape[-1], self.num_layers
+        for j in range(L):
+            ref_j = self.ref_proj(single_nn if j == 0 else out)
+            out = self.transformer_cross_attention_layers[j].attend(out, ref_j, kv_i[..., j * C:(j + 1) * C],
+                                                                    kv_i[..., (L + j) * C:(L + j + 1) * C])
+            out = self.transformer_self_attention_layers[j](out)
+            out = self.transformer_ffn_layers[j](out)
+        return out, self.ref_proj(single_nn)
 
     def _recurrence(self, fe_nn, idx_dev, last_outputs, first_is_start):
         """The genuinely sequential part.  fe_nn (T,Q,B,C) un-normed frame queries, idx_dev (T,Q,B) assignments,
         last_outputs (Q,B,C) carried state (ignored when the clip starts a video).  B > 1: B independent clips of equal
         length advance together — every op below is row-wise or per (batch, head), so a clip's rows see the same arithmetic
-        as alone, and the ~65 launch-bound kernels per frame are paid once for all B clips.
-        Returns (outputs (T,Q,B,C), references (T,Q,B,C), new last_outputs)."""
+        as alone, and the launch-bound kernels of a frame are paid once for all B clips.
+        Returns (outputs (T,Q,B,C), references (T,Q,B,C), new last_outputs).
+
+        Per frame i > 0 (tracker.py:276-318) the SAME reference = ref_proj(last output) is the query of all six layers'
+        cross-attention and the frame's own queries are their keys / values, so those six attentions and out-projections do
+        not depend on the layer chain: ONE attention call over layers x heads = 48 heads and ONE batched GEMM give every
+        layer's attention term t_j up front.  What remains sequential per layer is
+            x  = LN_cross(x + t_j);  qkv = in_proj(x);  a = attention;  v = x + out_proj(a);  x = LN_self(v);
+            h  = relu(linear1(x));   y = x + linear2(h);                x = LN_ffn(y)
+        and every LayerNorm of it runs in the prologue of the projection that consumes it (Fn.gemm_ln): five launches per
+        layer, 6 + 30 per frame."""
         T, Q, B, C = fe_nn.shape
+        L, H = self.num_layers, self.num_heads
         W, b = self._kv_weights()
         with Fn.gemm_sizes_as(rows=T * Q):
-            kv = Fn.linear(fe_nn, W, b, own=True)                              # (T, Q, B, layers * 2C): one GEMM
+            kv = Fn.linear(fe_nn, W, b, own=True)                              # (T, Q, B, 2 L C): K of all layers, then V
         Wq, bq = self._q_weights()
-        outputs, refs = [], []
-        gidx = idx_dev[..., None].expand(T, Q, B, C)
+        Wo, bo = self._o_weights()
+        cross, selfa, ffns = (self.transformer_cross_attention_layers, self.transformer_self_attention_layers,
+                              self.transformer_ffn_layers)
+        rp = self.ref_proj.layers
+        # the assignment-permuted frame queries of ALL frames (each frame's layer-0 input): one gather, outside the chain
+        x0_all = torch.gather(fe_nn, 1, idx_dev[..., None].expand(T, Q, B, C))
+        outputs, refs = torch.empty_like(fe_nn), torch.empty_like(fe_nn)
+        fused = self.fused_chain and Fn.gemm_ln_ok(fe_nn, rp[0].weight) and len(rp) == 3 \
+            and Fn.gemm_ln_ok(fe_nn.new_empty(1, ffns[0].linear2.in_features), ffns[0].linear2.weight, norms=False)
+        y_raw = None                 # previous frame's last FFN sum BEFORE its LayerNorm (fused form), else None
         with Fn.gemm_sizes_as(rows=Q):                                         # tile configuration of ONE clip's Q rows
             for i in range(T):
-                single_nn = fe_nn[i]                                           # (q, b, c)
-                out = torch.gather(single_nn, 0, gidx[i])                      # out[q, b] = single_nn[idx[q, b], b]
-                first = i == 0 and first_is_start
-                if not first:
-                    # the same reference feeds every layer's cross-attention (tracker.py:278, 293-318): its 6 query
-                    # projections are ONE GEMM (N = layers * C) instead of six launches in the sequential chain
+                if i == 0 and first_is_start:
+                    last_outputs, ref0 = self._first_frame(fe_nn[0], x0_all[0], kv[0])
+                    outputs[0], refs[0] = last_outputs, ref0
+                    continue
+                if not fused:
                     reference = self.ref_proj(last_outputs)
                     q_all = Fn.linear(reference, Wq, bq, own=True)
-                for j in range(self.num_layers):
-                    ref_j = self.ref_proj(single_nn if j == 0 else out) if first else reference
-                    kj = kv[i, :, :, (2 * j) * C:(2 * j + 1) * C]
-                    vj = kv[i, :, :, (2 * j + 1) * C:(2 * j + 2) * C]
-                    qj = None if first else q_all[..., j * C:(j + 1) * C]
-                    out = self.transformer_cross_attention_layers[j].attend(out, ref_j, kj, vj, q_proj=qj)
-                    out = self.transformer_self_attention_layers[j](out)
-                    out = self.transformer_ffn_layers[j](out)
-                refs.append(self.ref_proj(single_nn) if first else reference)
-                last_outputs = out
-                outputs.append(out)
-        return torch.stack(outputs, 0), torch.stack(refs, 0), last_outputs
+                    out = x0_all[i]
+                    for j in range(L):
+                        out = cross[j].attend(out, reference, kv[i][..., j * C:(j + 1) * C],
+                                              kv[i][..., (L + j) * C:(L + j + 1) * C], q_proj=q_all[..., j * C:(j + 1) * C])
+                        out = ffns[j](selfa[j](out))
+                    outputs[i], refs[i] = out, reference
+                    last_outputs = out
+                    continue
+                # ---- reference and the six layer-independent cross-attention terms
+                if y_raw is None:
+                    h, _ = Fn.gemm_ln(last_outputs, rp[0].weight, rp[0].bias, relu=True)
+                else:                 # ... which also materialises the previous frame's output LN_ffn(y) (a_out)
+                    h, _ = Fn.gemm_ln(y_raw, rp[0].weight, rp[0].bias, norm1=ffns[L - 1].norm, relu=True, a_out=outputs[i - 1])
+                h, _ = Fn.gemm_ln(h, rp[1].weight, rp[1].bias, relu=True)
+                reference, _ = Fn.gemm_ln(h, rp[2].weight, rp[2].bias, out=refs[i])
+                q_all = Fn.linear(reference, Wq, bq, own=True)                                     # (Q, B, L C)
+                att = Fn.attention(q_all, kv[i][..., :L * C], kv[i][..., L * C:], L * H, short=Q <= 128)   # 48 heads, one call
+                t = Fn.gemm_nt_stacked(att.view(Q * B, L * C), Wo, bo).view(L, Q, B, C)            # t_j = out_proj_j(att_j)
+                # ---- the layer chain
+                y = x0_all[i]
+                for j in range(L):
+                    sa, ff = selfa[j], ffns[j]
+                    qkv, xc = Fn.gemm_ln(y, sa.self_attn.in_proj_weight, sa.self_attn.in_proj_bias,
+                                         norm1=ffns[j - 1].norm if j else None, add=t[j], norm2=cross[j].norm)
+                    a = Fn.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], H, short=Q <= 128)
+                    v, _ = Fn.gemm_ln(a, sa.self_attn.out_proj.weight, sa.self_attn.out_proj.bias, res=xc)
+                    h, xs = Fn.gemm_ln(v, ff.linear1.weight, ff.linear1.bias, norm1=sa.norm, relu=True)
+                    y, _ = Fn.gemm_ln(h, ff.linear2.weight, ff.linear2.bias, res=xs)
+                y_raw = y
+            if y_raw is not None:
+                outputs[T - 1] = Fn.add_layer_norm(y_raw, None, ffns[L - 1].norm)
+                last_outputs = outputs[T - 1]
+        return outputs, refs, last_outputs
 
     def forward(self, frame_embeds, mask_features, resume=False, return_indices=False, frame_classes=None,
                 frame_embeds_no_norm=None, need_masks=True):
@@ -215,11 +275,11 @@ class ReferringTracker_noiser(nn.Module):
         self.last_indices = indices[0] if B == 1 else indices                  # this call's assignments (tests)
 
         # ---- 2 + 3. K / V of all layers for all frames (one GEMM) and the recurrence, replayed from a hipGraph
-        self._kv_weights(), self._q_weights()                                  # build the cached weights outside capture
+        self._kv_weights(), self._q_weights(), self._o_weights()               # build the cached weights outside capture
         state = self.last_outputs if not first_is_start else torch.zeros_like(fe_nn[0])
         self._rec_first = first_is_start                                       # part of the graph key: fixes control flow
         self._graph.enabled = self.use_graphs
-        outputs, refs, last = self._graph((T, first_is_start), fe_nn.contiguous(), idx_dev, state)
+        outputs, refs, last = self._graph((T, first_is_start, self.fused_chain), fe_nn.contiguous(), idx_dev, state)
         # carried state = the LAST batch entry's (a later `resume` call continues that video)
         self.last_outputs = last[:, B - 1:].clone()
         self.last_reference = refs[T - 1][:, B - 1:].clone()

@@ -47,6 +47,8 @@
  *                               (nn.MultiheadAttention in/out_proj, linear1/2, MLP: dvis_Plus/tracker.py:293-318,
  *                               dvis_Plus/refiner.py:104-139), the cosine matrices of Noiser.match_embds (noiser.py:43-56)
  *                               and the refiner's nn.Conv1d layers as im2col GEMMs (refiner.py:42-54,116-119)
+ *   dvis_gemm_ln             <- projection + the LayerNorm seam in front of it: `tgt = norm(identity + attn)`, `norm(tgt + ffn(tgt))`
+ *                               followed by the next in_proj / linear1 / ref_proj layer, dvis_Plus/tracker.py:45-52, 277-318
  */
 #ifndef DVIS_HIP_H
 #define DVIS_HIP_H
@@ -175,6 +177,14 @@ int dvis_attention_forward(const float *q, const int64_t *q_strides, const float
                            const float *v, const int64_t *v_strides, float *out, const int64_t *o_strides,
                            const uint8_t *mask, const int32_t *allowed_count, int B, int heads, int Lq, int Lk,
                            int d, float scale, void *ws, void *stream);
+/* Same with the kernel chosen by the CALLER instead of from the sizes: 0 = dvis_attention_forward's choice, 1 = the
+ * short-key latency kernel (Lk <= 128: one workgroup per (batch, head, 16-query tile), K / V staged in one memory round
+ * trip).  A (batch, head)'s result depends on the kernel, so a caller that needs the same bits for a clip whether it runs
+ * alone or batched with others (the referring tracker's recurrence, dvis_Plus/tracker.py:277-318) pins it. */
+int dvis_attention_forward_k(const float *q, const int64_t *q_strides, const float *k, const int64_t *k_strides,
+                           const float *v, const int64_t *v_strides, float *out, const int64_t *o_strides,
+                           const uint8_t *mask, const int32_t *allowed_count, int B, int heads, int Lq, int Lk,
+                           int d, float scale, void *ws, void *stream, int kernel);
 
 /*
  * out[r, :] = LayerNorm(x[r, :] + res[r, :]) * gamma + beta, rows x C fp32 (C % 4 == 0, C <= 1024); `res` may be NULL
@@ -380,11 +390,41 @@ int dvis_gemm_nt_hm(const float *A, int64_t lda, int64_t strideA, const float *W
                     const float *bias, const float *res, int64_t ldres, int64_t strideRes, float *C, int64_t ldc,
                     int64_t strideC, int M, int N, int K, int batch, int act, int config, int head_d, int64_t head_stride,
                     void *stream);
+/* Same as dvis_gemm_nt with a bias PER BATCH ENTRY (strideBias floats apart; 0 = dvis_gemm_nt): `batch` projections with
+ * their own weights and biases as one launch — the out-projections of the referring tracker's six cross-attention layers,
+ * whose attention does not depend on the layer chain (dvis_Plus/tracker.py:293-318: q = reference, k / v = the frame's queries
+ * in every layer), batched per frame. */
+int dvis_gemm_nt_bb(const float *A, int64_t lda, int64_t strideA, const float *W, int64_t ldw, int64_t strideW,
+                    const float *bias, int64_t strideBias, const float *res, int64_t ldres, int64_t strideRes, float *C,
+                    int64_t ldc, int64_t strideC, int M, int N, int K, int batch, int act, int config, void *stream);
 int dvis_gemm_num_configs(void);
 /* The configuration dvis_gemm_nt(config = -1) would choose for these sizes.  A row's result depends on (N, K, config) only,
  * so a caller that wants the SAME bits for a row whether it is computed alone or stacked with other rows (the tracker run
  * for one clip or for two clips at once) pins the configuration of the smaller problem. */
 int dvis_gemm_pick_config(int M, int N, int K, int batch);
+
+/*
+ * GEMM with the LayerNorm(s) of the post-norm transformer blocks folded into its A-operand prologue:
+ *   X = LN2( LN1(A) + ADD ),   C = act( X W^T + bias + res ),   a_out = X
+ * LN1 / LN2 = LayerNorm over the K columns of a row (two-pass mean / centred variance, eps1 / eps2) with affine
+ * (gamma, beta); each is skipped when its gamma is NULL, ADD (M x K, row stride ldadd) when NULL; a_out (M x K, optional)
+ * receives the normalised rows.  Replaces the `tgt = norm(identity + attn(...))` / `tgt = norm(tgt + ffn(tgt))` seams of
+ * ReferringCrossAttentionLayer / SelfAttentionLayer / FFNLayer (dvis_Plus/tracker.py:45-52,
+ * mask2former_video/.../video_mask2former_transformer_decoder.py:47-50,166-170) between two projections: the producing
+ * dvis_gemm_nt writes the raw residual sum, the consumer normalises it while its weight fragments are in flight — no
+ * LayerNorm launch, no inter-workgroup hand-off.  Forms: none / LN1 / ADD + LN2 / LN1 + ADD + LN2.  K % 16 == 0, K <= 512 (2048
+ * without norms), N % 4 == 0, row strides % 4 == 0, 16-byte aligned
+ * operands (dvis_gemm_ln_supported; DVIS_E_ARG otherwise).  Deterministic: a row's result depends on (N, K, config) only.
+ */
+int dvis_gemm_ln(const float *A, int64_t lda, const float *add, int64_t ldadd, const float *gamma1, const float *beta1,
+                 float eps1, const float *gamma2, const float *beta2, float eps2, float *a_out, int64_t ldaout,
+                 const float *W, int64_t ldw, const float *bias, const float *res, int64_t ldres, float *C, int64_t ldc,
+                 int M, int N, int K, int act, int config, void *stream);
+/* norms != 0: the call carries LayerNorms / ADD (K <= 512); a plain call (the "everything in one memory round trip" form of
+ * dvis_gemm_nt for launch-bound chains) reaches K <= 2048. */
+int dvis_gemm_ln_supported(int M, int N, int K, int norms);
+int dvis_gemm_ln_num_configs(void);
+int dvis_gemm_ln_pick_config(int M, int N, int K);
 
 #ifdef __cplusplus
 }

@@ -88,7 +88,7 @@ def make_msda_inputs(N, M, D, shapes, Lq, P, dtype=torch.float32, seed=0, spread
 # tests exercise the product's HOST logic (module wiring, state_dict keys, batching, clip sharding) on CPU
 # tensors.  The product itself has no such path: without this fixture the ops raise on CPU tensors.
 # ---------------------------------------------------------------------------------------------------------------
-def _o_attention(q, k, v, nheads, mask=None, allowed_count=None, out=None):
+def _o_attention(q, k, v, nheads, mask=None, allowed_count=None, out=None, short=False):
     Lq, B, C = q.shape
     Lk, d = k.shape[0], C // nheads
     qh = q.reshape(Lq, B, nheads, d).permute(1, 2, 0, 3)

@@ -82,8 +82,11 @@ def test_decoders_vs_reference_outputs():
         torch.testing.assert_close(out[k].cpu(), g.outs[k], **TIGHT)
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("graphs", [True, False])
-def test_tracker_vs_reference_outputs_and_indices(graphs):
+def test_tracker_vs_reference_outputs_and_indices(graphs, fused):
+    """fused: the chain with hoisted cross-attentions and LayerNorms in the GEMM prologues (dvis_gemm_ln, the default) /
+    the layer-by-layer form — both against the reference's outputs."""
     from dvis_plus_amd.tracker import ReferringTracker_noiser
     g = Golden("g4_tracker")
     cfg, o = g.meta["cfg"], g.outs
@@ -93,6 +96,7 @@ def test_tracker_vs_reference_outputs_and_indices(graphs):
     trk.load_state_dict(g.sd, strict=True)
     trk = trk.to(DEV)
     trk.use_graphs = graphs
+    trk.fused_chain = fused
     T1 = cfg["T1"]
     i = _dev(g.ins)
     fe, fn, mf = i["frame_embeds"], i["frame_embeds_no_norm"], i["mask_features"]

@@ -137,6 +137,38 @@ def test_match_chain_equals_framewise_reference_matching():
         last = cur[i][want]
 
 
+@pytest.mark.parametrize("kind", ["tracked", "unrelated", "ties", "identical", "zeros"])
+def test_threaded_match_chain_equals_sequential_solver(kind):
+    """dvis_match_chain solves the frames' canonical problems on host threads and composes the permutations where the
+    optimum is certified unique (no alternating cycle of tight reduced costs), else re-solves in the chain's row order:
+    the indices must be those of the frame-by-frame loop — scipy's scan order on tied matrices included (duplicate queries,
+    zero vectors), which is what `ties` / `zeros` / `identical` exercise."""
+    from dvis_plus_amd.tracker import cosine_costs, match_chain
+    from oracle.dvis_torch import match_embds
+    g = torch.Generator().manual_seed(3)
+    T, Q, C = 9, 40, 64
+    if kind == "tracked":
+        base = torch.randn(Q, C, generator=g)
+        cur = torch.stack([base[torch.randperm(Q, generator=g)] + 0.3 * torch.randn(Q, C, generator=g) for _ in range(T)])
+    else:
+        cur = torch.randn(T, Q, C, generator=g)
+    if kind == "ties":
+        cur[:, 4] = cur[:, 5]
+        cur[:, 20] = cur[:, 21]
+        cur[2:5, 10:14] = 0
+    if kind == "identical":
+        cur[:] = cur[0].clone()
+    if kind == "zeros":
+        cur[:] = 0
+    idx = match_chain(cosine_costs(cur, cur[0]))
+    last = None
+    for i in range(T):
+        ref = cur[i] if last is None else last
+        want = match_embds(ref[:, None], cur[i][:, None])
+        assert np.array_equal(idx[i], want), (kind, i)
+        last = cur[i][want]
+
+
 def test_lsap_matches_golden_and_scipy():
     import ctypes
     from scipy.optimize import linear_sum_assignment
@@ -612,7 +644,13 @@ def test_reloaded_weights_reach_the_fused_kv_projection(oracle_ops):
     assert torch.equal(got["pred_masks"], want["pred_masks"]) and got["segments_infos"] == want["segments_infos"]
     W, _ = m.tracker._kv_weights()
     C = m.tracker.decoder_norm.weight.shape[0]
-    assert torch.equal(W[:2 * C], other.tracker.transformer_cross_attention_layers[0].multihead_attn.in_proj_weight[C:])
+    # tracker layout: all layers' K rows, then all layers' V rows (layer l's head h = head 8 l + h of ONE attention call)
+    L = m.tracker.num_layers
+    ipw = other.tracker.transformer_cross_attention_layers[0].multihead_attn.in_proj_weight
+    assert torch.equal(W[:C], ipw[C:2 * C]) and torch.equal(W[L * C:(L + 1) * C], ipw[2 * C:])
+    Wo, bo = m.tracker._o_weights()
+    assert torch.equal(Wo[1], other.tracker.transformer_cross_attention_layers[1].multihead_attn.out_proj.weight)
+    assert torch.equal(bo[1], other.tracker.transformer_cross_attention_layers[1].multihead_attn.out_proj.bias)
     # the graph cache is bounded (least recently used entry dropped)
     calls = []
     g = GraphRunner(lambda x: calls.append(1) or x, max_entries=2)
