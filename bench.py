@@ -24,6 +24,8 @@ Also reported on the one JSON line:
   candidates_100  the same workload with every non-void query sent to the panoptic stage (short second timed pass);
   roofline      the dominant hand-written kernel of the path, MSDeformAttn forward: algorithmic bytes (61 824 000 B
                 per frame-layer) / its mean launch time (HIP events on the launch stream) vs 8 TB/s.
+  roofline_tracker  the referring tracker's recurrence (its captured hipGraph replayed alone): the tracker's parameter bytes
+                x frames / replay time vs 8 TB/s — SURVEY.md §8(d)'s weight-streaming bound for the latency-bound chain.
   cpu_baseline  the oracle's restatement of the reference pipeline (torch fp32 CPU ops, all host cores) on a bounded
                 sample of the same clip, in the metric's own unit, plus the oracle's C port of the MSDeformAttn kernel
                 (rank 0, N=1 only).
@@ -54,6 +56,39 @@ def synthetic_clip(T, device, seed=1234):
         pat = (127 + 100 * torch.sin(xx * (1 + t % 3) + 0.2 * t) * torch.cos(yy * 2 + 0.1 * t)).clamp(0, 255)
         frames.append(((noise[t].float() * 0.3 + pat[None] * 0.7)).to(torch.uint8))
     return torch.stack(frames).to(device)
+
+
+def tracker_roofline(model, n=10):
+    """"tracker: latency-bound (report achieved vs weight-streaming bound 101 MB/frame)".  Replays the
+    captured hipGraph of the referring tracker's recurrence (the strictly sequential part: dvis_plus_amd/tracker.py
+    _recurrence, dvis_Plus/tracker.py:277-318) on the current stream between two HIP events: algorithmic bytes = the
+    tracker's fp32 parameters, which every frame of the recurrence streams once, x frames per replay."""
+    trk = getattr(model, "tracker", None)
+    cache = getattr(getattr(trk, "_graph", None), "_cache", None)
+    if not cache:
+        return None
+    graph, static_in, _ = next(reversed(cache.values()))
+    T, Q, B, C = static_in[0].shape
+    params = sum(p.numel() for p in trk.parameters())
+    for _ in range(2):
+        graph.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        graph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / n
+    gbs = 4.0 * params * T / sec / 1e9
+    return {"bound": "hbm (weight streaming; latency-bound in practice)",
+            "kernel": "referring tracker recurrence (hipGraph: dvis_gemm_ln / dvis_gemm_nt / attn_short chain)",
+            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "traffic": None, "alg_bytes_per_frame": 4 * params, "frames_per_replay": int(T), "clips_per_replay": int(B),
+            "ms_per_replay": round(sec * 1e3, 3), "us_per_frame": round(sec * 1e6 / T, 1), "replays_timed": n,
+            "dependent_launches_per_frame": 36 if getattr(trk, "fused_chain", False) else 65,
+            "note": "the recurrence alone, nothing else on the device; 36 launches per frame = 6 (reference MLP, 48-head "
+                    "cross-attention, batched out-projection) + 6 layers x 5 (profiles/r04_tracker_timeline.txt)"}
 
 
 class MsdaTimer:
@@ -443,6 +478,15 @@ def main():
                 "host": socket.gethostname()}
         per_rank = [None] * torch.distributed.get_world_size()
         torch.distributed.all_gather_object(per_rank, mine)
+        if not one_device:
+            # a real multi-GPU run: one rank per GPU over RCCL, or it is not the measurement the line claims to be
+            bus = [r["pci_bus"] for r in per_rank]
+            ok = torch.distributed.get_backend() == "nccl" and len({(r["host"], r["device"]) for r in per_rank}) == len(per_rank) \
+                and (None in bus or len({(r["host"], b) for r, b in zip(per_rank, bus)}) == len(per_rank))
+            if not ok:
+                sys.stderr.write(f"bench.py: N > 1 needs backend nccl (RCCL) and one distinct GPU per rank; got backend "
+                                 f"{torch.distributed.get_backend()}, ranks {per_rank}\n")
+                sys.exit(3)
         dist_info = {"world_size": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
                      "ranks": per_rank, "ranks_share_one_gpu": bool(one_device),
                      "split": "frames sharded contiguously (fixed split), one all-gather of per-frame queries "
@@ -523,6 +567,10 @@ def main():
             res["owner_rounds"] = owner_line
         if cand100 is not None:
             res["candidates_100"] = cand100
+        if world == 1 and not dist_on and not args.no_extra:
+            trk_roof = tracker_roofline(model)
+            if trk_roof is not None:
+                res["roofline_tracker"] = trk_roof
         if world == 1 and not dist_on and args.mode == "offline" and not args.no_extra:
             res["stages_ms"] = stage_breakdown(model, videos[0], args.task)
         if world == 1 and not args.no_cpu_baseline:

@@ -430,6 +430,11 @@ class DVIS_Plus_offline(_VideoBase):
     def _track_core(self, embds, embds_nn):
         """Tracker + refiner over the T gathered frames of one clip: (mask_embed (1,T,Q,Cm), cls (Q,K+1), aux (Q,K+1))."""
         to_bctq = lambda z: z.permute(2, 0, 1).unsqueeze(0)
+        # one canonical memory layout, whatever the caller holds (a column slice of the all-gather's packed buffer, a copy
+        # of it, a decoder output): torch's reductions pick their vectorisation from the strides, so the SAME values in another
+        # layout give other last bits (1e-5 on the refined embeddings, tools/stream_shard_check.py) — and the replicated ranks
+        # of north_star's split must agree bit for bit
+        embds, embds_nn = embds.contiguous(), embds_nn.contiguous()
         track = self.tracker(to_bctq(embds), None, resume=self._resume, frame_embeds_no_norm=to_bctq(embds_nn),
                              need_masks=False)
         ref = self.refiner(track["pred_embds"], to_bctq(embds_nn), None, need_masks=False)

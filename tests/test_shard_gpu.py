@@ -23,3 +23,26 @@ def test_sharded_stream_on_one_gpu(world, frames, port, tmp_path):
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     tail = "\n".join((r.stdout + r.stderr).splitlines()[-25:])
     assert r.returncode == 0 and f"SHARD_CHECK OK world={world}" in r.stdout, tail
+
+
+def test_bench_self_launches_two_ranks_on_one_gpu(tmp_path):
+    """`python bench.py --gpus 2` without a launcher around it starts its two ranks itself (bench.launch_command; the
+    reference's analogue is detectron2's launch(main, args.num_gpus), train_net_video.py:322-329).  On a one-GPU box the ranks
+    share the device over gloo and the line says so; what is asserted is everything the first RCCL run will need to get
+    right above the transport: rc 0, ONE JSON line from rank 0, dist.world_size == 2, both measurements present (the
+    headline = north_star's split, and `owner_rounds`), the metric and the workload of BASELINE.json."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extra"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    tail = "\n".join((r.stdout + r.stderr).splitlines()[-25:])
+    assert r.returncode == 0, tail
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, tail
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["unit"] == "frames/s" and d["value"] > 0
+    assert d["metric"].startswith("frames/sec DVIS++ R50 offline, 720p T=30")
+    assert d["dist"]["world_size"] == 2 and len(d["dist"]["ranks"]) == 2
+    assert d["dist"]["ranks_share_one_gpu"] is True and d["dist"]["backend"] == "gloo"      # this box has one GPU
+    assert d["owner_rounds"]["value"] > 0 and d["config"]["tracker_owner_rounds"] is False
+    assert "frames sharded 2-way" in d["config"]["workload"]

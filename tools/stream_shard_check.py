@@ -28,61 +28,104 @@ def main():
     dev = torch.device("cuda", 0)
     dist.init_process_group(os.environ.get("DVIS_DIST_BACKEND", "gloo"))
     from dvis_plus_amd.meta_architecture import build_dvis_plus_r50
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import pipeline_parity as PPar
     torch.manual_seed(0)
-    model = build_dvis_plus_r50("offline", task="vps", object_mask_threshold=0.008).to(dev).eval()
+    model = build_dvis_plus_r50("offline", task="vps", object_mask_threshold=0.0)
+    # decisive masks (as trained ones are) and a deformable attention with something to do: with random-init mask heads every
+    # sigmoid is 0.5 +- 0.005, every pixel of every comparison below would sit "within tolerance" and prove nothing
+    PPar.perturb_msda(model.sem_seg_head.pixel_decoder)
+    PPar.sharpen_masks(model, PPar.SHARPEN)
+    model = model.to(dev).eval()
     g = torch.Generator().manual_seed(1)
     clips = []
     for c in range(args.clips):
         T = args.frames - (c % 2)                 # ragged lengths
-        clips.append({"image": torch.randint(0, 256, (T, 3, args.height, args.width), generator=g).float().to(dev),
-                      "height": args.height, "width": args.width})
-    stash = []
+        # low-frequency pattern + noise (bench.synthetic_clip's recipe at this size): non-degenerate, spatially coherent masks
+        yy, xx = torch.meshgrid(torch.linspace(0, 6.28, args.height), torch.linspace(0, 6.28, args.width), indexing="ij")
+        noise = torch.randint(0, 256, (T, 3, args.height, args.width), generator=g).float()
+        pat = torch.stack([(127 + 100 * torch.sin(xx * (1 + (t + c) % 3) + 0.2 * t) * torch.cos(yy * 2 + 0.1 * t)).clamp(0, 255)
+                           for t in range(T)])
+        img = (noise * 0.3 + pat[:, None] * 0.7).floor()
+        clips.append({"image": img.to(dev), "height": args.height, "width": args.width})
+    # per-clip score threshold that sends 8 queries to the panoptic stage (random-init class scores are near-uniform); rank
+    # 0's value for everybody (the calibration pass itself runs sharded: same collectives on every rank)
+    for clip in clips:
+        thr = [bench.calibrate_threshold(model, [clip], 8)]
+        dist.broadcast_object_list(thr, src=0)
+        clip["object_mask_threshold"] = thr[0]
+    model.allow_input_threshold = True          # (the per-clip thresholds above are honoured)
+    model.overlap_threshold = 0.0               # every candidate that wins a pixel becomes a segment: whole arg-max map compared
+    stash, gathered = [], []
     finish = model._finish_phase
+    gather = model.clip_shard.all_gather_frames
 
     def spy(st, mask_embed, cls, aux):
         stash.append((mask_embed.clone(), cls.clone(), aux.clone()))
         return finish(st, mask_embed, cls, aux)
+
+    def gather_spy(parts, T, **kw):
+        out = gather(parts, T, **kw)
+        gathered.append([t.clone() for t in out[:2]])
+        return out
     model._finish_phase = spy
+    model.clip_shard.all_gather_frames = gather_spy
 
     def run():
         stash.clear()
+        gathered.clear()
         outs = [{"masks": o["pred_masks"].cpu(), "segs": o["segments_infos"], "ids": o["pred_ids"],
                  "fr": o["frame_ids"]} for o in model.stream(clips)]
         torch.cuda.synchronize()
-        return outs, [tuple(t.cpu() for t in s_) for s_ in stash]
+        return outs, list(stash), list(gathered)
 
-    def compare(x, y):
-        """(largest |difference| of the refined mask embeddings / class logits, fraction of differing panoptic pixels)"""
-        d = max(float((a - b).abs().max()) for sx, sy in zip(x[1], y[1]) for a, b in zip(sx, sy))
-        # (the two schedules split a ragged clip differently — owner rounds rotate the split, one clip per round does
-        # not — so a rank's pixel maps are comparable only where it holds the same frames in both)
-        px = max([float((a["masks"] != b["masks"]).float().mean()) for a, b in zip(x[0], y[0])
-                  if a["fr"] == b["fr"] and a["masks"].numel()] or [0.0])
-        return d, px, all(a["segs"] == b["segs"] and a["ids"] == b["ids"] for a, b in zip(x[0], y[0]))
-    run()                                          # warm-up: library algorithm choices settle on the first call
+    def same_frames_equal(x, y):
+        """Both schedules' panoptic maps, where a rank holds the same frames in both (owner rounds rotate the ragged split)."""
+        return all(torch.equal(a["masks"], b["masks"]) for a, b in zip(x[0], y[0]) if a["fr"] == b["fr"])
+    run()                                          # warm-up
     own1, own2 = run(), run()                      # rounds of `world` clips, one tracker rank per clip
+    bad = 0
+    # (1) run to run.  Phase A goes through library kernels whose bits may differ from run to run at these small shapes
+    # (measured reproducible at the benchmark's 720p T = 30, tools/determinism_probe.py; not at 360p with several
+    # processes on one GPU): reported, not required.  Phase B is own deterministic code: the SAME gathered queries must
+    # give the same bits — checked in (2) below on this run's own tensors — and the decisions must agree either way.
+    in_eq = all(torch.equal(a, b) for gx, gy in zip(own1[2], own2[2]) for a, b in zip(gx, gy))
+    out_eq = all(torch.equal(a, b) for sx, sy in zip(own1[1], own2[1]) for a, b in zip(sx, sy))
+    r2r = (out_eq or not in_eq) and all(a["segs"] == b["segs"] and a["ids"] == b["ids"] for a, b in zip(own1[0], own2[0]))
+    print(f"rank {rank}: run-to-run: gathered queries (phase A) bit-identical={in_eq}, tracker / refiner results bit-identical={out_eq}",
+          flush=True)
+    # (2) the property north_star's split relies on (no broadcast of the replicated results): the tracker + refiner of clip
+    # j, run by ITS OWNER RANK in the owner rounds and received here through the all-gather, against THIS rank's own
+    # replicated run (_track_core) from the same gathered queries -> torch.equal, on every rank, for every clip.
+    model.keep = False
+    cross = True
+    for ci, ((emb, emb_nn), (me_o, cls_o, aux_o)) in enumerate(zip(own2[2], own2[1])):
+        with torch.no_grad():       # (under autograd the op front-ends take torch's library kernels: other bits)
+            me, cls, aux = model._track_core(emb, emb_nn)
+        T = me.shape[1]
+        eq = torch.equal(me, me_o[:, :T]) and torch.equal(cls, cls_o) and torch.equal(aux, aux_o)
+        if not eq:
+            print(f"  rank {rank} clip {ci}: owner's results differ from this rank's replicated run: max|d| embeddings "
+                  f"{float((me - me_o[:, :T]).abs().max()):.2e}, class logits {float((cls - cls_o).abs().max()):.2e}", flush=True)
+        cross &= eq
+    # (3) the replicated schedule end to end (one clip per round: other merged batch shapes in phase A): same segment lists
     model.owner_rounds = False
-    repl = run()                                   # tracker replicated on every rank
+    repl = run()
+    segs_eq = all(a["segs"] == b["segs"] and a["ids"] == b["ids"] for a, b in zip(own2[0], repl[0]))
+    print(f"rank {rank}: owner rounds run-to-run consistent={r2r}; owner's tracker results == this rank's replicated "
+          f"tracker from the same gathered queries (torch.equal)={cross}; owner vs replicated schedule segment lists equal="
+          f"{segs_eq}, maps equal on shared frames={same_frames_equal(own2, repl)}", flush=True)
     outs = own2[0]
-    d0, p0, s0 = compare(own1, own2)
-    d1, p1, s1 = compare(own2, repl)
-    print(f"rank {rank}: owner rounds run-to-run: max|d|={d0:.2e} pixels={p0:.2e} segments_equal={s0}; "
-          f"owner vs replicated tracker: max|d|={d1:.2e} pixels={p1:.2e} segments_equal={s1}", flush=True)
-    for ci in range(len(clips)):
-        f = lambda x, y: float((x[0][ci]["masks"] != y[0][ci]["masks"]).float().mean()) \
-            if x[0][ci]["masks"].numel() and x[0][ci]["fr"] == y[0][ci]["fr"] else 0.
-        print(f"  rank {rank} clip {ci} frames {own2[0][ci]['fr']}: pixels run-to-run {f(own1, own2):.2e}, "
-              f"owner vs replicated {f(own2, repl):.2e}, ids {own2[0][ci]['ids']} / {repl[0][ci]['ids']}", flush=True)
-    # run-to-run noise (library kernels with atomics) is 3e-6 .. 1e-4; the owner's and the replicated tracker are different
-    # hipGraph captures (the library may pick other GEMM algorithms) and the tracker feeds its own output back 6 layers x T
-    # frames: 1e-4 .. 1e-3 observed on embeddings of order 1.  Segment lists and ids must be EQUAL.
-    same = s1 and d1 <= 5e-3
+    same = r2r and cross and segs_eq
     flag = torch.tensor([0 if same else 1], device=dev if dist.get_backend() == 'nccl' else 'cpu')
     dist.all_reduce(flag)
     os.makedirs(args.out, exist_ok=True)
     torch.save(outs, os.path.join(args.out, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
+    model._finish_phase = finish
     model._clip_shard = None                       # forget the (forced) collectives of the destroyed group
     if rank == 0:
         parts = [torch.load(os.path.join(args.out, f"rank{r}.pt")) for r in range(world)]
@@ -98,20 +141,26 @@ def main():
                   f"segments_equal={segs}")
             bad += (not segs) or diff > 3e-3   # other batch sizes -> other conv / GEMM algorithms -> a few tie pixels flip
         # ---- and against the ORACLE (not only against the unsharded product): the sharded ranks' concatenated panoptic
-        # map of clip 0 vs the CPU oracle's windowed pipeline on the same frames and weights (from the backbone outputs on)
-        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-        import pipeline_parity as PPar
+        # map of clip 0 vs the CPU oracle's windowed pipeline on the same frames and weights (from the backbone outputs on),
+        # with decisive masks: only pixels the MEASURED logit error can explain may differ, and they must be a small minority
         sd = PPar.cpu_state(model)
         clip0 = clips[0]
         ref, stages = PPar.run_oracle(model, sd, [f for f in clip0["image"].cpu()], offline=True, task="vps",
-                                      object_mask_threshold=model.object_mask_threshold, out_hw=(args.height, args.width))
+                                      object_mask_threshold=clip0["object_mask_threshold"], overlap_threshold=0.0,
+                                      out_hw=(args.height, args.width))
         masks0 = torch.cat([p[0]["masks"] for p in sorted(parts, key=lambda p: (p[0]["fr"] or [1 << 30])[0])], 0)
         sharded = {"pred_masks": masks0, "segments_infos": parts[0][0]["segs"], "pred_ids": parts[0][0]["ids"]}
+        tol = PPar.logit_tolerance(float(stages["masks"][stages["vps_query_ids"]].abs().max()))
         try:
-            n = PPar.compare_vps(sharded, ref, stages, f"sharded stream() over {world} ranks, clip 0 vs ORACLE")
-            print(f"clip 0 vs oracle: segment lists equal, {n} differing pixels, all within the 1e-3 logit allowance")
+            assert len(ref[1]) > 0, "degenerate check: the oracle keeps no segment"
+            n = PPar.compare_vps(sharded, ref, stages, f"sharded stream() over {world} ranks, clip 0 vs ORACLE", tol_logit=tol,
+                                 max_count=int(0.02 * masks0.numel()))
+            print(f"clip 0 vs oracle: {len(ref[1])} segments, lists equal; {n} of {masks0.numel()} pixels differ, each within the "
+                  f"logit allowance {tol:.1e} (|logit| up to {float(stages['masks'][stages['vps_query_ids']].abs().max()):.1f})")
         except AssertionError as e:
             print("clip 0 vs oracle FAILED:", str(e)[:500])
+            print("   product ids", sharded["pred_ids"], "segments", sharded["segments_infos"], "\n   oracle ids", ref[2], "segments",
+                  ref[1], "\n   oracle candidate queries", stages["vps_query_ids"].tolist(), "threshold", clip0["object_mask_threshold"])
             bad += 1
         print("SHARD_CHECK", "OK" if not bad else "FAILED", f"world={world}")
         sys.exit(1 if bad else 0)
