@@ -82,6 +82,59 @@ def test_resnet50_fused_vs_unfused_fp64(hw, monkeypatch):
     assert m.output_shape()["res4"].channels == 1024 and m.output_shape()["res4"].stride == 16
 
 
+def test_resnet50_production_size_strict_own_kernels_vs_unfused_fp64():
+    """The benchmarked shape: 2 frames at 736 x 1280 (720p padded), product defaults (strict mode: a layer that met an
+    unserved shape would raise instead of taking a torch formulation).  The composed backbone — Winograd 3x3, MFMA 1x1,
+    stride-2 1x1 shortcut, direct stride-2 3x3, 7x7 stem, fused epilogues — against the independent fp64 evaluation on the
+    CPU (not against itself: every pipeline test feeds the oracle this backbone's own outputs), and a spy on the C ABI
+    asserting that each of the five own convolution kernels is what actually ran and that no library convolution did.
+    detectron2 semantics restated: STRIDE_IN_1X1 False (configs/dvis_Plus/VIPSeg/Base-*.yaml:13), FrozenBN, SURVEY App. B."""
+    from dvis_plus_amd import native
+    from dvis_plus_amd.backbone import build_resnet50
+    g = torch.Generator().manual_seed(21)
+    torch.manual_seed(21)
+    m = build_resnet50().eval()
+    _randomise_frozen_bn(m, g)
+    x = torch.randn(2, 3, 736, 1280, generator=g)
+    sd = {k: v.double() for k, v in m.state_dict().items()}
+    lib = native.lib()
+    names = ("dvis_conv3x3_winograd", "dvis_conv1x1_mfma", "dvis_conv1x1s2_mfma", "dvis_conv3x3s2", "dvis_conv7x7s2",
+             "dvis_conv1x1_bias_act", "dvis_bias_relu_maxpool")
+    calls = {n: 0 for n in names}
+    orig = {n: getattr(lib, n) for n in names}
+    lib_convs = []
+    conv2d = F.conv2d
+
+    def counting(n):
+        def call(*a):
+            calls[n] += 1
+            return orig[n](*a)
+        return call
+    m = m.to(DEV)
+    try:
+        for n in names:
+            setattr(lib, n, counting(n))
+        F.conv2d = lambda *a, **k: (lib_convs.append(tuple(a[0].shape)), conv2d(*a, **k))[1]
+        with torch.no_grad():
+            got = m(x.to(DEV))
+        torch.cuda.synchronize()
+    finally:
+        F.conv2d = conv2d
+        for n in names:
+            setattr(lib, n, orig[n])
+    assert not lib_convs, f"library convolutions ran at the production size: {lib_convs}"
+    # 16 bottlenecks: 13 stride-1 3x3 (Winograd) + 3 stride-2 3x3; 4 shortcuts (1 stride-1, 3 stride-2); the stem
+    assert calls["dvis_conv3x3_winograd"] == 13 and calls["dvis_conv3x3s2"] == 3 and calls["dvis_conv7x7s2"] == 1
+    assert calls["dvis_conv1x1s2_mfma"] == 3 and calls["dvis_bias_relu_maxpool"] == 1
+    assert calls["dvis_conv1x1_mfma"] > 0 and calls["dvis_conv1x1_mfma"] + calls["dvis_conv1x1_bias_act"] == 33, calls
+    want = _resnet50_fp64(sd, x.double())
+    for k, c, s in (("res2", 256, 4), ("res3", 512, 8), ("res4", 1024, 16), ("res5", 2048, 32)):
+        assert got[k].shape == want[k].shape == (2, c, 736 // s, 1280 // s)
+        err = (got[k].double().cpu() - want[k]).abs().max().item()
+        scale = want[k].abs().max().item()
+        assert err <= 2e-4 * scale, f"{k}: max|err| {err:.3e} vs max|ref| {scale:.3e}"
+
+
 def test_refold_after_weight_reload(monkeypatch):
     """The folded weights are cached per parameter version: loading other weights must refresh them."""
     from dvis_plus_amd.backbone import build_resnet50
