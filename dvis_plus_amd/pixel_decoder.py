@@ -36,7 +36,9 @@ from .registry import SEM_SEG_HEADS_REGISTRY, ShapeSpec
 # set-up phase reads 22 MB more through scattered 16-byte loads) — a wash, so the plain form stays the default.
 _POS_IN_KERNEL = os.environ.get("DVIS_MSDA_POS", "0") == "1"
 # rows of the fused offsets | logits projection permuted into per-head slots (MSDeformAttn._fused_projection)
-_MSDA_SLOTS = os.environ.get("DVIS_MSDA_SLOTS", "0") == "1"
+# 1: slot = [2LP offsets | LP logits | pad]; 2: slot = [LP logits | 2LP offsets | pad] (the logits 16-byte aligned at the slot
+# start — round 4's probe of round 3's "+6 %": profiles/r04_msda_slot_orders.txt)
+_MSDA_SLOTS = int(os.environ.get("DVIS_MSDA_SLOTS", "0") or 0)
 # the value projection written HEAD-MAJOR (M, N, S, D) by the own GEMM's epilogue and gathered from that layout
 _MSDA_HM = os.environ.get("DVIS_MSDA_HM", "0") == "1"
 
@@ -136,10 +138,11 @@ class MSDeformAttn(nn.Module):
                 C = so.weight.shape[1]
                 w = so.weight.new_zeros(M, slot, C)
                 b = so.bias.new_zeros(M, slot)
-                w[:, :2 * LP] = so.weight.detach().view(M, 2 * LP, C)
-                w[:, 2 * LP:3 * LP] = aw.weight.detach().view(M, LP, C)
-                b[:, :2 * LP] = so.bias.detach().view(M, 2 * LP)
-                b[:, 2 * LP:3 * LP] = aw.bias.detach().view(M, LP)
+                o0, l0 = (LP, 0) if _MSDA_SLOTS == 2 else (0, 2 * LP)       # where the offsets / the logits start in a slot
+                w[:, o0:o0 + 2 * LP] = so.weight.detach().view(M, 2 * LP, C)
+                w[:, l0:l0 + LP] = aw.weight.detach().view(M, LP, C)
+                b[:, o0:o0 + 2 * LP] = so.bias.detach().view(M, 2 * LP)
+                b[:, l0:l0 + LP] = aw.bias.detach().view(M, LP)
                 w, b = w.view(M * slot, C), b.view(M * slot)
             else:
                 w = torch.cat([so.weight.detach(), aw.weight.detach()], 0)
@@ -181,17 +184,18 @@ class MSDeformAttn(nn.Module):
             value = value.view(N, Len_in, M, self.d_model // M)
         if fast:
             w, b, slot = self._fused_projection()
-            n_off = 2 * L * P if slot else M * L * P * 2        # where a row's logits start (slots: inside the head's slot)
+            # where a row's offsets / logits start (slots: inside the head's slot)
+            o_off, l_off = ((L * P, 0) if _MSDA_SLOTS == 2 else (0, 2 * L * P)) if slot else (0, M * L * P * 2)
             po = pl = None
             if query_pos is not None and query_pos.shape[0] == 1 and _POS_IN_KERNEL:
                 pp = Fn.linear(query_pos[0], w)                                    # (Lq, 3*M*L*P): tiny, once per call
-                po, pl = pp, pp[:, n_off:]
+                po, pl = pp[:, o_off:], pp[:, l_off:]
             elif query_pos is not None:
                 query = query + query_pos
             proj = Fn.linear(query.reshape(N * Len_q, self.d_model), w, b)         # offsets | logits in one GEMM
             ref = reference_points if reference_points.is_contiguous() else reference_points.contiguous()
             output = Fn.msda_fused_forward(value, input_spatial_shapes, input_level_start_index, ref,
-                                           proj, proj[:, n_off:], L, P, shapes_host=spatial_shapes_py,
+                                           proj[:, o_off:], proj[:, l_off:], L, P, shapes_host=spatial_shapes_py,
                                            pos_offsets=po, pos_logits=pl, head_stride=slot, value_head_major=hm)
             return Fn.linear(output, self.output_proj.weight, self.output_proj.bias)
         if query_pos is not None:

@@ -19,7 +19,7 @@ def _dev(d):
     return {k: v.to(DEV) for k, v in d.items()}
 
 
-@pytest.mark.parametrize("slots,hm", [(False, False), (True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("slots,hm", [(0, False), (1, False), (0, True), (1, True), (2, False)])
 def test_pixel_decoder_vs_reference_outputs(slots, hm, monkeypatch):
     """slots: the fused offsets | logits projection with its rows permuted into per-head slots (dvis_msda_fused_forward_slots:
     a (query, head) pair reads one contiguous run of its projection row) — same results as the reference's row order."""
@@ -45,7 +45,7 @@ def test_pixel_decoder_vs_reference_outputs(slots, hm, monkeypatch):
         shapes = torch.tensor([(2, 3), (4, 6), (8, 12)], device=DEV)
         lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
         a = attn(i["attn_query"], i["attn_ref"], i["attn_src"], shapes, lsi, None)
-        assert (attn._fused_projection()[2] > 0) == slots            # 2 heads x 36 = 72 -> 128 columns = 2 slots of 64
+        assert (attn._fused_projection()[2] > 0) == bool(slots)            # 2 heads x 36 = 72 -> 128 columns = 2 slots of 64
     for got, key in ((mf, "mask_features"), (out0, "out0"), (ms[0], "ms0"), (ms[1], "ms1"), (ms[2], "ms2"),
                      (a, "attn_out")):
         torch.testing.assert_close(got.cpu(), g.outs[key], **TOL)

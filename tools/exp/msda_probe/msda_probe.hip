@@ -2,6 +2,8 @@
 //   EXP bit 0: skip the corner gathers of all levels but the last (what an LDS-served level would cost at best)
 //   EXP bit 1: skip every gather (set-up + stores only)
 //   EXP bit 2: value laid out head-major (N, M, S, D) instead of (N, S, M, D)
+//   EXP bit 6: the corner lines of the COARSEST level (l = 0) go TA -> LDS (buffer_load ... lds, no VGPR return) and are read
+//                back with ds_read_b128: is the wall the VGPR return path or the TCP tag / address path?  (round 4)
 //   EXP bit 3 / 4 / 5: left corners of every second query / of every query / three corners of four get an out-of-range
 //                offset (timing only: what register re-use of corners between x-neighbouring queries would save, and
 //                whether an out-of-range lane costs a request at all)
@@ -33,6 +35,7 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile_f32(
   __shared__ uint4 s_tap_o[QB * LP];    // 4 corner byte offsets (kOOB = outside the map / sample not counted)
   __shared__ float4 s_tap_c[QB * LP];   // 4 corner weights
   __shared__ float s_aw[QB * LP];       // attention weights
+  __shared__ dvis_v4u s_dma[(EXP & 64) ? 4 : 1][(EXP & 64) ? 4 * B : 1][64];   // EXP bit 6: one 1 KB landing slot per load
 
   // grid = (M, ceil(Lq/QB), N): x is the fastest dispatch dimension, so linear id % 8 == m % 8 -> head m on XCD m % 8.
   // blockIdx.* are SGPRs: everything derived from them (bases, descriptors) is wave-uniform.
@@ -171,10 +174,23 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile_f32(
           if ((EXP & 8) && (ql & 1)) { o[i].x = kOOB; o[i].z = kOOB; }   // every second query re-uses its left corners
           if (EXP & 16) { o[i].x = kOOB; o[i].z = kOOB; }                // every query does (a long walk along x)
           if (EXP & 32) { o[i].x = kOOB; o[i].z = kOOB; o[i].y = kOOB; }  // one corner of four left
+          if ((EXP & 64) && l == 0) {
+            typedef __attribute__((address_space(3))) void *lds_ptr;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[l], (lds_ptr)&s_dma[wv][4 * i][0], 16, o[i].x + lane_bytes, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[l], (lds_ptr)&s_dma[wv][4 * i + 1][0], 16, o[i].y + lane_bytes, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[l], (lds_ptr)&s_dma[wv][4 * i + 2][0], 16, o[i].z + lane_bytes, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[l], (lds_ptr)&s_dma[wv][4 * i + 3][0], 16, o[i].w + lane_bytes, 0, 0, 0);
+            continue;
+          }
           r[4 * i] = __builtin_amdgcn_raw_buffer_load_b128(rs[l], o[i].x + lane_bytes, 0, 0);
           r[4 * i + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs[l], o[i].y + lane_bytes, 0, 0);
           r[4 * i + 2] = __builtin_amdgcn_raw_buffer_load_b128(rs[l], o[i].z + lane_bytes, 0, 0);
           r[4 * i + 3] = __builtin_amdgcn_raw_buffer_load_b128(rs[l], o[i].w + lane_bytes, 0, 0);
+        }
+        if ((EXP & 64) && l == 0) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA writes are this wave's own: no barrier needed
+#pragma unroll
+          for (int k = 0; k < 4 * B; ++k) r[k] = s_dma[wv][k][lane];
         }
 #pragma unroll
         for (int i = 0; i < B; ++i) {
@@ -216,7 +232,7 @@ extern "C" __attribute__((visibility("default"))) int msda_probe(int exp, const 
   dim3 grid(M, (Lq + QB - 1) / QB, N);
 #define RUN(E) hipLaunchKernelGGL((msda_fwd_tile_f32<32, 3, 4, true, 2, 2, QB, E>), grid, dim3(256), 0, (hipStream_t)stream, value, shapes, ls, off, off_stride, lg, lg_stride, ref, nref, S, M, Lq, out, nullptr, nullptr, 0)
   switch (exp) {
-    case 0: RUN(0); break; case 1: RUN(1); break; case 2: RUN(2); break; case 4: RUN(4); break; case 5: RUN(5); break; case 8: RUN(8); break; case 16: RUN(16); break; case 32: RUN(32); break;
+    case 0: RUN(0); break; case 1: RUN(1); break; case 2: RUN(2); break; case 4: RUN(4); break; case 5: RUN(5); break; case 8: RUN(8); break; case 16: RUN(16); break; case 32: RUN(32); break; case 64: RUN(64); break; case 65: RUN(65); break;
     case 100: hipLaunchKernelGGL((msda_fwd_tile_f32<32, 3, 4, true, 2, 4, QB, 0>), grid, dim3(256), 0, (hipStream_t)stream, value, shapes, ls, off, off_stride, lg, lg_stride, ref, nref, S, M, Lq, out, nullptr, nullptr, 0); break;
     case 101: hipLaunchKernelGGL((msda_fwd_tile_f32<32, 3, 4, true, 2, 1, QB, 0>), grid, dim3(256), 0, (hipStream_t)stream, value, shapes, ls, off, off_stride, lg, lg_stride, ref, nref, S, M, Lq, out, nullptr, nullptr, 0); break;
     default: return 1;

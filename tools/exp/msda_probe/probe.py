@@ -55,11 +55,11 @@ def timeit(exp, iters=20):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-names = {0: "baseline", 1: "gather level 2 only", 2: "no gather (set-up + stores)", 4: "head-major value", 5: "head-major, level 2 only", 8: "left corners of odd queries skipped", 16: "left corners of all queries skipped", 32: "one corner of four", 100: "4 samples (16 loads) in flight per wave", 101: "1 sample (4 loads) in flight per wave"}
+names = {0: "baseline", 64: "coarsest level via TA -> LDS (buffer_load lds) + ds_read_b128", 65: "level 2 only, TA -> LDS (n/a: coarsest skipped)", 1: "gather level 2 only", 2: "no gather (set-up + stores)", 4: "head-major value", 5: "head-major, level 2 only", 8: "left corners of odd queries skipped", 16: "left corners of all queries skipped", 32: "one corner of four", 100: "4 samples (16 loads) in flight per wave", 101: "1 sample (4 loads) in flight per wave"}
 exps = [int(a) for a in sys.argv[1:]] or [0, 4, 1, 5, 2]
 base = None
 for e in exps:
-    if e in (0, 4):
+    if e in (0, 4, 64):
         run(e)
         cur = out.clone()
         if base is None:
