@@ -174,6 +174,7 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile_f32(
           if ((EXP & 8) && (ql & 1)) { o[i].x = kOOB; o[i].z = kOOB; }   // every second query re-uses its left corners
           if (EXP & 16) { o[i].x = kOOB; o[i].z = kOOB; }                // every query does (a long walk along x)
           if (EXP & 32) { o[i].x = kOOB; o[i].z = kOOB; o[i].y = kOOB; }  // one corner of four left
+#if defined(__HIP_DEVICE_COMPILE__)
           if ((EXP & 64) && l == 0) {
             typedef __attribute__((address_space(3))) void *lds_ptr;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[l], (lds_ptr)&s_dma[wv][4 * i][0], 16, o[i].x + lane_bytes, 0, 0, 0);
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile_f32(
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[l], (lds_ptr)&s_dma[wv][4 * i + 3][0], 16, o[i].w + lane_bytes, 0, 0, 0);
             continue;
           }
+#endif
           r[4 * i] = __builtin_amdgcn_raw_buffer_load_b128(rs[l], o[i].x + lane_bytes, 0, 0);
           r[4 * i + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs[l], o[i].y + lane_bytes, 0, 0);
           r[4 * i + 2] = __builtin_amdgcn_raw_buffer_load_b128(rs[l], o[i].z + lane_bytes, 0, 0);

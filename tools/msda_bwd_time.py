@@ -1,5 +1,5 @@
-"""MSDeformAttn backward (dvis_msda_backward), timed at the R50 720p encoder shape and the ViT-L extractor shape, old
-(scalar, DVIS_MSDA_BWD_VEC=0 in a child process) next to the lane-owned 16-byte form.  Algorithmic bytes = the forward's
+"""MSDeformAttn backward (dvis_msda_backward), timed at the R50 720p encoder shape and the ViT-L extractor shape.  (Round 4
+also timed a lane-owned 16-byte form through DVIS_MSDA_BWD_VEC: 4x slower, removed — profiles/r04_msda_bwd_time.txt.)  Algorithmic bytes = the forward's
 (value + loc + w + out read as grad_out) + the three gradient tensors written (SURVEY.md section 8(d) + (f)-1).
     python tools/msda_bwd_time.py"""
 import os
@@ -50,10 +50,8 @@ def case(name, N, shapes, M, D, Lq, P=4):
 
 def main():
     if os.environ.get("DVIS_MSDA_BWD_CHILD") != "1":
-        for vec in ("0", "1"):
-            print(f"--- DVIS_MSDA_BWD_VEC={vec}", flush=True)
-            subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, DVIS_MSDA_BWD_VEC=vec,
-                                                                               DVIS_MSDA_BWD_CHILD="1"), stdin=subprocess.DEVNULL)
+        subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, DVIS_MSDA_BWD_CHILD="1"),
+                       stdin=subprocess.DEVNULL)
         return
     case("R50 720p encoder layer (S = Lq = 19320, M = 8, D = 32, L = 3, P = 4)", 4, [(92, 160), (46, 80), (23, 40)], 8, 32, 19320)
     case("ViT-L extractor (value 46 x 80, M = 16, D = 64, L = 1; Lq = 19320)", 4, [(46, 80)], 16, 64, 19320)
