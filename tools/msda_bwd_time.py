@@ -20,9 +20,20 @@ def case(name, N, shapes, M, D, Lq, P=4):
     ss = torch.tensor(shapes, dtype=torch.int64, device=DEV)
     lsi = torch.cat([ss.new_zeros(1), (ss[:, 0] * ss[:, 1]).cumsum(0)[:-1]])
     value = torch.randn(N, S, M, D, generator=g).to(DEV)
-    # query pixel centres + small offsets (the encoder's geometry), weights a softmax
-    ref = torch.rand(N, Lq, 1, 1, 1, 2, generator=g)
-    loc = (ref + 0.03 * torch.randn(N, Lq, M, L, P, 2, generator=g)).to(DEV).contiguous()
+    # the callers' geometry: queries = the pixels of the (23, 40) / (46, 80) / (92, 160) pyramid in raster order per level, each
+    # looking at its own normalised centre + the init-rule ring (head m along angle 2 pi m / M, point p at p + 1 pixels) + a
+    # learned part of ~0.2 pixel; weights a softmax
+    import math
+    qshapes = [(92, 160), (46, 80), (23, 40)] if Lq == 19320 else shapes
+    ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w_) + 0.5) / w_, indexing="ij"), -1)
+                     .flip(-1).reshape(-1, 2) for h, w_ in qshapes])[:Lq]                       # (Lq, 2) as (x, y)
+    ang = torch.arange(M) * (2 * math.pi / M)
+    d = torch.stack([ang.cos(), ang.sin()], -1)
+    d = d / d.abs().max(-1, keepdim=True)[0]
+    ring = d[:, None, None, :] * torch.arange(1, P + 1)[None, None, :, None]                      # (M, 1, P, 2) pixels
+    off_px = ring.expand(M, L, P, 2)[None, None] + 0.2 * torch.randn(N, Lq, M, L, P, 2, generator=g)
+    wh = torch.tensor([[w_, h] for h, w_ in shapes], dtype=torch.float32)                        # (L, 2) as (W, H)
+    loc = (ref[None, :, None, None, None, :] + off_px / wh[None, None, None, :, None, :]).to(DEV).contiguous()
     w = torch.softmax(torch.randn(N, Lq, M, L * P, generator=g), -1).view(N, Lq, M, L, P).to(DEV).contiguous()
     go = torch.randn(N, Lq, M * D, generator=g).to(DEV)
     run = lambda: Fn.ms_deform_attn_backward(value, ss, lsi, loc, w, go)
