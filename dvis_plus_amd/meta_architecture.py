@@ -339,7 +339,7 @@ class DVIS_Plus_online(_VideoBase):
         cls, _ = PP.mean_logits(track["pred_logits"])
         dec = self.tracker.decoder_norm(track["pred_embds"][0].permute(1, 2, 0))   # (T, Q, C)
         emb = self.tracker.mask_embed(dec)
-        proj = self.tracker.mask_feature_proj(mask_features)
+        proj = self.tracker.project_mask_features(mask_features)
 
         def mask_fn(idx):
             from . import functions as Fn

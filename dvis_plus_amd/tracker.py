@@ -150,6 +150,13 @@ class ReferringTracker_noiser(nn.Module):
         self.last_outputs = None
         self.last_reference = None
 
+    def project_mask_features(self, x):
+        """``mask_feature_proj`` (tracker.py:199: a 1 x 1 convolution, 256 -> 256 at the stride-4 map) on the own fp32-MFMA 1 x 1
+        kernel with the bias in its epilogue where the shape is served (csrc/conv1x1_mfma.hip) — no MIOpen call in the online
+        path either; other shapes / CPU tensors: the library convolution."""
+        c = self.mask_feature_proj
+        return Fn.conv1x1(x, c.weight, c.bias)
+
     def _kv_weights(self):
         return self._kv_cache.get(self.transformer_cross_attention_layers, self.decoder_norm.weight.shape[0])
 
@@ -300,7 +307,7 @@ class ReferringTracker_noiser(nn.Module):
         if need_masks:
             assert B == 1, "tracker masks (online mode) are produced one video at a time"
             b_, t_, cm, h, w = mask_features.shape
-            mf = self.mask_feature_proj(mask_features.flatten(0, 1))           # (t, cm, h, w); online mode, main stream
+            mf = self.project_mask_features(mask_features.flatten(0, 1))       # (t, cm, h, w); online mode, main stream
             emb = self.mask_embed(dec[:, :, 0, :])                             # (t, q, cm)
             out["pred_masks"] = Fn.mask_logits(emb.contiguous(), mf).permute(1, 0, 2, 3).unsqueeze(0)
         if return_indices:

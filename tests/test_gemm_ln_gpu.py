@@ -182,3 +182,58 @@ def test_tracker_fused_chain_vs_layer_by_layer(B, resume):
         assert err <= 2e-4 * max(1.0, ref), f"{k}: {err:.3e} vs scale {ref:.2f}"
     assert float((la - lb).abs().max()) <= 2e-4 * max(1.0, float(lb.abs().max()))
     assert float((ra - rb).abs().max()) <= 2e-4 * max(1.0, float(rb.abs().max()))
+
+
+def test_tracker_chain_is_36_launches_per_frame():
+    """The claim of DESIGN.md section 3.10, counted at the C ABI with the hipGraph off: a resumed clip of T frames issues one
+    K / V GEMM, T x (3 reference-MLP GEMMs + the q projection + the 48-head attention + the batched out-projection + 6 layers x
+    [QKV with the LayerNorm seam in its prologue, self-attention, out-projection, linear1 with its seam, linear2]) = T x 36
+    kernels, and ONE stand-alone LayerNorm (the last frame's output); the layer-by-layer form needs ~65 per frame."""
+    from dvis_plus_amd import native
+    from dvis_plus_amd.tracker import ReferringTracker_noiser
+    torch.manual_seed(0)
+    trk = ReferringTracker_noiser(hidden_channel=512, feedforward_channel=2048, num_head=8, decoder_layer_num=6,
+                                  mask_dim=256, class_num=124).eval().to(DEV)
+    trk.use_graphs = False
+    g = torch.Generator().manual_seed(2)
+    T, Q = 3, 100
+    fe_nn = torch.randn(1, 512, 2 * T, Q, generator=g).to(DEV)
+    fe = torch.nn.functional.layer_norm(fe_nn.permute(0, 2, 3, 1), (512,)).permute(0, 3, 1, 2).contiguous()
+    lib = native.lib()
+    names = ("dvis_gemm_ln", "dvis_gemm_nt", "dvis_gemm_nt_hm", "dvis_gemm_nt_bb", "dvis_attention_forward_k", "dvis_add_layernorm")
+    orig = {n: getattr(lib, n) for n in names}
+    counts = {}
+
+    def counting(n):
+        def call(*a):
+            counts[n] = counts.get(n, 0) + 1
+            return orig[n](*a)
+        return call
+    per_frame = {}
+    try:
+        for fused in (True, False):
+            trk.fused_chain = fused
+            trk(fe[:, :, :T], None, resume=False, frame_embeds_no_norm=fe_nn[:, :, :T], need_masks=False)
+            rec = trk._recurrence
+            inside = {}
+
+            def spied(*a, **k):
+                counts.clear()
+                out = rec(*a, **k)
+                inside.update(counts)
+                return out
+            trk._recurrence = spied
+            for n in names:
+                setattr(lib, n, counting(n))
+            trk(fe[:, :, T:], None, resume=True, frame_embeds_no_norm=fe_nn[:, :, T:], need_masks=False)
+            for n in names:
+                setattr(lib, n, orig[n])
+            trk._recurrence = rec
+            per_frame[fused] = (sum(inside.values()) - 1 - (1 if fused else 0)) / T       # minus the K / V GEMM (and the final LN)
+            if fused:
+                assert inside == {"dvis_gemm_nt_hm": 1 + T, "dvis_gemm_ln": T * (3 + 6 * 4), "dvis_gemm_nt_bb": T,
+                                  "dvis_attention_forward_k": T * 7, "dvis_add_layernorm": 1}, inside
+    finally:
+        for n in names:
+            setattr(lib, n, orig[n])
+    assert per_frame[True] == 36 and per_frame[False] >= 60, per_frame
