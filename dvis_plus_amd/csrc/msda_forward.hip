@@ -49,6 +49,7 @@ template <> struct Chan<float> {
   }
   static __device__ __forceinline__ float load(const float *p) { return *p; }
   static __device__ __forceinline__ float2 load2(const float *p) { return *reinterpret_cast<const float2 *>(p); }
+  static __device__ __forceinline__ float4 load4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 };
 template <> struct Chan<__half> {
   static constexpr int kPerLane = 8;
@@ -80,6 +81,10 @@ template <> struct Chan<__half> {
     const h2 v = *reinterpret_cast<const h2 *>(p);
     return make_float2((float)v[0], (float)v[1]);
   }
+  static __device__ __forceinline__ float4 load4(const __half *p) {    // 8 bytes
+    const float2 a = load2(p), b = load2(p + 2);
+    return make_float4(a.x, a.y, b.x, b.y);
+  }
 };
 template <> struct Chan<__hip_bfloat16> {
   static constexpr int kPerLane = 8;
@@ -110,6 +115,10 @@ template <> struct Chan<__hip_bfloat16> {
   static __device__ __forceinline__ float2 load2(const __hip_bfloat16 *p) {
     const unsigned w = *reinterpret_cast<const unsigned *>(p);
     return make_float2(__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u));
+  }
+  static __device__ __forceinline__ float4 load4(const __hip_bfloat16 *p) {
+    const float2 a = load2(p), b = load2(p + 2);
+    return make_float4(a.x, a.y, b.x, b.y);
   }
 };
 
@@ -155,7 +164,9 @@ bool make_tile_map(const int64_t *shapes_host, int L, int Lq, TileMap *tm) {
 }
 
 // QB queries per workgroup; WPS = register budget in waves/SIMD; B = samples per batch of corner loads.
-// T: storage type of value / locations / weights / output (the FUSED form takes raw fp32 projections: T = float only).
+// T: storage type of value / locations (or raw offsets) / weights (or raw logits) / output; the arithmetic is fp32.  (Round 4: the
+// FUSED form takes half-precision projections too — the reference evaluates under autocast, train_net_video.py:259, where the
+// ViT-Adapter's extractors hand the op fp16 tensors.)
 template <typename T, int D, int L, int P, bool FUSED, int WPS, int B, int QB, bool TILE2D>
 __global__ __launch_bounds__(256, WPS) void msda_fwd_tile(
     const T *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
@@ -169,7 +180,6 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile(
   constexpr int GPW = 64 / G;       // pairs per wave-instruction
   constexpr int ITERS = (QB + 4 * GPW - 1) / (4 * GPW);
   static_assert(LP % 4 == 0 && D % CPL == 0 && 64 % G == 0 && P % B == 0, "tile shape");
-  static_assert(!FUSED || sizeof(T) == 4, "the fused form reads raw fp32 projections");
 
   // Bilinear set-up of every (query, sample) of the block, computed ONCE by one thread.  The D/4 lanes of a pair used
   // to redo the same ~50 VALU instructions per sample each: PMC showed 4.1e8 VALU instructions per 30-frame launch =
@@ -233,17 +243,17 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile(
     float aw[L];
     if constexpr (FUSED) {
       const int off_hs = tm.off_hs ? tm.off_hs : LP * 2, logit_hs = tm.logit_hs ? tm.logit_hs : LP;
-      const float *orow = loc_or_off + ((size_t)n * Lq + qq) * off_stride + (size_t)m * off_hs;
-      const float *lrow = w_or_logit + ((size_t)n * Lq + qq) * logit_stride + (size_t)m * logit_hs;
+      const T *orow = loc_or_off + ((size_t)n * Lq + qq) * off_stride + (size_t)m * off_hs;
+      const T *lrow = w_or_logit + ((size_t)n * Lq + qq) * logit_stride + (size_t)m * logit_hs;
       float2 ro[L], rr[L];
       float4 rl[LP / 4];
 #pragma unroll
       for (int l = 0; l < L; ++l) {
-        ro[l] = *reinterpret_cast<const float2 *>(orow + 2 * (l * P + p));
+        ro[l] = Chan<T>::load2(orow + 2 * (l * P + p));
         rr[l] = *reinterpret_cast<const float2 *>(refp + (((size_t)(nref == 1 ? 0 : n) * Lq + qq) * L + l) * 2);
       }
 #pragma unroll
-      for (int k = 0; k < LP / 4; ++k) rl[k] = *reinterpret_cast<const float4 *>(lrow + 4 * k);
+      for (int k = 0; k < LP / 4; ++k) rl[k] = Chan<T>::load4(lrow + 4 * k);
       if (pos_off != nullptr) {     // + projection of the query's position embedding (same for all n)
         const float *prow = pos_off + qq * pos_stride + (size_t)m * off_hs;
         const float *plrow = pos_logit + qq * pos_stride + (size_t)m * logit_hs;
@@ -573,6 +583,44 @@ DVIS_EXPORT int dvis_msda_fused_forward_slots(const float *value, const int64_t 
   if (handled) return rc;
   dvis_set_error("msda_fused_forward: unsupported (D=%d, L=%d, P=%d); supported D in {32,64}, (L,P) in {(1,4),(3,4),(4,4)}",
                  D, L, P);
+  return DVIS_E_UNSUPPORTED;
+}
+
+// The fused form on fp16 / bf16 storage: value, the raw offset / logit rows and the output in `dtype` (what nn.Linear hands
+// over under autocast), reference points fp32, all arithmetic fp32.  The reference's row layout only (no slots / head-major).
+template <typename T>
+static int fused_half(const void *value, const int64_t *shapes, const int64_t *level_start, const float *ref, int Nref,
+                      const void *offsets, int64_t off_stride, const void *logits, int64_t logit_stride, int N, int S, int M, int D,
+                      int L, int Lq, int P, void *out, const int64_t *shapes_host, hipStream_t st, bool *handled) {
+  TileMap tm{};
+  make_tile_map(shapes_host, L, Lq, &tm);
+  return dispatch_tile<T, true>(D, L, P, (const T *)value, shapes, level_start, (const T *)offsets, off_stride, (const T *)logits,
+                                logit_stride, ref, Nref, N, S, M, Lq, (T *)out, st, handled, nullptr, nullptr, 0, &tm);
+}
+
+DVIS_EXPORT int dvis_msda_fused_forward_h(int dtype, const void *value, const int64_t *shapes, const int64_t *level_start,
+                                          const float *ref, int Nref, const void *offsets, int64_t off_stride,
+                                          const void *logits, int64_t logit_stride, int N, int S, int M, int D, int L, int Lq,
+                                          int P, void *out, const int64_t *shapes_host, void *stream) {
+  DVIS_REQUIRE(dtype == DVIS_F16 || dtype == DVIS_BF16, "msda_fused_forward_h: dtype must be fp16 or bf16 (fp32: dvis_msda_fused_forward)");
+  DVIS_REQUIRE(N >= 0 && S > 0 && M > 0 && D > 0 && L > 0 && Lq >= 0 && P > 0, "msda_fused_forward_h: bad sizes");
+  if (N == 0 || Lq == 0) return DVIS_OK;
+  DVIS_REQUIRE(value && shapes && level_start && ref && offsets && logits && out, "msda_fused_forward_h: null pointer");
+  DVIS_REQUIRE(Nref == 1 || Nref == N, "msda_fused_forward_h: Nref must be 1 or N");
+  DVIS_REQUIRE(off_stride >= (int64_t)M * L * P * 2 && logit_stride >= (int64_t)M * L * P && off_stride % 4 == 0 &&
+                   logit_stride % 4 == 0 && (((uintptr_t)offsets | (uintptr_t)logits) & 7u) == 0 && aligned16(value) &&
+                   aligned16(out) && (M * D) % 8 == 0 && (L * P) % 4 == 0,
+               "msda_fused_forward_h: row strides must cover the rows and be multiples of 4 elements; 8-byte aligned rows, "
+               "16-byte aligned value / out");
+  DVIS_REQUIRE((size_t)S * M * D * 2 < 0x7fffffffu, "msda_fused_forward_h: frame slice >= 2 GiB");
+  bool handled = false;
+  const int rc = dtype == DVIS_F16
+                     ? fused_half<__half>(value, shapes, level_start, ref, Nref, offsets, off_stride, logits, logit_stride, N, S, M,
+                                          D, L, Lq, P, out, shapes_host, (hipStream_t)stream, &handled)
+                     : fused_half<__hip_bfloat16>(value, shapes, level_start, ref, Nref, offsets, off_stride, logits, logit_stride,
+                                                  N, S, M, D, L, Lq, P, out, shapes_host, (hipStream_t)stream, &handled);
+  if (handled) return rc;
+  dvis_set_error("msda_fused_forward_h: unsupported (D=%d, L=%d, P=%d); supported D in {32,64}, (L,P) in {(1,4),(3,4),(4,4)}", D, L, P);
   return DVIS_E_UNSUPPORTED;
 }
 

@@ -114,7 +114,8 @@ class MSDeformAttnFunction(Function):
 def msda_fused_forward(value, spatial_shapes, level_start_index, reference_points, offsets, logits, n_levels,
                        n_points, shapes_host=None, pos_offsets=None, pos_logits=None, head_stride=0,
                        value_head_major=False):
-    """Inference fast path of ``MSDeformAttn.forward`` (ops/modules/ms_deform_attn.py:101-117), fp32.
+    """Inference fast path of ``MSDeformAttn.forward`` (ops/modules/ms_deform_attn.py:101-117): fp32, or fp16 / bf16
+    storage with fp32 arithmetic (value, offsets, logits and the output in ONE dtype — the module under autocast).
 
     value (N,S,M,D); reference_points (1|N, Lq, L, 2); ``offsets`` / ``logits`` are 2-D row views
     (N*Lq, >= M*L*P*2) / (N*Lq, >= M*L*P) of the raw linear outputs (row stride may exceed the width, e.g.
@@ -135,11 +136,30 @@ def msda_fused_forward(value, spatial_shapes, level_start_index, reference_point
     nref, Lq = reference_points.shape[0], reference_points.shape[1]
     for name, t in (("value", value), ("reference_points", reference_points)):
         native.dev_ptr(t, name)
+    half = value.dtype in (torch.float16, torch.bfloat16)
     for name, t in (("offsets", offsets), ("logits", logits)):
-        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or t.shape[0] != N * Lq:
-            raise RuntimeError(f"{name} must be a float32 GPU (N*Lq, width) row view with unit inner stride")
-    if value.dtype != torch.float32 or reference_points.dtype != torch.float32:
-        raise RuntimeError("msda_fused_forward is fp32 only")
+        if not t.is_cuda or t.dtype != value.dtype or t.dim() != 2 or t.stride(1) != 1 or t.shape[0] != N * Lq:
+            raise RuntimeError(f"{name} must be a GPU (N*Lq, width) row view of value's dtype with unit inner stride")
+    if value.dtype not in (torch.float32, torch.float16, torch.bfloat16) or reference_points.dtype != torch.float32:
+        raise RuntimeError("msda_fused_forward: value / offsets / logits fp32, fp16 or bf16 (one dtype); reference points fp32")
+    if half:
+        # fp16 / bf16 storage (what the projections produce under autocast), fp32 arithmetic: dvis_msda_fused_forward_h
+        if head_stride or value_head_major or pos_offsets is not None or pos_logits is not None:
+            raise RuntimeError("msda_fused_forward: slots / head-major value / position rows are fp32-only layouts")
+        if offsets.shape[1] < M * L * P * 2 or logits.shape[1] < M * L * P or reference_points.shape[2:] != (L, 2):
+            raise RuntimeError("msda_fused_forward: inconsistent shapes")
+        out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+        hs = None
+        if shapes_host is not None:
+            hs = (ctypes.c_int64 * (2 * L))(*[int(v) for hw in shapes_host for v in hw])
+        with torch.cuda.device(value.device):
+            rc = native.lib().dvis_msda_fused_forward_h(
+                native.dtype_code(value), native.dev_ptr(value, "value"), native.dev_ptr(spatial_shapes, "spatial_shapes"),
+                native.dev_ptr(level_start_index, "level_start_index"), native.dev_ptr(reference_points, "ref"), nref,
+                ctypes.c_void_p(offsets.data_ptr()), offsets.stride(0), ctypes.c_void_p(logits.data_ptr()), logits.stride(0),
+                N, S, M, D, L, Lq, P, native.dev_ptr(out, "out"), hs, native.stream_ptr(value.device))
+        native.check(rc, "dvis_msda_fused_forward_h")
+        return out
     if head_stride:
         if offsets.shape[1] < (M - 1) * head_stride + L * P * 2 or logits.shape[1] < (M - 1) * head_stride + L * P:
             raise RuntimeError("msda_fused_forward: rows shorter than M slots")

@@ -27,6 +27,7 @@ SIGNATURES = {
     "dvis_msda_fused_forward": (_i, [_p, _p, _p, _p, _i, _p, _i64, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "dvis_msda_fused_forward_pos": (_i, [_p, _p, _p, _p, _i, _p, _i64, _p, _i64, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _i,
                                          _p, _p, _p]),
+    "dvis_msda_fused_forward_h": (_i, [_i, _p, _p, _p, _p, _i, _p, _i64, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "dvis_msda_fused_forward_slots": (_i, [_p, _p, _p, _p, _i, _p, _i64, _p, _i64, _i, _i, _i, _p, _p, _i64, _i, _i, _i, _i,
                                            _i, _i, _i, _p, _p, _p]),
     "dvis_nchw_to_tokens": (_i, [_p, _p, _i64, _i, _i64, _i64, _i64, _p]),

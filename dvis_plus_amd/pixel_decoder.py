@@ -156,7 +156,7 @@ class MSDeformAttn(nn.Module):
 
     def _fast_path_ok(self, query, reference_points, input_padding_mask):
         d = self.d_model // self.n_heads
-        return (not torch.is_grad_enabled() and query.is_cuda and query.dtype == torch.float32
+        return (not torch.is_grad_enabled() and query.is_cuda and query.dtype in (torch.float32, torch.float16, torch.bfloat16)
                 and input_padding_mask is None and reference_points.shape[-1] == 2 and d in (32, 64)
                 and (self.n_levels, self.n_points) in ((1, 4), (3, 4), (4, 4)))
 
@@ -172,7 +172,11 @@ class MSDeformAttn(nn.Module):
         N, Len_in, _ = input_flatten.shape
         M, L, P = self.n_heads, self.n_levels, self.n_points
         fast = self._fast_path_ok(query, reference_points, input_padding_mask)
-        hm = fast and _MSDA_HM and input_flatten.is_contiguous()
+        # half-precision storage (a .half() / .bfloat16() module, or fp32 parameters under torch.autocast — how the reference
+        # evaluates, train_net_video.py:259): the projections come out in fp16 / bf16 and the fused kernel takes them as they
+        # are (dvis_msda_fused_forward_h); the layout experiments below are fp32-only
+        lowp = query.dtype != torch.float32 or torch.is_autocast_enabled()
+        hm = fast and _MSDA_HM and input_flatten.is_contiguous() and not lowp
         if hm:
             # own GEMM with a head-major epilogue: value[m, n, s, :] — neighbouring pixels of a head are adjacent lines
             value = Fn.gemm_nt(input_flatten.view(N * Len_in, self.d_model), self.value_proj.weight.detach(),
@@ -187,7 +191,9 @@ class MSDeformAttn(nn.Module):
             # where a row's offsets / logits start (slots: inside the head's slot)
             o_off, l_off = ((L * P, 0) if _MSDA_SLOTS == 2 else (0, 2 * L * P)) if slot else (0, M * L * P * 2)
             po = pl = None
-            if query_pos is not None and query_pos.shape[0] == 1 and _POS_IN_KERNEL:
+            if lowp and slot:
+                raise RuntimeError("DVIS_MSDA_SLOTS is an fp32-only layout experiment")
+            if query_pos is not None and query_pos.shape[0] == 1 and _POS_IN_KERNEL and not lowp:
                 pp = Fn.linear(query_pos[0], w)                                    # (Lq, 3*M*L*P): tiny, once per call
                 po, pl = pp[:, o_off:], pp[:, l_off:]
             elif query_pos is not None:

@@ -127,6 +127,18 @@ int dvis_msda_fused_forward_pos(const float *value, const int64_t *shapes, const
                                 int P, float *out, const int64_t *shapes_host, void *stream);
 
 /*
+ * dvis_msda_fused_forward on HALF-PRECISION storage: `value`, the raw offset / logit rows and `out` in `dtype` (DVIS_F16 /
+ * DVIS_BF16 — what the projections of MSDeformAttn.forward, ops/modules/ms_deform_attn.py:97-105, produce under
+ * torch.autocast, how the reference evaluates: train_net_video.py:259), reference points fp32, arithmetic fp32, 8 channels
+ * per lane.  The reference's own op dispatches float / double only (ms_deform_attn_cuda.cu:69) and its module falls into the
+ * grid_sample path there.  Row strides in ELEMENTS; the reference's row layout (all heads' offsets, then all heads' logits).
+ */
+int dvis_msda_fused_forward_h(int dtype, const void *value, const int64_t *shapes, const int64_t *level_start,
+                              const float *ref, int Nref, const void *offsets, int64_t off_stride, const void *logits,
+                              int64_t logit_stride, int N, int S, int M, int D, int L, int Lq, int P, void *out,
+                              const int64_t *shapes_host, void *stream);
+
+/*
  * Same, with the per-head layout of a projection row made explicit: head m's 2*L*P offsets start `off_head_stride` floats
  * after head m-1's, its L*P logits `logit_head_stride` floats after head m-1's (0 = the reference's layout: L*P*2 and
  * L*P, i.e. all heads' offsets, then all heads' logits).  With the rows of the fused projection permuted into per-head

@@ -205,6 +205,64 @@ def test_half_precision_tiled_kernel(dt, rel, M, D, shapes):
 
 
 @pytest.mark.parametrize("dt,rel", [(torch.float16, 2.0 ** -10), (torch.bfloat16, 2.0 ** -7)])
+@pytest.mark.parametrize("M,D,shapes,Lq", [(8, 32, [(6, 10), (12, 20), (24, 40)], None),     # encoder self-attention (8 x 8 tiles)
+                                           (16, 64, [(23, 40)], 777)])                         # ViT-Adapter extractor layout
+def test_fused_forward_half_precision_storage(dt, rel, M, D, shapes, Lq):
+    """The fused form (softmax + location arithmetic in the kernel) on fp16 / bf16 value / offsets / logits / output — what the
+    module's projections produce under autocast — against the fp32 fused kernel run on the SAME rounded inputs: equal up to
+    the rounding of the output (arithmetic is fp32 in both)."""
+    from dvis_plus_amd.functions import msda_fused_forward
+    N, L, P = 2, len(shapes), 4
+    s, lsi = level_tensors(shapes)
+    S = int(s.prod(1).sum())
+    Lq = Lq or S
+    g = torch.Generator().manual_seed(23)
+    value = torch.randn(N, S, M, D, generator=g).to(dt)
+    proj = (torch.randn(N * Lq, M * L * P * 3 + 8, generator=g) * 1.5).to(dt)          # row stride != width
+    ref_pts = torch.rand(1, Lq, L, 2, generator=g)
+    n_off = M * L * P * 2
+    sh = [tuple(int(v) for v in hw) for hw in shapes] if Lq == S else None
+    vd, pd_, rd = value.to(DEV), proj.to(DEV), ref_pts.to(DEV)
+    got = msda_fused_forward(vd, s.to(DEV), lsi.to(DEV), rd, pd_[:, :n_off], pd_[:, n_off:n_off + M * L * P], L, P, shapes_host=sh)
+    assert got.dtype == dt and got.shape == (N, Lq, M * D)
+    pf = pd_.float()
+    want = msda_fused_forward(vd.float(), s.to(DEV), lsi.to(DEV), rd, pf[:, :n_off], pf[:, n_off:n_off + M * L * P], L, P,
+                              shapes_host=sh)
+    torch.testing.assert_close(got.float(), want, rtol=rel, atol=rel * float(want.abs().max()) * 0.25)
+    with pytest.raises(RuntimeError, match="dtype"):
+        msda_fused_forward(vd, s.to(DEV), lsi.to(DEV), rd, pf[:, :n_off], pf[:, n_off:n_off + M * L * P], L, P)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_msdeformattn_module_under_autocast_takes_the_fused_half_kernel(dt):
+    """How the reference evaluates (train_net_video.py:259: torch.autocast): fp32 parameters, projections in half precision.
+    The module must take the fused kernel (spy on the C ABI), not a torch formulation, and agree with its fp32 result to
+    half-precision accuracy."""
+    from dvis_plus_amd import native
+    from dvis_plus_amd.pixel_decoder import MSDeformAttn
+    torch.manual_seed(5)
+    shapes = [(6, 10), (12, 20), (24, 40)]
+    s, lsi = level_tensors(shapes)
+    S = int(s.prod(1).sum())
+    attn = MSDeformAttn(d_model=256, n_levels=3, n_heads=8, n_points=4).to(DEV).eval()
+    src = torch.randn(2, S, 256, device=DEV)
+    ref = torch.rand(1, S, 3, 2, device=DEV)
+    lib = native.lib()
+    orig, calls = lib.dvis_msda_fused_forward_h, []
+    try:
+        lib.dvis_msda_fused_forward_h = lambda *a: (calls.append(a[0]), orig(*a))[1]
+        with torch.no_grad():
+            want = attn(src, ref, src, s.to(DEV), lsi.to(DEV), None, spatial_shapes_py=shapes)
+            with torch.autocast("cuda", dtype=dt):
+                got = attn(src, ref, src, s.to(DEV), lsi.to(DEV), None, spatial_shapes_py=shapes)
+    finally:
+        lib.dvis_msda_fused_forward_h = orig
+    assert calls == [native.F16 if dt == torch.float16 else native.BF16] and got.dtype == dt
+    tol = 2.0 ** (-7 if dt == torch.float16 else -4) * float(want.abs().max())
+    assert float((got.float() - want).abs().max()) <= tol
+
+
+@pytest.mark.parametrize("dt,rel", [(torch.float16, 2.0 ** -10), (torch.bfloat16, 2.0 ** -7)])
 def test_half_precision_vs_reference_golden_vitl(dt, rel):
     """The reference's own outputs on the ViT-Adapter extractor layout (g1_msda_vitl: D = 64, L = 1, P = 4), inputs rounded
     to half precision: within the storage type's precision of the fp32 reference output."""
