@@ -44,6 +44,7 @@ sys.path.insert(0, ROOT)
 MSDA_BYTES_PER_FRAME_LAYER = 4 * (19320 * 8 * 32 + 19320 * 8 * 3 * 4 * 2 + 19320 * 8 * 3 * 4 + 19320 * 8 * 32)  # 61 824 000
 HBM_PEAK_GBS = 8000.0
 MFMA_F32_PEAK_TF = 157.3      # dense fp32 matrix peak (MI355X_MICROARCH.md)
+MFMA_F16_PEAK_TF = 2500.0     # dense f16 / bf16 matrix peak (MI355X_MICROARCH.md)
 
 
 def synthetic_clip(T, device, seed=1234):
@@ -146,6 +147,43 @@ class ConvTimer:
 
     def __exit__(self, *exc):
         self.lib.dvis_conv3x3_winograd = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        secs = sum(e0.elapsed_time(e1) / 1e3 for e0, e1, _ in self.events)
+        return secs, sum(f for _, _, f in self.events), len(self.events)
+
+
+DTYPE_NOTE = ("f32 (storage, accumulation, results; the deformable encoder's dense layers multiply each fp32 operand as two f16 "
+              "terms on the f16 matrix cores, 3 products per pair: error vs fp64 <= the fp32 GEMM's, tests/test_gemm_x3_gpu.py; "
+              "exact_f32 = the same run with DVIS_X3=0)")
+
+
+class FfnTimer:
+    """Times every launch of the encoder's fused FFN kernel (csrc/gemm_x3.hip, dvis_x3_ffn_ln) in the timed region the same
+    way: the largest kernel of a clip by arithmetic (2 x 579 600 x 256 x 1024 x 2 flops per layer at T = 30)."""
+
+    def __init__(self):
+        from dvis_plus_amd import native
+        self.native, self.events = native, []
+
+    def __enter__(self):
+        lib = self.native.lib()
+        self.lib, self.orig = lib, lib.dvis_x3_ffn_ln
+
+        def timed(x, ldx, M, K, H, N, *rest):
+            st = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            rc = self.orig(x, ldx, M, K, H, N, *rest)
+            e1.record(st)
+            self.events.append((e0, e1, 2.0 * M * H * (K + N)))
+            return rc
+        lib.dvis_x3_ffn_ln = timed
+        return self
+
+    def __exit__(self, *exc):
+        self.lib.dvis_x3_ffn_ln = self.orig
 
     def summary(self):
         torch.cuda.synchronize()
@@ -434,9 +472,9 @@ def main():
             torch.distributed.barrier()
         model.stream_timing = True
         tm, lt = MsdaTimer(), []
-        tm.conv = ConvTimer()
+        tm.conv, tm.ffn = ConvTimer(), FfnTimer()
         t0 = time.perf_counter()
-        with tm, tm.conv:
+        with tm, tm.conv, tm.ffn:
             res_ = run_pass(videos[:args.steps], lt)
         torch.cuda.synchronize()
         if dist_on:
@@ -508,6 +546,25 @@ def main():
         cand100 = {"value": round(T * n2 / dt2, 3), "unit": "frames/s", "steps": n2,
                    "panoptic_candidates": [int(o.get("num_candidates") or 0) for o in o2]}
 
+    # third, short timed pass: the encoder's GEMMs on the exact-fp32 matrix instructions / library GEMMs (DVIS_X3=0) instead of
+    # the split-f16 kernels of csrc/gemm_x3.hip — the same protocol on up to 6 clips
+    exact = None
+    from dvis_plus_amd import functions as _Fn
+    if world == 1 and not dist_on and not args.no_extra and _Fn.X3:
+        n3 = min(6, args.steps)
+        _Fn.X3 = False
+        try:
+            run_pass(videos[:2])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_pass(videos[:n3])
+            torch.cuda.synchronize()
+            dt3 = time.perf_counter() - t1
+        finally:
+            _Fn.X3 = True
+        exact = {"value": round(T * n3 / dt3, 3), "unit": "frames/s", "steps": n3, "ms_per_step": round(dt3 / n3 * 1e3, 2),
+                 "note": "DVIS_X3=0: every GEMM / convolution on v_mfma_f32_*_f32 or the fp32 library GEMM"}
+
     if rank == 0:
         fps = T * args.steps / dt
         sec, nfr, nlaunch = timer.summary()
@@ -531,12 +588,24 @@ def main():
                          "ms_per_clip": round(csec / args.steps * 1e3, 2), "traffic": None,
                          "note": "flops = 2 * 4 * N*C*K*H*W per launch (Winograd multiplies), summed over the timed launches / "
                                  "their summed HIP-event durations"}
+        fsec, fflops, flaunch = timer.ffn.summary()
+        ffn_roof = None
+        if flaunch:
+            # the kernel issues 3 f16 matrix-core products per fp32 product (a_lo w_hi + a_hi w_lo + a_hi w_hi)
+            tf16 = 3.0 * fflops / fsec / 1e12
+            ffn_roof = {"bound": "mfma", "kernel": "x3_ffn (encoder FFN: linear1 + ReLU + linear2 + residual + LayerNorm, one kernel)",
+                        "achieved": round(tf16, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf16 / MFMA_F16_PEAK_TF, 4),
+                        "fp32_equivalent_tflops": round(fflops / fsec / 1e12, 1), "launches_timed": flaunch,
+                        "ms_per_clip": round(fsec / args.steps * 1e3, 2), "traffic": None,
+                        "note": "f16 matrix-core flops issued = 3 x the fp32 GEMM flops 2*M*H*(K+N) per launch, summed over the "
+                                "timed launches / their summed HIP-event durations; fp32_equivalent = the fp32 GEMM flops / time "
+                                "(the fp32 matrix peak is 157.3)"}
         ms = sorted(e0.elapsed_time(e1) for e0, e1 in lat)
         pct = lambda q: round(ms[min(len(ms) - 1, int(q * len(ms)))], 2) if ms else None
         res = {
             "metric": f"frames/sec DVIS++ {BB_NAME[args.backbone]} {args.mode}, 720p T={T} synthetic", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPE_NOTE if _Fn.X3 else "f32", "data": "synthetic",
             "config": {"workload": f"DVIS++ {args.mode} {BB_NAME[args.backbone]}, T={T} 720p synthetic clip (padded 736x1280), "
                                    f"{args.queries} queries, "
                                    f"temporal refiner {'on' if args.mode == 'offline' else 'off'}, task={args.task}, "
@@ -563,6 +632,10 @@ def main():
             res["dist"] = dist_info
         if conv_roof is not None:
             res["roofline_conv3x3"] = conv_roof
+        if ffn_roof is not None:
+            res["roofline_ffn"] = ffn_roof
+        if exact is not None:
+            res["exact_f32"] = exact
         if owner_line is not None:
             res["owner_rounds"] = owner_line
         if cand100 is not None:

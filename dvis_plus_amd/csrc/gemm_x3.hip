@@ -1,0 +1,533 @@
+// gemm_x3.hip — the tall fp32 GEMMs of the deformable encoder (579 600 tokens x 256 per 30-frame clip and layer:
+// value / offset / weight / output projections and the FFN pair, mask2former/modeling/pixel_decoder/msdeformattn.py:103-131,
+// ops/modules/ms_deform_attn.py:96-117) on the F16 matrix cores with fp32-grade results.
+//
+// Arithmetic.  gfx950 multiplies fp32 operands on the matrix cores at the VECTOR rate (157 TF, v_mfma_f32_32x32x2_f32) and
+// f16 operands 16 x faster (v_mfma_f32_32x32x16_f16, fp32 accumulate).  Every fp32 operand v is carried as TWO f16 terms
+//     hi = rn16(v * 2^e),  lo = rn16(v * 2^e - hi)          (22 significand bits; e: a per-operand power of two)
+// and a product a*w as THREE matrix-core products  a_lo*w_hi + a_hi*w_lo + a_hi*w_hi  accumulated in fp32 (the dropped
+// a_lo*w_lo term is 2^-22 of the product).  Per-term error 2^-22 (2.4e-7) with random sign: a K-term dot product is off by
+// 2.4e-7 / sqrt(K) of sum|a||w| — below the 1e-7 * sum|a||w| rounding of the fp32 accumulation chain itself
+// (tests/test_gemm_x3_gpu.py measures both against fp64).  3 f16 products = 3/16 of the fp32 MFMA time.
+//
+// Decomposition (not the reference's, which calls cuBLAS through nn.Linear): everything is computed TRANSPOSED,
+//     out^T (n, token) = W (n, k) x^T (k, token):   MFMA "A" operand = weight fragment, "B" operand = activations.
+// A wave owns 32 tokens (the MFMA columns, lane & 31 = token) and ALL output features of them, so
+//   * a token's features are the 16 accumulator registers x NB blocks of ONE lane pair (l, l ^ 32): LayerNorm statistics are
+//     an in-lane sum + one exchange — no cross-wave reduction, no LDS;
+//   * the activations are read ONCE per tile, straight from memory in fragment shape (32 B per lane and k-step), split in
+//     registers and kept there for the whole K (K = 256: 128 registers per lane): no activation staging, no redundant split;
+//   * the FFN's hidden block comes out of phase 1 already in the layout phase 2 wants as its "B" operand — the k-order of an
+//     MFMA is free as long as both operands agree, and the packed W2 fragments are stored in ACCUMULATOR order — so
+//     linear1 -> ReLU -> linear2 -> + residual -> LayerNorm is one kernel and the 2.4 GB hidden tensor never exists.
+// Weights are split and packed once (dvis_x3_pack*) into the exact LDS image: fragments of 1 KB (64 lanes x 16 B), streamed
+// with global_load_lds_dwordx4 (no VGPR round trip) through a 3-stage ring of 32 - 36 KB items shared by the 4 waves of a
+// workgroup; one raw s_barrier per item, counted vmcnt so that the next item stays in flight across it.
+// 256 threads, one workgroup per CU (up to 512 VGPR + AGPR per lane: accumulators 128 - 192, activation fragments 128).
+#include "dvis_common.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+#define DVIS_LDS __attribute__((address_space(3)))
+#define DVIS_GLB __attribute__((address_space(1)))
+
+constexpr int kWaves = 4;
+constexpr int kThreads = kWaves * 64;
+constexpr int kTileTok = kWaves * 32;
+constexpr int kStages = 3;
+constexpr int kPiece = 1024;          // one operand fragment of a 32-row block: 64 lanes x 8 halves
+constexpr int kScratch = 4096;        // per wave: 32 tokens x 32 floats, the epilogue's transposition buffer
+
+__device__ __forceinline__ void glds16(const void *g, void *l) {
+  __builtin_amdgcn_global_load_lds((const DVIS_GLB void *)g, (DVIS_LDS void *)l, 16, 0, 0);
+}
+
+// v * s -> (hi, lo) for 8 values (round to nearest twice; s is a power of two, so v * s and the residual are exact)
+__device__ __forceinline__ void split8(f4 a, f4 b, float s, h8 &hi, h8 &lo) {
+  const float v[8] = {a.x * s, a.y * s, a.z * s, a.w * s, b.x * s, b.y * s, b.z * s, b.w * s};
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const f2 x = {v[2 * p], v[2 * p + 1]};
+    const h2 h = __builtin_convertvector(x, h2);
+    const f2 r = x - __builtin_convertvector(h, f2);
+    const h2 l = __builtin_convertvector(r, h2);
+    hi[2 * p] = h.x, hi[2 * p + 1] = h.y, lo[2 * p] = l.x, lo[2 * p + 1] = l.y;
+  }
+}
+
+// One item of the weight stream: STEPS k-steps x NBL blocks of 32 output features, image [s][nb][hi, lo][lane][8 halves].
+template <int STEPS, int NBL>
+__device__ __forceinline__ void mma_item(const char *stage, int lane, f16v *acc, const h8 *xh, const h8 *xl) {
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+#pragma unroll
+    for (int nb = 0; nb < NBL; ++nb) {
+      const char *p = stage + ((s * NBL + nb) * 2) * kPiece + lane * 16;
+      const h8 wh = *(const h8 *)p;
+      const h8 wl = *(const h8 *)(p + kPiece);
+      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[s], acc[nb], 0, 0, 0);
+      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[s], acc[nb], 0, 0, 0);
+      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[s], acc[nb], 0, 0, 0);
+    }
+  }
+}
+
+// The weight ring.  Item i of this workgroup's sequence = item (i mod period) of the packed stream.
+template <int PW>      // 1 KB pieces per wave and item (item bytes = 4 * PW * 1024)
+struct Ring {
+  const char *src;
+  char *lds;
+  int period, total, it, st_cmp, st_iss, wave, lane;
+  static constexpr int kItemBytes = kWaves * PW * kPiece;
+
+  __device__ __forceinline__ void issue(int item) {
+    const char *g = src + (size_t)(item % period) * kItemBytes + lane * 16;
+    char *l = lds + st_iss * kItemBytes;
+#pragma unroll
+    for (int p = 0; p < PW; ++p) glds16(g + (wave + kWaves * p) * kPiece, l + (wave + kWaves * p) * kPiece);
+    st_iss = st_iss + 1 == kStages ? 0 : st_iss + 1;
+  }
+  __device__ __forceinline__ void start(const void *stream, char *ring, int period_, int total_, int wave_, int lane_) {
+    src = (const char *)stream, lds = ring, period = period_, total = total_, it = 0, st_cmp = 0, st_iss = 0;
+    wave = wave_, lane = lane_;
+    if (total > 0) issue(0);
+    if (total > 1) issue(1);
+  }
+  // Make item `it` readable by every wave and put item it + 2 in flight.  drain: other vector-memory work (activation
+  // loads, the previous tile's stores) may be outstanding — wait for everything.
+  __device__ __forceinline__ const char *acquire(bool drain) {
+    if (drain || it + 1 >= total)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    if (it + 2 < total) issue(it + 2);
+    const char *stage = lds + st_cmp * kItemBytes;
+    st_cmp = st_cmp + 1 == kStages ? 0 : st_cmp + 1;
+    ++it;
+    return stage;
+  }
+};
+
+// Activation fragments of a wave's 32 tokens for K = 16 * KS, natural k order: lane (token j, half g) holds
+// x[token][16 S + 8 g + 0..7] for k-step S.
+template <int KS>
+__device__ __forceinline__ void load_x(const float *x, int64_t ldx, int64_t row, int g, float s, h8 *xh, h8 *xl) {
+  const float *p = x + row * ldx + 8 * g;
+  f4 raw[2 * KS];
+#pragma unroll
+  for (int S = 0; S < KS; ++S) raw[2 * S] = *(const f4 *)(p + 16 * S), raw[2 * S + 1] = *(const f4 *)(p + 16 * S + 4);
+#pragma unroll
+  for (int S = 0; S < KS; ++S) split8(raw[2 * S], raw[2 * S + 1], s, xh[S], xl[S]);
+}
+
+// Row-contiguous stores of one 32-feature block: the lane-per-token accumulator quads go through the wave's 4 KB of LDS
+// (rows of 128 B, 16-byte slots XOR-swizzled with (row >> 1) & 7: conflict-free both ways) and leave as 8 lanes x 16 B per
+// token row — 8 lines per store instruction instead of 32.
+__device__ __forceinline__ void store_block(char *scr, int lane, const f4 *v, float *dst, int64_t ld, int rows_valid) {
+  const int j = lane & 31, g = lane >> 5, sw = (j >> 1) & 7;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) *(f4 *)(scr + j * 128 + (((2 * q + g) ^ sw) << 4)) = v[q];
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int jr = 8 * t + (lane >> 3), pp = lane & 7;
+    const f4 o = *(const f4 *)(scr + jr * 128 + ((pp ^ ((jr >> 1) & 7)) << 4));
+    if (jr < rows_valid) *(f4 *)(dst + jr * ld + 4 * pp) = o;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+struct EpiArgs {
+  const float *bias;                 // N
+  const float *res;                  // M x N (LayerNorm forms), row stride ldres
+  int64_t ldres;
+  const float *gamma, *beta;         // N
+  float eps;
+  const float *pos;                  // pos_rows x N or NULL: second output out2[t] = out[t] + pos[t mod pos_rows]
+  int64_t pos_rows;
+  float *out, *out2;
+  int64_t ldo;
+  float inv;                         // 2^-(xexp + wexp)
+  int relu;
+};
+
+// acc (NB blocks x 16) -> out.  LN = false: act(acc * inv + bias).  LN = true: LayerNorm(acc * inv + bias + res) over the
+// 32 * NB features (two-pass mean / centred variance as torch), optional out2 = out + pos.
+template <int NB, bool LN>
+__device__ __forceinline__ void epilogue(f16v *acc, const EpiArgs &e, char *scr, int lane, int64_t tok0, int64_t M, int col0 = 0) {
+  const int j = lane & 31, g = lane >> 5;
+  const int64_t tok = tok0 + j < M ? tok0 + j : M - 1;
+  const int rows_valid = M - tok0 < 32 ? (int)(M - tok0) : 32;
+  constexpr int N = 32 * NB;
+  float mean = 0.f, rstd = 1.f;
+  if constexpr (LN) {
+    float sum = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = 32 * nb + 8 * q + 4 * g;
+        const f4 b = *(const f4 *)(e.bias + n);
+        const f4 r = *(const f4 *)(e.res + tok * e.ldres + n);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = acc[nb][4 * q + i] * e.inv + b[i] + r[i];
+          acc[nb][4 * q + i] = v;
+          sum += v;
+        }
+      }
+    sum += __shfl_xor(sum, 32);
+    mean = sum * (1.f / N);
+    float sq = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float d = acc[nb][i] - mean;
+        sq += d * d;
+      }
+    sq += __shfl_xor(sq, 32);
+    rstd = rsqrtf(sq * (1.f / N) + e.eps);
+  }
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    f4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = 32 * nb + 8 * q + 4 * g;
+      if constexpr (LN) {
+        const f4 ga = *(const f4 *)(e.gamma + n), be = *(const f4 *)(e.beta + n);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[q][i] = (acc[nb][4 * q + i] - mean) * rstd * ga[i] + be[i];
+      } else {
+        const f4 b = *(const f4 *)(e.bias + col0 + n);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float t = acc[nb][4 * q + i] * e.inv + b[i];
+          v[q][i] = e.relu ? fmaxf(t, 0.f) : t;
+        }
+      }
+    }
+    store_block(scr, lane, v, e.out + tok0 * e.ldo + col0 + 32 * nb, e.ldo, rows_valid);
+    if constexpr (LN) {
+      if (e.pos != nullptr) {
+        const float *pr = e.pos + (tok % e.pos_rows) * N;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += *(const f4 *)(pr + 32 * nb + 8 * q + 4 * g);
+        store_block(scr, lane, v, e.out2 + tok0 * e.ldo + 32 * nb, e.ldo, rows_valid);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// out (M x 32 NB npass) = epilogue( x (M x K) W^T ): one projection, its output features in `npass` passes of 32 NB over the
+// same activation fragments.  Weight stream: [pass][K / 32 items of 2 k-steps x NB blocks].
+template <int K, int NB, bool LN>
+__global__ __launch_bounds__(kThreads) void x3_linear_kernel(const float *__restrict__ x, int64_t ldx, int64_t M,
+                                                             const void *__restrict__ wp, float xscale, int npass, EpiArgs e) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  constexpr int KS = K / 16, NI = K / 32;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
+  const int64_t ntiles = (M + kTileTok - 1) / kTileTok;
+  const int64_t my = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  Ring<NB> ring;
+  ring.start(wp, lds, NI * npass, (int)(my * NI * npass), wave, lane);
+  char *scr = lds + kStages * Ring<NB>::kItemBytes + wave * kScratch;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t tok0 = tile * kTileTok + wave * 32;
+    const int64_t row = tok0 + j < M ? tok0 + j : M - 1;
+    h8 xh[KS], xl[KS];
+    load_x<KS>(x, ldx, row, g, xscale, xh, xl);
+    for (int pass = 0; pass < npass; ++pass) {
+      f16v acc[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+#pragma unroll
+      for (int c = 0; c < NI; ++c) {
+        const char *stage = ring.acquire(c == 0);
+        mma_item<2, NB>(stage, lane, acc, xh + 2 * c, xl + 2 * c);
+      }
+      if (tok0 < M) epilogue<NB, LN>(acc, e, scr, lane, tok0, M, pass * 32 * NB);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// out = LayerNorm( x + linear2( relu( linear1(x) ) ) ) for K = N = 256 model features and H = 128 HB hidden units.
+// Weight stream per tile: HB hidden blocks x [4 items of linear1 (4 k-steps x 4 blocks of 32 hidden units), 4 items of
+// linear2 (2 hidden k-steps x 8 blocks of 32 outputs, k in accumulator order)], every item 32 KB.
+struct FfnArgs {
+  const float *b1;                   // H
+  float inv1, hscale;                // 2^-(xexp + w1exp); 2^hexp (the hidden activations' split exponent)
+  int HB;
+};
+
+__global__ __launch_bounds__(kThreads) void x3_ffn_kernel(const float *__restrict__ x, int64_t ldx, int64_t M,
+                                                          const void *__restrict__ wp, float xscale, FfnArgs f, EpiArgs e) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  constexpr int KS = 16;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
+  const int64_t ntiles = (M + kTileTok - 1) / kTileTok;
+  const int64_t my = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  const int per_tile = 8 * f.HB;
+  Ring<8> ring;
+  ring.start(wp, lds, per_tile, (int)(my * per_tile), wave, lane);
+  char *scr = lds + kStages * Ring<8>::kItemBytes + wave * kScratch;
+  // linear1's bias lives in LDS: a global load between two items would make the compiler drain the ring behind it
+  float *b1s = (float *)(lds + kStages * Ring<8>::kItemBytes + kWaves * kScratch);
+  for (int i = threadIdx.x; i < 128 * f.HB; i += kThreads) b1s[i] = f.b1[i];
+  __syncthreads();
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t tok0 = tile * kTileTok + wave * 32;
+    const int64_t row = tok0 + j < M ? tok0 + j : M - 1;
+    h8 xh[KS], xl[KS];
+    load_x<KS>(x, ldx, row, g, xscale, xh, xl);
+    f16v acc2[8];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc2[nb][i] = 0.f;
+    for (int hb = 0; hb < f.HB; ++hb) {
+      f16v acc1[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc1[t][i] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const char *stage = ring.acquire(hb == 0 && c == 0);
+        mma_item<4, 4>(stage, lane, acc1, xh + 4 * c, xl + 4 * c);
+      }
+      // hidden block -> phase-2 "B" fragments, in place: k-step 2 t + u of the block takes registers 8 u .. 8 u + 7 of tile t
+      h8 hh[8], hl[8];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          f4 a, b;
+          const float *bp = b1s + 128 * hb + 32 * t + 16 * u + 4 * g;
+          const f4 ba = *(const f4 *)bp, bb = *(const f4 *)(bp + 8);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            a[i] = fmaxf(acc1[t][8 * u + i] * f.inv1 + ba[i], 0.f);
+            b[i] = fmaxf(acc1[t][8 * u + 4 + i] * f.inv1 + bb[i], 0.f);
+          }
+          split8(a, b, f.hscale, hh[2 * t + u], hl[2 * t + u]);
+        }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const char *stage = ring.acquire(false);
+        mma_item<2, 8>(stage, lane, acc2, hh + 2 * c, hl + 2 * c);
+      }
+    }
+    if (tok0 < M) epilogue<8, true>(acc2, e, scr, lane, tok0, M);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Packing.  order 0: natural k (k-step S, lane half g, element e -> k = 16 S + 8 g + e); order 1: accumulator order
+// (k = 32 (S >> 1) + 16 (S & 1) + 8 (e >> 2) + 4 g + (e & 3)): the order in which a lane holds the previous GEMM's output.
+__device__ __forceinline__ int x3_k(int order, int S, int g, int e) {
+  return order == 0 ? 16 * S + 8 * g + e : 32 * (S >> 1) + 16 * (S & 1) + 8 * (e >> 2) + 4 * g + (e & 3);
+}
+
+// rows [n0, n0 + 32 nbl) x k-steps [S0, S0 + steps) of W (N x K) -> one item image [s][nb][hi, lo][lane][8]
+__device__ __forceinline__ void x3_pack_fragment(const float *w, int64_t ldw, int N, int K, int n, int order, int S, int g,
+                                                 float scale, _Float16 *hi, _Float16 *lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = x3_k(order, S, g, e);
+    const float v = (n < N && k < K) ? w[(int64_t)n * ldw + k] * scale : 0.f;
+    const _Float16 h = (_Float16)v;
+    hi[e] = h;
+    lo[e] = (_Float16)(v - (float)h);
+  }
+}
+
+__global__ void x3_pack_kernel(const float *w, int64_t ldw, int N, int K, int NB, int order, float scale, _Float16 *out,
+                               int64_t fragments) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (pass, k-step, nb, lane)
+  if (idx >= fragments) return;
+  const int lane = idx & 63;
+  int64_t t = idx >> 6;
+  const int nb = t % NB;
+  t /= NB;
+  const int KS = K / 16;
+  const int S = t % KS, pass = t / KS;
+  _Float16 *o = out + (idx >> 6) * 1024 + lane * 8;
+  x3_pack_fragment(w, ldw, N, K, 32 * (pass * NB + nb) + (lane & 31), order, S, lane >> 5, scale, o, o + 512);
+}
+
+// FFN stream: [hb][linear1: 4 items][linear2: 4 items]
+__global__ void x3_ffn_pack_kernel(const float *w1, int64_t ldw1, const float *w2, int64_t ldw2, int H, float s1, float s2,
+                                   _Float16 *out, int64_t fragments) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (hb, item, fragment pair, lane)
+  if (idx >= fragments) return;
+  const int lane = idx & 63;
+  int64_t t = idx >> 6;
+  const int fr = t & 15;             // fragment pair within the item
+  t >>= 4;
+  const int item = t & 7, hb = t >> 3;
+  _Float16 *o = out + (((int64_t)hb * 8 + item) * 16 + fr) * 1024 + lane * 8;
+  if (item < 4) {                    // W1 rows 128 hb + 32 nb + i, k-steps 4 item + s
+    const int s = fr >> 2, nb = fr & 3;
+    x3_pack_fragment(w1, ldw1, H, 256, 128 * hb + 32 * nb + (lane & 31), 0, 4 * item + s, lane >> 5, s1, o, o + 512);
+  } else {                           // W2 rows 32 nb + i, hidden k-steps 8 hb + 2 (item - 4) + s, accumulator order
+    const int s = fr >> 3, nb = fr & 7;
+    x3_pack_fragment(w2, ldw2, 256, H, 32 * nb + (lane & 31), 1, 8 * hb + 2 * (item - 4) + s, lane >> 5, s2, o, o + 512);
+  }
+}
+
+int x3_grid(int64_t ntiles) {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  return (int)(ntiles < cus ? ntiles : cus);
+}
+
+float x3_pow2(int e) { return ldexpf(1.f, e); }
+
+template <typename Kern, typename... Args>
+int x3_launch(Kern kern, DvisLdsOptIn *opted, size_t lds_bytes, int64_t M, hipStream_t st, const char *what, Args... args) {
+  const int rc = dvis_lds_opt_in((const void *)kern, lds_bytes, opted, what);
+  if (rc != DVIS_OK) return rc;
+  const int64_t ntiles = (M + kTileTok - 1) / kTileTok;
+  hipLaunchKernelGGL(kern, dim3(x3_grid(ntiles)), dim3(kThreads), lds_bytes, st, args...);
+  return dvis_check_launch(what);
+}
+
+int x3_check_common(const float *x, int64_t ldx, int64_t M, const void *wp, const float *out, int64_t ldo) {
+  DVIS_REQUIRE(x && wp && out, "dvis_x3: null operand");
+  DVIS_REQUIRE(M >= 0 && M < (int64_t)1 << 31, "dvis_x3: M = %lld out of range", (long long)M);
+  DVIS_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)wp % 16 == 0,
+               "dvis_x3: operands must be 16-byte aligned with row strides %% 4 == 0");
+  return DVIS_OK;
+}
+
+}  // namespace
+
+// output features per pass (in blocks of 32) and the number of passes; 0 = not served
+static int x3_passes(int N, int *nb) {
+  if (N == 128 || N == 192 || N == 256 || N == 288) return *nb = N / 32, 1;
+  if (N > 0 && N % 256 == 0 && N <= 8192) return *nb = 8, N / 256;
+  return *nb = 0, 0;
+}
+
+DVIS_EXPORT int dvis_x3_linear_supported(int N, int K, int ln) {
+  int nb;
+  if (K != 256) return 0;
+  if (ln) return N == 256;
+  return x3_passes(N, &nb) > 0;
+}
+
+DVIS_EXPORT int64_t dvis_x3_packed_bytes(int N, int K) {
+  if (!dvis_x3_linear_supported(N, K, 0)) return -1;
+  return (int64_t)(K / 16) * (N / 32) * 2 * kPiece;
+}
+
+DVIS_EXPORT int dvis_x3_pack(const float *w, int64_t ldw, int N, int K, int wexp, void *packed, void *stream) {
+  DVIS_REQUIRE(w && packed, "dvis_x3_pack: null operand");
+  DVIS_REQUIRE(dvis_x3_linear_supported(N, K, 0), "dvis_x3_pack: (N, K) = (%d, %d) is not served (K = 256; N in 128 / 192 / 256 / 288 or N %% 256 == 0)", N, K);
+  DVIS_REQUIRE(wexp >= -60 && wexp <= 60, "dvis_x3_pack: wexp = %d", wexp);
+  int NB;
+  x3_passes(N, &NB);
+  const int64_t fragments = (int64_t)(K / 16) * (N / 32) * 64;
+  hipLaunchKernelGGL(x3_pack_kernel, dim3((unsigned)((fragments + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, ldw, N, K,
+                     NB, 0, x3_pow2(wexp), (_Float16 *)packed, fragments);
+  return dvis_check_launch("dvis_x3_pack");
+}
+
+DVIS_EXPORT int dvis_x3_linear(const float *x, int64_t ldx, int64_t M, int K, const void *wp, int N, int xexp, int wexp,
+                               const float *bias, int relu, float *out, int64_t ldo, void *stream) {
+  DVIS_REQUIRE(dvis_x3_linear_supported(N, K, 0), "dvis_x3_linear: (N, K) = (%d, %d) is not served (K = 256; N in 128 / 192 / 256 / 288 or N %% 256 == 0)", N, K);
+  DVIS_REQUIRE(bias, "dvis_x3_linear: bias is required");
+  const int rc = x3_check_common(x, ldx, M, wp, out, ldo);
+  if (rc != DVIS_OK) return rc;
+  if (M == 0) return DVIS_OK;
+  EpiArgs e = {};
+  e.bias = bias, e.out = out, e.ldo = ldo, e.inv = x3_pow2(-(xexp + wexp)), e.relu = relu;
+  const float xs = x3_pow2(xexp);
+  hipStream_t st = (hipStream_t)stream;
+  int NB;
+  const int npass = x3_passes(N, &NB);
+#define DVIS_X3_LINEAR(NBV)                                                                                          \
+  {                                                                                                                  \
+    static DvisLdsOptIn opted;                                                                                       \
+    return x3_launch(x3_linear_kernel<256, NBV, false>, &opted, kStages * Ring<NBV>::kItemBytes + kWaves * kScratch, \
+                     M, st, "dvis_x3_linear", x, ldx, M, wp, xs, npass, e);                                          \
+  }
+  switch (NB) {
+    case 4: DVIS_X3_LINEAR(4)
+    case 6: DVIS_X3_LINEAR(6)
+    case 8: DVIS_X3_LINEAR(8)
+    default: DVIS_X3_LINEAR(9)
+  }
+#undef DVIS_X3_LINEAR
+}
+
+DVIS_EXPORT int dvis_x3_linear_ln(const float *x, int64_t ldx, int64_t M, int K, const void *wp, int N, int xexp, int wexp,
+                                  const float *bias, const float *res, int64_t ldres, const float *gamma, const float *beta,
+                                  float eps, const float *pos, int64_t pos_rows, float *out, float *out2, int64_t ldo,
+                                  void *stream) {
+  DVIS_REQUIRE(dvis_x3_linear_supported(N, K, 1), "dvis_x3_linear_ln: (N, K) = (%d, %d) is not served (256, 256)", N, K);
+  DVIS_REQUIRE(bias && res && gamma && beta, "dvis_x3_linear_ln: bias, res, gamma, beta are required");
+  DVIS_REQUIRE(ldres % 4 == 0 && (uintptr_t)res % 16 == 0, "dvis_x3_linear_ln: res must be 16-byte aligned, ldres %% 4 == 0");
+  DVIS_REQUIRE(pos == nullptr || (out2 && pos_rows > 0 && (uintptr_t)pos % 16 == 0 && (uintptr_t)out2 % 16 == 0),
+               "dvis_x3_linear_ln: pos needs out2, pos_rows > 0 and 16-byte alignment");
+  const int rc = x3_check_common(x, ldx, M, wp, out, ldo);
+  if (rc != DVIS_OK) return rc;
+  if (M == 0) return DVIS_OK;
+  EpiArgs e = {};
+  e.bias = bias, e.res = res, e.ldres = ldres, e.gamma = gamma, e.beta = beta, e.eps = eps, e.pos = pos, e.pos_rows = pos_rows;
+  e.out = out, e.out2 = out2, e.ldo = ldo, e.inv = x3_pow2(-(xexp + wexp));
+  static DvisLdsOptIn opted;
+  return x3_launch(x3_linear_kernel<256, 8, true>, &opted, kStages * Ring<8>::kItemBytes + kWaves * kScratch, M,
+                   (hipStream_t)stream, "dvis_x3_linear_ln", x, ldx, M, wp, x3_pow2(xexp), 1, e);
+}
+
+DVIS_EXPORT int64_t dvis_x3_ffn_packed_bytes(int K, int H, int N) {
+  if (K != 256 || N != 256 || H <= 0 || H % 128 != 0 || H > 4096) return -1;
+  return (int64_t)(H / 128) * 8 * Ring<8>::kItemBytes;
+}
+
+DVIS_EXPORT int dvis_x3_ffn_pack(const float *w1, int64_t ldw1, const float *w2, int64_t ldw2, int K, int H, int N, int w1exp,
+                                 int w2exp, void *packed, void *stream) {
+  DVIS_REQUIRE(w1 && w2 && packed, "dvis_x3_ffn_pack: null operand");
+  DVIS_REQUIRE(dvis_x3_ffn_packed_bytes(K, H, N) > 0, "dvis_x3_ffn_pack: needs K = N = 256, H %% 128 == 0 (K %d, H %d, N %d)", K, H, N);
+  const int64_t fragments = (int64_t)(H / 128) * 8 * 16 * 64;
+  hipLaunchKernelGGL(x3_ffn_pack_kernel, dim3((unsigned)((fragments + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w1, ldw1,
+                     w2, ldw2, H, x3_pow2(w1exp), x3_pow2(w2exp), (_Float16 *)packed, fragments);
+  return dvis_check_launch("dvis_x3_ffn_pack");
+}
+
+DVIS_EXPORT int dvis_x3_ffn_ln(const float *x, int64_t ldx, int64_t M, int K, int H, int N, const void *wp, int xexp, int w1exp,
+                               int hexp, int w2exp, const float *b1, const float *b2, const float *gamma, const float *beta,
+                               float eps, const float *pos, int64_t pos_rows, float *out, float *out2, int64_t ldo,
+                               void *stream) {
+  DVIS_REQUIRE(dvis_x3_ffn_packed_bytes(K, H, N) > 0, "dvis_x3_ffn_ln: needs K = N = 256, H %% 128 == 0 (K %d, H %d, N %d)", K, H, N);
+  DVIS_REQUIRE(b1 && b2 && gamma && beta, "dvis_x3_ffn_ln: biases, gamma, beta are required");
+  DVIS_REQUIRE(pos == nullptr || (out2 && pos_rows > 0 && (uintptr_t)pos % 16 == 0 && (uintptr_t)out2 % 16 == 0),
+               "dvis_x3_ffn_ln: pos needs out2, pos_rows > 0 and 16-byte alignment");
+  const int rc = x3_check_common(x, ldx, M, wp, out, ldo);
+  if (rc != DVIS_OK) return rc;
+  if (M == 0) return DVIS_OK;
+  EpiArgs e = {};
+  e.bias = b2, e.res = x, e.ldres = ldx, e.gamma = gamma, e.beta = beta, e.eps = eps, e.pos = pos, e.pos_rows = pos_rows;
+  e.out = out, e.out2 = out2, e.ldo = ldo, e.inv = x3_pow2(-(hexp + w2exp));
+  FfnArgs f = {b1, x3_pow2(-(xexp + w1exp)), x3_pow2(hexp), H / 128};
+  static DvisLdsOptIn opted;
+  return x3_launch(x3_ffn_kernel, &opted, kStages * Ring<8>::kItemBytes + kWaves * kScratch + (size_t)H * 4, M,
+                   (hipStream_t)stream, "dvis_x3_ffn_ln", x, ldx, M, wp, x3_pow2(xexp), f, e);
+}

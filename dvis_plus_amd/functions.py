@@ -10,6 +10,7 @@ unchanged.  Differences, all deliberate:
   * failures raise ``RuntimeError`` — there is no torch/CPU fallback to hide them.
 """
 import ctypes
+import math
 import os
 import threading
 
@@ -716,6 +717,136 @@ def linear(x, weight, bias=None, relu=False, own=None):
 def linear_relu(x, lin, own=None):
     """relu(lin(x)) for an ``nn.Linear``."""
     return linear(x, lin.weight, lin.bias, relu=True, own=own)
+
+
+# ---- the encoder's tall GEMMs on the F16 matrix cores (csrc/gemm_x3.hip): fp32 operands as two f16 terms, three products
+# per pair, fp32 accumulation -> the error of an fp32 GEMM at 3/16 of its matrix-core time.
+X3 = os.environ.get("DVIS_X3", "1") != "0"
+X3_XEXP = int(os.environ.get("DVIS_X3_XEXP", "4"))      # activations are scaled by 2^4 before the split (|x| < 4094)
+_X3_PACKED = {}
+
+
+def _x3_exp(w):
+    """e with max|w| * 2^e in [2^13, 2^14): the weight fills the f16 range, its low term stays a normal number."""
+    m = float(w.detach().abs().max())
+    return 0 if m == 0.0 or m != m else 14 - math.frexp(m)[1]
+
+
+def _x3_cache(key_obj, version_key, make):
+    ent = _X3_PACKED.get(id(key_obj))
+    if ent is None or ent[0] != version_key:
+        if len(_X3_PACKED) > 512:
+            _X3_PACKED.clear()
+        _X3_PACKED[id(key_obj)] = ent = (version_key, make(), key_obj)       # (holds key_obj: id() stays unique)
+    return ent[1]
+
+
+def x3_pack(weight):
+    """(packed uint8 buffer, wexp) of an (N, K) float32 GPU weight, made once per weight version."""
+    def make():
+        w = weight.detach()
+        if w.stride(1) != 1:
+            w = w.contiguous()
+        N, K = w.shape
+        nbytes = native.lib().dvis_x3_packed_bytes(N, K)
+        if nbytes <= 0:
+            raise RuntimeError(f"x3_pack: weight {tuple(w.shape)} is not served (K % 32 == 0)")
+        e = _x3_exp(w)
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        with torch.cuda.device(w.device):
+            native.check(native.lib().dvis_x3_pack(ctypes.c_void_p(w.data_ptr()), w.stride(0), N, K, e,
+                                                   ctypes.c_void_p(buf.data_ptr()), native.stream_ptr(w.device)), "dvis_x3_pack")
+        return buf, e
+    return _x3_cache(weight, (weight._version, weight.data_ptr(), weight.device, tuple(weight.shape)), make)
+
+
+def x3_ok(x, N, K, ln=False):
+    return (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and x.shape[-1] == K
+            and bool(native.lib().dvis_x3_linear_supported(N, K, int(ln))))
+
+
+def _x3_rows(x, name):
+    K = x.shape[-1]
+    x2, ld = _rows2d(x, K)
+    if x2.data_ptr() % 16 or ld % 4:
+        raise RuntimeError(f"x3: {name} must be 16-byte aligned with a row stride % 4 == 0")
+    return x2, ld
+
+
+def x3_linear(x, weight, bias, relu=False, xexp=None):
+    """``relu?(x @ weight.T + bias)`` through dvis_x3_linear.  x (..., 256) float32 GPU; weight (N, 256)."""
+    N, K = weight.shape
+    x2, ldx = _x3_rows(x, "x")
+    buf, wexp = x3_pack(weight)
+    out = torch.empty((*x.shape[:-1], N), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        native.check(native.lib().dvis_x3_linear(
+            ctypes.c_void_p(x2.data_ptr()), ldx, x2.shape[0], K, ctypes.c_void_p(buf.data_ptr()), N,
+            X3_XEXP if xexp is None else xexp, wexp, native.dev_ptr(bias.detach(), "bias"), int(relu),
+            ctypes.c_void_p(out.data_ptr()), N, native.stream_ptr(x.device)), "dvis_x3_linear")
+    return out
+
+
+def _x3_pos(pos, x, N):
+    if pos is None:
+        return None, 0, None
+    if x.dim() != 3 or pos.numel() != x.shape[1] * N or pos.dtype != torch.float32 or not pos.is_cuda:
+        raise RuntimeError("x3: pos must be a float32 GPU (S, C) embedding for x of shape (N, S, C)")
+    return pos.contiguous(), x.shape[1], torch.empty((*x.shape[:-1], N), dtype=torch.float32, device=x.device)
+
+
+def x3_linear_ln(x, weight, bias, res, norm, pos=None, xexp=None):
+    """``norm(res + x @ weight.T + bias)`` (+ second output ``out + pos``) in one kernel (dvis_x3_linear_ln)."""
+    N, K = weight.shape
+    x2, ldx = _x3_rows(x, "x")
+    r2, ldr = _x3_rows(res, "res")
+    buf, wexp = x3_pack(weight)
+    out = torch.empty((*x.shape[:-1], N), dtype=torch.float32, device=x.device)
+    pos, pos_rows, out2 = _x3_pos(pos, x, N)
+    with torch.cuda.device(x.device):
+        native.check(native.lib().dvis_x3_linear_ln(
+            ctypes.c_void_p(x2.data_ptr()), ldx, x2.shape[0], K, ctypes.c_void_p(buf.data_ptr()), N,
+            X3_XEXP if xexp is None else xexp, wexp, native.dev_ptr(bias.detach(), "bias"), ctypes.c_void_p(r2.data_ptr()), ldr,
+            native.dev_ptr(norm.weight.detach(), "gamma"), native.dev_ptr(norm.bias.detach(), "beta"), float(norm.eps),
+            None if pos is None else ctypes.c_void_p(pos.data_ptr()), pos_rows, ctypes.c_void_p(out.data_ptr()),
+            None if out2 is None else ctypes.c_void_p(out2.data_ptr()), N, native.stream_ptr(x.device)), "dvis_x3_linear_ln")
+    return out if out2 is None else (out, out2)
+
+
+def x3_ffn_ok(x, lin1, lin2):
+    K, H, N = lin1.weight.shape[1], lin1.weight.shape[0], lin2.weight.shape[0]
+    return (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and x.shape[-1] == K
+            and lin2.weight.shape[1] == H and native.lib().dvis_x3_ffn_packed_bytes(K, H, N) > 0)
+
+
+def x3_ffn_ln(x, lin1, lin2, norm, pos=None, xexp=None, hexp=None):
+    """``norm(x + lin2(relu(lin1(x))))`` (+ ``out + pos``) in one kernel (dvis_x3_ffn_ln): the hidden tensor stays on chip."""
+    w1, w2 = lin1.weight, lin2.weight
+    H, K = w1.shape
+    N = w2.shape[0]
+    x2, ldx = _x3_rows(x, "x")
+
+    def make():
+        a, b = w1.detach().contiguous(), w2.detach().contiguous()
+        e1, e2 = _x3_exp(a), _x3_exp(b)
+        buf = torch.empty(native.lib().dvis_x3_ffn_packed_bytes(K, H, N), dtype=torch.uint8, device=a.device)
+        with torch.cuda.device(a.device):
+            native.check(native.lib().dvis_x3_ffn_pack(ctypes.c_void_p(a.data_ptr()), K, ctypes.c_void_p(b.data_ptr()), H, K, H,
+                                                       N, e1, e2, ctypes.c_void_p(buf.data_ptr()),
+                                                       native.stream_ptr(a.device)), "dvis_x3_ffn_pack")
+        return buf, e1, e2
+    buf, e1, e2 = _x3_cache(w1, (w1._version, w2._version, w1.data_ptr(), w2.data_ptr(), w1.device), make)
+    out = torch.empty((*x.shape[:-1], N), dtype=torch.float32, device=x.device)
+    pos, pos_rows, out2 = _x3_pos(pos, x, N)
+    with torch.cuda.device(x.device):
+        native.check(native.lib().dvis_x3_ffn_ln(
+            ctypes.c_void_p(x2.data_ptr()), ldx, x2.shape[0], K, H, N, ctypes.c_void_p(buf.data_ptr()),
+            X3_XEXP if xexp is None else xexp, e1, X3_XEXP if hexp is None else hexp, e2,
+            native.dev_ptr(lin1.bias.detach(), "b1"), native.dev_ptr(lin2.bias.detach(), "b2"),
+            native.dev_ptr(norm.weight.detach(), "gamma"), native.dev_ptr(norm.bias.detach(), "beta"), float(norm.eps),
+            None if pos is None else ctypes.c_void_p(pos.data_ptr()), pos_rows, ctypes.c_void_p(out.data_ptr()),
+            None if out2 is None else ctypes.c_void_p(out2.data_ptr()), N, native.stream_ptr(x.device)), "dvis_x3_ffn_ln")
+    return out if out2 is None else (out, out2)
 
 
 def maps_to_tokens(maps, affines=None, pos=None):

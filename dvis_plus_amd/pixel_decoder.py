@@ -151,7 +151,9 @@ class MSDeformAttn(nn.Module):
                 if pad:
                     w = torch.cat([w, w.new_zeros(pad, w.shape[1])], 0)
                     b = torch.cat([b, b.new_zeros(pad)], 0)
-            self._fused = (key, w.contiguous(), b.contiguous(), slot)
+            w, b = w.contiguous(), b.contiguous()
+            rows = w.shape[0] if slot else 3 * self.n_heads * self.n_levels * self.n_points
+            self._fused = (key, w, b, slot, w[:rows], b[:rows])     # [4:]: without the zero rows (csrc/gemm_x3.hip needs none)
         return self._fused[1], self._fused[2], self._fused[3]
 
     def _fast_path_ok(self, query, reference_points, input_padding_mask):
@@ -161,13 +163,25 @@ class MSDeformAttn(nn.Module):
                 and (self.n_levels, self.n_points) in ((1, 4), (3, 4), (4, 4)))
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
-                input_padding_mask=None, spatial_shapes_py=None, query_pos=None):
-        """Reference signature + one optional extra: `spatial_shapes_py`, a python copy of the shapes.  When the
+                input_padding_mask=None, spatial_shapes_py=None, query_pos=None, post=None):
+        """Reference signature + optional extras.  post: (residual, LayerNorm) — return ``norm(residual + forward(...))``,
+        the encoder layer's next step (msdeformattn.py:124-125), fused into the output projection where that is served.
+        `spatial_shapes_py`: a python copy of the shapes.  When the
         queries are the pixels themselves (encoder self-attention) it lets the kernel give each block an 8x8 pixel
         tile (cache locality); results do not depend on it.
         `query_pos` (second extra): when given, `query` is the query WITHOUT its position embedding ((1, Lq, C), shared by
         the batch); the fast path projects it once (bias-free) and the kernel adds it to the projected rows, so the
         (N, Lq, C) sum `query + query_pos` is never formed.  Other paths add it up front."""
+        if post is not None:
+            out = self._forward(query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                                input_padding_mask, spatial_shapes_py, query_pos, post)
+            return out[0] if isinstance(out, tuple) else Fn.add_layer_norm(out, post[0], post[1])
+        return self._forward(query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                             input_padding_mask, spatial_shapes_py, query_pos, None)
+
+    def _forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                 input_padding_mask, spatial_shapes_py, query_pos, post):
+        """-> projected attention output, or a 1-tuple (norm(residual + it),) when `post` was fused."""
         N, Len_q, _ = query.shape
         N, Len_in, _ = input_flatten.shape
         M, L, P = self.n_heads, self.n_levels, self.n_points
@@ -177,7 +191,12 @@ class MSDeformAttn(nn.Module):
         # are (dvis_msda_fused_forward_h); the layout experiments below are fp32-only
         lowp = query.dtype != torch.float32 or torch.is_autocast_enabled()
         hm = fast and _MSDA_HM and input_flatten.is_contiguous() and not lowp
-        if hm:
+        # the tall projections on the F16 matrix cores with split fp32 operands (csrc/gemm_x3.hip)
+        x3 = fast and Fn.X3 and not lowp and not hm and not _MSDA_SLOTS and Fn.x3_ok(input_flatten, self.d_model, self.d_model) \
+            and Fn.x3_ok(query, 3 * M * L * P, self.d_model)
+        if x3:
+            value = Fn.x3_linear(input_flatten, self.value_proj.weight, self.value_proj.bias).view(N, Len_in, M, -1)
+        elif hm:
             # own GEMM with a head-major epilogue: value[m, n, s, :] — neighbouring pixels of a head are adjacent lines
             value = Fn.gemm_nt(input_flatten.view(N * Len_in, self.d_model), self.value_proj.weight.detach(),
                                self.value_proj.bias.detach(), head_major=self.d_model // M).view(M, N, Len_in, -1)
@@ -198,11 +217,19 @@ class MSDeformAttn(nn.Module):
                 po, pl = pp[:, o_off:], pp[:, l_off:]
             elif query_pos is not None:
                 query = query + query_pos
-            proj = Fn.linear(query.reshape(N * Len_q, self.d_model), w, b)         # offsets | logits in one GEMM
+            if x3:
+                proj = Fn.x3_linear(query.reshape(N * Len_q, self.d_model), self._fused[4], self._fused[5])
+            else:
+                proj = Fn.linear(query.reshape(N * Len_q, self.d_model), w, b)     # offsets | logits in one GEMM
             ref = reference_points if reference_points.is_contiguous() else reference_points.contiguous()
             output = Fn.msda_fused_forward(value, input_spatial_shapes, input_level_start_index, ref,
                                            proj[:, o_off:], proj[:, l_off:], L, P, shapes_host=spatial_shapes_py,
                                            pos_offsets=po, pos_logits=pl, head_stride=slot, value_head_major=hm)
+            if x3 and post is not None and Fn.x3_ok(output, self.d_model, self.d_model, ln=True) \
+                    and post[0].shape == output.shape and post[0].dtype == torch.float32 and post[1].weight is not None:
+                return (Fn.x3_linear_ln(output, self.output_proj.weight, self.output_proj.bias, post[0], post[1]),)
+            if x3:
+                return Fn.x3_linear(output, self.output_proj.weight, self.output_proj.bias)
             return Fn.linear(output, self.output_proj.weight, self.output_proj.bias)
         if query_pos is not None:
             query = query + query_pos
@@ -243,12 +270,16 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         the previous layer already wrote it; emit_next_query: return (out, out + pos), the sum written by the final
         add+LayerNorm kernel — the encoder then never runs an add pass for `with_pos_embed` after the first layer."""
         if query is not None:
-            src2 = self.self_attn(query, reference_points, src, spatial_shapes, level_start_index, padding_mask,
-                                  spatial_shapes_py=shapes_py)
+            src = self.self_attn(query, reference_points, src, spatial_shapes, level_start_index, padding_mask,
+                                 spatial_shapes_py=shapes_py, post=(src, self.norm1))
         else:
-            src2 = self.self_attn(src, reference_points, src, spatial_shapes, level_start_index, padding_mask,
-                                  spatial_shapes_py=shapes_py, query_pos=pos)
-        src = Fn.add_layer_norm(src2, src, self.norm1)
+            src = self.self_attn(src, reference_points, src, spatial_shapes, level_start_index, padding_mask,
+                                 spatial_shapes_py=shapes_py, query_pos=pos, post=(src, self.norm1))
+        if Fn.X3 and Fn.x3_ffn_ok(src, self.linear1, self.linear2) and self.norm2.weight is not None:
+            # linear1 -> ReLU -> linear2 -> + src -> norm2 (-> + pos) in one kernel; the hidden tensor stays on chip
+            with_pos = emit_next_query and pos is not None and pos.shape[0] == 1 and src.dim() == 3
+            r = Fn.x3_ffn_ln(src, self.linear1, self.linear2, self.norm2, pos=pos if with_pos else None)
+            return r if with_pos or not emit_next_query else (r, None)
         src2 = Fn.linear(Fn.linear_relu(src, self.linear1), self.linear2.weight, self.linear2.bias)
         if emit_next_query and pos is not None and pos.shape[0] == 1:
             return Fn.add_layer_norm(src2, src, self.norm2, pos=pos)

@@ -235,8 +235,13 @@ class _MaskedDecoderBase(nn.Module):
                 # V = (tok + level_embed) Wv^T + bv = tok Wv^T + (bv + Wv level_embed): no pass at all
                 tok = tokens[lvl]                                                               # (N, hw, C)
                 pos_t = self.pe_layer.compute(h, w, tok.device).flatten(2).transpose(1, 2)      # (1, hw, C)
-                kall = Fn.linear(tok + (pos_t + le), Wk, bk).transpose(0, 1)                    # (hw, N, n_l * C) view
-                vall = Fn.linear(tok, Wv, bv + F.linear(le, Wv)).transpose(0, 1)
+                if Fn.X3 and Fn.x3_ok(tok, Wk.shape[0], Wk.shape[1]):
+                    # every pixel's keys / values for all layers of the level: split-f16 matrix-core GEMM (csrc/gemm_x3.hip)
+                    kall = Fn.x3_linear(tok + (pos_t + le), Wk, bk).transpose(0, 1)
+                    vall = Fn.x3_linear(tok, Wv, bv + F.linear(le, Wv)).transpose(0, 1)
+                else:
+                    kall = Fn.linear(tok + (pos_t + le), Wk, bk).transpose(0, 1)                # (hw, N, n_l * C) view
+                    vall = Fn.linear(tok, Wv, bv + F.linear(le, Wv)).transpose(0, 1)
             else:
                 src = (self.input_proj[lvl](x[lvl]).flatten(2) + le[None, :, None]).permute(2, 0, 1)
                 pos = self.pe_layer.compute(h, w, x[lvl].device).flatten(2).permute(2, 0, 1)   # (hw, 1, C)

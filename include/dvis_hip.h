@@ -49,6 +49,11 @@
  *                               and the refiner's nn.Conv1d layers as im2col GEMMs (refiner.py:42-54,116-119)
  *   dvis_gemm_ln             <- projection + the LayerNorm seam in front of it: `tgt = norm(identity + attn)`, `norm(tgt + ffn(tgt))`
  *                               followed by the next in_proj / linear1 / ref_proj layer, dvis_Plus/tracker.py:45-52, 277-318
+ *   dvis_x3_linear / dvis_x3_linear_ln / dvis_x3_ffn_ln
+ *                            <- the dense layers of MSDeformAttnTransformerEncoderLayer over all pixels of all frames:
+ *                               value_proj / sampling_offsets / attention_weights / output_proj
+ *                               (ops/modules/ms_deform_attn.py:96-117), `norm1(src + src2)`, forward_ffn =
+ *                               `norm2(src + linear2(relu(linear1(src))))` (mask2former/modeling/pixel_decoder/msdeformattn.py:103-131)
  */
 #ifndef DVIS_HIP_H
 #define DVIS_HIP_H
@@ -437,6 +442,45 @@ int dvis_gemm_ln(const float *A, int64_t lda, const float *add, int64_t ldadd, c
 int dvis_gemm_ln_supported(int M, int N, int K, int norms);
 int dvis_gemm_ln_num_configs(void);
 int dvis_gemm_ln_pick_config(int M, int N, int K);
+
+/*
+ * Tall fp32 GEMMs (M = every pixel of every frame, K = 256) on the F16 matrix cores with fp32-grade results: each fp32
+ * operand v is carried as two f16 terms hi = rn16(v 2^e), lo = rn16(v 2^e - hi) (22 significand bits) and each product as
+ * three matrix-core products lo*hi + hi*lo + hi*hi accumulated in fp32; the result is scaled back by 2^-(xexp + wexp).
+ * Measured against fp64 the error is that of an fp32 GEMM (its accumulation rounding dominates; tests/test_gemm_x3_gpu.py).
+ * xexp / wexp / hexp: the power-of-two exponents the activations / weights / hidden activations are scaled by before the
+ * split; |v 2^e| must stay below 65504 (f16 range; values beyond saturate to +-inf in the hi term).
+ *
+ * dvis_x3_pack: W (N x K, row stride ldw) -> `packed` (dvis_x3_packed_bytes(N, K) bytes), the kernels' LDS image (1 KB
+ * fragments [pass][k-step][row block][hi, lo][lane][8 halves]).  Once per weight.
+ */
+int64_t dvis_x3_packed_bytes(int N, int K);
+int dvis_x3_pack(const float *W, int64_t ldw, int N, int K, int wexp, void *packed, void *stream);
+/* which (N, K) the projection kernels serve (ln != 0: the LayerNorm form) */
+int dvis_x3_linear_supported(int N, int K, int ln);
+/* out (M x N, row stride ldo) = act( x (M x K, row stride ldx) W^T + bias ),  act = ReLU if relu != 0.
+ * Replaces nn.Linear over the flattened (frames x pixels) batch: ms_deform_attn.py:96-99 (value_proj), :101-102
+ * (sampling_offsets | attention_weights as one stacked weight), and the masked-attention decoder's key / value projections of
+ * every pixel for all layers of a level at once (mask2former_video/.../video_mask2former_transformer_decoder.py:81-88,
+ * nn.MultiheadAttention in_proj).  K = 256; N in {128, 192, 256, 288}, or N % 256 == 0 (output features in passes of 256
+ * over one read of x). */
+int dvis_x3_linear(const float *x, int64_t ldx, int64_t M, int K, const void *packed, int N, int xexp, int wexp,
+                   const float *bias, int relu, float *out, int64_t ldo, void *stream);
+/* out = LayerNorm( x W^T + bias + res ) over the N = 256 features (gamma, beta, eps; two-pass statistics as torch);
+ * pos (pos_rows x N, optional): out2[t] = out[t] + pos[t mod pos_rows] (the next layer's `with_pos_embed(src, pos)`,
+ * msdeformattn.py:99-101,122).  Replaces output_proj + `src = norm1(src + dropout1(src2))`, msdeformattn.py:124-125. */
+int dvis_x3_linear_ln(const float *x, int64_t ldx, int64_t M, int K, const void *packed, int N, int xexp, int wexp,
+                      const float *bias, const float *res, int64_t ldres, const float *gamma, const float *beta, float eps,
+                      const float *pos, int64_t pos_rows, float *out, float *out2, int64_t ldo, void *stream);
+/* The FFN block in one kernel: out = LayerNorm( x + linear2( relu( linear1(x) ) ) ), K = N = 256, H % 128 == 0; the
+ * (M x H) hidden tensor is never written.  Replaces forward_ffn, msdeformattn.py:116-120 (+ :130).
+ * dvis_x3_ffn_pack interleaves W1 (H x K) and W2 (N x H) in the order the kernel streams them (W2's k in accumulator order). */
+int64_t dvis_x3_ffn_packed_bytes(int K, int H, int N);
+int dvis_x3_ffn_pack(const float *W1, int64_t ldw1, const float *W2, int64_t ldw2, int K, int H, int N, int w1exp, int w2exp,
+                     void *packed, void *stream);
+int dvis_x3_ffn_ln(const float *x, int64_t ldx, int64_t M, int K, int H, int N, const void *packed, int xexp, int w1exp,
+                   int hexp, int w2exp, const float *b1, const float *b2, const float *gamma, const float *beta, float eps,
+                   const float *pos, int64_t pos_rows, float *out, float *out2, int64_t ldo, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,204 @@
+"""csrc/gemm_x3.hip: the deformable encoder's dense layers (ops/modules/ms_deform_attn.py:96-117, msdeformattn.py:103-131)
+with every fp32 operand as two f16 terms on the f16 matrix cores, three products per pair, fp32 accumulation.
+
+The claim these tests pin: the results are fp32-GRADE — measured against fp64 the error of the split kernels is not larger
+than the error of an fp32 GEMM of the same operands (whose own accumulation rounding dominates both) — and the layout is
+exact: integer-valued operands come out bit for bit.  Plus the edges: ragged row counts, strided rows, rows of very
+different magnitude, the f16 range, run-to-run bits, a token's result independent of what else is in the batch."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    with torch.no_grad():
+        yield
+
+
+def _lin(K, N, seed, bias_std=1.0):
+    torch.manual_seed(seed)
+    lin = nn.Linear(K, N).to(DEV)
+    nn.init.xavier_uniform_(lin.weight)
+    nn.init.normal_(lin.bias, 0.0, bias_std)
+    return lin
+
+
+def _norm(C, seed):
+    torch.manual_seed(seed)
+    n = nn.LayerNorm(C).to(DEV)
+    nn.init.normal_(n.weight, 1.0, 0.3)
+    nn.init.normal_(n.bias, 0.0, 0.2)
+    return n
+
+
+def _rel(c, ref, scale):
+    return float(((c.double() - ref).abs() / scale).max())
+
+
+@pytest.mark.parametrize("N", [128, 192, 256, 288, 768])
+@pytest.mark.parametrize("M", [1, 33, 127, 129, 5000])
+def test_linear_error_is_that_of_an_fp32_gemm(N, M):
+    from dvis_plus_amd import functions as Fn
+    lin = _lin(256, N, N + M)
+    x = torch.randn(M, 256, device=DEV)
+    ref = x.double() @ lin.weight.double().t() + lin.bias.double()
+    scale = x.double().abs() @ lin.weight.double().abs().t() + lin.bias.double().abs()
+    e_lib = _rel(F.linear(x, lin.weight, lin.bias), ref, scale)
+    for relu in (False, True):
+        got = Fn.x3_linear(x, lin.weight, lin.bias, relu=relu)
+        assert got.shape == (M, N)
+        e = _rel(got, ref.clamp_min(0) if relu else ref, scale)
+        # fp32 GEMMs measure 2.5 - 3.5e-7 here; the split kernels 1.5 - 2.5e-7
+        assert e <= max(1.25 * e_lib, 3e-7), (e, e_lib)
+
+
+def test_layout_is_exact_on_integer_operands():
+    """Small integers and a signed permutation-like weight are exactly representable in the hi term alone: every product and
+    every partial sum is an integer below 2^24, so the result must equal the fp64 one bit for bit — any fragment / k-order /
+    block mix-up shows as a wrong integer (asymmetric operands: G9 of the HIP guide)."""
+    from dvis_plus_amd import functions as Fn
+    g = torch.Generator().manual_seed(5)
+    for N in (256, 288):
+        lin = nn.Linear(256, N).to(DEV)
+        lin.weight.copy_(torch.randint(-3, 4, (N, 256), generator=g).float())
+        lin.bias.copy_(torch.randint(-50, 50, (N,), generator=g).float())
+        x = torch.randint(-40, 41, (777, 256), generator=g).float().to(DEV)
+        ref = (x.double() @ lin.weight.double().t() + lin.bias.double()).float()
+        assert torch.equal(Fn.x3_linear(x, lin.weight, lin.bias), ref)
+    l1, l2, norm = nn.Linear(256, 1024).to(DEV), nn.Linear(1024, 256).to(DEV), nn.LayerNorm(256).to(DEV)
+    l1.weight.copy_(torch.randint(-2, 3, (1024, 256), generator=g).float())
+    l1.bias.copy_(torch.randint(-20, 20, (1024,), generator=g).float())
+    l2.weight.copy_(torch.randint(-2, 3, (256, 1024), generator=g).float())
+    l2.bias.copy_(torch.randint(-20, 20, (256,), generator=g).float())
+    x = torch.randint(-3, 4, (300, 256), generator=g).float().to(DEV)
+    pre = x.double() + F.relu(x.double() @ l1.weight.double().t() + l1.bias.double()) @ l2.weight.double().t() + l2.bias.double()
+    assert float(pre.abs().max()) < 2 ** 24 and float(F.relu(x.double() @ l1.weight.double().t() + l1.bias.double()).max()) < 4000
+    ref = F.layer_norm(pre, (256,), norm.weight.double(), norm.bias.double(), norm.eps)
+    got = Fn.x3_ffn_ln(x, l1, l2, norm)
+    assert float((got.double() - ref).abs().max()) < 2e-6          # exact pre-norm sums; only the LayerNorm rounds
+
+
+def test_linear_strided_rows_and_magnitudes():
+    from dvis_plus_amd import functions as Fn
+    lin = _lin(256, 256, 3, bias_std=0.0)
+    big = torch.randn(400, 320, device=DEV)
+    x = big[:, 32:288]                                                   # row stride 320, 128-byte offset
+    x = x * torch.logspace(-3, 2.5, 400, device=DEV)[:, None]            # |x| from 1e-3 to ~1300 per row
+    ref = x.double() @ lin.weight.double().t()
+    scale = x.double().abs() @ lin.weight.double().abs().t()
+    assert _rel(Fn.x3_linear(x, lin.weight, lin.bias), ref, scale) <= 4e-7
+
+
+def test_f16_range_is_loud():
+    """|x * 2^xexp| beyond the f16 range (|x| >= 4094 at the default exponent) cannot be split: the result is not finite —
+    never a silently clipped number.  A smaller exponent serves such data."""
+    from dvis_plus_amd import functions as Fn
+    lin = _lin(256, 256, 4)
+    x = torch.randn(64, 256, device=DEV)
+    x[3, 17] = 9000.0
+    out = Fn.x3_linear(x, lin.weight, lin.bias)
+    assert not torch.isfinite(out[3]).all() and torch.isfinite(out[:3]).all() and torch.isfinite(out[4:]).all()
+    out = Fn.x3_linear(x, lin.weight, lin.bias, xexp=0)
+    ref = x.double() @ lin.weight.double().t() + lin.bias.double()
+    scale = x.double().abs() @ lin.weight.double().abs().t() + lin.bias.double().abs()
+    # (at exponent 0 the low terms of |x| < 0.125 are f16 subnormals: an absolute floor of 2^-25 per element instead of
+    # 2^-29 — measured 6e-7 of sum|a||w| on unit-normal rows, the price of the extra range)
+    assert _rel(out, ref, scale) <= 2e-6
+
+
+@pytest.mark.parametrize("M", [1, 129, 4001])
+@pytest.mark.parametrize("with_pos", [False, True])
+def test_linear_ln(M, with_pos):
+    from dvis_plus_amd import functions as Fn
+    lin, norm = _lin(256, 256, 11), _norm(256, 12)
+    S = max(1, M // 3) if with_pos else M
+    frames = M // S
+    x = torch.randn(frames, S, 256, device=DEV)
+    res = torch.randn(frames, S, 256, device=DEV)
+    pos = torch.randn(1, S, 256, device=DEV) if with_pos else None
+    ref = F.layer_norm(res.double() + x.double() @ lin.weight.double().t() + lin.bias.double(), (256,), norm.weight.double(),
+                       norm.bias.double(), norm.eps)
+    lib = norm(res + F.linear(x, lin.weight, lin.bias))
+    e_lib = float((lib.double() - ref).abs().max())
+    r = Fn.x3_linear_ln(x, lin.weight, lin.bias, res, norm, pos=pos)
+    out = r[0] if with_pos else r
+    assert float((out.double() - ref).abs().max()) <= max(1.25 * e_lib, 3e-6)
+    if with_pos:
+        assert float((r[1].double() - (ref + pos.double())).abs().max()) <= max(1.25 * e_lib, 4e-6)
+
+
+@pytest.mark.parametrize("M", [1, 33, 300, 9000])
+def test_ffn_ln(M):
+    from dvis_plus_amd import functions as Fn
+    l1, l2, norm = _lin(256, 1024, 21, 0.5), _lin(1024, 256, 22, 0.5), _norm(256, 23)
+    x = torch.randn(M, 256, device=DEV)
+    h = F.relu(x.double() @ l1.weight.double().t() + l1.bias.double())
+    ref = F.layer_norm(x.double() + h @ l2.weight.double().t() + l2.bias.double(), (256,), norm.weight.double(), norm.bias.double(),
+                       norm.eps)
+    lib = norm(x + l2(F.relu(l1(x))))
+    e_lib = float((lib.double() - ref).abs().max())
+    out = Fn.x3_ffn_ln(x, l1, l2, norm)
+    assert float((out.double() - ref).abs().max()) <= max(1.25 * e_lib, 4e-6)
+    pos = torch.randn(1, M, 256, device=DEV)
+    o1, o2 = Fn.x3_ffn_ln(x.view(1, M, 256), l1, l2, norm, pos=pos)
+    assert torch.equal(o1.view(M, 256), out)
+    assert float((o2.double() - (ref + pos.double())).abs().max()) <= max(1.25 * e_lib, 5e-6)
+
+
+def test_a_tokens_result_does_not_depend_on_the_batch_and_bits_repeat():
+    """What frame sharding relies on: a rank that holds 2 frames of a clip gets, for its tokens, the bits the unsharded run
+    gets (the library GEMM picks other kernels for other row counts; these kernels have one summation order per token)."""
+    from dvis_plus_amd import functions as Fn
+    l1, l2, norm, lin = _lin(256, 1024, 31, 0.5), _lin(1024, 256, 32, 0.5), _norm(256, 33), _lin(256, 288, 34)
+    x = torch.randn(6000, 256, device=DEV)
+    full_f, full_l = Fn.x3_ffn_ln(x, l1, l2, norm), Fn.x3_linear(x, lin.weight, lin.bias)
+    assert torch.equal(full_f, Fn.x3_ffn_ln(x, l1, l2, norm)) and torch.equal(full_l, Fn.x3_linear(x, lin.weight, lin.bias))
+    for a, b in ((0, 1), (17, 1000), (4097, 6000), (5999, 6000)):
+        part = x[a:b].contiguous()
+        assert torch.equal(Fn.x3_ffn_ln(part, l1, l2, norm), full_f[a:b])
+        assert torch.equal(Fn.x3_linear(part, lin.weight, lin.bias), full_l[a:b])
+
+
+def test_encoder_layer_takes_the_split_kernels_and_matches_the_fp32_path():
+    """The module-level switch: the same MSDeformAttnTransformerEncoderLayer with DVIS_X3 on and off (fp32 library GEMMs +
+    add_layernorm kernel), at a 2-frame 96 x 160 pyramid — and a spy that the three entry points really ran."""
+    from dvis_plus_amd import functions as Fn, native
+    from dvis_plus_amd.pixel_decoder import MSDeformAttnTransformerEncoderLayer, MSDeformAttnTransformerEncoder
+    torch.manual_seed(0)
+    layer = MSDeformAttnTransformerEncoderLayer(256, 1024, 0.0, "relu", 3, 8, 4).to(DEV).eval()
+    for p in layer.parameters():
+        if p.dim() > 1:
+            nn.init.xavier_uniform_(p)
+    layer.self_attn._reset_parameters()
+    with torch.no_grad():
+        layer.self_attn.attention_weights.weight.normal_(0, 0.05)
+        layer.self_attn.sampling_offsets.weight.normal_(0, 0.02)
+    shapes = [(3, 5), (6, 10), (12, 20)]
+    S = sum(h * w for h, w in shapes)
+    src, pos = torch.randn(2, S, 256, device=DEV), torch.randn(1, S, 256, device=DEV)
+    enc = MSDeformAttnTransformerEncoder(lambda: layer, 1)
+    ref_pts = enc.reference_points_unpadded(shapes, DEV)
+    ss = torch.as_tensor(shapes, dtype=torch.long, device=DEV)
+    lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
+    lib, calls = native.lib(), []
+    orig = {n: getattr(lib, n) for n in ("dvis_x3_linear", "dvis_x3_linear_ln", "dvis_x3_ffn_ln")}
+    for n, f in orig.items():
+        setattr(lib, n, (lambda n, f: lambda *a: (calls.append(n), f(*a))[1])(n, f))
+    try:
+        assert Fn.X3
+        out_x3, q_x3 = layer(src, pos, ref_pts, ss, lsi, None, shapes_py=shapes, emit_next_query=True)
+    finally:
+        for n, f in orig.items():
+            setattr(lib, n, f)
+    assert calls.count("dvis_x3_linear") == 2 and calls.count("dvis_x3_linear_ln") == 1 and calls.count("dvis_x3_ffn_ln") == 1
+    Fn.X3 = False
+    try:
+        out_f32, q_f32 = layer(src, pos, ref_pts, ss, lsi, None, shapes_py=shapes, emit_next_query=True)
+    finally:
+        Fn.X3 = True
+    assert float((out_x3 - out_f32).abs().max()) < 2e-5 and float((q_x3 - q_f32).abs().max()) < 2e-5

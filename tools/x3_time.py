@@ -1,0 +1,112 @@
+"""csrc/gemm_x3.hip at the encoder's shapes: error against fp64 (next to the fp32 library GEMM's on the same data) and time.
+    python tools/x3_time.py [frames]
+Per layer of the deformable encoder (30 frames x 19 320 tokens): value_proj 256 -> 256, offsets | logits 256 -> 288,
+output_proj + residual + LayerNorm, FFN 256 -> 1024 -> 256 + residual + LayerNorm."""
+import sys
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+sys.path.insert(0, ".")
+from dvis_plus_amd import functions as Fn  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def timeit(fn, iters=10):
+    fn()
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def rel(c, ref, scale):
+    return float(((c.double() - ref).abs() / scale).max())
+
+
+def main():
+    frames = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    S = 19320
+    M = S * frames
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn(frames, S, 256, device=DEV, generator=g)
+    x[0, :64] *= torch.logspace(-6, 2, 64, device=DEV)[:, None]          # rows of very different magnitude
+    res = torch.randn(frames, S, 256, device=DEV, generator=g)
+    pos = torch.randn(1, S, 256, device=DEV, generator=g)
+    R = 4096                                                              # rows checked against fp64
+    sel = torch.cat([torch.arange(0, R // 2), torch.arange(M - R // 2, M)]).to(DEV)
+    print(f"M = {M} tokens ({frames} frames); errors = max |c - fp64| / sum|a||w| over {R} rows")
+    for N in (256, 288, 128, 192):
+        lin = nn.Linear(256, N).to(DEV)
+        nn.init.xavier_uniform_(lin.weight)
+        nn.init.normal_(lin.bias)
+        xs = x.view(M, 256)[sel]
+        ref = xs.double() @ lin.weight.double().t() + lin.bias.double()
+        scale = xs.double().abs() @ lin.weight.double().abs().t() + lin.bias.double().abs()
+        for relu in (False, True):
+            got = Fn.x3_linear(x, lin.weight, lin.bias, relu=relu).view(M, N)[sel]
+            lib = F.linear(xs, lin.weight, lin.bias)
+            r = ref.clamp_min(0) if relu else ref
+            print(f"  linear 256 -> {N} relu={int(relu)}: x3 {rel(got, r, scale):.2e}   fp32 library {rel(F.relu(lib) if relu else lib, r, scale):.2e}")
+        t = timeit(lambda: Fn.x3_linear(x, lin.weight, lin.bias))
+        tl = timeit(lambda: F.linear(x, lin.weight, lin.bias))
+        fl = 2.0 * M * 256 * N
+        gb = 4.0 * M * (256 + N)
+        print(f"    x3 {t:.3f} ms ({fl / t / 1e9:.0f} TF fp32-equivalent, {gb / t / 1e6:.0f} GB/s)   library fp32 {tl:.3f} ms ({fl / tl / 1e9:.0f} TF)")
+    # output_proj + residual + LayerNorm (+ pos)
+    lin = nn.Linear(256, 256).to(DEV)
+    nn.init.xavier_uniform_(lin.weight)
+    norm = nn.LayerNorm(256).to(DEV)
+    nn.init.normal_(norm.weight, 1.0, 0.2)
+    nn.init.normal_(norm.bias, 0.0, 0.2)
+    xs, rs = x.view(M, 256)[sel], res.view(M, 256)[sel]
+    ps = pos.view(S, 256)[sel % S]
+    ref = F.layer_norm(rs.double() + xs.double() @ lin.weight.double().t() + lin.bias.double(), (256,), norm.weight.double(),
+                       norm.bias.double(), norm.eps)
+    out, out2 = Fn.x3_linear_ln(x, lin.weight, lin.bias, res, norm, pos=pos)
+    lib = norm(rs + F.linear(xs, lin.weight, lin.bias))
+    print(f"  linear + res + LN: x3 max abs err {float((out.view(M, 256)[sel].double() - ref).abs().max()):.2e}, "
+          f"out + pos {float((out2.view(M, 256)[sel].double() - ref - ps.double()).abs().max()):.2e}; fp32 torch {float((lib.double() - ref).abs().max()):.2e}")
+    t = timeit(lambda: Fn.x3_linear_ln(x, lin.weight, lin.bias, res, norm, pos=pos))
+    t1 = timeit(lambda: Fn.x3_linear_ln(x, lin.weight, lin.bias, res, norm))
+    tl = timeit(lambda: Fn.add_layer_norm(F.linear(x, lin.weight, lin.bias), res, norm, pos=pos))
+    print(f"    x3 {t:.3f} ms with out + pos, {t1:.3f} ms without; library GEMM + add_layernorm kernel {tl:.3f} ms")
+    # FFN
+    l1, l2 = nn.Linear(256, 1024).to(DEV), nn.Linear(1024, 256).to(DEV)
+    nn.init.xavier_uniform_(l1.weight)
+    nn.init.xavier_uniform_(l2.weight)
+    nn.init.normal_(l1.bias, 0.0, 0.5)
+    nn.init.normal_(l2.bias, 0.0, 0.5)
+    h = F.relu(xs.double() @ l1.weight.double().t() + l1.bias.double())
+    ref = F.layer_norm(xs.double() + h @ l2.weight.double().t() + l2.bias.double(), (256,), norm.weight.double(), norm.bias.double(),
+                       norm.eps)
+    out, out2 = Fn.x3_ffn_ln(x, l1, l2, norm, pos=pos)
+    lib = norm(xs + l2(F.relu(l1(xs))))
+    print(f"  FFN + res + LN: x3 max abs err {float((out.view(M, 256)[sel].double() - ref).abs().max()):.2e}, "
+          f"out + pos {float((out2.view(M, 256)[sel].double() - ref - ps.double()).abs().max()):.2e}; fp32 torch {float((lib.double() - ref).abs().max()):.2e}")
+    t = timeit(lambda: Fn.x3_ffn_ln(x, l1, l2, norm, pos=pos), 5)
+    t1 = timeit(lambda: Fn.x3_ffn_ln(x, l1, l2, norm), 5)
+    tl = timeit(lambda: Fn.add_layer_norm(Fn.linear(Fn.linear_relu(x, l1), l2.weight, l2.bias), x, norm, pos=pos), 5)
+    fl = 2.0 * M * 256 * 1024 * 2
+    print(f"    x3 {t:.3f} ms with out + pos ({fl / t / 1e9:.0f} TF fp32-equivalent), {t1:.3f} ms without; "
+          f"library GEMMs + add_layernorm kernel {tl:.3f} ms ({fl / tl / 1e9:.0f} TF)")
+    # run-to-run bits
+    a, b = Fn.x3_ffn_ln(x, l1, l2, norm), Fn.x3_ffn_ln(x, l1, l2, norm)
+    print("  FFN bit-reproducible:", bool(torch.equal(a, b)))
+    # a ragged tail and a tiny M
+    for m in (1, 33, 127, 129, 300):
+        xm = x.view(M, 256)[:m].contiguous()
+        o = Fn.x3_ffn_ln(xm, l1, l2, norm)
+        r = norm(xm + l2(F.relu(l1(xm))))
+        print(f"  M = {m}: FFN max abs diff vs torch fp32 {float((o - r).abs().max()):.2e}")
+
+
+if __name__ == "__main__":
+    main()
