@@ -1,0 +1,250 @@
+// conv1x1_x3.hip — the compute-bound 1x1 convolutions of the R50 bottlenecks (conv1 / conv3 / the stride-2 shortcuts of
+// res3 - res5: detectron2 BottleneckBlock with STRIDE_IN_1X1 False) on the F16 matrix cores with split fp32
+// operands: the arithmetic and the skeleton of csrc/gemm_x3.hip (fp32 operand = two f16 terms, three products per pair, fp32
+// accumulation; everything transposed: out^T (co, pixel) = W (co, ci) x (ci, pixel)), on NCHW as it lies in memory:
+//   * a wave owns 32 consecutive output pixels (lane & 31 = pixel, in (n, y, x) order — a tile may straddle two images) and a
+//     pass of 32 NB output channels; the MFMA "B" fragment of a k-step is 8 channels of the lane's pixel: 8 dword buffer loads,
+//     each 32 consecutive pixels of one channel row per half-wave (a full 128-byte line), split in registers;
+//   * the input channels stream in chunks of 64 (32 loads): the chunk after the one being multiplied is in flight (the ring's
+//     counted wait leaves those 32 loads out), so the activations never wait behind the weights and vice versa;
+//   * weights: the pass's packed fragments through the 3-stage LDS ring (global_load_lds), one item = 2 k-steps x NB blocks;
+//   * work items (pixel tile, channel pass) are dealt so that the passes of one pixel tile run at the same time on ONE XCD:
+//     the tile's activations come from HBM once, the other passes hit that XCD's L2;
+//   * epilogue in place: + folded-BN shift, + shortcut, ReLU; a store instruction writes 32 consecutive pixels of a channel
+//     per half-wave.  stride 2 (the down-sampling shortcut): the lane's pixel offset is that of input pixel (2 oy, 2 ox).
+// One summation order per output: bit-reproducible, independent of the batch.
+#include "dvis_common.h"
+#include "x3_common.h"
+
+namespace {
+
+constexpr unsigned kOOB = 0x80000000u;     // beyond any served tensor (< 2 GiB): buffer loads return 0, stores are dropped
+
+struct CxArgs {
+  const float *x, *bias, *res;
+  const void *wp;
+  float *y;
+  int N, C, K, relu, npass;
+  int stride, W_in, OW;
+  long long HW, HW_in, pixels;             // output pixels per image, input pixels per image, output pixels in total
+  long long tiles;                         // ceil(pixels / 128)
+  float xscale, inv;
+};
+
+// the w-th work item of workgroup b: XCD x = b % 8 owns the tiles t = x (mod 8); its workgroups deal (tile, pass) pairs
+// pass-fastest, so a tile's passes run concurrently on that XCD
+__device__ __forceinline__ bool cx_item(const CxArgs &a, long long w, long long *tile, int *pass) {
+  const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3, per = gridDim.x >> 3;
+  const long long m = i + (long long)per * w;
+  const long long u = m / a.npass;
+  *pass = (int)(m - u * a.npass);
+  *tile = xcd + 8 * u;
+  return *tile < a.tiles;
+}
+
+__device__ __forceinline__ unsigned cx_pixel_offset(const CxArgs &a, long long p) {      // byte offset of channel 0 of output pixel p's input
+  if (p >= a.pixels) return kOOB;
+  const long long n = p / a.HW;
+  long long pix = p - n * a.HW;
+  if (a.stride == 2) {
+    const int oy = (int)(pix / a.OW), ox = (int)(pix - (long long)oy * a.OW);
+    pix = 2ll * oy * a.W_in + 2 * ox;
+  }
+  return (unsigned)((n * a.C * a.HW_in + pix) * 4);
+}
+
+template <int NB>
+__global__ __launch_bounds__(kThreads) void conv1x1_x3_kernel(const CxArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
+  const int NI = a.C / 32, NC = a.C / 64;                     // ring items / activation chunks per work item
+  long long wcount = 0;
+  {
+    long long t;
+    int q;
+    while (cx_item(a, wcount, &t, &q)) ++wcount;
+  }
+  if (wcount == 0) return;
+  const __amdgpu_buffer_rsrc_t rx = dvis_make_rsrc_uniform(a.x, (unsigned)((long long)a.N * a.C * a.HW_in * 4));
+  const __amdgpu_buffer_rsrc_t ry = dvis_make_rsrc_uniform(a.y, (unsigned)((long long)a.N * a.K * a.HW * 4));
+  const __amdgpu_buffer_rsrc_t rr = dvis_make_rsrc_uniform(a.res ? a.res : a.y, (unsigned)((long long)a.N * a.K * a.HW * 4));
+  const unsigned chan = (unsigned)(a.HW_in * 4);              // bytes between two input channels of a pixel
+
+  typedef Ring<NB, 32> RingT;
+  RingT ring;
+  // issue cursor: where the next item to request lives
+  long long iw = 0;
+  int ic = 0, ipass;
+  {
+    long long t;
+    cx_item(a, 0, &t, &ipass);
+  }
+  auto next_offset = [&]() -> size_t {
+    const size_t o = ((size_t)ipass * NI + ic) * RingT::kItemBytes;
+    if (++ic == NI) {
+      ic = 0;
+      long long t;
+      if (!cx_item(a, ++iw, &t, &ipass)) ipass = 0;
+    }
+    return o;
+  };
+  ring.src = (const char *)a.wp, ring.lds = lds, ring.period = 1, ring.total = (int)(wcount * NI), ring.it = 0, ring.st_cmp = 0;
+  ring.st_iss = 0, ring.wave = wave, ring.lane = lane;
+  ring.issue_at(next_offset());
+  if (ring.total > 1) ring.issue_at(next_offset());
+
+  // activation chunk = 64 channels of the lane's pixel: k-step s, element e -> channel 16 s + 8 g + e
+  float raw[32];
+  // (an out-of-range pixel has offset kOOB = 2^31; the served tensors are below 2^31 bytes, so kOOB + anything stays out of
+  // range without a select — a per-load select makes hipcc branch around every load)
+  auto load_raw = [&](unsigned pixoff, int kc) {
+    const unsigned vo = pixoff + (unsigned)(8 * g) * chan;
+    const unsigned so = (unsigned)(64 * kc) * chan;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        raw[8 * s + e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo, so + (unsigned)(16 * s + e) * chan, 0));
+  };
+  long long tile;
+  int pass;
+  cx_item(a, 0, &tile, &pass);
+  unsigned pixoff = cx_pixel_offset(a, tile * kTileTok + wave * 32 + j);
+  load_raw(pixoff, 0);
+  for (long long w = 0; w < wcount; ++w) {
+    const long long p = tile * kTileTok + wave * 32 + j;
+    // the next work item (its first chunk is requested while this one's last chunk is multiplied)
+    long long ntile = tile;
+    int npass_ = pass;
+    const bool more = cx_item(a, w + 1, &ntile, &npass_);
+    const unsigned npixoff = more ? cx_pixel_offset(a, ntile * kTileTok + wave * 32 + j) : kOOB;
+    f16v acc[NB];
+    f16v resv[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f, resv[nb][i] = 0.f;
+    const long long n = p / a.HW;
+    const unsigned obase = p < a.pixels ? (unsigned)((n * a.K * a.HW + (p - n * a.HW)) * 4) : kOOB;
+    const unsigned ochan = (unsigned)(a.HW * 4);
+    const int co0 = pass * 32 * NB;
+    for (int kc = 0; kc < NC; ++kc) {
+      // the chunk's values are taken HERE (an opaque use: hipcc otherwise sinks the split below the requests that follow and,
+      // with LDS-DMA in flight, waits for everything it finds outstanding there — the next chunk included)
+#pragma unroll
+      for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(raw[i]));
+      h8 xh[4], xl[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const f4 lo4 = {raw[8 * s], raw[8 * s + 1], raw[8 * s + 2], raw[8 * s + 3]};
+        const f4 hi4 = {raw[8 * s + 4], raw[8 * s + 5], raw[8 * s + 6], raw[8 * s + 7]};
+        split8(lo4, hi4, a.xscale, xh[s], xl[s]);
+      }
+      // ALWAYS 32 loads here (the ring's counted wait relies on it): the next chunk, the next item's first, or nothing (OOB)
+      load_raw(kc + 1 < NC ? pixoff : npixoff, kc + 1 < NC ? kc + 1 : 0);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const char *stage = ring.wait(false);
+        ring.begin(ring.it + 1 < ring.total ? next_offset() : 0);
+        if (half == 1 && kc + 1 == NC && a.res) {
+          // the shortcut's values for the epilogue: requested before the item's products (their latency would otherwise be
+          // paid 16 NB times in a row)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              resv[nb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                          rr, obase + (unsigned)(co0 + 32 * nb + 8 * (r >> 2) + 4 * g + (r & 3)) * ochan, 0, 0));
+        }
+        mma_item<2, NB, NB>(stage, lane, acc, xh + 2 * half, xl + 2 * half, [&](int i) { ring.piece(i); });
+      }
+    }
+    // epilogue: lane = pixel; registers = channels co0 + 32 nb + 8 q + 4 g + i
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = co0 + 32 * nb + 8 * q + 4 * g;
+        f4 b = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) b = *(const f4 *)(a.bias + co);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const unsigned o = obase + (unsigned)(co + i) * ochan;
+          float v = acc[nb][4 * q + i] * a.inv + b[i] + resv[nb][4 * q + i];
+          if (a.relu) v = fmaxf(v, 0.f);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, o, 0, 0);
+        }
+      }
+    tile = ntile, pass = npass_, pixoff = npixoff;
+  }
+}
+
+}  // namespace
+
+DVIS_EXPORT int dvis_conv1x1_x3_supported(int C, int K, int64_t N, int64_t HW_in, int64_t HW_out) {
+  if (C < 64 || C % 64 != 0 || C > 4096) return 0;
+  if (!(K == 64 || K == 128 || (K > 0 && K % 256 == 0 && K <= 8192))) return 0;
+  if (N <= 0 || HW_out <= 0 || HW_in < HW_out) return 0;
+  if (N * C * HW_in * 4 >= ((int64_t)1 << 31) || N * K * HW_out * 4 >= ((int64_t)1 << 31)) return 0;   // 32-bit buffer offsets, kOOB
+  return 1;
+}
+
+DVIS_EXPORT int64_t dvis_conv1x1_x3_packed_bytes(int C, int K) {
+  if (!dvis_conv1x1_x3_supported(C, K, 1, 1, 1)) return -1;
+  return (int64_t)(C / 16) * (K / 32) * 2 * kPiece;
+}
+
+/* weights (K x C) -> [pass][k-step][block][hi, lo][lane][8 halves]; wexp as in dvis_x3_pack */
+DVIS_EXPORT int dvis_conv1x1_x3_pack(const float *w, int K, int C, int wexp, void *packed, void *stream) {
+  DVIS_REQUIRE(w && packed, "dvis_conv1x1_x3_pack: null operand");
+  DVIS_REQUIRE(dvis_conv1x1_x3_supported(C, K, 1, 1, 1), "dvis_conv1x1_x3_pack: (C, K) = (%d, %d) is not served", C, K);
+  DVIS_REQUIRE(wexp >= -60 && wexp <= 60, "dvis_conv1x1_x3_pack: wexp = %d", wexp);
+  const int NB = K == 64 ? 2 : K == 128 ? 4 : 8;
+  const int64_t fragments = (int64_t)(C / 16) * (K / 32) * 64;
+  hipLaunchKernelGGL(x3_pack_kernel, dim3((unsigned)((fragments + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (int64_t)C, K, C,
+                     NB, 0, ldexpf(1.f, wexp), (_Float16 *)packed, fragments);
+  return dvis_check_launch("dvis_conv1x1_x3_pack");
+}
+
+DVIS_EXPORT int dvis_conv1x1_x3(const float *x, const void *packed, const float *bias, const float *res, float *y, int N, int C, int K,
+                                int H, int W, int stride, int xexp, int wexp, int relu, void *stream) {
+  DVIS_REQUIRE(x && packed && y, "dvis_conv1x1_x3: null operand");
+  DVIS_REQUIRE(stride == 1 || stride == 2, "dvis_conv1x1_x3: stride %d", stride);
+  const int OH = (H + stride - 1) / stride, OW = (W + stride - 1) / stride;
+  DVIS_REQUIRE(dvis_conv1x1_x3_supported(C, K, N, (int64_t)H * W, (int64_t)OH * OW), "dvis_conv1x1_x3: shape (N %d, C %d, K %d, %d x %d, "
+               "stride %d) is not served (C %% 64 == 0, K = 64 / 128 or K %% 256 == 0, tensors below 2 GiB)", N, C, K, H, W, stride);
+  DVIS_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)packed % 16 == 0 && (bias == nullptr || (uintptr_t)bias % 16 == 0),
+               "dvis_conv1x1_x3: operands must be 16-byte aligned");
+  CxArgs a = {};
+  a.x = x, a.bias = bias, a.res = res, a.wp = packed, a.y = y, a.N = N, a.C = C, a.K = K, a.relu = relu;
+  a.stride = stride, a.W_in = W, a.OW = OW, a.HW = (long long)OH * OW, a.HW_in = (long long)H * W, a.pixels = a.HW * N;
+  a.tiles = (a.pixels + kTileTok - 1) / kTileTok;
+  a.xscale = ldexpf(1.f, xexp), a.inv = ldexpf(1.f, -(xexp + wexp));
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v >= 8) cus = v;
+  }
+  const int grid = cus / 8 * 8;
+  hipStream_t st = (hipStream_t)stream;
+  if (K == 64) {
+    a.npass = 1;
+    const size_t lds = kStages * Ring<2, 32>::kItemBytes;
+    hipLaunchKernelGGL(conv1x1_x3_kernel<2>, dim3(grid), dim3(kThreads), lds, st, a);
+  } else if (K == 128) {
+    a.npass = 1;
+    static DvisLdsOptIn opted;
+    const size_t lds = kStages * Ring<4, 32>::kItemBytes;
+    const int rc = dvis_lds_opt_in((const void *)conv1x1_x3_kernel<4>, lds, &opted, "dvis_conv1x1_x3");
+    if (rc != DVIS_OK) return rc;
+    hipLaunchKernelGGL(conv1x1_x3_kernel<4>, dim3(grid), dim3(kThreads), lds, st, a);
+  } else {
+    a.npass = K / 256;
+    static DvisLdsOptIn opted;
+    const size_t lds = kStages * Ring<8, 32>::kItemBytes;
+    const int rc = dvis_lds_opt_in((const void *)conv1x1_x3_kernel<8>, lds, &opted, "dvis_conv1x1_x3");
+    if (rc != DVIS_OK) return rc;
+    hipLaunchKernelGGL(conv1x1_x3_kernel<8>, dim3(grid), dim3(kThreads), lds, st, a);
+  }
+  return dvis_check_launch("dvis_conv1x1_x3");
+}

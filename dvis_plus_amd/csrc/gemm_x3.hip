@@ -25,95 +25,9 @@
 // workgroup; one raw s_barrier per item, counted vmcnt so that the next item stays in flight across it.
 // 256 threads, one workgroup per CU (up to 512 VGPR + AGPR per lane: accumulators 128 - 192, activation fragments 128).
 #include "dvis_common.h"
+#include "x3_common.h"
 
 namespace {
-
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-typedef float f16v __attribute__((ext_vector_type(16)));
-
-#define DVIS_LDS __attribute__((address_space(3)))
-#define DVIS_GLB __attribute__((address_space(1)))
-
-constexpr int kWaves = 4;
-constexpr int kThreads = kWaves * 64;
-constexpr int kTileTok = kWaves * 32;
-constexpr int kStages = 3;
-constexpr int kPiece = 1024;          // one operand fragment of a 32-row block: 64 lanes x 8 halves
-constexpr int kScratch = 4096;        // per wave: 32 tokens x 32 floats, the epilogue's transposition buffer
-
-__device__ __forceinline__ void glds16(const void *g, void *l) {
-  __builtin_amdgcn_global_load_lds((const DVIS_GLB void *)g, (DVIS_LDS void *)l, 16, 0, 0);
-}
-
-// v * s -> (hi, lo) for 8 values (round to nearest twice; s is a power of two, so v * s and the residual are exact)
-__device__ __forceinline__ void split8(f4 a, f4 b, float s, h8 &hi, h8 &lo) {
-  const float v[8] = {a.x * s, a.y * s, a.z * s, a.w * s, b.x * s, b.y * s, b.z * s, b.w * s};
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const f2 x = {v[2 * p], v[2 * p + 1]};
-    const h2 h = __builtin_convertvector(x, h2);
-    const f2 r = x - __builtin_convertvector(h, f2);
-    const h2 l = __builtin_convertvector(r, h2);
-    hi[2 * p] = h.x, hi[2 * p + 1] = h.y, lo[2 * p] = l.x, lo[2 * p + 1] = l.y;
-  }
-}
-
-// One item of the weight stream: STEPS k-steps x NBL blocks of 32 output features, image [s][nb][hi, lo][lane][8 halves].
-template <int STEPS, int NBL>
-__device__ __forceinline__ void mma_item(const char *stage, int lane, f16v *acc, const h8 *xh, const h8 *xl) {
-#pragma unroll
-  for (int s = 0; s < STEPS; ++s) {
-#pragma unroll
-    for (int nb = 0; nb < NBL; ++nb) {
-      const char *p = stage + ((s * NBL + nb) * 2) * kPiece + lane * 16;
-      const h8 wh = *(const h8 *)p;
-      const h8 wl = *(const h8 *)(p + kPiece);
-      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[s], acc[nb], 0, 0, 0);
-      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[s], acc[nb], 0, 0, 0);
-      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[s], acc[nb], 0, 0, 0);
-    }
-  }
-}
-
-// The weight ring.  Item i of this workgroup's sequence = item (i mod period) of the packed stream.
-template <int PW>      // 1 KB pieces per wave and item (item bytes = 4 * PW * 1024)
-struct Ring {
-  const char *src;
-  char *lds;
-  int period, total, it, st_cmp, st_iss, wave, lane;
-  static constexpr int kItemBytes = kWaves * PW * kPiece;
-
-  __device__ __forceinline__ void issue(int item) {
-    const char *g = src + (size_t)(item % period) * kItemBytes + lane * 16;
-    char *l = lds + st_iss * kItemBytes;
-#pragma unroll
-    for (int p = 0; p < PW; ++p) glds16(g + (wave + kWaves * p) * kPiece, l + (wave + kWaves * p) * kPiece);
-    st_iss = st_iss + 1 == kStages ? 0 : st_iss + 1;
-  }
-  __device__ __forceinline__ void start(const void *stream, char *ring, int period_, int total_, int wave_, int lane_) {
-    src = (const char *)stream, lds = ring, period = period_, total = total_, it = 0, st_cmp = 0, st_iss = 0;
-    wave = wave_, lane = lane_;
-    if (total > 0) issue(0);
-    if (total > 1) issue(1);
-  }
-  // Make item `it` readable by every wave and put item it + 2 in flight.  drain: other vector-memory work (activation
-  // loads, the previous tile's stores) may be outstanding — wait for everything.
-  __device__ __forceinline__ const char *acquire(bool drain) {
-    if (drain || it + 1 >= total)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
-    __builtin_amdgcn_s_barrier();
-    if (it + 2 < total) issue(it + 2);
-    const char *stage = lds + st_cmp * kItemBytes;
-    st_cmp = st_cmp + 1 == kStages ? 0 : st_cmp + 1;
-    ++it;
-    return stage;
-  }
-};
 
 // Activation fragments of a wave's 32 tokens for K = 16 * KS, natural k order: lane (token j, half g) holds
 // x[token][16 S + 8 g + 0..7] for k-step S.
@@ -160,29 +74,49 @@ struct EpiArgs {
 
 // acc (NB blocks x 16) -> out.  LN = false: act(acc * inv + bias).  LN = true: LayerNorm(acc * inv + bias + res) over the
 // 32 * NB features (two-pass mean / centred variance as torch), optional out2 = out + pos.
+// cb / cg / cbeta: bias (of this pass) / gamma / beta in LDS (staged once per workgroup): at 512 registers per lane hipcc
+// serialises global loads in an epilogue (one in flight, 32 round trips in a row); the residual rows and the position rows
+// are requested as ONE batch each, into the registers the activation fragments no longer need.
 template <int NB, bool LN>
-__device__ __forceinline__ void epilogue(f16v *acc, const EpiArgs &e, char *scr, int lane, int64_t tok0, int64_t M, int col0 = 0) {
+__device__ __forceinline__ void epilogue(f16v *acc, const EpiArgs &e, const float *cb, const float *cg, const float *cbeta, char *scr,
+                                         int lane, int64_t tok0, int64_t M, int col0 = 0) {
   const int j = lane & 31, g = lane >> 5;
   const int64_t tok = tok0 + j < M ? tok0 + j : M - 1;
   const int rows_valid = M - tok0 < 32 ? (int)(M - tok0) : 32;
   constexpr int N = 32 * NB;
   float mean = 0.f, rstd = 1.f;
+  // residual rows in batches of 2 blocks (8 x 16 bytes per lane), the next batch in flight while one is consumed: the VALU
+  // sees only 256 of the 512 registers, so the whole row (128 values) next to the 128 accumulator values does not fit
+  constexpr int NBT = (NB + 1) / 2;
   if constexpr (LN) {
+    const float *rp = e.res + tok * e.ldres + 4 * g;
+    f4 r[2][8];
+    auto fetch = [&](int bt, f4 *dst) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int nb = 2 * bt + (u >> 2);
+        if (nb < NB) dst[u] = *(const f4 *)(rp + 32 * nb + 8 * (u & 3));
+      }
+    };
+    fetch(0, r[0]);
     float sum = 0.f;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+    for (int bt = 0; bt < NBT; ++bt) {
+      if (bt + 1 < NBT) fetch(bt + 1, r[(bt + 1) & 1]);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = 32 * nb + 8 * q + 4 * g;
-        const f4 b = *(const f4 *)(e.bias + n);
-        const f4 r = *(const f4 *)(e.res + tok * e.ldres + n);
+      for (int u = 0; u < 8; ++u) {
+        const int nb = 2 * bt + (u >> 2), q = u & 3;
+        if (nb < NB) {
+          const f4 b = *(const f4 *)(cb + 32 * nb + 8 * q + 4 * g);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float v = acc[nb][4 * q + i] * e.inv + b[i] + r[i];
-          acc[nb][4 * q + i] = v;
-          sum += v;
+          for (int i = 0; i < 4; ++i) {
+            const float v = acc[nb][4 * q + i] * e.inv + b[i] + r[bt & 1][u][i];
+            acc[nb][4 * q + i] = v;
+            sum += v;
+          }
         }
       }
+    }
     sum += __shfl_xor(sum, 32);
     mean = sum * (1.f / N);
     float sq = 0.f;
@@ -196,18 +130,33 @@ __device__ __forceinline__ void epilogue(f16v *acc, const EpiArgs &e, char *scr,
     sq += __shfl_xor(sq, 32);
     rstd = rsqrtf(sq * (1.f / N) + e.eps);
   }
+  const float *pr = nullptr;
+  f4 pv[2][4];
+  auto fetch_pos = [&](int nb, f4 *dst) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = *(const f4 *)(pr + 32 * nb + 8 * q);
+  };
+  if constexpr (LN) {
+    if (e.pos != nullptr) {
+      pr = e.pos + (tok % e.pos_rows) * N + 4 * g;
+      fetch_pos(0, pv[0]);
+    }
+  }
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     f4 v[4];
+    if constexpr (LN) {
+      if (e.pos != nullptr && nb + 1 < NB) fetch_pos(nb + 1, pv[(nb + 1) & 1]);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int n = 32 * nb + 8 * q + 4 * g;
       if constexpr (LN) {
-        const f4 ga = *(const f4 *)(e.gamma + n), be = *(const f4 *)(e.beta + n);
+        const f4 ga = *(const f4 *)(cg + n), be = *(const f4 *)(cbeta + n);
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[q][i] = (acc[nb][4 * q + i] - mean) * rstd * ga[i] + be[i];
       } else {
-        const f4 b = *(const f4 *)(e.bias + col0 + n);
+        const f4 b = *(const f4 *)(cb + n);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float t = acc[nb][4 * q + i] * e.inv + b[i];
@@ -218,9 +167,8 @@ __device__ __forceinline__ void epilogue(f16v *acc, const EpiArgs &e, char *scr,
     store_block(scr, lane, v, e.out + tok0 * e.ldo + col0 + 32 * nb, e.ldo, rows_valid);
     if constexpr (LN) {
       if (e.pos != nullptr) {
-        const float *pr = e.pos + (tok % e.pos_rows) * N;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] += *(const f4 *)(pr + 32 * nb + 8 * q + 4 * g);
+        for (int q = 0; q < 4; ++q) v[q] += pv[nb & 1][q];
         store_block(scr, lane, v, e.out2 + tok0 * e.ldo + 32 * nb, e.ldo, rows_valid);
       }
     }
@@ -241,6 +189,13 @@ __global__ __launch_bounds__(kThreads) void x3_linear_kernel(const float *__rest
   Ring<NB> ring;
   ring.start(wp, lds, NI * npass, (int)(my * NI * npass), wave, lane);
   char *scr = lds + kStages * Ring<NB>::kItemBytes + wave * kScratch;
+  // bias (all passes) | gamma | beta in LDS
+  float *cst = (float *)(lds + kStages * Ring<NB>::kItemBytes + kWaves * kScratch);
+  const int ntot = 32 * NB * npass;
+  for (int i = threadIdx.x; i < ntot; i += kThreads) cst[i] = e.bias[i];
+  if constexpr (LN)
+    for (int i = threadIdx.x; i < 32 * NB; i += kThreads) cst[ntot + i] = e.gamma[i], cst[ntot + 32 * NB + i] = e.beta[i];
+  __syncthreads();
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t tok0 = tile * kTileTok + wave * 32;
     const int64_t row = tok0 + j < M ? tok0 + j : M - 1;
@@ -254,10 +209,11 @@ __global__ __launch_bounds__(kThreads) void x3_linear_kernel(const float *__rest
         for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
 #pragma unroll
       for (int c = 0; c < NI; ++c) {
-        const char *stage = ring.acquire(c == 0);
-        mma_item<2, NB>(stage, lane, acc, xh + 2 * c, xl + 2 * c);
+        const char *stage = ring.wait(c == 0);
+        ring.begin_periodic();
+        mma_item<2, NB, NB>(stage, lane, acc, xh + 2 * c, xl + 2 * c, [&](int i) { ring.piece(i); });
       }
-      if (tok0 < M) epilogue<NB, LN>(acc, e, scr, lane, tok0, M, pass * 32 * NB);
+      if (tok0 < M) epilogue<NB, LN>(acc, e, cst + pass * 32 * NB, cst + ntot, cst + ntot + 32 * NB, scr, lane, tok0, M, pass * 32 * NB);
     }
   }
 }
@@ -286,6 +242,8 @@ __global__ __launch_bounds__(kThreads) void x3_ffn_kernel(const float *__restric
   // linear1's bias lives in LDS: a global load between two items would make the compiler drain the ring behind it
   float *b1s = (float *)(lds + kStages * Ring<8>::kItemBytes + kWaves * kScratch);
   for (int i = threadIdx.x; i < 128 * f.HB; i += kThreads) b1s[i] = f.b1[i];
+  float *cst = b1s + 128 * f.HB;             // b2 | gamma | beta
+  for (int i = threadIdx.x; i < 256; i += kThreads) cst[i] = e.bias[i], cst[256 + i] = e.gamma[i], cst[512 + i] = e.beta[i];
   __syncthreads();
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t tok0 = tile * kTileTok + wave * 32;
@@ -305,8 +263,9 @@ __global__ __launch_bounds__(kThreads) void x3_ffn_kernel(const float *__restric
         for (int i = 0; i < 16; ++i) acc1[t][i] = 0.f;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const char *stage = ring.acquire(hb == 0 && c == 0);
-        mma_item<4, 4>(stage, lane, acc1, xh + 4 * c, xl + 4 * c);
+        const char *stage = ring.wait(hb == 0 && c == 0);
+        ring.begin_periodic();
+        mma_item<4, 4, 8>(stage, lane, acc1, xh + 4 * c, xl + 4 * c, [&](int i) { ring.piece(i); });
       }
       // hidden block -> phase-2 "B" fragments, in place: k-step 2 t + u of the block takes registers 8 u .. 8 u + 7 of tile t
       h8 hh[8], hl[8];
@@ -326,48 +285,16 @@ __global__ __launch_bounds__(kThreads) void x3_ffn_kernel(const float *__restric
         }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const char *stage = ring.acquire(false);
-        mma_item<2, 8>(stage, lane, acc2, hh + 2 * c, hl + 2 * c);
+        const char *stage = ring.wait(false);
+        ring.begin_periodic();
+        mma_item<2, 8, 8>(stage, lane, acc2, hh + 2 * c, hl + 2 * c, [&](int i) { ring.piece(i); });
       }
     }
-    if (tok0 < M) epilogue<8, true>(acc2, e, scr, lane, tok0, M);
+    if (tok0 < M) epilogue<8, true>(acc2, e, cst, cst + 256, cst + 512, scr, lane, tok0, M);
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Packing.  order 0: natural k (k-step S, lane half g, element e -> k = 16 S + 8 g + e); order 1: accumulator order
-// (k = 32 (S >> 1) + 16 (S & 1) + 8 (e >> 2) + 4 g + (e & 3)): the order in which a lane holds the previous GEMM's output.
-__device__ __forceinline__ int x3_k(int order, int S, int g, int e) {
-  return order == 0 ? 16 * S + 8 * g + e : 32 * (S >> 1) + 16 * (S & 1) + 8 * (e >> 2) + 4 * g + (e & 3);
-}
-
-// rows [n0, n0 + 32 nbl) x k-steps [S0, S0 + steps) of W (N x K) -> one item image [s][nb][hi, lo][lane][8]
-__device__ __forceinline__ void x3_pack_fragment(const float *w, int64_t ldw, int N, int K, int n, int order, int S, int g,
-                                                 float scale, _Float16 *hi, _Float16 *lo) {
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int k = x3_k(order, S, g, e);
-    const float v = (n < N && k < K) ? w[(int64_t)n * ldw + k] * scale : 0.f;
-    const _Float16 h = (_Float16)v;
-    hi[e] = h;
-    lo[e] = (_Float16)(v - (float)h);
-  }
-}
-
-__global__ void x3_pack_kernel(const float *w, int64_t ldw, int N, int K, int NB, int order, float scale, _Float16 *out,
-                               int64_t fragments) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (pass, k-step, nb, lane)
-  if (idx >= fragments) return;
-  const int lane = idx & 63;
-  int64_t t = idx >> 6;
-  const int nb = t % NB;
-  t /= NB;
-  const int KS = K / 16;
-  const int S = t % KS, pass = t / KS;
-  _Float16 *o = out + (idx >> 6) * 1024 + lane * 8;
-  x3_pack_fragment(w, ldw, N, K, 32 * (pass * NB + nb) + (lane & 31), order, S, lane >> 5, scale, o, o + 512);
-}
-
 // FFN stream: [hb][linear1: 4 items][linear2: 4 items]
 __global__ void x3_ffn_pack_kernel(const float *w1, int64_t ldw1, const float *w2, int64_t ldw2, int H, float s1, float s2,
                                    _Float16 *out, int64_t fragments) {
@@ -465,8 +392,9 @@ DVIS_EXPORT int dvis_x3_linear(const float *x, int64_t ldx, int64_t M, int K, co
 #define DVIS_X3_LINEAR(NBV)                                                                                          \
   {                                                                                                                  \
     static DvisLdsOptIn opted;                                                                                       \
-    return x3_launch(x3_linear_kernel<256, NBV, false>, &opted, kStages * Ring<NBV>::kItemBytes + kWaves * kScratch, \
-                     M, st, "dvis_x3_linear", x, ldx, M, wp, xs, npass, e);                                          \
+    return x3_launch(x3_linear_kernel<256, NBV, false>, &opted,                                                      \
+                     kStages * Ring<NBV>::kItemBytes + kWaves * kScratch + (size_t)N * 4, M, st, "dvis_x3_linear", x, ldx, M, wp, \
+                     xs, npass, e);                                                                                  \
   }
   switch (NB) {
     case 4: DVIS_X3_LINEAR(4)
@@ -493,7 +421,7 @@ DVIS_EXPORT int dvis_x3_linear_ln(const float *x, int64_t ldx, int64_t M, int K,
   e.bias = bias, e.res = res, e.ldres = ldres, e.gamma = gamma, e.beta = beta, e.eps = eps, e.pos = pos, e.pos_rows = pos_rows;
   e.out = out, e.out2 = out2, e.ldo = ldo, e.inv = x3_pow2(-(xexp + wexp));
   static DvisLdsOptIn opted;
-  return x3_launch(x3_linear_kernel<256, 8, true>, &opted, kStages * Ring<8>::kItemBytes + kWaves * kScratch, M,
+  return x3_launch(x3_linear_kernel<256, 8, true>, &opted, kStages * Ring<8>::kItemBytes + kWaves * kScratch + 3 * 256 * 4, M,
                    (hipStream_t)stream, "dvis_x3_linear_ln", x, ldx, M, wp, x3_pow2(xexp), 1, e);
 }
 
@@ -528,6 +456,6 @@ DVIS_EXPORT int dvis_x3_ffn_ln(const float *x, int64_t ldx, int64_t M, int K, in
   e.out = out, e.out2 = out2, e.ldo = ldo, e.inv = x3_pow2(-(hexp + w2exp));
   FfnArgs f = {b1, x3_pow2(-(xexp + w1exp)), x3_pow2(hexp), H / 128};
   static DvisLdsOptIn opted;
-  return x3_launch(x3_ffn_kernel, &opted, kStages * Ring<8>::kItemBytes + kWaves * kScratch + (size_t)H * 4, M,
+  return x3_launch(x3_ffn_kernel, &opted, kStages * Ring<8>::kItemBytes + kWaves * kScratch + (size_t)(H + 3 * 256) * 4, M,
                    (hipStream_t)stream, "dvis_x3_ffn_ln", x, ldx, M, wp, x3_pow2(xexp), f, e);
 }

@@ -1,0 +1,184 @@
+// Shared device code of the split-f16 matrix-core kernels (csrc/gemm_x3.hip, csrc/conv1x1_x3.hip): operand split, fragment
+// MFMA loop over one item of the packed weight stream, the LDS ring that streams it.  See gemm_x3.hip for the design.
+#pragma once
+#include "dvis_common.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+#define DVIS_LDS __attribute__((address_space(3)))
+#define DVIS_GLB __attribute__((address_space(1)))
+
+constexpr int kWaves = 4;
+constexpr int kThreads = kWaves * 64;
+constexpr int kTileTok = kWaves * 32;
+constexpr int kStages = 3;
+constexpr int kPiece = 1024;          // one operand fragment of a 32-row block: 64 lanes x 8 halves
+constexpr int kScratch = 4096;        // per wave: 32 tokens x 32 floats, the epilogue's transposition buffer
+
+__device__ __forceinline__ void glds16(const void *g, void *l) {
+  __builtin_amdgcn_global_load_lds((const DVIS_GLB void *)g, (DVIS_LDS void *)l, 16, 0, 0);
+}
+
+// v * s -> (hi, lo) for 8 values (round to nearest twice; s is a power of two, so v * s and the residual are exact)
+__device__ __forceinline__ void split8(f4 a, f4 b, float s, h8 &hi, h8 &lo) {
+  const float v[8] = {a.x * s, a.y * s, a.z * s, a.w * s, b.x * s, b.y * s, b.z * s, b.w * s};
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const f2 x = {v[2 * p], v[2 * p + 1]};
+    const h2 h = __builtin_convertvector(x, h2);
+    const f2 r = x - __builtin_convertvector(h, f2);
+    const h2 l = __builtin_convertvector(r, h2);
+    hi[2 * p] = h.x, hi[2 * p + 1] = h.y, lo[2 * p] = l.x, lo[2 * p + 1] = l.y;
+  }
+}
+
+// One item of the weight stream: STEPS k-steps x NBL blocks of 32 output features, image [s][nb][hi, lo][lane][8 halves].
+//   * The fragment pair of block t + 1 is requested before block t's three products are issued (hipcc on its own reads each
+//     fragment into one register quad and waits for it right away: an LDS round trip per product pair with the matrix pipe idle
+//     — one wave per SIMD has nobody else to fill it).
+//   * `dma(i)`, i < NDMA: the caller's LDS-DMA requests for a LATER item, spread over the products instead of issued in one
+//     burst after the barrier: a burst of 8 x 1 KB from each of the 4 waves queues 512 cycles of vector-memory issue in front
+//     of the first product of every wave; between products the same requests cost their issue slot.
+template <int STEPS, int NBL, int NDMA, typename Dma>
+__device__ __forceinline__ void mma_item(const char *stage, int lane, f16v *acc, const h8 *xh, const h8 *xl, Dma dma) {
+  constexpr int T = STEPS * NBL;
+  static_assert(NDMA <= T, "one request per block at most");
+  const char *p = stage + lane * 16;
+  h8 wh[2], wl[2];
+  wh[0] = *(const h8 *)p, wl[0] = *(const h8 *)(p + kPiece);
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int s = t / NBL, nb = t % NBL, c = t & 1;
+    if (t + 1 < T) wh[c ^ 1] = *(const h8 *)(p + (t + 1) * 2 * kPiece), wl[c ^ 1] = *(const h8 *)(p + (t + 1) * 2 * kPiece + kPiece);
+    if (NDMA > 0 && t * NDMA / T != (t + 1) * NDMA / T) dma(t * NDMA / T);
+    __builtin_amdgcn_sched_barrier(0);      // the requests above stay above the products below
+    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[c], xh[s], acc[nb], 0, 0, 0);
+    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[c], xl[s], acc[nb], 0, 0, 0);
+    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[c], xh[s], acc[nb], 0, 0, 0);
+  }
+}
+template <int STEPS, int NBL>
+__device__ __forceinline__ void mma_item(const char *stage, int lane, f16v *acc, const h8 *xh, const h8 *xl) {
+  mma_item<STEPS, NBL, 0>(stage, lane, acc, xh, xl, [](int) {});
+}
+
+// EXTRA: ordinary loads the kernel keeps in flight, issued between an item's pieces and the next-but-one item's (the
+// activation prefetch of csrc/conv1x1_x3.hip): they are newer than the item waited for, so the counted wait leaves them out too.
+template <int PW, int EXTRA = 0>      // PW: 1 KB pieces per wave and item (item bytes = 4 * PW * 1024)
+struct Ring {
+  const char *src;
+  char *lds;
+  int period, total, it, st_cmp, st_iss, wave, lane;
+  static constexpr int kItemBytes = kWaves * PW * kPiece;
+
+  __device__ __forceinline__ void issue(int item) { issue_at((size_t)(item % period) * kItemBytes); }
+  __device__ __forceinline__ void issue_at(size_t byte_offset) {
+    const char *g = src + byte_offset + lane * 16;
+    char *l = lds + st_iss * kItemBytes;
+#pragma unroll
+    for (int p = 0; p < PW; ++p) glds16(g + (wave + kWaves * p) * kPiece, l + (wave + kWaves * p) * kPiece);
+    st_iss = st_iss + 1 == kStages ? 0 : st_iss + 1;
+  }
+  __device__ __forceinline__ void start(const void *stream, char *ring, int period_, int total_, int wave_, int lane_) {
+    src = (const char *)stream, lds = ring, period = period_, total = total_, it = 0, st_cmp = 0, st_iss = 0;
+    wave = wave_, lane = lane_;
+    if (total > 0) issue(0);
+    if (total > 1) issue(1);
+  }
+  // Make item `it` readable by every wave and put item it + 2 in flight.  drain: other vector-memory work (activation
+  // loads, the previous tile's stores) may be outstanding — wait for everything.
+  __device__ __forceinline__ const char *acquire(bool drain) {
+    if (drain || it + 1 >= total)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW + EXTRA) : "memory");
+    __builtin_amdgcn_s_barrier();
+    if (it + 2 < total) issue(it + 2);
+    const char *stage = lds + st_cmp * kItemBytes;
+    st_cmp = st_cmp + 1 == kStages ? 0 : st_cmp + 1;
+    ++it;
+    return stage;
+  }
+  // The two halves of acquire for callers that spread the requests over the products (mma_item's dma):
+  //   stage = ring.wait(drain); ring.begin(offset of item it + 1 ... i.e. the item two after the one just waited for);
+  //   mma_item<..., PW>(stage, ..., [&](int i) { ring.piece(i); });
+  __device__ __forceinline__ const char *wait(bool drain) {
+    if (drain || it + 1 >= total)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW + EXTRA) : "memory");
+    __builtin_amdgcn_s_barrier();
+    const char *stage = lds + st_cmp * kItemBytes;
+    st_cmp = st_cmp + 1 == kStages ? 0 : st_cmp + 1;
+    ++it;
+    return stage;
+  }
+  const char *dma_src;
+  char *dma_dst;
+  bool dma_on;
+  __device__ __forceinline__ void begin(size_t byte_offset) {       // after wait(): `it` already counts the waited item
+    dma_on = it + 1 < total;
+    dma_src = src + byte_offset + lane * 16 + wave * kPiece;
+    dma_dst = lds + st_iss * kItemBytes + wave * kPiece;
+    if (dma_on) st_iss = st_iss + 1 == kStages ? 0 : st_iss + 1;
+  }
+  __device__ __forceinline__ void begin_periodic() { begin((size_t)((it + 1) % period) * kItemBytes); }
+  __device__ __forceinline__ void piece(int i) {
+    if (dma_on) glds16(dma_src + i * (kWaves * kPiece), dma_dst + i * (kWaves * kPiece));
+  }
+  // the same with the caller naming where item it + 2 lives in the packed stream (a sequence that is not periodic)
+  __device__ __forceinline__ const char *acquire_at(bool drain, size_t next2_byte_offset) {
+    if (drain || it + 1 >= total)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW + EXTRA) : "memory");
+    __builtin_amdgcn_s_barrier();
+    if (it + 2 < total) issue_at(next2_byte_offset);
+    const char *stage = lds + st_cmp * kItemBytes;
+    st_cmp = st_cmp + 1 == kStages ? 0 : st_cmp + 1;
+    ++it;
+    return stage;
+  }
+};
+
+
+// Packing.  order 0: natural k (k-step S, lane half g, element e -> k = 16 S + 8 g + e); order 1: accumulator order
+// (k = 32 (S >> 1) + 16 (S & 1) + 8 (e >> 2) + 4 g + (e & 3)): the order in which a lane holds the previous GEMM's output.
+__device__ __forceinline__ int x3_k(int order, int S, int g, int e) {
+  return order == 0 ? 16 * S + 8 * g + e : 32 * (S >> 1) + 16 * (S & 1) + 8 * (e >> 2) + 4 * g + (e & 3);
+}
+
+// rows [n0, n0 + 32 nbl) x k-steps [S0, S0 + steps) of W (N x K) -> one item image [s][nb][hi, lo][lane][8]
+__device__ __forceinline__ void x3_pack_fragment(const float *w, int64_t ldw, int N, int K, int n, int order, int S, int g,
+                                                 float scale, _Float16 *hi, _Float16 *lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = x3_k(order, S, g, e);
+    const float v = (n < N && k < K) ? w[(int64_t)n * ldw + k] * scale : 0.f;
+    const _Float16 h = (_Float16)v;
+    hi[e] = h;
+    lo[e] = (_Float16)(v - (float)h);
+  }
+}
+
+__global__ void x3_pack_kernel(const float *w, int64_t ldw, int N, int K, int NB, int order, float scale, _Float16 *out,
+                               int64_t fragments) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (pass, k-step, nb, lane)
+  if (idx >= fragments) return;
+  const int lane = idx & 63;
+  int64_t t = idx >> 6;
+  const int nb = t % NB;
+  t /= NB;
+  const int KS = K / 16;
+  const int S = t % KS, pass = t / KS;
+  _Float16 *o = out + (idx >> 6) * 1024 + lane * 8;
+  x3_pack_fragment(w, ldw, N, K, 32 * (pass * NB + nb) + (lane & 31), order, S, lane >> 5, scale, o, o + 512);
+}
+
+}  // namespace

@@ -890,6 +890,8 @@ def conv1x1(x, weight, bias=None):
     MI355X at the R50 / pixel-decoder shapes (tools/conv1x1_probe.py): 256->64 @184x320 1.10 -> 0.56 ms, 64->64
     0.55 -> 0.24 ms, 2048->256 0.32 -> 0.25 ms; channel-expanding ones are faster through MIOpen and stay there."""
     Co, Ci = weight.shape[:2]
+    if conv1x1_x3_ok(x, weight):
+        return conv1x1_x3(x, weight, bias)            # split-f16 matrix-core kernel (lateral / input / mask-feature projections)
     if bias is not None and CONV1X1_MFMA and x.is_cuda and x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32 \
             and weight.dtype == torch.float32 and not torch.is_grad_enabled() \
             and native.lib().dvis_conv1x1_mfma_supported(Ci, Co, x.shape[2] * x.shape[3]):
@@ -926,9 +928,47 @@ def conv1x1_bias_act(x, weight, bias=None, res=None, relu=False):
                     1 if relu else 0, native.stream_ptr(x.device))
             native.check(rc, "dvis_conv1x1_bias_act")
             return out
+        if conv1x1_x3_ok(x, weight, 1, res) and Ci >= 128:
+            return conv1x1_x3(x, weight, bias, res, relu)
         if CONV1X1_MFMA and native.lib().dvis_conv1x1_mfma_supported(Ci, Co, H * W) and (res is None or res.shape == (N, Co, H, W)):
             return conv1x1_mfma(x, weight, bias, res, relu)
     return bias_act_(conv1x1(x, weight), None if bias is None else bias.detach(), res, relu)
+
+
+def conv1x1_x3_ok(x, weight, stride=1, res=None):
+    """Does csrc/conv1x1_x3.hip (split-f16 matrix-core arithmetic, see csrc/gemm_x3.hip) serve this 1x1 convolution?"""
+    if not (X3 and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.is_contiguous()
+            and not torch.is_grad_enabled()):
+        return False
+    N, Ci, H, W = x.shape
+    Co = weight.shape[0]
+    OH, OW = (H + stride - 1) // stride, (W + stride - 1) // stride
+    if res is not None and not (res.is_contiguous() and res.dtype == torch.float32 and tuple(res.shape) == (N, Co, OH, OW)):
+        return False
+    return bool(native.lib().dvis_conv1x1_x3_supported(Ci, Co, N, H * W, OH * OW))
+
+
+def conv1x1_x3(x, weight, bias=None, res=None, relu=False, stride=1, xexp=None):
+    """relu?(conv1x1(x, weight)[:, :, ::stride, ::stride] + bias[c] + res) through dvis_conv1x1_x3."""
+    N, Ci, H, W = x.shape
+    Co = weight.shape[0]
+
+    def make():
+        w2 = weight.detach().reshape(Co, Ci).contiguous()
+        e = _x3_exp(w2)
+        buf = torch.empty(native.lib().dvis_conv1x1_x3_packed_bytes(Ci, Co), dtype=torch.uint8, device=w2.device)
+        with torch.cuda.device(w2.device):
+            native.check(native.lib().dvis_conv1x1_x3_pack(native.dev_ptr(w2, "weight"), Co, Ci, e, ctypes.c_void_p(buf.data_ptr()),
+                                                           native.stream_ptr(w2.device)), "dvis_conv1x1_x3_pack")
+        return buf, e
+    buf, wexp = _x3_cache(weight, ("c1", weight._version, weight.data_ptr(), weight.device), make)
+    out = torch.empty((N, Co, (H + stride - 1) // stride, (W + stride - 1) // stride), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        native.check(native.lib().dvis_conv1x1_x3(
+            native.dev_ptr(x, "x"), ctypes.c_void_p(buf.data_ptr()), None if bias is None else native.dev_ptr(bias.detach(), "bias"),
+            None if res is None else native.dev_ptr(res, "res"), native.dev_ptr(out, "out"), N, Ci, Co, H, W, stride,
+            X3_XEXP if xexp is None else xexp, wexp, 1 if relu else 0, native.stream_ptr(x.device)), "dvis_conv1x1_x3")
+    return out
 
 
 CONV1X1_MFMA = os.environ.get("DVIS_CONV1X1_MFMA", "1") != "0"

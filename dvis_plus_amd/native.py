@@ -84,6 +84,10 @@ SIGNATURES = {
     "dvis_x3_ffn_packed_bytes": (_i64, [_i, _i, _i]),
     "dvis_x3_ffn_pack": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _i, _i, _p, _p]),
     "dvis_x3_ffn_ln": (_i, [_p, _i64, _i64, _i, _i, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _f, _p, _i64, _p, _p, _i64, _p]),
+    "dvis_conv1x1_x3_supported": (_i, [_i, _i, _i64, _i64, _i64]),
+    "dvis_conv1x1_x3_packed_bytes": (_i64, [_i, _i]),
+    "dvis_conv1x1_x3_pack": (_i, [_p, _i, _i, _i, _p, _p]),
+    "dvis_conv1x1_x3": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dvis_gemm_num_configs": (_i, []),
     "dvis_gemm_pick_config": (_i, [_i, _i, _i, _i]),
 }

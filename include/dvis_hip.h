@@ -54,6 +54,7 @@
  *                               value_proj / sampling_offsets / attention_weights / output_proj
  *                               (ops/modules/ms_deform_attn.py:96-117), `norm1(src + src2)`, forward_ffn =
  *                               `norm2(src + linear2(relu(linear1(src))))` (mask2former/modeling/pixel_decoder/msdeformattn.py:103-131)
+ *   dvis_conv1x1_x3          <- the compute-bound 1x1 convolutions of the R50 bottlenecks (as dvis_conv1x1_mfma) in that arithmetic
  */
 #ifndef DVIS_HIP_H
 #define DVIS_HIP_H
@@ -476,6 +477,19 @@ int dvis_x3_linear_ln(const float *x, int64_t ldx, int64_t M, int K, const void 
  * (M x H) hidden tensor is never written.  Replaces forward_ffn, msdeformattn.py:116-120 (+ :130).
  * dvis_x3_ffn_pack interleaves W1 (H x K) and W2 (N x H) in the order the kernel streams them (W2's k in accumulator order). */
 int64_t dvis_x3_ffn_packed_bytes(int K, int H, int N);
+/*
+ * The compute-bound 1x1 convolutions of the R50 bottlenecks in the same arithmetic, on NCHW:
+ *   y (N, K, OH, OW) = relu?( w (K, C) x (N, C, H, W)[:, :, ::stride, ::stride] + bias[k] + res ),  stride 1 or 2,
+ * bias (K) / res (N, K, OH, OW) optional.  Replaces conv1 / conv3 / the stride-2 shortcut of detectron2's BottleneckBlock with
+ * the FrozenBN folded by the caller (`build_resnet_backbone`, configs/dvis_Plus/.../Base-*.yaml:2-16).
+ * C % 64 == 0, K = 64 / 128 or K % 256 == 0, every tensor below 2 GiB (dvis_conv1x1_x3_supported).  `packed`: dvis_conv1x1_x3_pack
+ * of the (K x C) weight, dvis_conv1x1_x3_packed_bytes(C, K) bytes.
+ */
+int dvis_conv1x1_x3_supported(int C, int K, int64_t N, int64_t HW_in, int64_t HW_out);
+int64_t dvis_conv1x1_x3_packed_bytes(int C, int K);
+int dvis_conv1x1_x3_pack(const float *w, int K, int C, int wexp, void *packed, void *stream);
+int dvis_conv1x1_x3(const float *x, const void *packed, const float *bias, const float *res, float *y, int N, int C, int K, int H,
+                    int W, int stride, int xexp, int wexp, int relu, void *stream);
 int dvis_x3_ffn_pack(const float *W1, int64_t ldw1, const float *W2, int64_t ldw2, int K, int H, int N, int w1exp, int w2exp,
                      void *packed, void *stream);
 int dvis_x3_ffn_ln(const float *x, int64_t ldx, int64_t M, int K, int H, int N, const void *packed, int xexp, int w1exp,

@@ -99,7 +99,7 @@ def test_resnet50_production_size_strict_own_kernels_vs_unfused_fp64():
     sd = {k: v.double() for k, v in m.state_dict().items()}
     lib = native.lib()
     names = ("dvis_conv3x3_winograd", "dvis_conv1x1_mfma", "dvis_conv1x1s2_mfma", "dvis_conv3x3s2", "dvis_conv7x7s2",
-             "dvis_conv1x1_bias_act", "dvis_bias_relu_maxpool")
+             "dvis_conv1x1_bias_act", "dvis_bias_relu_maxpool", "dvis_conv1x1_x3")
     calls = {n: 0 for n in names}
     orig = {n: getattr(lib, n) for n in names}
     lib_convs = []
@@ -125,8 +125,14 @@ def test_resnet50_production_size_strict_own_kernels_vs_unfused_fp64():
     assert not lib_convs, f"library convolutions ran at the production size: {lib_convs}"
     # 16 bottlenecks: 13 stride-1 3x3 (Winograd) + 3 stride-2 3x3; 4 shortcuts (1 stride-1, 3 stride-2); the stem
     assert calls["dvis_conv3x3_winograd"] == 13 and calls["dvis_conv3x3s2"] == 3 and calls["dvis_conv7x7s2"] == 1
-    assert calls["dvis_conv1x1s2_mfma"] == 3 and calls["dvis_bias_relu_maxpool"] == 1
-    assert calls["dvis_conv1x1_mfma"] > 0 and calls["dvis_conv1x1_mfma"] + calls["dvis_conv1x1_bias_act"] == 33, calls
+    assert calls["dvis_bias_relu_maxpool"] == 1
+    # the 1x1 layers: 16 x (conv1, conv3) + 4 shortcuts = 36; the compute-bound ones (>= 128 input channels where the
+    # memory-bound kernel does not serve the shape) and the three stride-2 shortcuts on the split-f16 matrix-core kernel
+    # (csrc/conv1x1_x3.hip; DVIS_X3=0: csrc/conv1x1_mfma.hip), the rest on the memory-bound kernel
+    from dvis_plus_amd import functions as Fn
+    mm = calls["dvis_conv1x1_x3"] if Fn.X3 else calls["dvis_conv1x1_mfma"] + calls["dvis_conv1x1s2_mfma"]
+    assert mm >= 20 and mm + calls["dvis_conv1x1_bias_act"] == 36, calls
+    assert calls["dvis_conv1x1_x3"] + calls["dvis_conv1x1_mfma"] + calls["dvis_conv1x1s2_mfma"] == mm, calls
     want = _resnet50_fp64(sd, x.double())
     for k, c, s in (("res2", 256, 4), ("res3", 512, 8), ("res4", 1024, 16), ("res5", 2048, 32)):
         assert got[k].shape == want[k].shape == (2, c, 736 // s, 1280 // s)

@@ -170,11 +170,12 @@ def test_encoder_layer_takes_the_split_kernels_and_matches_the_fp32_path():
     from dvis_plus_amd import functions as Fn, native
     from dvis_plus_amd.pixel_decoder import MSDeformAttnTransformerEncoderLayer, MSDeformAttnTransformerEncoder
     torch.manual_seed(0)
-    layer = MSDeformAttnTransformerEncoderLayer(256, 1024, 0.0, "relu", 3, 8, 4).to(DEV).eval()
+    layer = MSDeformAttnTransformerEncoderLayer(256, 1024, 0.0, "relu", 3, 8, 4)
     for p in layer.parameters():
         if p.dim() > 1:
             nn.init.xavier_uniform_(p)
     layer.self_attn._reset_parameters()
+    layer = layer.to(DEV).eval()
     with torch.no_grad():
         layer.self_attn.attention_weights.weight.normal_(0, 0.05)
         layer.self_attn.sampling_offsets.weight.normal_(0, 0.02)
@@ -202,3 +203,50 @@ def test_encoder_layer_takes_the_split_kernels_and_matches_the_fp32_path():
     finally:
         Fn.X3 = True
     assert float((out_x3 - out_f32).abs().max()) < 2e-5 and float((q_x3 - q_f32).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("Ci,Co,H,W,stride,N,res,relu", [
+    (512, 128, 23, 40, 1, 3, False, True),        # conv1 of a res3 block; 920 pixels per image: tiles straddle images
+    (128, 512, 46, 80, 1, 1, True, True),         # conv3 + shortcut + ReLU
+    (256, 1024, 12, 20, 1, 2, True, True),
+    (2048, 512, 23, 40, 1, 2, False, True),       # 32 chunks of 64 input channels
+    (512, 2048, 7, 9, 1, 3, True, False),         # 8 passes of 256 output channels, 63 pixels per image
+    (1024, 2048, 23, 41, 2, 2, False, False),     # the stride-2 shortcut, odd width
+    (256, 512, 45, 80, 2, 1, False, False),       # ... odd height
+    (64, 256, 20, 31, 1, 2, True, True),          # one chunk
+    (256, 64, 33, 47, 1, 2, False, True),         # 64 output channels (res2 conv1)
+])
+def test_conv1x1_x3(Ci, Co, H, W, stride, N, res, relu):
+    """csrc/conv1x1_x3.hip against fp64, next to the fp32 library convolution's error on the same operands."""
+    from dvis_plus_amd import functions as Fn
+    torch.manual_seed(Ci + Co + H)
+    x = torch.randn(N, Ci, H, W, device=DEV)
+    w = torch.randn(Co, Ci, 1, 1, device=DEV) * (2.0 / Ci) ** 0.5
+    b = torch.randn(Co, device=DEV)
+    OH, OW = (H + stride - 1) // stride, (W + stride - 1) // stride
+    r = torch.randn(N, Co, OH, OW, device=DEV) if res else None
+    assert Fn.conv1x1_x3_ok(x, w, stride, r)
+    xs = x[:, :, ::stride, ::stride]
+    ref = F.conv2d(xs.double(), w.double(), b.double()) + (r.double() if res else 0)
+    scale = F.conv2d(xs.double().abs(), w.double().abs(), b.double().abs()) + (r.double().abs() if res else 0)
+    lib = F.conv2d(xs.contiguous(), w, b) + (r if res else 0)
+    if relu:
+        ref, lib = ref.clamp_min(0), lib.clamp_min(0)
+    got = Fn.conv1x1_x3(x, w, b, r, relu, stride)
+    assert got.shape == ref.shape
+    e, e_lib = _rel(got, ref, scale), _rel(lib, ref, scale)
+    assert e <= max(1.25 * e_lib, 3e-7), (e, e_lib)
+    assert torch.equal(got, Fn.conv1x1_x3(x, w, b, r, relu, stride))
+
+
+def test_conv1x1_x3_layout_is_exact_on_integer_operands():
+    from dvis_plus_amd import functions as Fn
+    g = torch.Generator().manual_seed(9)
+    for Ci, Co, H, W, stride in ((192, 256, 9, 13, 1), (128, 128, 10, 7, 2), (320, 512, 5, 11, 1)):
+        x = torch.randint(-30, 31, (3, Ci, H, W), generator=g).float().to(DEV)
+        w = torch.randint(-3, 4, (Co, Ci, 1, 1), generator=g).float().to(DEV)
+        b = torch.randint(-50, 50, (Co,), generator=g).float().to(DEV)
+        OH, OW = (H + stride - 1) // stride, (W + stride - 1) // stride
+        r = torch.randint(-99, 99, (3, Co, OH, OW), generator=g).float().to(DEV)
+        ref = (F.conv2d(x[:, :, ::stride, ::stride].double(), w.double(), b.double()) + r.double()).float()
+        assert torch.equal(Fn.conv1x1_x3(x, w, b, r, False, stride), ref)

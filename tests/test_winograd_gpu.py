@@ -196,8 +196,15 @@ def test_conv1x1_mfma_equals_fp64(N, C, K, H, W, bias, res, relu):
     # the dispatcher picks it for these shapes (conv1x1.hip does not serve them), and refuses what it cannot do
     from dvis_plus_amd import native
     assert native.lib().dvis_conv1x1_mfma_supported(C, K, H * W) and not native.lib().dvis_conv1x1_mfma_supported(64, 64, H * W)
+    x3 = Fn.X3
     with torch.no_grad():
-        assert torch.equal(Fn.conv1x1_bias_act(x, w, b, r, relu), got) or native.lib().dvis_conv1x1_supported(C, K, H * W)
+        Fn.X3 = False                     # the exact-fp32 dispatch
+        try:
+            assert torch.equal(Fn.conv1x1_bias_act(x, w, b, r, relu), got) or native.lib().dvis_conv1x1_supported(C, K, H * W)
+        finally:
+            Fn.X3 = x3
+        if x3:                            # the default dispatch (split-f16 matrix-core kernel where it serves the shape): same bound
+            assert float((Fn.conv1x1_bias_act(x, w, b, r, relu).double() - want).abs().max()) <= 4 * 2.0 ** -24 * mag
 
 
 @pytest.mark.parametrize("N,C,K,H,W", [(2, 256, 512, 46, 80), (3, 128, 64, 17, 22), (1, 1024, 2048, 46, 80)])

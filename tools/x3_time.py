@@ -108,5 +108,31 @@ def main():
         print(f"  M = {m}: FFN max abs diff vs torch fp32 {float((o - r).abs().max()):.2e}")
 
 
+def conv_main():
+    """the R50's compute-bound 1x1 layers at 30 frames of 736 x 1280: csrc/conv1x1_x3.hip vs csrc/conv1x1_mfma.hip (exact fp32)"""
+    shapes = [(512, 128, 92, 160, 1), (128, 512, 92, 160, 1), (256, 512, 184, 320, 2), (1024, 256, 46, 80, 1), (256, 1024, 46, 80, 1),
+              (512, 1024, 92, 160, 2), (2048, 512, 23, 40, 1), (512, 2048, 23, 40, 1), (1024, 2048, 46, 80, 2), (512, 256, 92, 160, 1),
+              (1024, 512, 46, 80, 1)]
+    for Ci, Co, H, W, stride in shapes:
+        x = torch.randn(30, Ci, H, W, device=DEV)
+        w = torch.randn(Co, Ci, 1, 1, device=DEV) * (2.0 / Ci) ** 0.5
+        b = torch.randn(Co, device=DEV)
+        OH, OW = (H + stride - 1) // stride, (W + stride - 1) // stride
+        r = torch.randn(30, Co, OH, OW, device=DEV) if stride == 1 and Co > Ci else None
+        if not Fn.conv1x1_x3_ok(x, w, stride, r):
+            print(f"  conv {Ci} -> {Co} {H}x{W} s{stride}: not served")
+            continue
+        t = timeit(lambda: Fn.conv1x1_x3(x, w, b, r, True, stride))
+        tm = timeit(lambda: Fn.conv1x1_mfma(x, w, b, r, True, stride)) if Ci % 128 == 0 else float("nan")
+        fl = 2.0 * 30 * OH * OW * Ci * Co
+        gb = 4.0 * 30 * (OH * OW * (Ci + Co * (2 if r is not None else 1)))
+        print(f"  conv {Ci:4d} -> {Co:4d} {H}x{W} s{stride} res={int(r is not None)}: x3 {t:.3f} ms ({fl / t / 1e9:.0f} TF fp32-eq, {gb / t / 1e6:.0f} GB/s)"
+              f"   exact-fp32 MFMA kernel {tm:.3f} ms ({fl / tm / 1e9:.0f} TF)")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "conv":
+        with torch.no_grad():
+            conv_main()
+        sys.exit(0)
     main()
