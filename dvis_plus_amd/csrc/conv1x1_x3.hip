@@ -27,7 +27,7 @@ struct CxArgs {
   int N, C, K, relu, npass;
   int stride, W_in, OW;
   long long HW, HW_in, pixels;             // output pixels per image, input pixels per image, output pixels in total
-  long long tiles;                         // ceil(pixels / 128)
+  long long tiles;                         // ceil(pixels / (32 NW))
   float xscale, inv;
 };
 
@@ -53,8 +53,10 @@ __device__ __forceinline__ unsigned cx_pixel_offset(const CxArgs &a, long long p
   return (unsigned)((n * a.C * a.HW_in + pix) * 4);
 }
 
-template <int NB>
-__global__ __launch_bounds__(kThreads) void conv1x1_x3_kernel(const CxArgs a) {
+template <int NB, int NW>      // NW waves x 32 pixels per tile; 8 waves = two per SIMD (<= 256 registers each) cover each other's stalls
+__global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
+  constexpr int kTile = NW * 32, PW = 4 * NB / NW;
+  static_assert(4 * NB % NW == 0, "the item's pieces must divide among the waves");
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
   const int NI = a.C / 32, NC = a.C / 64;                     // ring items / activation chunks per work item
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(kThreads) void conv1x1_x3_kernel(const CxArgs a) {
   const __amdgpu_buffer_rsrc_t rr = dvis_make_rsrc_uniform(a.res ? a.res : a.y, (unsigned)((long long)a.N * a.K * a.HW * 4));
   const unsigned chan = (unsigned)(a.HW_in * 4);              // bytes between two input channels of a pixel
 
-  typedef Ring<NB, 32> RingT;
+  typedef Ring<PW, 32, NW> RingT;
   RingT ring;
   // issue cursor: where the next item to request lives
   long long iw = 0;
@@ -109,21 +111,20 @@ __global__ __launch_bounds__(kThreads) void conv1x1_x3_kernel(const CxArgs a) {
   long long tile;
   int pass;
   cx_item(a, 0, &tile, &pass);
-  unsigned pixoff = cx_pixel_offset(a, tile * kTileTok + wave * 32 + j);
+  unsigned pixoff = cx_pixel_offset(a, tile * kTile + wave * 32 + j);
   load_raw(pixoff, 0);
   for (long long w = 0; w < wcount; ++w) {
-    const long long p = tile * kTileTok + wave * 32 + j;
+    const long long p = tile * kTile + wave * 32 + j;
     // the next work item (its first chunk is requested while this one's last chunk is multiplied)
     long long ntile = tile;
     int npass_ = pass;
     const bool more = cx_item(a, w + 1, &ntile, &npass_);
-    const unsigned npixoff = more ? cx_pixel_offset(a, ntile * kTileTok + wave * 32 + j) : kOOB;
+    const unsigned npixoff = more ? cx_pixel_offset(a, ntile * kTile + wave * 32 + j) : kOOB;
     f16v acc[NB];
-    f16v resv[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f, resv[nb][i] = 0.f;
+      for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
     const long long n = p / a.HW;
     const unsigned obase = p < a.pixels ? (unsigned)((n * a.K * a.HW + (p - n * a.HW)) * 4) : kOOB;
     const unsigned ochan = (unsigned)(a.HW * 4);
@@ -146,22 +147,18 @@ __global__ __launch_bounds__(kThreads) void conv1x1_x3_kernel(const CxArgs a) {
       for (int half = 0; half < 2; ++half) {
         const char *stage = ring.wait(false);
         ring.begin(ring.it + 1 < ring.total ? next_offset() : 0);
-        if (half == 1 && kc + 1 == NC && a.res) {
-          // the shortcut's values for the epilogue: requested before the item's products (their latency would otherwise be
-          // paid 16 NB times in a row)
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              resv[nb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                          rr, obase + (unsigned)(co0 + 32 * nb + 8 * (r >> 2) + 4 * g + (r & 3)) * ochan, 0, 0));
-        }
-        mma_item<2, NB, NB>(stage, lane, acc, xh + 2 * half, xl + 2 * half, [&](int i) { ring.piece(i); });
+        mma_item<2, NB, PW>(stage, lane, acc, xh + 2 * half, xl + 2 * half, [&](int i) { ring.piece(i); });
       }
     }
     // epilogue: lane = pixel; registers = channels co0 + 32 nb + 8 q + 4 g + i
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+    for (int nb = 0; nb < NB; ++nb) {
+      float rv[16];                    // the shortcut's 16 values of the block as one batch of requests
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        rv[r] = a.res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                      rr, obase + (unsigned)(co0 + 32 * nb + 8 * (r >> 2) + 4 * g + (r & 3)) * ochan, 0, 0))
+                      : 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int co = co0 + 32 * nb + 8 * q + 4 * g;
@@ -170,11 +167,12 @@ __global__ __launch_bounds__(kThreads) void conv1x1_x3_kernel(const CxArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const unsigned o = obase + (unsigned)(co + i) * ochan;
-          float v = acc[nb][4 * q + i] * a.inv + b[i] + resv[nb][4 * q + i];
+          float v = acc[nb][4 * q + i] * a.inv + b[i] + rv[4 * q + i];
           if (a.relu) v = fmaxf(v, 0.f);
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, o, 0, 0);
         }
       }
+    }
     tile = ntile, pass = npass_, pixoff = npixoff;
   }
 }
@@ -218,7 +216,6 @@ DVIS_EXPORT int dvis_conv1x1_x3(const float *x, const void *packed, const float 
   CxArgs a = {};
   a.x = x, a.bias = bias, a.res = res, a.wp = packed, a.y = y, a.N = N, a.C = C, a.K = K, a.relu = relu;
   a.stride = stride, a.W_in = W, a.OW = OW, a.HW = (long long)OH * OW, a.HW_in = (long long)H * W, a.pixels = a.HW * N;
-  a.tiles = (a.pixels + kTileTok - 1) / kTileTok;
   a.xscale = ldexpf(1.f, xexp), a.inv = ldexpf(1.f, -(xexp + wexp));
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
@@ -227,24 +224,25 @@ DVIS_EXPORT int dvis_conv1x1_x3(const float *x, const void *packed, const float 
   }
   const int grid = cus / 8 * 8;
   hipStream_t st = (hipStream_t)stream;
-  if (K == 64) {
-    a.npass = 1;
-    const size_t lds = kStages * Ring<2, 32>::kItemBytes;
-    hipLaunchKernelGGL(conv1x1_x3_kernel<2>, dim3(grid), dim3(kThreads), lds, st, a);
-  } else if (K == 128) {
-    a.npass = 1;
-    static DvisLdsOptIn opted;
-    const size_t lds = kStages * Ring<4, 32>::kItemBytes;
-    const int rc = dvis_lds_opt_in((const void *)conv1x1_x3_kernel<4>, lds, &opted, "dvis_conv1x1_x3");
-    if (rc != DVIS_OK) return rc;
-    hipLaunchKernelGGL(conv1x1_x3_kernel<4>, dim3(grid), dim3(kThreads), lds, st, a);
-  } else {
-    a.npass = K / 256;
-    static DvisLdsOptIn opted;
-    const size_t lds = kStages * Ring<8, 32>::kItemBytes;
-    const int rc = dvis_lds_opt_in((const void *)conv1x1_x3_kernel<8>, lds, &opted, "dvis_conv1x1_x3");
-    if (rc != DVIS_OK) return rc;
-    hipLaunchKernelGGL(conv1x1_x3_kernel<8>, dim3(grid), dim3(kThreads), lds, st, a);
+  static const int nw = getenv("DVIS_X3_CONV_WAVES") ? atoi(getenv("DVIS_X3_CONV_WAVES")) : 8;
+  a.npass = K <= 128 ? 1 : K / 256;
+#define DVIS_CX_LAUNCH(NBV, NWV)                                                                                   \
+  {                                                                                                                \
+    static DvisLdsOptIn opted;                                                                                     \
+    typedef Ring<4 * NBV / NWV, 32, NWV> R;                                                                        \
+    a.tiles = (a.pixels + 32 * NWV - 1) / (32 * NWV);                                                              \
+    const size_t lds = kStages * R::kItemBytes;                                                                    \
+    const int rc = dvis_lds_opt_in((const void *)conv1x1_x3_kernel<NBV, NWV>, lds, &opted, "dvis_conv1x1_x3");     \
+    if (rc != DVIS_OK) return rc;                                                                                  \
+    hipLaunchKernelGGL((conv1x1_x3_kernel<NBV, NWV>), dim3(grid), dim3(NWV * 64), lds, st, a);                     \
   }
+  if (K == 64) {
+    if (nw == 8) DVIS_CX_LAUNCH(2, 8) else DVIS_CX_LAUNCH(2, 4)
+  } else if (K == 128) {
+    if (nw == 8) DVIS_CX_LAUNCH(4, 8) else DVIS_CX_LAUNCH(4, 4)
+  } else {
+    if (nw == 8) DVIS_CX_LAUNCH(8, 8) else DVIS_CX_LAUNCH(8, 4)
+  }
+#undef DVIS_CX_LAUNCH
   return dvis_check_launch("dvis_conv1x1_x3");
 }

@@ -85,35 +85,28 @@ __device__ __forceinline__ void epilogue(f16v *acc, const EpiArgs &e, const floa
   const int rows_valid = M - tok0 < 32 ? (int)(M - tok0) : 32;
   constexpr int N = 32 * NB;
   float mean = 0.f, rstd = 1.f;
-  // residual rows in batches of 2 blocks (8 x 16 bytes per lane), the next batch in flight while one is consumed: the VALU
-  // sees only 256 of the 512 registers, so the whole row (128 values) next to the 128 accumulator values does not fit
-  constexpr int NBT = (NB + 1) / 2;
+  // residual rows one block (4 x 16 bytes per lane) at a time, the next block in flight while one is consumed: the VALU sees
+  // only 256 registers, so a whole row (128 values) next to the 128 accumulator values does not fit
   if constexpr (LN) {
     const float *rp = e.res + tok * e.ldres + 4 * g;
-    f4 r[2][8];
-    auto fetch = [&](int bt, f4 *dst) {
+    f4 r[2][4];
+    auto fetch = [&](int nb, f4 *dst) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int nb = 2 * bt + (u >> 2);
-        if (nb < NB) dst[u] = *(const f4 *)(rp + 32 * nb + 8 * (u & 3));
-      }
+      for (int q = 0; q < 4; ++q) dst[q] = *(const f4 *)(rp + 32 * nb + 8 * q);
     };
     fetch(0, r[0]);
     float sum = 0.f;
 #pragma unroll
-    for (int bt = 0; bt < NBT; ++bt) {
-      if (bt + 1 < NBT) fetch(bt + 1, r[(bt + 1) & 1]);
+    for (int nb = 0; nb < NB; ++nb) {
+      if (nb + 1 < NB) fetch(nb + 1, r[(nb + 1) & 1]);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int nb = 2 * bt + (u >> 2), q = u & 3;
-        if (nb < NB) {
-          const f4 b = *(const f4 *)(cb + 32 * nb + 8 * q + 4 * g);
+      for (int q = 0; q < 4; ++q) {
+        const f4 b = *(const f4 *)(cb + 32 * nb + 8 * q + 4 * g);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float v = acc[nb][4 * q + i] * e.inv + b[i] + r[bt & 1][u][i];
-            acc[nb][4 * q + i] = v;
-            sum += v;
-          }
+        for (int i = 0; i < 4; ++i) {
+          const float v = acc[nb][4 * q + i] * e.inv + b[i] + r[nb & 1][q][i];
+          acc[nb][4 * q + i] = v;
+          sum += v;
         }
       }
     }
@@ -215,6 +208,77 @@ __global__ __launch_bounds__(kThreads) void x3_linear_kernel(const float *__rest
       }
       if (tok0 < M) epilogue<NB, LN>(acc, e, cst + pass * 32 * NB, cst + ntot, cst + ntot + 32 * NB, scr, lane, tok0, M, pass * 32 * NB);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same projection with the activations STREAMED: 8 waves (two per SIMD, <= 256 registers each: one wave's barrier,
+// LDS-DMA issue and epilogue are covered by its partner's products) x 32 tokens; the 64 k-values of the chunk after the one
+// being multiplied are in flight (8 x 16 bytes per lane; the ring's counted wait leaves them out), so neither operand waits
+// behind the other and K is any multiple of 64.  Passes of 32 NB output features re-read the tile's rows from L2.
+template <int NB, bool LN>
+__global__ __launch_bounds__(512) void x3_linear_stream_kernel(const float *__restrict__ x, int64_t ldx, int64_t M, int K,
+                                                               const void *__restrict__ wp, float xscale, int npass, EpiArgs e) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  constexpr int NW = 8, PW = 4 * NB / NW, kTile = NW * 32;
+  static_assert(4 * NB % NW == 0, "the item's pieces must divide among the waves");
+  typedef Ring<PW, 8, NW> RingT;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
+  const int NI = K / 32, NC = K / 64;
+  const int64_t ntiles = (M + kTile - 1) / kTile;
+  const int64_t my = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  if (my == 0) return;
+  RingT ring;
+  ring.start(wp, lds, NI * npass, (int)(my * NI * npass), wave, lane);
+  char *scr = lds + kStages * RingT::kItemBytes + wave * kScratch;
+  float *cst = (float *)(lds + kStages * RingT::kItemBytes + NW * kScratch);
+  const int ntot = 32 * NB * npass;
+  for (int i = threadIdx.x; i < ntot; i += 512) cst[i] = e.bias[i];
+  if constexpr (LN)
+    for (int i = threadIdx.x; i < 32 * NB; i += 512) cst[ntot + i] = e.gamma[i], cst[ntot + 32 * NB + i] = e.beta[i];
+  __syncthreads();
+  f4 raw[8];
+  auto load_raw = [&](const float *rowp, int kc) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) raw[2 * s] = *(const f4 *)(rowp + 64 * kc + 16 * s), raw[2 * s + 1] = *(const f4 *)(rowp + 64 * kc + 16 * s + 4);
+  };
+  auto row_ptr = [&](int64_t tile) {
+    const int64_t t = tile * kTile + wave * 32 + j;
+    return x + (t < M ? t : M - 1) * ldx + 8 * g;
+  };
+  const float *rowp = row_ptr(blockIdx.x);
+  load_raw(rowp, 0);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t tok0 = tile * kTile + wave * 32;
+    const float *nrowp = row_ptr(tile + gridDim.x < ntiles ? tile + gridDim.x : tile);
+    for (int pass = 0; pass < npass; ++pass) {
+      f16v acc[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+      for (int kc = 0; kc < NC; ++kc) {
+        // the chunk's values are taken HERE (see csrc/conv1x1_x3.hip)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(raw[i]));
+        h8 xh[4], xl[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) split8(raw[2 * s], raw[2 * s + 1], xscale, xh[s], xl[s]);
+        // ALWAYS 8 loads here: the next chunk, the next pass's first, the next tile's first
+        if (kc + 1 < NC)
+          load_raw(rowp, kc + 1);
+        else
+          load_raw(pass + 1 < npass ? rowp : nrowp, 0);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const char *stage = ring.wait(false);
+          ring.begin_periodic();
+          mma_item<2, NB, PW>(stage, lane, acc, xh + 2 * half, xl + 2 * half, [&](int i) { ring.piece(i); });
+        }
+      }
+      if (tok0 < M) epilogue<NB, LN>(acc, e, cst + pass * 32 * NB, cst + ntot, cst + ntot + 32 * NB, scr, lane, tok0, M, pass * 32 * NB);
+    }
+    rowp = nrowp;
   }
 }
 
@@ -354,8 +418,9 @@ static int x3_passes(int N, int *nb) {
 
 DVIS_EXPORT int dvis_x3_linear_supported(int N, int K, int ln) {
   int nb;
-  if (K != 256) return 0;
+  if (K < 64 || K % 64 != 0 || K > 8192) return 0;
   if (ln) return N == 256;
+  if (N == 288) return K == 256;            // (9 blocks of 32 do not divide among the streaming kernel's 8 waves)
   return x3_passes(N, &nb) > 0;
 }
 
@@ -366,7 +431,7 @@ DVIS_EXPORT int64_t dvis_x3_packed_bytes(int N, int K) {
 
 DVIS_EXPORT int dvis_x3_pack(const float *w, int64_t ldw, int N, int K, int wexp, void *packed, void *stream) {
   DVIS_REQUIRE(w && packed, "dvis_x3_pack: null operand");
-  DVIS_REQUIRE(dvis_x3_linear_supported(N, K, 0), "dvis_x3_pack: (N, K) = (%d, %d) is not served (K = 256; N in 128 / 192 / 256 / 288 or N %% 256 == 0)", N, K);
+  DVIS_REQUIRE(dvis_x3_linear_supported(N, K, 0), "dvis_x3_pack: (N, K) = (%d, %d) is not served (K %% 64 == 0; N in 128 / 192 / 256 or N %% 256 == 0; N = 288 at K = 256)", N, K);
   DVIS_REQUIRE(wexp >= -60 && wexp <= 60, "dvis_x3_pack: wexp = %d", wexp);
   int NB;
   x3_passes(N, &NB);
@@ -378,7 +443,7 @@ DVIS_EXPORT int dvis_x3_pack(const float *w, int64_t ldw, int N, int K, int wexp
 
 DVIS_EXPORT int dvis_x3_linear(const float *x, int64_t ldx, int64_t M, int K, const void *wp, int N, int xexp, int wexp,
                                const float *bias, int relu, float *out, int64_t ldo, void *stream) {
-  DVIS_REQUIRE(dvis_x3_linear_supported(N, K, 0), "dvis_x3_linear: (N, K) = (%d, %d) is not served (K = 256; N in 128 / 192 / 256 / 288 or N %% 256 == 0)", N, K);
+  DVIS_REQUIRE(dvis_x3_linear_supported(N, K, 0), "dvis_x3_linear: (N, K) = (%d, %d) is not served (K %% 64 == 0; N in 128 / 192 / 256 or N %% 256 == 0; N = 288 at K = 256)", N, K);
   DVIS_REQUIRE(bias, "dvis_x3_linear: bias is required");
   const int rc = x3_check_common(x, ldx, M, wp, out, ldo);
   if (rc != DVIS_OK) return rc;
@@ -389,20 +454,28 @@ DVIS_EXPORT int dvis_x3_linear(const float *x, int64_t ldx, int64_t M, int K, co
   hipStream_t st = (hipStream_t)stream;
   int NB;
   const int npass = x3_passes(N, &NB);
-#define DVIS_X3_LINEAR(NBV)                                                                                          \
+#define DVIS_X3_STREAM(NBV, LNV, WHAT, LDS_EXTRA)                                                                   \
   {                                                                                                                  \
     static DvisLdsOptIn opted;                                                                                       \
-    return x3_launch(x3_linear_kernel<256, NBV, false>, &opted,                                                      \
-                     kStages * Ring<NBV>::kItemBytes + kWaves * kScratch + (size_t)N * 4, M, st, "dvis_x3_linear", x, ldx, M, wp, \
-                     xs, npass, e);                                                                                  \
+    typedef Ring<4 * NBV / 8, 8, 8> R;                                                                               \
+    const size_t lds_bytes = kStages * R::kItemBytes + 8 * kScratch + (LDS_EXTRA);                                   \
+    const int rc2 = dvis_lds_opt_in((const void *)x3_linear_stream_kernel<NBV, LNV>, lds_bytes, &opted, WHAT);       \
+    if (rc2 != DVIS_OK) return rc2;                                                                                  \
+    const int64_t ntiles = (M + 255) / 256;                                                                          \
+    hipLaunchKernelGGL((x3_linear_stream_kernel<NBV, LNV>), dim3(x3_grid(ntiles)), dim3(512), lds_bytes, st, x, ldx, M, K, wp, xs, \
+                       npass, e);                                                                                    \
+    return dvis_check_launch(WHAT);                                                                                  \
   }
   switch (NB) {
-    case 4: DVIS_X3_LINEAR(4)
-    case 6: DVIS_X3_LINEAR(6)
-    case 8: DVIS_X3_LINEAR(8)
-    default: DVIS_X3_LINEAR(9)
+    case 4: DVIS_X3_STREAM(4, false, "dvis_x3_linear", (size_t)N * 4)
+    case 6: DVIS_X3_STREAM(6, false, "dvis_x3_linear", (size_t)N * 4)
+    case 8: DVIS_X3_STREAM(8, false, "dvis_x3_linear", (size_t)N * 4)
+    default: {
+      static DvisLdsOptIn opted;
+      return x3_launch(x3_linear_kernel<256, 9, false>, &opted, kStages * Ring<9>::kItemBytes + kWaves * kScratch + (size_t)N * 4, M, st,
+                       "dvis_x3_linear", x, ldx, M, wp, xs, npass, e);
+    }
   }
-#undef DVIS_X3_LINEAR
 }
 
 DVIS_EXPORT int dvis_x3_linear_ln(const float *x, int64_t ldx, int64_t M, int K, const void *wp, int N, int xexp, int wexp,
@@ -420,9 +493,11 @@ DVIS_EXPORT int dvis_x3_linear_ln(const float *x, int64_t ldx, int64_t M, int K,
   EpiArgs e = {};
   e.bias = bias, e.res = res, e.ldres = ldres, e.gamma = gamma, e.beta = beta, e.eps = eps, e.pos = pos, e.pos_rows = pos_rows;
   e.out = out, e.out2 = out2, e.ldo = ldo, e.inv = x3_pow2(-(xexp + wexp));
-  static DvisLdsOptIn opted;
-  return x3_launch(x3_linear_kernel<256, 8, true>, &opted, kStages * Ring<8>::kItemBytes + kWaves * kScratch + 3 * 256 * 4, M,
-                   (hipStream_t)stream, "dvis_x3_linear_ln", x, ldx, M, wp, x3_pow2(xexp), 1, e);
+  const float xs = x3_pow2(xexp);
+  const int npass = 1;
+  hipStream_t st = (hipStream_t)stream;
+  DVIS_X3_STREAM(8, true, "dvis_x3_linear_ln", (size_t)3 * 256 * 4)
+#undef DVIS_X3_STREAM
 }
 
 DVIS_EXPORT int64_t dvis_x3_ffn_packed_bytes(int K, int H, int N) {

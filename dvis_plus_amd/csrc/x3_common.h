@@ -70,19 +70,19 @@ __device__ __forceinline__ void mma_item(const char *stage, int lane, f16v *acc,
 
 // EXTRA: ordinary loads the kernel keeps in flight, issued between an item's pieces and the next-but-one item's (the
 // activation prefetch of csrc/conv1x1_x3.hip): they are newer than the item waited for, so the counted wait leaves them out too.
-template <int PW, int EXTRA = 0>      // PW: 1 KB pieces per wave and item (item bytes = 4 * PW * 1024)
+template <int PW, int EXTRA = 0, int NW = kWaves>      // PW: 1 KB pieces per wave and item (item bytes = NW * PW * 1024)
 struct Ring {
   const char *src;
   char *lds;
   int period, total, it, st_cmp, st_iss, wave, lane;
-  static constexpr int kItemBytes = kWaves * PW * kPiece;
+  static constexpr int kItemBytes = NW * PW * kPiece;
 
   __device__ __forceinline__ void issue(int item) { issue_at((size_t)(item % period) * kItemBytes); }
   __device__ __forceinline__ void issue_at(size_t byte_offset) {
     const char *g = src + byte_offset + lane * 16;
     char *l = lds + st_iss * kItemBytes;
 #pragma unroll
-    for (int p = 0; p < PW; ++p) glds16(g + (wave + kWaves * p) * kPiece, l + (wave + kWaves * p) * kPiece);
+    for (int p = 0; p < PW; ++p) glds16(g + (wave + NW * p) * kPiece, l + (wave + NW * p) * kPiece);
     st_iss = st_iss + 1 == kStages ? 0 : st_iss + 1;
   }
   __device__ __forceinline__ void start(const void *stream, char *ring, int period_, int total_, int wave_, int lane_) {
@@ -130,7 +130,7 @@ struct Ring {
   }
   __device__ __forceinline__ void begin_periodic() { begin((size_t)((it + 1) % period) * kItemBytes); }
   __device__ __forceinline__ void piece(int i) {
-    if (dma_on) glds16(dma_src + i * (kWaves * kPiece), dma_dst + i * (kWaves * kPiece));
+    if (dma_on) glds16(dma_src + i * (NW * kPiece), dma_dst + i * (NW * kPiece));
   }
   // the same with the caller naming where item it + 2 lives in the packed stream (a sequence that is not periodic)
   __device__ __forceinline__ const char *acquire_at(bool drain, size_t next2_byte_offset) {

@@ -250,3 +250,18 @@ def test_conv1x1_x3_layout_is_exact_on_integer_operands():
         r = torch.randint(-99, 99, (3, Co, OH, OW), generator=g).float().to(DEV)
         ref = (F.conv2d(x[:, :, ::stride, ::stride].double(), w.double(), b.double()) + r.double()).float()
         assert torch.equal(Fn.conv1x1_x3(x, w, b, r, False, stride), ref)
+
+
+@pytest.mark.parametrize("K,N,M", [(64, 128, 300), (512, 256, 1000), (1024, 512, 777), (192, 192, 4097)])
+def test_linear_streams_any_k(K, N, M):
+    """The streaming projection kernel takes K in chunks of 64: any multiple (the ViT-Adapter's 1024-wide layers included)."""
+    from dvis_plus_amd import functions as Fn
+    lin = _lin(K, N, K + N)
+    x = torch.randn(M, K, device=DEV)
+    assert Fn.x3_ok(x, N, K)
+    ref = x.double() @ lin.weight.double().t() + lin.bias.double()
+    scale = x.double().abs() @ lin.weight.double().abs().t() + lin.bias.double().abs()
+    e_lib = _rel(F.linear(x, lin.weight, lin.bias), ref, scale)
+    got = Fn.x3_linear(x, lin.weight, lin.bias)
+    assert _rel(got, ref, scale) <= max(1.25 * e_lib, 3e-7)
+    assert torch.equal(got, Fn.x3_linear(x, lin.weight, lin.bias))
