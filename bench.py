@@ -123,18 +123,21 @@ class MsdaTimer:
 
 
 class ConvTimer:
-    """Times every launch of the own 3x3 convolution (csrc/winograd_conv.hip) in the timed region the same way — the largest
-    MFMA-bound own kernel of a clip (the FPN output convolution and the R50 conv2 layers)."""
+    """Times every launch of the own 3x3 convolution in the timed region the same way — the largest convolution kernel of a clip
+    (the FPN output convolution and the R50 conv2 layers): csrc/conv1x1_x3.hip's nine-tap form (split-f16 matrix-core
+    arithmetic), or with DVIS_X3=0 the exact-fp32 Winograd kernel (csrc/winograd_conv.hip)."""
 
     def __init__(self):
-        from dvis_plus_amd import native
-        self.native, self.events = native, []
+        from dvis_plus_amd import native, functions
+        self.native, self.events, self.x3 = native, [], functions.X3
 
     def __enter__(self):
         lib = self.native.lib()
-        self.lib, self.orig = lib, lib.dvis_conv3x3_winograd
+        self.lib = lib
+        self.name = "dvis_conv3x3_x3" if self.x3 else "dvis_conv3x3_winograd"
+        self.orig = getattr(lib, self.name)
 
-        def timed(x, uf, bias, y, N, C, K, H, W, relu, stream):
+        def timed_w(x, uf, bias, y, N, C, K, H, W, relu, stream):
             st = torch.cuda.current_stream()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(st)
@@ -142,11 +145,20 @@ class ConvTimer:
             e1.record(st)
             self.events.append((e0, e1, 2.0 * 9 * N * C * K * H * W))      # direct-convolution FLOPs of the launch
             return rc
-        lib.dvis_conv3x3_winograd = timed
+
+        def timed_x(x, packed, bias, res, y, N, C, K, H, W, stride, *rest):
+            st = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            rc = self.orig(x, packed, bias, res, y, N, C, K, H, W, stride, *rest)
+            e1.record(st)
+            self.events.append((e0, e1, 2.0 * 9 * N * C * K * ((H + stride - 1) // stride) * ((W + stride - 1) // stride)))
+            return rc
+        setattr(lib, self.name, timed_x if self.x3 else timed_w)
         return self
 
     def __exit__(self, *exc):
-        self.lib.dvis_conv3x3_winograd = self.orig
+        setattr(self.lib, self.name, self.orig)
 
     def summary(self):
         torch.cuda.synchronize()
@@ -579,7 +591,18 @@ def main():
                 break
         csec, cflops, claunch = timer.conv.summary()
         conv_roof = None
-        if claunch:
+        if claunch and timer.conv.x3:
+            # nine taps, 3 f16 matrix-core products per fp32 product
+            tf16 = 3.0 * cflops / csec / 1e12
+            conv_roof = {"bound": "mfma", "kernel": "conv3x3_x3 (3x3 convolutions from 128 channels on: FPN output conv + R50 conv2, nine-tap "
+                                                    "split-f16 kernel)",
+                         "achieved": round(tf16, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf16 / MFMA_F16_PEAK_TF, 4),
+                         "fp32_equivalent_tflops": round(cflops / csec / 1e12, 1), "launches_timed": claunch,
+                         "ms_per_clip": round(csec / args.steps * 1e3, 2), "traffic": None,
+                         "note": "f16 matrix-core flops issued = 3 x 2*9*N*C*K*OH*OW per launch, summed over the timed launches / their "
+                                 "summed HIP-event durations (the exact-fp32 Winograd kernel it replaces ran these layers at 216 - 264 "
+                                 "TF direct-equivalent)"}
+        elif claunch:
             # the kernel's own arithmetic: F(2x2, 3x3) does 4 multiply-adds per output where the direct form does 9
             tf = cflops / 2.25 / csec / 1e12
             conv_roof = {"bound": "mfma", "kernel": "winograd_f2x3 (3x3 convolutions: FPN output conv + R50 conv2)",

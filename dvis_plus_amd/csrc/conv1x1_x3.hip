@@ -25,7 +25,8 @@ struct CxArgs {
   const void *wp;
   float *y;
   int N, C, K, relu, npass;
-  int stride, W_in, OW;
+  int stride, W_in, OW, H_in;
+  int taps;                                // 1: 1x1; 9: 3x3 with padding 1 (k = tap * C + channel, tap = 3 dy + dx)
   long long HW, HW_in, pixels;             // output pixels per image, input pixels per image, output pixels in total
   long long tiles;                         // ceil(pixels / (32 NW))
   float xscale, inv;
@@ -42,15 +43,27 @@ __device__ __forceinline__ bool cx_item(const CxArgs &a, long long w, long long 
   return *tile < a.tiles;
 }
 
-__device__ __forceinline__ unsigned cx_pixel_offset(const CxArgs &a, long long p) {      // byte offset of channel 0 of output pixel p's input
-  if (p >= a.pixels) return kOOB;
+// where output pixel p reads: image base (bytes), its top-left input coordinate (before the tap is added)
+struct CxGeom {
+  unsigned base;      // byte offset of channel 0 of image n; kOOB for a pixel past the end
+  int iy, ix;         // oy * stride - pad, ox * stride - pad
+};
+__device__ __forceinline__ CxGeom cx_geom(const CxArgs &a, long long p) {
+  CxGeom gm = {kOOB, 0, 0};
+  if (p >= a.pixels) return gm;
   const long long n = p / a.HW;
-  long long pix = p - n * a.HW;
-  if (a.stride == 2) {
-    const int oy = (int)(pix / a.OW), ox = (int)(pix - (long long)oy * a.OW);
-    pix = 2ll * oy * a.W_in + 2 * ox;
-  }
-  return (unsigned)((n * a.C * a.HW_in + pix) * 4);
+  const int pix = (int)(p - n * a.HW);
+  const int oy = pix / a.OW, ox = pix - oy * a.OW, pad = a.taps == 9 ? 1 : 0;
+  gm.base = (unsigned)(n * a.C * a.HW_in * 4);
+  gm.iy = oy * a.stride - pad, gm.ix = ox * a.stride - pad;
+  return gm;
+}
+// byte offset of channel 0 of the input pixel tap (dy, dx) of the geometry; kOOB outside the image (zero padding)
+__device__ __forceinline__ unsigned cx_tap_offset(const CxArgs &a, const CxGeom &gm, int tap) {
+  const int dy = a.taps == 9 ? tap / 3 : 0, dx = a.taps == 9 ? tap - 3 * dy : 0;
+  const int iy = gm.iy + dy, ix = gm.ix + dx;
+  const bool ok = gm.base != kOOB && iy >= 0 && iy < a.H_in && ix >= 0 && ix < a.W_in;
+  return ok ? gm.base + (unsigned)((iy * a.W_in + ix) * 4) : kOOB;
 }
 
 template <int NB, int NW>      // NW waves x 32 pixels per tile; 8 waves = two per SIMD (<= 256 registers each) cover each other's stalls
@@ -59,7 +72,7 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
   static_assert(4 * NB % NW == 0, "the item's pieces must divide among the waves");
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
-  const int NI = a.C / 32, NC = a.C / 64;                     // ring items / activation chunks per work item
+  const int NCC = a.C / 64, NC = a.taps * NCC, NI = 2 * NC;   // chunks per tap, chunks and ring items per work item
   long long wcount = 0;
   {
     long long t;
@@ -99,9 +112,9 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
   float raw[32];
   // (an out-of-range pixel has offset kOOB = 2^31; the served tensors are below 2^31 bytes, so kOOB + anything stays out of
   // range without a select — a per-load select makes hipcc branch around every load)
-  auto load_raw = [&](unsigned pixoff, int kc) {
+  auto load_raw = [&](unsigned pixoff, int cc) {
     const unsigned vo = pixoff + (unsigned)(8 * g) * chan;
-    const unsigned so = (unsigned)(64 * kc) * chan;
+    const unsigned so = (unsigned)(64 * cc) * chan;
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -111,15 +124,16 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
   long long tile;
   int pass;
   cx_item(a, 0, &tile, &pass);
-  unsigned pixoff = cx_pixel_offset(a, tile * kTile + wave * 32 + j);
-  load_raw(pixoff, 0);
+  CxGeom gm = cx_geom(a, tile * kTile + wave * 32 + j);
+  load_raw(cx_tap_offset(a, gm, 0), 0);
   for (long long w = 0; w < wcount; ++w) {
     const long long p = tile * kTile + wave * 32 + j;
     // the next work item (its first chunk is requested while this one's last chunk is multiplied)
     long long ntile = tile;
     int npass_ = pass;
     const bool more = cx_item(a, w + 1, &ntile, &npass_);
-    const unsigned npixoff = more ? cx_pixel_offset(a, ntile * kTile + wave * 32 + j) : kOOB;
+    const CxGeom ngm = more ? cx_geom(a, ntile * kTile + wave * 32 + j) : CxGeom{kOOB, 0, 0};
+    int tap = 0, cc = 0;                   // of the chunk that is requested next
     f16v acc[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -142,7 +156,8 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
         split8(lo4, hi4, a.xscale, xh[s], xl[s]);
       }
       // ALWAYS 32 loads here (the ring's counted wait relies on it): the next chunk, the next item's first, or nothing (OOB)
-      load_raw(kc + 1 < NC ? pixoff : npixoff, kc + 1 < NC ? kc + 1 : 0);
+      if (++cc == NCC) cc = 0, ++tap;
+      load_raw(kc + 1 < NC ? cx_tap_offset(a, gm, tap) : cx_tap_offset(a, ngm, 0), kc + 1 < NC ? cc : 0);
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const char *stage = ring.wait(false);
@@ -173,7 +188,7 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
         }
       }
     }
-    tile = ntile, pass = npass_, pixoff = npixoff;
+    tile = ntile, pass = npass_, gm = ngm;
   }
 }
 
@@ -204,8 +219,38 @@ DVIS_EXPORT int dvis_conv1x1_x3_pack(const float *w, int K, int C, int wexp, voi
   return dvis_check_launch("dvis_conv1x1_x3_pack");
 }
 
+static int cx_launch(const float *x, const void *packed, const float *bias, const float *res, float *y, int N, int C, int K, int H, int W,
+                     int stride, int taps, int xexp, int wexp, int relu, void *stream);
+
 DVIS_EXPORT int dvis_conv1x1_x3(const float *x, const void *packed, const float *bias, const float *res, float *y, int N, int C, int K,
                                 int H, int W, int stride, int xexp, int wexp, int relu, void *stream) {
+  return cx_launch(x, packed, bias, res, y, N, C, K, H, W, stride, 1, xexp, wexp, relu, stream);
+}
+
+DVIS_EXPORT int64_t dvis_conv3x3_x3_packed_bytes(int C, int K) {
+  const int64_t b = dvis_conv1x1_x3_packed_bytes(C, K);
+  return b < 0 ? b : 9 * b;
+}
+
+/* weights (K x C x 3 x 3) -> [pass][k-step of (tap, channel)][block][hi, lo][lane][8 halves] */
+DVIS_EXPORT int dvis_conv3x3_x3_pack(const float *w, int K, int C, int wexp, void *packed, void *stream) {
+  DVIS_REQUIRE(w && packed, "dvis_conv3x3_x3_pack: null operand");
+  DVIS_REQUIRE(dvis_conv1x1_x3_supported(C, K, 1, 1, 1), "dvis_conv3x3_x3_pack: (C, K) = (%d, %d) is not served", C, K);
+  DVIS_REQUIRE(wexp >= -60 && wexp <= 60, "dvis_conv3x3_x3_pack: wexp = %d", wexp);
+  const int NB = K == 64 ? 2 : K == 128 ? 4 : 8;
+  const int64_t fragments = (int64_t)(9 * C / 16) * (K / 32) * 64;
+  hipLaunchKernelGGL(x3_pack_kernel, dim3((unsigned)((fragments + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (int64_t)9 * C, K, 9 * C,
+                     NB, 0, ldexpf(1.f, wexp), (_Float16 *)packed, fragments, 9);
+  return dvis_check_launch("dvis_conv3x3_x3_pack");
+}
+
+DVIS_EXPORT int dvis_conv3x3_x3(const float *x, const void *packed, const float *bias, const float *res, float *y, int N, int C, int K,
+                                int H, int W, int stride, int xexp, int wexp, int relu, void *stream) {
+  return cx_launch(x, packed, bias, res, y, N, C, K, H, W, stride, 9, xexp, wexp, relu, stream);
+}
+
+static int cx_launch(const float *x, const void *packed, const float *bias, const float *res, float *y, int N, int C, int K, int H, int W,
+                     int stride, int taps, int xexp, int wexp, int relu, void *stream) {
   DVIS_REQUIRE(x && packed && y, "dvis_conv1x1_x3: null operand");
   DVIS_REQUIRE(stride == 1 || stride == 2, "dvis_conv1x1_x3: stride %d", stride);
   const int OH = (H + stride - 1) / stride, OW = (W + stride - 1) / stride;
@@ -215,7 +260,8 @@ DVIS_EXPORT int dvis_conv1x1_x3(const float *x, const void *packed, const float 
                "dvis_conv1x1_x3: operands must be 16-byte aligned");
   CxArgs a = {};
   a.x = x, a.bias = bias, a.res = res, a.wp = packed, a.y = y, a.N = N, a.C = C, a.K = K, a.relu = relu;
-  a.stride = stride, a.W_in = W, a.OW = OW, a.HW = (long long)OH * OW, a.HW_in = (long long)H * W, a.pixels = a.HW * N;
+  a.stride = stride, a.W_in = W, a.H_in = H, a.taps = taps, a.OW = OW, a.HW = (long long)OH * OW, a.HW_in = (long long)H * W;
+  a.pixels = a.HW * N;
   a.xscale = ldexpf(1.f, xexp), a.inv = ldexpf(1.f, -(xexp + wexp));
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {

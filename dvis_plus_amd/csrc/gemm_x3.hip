@@ -284,8 +284,11 @@ __global__ __launch_bounds__(512) void x3_linear_stream_kernel(const float *__re
 
 // ---------------------------------------------------------------------------------------------------------------------
 // out = LayerNorm( x + linear2( relu( linear1(x) ) ) ) for K = N = 256 model features and H = 128 HB hidden units.
-// Weight stream per tile: HB hidden blocks x [4 items of linear1 (4 k-steps x 4 blocks of 32 hidden units), 4 items of
-// linear2 (2 hidden k-steps x 8 blocks of 32 outputs, k in accumulator order)], every item 32 KB.
+// Weight stream per tile: HB hidden blocks x [4 items of linear1 (ONE block of 32 hidden units x all 16 k-steps), 4 items of
+// linear2 (2 hidden k-steps x 8 blocks of 32 outputs, k in accumulator order)], every item 32 KB.  A block of hidden units is
+// complete after its item, so its bias + ReLU + split (80 VALU instructions) is threaded through the NEXT item's products,
+// five instructions behind the first product of each of its 16 blocks (mma_item's valu) — between the items it cost 0.3 ms
+// of 1.8 per 30-frame layer with the matrix pipe idle.
 struct FfnArgs {
   const float *b1;                   // H
   float inv1, hscale;                // 2^-(xexp + w1exp); 2^hexp (the hidden activations' split exponent)
@@ -325,33 +328,42 @@ __global__ __launch_bounds__(kThreads) void x3_ffn_kernel(const float *__restric
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc1[t][i] = 0.f;
+      h8 hh[8], hl[8];
+      // half-step t of the conversion of hidden tile `tc`: pair = t >> 1 (k-step u = pair >> 2 of the tile, elements 2 pp, 2 pp + 1),
+      // first half: bias + ReLU + scale, second half: the split
+      f2 cv = {0.f, 0.f};
+      auto convert = [&](int tc, int t) {
+        const int pair = t >> 1, u = pair >> 2, pp = pair & 3;
+        if ((t & 1) == 0) {
+          const f2 b = *(const f2 *)(b1s + 128 * hb + 32 * tc + 16 * u + 8 * (pp >> 1) + 4 * g + 2 * (pp & 1));
+          cv[0] = fmaxf(acc1[tc][8 * u + 2 * pp] * f.inv1 + b[0], 0.f) * f.hscale;
+          cv[1] = fmaxf(acc1[tc][8 * u + 2 * pp + 1] * f.inv1 + b[1], 0.f) * f.hscale;
+        } else {
+          const h2 h = __builtin_convertvector(cv, h2);
+          const f2 r = cv - __builtin_convertvector(h, f2);
+          const h2 l = __builtin_convertvector(r, h2);
+          hh[2 * tc + u][2 * pp] = h.x, hh[2 * tc + u][2 * pp + 1] = h.y;
+          hl[2 * tc + u][2 * pp] = l.x, hl[2 * tc + u][2 * pp + 1] = l.y;
+        }
+      };
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const char *stage = ring.wait(hb == 0 && c == 0);
         ring.begin_periodic();
-        mma_item<4, 4, 8>(stage, lane, acc1, xh + 4 * c, xl + 4 * c, [&](int i) { ring.piece(i); });
+        mma_item<16, 1, 8>(stage, lane, acc1 + c, xh, xl, [&](int i) { ring.piece(i); }, [&](int t) {
+          if (c > 0) convert(c - 1, t);
+        });
       }
-      // hidden block -> phase-2 "B" fragments, in place: k-step 2 t + u of the block takes registers 8 u .. 8 u + 7 of tile t
-      h8 hh[8], hl[8];
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          f4 a, b;
-          const float *bp = b1s + 128 * hb + 32 * t + 16 * u + 4 * g;
-          const f4 ba = *(const f4 *)bp, bb = *(const f4 *)(bp + 8);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            a[i] = fmaxf(acc1[t][8 * u + i] * f.inv1 + ba[i], 0.f);
-            b[i] = fmaxf(acc1[t][8 * u + 4 + i] * f.inv1 + bb[i], 0.f);
-          }
-          split8(a, b, f.hscale, hh[2 * t + u], hl[2 * t + u]);
-        }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const char *stage = ring.wait(false);
         ring.begin_periodic();
-        mma_item<2, 8, 8>(stage, lane, acc2, hh + 2 * c, hl + 2 * c, [&](int i) { ring.piece(i); });
+        if (c == 0) {
+          // tile 3 is converted behind item 0's products, which read tile 0's fragments only (hh[0], hh[1])
+          mma_item<2, 8, 8>(stage, lane, acc2, hh, hl, [&](int i) { ring.piece(i); }, [&](int t) { convert(3, t); });
+        } else {
+          mma_item<2, 8, 8>(stage, lane, acc2, hh + 2 * c, hl + 2 * c, [&](int i) { ring.piece(i); });
+        }
       }
     }
     if (tok0 < M) epilogue<8, true>(acc2, e, cst, cst + 256, cst + 512, scr, lane, tok0, M);
@@ -370,9 +382,8 @@ __global__ void x3_ffn_pack_kernel(const float *w1, int64_t ldw1, const float *w
   t >>= 4;
   const int item = t & 7, hb = t >> 3;
   _Float16 *o = out + (((int64_t)hb * 8 + item) * 16 + fr) * 1024 + lane * 8;
-  if (item < 4) {                    // W1 rows 128 hb + 32 nb + i, k-steps 4 item + s
-    const int s = fr >> 2, nb = fr & 3;
-    x3_pack_fragment(w1, ldw1, H, 256, 128 * hb + 32 * nb + (lane & 31), 0, 4 * item + s, lane >> 5, s1, o, o + 512);
+  if (item < 4) {                    // W1 rows 128 hb + 32 item + i (one tile of 32 hidden units), all 16 k-steps
+    x3_pack_fragment(w1, ldw1, H, 256, 128 * hb + 32 * item + (lane & 31), 0, fr, lane >> 5, s1, o, o + 512);
   } else {                           // W2 rows 32 nb + i, hidden k-steps 8 hb + 2 (item - 4) + s, accumulator order
     const int s = fr >> 3, nb = fr & 7;
     x3_pack_fragment(w2, ldw2, 256, H, 32 * nb + (lane & 31), 1, 8 * hb + 2 * (item - 4) + s, lane >> 5, s2, o, o + 512);

@@ -45,8 +45,11 @@ __device__ __forceinline__ void split8(f4 a, f4 b, float s, h8 &hi, h8 &lo) {
 //   * `dma(i)`, i < NDMA: the caller's LDS-DMA requests for a LATER item, spread over the products instead of issued in one
 //     burst after the barrier: a burst of 8 x 1 KB from each of the 4 waves queues 512 cycles of vector-memory issue in front
 //     of the first product of every wave; between products the same requests cost their issue slot.
-template <int STEPS, int NBL, int NDMA, typename Dma>
-__device__ __forceinline__ void mma_item(const char *stage, int lane, f16v *acc, const h8 *xh, const h8 *xl, Dma dma) {
+//   * `valu(t)`, t < STEPS * NBL: a few (<= 5) VALU instructions of the caller's, issued behind the FIRST product of block t:
+//     the matrix pipe runs the block's three products (96 cycles) while the wave issues them — work that would otherwise
+//     sit between two items with the pipe idle (the FFN's hidden-activation split).
+template <int STEPS, int NBL, int NDMA, typename Dma, typename Valu>
+__device__ __forceinline__ void mma_item(const char *stage, int lane, f16v *acc, const h8 *xh, const h8 *xl, Dma dma, Valu valu) {
   constexpr int T = STEPS * NBL;
   static_assert(NDMA <= T, "one request per block at most");
   const char *p = stage + lane * 16;
@@ -59,13 +62,19 @@ __device__ __forceinline__ void mma_item(const char *stage, int lane, f16v *acc,
     if (NDMA > 0 && t * NDMA / T != (t + 1) * NDMA / T) dma(t * NDMA / T);
     __builtin_amdgcn_sched_barrier(0);      // the requests above stay above the products below
     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[c], xh[s], acc[nb], 0, 0, 0);
+    valu(t);
+    __builtin_amdgcn_sched_barrier(0);
     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[c], xl[s], acc[nb], 0, 0, 0);
     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[c], xh[s], acc[nb], 0, 0, 0);
   }
 }
+template <int STEPS, int NBL, int NDMA, typename Dma>
+__device__ __forceinline__ void mma_item(const char *stage, int lane, f16v *acc, const h8 *xh, const h8 *xl, Dma dma) {
+  mma_item<STEPS, NBL, NDMA>(stage, lane, acc, xh, xl, dma, [](int) {});
+}
 template <int STEPS, int NBL>
 __device__ __forceinline__ void mma_item(const char *stage, int lane, f16v *acc, const h8 *xh, const h8 *xl) {
-  mma_item<STEPS, NBL, 0>(stage, lane, acc, xh, xl, [](int) {});
+  mma_item<STEPS, NBL, 0>(stage, lane, acc, xh, xl, [](int) {}, [](int) {});
 }
 
 // EXTRA: ordinary loads the kernel keeps in flight, issued between an item's pieces and the next-but-one item's (the
@@ -155,12 +164,15 @@ __device__ __forceinline__ int x3_k(int order, int S, int g, int e) {
 }
 
 // rows [n0, n0 + 32 nbl) x k-steps [S0, S0 + steps) of W (N x K) -> one item image [s][nb][hi, lo][lane][8]
+// taps > 1: a convolution weight (N, K / taps, taps) read as N x K with k = tap * (K / taps) + channel
 __device__ __forceinline__ void x3_pack_fragment(const float *w, int64_t ldw, int N, int K, int n, int order, int S, int g,
-                                                 float scale, _Float16 *hi, _Float16 *lo) {
+                                                 float scale, _Float16 *hi, _Float16 *lo, int taps = 1) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int k = x3_k(order, S, g, e);
-    const float v = (n < N && k < K) ? w[(int64_t)n * ldw + k] * scale : 0.f;
+    const int ci = K / taps;
+    const int src = taps == 1 ? k : (k % ci) * taps + k / ci;
+    const float v = (n < N && k < K) ? w[(int64_t)n * ldw + src] * scale : 0.f;
     const _Float16 h = (_Float16)v;
     hi[e] = h;
     lo[e] = (_Float16)(v - (float)h);
@@ -168,7 +180,7 @@ __device__ __forceinline__ void x3_pack_fragment(const float *w, int64_t ldw, in
 }
 
 __global__ void x3_pack_kernel(const float *w, int64_t ldw, int N, int K, int NB, int order, float scale, _Float16 *out,
-                               int64_t fragments) {
+                               int64_t fragments, int taps = 1) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (pass, k-step, nb, lane)
   if (idx >= fragments) return;
   const int lane = idx & 63;
@@ -178,7 +190,7 @@ __global__ void x3_pack_kernel(const float *w, int64_t ldw, int N, int K, int NB
   const int KS = K / 16;
   const int S = t % KS, pass = t / KS;
   _Float16 *o = out + (idx >> 6) * 1024 + lane * 8;
-  x3_pack_fragment(w, ldw, N, K, 32 * (pass * NB + nb) + (lane & 31), order, S, lane >> 5, scale, o, o + 512);
+  x3_pack_fragment(w, ldw, N, K, 32 * (pass * NB + nb) + (lane & 31), order, S, lane >> 5, scale, o, o + 512, taps);
 }
 
 }  // namespace

@@ -490,6 +490,13 @@ int64_t dvis_conv1x1_x3_packed_bytes(int C, int K);
 int dvis_conv1x1_x3_pack(const float *w, int K, int C, int wexp, void *packed, void *stream);
 int dvis_conv1x1_x3(const float *x, const void *packed, const float *bias, const float *res, float *y, int N, int C, int K, int H,
                     int W, int stride, int xexp, int wexp, int relu, void *stream);
+/* The 3x3 / padding 1 / stride 1 or 2 convolution through the same kernel: nine taps = nine times the input channels, each
+ * chunk of 64 channels read at the tap's pixel (outside the image: an out-of-range buffer offset, i.e. exact zero padding).
+ * w (K, C, 3, 3).  Serves the stride-2 conv2 of the first res3 / res4 / res5 bottleneck (detectron2 BottleneckBlock). */
+int64_t dvis_conv3x3_x3_packed_bytes(int C, int K);
+int dvis_conv3x3_x3_pack(const float *w, int K, int C, int wexp, void *packed, void *stream);
+int dvis_conv3x3_x3(const float *x, const void *packed, const float *bias, const float *res, float *y, int N, int C, int K, int H,
+                    int W, int stride, int xexp, int wexp, int relu, void *stream);
 int dvis_x3_ffn_pack(const float *W1, int64_t ldw1, const float *W2, int64_t ldw2, int K, int H, int N, int w1exp, int w2exp,
                      void *packed, void *stream);
 int dvis_x3_ffn_ln(const float *x, int64_t ldx, int64_t M, int K, int H, int N, const void *packed, int xexp, int w1exp,

@@ -99,7 +99,7 @@ def test_resnet50_production_size_strict_own_kernels_vs_unfused_fp64():
     sd = {k: v.double() for k, v in m.state_dict().items()}
     lib = native.lib()
     names = ("dvis_conv3x3_winograd", "dvis_conv1x1_mfma", "dvis_conv1x1s2_mfma", "dvis_conv3x3s2", "dvis_conv7x7s2",
-             "dvis_conv1x1_bias_act", "dvis_bias_relu_maxpool", "dvis_conv1x1_x3")
+             "dvis_conv1x1_bias_act", "dvis_bias_relu_maxpool", "dvis_conv1x1_x3", "dvis_conv3x3_x3")
     calls = {n: 0 for n in names}
     orig = {n: getattr(lib, n) for n in names}
     lib_convs = []
@@ -124,7 +124,12 @@ def test_resnet50_production_size_strict_own_kernels_vs_unfused_fp64():
             setattr(lib, n, orig[n])
     assert not lib_convs, f"library convolutions ran at the production size: {lib_convs}"
     # 16 bottlenecks: 13 stride-1 3x3 (Winograd) + 3 stride-2 3x3; 4 shortcuts (1 stride-1, 3 stride-2); the stem
-    assert calls["dvis_conv3x3_winograd"] == 13 and calls["dvis_conv3x3s2"] == 3 and calls["dvis_conv7x7s2"] == 1
+    from dvis_plus_amd import functions as Fn
+    assert calls["dvis_conv7x7s2"] == 1
+    if Fn.X3:     # from 128 channels on (and every stride-2 layer) the nine-tap split-f16 kernel, the three 64-channel ones Winograd
+        assert calls["dvis_conv3x3_winograd"] == 3 and calls["dvis_conv3x3s2"] == 0 and calls["dvis_conv3x3_x3"] == 13, calls
+    else:
+        assert calls["dvis_conv3x3_winograd"] == 13 and calls["dvis_conv3x3s2"] == 3 and calls["dvis_conv3x3_x3"] == 0, calls
     assert calls["dvis_bias_relu_maxpool"] == 1
     # the 1x1 layers: 16 x (conv1, conv3) + 4 shortcuts = 36; the compute-bound ones (>= 128 input channels where the
     # memory-bound kernel does not serve the shape) and the three stride-2 shortcuts on the split-f16 matrix-core kernel

@@ -265,3 +265,32 @@ def test_linear_streams_any_k(K, N, M):
     got = Fn.x3_linear(x, lin.weight, lin.bias)
     assert _rel(got, ref, scale) <= max(1.25 * e_lib, 3e-7)
     assert torch.equal(got, Fn.x3_linear(x, lin.weight, lin.bias))
+
+
+@pytest.mark.parametrize("Ci,Co,H,W,stride,N,relu", [
+    (64, 64, 17, 23, 1, 2, True),
+    (128, 128, 23, 40, 2, 3, True),       # conv2 of the first res3 bottleneck (stride 2), tiles straddle images
+    (256, 256, 12, 20, 1, 2, False),
+    (512, 512, 9, 11, 2, 2, True),        # odd sizes
+    (64, 256, 32, 32, 1, 1, False),
+])
+def test_conv3x3_x3(Ci, Co, H, W, stride, N, relu):
+    """The nine-tap form of csrc/conv1x1_x3.hip (3x3, padding 1) against fp64, next to the library convolution's error."""
+    from dvis_plus_amd import functions as Fn
+    torch.manual_seed(Ci + H)
+    x = torch.randn(N, Ci, H, W, device=DEV)
+    w = torch.randn(Co, Ci, 3, 3, device=DEV) * (2.0 / (9 * Ci)) ** 0.5
+    b = torch.randn(Co, device=DEV)
+    assert Fn.conv3x3_x3_ok(x, w, stride)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride, 1)
+    scale = F.conv2d(x.double().abs(), w.double().abs(), b.double().abs(), stride, 1)
+    lib = F.conv2d(x, w, b, stride, 1)
+    if relu:
+        ref, lib = ref.clamp_min(0), lib.clamp_min(0)
+    got = Fn.conv3x3_x3(x, w, b, None, relu, stride)
+    assert got.shape == ref.shape
+    e, e_lib = _rel(got, ref, scale), _rel(lib, ref, scale)
+    assert e <= max(1.25 * e_lib, 3e-7), (e, e_lib)
+    xi = torch.randint(-9, 10, (N, Ci, H, W), device=DEV).float()
+    wi = torch.randint(-2, 3, (Co, Ci, 3, 3), device=DEV).float()
+    assert torch.equal(Fn.conv3x3_x3(xi, wi, None, None, False, stride), F.conv2d(xi.double(), wi.double(), None, stride, 1).float())

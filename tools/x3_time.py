@@ -130,7 +130,31 @@ def conv_main():
               f"   exact-fp32 MFMA kernel {tm:.3f} ms ({fl / tm / 1e9:.0f} TF)")
 
 
+def conv3_main():
+    """the R50's 3x3 layers and the FPN output convolution at 30 frames of 736 x 1280: nine-tap split-f16 kernel vs the exact-fp32
+    Winograd / direct stride-2 kernels"""
+    shapes = [(64, 64, 184, 320, 1), (128, 128, 184, 320, 2), (128, 128, 92, 160, 1), (256, 256, 92, 160, 2), (256, 256, 46, 80, 1),
+              (512, 512, 46, 80, 2), (512, 512, 23, 40, 1), (256, 256, 184, 320, 1)]
+    for Ci, Co, H, W, stride in shapes:
+        x = torch.randn(30, Ci, H, W, device=DEV)
+        w = torch.randn(Co, Ci, 3, 3, device=DEV) * (2.0 / (9 * Ci)) ** 0.5
+        b = torch.randn(Co, device=DEV)
+        OH, OW = (H + stride - 1) // stride, (W + stride - 1) // stride
+        if not Fn.conv3x3_x3_ok(x, w, stride):
+            print(f"  conv3x3 {Ci} -> {Co} {H}x{W} s{stride}: not served")
+            continue
+        t = timeit(lambda: Fn.conv3x3_x3(x, w, b, None, True, stride))
+        te = timeit(lambda: Fn.conv3x3_bias_act(x, w, b, True)) if stride == 1 else timeit(lambda: Fn.conv3x3s2_bias_act(x, w, b, True))
+        fl = 2.0 * 30 * OH * OW * Ci * Co * 9
+        print(f"  conv3x3 {Ci:4d} -> {Co:4d} {H}x{W} s{stride}: x3 nine taps {t:.3f} ms ({fl / t / 1e9:.0f} TF fp32-eq direct)"
+              f"   exact-fp32 {'Winograd' if stride == 1 else 'direct'} kernel {te:.3f} ms ({fl / te / 1e9:.0f} TF direct-eq)")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "conv3":
+        with torch.no_grad():
+            conv3_main()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "conv":
         with torch.no_grad():
             conv_main()
