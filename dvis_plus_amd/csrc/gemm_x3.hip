@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kThreads) void x3_linear_kernel(const float *__rest
   // bias (all passes) | gamma | beta in LDS
   float *cst = (float *)(lds + kStages * Ring<NB>::kItemBytes + kWaves * kScratch);
   const int ntot = 32 * NB * npass;
-  for (int i = threadIdx.x; i < ntot; i += kThreads) cst[i] = e.bias[i];
+  for (int i = threadIdx.x; i < ntot; i += kThreads) cst[i] = e.bias ? e.bias[i] : 0.f;
   if constexpr (LN)
     for (int i = threadIdx.x; i < 32 * NB; i += kThreads) cst[ntot + i] = e.gamma[i], cst[ntot + 32 * NB + i] = e.beta[i];
   __syncthreads();
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(512) void x3_linear_stream_kernel(const float *__re
   char *scr = lds + kStages * RingT::kItemBytes + wave * kScratch;
   float *cst = (float *)(lds + kStages * RingT::kItemBytes + NW * kScratch);
   const int ntot = 32 * NB * npass;
-  for (int i = threadIdx.x; i < ntot; i += 512) cst[i] = e.bias[i];
+  for (int i = threadIdx.x; i < ntot; i += 512) cst[i] = e.bias ? e.bias[i] : 0.f;
   if constexpr (LN)
     for (int i = threadIdx.x; i < 32 * NB; i += 512) cst[ntot + i] = e.gamma[i], cst[ntot + 32 * NB + i] = e.beta[i];
   __syncthreads();
@@ -455,7 +455,6 @@ DVIS_EXPORT int dvis_x3_pack(const float *w, int64_t ldw, int N, int K, int wexp
 DVIS_EXPORT int dvis_x3_linear(const float *x, int64_t ldx, int64_t M, int K, const void *wp, int N, int xexp, int wexp,
                                const float *bias, int relu, float *out, int64_t ldo, void *stream) {
   DVIS_REQUIRE(dvis_x3_linear_supported(N, K, 0), "dvis_x3_linear: (N, K) = (%d, %d) is not served (K %% 64 == 0; N in 128 / 192 / 256 or N %% 256 == 0; N = 288 at K = 256)", N, K);
-  DVIS_REQUIRE(bias, "dvis_x3_linear: bias is required");
   const int rc = x3_check_common(x, ldx, M, wp, out, ldo);
   if (rc != DVIS_OK) return rc;
   if (M == 0) return DVIS_OK;

@@ -695,6 +695,11 @@ def linear(x, weight, bias=None, relu=False, own=None):
     OWN_GEMM_DEFAULT decides; otherwise the library GEMM — with a bias the ReLU then runs as the GEMM's epilogue
     (hipBLASLt via torch._addmm_activation) instead of a second pass.  CPU tensors / autograd always take torch ops."""
     forced = own is True
+    if X3 and not forced and x.is_cuda and x.numel() // max(1, x.shape[-1]) >= X3_MIN_ROWS and weight.dim() == 2 \
+            and weight._base is None and x3_ok(x, weight.shape[0], weight.shape[1]):
+        # tall projections (every pixel / every ViT token of every frame): split-f16 matrix-core kernel (csrc/gemm_x3.hip).
+        # Weights that are views (slices made per call) would be re-packed per call: they stay on the paths below.
+        return x3_linear(x, weight, bias, relu=relu)
     own = OWN_GEMM_DEFAULT if own is None else own
     if own and x.is_cuda and not torch.is_grad_enabled():
         if _own_gemm_ok(x, weight):
@@ -722,6 +727,7 @@ def linear_relu(x, lin, own=None):
 # ---- the encoder's tall GEMMs on the F16 matrix cores (csrc/gemm_x3.hip): fp32 operands as two f16 terms, three products
 # per pair, fp32 accumulation -> the error of an fp32 GEMM at 3/16 of its matrix-core time.
 X3 = os.environ.get("DVIS_X3", "1") != "0"
+X3_MIN_ROWS = 32768        # linear(): below this many rows (128 tiles of 256) the persistent kernel cannot fill the chip
 X3_XEXP = int(os.environ.get("DVIS_X3_XEXP", "4"))      # activations are scaled by 2^4 before the split (|x| < 4094)
 # the convolutions see ReLU'd feature maps without a normalisation in front: more range (|x| < 16376), an absolute floor of
 # 2^-27 = 7.5e-9 per element below |x| = 0.03
@@ -785,7 +791,7 @@ def x3_linear(x, weight, bias, relu=False, xexp=None):
     with torch.cuda.device(x.device):
         native.check(native.lib().dvis_x3_linear(
             ctypes.c_void_p(x2.data_ptr()), ldx, x2.shape[0], K, ctypes.c_void_p(buf.data_ptr()), N,
-            X3_XEXP if xexp is None else xexp, wexp, native.dev_ptr(bias.detach(), "bias"), int(relu),
+            X3_XEXP if xexp is None else xexp, wexp, None if bias is None else native.dev_ptr(bias.detach(), "bias"), int(relu),
             ctypes.c_void_p(out.data_ptr()), N, native.stream_ptr(x.device)), "dvis_x3_linear")
     return out
 

@@ -459,12 +459,13 @@ int64_t dvis_x3_packed_bytes(int N, int K);
 int dvis_x3_pack(const float *W, int64_t ldw, int N, int K, int wexp, void *packed, void *stream);
 /* which (N, K) the projection kernels serve (ln != 0: the LayerNorm form) */
 int dvis_x3_linear_supported(int N, int K, int ln);
-/* out (M x N, row stride ldo) = act( x (M x K, row stride ldx) W^T + bias ),  act = ReLU if relu != 0.
+/* out (M x N, row stride ldo) = act( x (M x K, row stride ldx) W^T + bias ),  act = ReLU if relu != 0; bias may be NULL.
  * Replaces nn.Linear over the flattened (frames x pixels) batch: ms_deform_attn.py:96-99 (value_proj), :101-102
  * (sampling_offsets | attention_weights as one stacked weight), and the masked-attention decoder's key / value projections of
  * every pixel for all layers of a level at once (mask2former_video/.../video_mask2former_transformer_decoder.py:81-88,
- * nn.MultiheadAttention in_proj).  K = 256; N in {128, 192, 256, 288}, or N % 256 == 0 (output features in passes of 256
- * over one read of x). */
+ * nn.MultiheadAttention in_proj), and the DINOv2 blocks' qkv / proj / fc1 / fc2 over every token of every frame
+ * (mask2former/modeling/backbones_vitAdapter/.../vision_transformer blocks).  K % 64 == 0; N in {128, 192, 256} or N % 256 == 0
+ * (output features in passes of 256 over one tile of x); N = 288 at K = 256. */
 int dvis_x3_linear(const float *x, int64_t ldx, int64_t M, int K, const void *packed, int N, int xexp, int wexp,
                    const float *bias, int relu, float *out, int64_t ldo, void *stream);
 /* out = LayerNorm( x W^T + bias + res ) over the N = 256 features (gamma, beta, eps; two-pass statistics as torch);
