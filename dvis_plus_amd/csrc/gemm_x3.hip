@@ -391,11 +391,7 @@ __global__ void x3_ffn_pack_kernel(const float *w1, int64_t ldw1, const float *w
 }
 
 int x3_grid(int64_t ntiles) {
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-  }
+  const int cus = x3_persistent_cus();
   return (int)(ntiles < cus ? ntiles : cus);
 }
 

@@ -501,7 +501,9 @@ class MSDeformAttnPixelDecoder(nn.Module):
             for idx, f in enumerate(self.transformer_in_features[::-1]):
                 x = features[f].float().contiguous()      # (a backbone may hand over channels-last strided maps)
                 conv, gn = self.input_proj[idx][0], self.input_proj[idx][1]
-                s_ = conv(x)
+                # (nn.Conv2d's own forward is the library convolution; Fn.conv1x1 = the 1x1 kernels, torch ops on the CPU)
+                s_ = Fn.conv1x1(x, conv.weight, conv.bias) if conv.kernel_size == (1, 1) and conv.stride == (1, 1) \
+                    and conv.padding == (0, 0) and conv.groups == 1 else conv(x)
                 affine = Fn.group_norm_affine(s_, gn)        # GroupNorm applied while the map is laid down as tokens
                 srcs.append(s_ if affine is not None else gn(s_))
                 affines.append(affine)

@@ -74,3 +74,52 @@ def test_convolution_wrappers_keep_torch_semantics_on_cpu_tensors():
     xs = torch.randn(1, 3, 16, 20, generator=g)
     ws = torch.randn(64, 3, 7, 7, generator=g) * 0.1
     torch.testing.assert_close(Fn.conv7x7s2_stem(xs, ws), F.conv2d(xs, ws, None, 2, 3))
+
+
+def test_x3_split_arithmetic_on_the_cpu():
+    """The arithmetic of csrc/gemm_x3.hip restated in numpy: an fp32 operand as two f16 terms (hi = rn16(v 2^e), lo = rn16(v 2^e
+    - hi)), a product as a_lo w_hi + a_hi w_lo + a_hi w_hi.  With exact accumulation the 256-term dot product is within
+    2^-22 / sqrt(K)-ish of sum|a||w| of the exact one — an order below the 1e-7 sum|a||w| an fp32 accumulation chain loses —
+    and the weight exponent the host picks fills the f16 range without overflow."""
+    import numpy as np
+    from dvis_plus_amd import functions as Fn
+    rng = np.random.default_rng(0)
+    K = 256
+    a = rng.standard_normal((64, K)).astype(np.float32)
+    w = (rng.standard_normal((32, K)) * 0.06).astype(np.float32)
+    ew = Fn._x3_exp(torch.from_numpy(w))
+    assert 2.0 ** 13 <= float(np.abs(w).max()) * 2.0 ** ew < 2.0 ** 14
+    assert Fn._x3_exp(torch.zeros(3, 4)) == 0
+
+    def split(v, e):
+        s = (v.astype(np.float64) * 2.0 ** e).astype(np.float32)
+        hi = s.astype(np.float16)
+        lo = (s - hi.astype(np.float32)).astype(np.float16)
+        assert np.isfinite(hi).all()
+        return hi.astype(np.float64), lo.astype(np.float64)
+    ah, al = split(a, Fn.X3_XEXP)
+    wh, wl = split(w, ew)
+    got = (al @ wh.T + ah @ wl.T + ah @ wh.T) * 2.0 ** -(Fn.X3_XEXP + ew)
+    ref = a.astype(np.float64) @ w.astype(np.float64).T
+    scale = np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64).T
+    assert float((np.abs(got - ref) / scale).max()) < 5e-8
+    # the same operands through an fp32 accumulation chain (numpy float32 matmul): the error an fp32 GEMM has anyway
+    e32 = float((np.abs((a @ w.T).astype(np.float64) - ref) / scale).max())
+    assert e32 > 2e-8
+
+
+def test_x3_shape_tables():
+    """Host-side tables of the split-f16 kernels (no GPU): which shapes are served, how large the packed weights are."""
+    from dvis_plus_amd import native
+    lib = native.lib()
+    for N, K, ok in ((256, 256, 1), (288, 256, 1), (288, 512, 0), (768, 256, 1), (128, 64, 1), (192, 1024, 1), (3072, 1024, 1),
+                     (100, 256, 0), (256, 100, 0), (320, 256, 0)):
+        assert lib.dvis_x3_linear_supported(N, K, 0) == ok, (N, K)
+        assert (lib.dvis_x3_packed_bytes(N, K) == N * K * 4) == bool(ok)          # hi + lo halves: 4 bytes per weight
+    assert lib.dvis_x3_linear_supported(256, 256, 1) == 1 and lib.dvis_x3_linear_supported(512, 256, 1) == 0
+    assert lib.dvis_x3_ffn_packed_bytes(256, 1024, 256) == 2 * 256 * 1024 * 4 and lib.dvis_x3_ffn_packed_bytes(256, 1000, 256) < 0
+    for C, K, ok in ((512, 128, 1), (64, 64, 1), (2048, 512, 1), (96, 128, 0), (256, 100, 0)):
+        assert lib.dvis_conv1x1_x3_supported(C, K, 2, 920, 920) == ok
+        assert (lib.dvis_conv3x3_x3_packed_bytes(C, K) == 9 * C * K * 4) == bool(ok)
+    assert lib.dvis_conv1x1_x3_supported(256, 256, 30, 58880, 58880) == 1       # 1.81 GB: below the 2 GiB of 32-bit buffer offsets
+    assert lib.dvis_conv1x1_x3_supported(256, 256, 64, 58880, 58880) == 0       # T = 64 in one call: served by the fp32 kernels
