@@ -263,7 +263,7 @@ static int cx_launch(const float *x, const void *packed, const float *bias, cons
   a.stride = stride, a.W_in = W, a.H_in = H, a.taps = taps, a.OW = OW, a.HW = (long long)OH * OW, a.HW_in = (long long)H * W;
   a.pixels = a.HW * N;
   a.xscale = ldexpf(1.f, xexp), a.inv = ldexpf(1.f, -(xexp + wexp));
-  const int grid = x3_persistent_cus();
+  const int grid = dvis_x3_persistent_cus();
   hipStream_t st = (hipStream_t)stream;
   static const int nw = getenv("DVIS_X3_CONV_WAVES") ? atoi(getenv("DVIS_X3_CONV_WAVES")) : 8;
   a.npass = K <= 128 ? 1 : K / 256;

@@ -27,6 +27,8 @@
 #include "dvis_common.h"
 #include "x3_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 // Activation fragments of a wave's 32 tokens for K = 16 * KS, natural k order: lane (token j, half g) holds
@@ -391,7 +393,7 @@ __global__ void x3_ffn_pack_kernel(const float *w1, int64_t ldw1, const float *w
 }
 
 int x3_grid(int64_t ntiles) {
-  const int cus = x3_persistent_cus();
+  const int cus = dvis_x3_persistent_cus();
   return (int)(ntiles < cus ? ntiles : cus);
 }
 
@@ -421,6 +423,31 @@ static int x3_passes(int N, int *nb) {
   if (N == 128 || N == 192 || N == 256 || N == 288) return *nb = N / 32, 1;
   if (N > 0 && N % 256 == 0 && N <= 8192) return *nb = 8, N / 256;
   return *nb = 0, 0;
+}
+
+// These kernels hold a CU's whole register file for the length of a launch (one persistent workgroup per CU), so a concurrent
+// stream's small kernels — the previous clip's tracker chain under DVIS_Plus_offline.stream() — could otherwise start only
+// between two launches.  `reserve` CUs (rounded down to a multiple of 8: one per XCD and step) are left out of the grids.
+static int g_x3_reserve = [] {
+  const char *e = getenv("DVIS_X3_RESERVE");
+  const int r = e ? atoi(e) : 0;
+  return r < 0 ? 0 : r / 8 * 8;
+}();
+
+int dvis_x3_persistent_cus() {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v >= 8) cus = v;
+  }
+  cus = cus / 8 * 8;
+  const int r = __atomic_load_n(&g_x3_reserve, __ATOMIC_RELAXED);
+  return cus - r >= 8 ? cus - r : cus;
+}
+
+DVIS_EXPORT int dvis_x3_set_reserve(int cus) {
+  const int r = cus < 0 ? 0 : cus / 8 * 8;
+  return __atomic_exchange_n(&g_x3_reserve, r, __ATOMIC_RELAXED);
 }
 
 DVIS_EXPORT int dvis_x3_linear_supported(int N, int K, int ln) {

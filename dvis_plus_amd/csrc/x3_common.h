@@ -78,23 +78,10 @@ __device__ __forceinline__ void mma_item(const char *stage, int lane, f16v *acc,
   mma_item<STEPS, NBL, 0>(stage, lane, acc, xh, xl, [](int) {}, [](int) {});
 }
 
-// Persistent grids: one workgroup per CU minus DVIS_X3_RESERVE CUs (a multiple of 8, one per XCD and step).  These kernels
-// hold a CU's whole register file for the length of the launch, so a concurrent stream's small kernels (the tracker chain of
-// the previous clip) could otherwise start only between two launches.
-static inline int x3_persistent_cus() {
-  static const int reserve = [] {
-    const char *e = getenv("DVIS_X3_RESERVE");
-    const int r = e ? atoi(e) : 0;
-    return r < 0 ? 0 : r / 8 * 8;
-  }();
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v >= 8) cus = v;
-  }
-  cus = cus / 8 * 8;
-  return cus - reserve >= 8 ? cus - reserve : cus;
-}
+}  // namespace
+// Persistent grids: one workgroup per CU minus the reserve of dvis_x3_set_reserve (defined in csrc/gemm_x3.hip).
+int dvis_x3_persistent_cus();
+namespace {
 
 // EXTRA: ordinary loads the kernel keeps in flight, issued between an item's pieces and the next-but-one item's (the
 // activation prefetch of csrc/conv1x1_x3.hip): they are newer than the item waited for, so the counted wait leaves them out too.

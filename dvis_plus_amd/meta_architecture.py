@@ -23,6 +23,7 @@ import torch
 from torch import nn
 
 from . import d2
+from . import native
 from . import postprocess as PP
 from .clip_shard import ClipShard, EmulatedShard
 from .d2 import configurable
@@ -612,6 +613,18 @@ class DVIS_Plus_offline(_VideoBase):
                             v.record_stream(main)
             return [PP.to_reference_format(out) if self.reference_outputs else out for out in outs]
 
+        # the split-f16 kernels of phase A are persistent (one workgroup per CU for the whole launch): leave 32 CUs (4 per XCD)
+        # to phase B's small kernels on the side stream — measured 356 -> 365 - 370 frames/s (8 / 16 / 24 CUs lose, 40 - 64 gain less)
+        reserve = int(os.environ.get("DVIS_X3_RESERVE", "32")) if overlap else 0
+        prev_reserve = native.lib().dvis_x3_set_reserve(reserve) if overlap else 0
+        try:
+            yield from self._stream_rounds(videos, per_round, sharded_owner, overlap, main, side, phase_b, hand_over)
+        finally:
+            if overlap:
+                native.lib().dvis_x3_set_reserve(prev_reserve)
+
+    def _stream_rounds(self, videos, per_round, sharded_owner, overlap, main, side, phase_b, hand_over):
+        import itertools
         if overlap and self.stream_thread:
             yield from self._stream_threaded(videos, per_round, sharded_owner, main, phase_b, hand_over)
             return

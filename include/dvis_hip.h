@@ -456,6 +456,10 @@ int dvis_gemm_ln_pick_config(int M, int N, int K);
  * fragments [pass][k-step][row block][hi, lo][lane][8 halves]).  Once per weight.
  */
 int64_t dvis_x3_packed_bytes(int N, int K);
+/* The dvis_x3_* / dvis_conv*_x3 kernels are persistent (one workgroup per CU for the length of the launch).  A host that runs a
+ * second stream of small kernels next to them (DVIS_Plus_offline.stream(): the previous clip's tracker chain) leaves `cus` CUs
+ * (a multiple of 8) out of their grids; returns the previous setting.  Default 0 (env DVIS_X3_RESERVE). */
+int dvis_x3_set_reserve(int cus);
 int dvis_x3_pack(const float *W, int64_t ldw, int N, int K, int wexp, void *packed, void *stream);
 /* which (N, K) the projection kernels serve (ln != 0: the LayerNorm form) */
 int dvis_x3_linear_supported(int N, int K, int ln);
