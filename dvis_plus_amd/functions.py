@@ -696,7 +696,7 @@ def linear(x, weight, bias=None, relu=False, own=None):
     (hipBLASLt via torch._addmm_activation) instead of a second pass.  CPU tensors / autograd always take torch ops."""
     forced = own is True
     if X3 and not forced and x.is_cuda and x.numel() // max(1, x.shape[-1]) >= X3_MIN_ROWS and weight.dim() == 2 \
-            and weight._base is None and x3_ok(x, weight.shape[0], weight.shape[1]):
+            and weight._base is None and not torch.is_autocast_enabled() and x3_ok(x, weight.shape[0], weight.shape[1]):
         # tall projections (every pixel / every ViT token of every frame): split-f16 matrix-core kernel (csrc/gemm_x3.hip).
         # Weights that are views (slices made per call) would be re-packed per call: they stay on the paths below.
         return x3_linear(x, weight, bias, relu=relu)
