@@ -7,7 +7,9 @@
 //     each 32 consecutive pixels of one channel row per half-wave (a full 128-byte line), split in registers;
 //   * the input channels stream in chunks of 64 (32 loads): the chunk after the one being multiplied is in flight (the ring's
 //     counted wait leaves those 32 loads out), so the activations never wait behind the weights and vice versa;
-//   * weights: the pass's packed fragments through the 3-stage LDS ring (global_load_lds), one item = 2 k-steps x NB blocks;
+//   * weights: the pass's packed fragments through the LDS ring (global_load_lds): at 256 output channels per pass one item =
+//     one activation chunk (4 k-steps x 8 blocks = 64 KB, two stages, one barrier per 96 products of a wave), otherwise
+//     2 k-steps x NB blocks in three stages;
 //   * work items (pixel tile, channel pass) are dealt so that the passes of one pixel tile run at the same time on ONE XCD:
 //     the tile's activations come from HBM once, the other passes hit that XCD's L2;
 //   * epilogue in place: + folded-BN shift, + shortcut, ReLU; a store instruction writes 32 consecutive pixels of a channel
@@ -66,13 +68,15 @@ __device__ __forceinline__ unsigned cx_tap_offset(const CxArgs &a, const CxGeom 
   return ok ? gm.base + (unsigned)((iy * a.W_in + ix) * 4) : kOOB;
 }
 
-template <int NB, int NW>      // NW waves x 32 pixels per tile; 8 waves = two per SIMD (<= 256 registers each) cover each other's stalls
+// NW waves x 32 pixels per tile; 8 waves = two per SIMD (<= 256 registers each) cover each other's stalls.
+// IK k-steps per ring item: 2 (three stages) or 4 (= one activation chunk; two stages of up to 64 KB: half the barriers).
+template <int NB, int NW, int IK>
 __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
-  constexpr int kTile = NW * 32, PW = 4 * NB / NW;
-  static_assert(4 * NB % NW == 0, "the item's pieces must divide among the waves");
+  constexpr int kTile = NW * 32, PW = 2 * IK * NB / NW, STAGES = IK == 4 ? 2 : 3, IPC = 4 / IK;
+  static_assert(2 * IK * NB % NW == 0, "the item's pieces must divide among the waves");
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
-  const int NCC = a.C / 64, NC = a.taps * NCC, NI = 2 * NC;   // chunks per tap, chunks and ring items per work item
+  const int NCC = a.C / 64, NC = a.taps * NCC, NI = IPC * NC;   // chunks per tap, chunks and ring items per work item
   long long wcount = 0;
   {
     long long t;
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
   const __amdgpu_buffer_rsrc_t rr = dvis_make_rsrc_uniform(a.res ? a.res : a.y, (unsigned)((long long)a.N * a.K * a.HW * 4));
   const unsigned chan = (unsigned)(a.HW_in * 4);              // bytes between two input channels of a pixel
 
-  typedef Ring<PW, 32, NW> RingT;
+  typedef Ring<PW, 32, NW, STAGES> RingT;
   RingT ring;
   // issue cursor: where the next item to request lives
   long long iw = 0;
@@ -103,10 +107,10 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
     }
     return o;
   };
-  ring.src = (const char *)a.wp, ring.lds = lds, ring.period = 1, ring.total = (int)(wcount * NI), ring.it = 0, ring.st_cmp = 0;
-  ring.st_iss = 0, ring.wave = wave, ring.lane = lane;
-  ring.issue_at(next_offset());
-  if (ring.total > 1) ring.issue_at(next_offset());
+  ring.init(a.wp, lds, 1, (int)(wcount * NI), wave, lane);
+#pragma unroll
+  for (int i = 0; i < RingT::kAhead; ++i)
+    if (ring.total > i) ring.issue_at(next_offset());
 
   // activation chunk = 64 channels of the lane's pixel: k-step s, element e -> channel 16 s + 8 g + e
   float raw[32];
@@ -159,10 +163,10 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
       if (++cc == NCC) cc = 0, ++tap;
       load_raw(kc + 1 < NC ? cx_tap_offset(a, gm, tap) : cx_tap_offset(a, ngm, 0), kc + 1 < NC ? cc : 0);
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
+      for (int part = 0; part < IPC; ++part) {
         const char *stage = ring.wait(false);
-        ring.begin(ring.it + 1 < ring.total ? next_offset() : 0);
-        mma_item<2, NB, PW>(stage, lane, acc, xh + 2 * half, xl + 2 * half, [&](int i) { ring.piece(i); });
+        ring.begin(ring.more() ? next_offset() : 0);
+        mma_item<IK, NB, PW>(stage, lane, acc, xh + IK * part, xl + IK * part, [&](int i) { ring.piece(i); });
       }
     }
     // epilogue: lane = pixel; registers = channels co0 + 32 nb + 8 q + 4 g + i
@@ -267,22 +271,25 @@ static int cx_launch(const float *x, const void *packed, const float *bias, cons
   hipStream_t st = (hipStream_t)stream;
   static const int nw = getenv("DVIS_X3_CONV_WAVES") ? atoi(getenv("DVIS_X3_CONV_WAVES")) : 8;
   a.npass = K <= 128 ? 1 : K / 256;
-#define DVIS_CX_LAUNCH(NBV, NWV)                                                                                   \
+#define DVIS_CX_LAUNCH(NBV, NWV, IKV)                                                                              \
   {                                                                                                                \
     static DvisLdsOptIn opted;                                                                                     \
-    typedef Ring<4 * NBV / NWV, 32, NWV> R;                                                                        \
+    typedef Ring<2 * IKV * NBV / NWV, 32, NWV, (IKV == 4 ? 2 : 3)> R;                                              \
     a.tiles = (a.pixels + 32 * NWV - 1) / (32 * NWV);                                                              \
-    const size_t lds = kStages * R::kItemBytes;                                                                    \
-    const int rc = dvis_lds_opt_in((const void *)conv1x1_x3_kernel<NBV, NWV>, lds, &opted, "dvis_conv1x1_x3");     \
+    const size_t lds = (IKV == 4 ? 2 : 3) * R::kItemBytes;                                                         \
+    const int rc = dvis_lds_opt_in((const void *)conv1x1_x3_kernel<NBV, NWV, IKV>, lds, &opted, "dvis_conv1x1_x3"); \
     if (rc != DVIS_OK) return rc;                                                                                  \
-    hipLaunchKernelGGL((conv1x1_x3_kernel<NBV, NWV>), dim3(grid), dim3(NWV * 64), lds, st, a);                     \
+    hipLaunchKernelGGL((conv1x1_x3_kernel<NBV, NWV, IKV>), dim3(grid), dim3(NWV * 64), lds, st, a);                \
   }
+  static const int ik = getenv("DVIS_X3_CONV_ITEM") ? atoi(getenv("DVIS_X3_CONV_ITEM")) : 4;   // (2: three stages of 32 KB, 2 - 5 % slower)
   if (K == 64) {
-    if (nw == 8) DVIS_CX_LAUNCH(2, 8) else DVIS_CX_LAUNCH(2, 4)
+    if (nw == 8) DVIS_CX_LAUNCH(2, 8, 2) else DVIS_CX_LAUNCH(2, 4, 2)
   } else if (K == 128) {
-    if (nw == 8) DVIS_CX_LAUNCH(4, 8) else DVIS_CX_LAUNCH(4, 4)
+    if (nw == 8) DVIS_CX_LAUNCH(4, 8, 2) else DVIS_CX_LAUNCH(4, 4, 2)
+  } else if (ik == 4) {
+    DVIS_CX_LAUNCH(8, 8, 4)
   } else {
-    if (nw == 8) DVIS_CX_LAUNCH(8, 8) else DVIS_CX_LAUNCH(8, 4)
+    if (nw == 8) DVIS_CX_LAUNCH(8, 8, 2) else DVIS_CX_LAUNCH(8, 4, 2)
   }
 #undef DVIS_CX_LAUNCH
   return dvis_check_launch("dvis_conv1x1_x3");

@@ -12,18 +12,24 @@
 //
 // Decomposition (not the reference's, which calls cuBLAS through nn.Linear): everything is computed TRANSPOSED,
 //     out^T (n, token) = W (n, k) x^T (k, token):   MFMA "A" operand = weight fragment, "B" operand = activations.
-// A wave owns 32 tokens (the MFMA columns, lane & 31 = token) and ALL output features of them, so
+// A wave owns 32 tokens (the MFMA columns, lane & 31 = token) and ALL output features of a pass, so
 //   * a token's features are the 16 accumulator registers x NB blocks of ONE lane pair (l, l ^ 32): LayerNorm statistics are
 //     an in-lane sum + one exchange — no cross-wave reduction, no LDS;
-//   * the activations are read ONCE per tile, straight from memory in fragment shape (32 B per lane and k-step), split in
-//     registers and kept there for the whole K (K = 256: 128 registers per lane): no activation staging, no redundant split;
+//   * the activations are read straight from memory in fragment shape (32 B per lane and k-step) and split in registers: no
+//     activation staging in LDS, no redundant split;
 //   * the FFN's hidden block comes out of phase 1 already in the layout phase 2 wants as its "B" operand — the k-order of an
 //     MFMA is free as long as both operands agree, and the packed W2 fragments are stored in ACCUMULATOR order — so
 //     linear1 -> ReLU -> linear2 -> + residual -> LayerNorm is one kernel and the 2.4 GB hidden tensor never exists.
 // Weights are split and packed once (dvis_x3_pack*) into the exact LDS image: fragments of 1 KB (64 lanes x 16 B), streamed
-// with global_load_lds_dwordx4 (no VGPR round trip) through a 3-stage ring of 32 - 36 KB items shared by the 4 waves of a
-// workgroup; one raw s_barrier per item, counted vmcnt so that the next item stays in flight across it.
-// 256 threads, one workgroup per CU (up to 512 VGPR + AGPR per lane: accumulators 128 - 192, activation fragments 128).
+// with global_load_lds_dwordx4 (no VGPR round trip) through a ring of 32 - 36 KB items shared by the waves of a workgroup
+// (x3_common.h); one raw s_barrier per item, counted vmcnt so that the next item stays in flight across it.
+// Three kernels, all persistent (one workgroup per CU, dvis_x3_set_reserve CUs left out):
+//   x3_linear_stream_kernel  projections (+ residual + LayerNorm (+ pos)): 8 waves = two per SIMD at <= 256 registers, the
+//                            activations streamed in chunks of 64 k with the next chunk in flight; any K % 64 == 0;
+//   x3_linear_kernel         the 288-column projection (9 blocks do not divide among 8 waves): 4 waves, the row's fragments
+//                            resident (K = 256: 128 registers per lane);
+//   x3_ffn_kernel            linear1 + ReLU + linear2 + residual + LayerNorm: 4 waves at 512 registers (fragments of the row
+//                            128, accumulators 128 + 64, hidden fragments 64).
 #include "dvis_common.h"
 #include "x3_common.h"
 

@@ -85,80 +85,61 @@ namespace {
 
 // EXTRA: ordinary loads the kernel keeps in flight, issued between an item's pieces and the next-but-one item's (the
 // activation prefetch of csrc/conv1x1_x3.hip): they are newer than the item waited for, so the counted wait leaves them out too.
-template <int PW, int EXTRA = 0, int NW = kWaves>      // PW: 1 KB pieces per wave and item (item bytes = NW * PW * 1024)
+template <int PW, int EXTRA = 0, int NW = kWaves, int STAGES = kStages>      // PW: 1 KB pieces per wave and item (item bytes = NW * PW * 1024)
 struct Ring {
   const char *src;
   char *lds;
   int period, total, it, st_cmp, st_iss, wave, lane;
   static constexpr int kItemBytes = NW * PW * kPiece;
+  static constexpr int kAhead = STAGES - 1;                 // items requested ahead of the one being multiplied
+  static constexpr int kLeave = (STAGES - 2) * PW + EXTRA;  // loads newer than the item waited for that may stay in flight
 
-  __device__ __forceinline__ void issue(int item) { issue_at((size_t)(item % period) * kItemBytes); }
   __device__ __forceinline__ void issue_at(size_t byte_offset) {
     const char *g = src + byte_offset + lane * 16;
     char *l = lds + st_iss * kItemBytes;
 #pragma unroll
     for (int p = 0; p < PW; ++p) glds16(g + (wave + NW * p) * kPiece, l + (wave + NW * p) * kPiece);
-    st_iss = st_iss + 1 == kStages ? 0 : st_iss + 1;
+    st_iss = st_iss + 1 == STAGES ? 0 : st_iss + 1;
   }
-  __device__ __forceinline__ void start(const void *stream, char *ring, int period_, int total_, int wave_, int lane_) {
+  __device__ __forceinline__ void init(const void *stream, char *ring, int period_, int total_, int wave_, int lane_) {
     src = (const char *)stream, lds = ring, period = period_, total = total_, it = 0, st_cmp = 0, st_iss = 0;
     wave = wave_, lane = lane_;
-    if (total > 0) issue(0);
-    if (total > 1) issue(1);
   }
-  // Make item `it` readable by every wave and put item it + 2 in flight.  drain: other vector-memory work (activation
-  // loads, the previous tile's stores) may be outstanding — wait for everything.
-  __device__ __forceinline__ const char *acquire(bool drain) {
-    if (drain || it + 1 >= total)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW + EXTRA) : "memory");
-    __builtin_amdgcn_s_barrier();
-    if (it + 2 < total) issue(it + 2);
-    const char *stage = lds + st_cmp * kItemBytes;
-    st_cmp = st_cmp + 1 == kStages ? 0 : st_cmp + 1;
-    ++it;
-    return stage;
+  __device__ __forceinline__ void start(const void *stream, char *ring, int period_, int total_, int wave_, int lane_) {
+    init(stream, ring, period_, total_, wave_, lane_);
+#pragma unroll
+    for (int i = 0; i < kAhead; ++i)
+      if (total > i) issue_at((size_t)(i % period) * kItemBytes);
   }
-  // The two halves of acquire for callers that spread the requests over the products (mma_item's dma):
-  //   stage = ring.wait(drain); ring.begin(offset of item it + 1 ... i.e. the item two after the one just waited for);
-  //   mma_item<..., PW>(stage, ..., [&](int i) { ring.piece(i); });
+  // Make item `it` readable by every wave: wait for this wave's pieces of it (the kLeave newer loads stay in flight), then the
+  // barrier.  drain: other vector-memory work (activation loads, the previous tile's stores) may be outstanding, or fewer
+  // items than assumed are in flight — wait for everything.
+  //   stage = ring.wait(drain); ring.begin(offset of the item kAhead after the one just waited for);
+  //   mma_item<..., PW>(stage, ..., [&](int i) { ring.piece(i); });        // its requests, spread over the products
   __device__ __forceinline__ const char *wait(bool drain) {
-    if (drain || it + 1 >= total)
+    if (drain || it + kAhead > total)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW + EXTRA) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLeave) : "memory");
     __builtin_amdgcn_s_barrier();
     const char *stage = lds + st_cmp * kItemBytes;
-    st_cmp = st_cmp + 1 == kStages ? 0 : st_cmp + 1;
+    st_cmp = st_cmp + 1 == STAGES ? 0 : st_cmp + 1;
     ++it;
     return stage;
   }
   const char *dma_src;
   char *dma_dst;
   bool dma_on;
+  __device__ __forceinline__ bool more() const { return it + kAhead - 1 < total; }      // after wait(): is there an item to request?
   __device__ __forceinline__ void begin(size_t byte_offset) {       // after wait(): `it` already counts the waited item
-    dma_on = it + 1 < total;
+    dma_on = more();
     dma_src = src + byte_offset + lane * 16 + wave * kPiece;
     dma_dst = lds + st_iss * kItemBytes + wave * kPiece;
-    if (dma_on) st_iss = st_iss + 1 == kStages ? 0 : st_iss + 1;
+    if (dma_on) st_iss = st_iss + 1 == STAGES ? 0 : st_iss + 1;
   }
-  __device__ __forceinline__ void begin_periodic() { begin((size_t)((it + 1) % period) * kItemBytes); }
+  __device__ __forceinline__ void begin_periodic() { begin((size_t)((it + kAhead - 1) % period) * kItemBytes); }
   __device__ __forceinline__ void piece(int i) {
     if (dma_on) glds16(dma_src + i * (NW * kPiece), dma_dst + i * (NW * kPiece));
-  }
-  // the same with the caller naming where item it + 2 lives in the packed stream (a sequence that is not periodic)
-  __device__ __forceinline__ const char *acquire_at(bool drain, size_t next2_byte_offset) {
-    if (drain || it + 1 >= total)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW + EXTRA) : "memory");
-    __builtin_amdgcn_s_barrier();
-    if (it + 2 < total) issue_at(next2_byte_offset);
-    const char *stage = lds + st_cmp * kItemBytes;
-    st_cmp = st_cmp + 1 == kStages ? 0 : st_cmp + 1;
-    ++it;
-    return stage;
   }
 };
 

@@ -294,3 +294,21 @@ def test_conv3x3_x3(Ci, Co, H, W, stride, N, relu):
     xi = torch.randint(-9, 10, (N, Ci, H, W), device=DEV).float()
     wi = torch.randint(-2, 3, (Co, Ci, 3, 3), device=DEV).float()
     assert torch.equal(Fn.conv3x3_x3(xi, wi, None, None, False, stride), F.conv2d(xi.double(), wi.double(), None, stride, 1).float())
+
+
+def test_reserved_cus_do_not_change_bits():
+    """dvis_x3_set_reserve only changes how many persistent workgroups share the tiles: same bits for every reserve."""
+    from dvis_plus_amd import functions as Fn, native
+    l1, l2, norm = _lin(256, 1024, 41, 0.5), _lin(1024, 256, 42, 0.5), _norm(256, 43)
+    x = torch.randn(40000, 256, device=DEV)
+    xc = torch.randn(2, 256, 46, 80, device=DEV)
+    w = torch.randn(256, 256, 3, 3, device=DEV) * 0.03
+    lib = native.lib()
+    prev = lib.dvis_x3_set_reserve(0)
+    try:
+        a, c = Fn.x3_ffn_ln(x, l1, l2, norm), Fn.conv3x3_x3(xc, w, None, None, True, 1)
+        for r in (8, 32, 200, 1000):
+            assert lib.dvis_x3_set_reserve(r) in (0, 8, 32, 200)
+            assert torch.equal(Fn.x3_ffn_ln(x, l1, l2, norm), a) and torch.equal(Fn.conv3x3_x3(xc, w, None, None, True, 1), c)
+    finally:
+        lib.dvis_x3_set_reserve(prev)
