@@ -228,7 +228,40 @@ __global__ __launch_bounds__(256) void nchw_to_tokens_kernel(const float *__rest
   }
 }
 
+// The way back: out[n][c][p] = tok[n][row0 + p][c] — one level of the encoder's token matrix as the (N, C, h, w) map the FPN's
+// top-down path reads (msdeformattn.py:333-339 `y[:, :, ...].transpose(1, 2).view(bs, -1, h, w)`; the reference leaves it a
+// strided view and pays in the consumer).  64 x 64 tiles through LDS: reads run along c, writes along p.
+__global__ __launch_bounds__(256) void tokens_to_nchw_kernel(const float *__restrict__ tok, float *__restrict__ out, int C, int HW,
+                                                             int64_t S, int64_t row0) {
+  __shared__ float tile[64][65];
+  const int n = blockIdx.z, c0 = blockIdx.y * 64, p0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const float *tb = tok + ((size_t)n * S + row0) * C;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int p = p0 + ty + 4 * i, c = c0 + tx;
+    tile[ty + 4 * i][tx] = (p < HW && c < C) ? tb[(size_t)p * C + c] : 0.f;
+  }
+  __syncthreads();
+  float *ob = out + (size_t)n * C * HW;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty + 4 * i, p = p0 + tx;
+    if (c < C && p < HW) ob[(size_t)c * HW + p] = tile[tx][ty + 4 * i];
+  }
+}
+
 }  // namespace
+
+DVIS_EXPORT int dvis_tokens_to_nchw(const float *tok, float *out, int64_t N, int C, int64_t HW, int64_t S, int64_t row0, void *stream) {
+  DVIS_REQUIRE(N >= 0 && C > 0 && HW > 0 && S >= HW && row0 >= 0 && row0 + HW <= S, "tokens_to_nchw: bad sizes");
+  if (N == 0) return DVIS_OK;
+  DVIS_REQUIRE(tok && out, "tokens_to_nchw: null pointer");
+  DVIS_REQUIRE(N <= 65535 && (C + 63) / 64 <= 65535 && HW < (1ll << 31), "tokens_to_nchw: grid too large");
+  hipLaunchKernelGGL(tokens_to_nchw_kernel, dim3((unsigned)((HW + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)N), dim3(256), 0,
+                     (hipStream_t)stream, tok, out, C, (int)HW, S, row0);
+  return dvis_check_launch("tokens_to_nchw_kernel");
+}
 
 static int nchw_to_tokens_launch(const float *x, float *out, int64_t N, int C, int64_t HW, int64_t S, int64_t row0,
                                  const float *scale, const float *shift, const float *pos, float *out_pos, void *stream) {

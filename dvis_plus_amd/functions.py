@@ -893,6 +893,20 @@ def maps_to_tokens(maps, affines=None, pos=None):
     return out if pos is None else (out, out_pos)
 
 
+def tokens_to_map(tokens, row0, h, w):
+    """``tokens[:, row0 : row0 + h * w].transpose(1, 2).reshape(N, C, h, w)`` as a CONTIGUOUS map (tokens: (N, S, C) float32):
+    one tiled transpose (dvis_tokens_to_nchw) instead of the strided view whose consumer copies it with torch's generic kernel
+    (452 MB at the finest encoder level of 30 frames: 0.75 ms).  CPU / other dtypes / autograd: the view."""
+    N, S, C = tokens.shape
+    if not (tokens.is_cuda and tokens.dtype == torch.float32 and tokens.is_contiguous() and not torch.is_grad_enabled()):
+        return tokens[:, row0:row0 + h * w].transpose(1, 2).reshape(N, C, h, w)
+    out = torch.empty((N, C, h, w), dtype=torch.float32, device=tokens.device)
+    with torch.cuda.device(tokens.device):
+        native.check(native.lib().dvis_tokens_to_nchw(ctypes.c_void_p(tokens.data_ptr()), ctypes.c_void_p(out.data_ptr()), N, C, h * w,
+                                                      S, row0, native.stream_ptr(tokens.device)), "dvis_tokens_to_nchw")
+    return out
+
+
 def conv1x1(x, weight, bias=None):
     """1x1 stride-1 convolution on NCHW.  On the GPU a channel-REDUCING 1x1 conv (Ci >= Co) is issued as the batched
     library GEMM W (Co,Ci) @ X (N,Ci,HW) instead of a MIOpen convolution: same contraction, same layout, measured on

@@ -511,9 +511,12 @@ class MSDeformAttnPixelDecoder(nn.Module):
             y, _, _, shapes_py = self.transformer(srcs, pos, affines)
             bs = y.shape[0]
             out, tokens, start = [], [], 0
-            for (h, w) in shapes_py:
+            for li, (h, w) in enumerate(shapes_py):
                 tokens.append(y[:, start:start + h * w])
-                out.append(tokens[-1].transpose(1, 2).reshape(bs, -1, h, w))      # a strided view, no copy
+                if li + 1 == len(shapes_py) and self.num_fpn_levels > 0:
+                    out.append(Fn.tokens_to_map(y, start, h, w))    # the FPN's top-down path reads this one: a real map
+                else:
+                    out.append(tokens[-1].transpose(1, 2).reshape(bs, -1, h, w))  # a strided view, no copy
                 start += h * w
             for idx, f in enumerate(self.in_features[:self.num_fpn_levels][::-1]):
                 x = features[f].float().contiguous()      # NCHW for the fused FPN path (no-op for the R50's maps)

@@ -240,6 +240,9 @@ int dvis_nchw_to_tokens(const float *x, float *out, int64_t N, int C, int64_t HW
  * out_pos[n][row0 + p][c] = out[n][row0 + p][c] + pos[row0 + p][c] (pos: (S, C) token-major position + level embedding;
  * the first encoder layer's query, msdeformattn.py:121-123; NULL pair = not written).
  */
+/* The way back for one level: out (N, C, HW) = tok[:, row0 : row0 + HW, :] transposed (tok: (N, S, C)) — the encoder output
+ * as the map the FPN's top-down path reads, msdeformattn.py:333-339 (+ :347). */
+int dvis_tokens_to_nchw(const float *tok, float *out, int64_t N, int C, int64_t HW, int64_t S, int64_t row0, void *stream);
 int dvis_nchw_to_tokens_affine(const float *x, const float *scale, const float *shift, const float *pos, float *out,
                                float *out_pos, int64_t N, int C, int64_t HW, int64_t S, int64_t row0, void *stream);
 

@@ -183,3 +183,13 @@ def test_zero_size_batches_pass_through_every_glue_op():
         sc, sh = Fn.group_norm_affine(z(0, 8, 4, 8), gn)
         assert sc.numel() == 0 and sh.numel() == 0
         assert Fn.scale_shift_act_(z(0, 8, 4, 8), sc, sh, relu=True).shape == (0, 8, 4, 8)
+
+
+@pytest.mark.parametrize("N,S,C,row0,h,w", [(2, 300, 256, 60, 12, 20), (1, 77, 96, 0, 7, 11), (3, 1000, 32, 500, 20, 25)])
+def test_tokens_to_map_equals_the_strided_view(N, S, C, row0, h, w):
+    """dvis_tokens_to_nchw: one level of the encoder's token matrix as a contiguous (N, C, h, w) map (msdeformattn.py:333-339)."""
+    from dvis_plus_amd import functions as Fn
+    tok = torch.randn(N, S, C, device="cuda")
+    with torch.no_grad():
+        got = Fn.tokens_to_map(tok, row0, h, w)
+    assert got.is_contiguous() and torch.equal(got, tok[:, row0:row0 + h * w].transpose(1, 2).reshape(N, C, h, w))
