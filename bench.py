@@ -274,10 +274,12 @@ def warmup_clip_count(warmup, steps, world, owner_rounds, streamed, tracker_batc
     return k * size + r
 
 
-def calibrate_threshold(model, inputs, candidates):
+def calibrate_threshold(model, inputs, candidates, slack=0):
     """Random-init class logits are near-uniform (max prob ~ 1/125), so the reference's 0.8 score threshold would keep no
     query and the panoptic stage would be skipped.  One untimed pass finds the score threshold that sends `candidates`
-    queries of THIS clip there (mid-way between the k-th and the (k+1)-th best non-void score)."""
+    queries of THIS clip there (mid-way between the k-th and the (k+1)-th best non-void score).  slack > 0 (comparisons
+    between schedules / against the oracle): k anywhere in candidates +- slack, at the LARGEST gap between neighbouring scores
+    — neighbouring random-init scores can sit 1e-7 apart, and a threshold between two such scores is decided by rounding."""
     from dvis_plus_amd import postprocess as PP
     seen = {}
     orig_sel = PP.vps_select
@@ -296,6 +298,10 @@ def calibrate_threshold(model, inputs, candidates):
     if candidates >= s.numel():
         return 0.0                             # every non-void query
     k = max(0, min(candidates, s.numel() - 1))
+    if slack > 0 and k > 0:
+        lo, hi = max(1, k - slack), min(s.numel() - 1, k + slack)
+        gaps = s[lo - 1:hi] - s[lo:hi + 1]
+        k = lo + int(gaps.argmax())
     return float((s[k - 1] + s[k]) / 2) if k > 0 else 2.0
 
 

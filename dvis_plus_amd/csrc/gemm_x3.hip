@@ -39,12 +39,18 @@ namespace {
 
 // Activation fragments of a wave's 32 tokens for K = 16 * KS, natural k order: lane (token j, half g) holds
 // x[token][16 S + 8 g + 0..7] for k-step S.
+// addp: NULL or the row of an embedding added in front of the split (x + pos is never written).
 template <int KS>
-__device__ __forceinline__ void load_x(const float *x, int64_t ldx, int64_t row, int g, float s, h8 *xh, h8 *xl) {
+__device__ __forceinline__ void load_x(const float *x, int64_t ldx, int64_t row, int g, float s, h8 *xh, h8 *xl,
+                                       const float *addp = nullptr) {
   const float *p = x + row * ldx + 8 * g;
   f4 raw[2 * KS];
 #pragma unroll
   for (int S = 0; S < KS; ++S) raw[2 * S] = *(const f4 *)(p + 16 * S), raw[2 * S + 1] = *(const f4 *)(p + 16 * S + 4);
+  if (addp != nullptr) {
+#pragma unroll
+    for (int S = 0; S < KS; ++S) raw[2 * S] += *(const f4 *)(addp + 16 * S), raw[2 * S + 1] += *(const f4 *)(addp + 16 * S + 4);
+  }
 #pragma unroll
   for (int S = 0; S < KS; ++S) split8(raw[2 * S], raw[2 * S + 1], s, xh[S], xl[S]);
 }
@@ -181,7 +187,8 @@ __device__ __forceinline__ void epilogue(f16v *acc, const EpiArgs &e, const floa
 // same activation fragments.  Weight stream: [pass][K / 32 items of 2 k-steps x NB blocks].
 template <int K, int NB, bool LN>
 __global__ __launch_bounds__(kThreads) void x3_linear_kernel(const float *__restrict__ x, int64_t ldx, int64_t M,
-                                                             const void *__restrict__ wp, float xscale, int npass, EpiArgs e) {
+                                                             const void *__restrict__ wp, float xscale, int npass,
+                                                             const float *__restrict__ xadd, int64_t xadd_rows, EpiArgs e) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   constexpr int KS = K / 16, NI = K / 32;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(kThreads) void x3_linear_kernel(const float *__rest
     const int64_t tok0 = tile * kTileTok + wave * 32;
     const int64_t row = tok0 + j < M ? tok0 + j : M - 1;
     h8 xh[KS], xl[KS];
-    load_x<KS>(x, ldx, row, g, xscale, xh, xl);
+    load_x<KS>(x, ldx, row, g, xscale, xh, xl, xadd ? xadd + (row % xadd_rows) * K + 8 * g : nullptr);
     for (int pass = 0; pass < npass; ++pass) {
       f16v acc[NB];
 #pragma unroll
@@ -481,8 +488,25 @@ DVIS_EXPORT int dvis_x3_pack(const float *w, int64_t ldw, int N, int K, int wexp
   return dvis_check_launch("dvis_x3_pack");
 }
 
+static int x3_linear_impl(const float *x, int64_t ldx, int64_t M, int K, const void *wp, int N, int xexp, int wexp, const float *xadd,
+                          int64_t xadd_rows, const float *bias, int relu, float *out, int64_t ldo, void *stream);
+
 DVIS_EXPORT int dvis_x3_linear(const float *x, int64_t ldx, int64_t M, int K, const void *wp, int N, int xexp, int wexp,
                                const float *bias, int relu, float *out, int64_t ldo, void *stream) {
+  return x3_linear_impl(x, ldx, M, K, wp, N, xexp, wexp, nullptr, 0, bias, relu, out, ldo, stream);
+}
+
+DVIS_EXPORT int dvis_x3_linear_add(const float *x, int64_t ldx, int64_t M, int K, const void *wp, int N, int xexp, int wexp,
+                                   const float *xadd, int64_t xadd_rows, const float *bias, int relu, float *out, int64_t ldo,
+                                   void *stream) {
+  DVIS_REQUIRE(xadd && xadd_rows > 0 && (uintptr_t)xadd % 16 == 0, "dvis_x3_linear_add: xadd (xadd_rows x K, 16-byte aligned) is required");
+  DVIS_REQUIRE(K == 256 && (N == 128 || N == 192 || N == 256 || N == 288),
+               "dvis_x3_linear_add: served for K = 256, N in 128 / 192 / 256 / 288 (N %d, K %d)", N, K);
+  return x3_linear_impl(x, ldx, M, K, wp, N, xexp, wexp, xadd, xadd_rows, bias, relu, out, ldo, stream);
+}
+
+static int x3_linear_impl(const float *x, int64_t ldx, int64_t M, int K, const void *wp, int N, int xexp, int wexp, const float *xadd,
+                          int64_t xadd_rows, const float *bias, int relu, float *out, int64_t ldo, void *stream) {
   DVIS_REQUIRE(dvis_x3_linear_supported(N, K, 0), "dvis_x3_linear: (N, K) = (%d, %d) is not served (K %% 64 == 0; N in 128 / 192 / 256 or N %% 256 == 0; N = 288 at K = 256)", N, K);
   const int rc = x3_check_common(x, ldx, M, wp, out, ldo);
   if (rc != DVIS_OK) return rc;
@@ -505,16 +529,27 @@ DVIS_EXPORT int dvis_x3_linear(const float *x, int64_t ldx, int64_t M, int K, co
                        npass, e);                                                                                    \
     return dvis_check_launch(WHAT);                                                                                  \
   }
+#define DVIS_X3_RESIDENT(NBV)                                                                                        \
+  {                                                                                                                  \
+    static DvisLdsOptIn opted;                                                                                       \
+    return x3_launch(x3_linear_kernel<256, NBV, false>, &opted, kStages * Ring<NBV>::kItemBytes + kWaves * kScratch + (size_t)N * 4, \
+                     M, st, "dvis_x3_linear", x, ldx, M, wp, xs, npass, xadd, xadd_rows, e);                         \
+  }
+  if (xadd) {      // the resident-fragment kernel adds the embedding while it builds the row's fragments (K = 256)
+    switch (NB) {
+      case 4: DVIS_X3_RESIDENT(4)
+      case 6: DVIS_X3_RESIDENT(6)
+      case 8: DVIS_X3_RESIDENT(8)
+      default: DVIS_X3_RESIDENT(9)
+    }
+  }
   switch (NB) {
     case 4: DVIS_X3_STREAM(4, false, "dvis_x3_linear", (size_t)N * 4)
     case 6: DVIS_X3_STREAM(6, false, "dvis_x3_linear", (size_t)N * 4)
     case 8: DVIS_X3_STREAM(8, false, "dvis_x3_linear", (size_t)N * 4)
-    default: {
-      static DvisLdsOptIn opted;
-      return x3_launch(x3_linear_kernel<256, 9, false>, &opted, kStages * Ring<9>::kItemBytes + kWaves * kScratch + (size_t)N * 4, M, st,
-                       "dvis_x3_linear", x, ldx, M, wp, xs, npass, e);
-    }
+    default: DVIS_X3_RESIDENT(9)
   }
+#undef DVIS_X3_RESIDENT
 }
 
 DVIS_EXPORT int dvis_x3_linear_ln(const float *x, int64_t ldx, int64_t M, int K, const void *wp, int N, int xexp, int wexp,

@@ -782,12 +782,25 @@ def _x3_rows(x, name):
     return x2, ld
 
 
-def x3_linear(x, weight, bias, relu=False, xexp=None):
-    """``relu?(x @ weight.T + bias)`` through dvis_x3_linear.  x (..., 256) float32 GPU; weight (N, 256)."""
+def x3_linear(x, weight, bias, relu=False, xexp=None, xadd=None):
+    """``relu?((x + xadd) @ weight.T + bias)`` through dvis_x3_linear[_add].  x (..., K) float32 GPU; weight (N, K); xadd: None or
+    a (1, S, 256) / (S, 256) embedding for x of shape (B, S, 256), broadcast over B — added inside the kernel while it builds the
+    row's fragments, the sum is never written (N in 128 / 192 / 256 / 288)."""
     N, K = weight.shape
     x2, ldx = _x3_rows(x, "x")
     buf, wexp = x3_pack(weight)
     out = torch.empty((*x.shape[:-1], N), dtype=torch.float32, device=x.device)
+    if xadd is not None:
+        if x.dim() != 3 or xadd.numel() != x.shape[1] * K or xadd.dtype != torch.float32 or not xadd.is_cuda:
+            raise RuntimeError("x3_linear: xadd must be a float32 GPU (S, K) embedding for x of shape (B, S, K)")
+        xadd = xadd.contiguous()
+        with torch.cuda.device(x.device):
+            native.check(native.lib().dvis_x3_linear_add(
+                ctypes.c_void_p(x2.data_ptr()), ldx, x2.shape[0], K, ctypes.c_void_p(buf.data_ptr()), N,
+                X3_XEXP if xexp is None else xexp, wexp, ctypes.c_void_p(xadd.data_ptr()), x.shape[1],
+                None if bias is None else native.dev_ptr(bias.detach(), "bias"), int(relu), ctypes.c_void_p(out.data_ptr()), N,
+                native.stream_ptr(x.device)), "dvis_x3_linear_add")
+        return out
     with torch.cuda.device(x.device):
         native.check(native.lib().dvis_x3_linear(
             ctypes.c_void_p(x2.data_ptr()), ldx, x2.shape[0], K, ctypes.c_void_p(buf.data_ptr()), N,

@@ -215,9 +215,13 @@ class MSDeformAttn(nn.Module):
             if query_pos is not None and query_pos.shape[0] == 1 and _POS_IN_KERNEL and not lowp:
                 pp = Fn.linear(query_pos[0], w)                                    # (Lq, 3*M*L*P): tiny, once per call
                 po, pl = pp[:, o_off:], pp[:, l_off:]
-            elif query_pos is not None:
+            elif query_pos is not None and not (x3 and query_pos.shape[0] == 1 and query.dim() == 3):
                 query = query + query_pos
-            if x3:
+                query_pos = None
+            if x3 and query_pos is not None and po is None:
+                # `with_pos_embed(src, pos)` inside the projection kernel: the (N, Lq, C) sum is never written
+                proj = Fn.x3_linear(query, self._fused[4], self._fused[5], xadd=query_pos).view(N * Len_q, -1)
+            elif x3:
                 proj = Fn.x3_linear(query.reshape(N * Len_q, self.d_model), self._fused[4], self._fused[5])
             else:
                 proj = Fn.linear(query.reshape(N * Len_q, self.d_model), w, b)     # offsets | logits in one GEMM
@@ -264,12 +268,23 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         self.norm2 = nn.LayerNorm(d_model)
         self.dropout_p = dropout     # inference path: dropout is the identity
 
+    def pos_in_projection(self, src, pos):
+        """True when `with_pos_embed(src, pos)` is formed inside the offsets | logits projection kernel (dvis_x3_linear_add): no
+        layer then needs the (N, S, C) tensor src + pos, neither from the previous layer nor from maps_to_tokens."""
+        a = self.self_attn
+        return bool(Fn.X3 and pos is not None and pos.dim() == 3 and pos.shape[0] == 1 and src.dim() == 3 and src.is_cuda
+                    and src.dtype == torch.float32 and not torch.is_grad_enabled() and not torch.is_autocast_enabled()
+                    and not _POS_IN_KERNEL and not _MSDA_SLOTS and not _MSDA_HM and a.d_model == 256
+                    and 3 * a.n_heads * a.n_levels * a.n_points in (128, 192, 256, 288) and a.d_model // a.n_heads in (32, 64)
+                    and (a.n_levels, a.n_points) in ((1, 4), (3, 4), (4, 4)))
+
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None,
                 shapes_py=None, query=None, emit_next_query=False):
         """Reference signature + three optional extras (shapes_py: see MSDeformAttn.forward).  `query`: src + pos when
         the previous layer already wrote it; emit_next_query: return (out, out + pos), the sum written by the final
         add+LayerNorm kernel — the encoder then never runs an add pass for `with_pos_embed` after the first layer."""
-        if query is not None:
+        pos_in_proj = self.pos_in_projection(src, pos)
+        if query is not None and not pos_in_proj:
             src = self.self_attn(query, reference_points, src, spatial_shapes, level_start_index, padding_mask,
                                  spatial_shapes_py=shapes_py, post=(src, self.norm1))
         else:
@@ -277,7 +292,7 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
                                  spatial_shapes_py=shapes_py, query_pos=pos, post=(src, self.norm1))
         if Fn.X3 and Fn.x3_ffn_ok(src, self.linear1, self.linear2) and self.norm2.weight is not None:
             # linear1 -> ReLU -> linear2 -> + src -> norm2 (-> + pos) in one kernel; the hidden tensor stays on chip
-            with_pos = emit_next_query and pos is not None and pos.shape[0] == 1 and src.dim() == 3
+            with_pos = emit_next_query and pos is not None and pos.shape[0] == 1 and src.dim() == 3 and not pos_in_proj
             r = Fn.x3_ffn_ln(src, self.linear1, self.linear2, self.norm2, pos=pos if with_pos else None)
             return r if with_pos or not emit_next_query else (r, None)
         src2 = Fn.linear(Fn.linear_relu(src, self.linear1), self.linear2.weight, self.linear2.bias)
@@ -369,7 +384,11 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         lvl_pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1)
                              for lvl, p in enumerate(pos_embeds)], 1)
         query0 = None
-        if lvl_pos.shape[0] == 1 and srcs[0].is_cuda and not torch.is_grad_enabled():
+        layer0 = self.encoder.layers[0] if len(self.encoder.layers) else None
+        probe = srcs[0].new_empty((1, 1, srcs[0].shape[1]))            # (shape / dtype / device of the token matrix)
+        if layer0 is not None and layer0.pos_in_projection(probe, lvl_pos):
+            src_flatten = Fn.maps_to_tokens(srcs, affines)              # src + pos is formed inside the projection kernels
+        elif lvl_pos.shape[0] == 1 and srcs[0].is_cuda and not torch.is_grad_enabled():
             src_flatten, query0 = Fn.maps_to_tokens(srcs, affines, pos=lvl_pos)   # tokens and tokens + pos in one pass
         else:
             src_flatten = Fn.maps_to_tokens(srcs, affines)

@@ -475,6 +475,11 @@ int dvis_x3_linear_supported(int N, int K, int ln);
  * (output features in passes of 256 over one tile of x); N = 288 at K = 256. */
 int dvis_x3_linear(const float *x, int64_t ldx, int64_t M, int K, const void *packed, int N, int xexp, int wexp,
                    const float *bias, int relu, float *out, int64_t ldo, void *stream);
+/* The same with the activations x[t] + xadd[t mod xadd_rows] (xadd: xadd_rows x K, the position embedding shared by the frames;
+ * the sum is formed in registers and never written): `query = with_pos_embed(src, pos)` in front of sampling_offsets /
+ * attention_weights, msdeformattn.py:99-101,122.  K = 256, N in {128, 192, 256, 288}. */
+int dvis_x3_linear_add(const float *x, int64_t ldx, int64_t M, int K, const void *packed, int N, int xexp, int wexp,
+                       const float *xadd, int64_t xadd_rows, const float *bias, int relu, float *out, int64_t ldo, void *stream);
 /* out = LayerNorm( x W^T + bias + res ) over the N = 256 features (gamma, beta, eps; two-pass statistics as torch);
  * pos (pos_rows x N, optional): out2[t] = out[t] + pos[t mod pos_rows] (the next layer's `with_pos_embed(src, pos)`,
  * msdeformattn.py:99-101,122).  Replaces output_proj + `src = norm1(src + dropout1(src2))`, msdeformattn.py:124-125. */

@@ -187,7 +187,7 @@ def test_encoder_layer_takes_the_split_kernels_and_matches_the_fp32_path():
     ss = torch.as_tensor(shapes, dtype=torch.long, device=DEV)
     lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
     lib, calls = native.lib(), []
-    orig = {n: getattr(lib, n) for n in ("dvis_x3_linear", "dvis_x3_linear_ln", "dvis_x3_ffn_ln")}
+    orig = {n: getattr(lib, n) for n in ("dvis_x3_linear", "dvis_x3_linear_add", "dvis_x3_linear_ln", "dvis_x3_ffn_ln")}
     for n, f in orig.items():
         setattr(lib, n, (lambda n, f: lambda *a: (calls.append(n), f(*a))[1])(n, f))
     try:
@@ -196,13 +196,16 @@ def test_encoder_layer_takes_the_split_kernels_and_matches_the_fp32_path():
     finally:
         for n, f in orig.items():
             setattr(lib, n, f)
-    assert calls.count("dvis_x3_linear") == 2 and calls.count("dvis_x3_linear_ln") == 1 and calls.count("dvis_x3_ffn_ln") == 1
+    # value_proj; offsets | logits with `src + pos` formed inside the kernel; output_proj + norm1; the FFN + norm2
+    assert calls.count("dvis_x3_linear") == 1 and calls.count("dvis_x3_linear_add") == 1
+    assert calls.count("dvis_x3_linear_ln") == 1 and calls.count("dvis_x3_ffn_ln") == 1
+    assert q_x3 is None            # no layer needs the (N, S, C) tensor out + pos any more
     Fn.X3 = False
     try:
         out_f32, q_f32 = layer(src, pos, ref_pts, ss, lsi, None, shapes_py=shapes, emit_next_query=True)
     finally:
         Fn.X3 = True
-    assert float((out_x3 - out_f32).abs().max()) < 2e-5 and float((q_x3 - q_f32).abs().max()) < 2e-5
+    assert float((out_x3 - out_f32).abs().max()) < 2e-5 and float((q_f32 - (out_f32 + pos)).abs().max()) < 1e-6
 
 
 @pytest.mark.parametrize("Ci,Co,H,W,stride,N,res,relu", [
@@ -312,3 +315,18 @@ def test_reserved_cus_do_not_change_bits():
             assert torch.equal(Fn.x3_ffn_ln(x, l1, l2, norm), a) and torch.equal(Fn.conv3x3_x3(xc, w, None, None, True, 1), c)
     finally:
         lib.dvis_x3_set_reserve(prev)
+
+
+@pytest.mark.parametrize("N,B,S", [(288, 3, 1000), (256, 2, 129), (128, 1, 77)])
+def test_linear_with_the_position_added_in_the_kernel(N, B, S):
+    """dvis_x3_linear_add: (x + pos) W^T + b with pos (S, K) shared by the B frames (`with_pos_embed(src, pos)`,
+    msdeformattn.py:99-101) — bit-identical to the kernel fed the materialised fp32 sum, and against fp64."""
+    from dvis_plus_amd import functions as Fn
+    lin = _lin(256, N, N + S)
+    x, pos = torch.randn(B, S, 256, device=DEV), torch.randn(1, S, 256, device=DEV)
+    got = Fn.x3_linear(x, lin.weight, lin.bias, xadd=pos)
+    assert got.shape == (B, S, N) and torch.equal(got, Fn.x3_linear(x + pos, lin.weight, lin.bias))
+    xs = (x + pos).double()
+    ref = xs @ lin.weight.double().t() + lin.bias.double()
+    scale = xs.abs() @ lin.weight.double().abs().t() + lin.bias.double().abs()
+    assert _rel(got, ref, scale) <= 4e-7
