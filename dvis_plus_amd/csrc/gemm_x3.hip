@@ -500,8 +500,7 @@ DVIS_EXPORT int dvis_x3_linear_add(const float *x, int64_t ldx, int64_t M, int K
                                    const float *xadd, int64_t xadd_rows, const float *bias, int relu, float *out, int64_t ldo,
                                    void *stream) {
   DVIS_REQUIRE(xadd && xadd_rows > 0 && (uintptr_t)xadd % 16 == 0, "dvis_x3_linear_add: xadd (xadd_rows x K, 16-byte aligned) is required");
-  DVIS_REQUIRE(K == 256 && (N == 128 || N == 192 || N == 256 || N == 288),
-               "dvis_x3_linear_add: served for K = 256, N in 128 / 192 / 256 / 288 (N %d, K %d)", N, K);
+  DVIS_REQUIRE(K == 256 && dvis_x3_linear_supported(N, K, 0), "dvis_x3_linear_add: served for K = 256 (N %d, K %d)", N, K);
   return x3_linear_impl(x, ldx, M, K, wp, N, xexp, wexp, xadd, xadd_rows, bias, relu, out, ldo, stream);
 }
 

@@ -477,7 +477,8 @@ int dvis_x3_linear(const float *x, int64_t ldx, int64_t M, int K, const void *pa
                    const float *bias, int relu, float *out, int64_t ldo, void *stream);
 /* The same with the activations x[t] + xadd[t mod xadd_rows] (xadd: xadd_rows x K, the position embedding shared by the frames;
  * the sum is formed in registers and never written): `query = with_pos_embed(src, pos)` in front of sampling_offsets /
- * attention_weights, msdeformattn.py:99-101,122.  K = 256, N in {128, 192, 256, 288}. */
+ * attention_weights, msdeformattn.py:99-101,122, and the decoder's keys `with_pos_embed(memory, pos)`,
+ * video_mask2former_transformer_decoder.py:81-88.  K = 256 (the row's fragments stay in registers for every pass over N). */
 int dvis_x3_linear_add(const float *x, int64_t ldx, int64_t M, int K, const void *packed, int N, int xexp, int wexp,
                        const float *xadd, int64_t xadd_rows, const float *bias, int relu, float *out, int64_t ldo, void *stream);
 /* out = LayerNorm( x W^T + bias + res ) over the N = 256 features (gamma, beta, eps; two-pass statistics as torch);

@@ -317,7 +317,7 @@ def test_reserved_cus_do_not_change_bits():
         lib.dvis_x3_set_reserve(prev)
 
 
-@pytest.mark.parametrize("N,B,S", [(288, 3, 1000), (256, 2, 129), (128, 1, 77)])
+@pytest.mark.parametrize("N,B,S", [(288, 3, 1000), (256, 2, 129), (128, 1, 77), (768, 2, 515)])
 def test_linear_with_the_position_added_in_the_kernel(N, B, S):
     """dvis_x3_linear_add: (x + pos) W^T + b with pos (S, K) shared by the B frames (`with_pos_embed(src, pos)`,
     msdeformattn.py:99-101) — bit-identical to the kernel fed the materialised fp32 sum, and against fp64."""
