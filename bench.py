@@ -155,20 +155,40 @@ class ConvTimer:
             self.events.append((e0, e1, 2.0 * 9 * N * C * K * ((H + stride - 1) // stride) * ((W + stride - 1) // stride)))
             return rc
         setattr(lib, self.name, timed_x if self.x3 else timed_w)
+        self.orig1, self.events1 = lib.dvis_conv1x1_x3, []
+
+        def timed_1(x, packed, bias, res, y, N, C, K, H, W, stride, *rest):
+            st = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            rc = self.orig1(x, packed, bias, res, y, N, C, K, H, W, stride, *rest)
+            e1.record(st)
+            self.events1.append((e0, e1, 2.0 * N * C * K * ((H + stride - 1) // stride) * ((W + stride - 1) // stride)))
+            return rc
+        lib.dvis_conv1x1_x3 = timed_1
         return self
 
     def __exit__(self, *exc):
         setattr(self.lib, self.name, self.orig)
+        self.lib.dvis_conv1x1_x3 = self.orig1
 
     def summary(self):
         torch.cuda.synchronize()
         secs = sum(e0.elapsed_time(e1) / 1e3 for e0, e1, _ in self.events)
         return secs, sum(f for _, _, f in self.events), len(self.events)
 
+    def summary_kernel(self):
+        """every launch of conv1x1_x3_kernel in the timed region (1 x 1 and nine-tap forms): the kernel a clip spends most time in"""
+        torch.cuda.synchronize()
+        ev = (self.events if self.x3 else []) + self.events1
+        secs = sum(e0.elapsed_time(e1) / 1e3 for e0, e1, _ in ev)
+        return secs, sum(f for _, _, f in ev), len(ev)
 
-DTYPE_NOTE = ("f32 (storage, accumulation, results; the deformable encoder's dense layers multiply each fp32 operand as two f16 "
-              "terms on the f16 matrix cores, 3 products per pair: error vs fp64 <= the fp32 GEMM's, tests/test_gemm_x3_gpu.py; "
-              "exact_f32 = the same run with DVIS_X3=0)")
+
+DTYPE_NOTE = ("f32 (storage, accumulation, results; the segmenter's dense layers - R50 convolutions from 128 channels on, pixel-decoder "
+              "projections and FPN output convolution, the deformable encoder's projections and FFN, the decoder's key / value "
+              "projections - multiply each fp32 operand as two f16 terms on the f16 matrix cores, 3 products per pair: error vs fp64 "
+              "<= the fp32 GEMM's, tests/test_gemm_x3_gpu.py; exact_f32 = the same run with DVIS_X3=0)")
 
 
 class FfnTimer:
@@ -617,6 +637,17 @@ def main():
                          "ms_per_clip": round(csec / args.steps * 1e3, 2), "traffic": None,
                          "note": "flops = 2 * 4 * N*C*K*H*W per launch (Winograd multiplies), summed over the timed launches / "
                                  "their summed HIP-event durations"}
+        ksec, kflops, klaunch = timer.conv.summary_kernel()
+        convk_roof = None
+        if klaunch:
+            tf16 = 3.0 * kflops / ksec / 1e12
+            convk_roof = {"bound": "mfma", "kernel": "conv1x1_x3_kernel, every launch (1x1 and nine-tap 3x3 forms: R50, pixel-decoder "
+                                                     "projections, FPN output conv) - the kernel with the largest share of a clip's time",
+                          "achieved": round(tf16, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf16 / MFMA_F16_PEAK_TF, 4),
+                          "fp32_equivalent_tflops": round(kflops / ksec / 1e12, 1), "launches_timed": klaunch,
+                          "ms_per_clip": round(ksec / args.steps * 1e3, 2), "traffic": None,
+                          "note": "f16 matrix-core flops issued = 3 x 2*taps*N*C*K*OH*OW per launch, summed over the timed launches / their "
+                                  "summed HIP-event durations; includes the HBM-bound layers (64 / 128 input channels at the large maps)"}
         fsec, fflops, flaunch = timer.ffn.summary()
         ffn_roof = None
         if flaunch:
@@ -661,6 +692,8 @@ def main():
             res["dist"] = dist_info
         if conv_roof is not None:
             res["roofline_conv3x3"] = conv_roof
+        if convk_roof is not None:
+            res["roofline_conv_x3"] = convk_roof
         if ffn_roof is not None:
             res["roofline_ffn"] = ffn_roof
         if exact is not None:
