@@ -251,7 +251,54 @@ __global__ __launch_bounds__(256) void tokens_to_nchw_kernel(const float *__rest
   }
 }
 
+// Input normalisation + padding of a clip in one pass: out[p][y][x] = y < H && x < W ? (float(in[p][y][x]) - mean[p % C]) / std[p % C] : 0
+// (dvis_Plus/meta_architecture.py:1310-1311: `(x - pixel_mean) / pixel_std`, then ImageList.from_tensors pads with zeros to the
+// size divisibility).  Same fp32 operations in the same order as the torch expression (IEEE subtract, IEEE divide): same bits,
+// one read of the uint8 / float frames and one write of the padded tensor instead of conversion + sub + div + fill + copy.
+template <typename T>
+__global__ __launch_bounds__(256) void normalize_pad_kernel(const T *__restrict__ in, float *__restrict__ out, int C, int H, int W,
+                                                            int Hp, int Wp, const float *__restrict__ mean,
+                                                            const float *__restrict__ stdv) {
+  // block = 64 groups of 4 pixels x 4 rows; grid = (groups of a row / 64, rows / 4, planes)
+  const int g = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int64_t p = blockIdx.z;
+  if (4 * g >= Wp || y >= Hp) return;
+  const int c = (int)(p % C);
+  const float m = mean[c], sd = stdv[c];
+  const T *src = in + (p * H + y) * (int64_t)W;
+  float *dst = out + (p * Hp + y) * (int64_t)Wp;
+  float v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int x = 4 * g + k;
+    v[k] = (y < H && x < W) ? __fdiv_rn(__fsub_rn((float)src[x], m), sd) : 0.f;
+  }
+  if ((Wp & 3) == 0) {
+    *reinterpret_cast<dvis_f4 *>(dst + 4 * g) = dvis_f4{v[0], v[1], v[2], v[3]};
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (4 * g + k < Wp) dst[4 * g + k] = v[k];
+  }
+}
+
 }  // namespace
+
+DVIS_EXPORT int dvis_normalize_pad(const void *in, int is_u8, float *out, int64_t planes, int C, int H, int W, int Hp, int Wp,
+                                   const float *mean, const float *stdv, void *stream) {
+  DVIS_REQUIRE(planes >= 0 && C > 0 && H > 0 && W > 0 && Hp >= H && Wp >= W, "normalize_pad: bad sizes");
+  if (planes == 0) return DVIS_OK;
+  DVIS_REQUIRE(in && out && mean && stdv, "normalize_pad: null pointer");
+  DVIS_REQUIRE(planes <= 65535 && (Hp + 3) / 4 <= 65535, "normalize_pad: grid too large");
+  const dim3 grid((unsigned)(((Wp + 3) / 4 + 63) / 64), (unsigned)((Hp + 3) / 4), (unsigned)planes);
+  if (is_u8)
+    hipLaunchKernelGGL(normalize_pad_kernel<unsigned char>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned char *)in, out, C,
+                       H, W, Hp, Wp, mean, stdv);
+  else
+    hipLaunchKernelGGL(normalize_pad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)in, out, C, H, W, Hp, Wp,
+                       mean, stdv);
+  return dvis_check_launch("normalize_pad_kernel");
+}
 
 DVIS_EXPORT int dvis_tokens_to_nchw(const float *tok, float *out, int64_t N, int C, int64_t HW, int64_t S, int64_t row0, void *stream) {
   DVIS_REQUIRE(N >= 0 && C > 0 && HW > 0 && S >= HW && row0 >= 0 && row0 + HW <= S, "tokens_to_nchw: bad sizes");

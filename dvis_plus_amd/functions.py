@@ -732,6 +732,10 @@ X3_XEXP = int(os.environ.get("DVIS_X3_XEXP", "4"))      # activations are scaled
 # the convolutions see ReLU'd feature maps without a normalisation in front: more range (|x| < 16376), an absolute floor of
 # 2^-27 = 7.5e-9 per element below |x| = 0.03
 X3_CONV_XEXP = int(os.environ.get("DVIS_X3_CONV_XEXP", "2"))
+# conv1x1_bias_act: from this many input channels on a 1x1 layer goes to the split-f16 kernel first — also the memory-bound
+# ones csrc/conv1x1.hip (weights resident in LDS, exact fp32) was written for: 64 -> 256 + shortcut at 184 x 320 runs at 5.0
+# TB/s there against 4.3, 256 -> 128 in 0.62 ms against 1.13 (tools/x3_time.py conv)
+X3_CONV1X1_MIN_CI = int(os.environ.get("DVIS_X3_CONV1X1_MIN_CI", "64"))
 _X3_PACKED = {}
 
 
@@ -906,6 +910,24 @@ def maps_to_tokens(maps, affines=None, pos=None):
     return out if pos is None else (out, out_pos)
 
 
+def normalize_pad_ok(x, mean):
+    return bool(x.is_cuda and x.dim() == 4 and x.dtype in (torch.uint8, torch.float32) and x.is_contiguous()
+                and mean.numel() == x.shape[1] and mean.dtype == torch.float32 and not torch.is_grad_enabled())
+
+
+def normalize_pad(x, mean, std, Hp, Wp):
+    """zero-padded ((x - mean[c]) / std[c]) of (N, C, H, W) uint8 / fp32 frames as ONE pass: conversion, normalisation and
+    ImageList.from_tensors' padding (dvis_Plus/meta_architecture.py:1310-1311).  The same fp32 subtract and divide: same bits."""
+    N, C, H, W = x.shape
+    out = torch.empty((N, C, Hp, Wp), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        native.check(native.lib().dvis_normalize_pad(
+            native.dev_ptr(x, "frames"), int(x.dtype == torch.uint8), native.dev_ptr(out, "out"), N * C, C, H, W, Hp, Wp,
+            native.dev_ptr(mean.detach().reshape(-1), "pixel_mean"), native.dev_ptr(std.detach().reshape(-1), "pixel_std"),
+            native.stream_ptr(x.device)), "dvis_normalize_pad")
+    return out
+
+
 def tokens_to_map(tokens, row0, h, w):
     """``tokens[:, row0 : row0 + h * w].transpose(1, 2).reshape(N, C, h, w)`` as a CONTIGUOUS map (tokens: (N, S, C) float32):
     one tiled transpose (dvis_tokens_to_nchw) instead of the strided view whose consumer copies it with torch's generic kernel
@@ -951,6 +973,8 @@ def conv1x1_bias_act(x, weight, bias=None, res=None, relu=False):
     if x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.is_contiguous() \
             and not torch.is_grad_enabled() and (res is None or (res.is_contiguous() and res.dtype == torch.float32)):
         N, _, H, W = x.shape
+        if Ci >= X3_CONV1X1_MIN_CI and conv1x1_x3_ok(x, weight, 1, res):
+            return conv1x1_x3(x, weight, bias, res, relu)
         if native.lib().dvis_conv1x1_supported(Ci, Co, H * W) and (res is None or res.shape == (N, Co, H, W)):
             w2 = weight.detach().reshape(Co, Ci)
             if not w2.is_contiguous():
@@ -964,8 +988,6 @@ def conv1x1_bias_act(x, weight, bias=None, res=None, relu=False):
                     1 if relu else 0, native.stream_ptr(x.device))
             native.check(rc, "dvis_conv1x1_bias_act")
             return out
-        if conv1x1_x3_ok(x, weight, 1, res) and Ci >= 128:
-            return conv1x1_x3(x, weight, bias, res, relu)
         if CONV1X1_MFMA and native.lib().dvis_conv1x1_mfma_supported(Ci, Co, H * W) and (res is None or res.shape == (N, Co, H, W)):
             return conv1x1_mfma(x, weight, bias, res, relu)
     return bias_act_(conv1x1(x, weight), None if bias is None else bias.detach(), res, relu)

@@ -23,6 +23,7 @@ import torch
 from torch import nn
 
 from . import d2
+from . import functions as Fn
 from . import native
 from . import postprocess as PP
 from .clip_shard import ClipShard, EmulatedShard
@@ -214,10 +215,13 @@ class _VideoBase(nn.Module):
     # ---- meta_architecture.py:1306-1311: normalise, then pad bottom/right to a multiple of size_divisibility
     def preprocess(self, frames):
         x = frames if torch.is_tensor(frames) else torch.stack([f.to(self.device) for f in frames])
-        x = (x.to(self.device, torch.float32) - self.pixel_mean) / self.pixel_std
         H, W = x.shape[-2:]
         d = self.size_divisibility
         Hp, Wp = ((H + d - 1) // d * d, (W + d - 1) // d * d) if d > 1 else (H, W)
+        x = x.to(self.device)
+        if Fn.normalize_pad_ok(x, self.pixel_mean):
+            return Fn.normalize_pad(x, self.pixel_mean, self.pixel_std, Hp, Wp), (H, W)
+        x = (x.to(torch.float32) - self.pixel_mean) / self.pixel_std
         if (Hp, Wp) != (H, W):
             x = torch.nn.functional.pad(x, (0, Wp - W, 0, Hp - H))
         return x, (H, W)

@@ -32,6 +32,7 @@ SIGNATURES = {
                                            _i, _i, _i, _p, _p, _p]),
     "dvis_nchw_to_tokens": (_i, [_p, _p, _i64, _i, _i64, _i64, _i64, _p]),
     "dvis_tokens_to_nchw": (_i, [_p, _p, _i64, _i, _i64, _i64, _i64, _p]),
+    "dvis_normalize_pad": (_i, [_p, _i, _p, _i64, _i, _i, _i, _i, _i, _p, _p, _p]),
     "dvis_nchw_to_tokens_affine": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i64, _i64, _i64, _p]),
     "dvis_mask_logits": (_i, [_p, _p, _i, _i, _i, _i64, _p, _p]),
     "dvis_attn_mask": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),

@@ -243,6 +243,12 @@ int dvis_nchw_to_tokens(const float *x, float *out, int64_t N, int C, int64_t HW
 /* The way back for one level: out (N, C, HW) = tok[:, row0 : row0 + HW, :] transposed (tok: (N, S, C)) — the encoder output
  * as the map the FPN's top-down path reads, msdeformattn.py:333-339 (+ :347). */
 int dvis_tokens_to_nchw(const float *tok, float *out, int64_t N, int C, int64_t HW, int64_t S, int64_t row0, void *stream);
+/* Input normalisation + zero padding of a clip in one pass (dvis_Plus/meta_architecture.py:1310-1311, :186-187, :638-639:
+ * `(x - pixel_mean) / pixel_std`, then ImageList.from_tensors(images, size_divisibility)):
+ * out (planes, Hp, Wp) = (float(in (planes, H, W)) - mean[p % C]) / std[p % C] inside the image, 0 in the padding; in: uint8
+ * (is_u8 = 1) or fp32 planes, planes = frames * C.  The same fp32 subtract and divide as the torch expression: same bits. */
+int dvis_normalize_pad(const void *in, int is_u8, float *out, int64_t planes, int C, int H, int W, int Hp, int Wp, const float *mean,
+                       const float *stdv, void *stream);
 int dvis_nchw_to_tokens_affine(const float *x, const float *scale, const float *shift, const float *pos, float *out,
                                float *out_pos, int64_t N, int C, int64_t HW, int64_t S, int64_t row0, void *stream);
 

@@ -8,6 +8,14 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
+
+@pytest.fixture(autouse=True)
+def exact_fp32_dispatch(monkeypatch):
+    """this file tests csrc/conv1x1.hip: with the split-f16 kernels on (the default) conv1x1_bias_act hands every layer with
+    >= 64 input channels to csrc/conv1x1_x3.hip first (tests/test_gemm_x3_gpu.py)"""
+    from dvis_plus_amd import functions as Fn
+    monkeypatch.setattr(Fn, "X3", False)
+
 # (N, K, M, H, W): the three kernel forms (<= 64, <= 128, passes of 256 rows), ragged pixel groups (H*W not a multiple of
 # 64 / 32 / 512), row counts that are not a multiple of 16, several row passes, K that is not a multiple of 32
 CASES = [(2, 256, 64, 24, 40), (1, 64, 64, 8, 12), (3, 64, 256, 8, 36), (2, 128, 512, 6, 10), (1, 256, 128, 16, 20),

@@ -193,3 +193,35 @@ def test_tokens_to_map_equals_the_strided_view(N, S, C, row0, h, w):
     with torch.no_grad():
         got = Fn.tokens_to_map(tok, row0, h, w)
     assert got.is_contiguous() and torch.equal(got, tok[:, row0:row0 + h * w].transpose(1, 2).reshape(N, C, h, w))
+
+
+@pytest.mark.parametrize("dtype", [torch.uint8, torch.float32])
+@pytest.mark.parametrize("N,H,W,Hp,Wp", [(2, 37, 53, 64, 64), (3, 32, 64, 32, 64), (1, 45, 53, 45, 53), (2, 720, 1280, 736, 1280)])
+def test_normalize_pad_has_the_bits_of_the_torch_expression(dtype, N, H, W, Hp, Wp):
+    """dvis_normalize_pad: `(x - pixel_mean) / pixel_std` + zero padding to the size divisibility
+    (dvis_Plus/meta_architecture.py:1310-1311) in one pass, with the same fp32 subtract / divide: torch.equal."""
+    from dvis_plus_amd import functions as Fn
+    g = torch.Generator().manual_seed(H * W + N)
+    x = torch.randint(0, 256, (N, 3, H, W), generator=g, dtype=torch.uint8)
+    x = x.to(DEV) if dtype == torch.uint8 else (x.float() + torch.rand(N, 3, H, W, generator=g)).to(DEV)
+    mean = torch.tensor([123.675, 116.280, 103.530], device=DEV).view(-1, 1, 1)
+    std = torch.tensor([58.395, 57.120, 57.375], device=DEV).view(-1, 1, 1)
+    with torch.no_grad():
+        assert Fn.normalize_pad_ok(x, mean)
+        got = Fn.normalize_pad(x, mean, std, Hp, Wp)
+    ref = F.pad((x.float() - mean) / std, (0, Wp - W, 0, Hp - H))
+    assert got.shape == ref.shape and torch.equal(got, ref)
+
+
+def test_preprocess_of_the_meta_architecture_takes_the_fused_pass(monkeypatch):
+    from dvis_plus_amd import functions as Fn
+    from dvis_plus_amd.meta_architecture import build_dvis_plus_r50
+    calls = []
+    orig = Fn.normalize_pad
+    monkeypatch.setattr(Fn, "normalize_pad", lambda *a: (calls.append(1), orig(*a))[1])
+    m = build_dvis_plus_r50("offline", task="vps").to(DEV).eval()
+    frames = [torch.randint(0, 256, (3, 50, 70), dtype=torch.uint8) for _ in range(2)]
+    with torch.no_grad():
+        x, size = m.preprocess(frames)
+    ref = F.pad((torch.stack(frames).to(DEV).float() - m.pixel_mean) / m.pixel_std, (0, 96 - 70, 0, 64 - 50))
+    assert calls and size == (50, 70) and torch.equal(x, ref)

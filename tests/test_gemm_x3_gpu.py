@@ -218,6 +218,9 @@ def test_encoder_layer_takes_the_split_kernels_and_matches_the_fp32_path():
     (256, 512, 45, 80, 2, 1, False, False),       # ... odd height
     (64, 256, 20, 31, 1, 2, True, True),          # one chunk
     (256, 64, 33, 47, 1, 2, False, True),         # 64 output channels (res2 conv1)
+    (64, 64, 37, 50, 1, 2, False, True),          # res2.0 conv1: one chunk, one block pair
+    (256, 128, 30, 44, 1, 2, False, True),        # res3.0 conv1 (reads the stride-4 map)
+    (64, 256, 25, 36, 1, 3, False, False),        # res2.0 shortcut: no residual, no ReLU
 ])
 def test_conv1x1_x3(Ci, Co, H, W, stride, N, res, relu):
     """csrc/conv1x1_x3.hip against fp64, next to the fp32 library convolution's error on the same operands."""

@@ -41,8 +41,11 @@ def main():
     res = torch.randn(frames, S, 256, device=DEV, generator=g)
     pos = torch.randn(1, S, 256, device=DEV, generator=g)
     R = 4096                                                              # rows checked against fp64
-    sel = torch.cat([torch.arange(0, R // 2), torch.arange(M - R // 2, M)]).to(DEV)
-    print(f"M = {M} tokens ({frames} frames); errors = max |c - fp64| / sum|a||w| over {R} rows")
+    sel = torch.cat([torch.arange(64, R // 2), torch.arange(M - R // 2, M)]).to(DEV)
+    tiny = torch.arange(0, 64, device=DEV)                                # the rows scaled by 1e-6 ... 1e2
+    print(f"M = {M} tokens ({frames} frames); errors = max |c - fp64| / (sum|a||w| + |bias|) over {R - 64} rows of unit scale; "
+          f"'scaled rows' = the 64 rows multiplied by 1e-6 ... 1e2: elements below 2^-3 / 2^xexp = 0.0078 keep an ABSOLUTE precision "
+          f"of 2^-25 / 2^xexp = 1.9e-9 (f16 subnormal low term), so relative to such a row's own scale the error grows as the row shrinks")
     for N in (256, 288, 128, 192):
         lin = nn.Linear(256, N).to(DEV)
         nn.init.xavier_uniform_(lin.weight)
@@ -55,6 +58,12 @@ def main():
             lib = F.linear(xs, lin.weight, lin.bias)
             r = ref.clamp_min(0) if relu else ref
             print(f"  linear 256 -> {N} relu={int(relu)}: x3 {rel(got, r, scale):.2e}   fp32 library {rel(F.relu(lib) if relu else lib, r, scale):.2e}")
+        xt = x.view(M, 256)[tiny]
+        reft = xt.double() @ lin.weight.double().t() + lin.bias.double()
+        gott = Fn.x3_linear(x, lin.weight, lin.bias).view(M, N)[tiny]
+        libt = F.linear(xt, lin.weight, lin.bias)
+        print(f"    scaled rows: max |c - fp64| absolute: x3 {float((gott.double() - reft).abs().max()):.2e}   fp32 library "
+              f"{float((libt.double() - reft).abs().max()):.2e}   (results are O(1): the bias)")
         t = timeit(lambda: Fn.x3_linear(x, lin.weight, lin.bias))
         tl = timeit(lambda: F.linear(x, lin.weight, lin.bias))
         fl = 2.0 * M * 256 * N
@@ -112,7 +121,9 @@ def conv_main():
     """the R50's compute-bound 1x1 layers at 30 frames of 736 x 1280: csrc/conv1x1_x3.hip vs csrc/conv1x1_mfma.hip (exact fp32)"""
     shapes = [(512, 128, 92, 160, 1), (128, 512, 92, 160, 1), (256, 512, 184, 320, 2), (1024, 256, 46, 80, 1), (256, 1024, 46, 80, 1),
               (512, 1024, 92, 160, 2), (2048, 512, 23, 40, 1), (512, 2048, 23, 40, 1), (1024, 2048, 46, 80, 2), (512, 256, 92, 160, 1),
-              (1024, 512, 46, 80, 1)]
+              (1024, 512, 46, 80, 1),
+              # the layers csrc/conv1x1.hip (weights resident in LDS, exact fp32) claims: res2 conv1 / conv3, res3.0 conv1
+              (256, 64, 184, 320, 1), (256, 128, 184, 320, 1), (64, 256, 184, 320, 1), (64, 64, 184, 320, 1)]
     for Ci, Co, H, W, stride in shapes:
         x = torch.randn(30, Ci, H, W, device=DEV)
         w = torch.randn(Co, Ci, 1, 1, device=DEV) * (2.0 / Ci) ** 0.5
@@ -125,9 +136,15 @@ def conv_main():
         t = timeit(lambda: Fn.conv1x1_x3(x, w, b, r, True, stride))
         tm = timeit(lambda: Fn.conv1x1_mfma(x, w, b, r, True, stride)) if Ci % 128 == 0 else float("nan")
         fl = 2.0 * 30 * OH * OW * Ci * Co
-        gb = 4.0 * 30 * (OH * OW * (Ci + Co * (2 if r is not None else 1)))
-        print(f"  conv {Ci:4d} -> {Co:4d} {H}x{W} s{stride} res={int(r is not None)}: x3 {t:.3f} ms ({fl / t / 1e9:.0f} TF fp32-eq, {gb / t / 1e6:.0f} GB/s)"
-              f"   exact-fp32 MFMA kernel {tm:.3f} ms ({fl / tm / 1e9:.0f} TF)")
+        gb = 4.0 * 30 * (H * W * Ci / (stride * stride) + OH * OW * Co * (2 if r is not None else 1))
+        line = (f"  conv {Ci:4d} -> {Co:4d} {H}x{W} s{stride} res={int(r is not None)}: x3 {t:.3f} ms ({fl / t / 1e9:.0f} TF fp32-eq, "
+                f"{gb / t / 1e6:.0f} GB/s)   exact-fp32 MFMA kernel {tm:.3f} ms ({fl / tm / 1e9:.0f} TF)")
+        if stride == 1 and Fn.native.lib().dvis_conv1x1_supported(Ci, Co, H * W):
+            Fn.X3 = False                                                   # -> csrc/conv1x1.hip (weights resident in LDS)
+            tb = timeit(lambda: Fn.conv1x1_bias_act(x, w, b, r, True))
+            Fn.X3 = True
+            line += f"   exact-fp32 LDS-weights kernel {tb:.3f} ms ({gb / tb / 1e6:.0f} GB/s)"
+        print(line)
 
 
 def conv3_main():
@@ -144,7 +161,9 @@ def conv3_main():
             print(f"  conv3x3 {Ci} -> {Co} {H}x{W} s{stride}: not served")
             continue
         t = timeit(lambda: Fn.conv3x3_x3(x, w, b, None, True, stride))
+        Fn.X3 = False                                       # the dispatchers would hand these layers to the x3 kernel again
         te = timeit(lambda: Fn.conv3x3_bias_act(x, w, b, True)) if stride == 1 else timeit(lambda: Fn.conv3x3s2_bias_act(x, w, b, True))
+        Fn.X3 = True
         fl = 2.0 * 30 * OH * OW * Ci * Co * 9
         print(f"  conv3x3 {Ci:4d} -> {Co:4d} {H}x{W} s{stride}: x3 nine taps {t:.3f} ms ({fl / t / 1e9:.0f} TF fp32-eq direct)"
               f"   exact-fp32 {'Winograd' if stride == 1 else 'direct'} kernel {te:.3f} ms ({fl / te / 1e9:.0f} TF direct-eq)")
