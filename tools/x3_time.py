@@ -62,8 +62,10 @@ def main():
         reft = xt.double() @ lin.weight.double().t() + lin.bias.double()
         gott = Fn.x3_linear(x, lin.weight, lin.bias).view(M, N)[tiny]
         libt = F.linear(xt, lin.weight, lin.bias)
+        scalet = xt.double().abs() @ lin.weight.double().abs().t() + lin.bias.double().abs()
         print(f"    scaled rows: max |c - fp64| absolute: x3 {float((gott.double() - reft).abs().max()):.2e}   fp32 library "
-              f"{float((libt.double() - reft).abs().max()):.2e}   (results are O(1): the bias)")
+              f"{float((libt.double() - reft).abs().max()):.2e};  relative to the row's own sum|a||w| + |bias|: x3 "
+              f"{rel(gott, reft, scalet):.2e}   fp32 library {rel(libt, reft, scalet):.2e}")
         t = timeit(lambda: Fn.x3_linear(x, lin.weight, lin.bias))
         tl = timeit(lambda: F.linear(x, lin.weight, lin.bias))
         fl = 2.0 * M * 256 * N
