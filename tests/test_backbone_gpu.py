@@ -131,9 +131,9 @@ def test_resnet50_production_size_strict_own_kernels_vs_unfused_fp64():
     else:
         assert calls["dvis_conv3x3_winograd"] == 13 and calls["dvis_conv3x3s2"] == 3 and calls["dvis_conv3x3_x3"] == 0, calls
     assert calls["dvis_bias_relu_maxpool"] == 1
-    # the 1x1 layers: 16 x (conv1, conv3) + 4 shortcuts = 36; the compute-bound ones (>= 128 input channels where the
-    # memory-bound kernel does not serve the shape) and the three stride-2 shortcuts on the split-f16 matrix-core kernel
-    # (csrc/conv1x1_x3.hip; DVIS_X3=0: csrc/conv1x1_mfma.hip), the rest on the memory-bound kernel
+    # the 1x1 layers: 16 x (conv1, conv3) + 4 shortcuts = 36: with the split-f16 kernels on, every one of them (>= 64 input
+    # channels) runs on csrc/conv1x1_x3.hip; DVIS_X3=0: the compute-bound ones and the stride-2 shortcuts on
+    # csrc/conv1x1_mfma.hip, the rest on the LDS-weights kernel csrc/conv1x1.hip
     from dvis_plus_amd import functions as Fn
     mm = calls["dvis_conv1x1_x3"] if Fn.X3 else calls["dvis_conv1x1_mfma"] + calls["dvis_conv1x1s2_mfma"]
     assert mm >= 20 and mm + calls["dvis_conv1x1_bias_act"] == 36, calls
