@@ -789,7 +789,7 @@ def _x3_rows(x, name):
 def x3_linear(x, weight, bias, relu=False, xexp=None, xadd=None):
     """``relu?((x + xadd) @ weight.T + bias)`` through dvis_x3_linear[_add].  x (..., K) float32 GPU; weight (N, K); xadd: None or
     a (1, S, 256) / (S, 256) embedding for x of shape (B, S, 256), broadcast over B — added inside the kernel while it builds the
-    row's fragments, the sum is never written (N in 128 / 192 / 256 / 288)."""
+    row's fragments, the sum is never written (K = 256, any N the kernels serve: all passes over N run from one read of the row)."""
     N, K = weight.shape
     x2, ldx = _x3_rows(x, "x")
     buf, wexp = x3_pack(weight)

@@ -219,6 +219,10 @@ class _VideoBase(nn.Module):
         d = self.size_divisibility
         Hp, Wp = ((H + d - 1) // d * d, (W + d - 1) // d * d) if d > 1 else (H, W)
         x = x.to(self.device)
+        if x.is_cuda and x.dim() == 4 and not torch.is_grad_enabled():
+            # one pass on the device (csrc/fused_elementwise.hip); other integer / half dtypes convert to fp32 exactly first
+            exact = x.dtype in (torch.int8, torch.int16, torch.float16, torch.bfloat16, torch.bool)    # (float64 keeps torch's path)
+            x = (x.to(torch.float32) if exact else x).contiguous()
         if Fn.normalize_pad_ok(x, self.pixel_mean):
             return Fn.normalize_pad(x, self.pixel_mean, self.pixel_std, Hp, Wp), (H, W)
         x = (x.to(torch.float32) - self.pixel_mean) / self.pixel_std
