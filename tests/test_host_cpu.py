@@ -123,3 +123,26 @@ def test_x3_shape_tables():
         assert (lib.dvis_conv3x3_x3_packed_bytes(C, K) == 9 * C * K * 4) == bool(ok)
     assert lib.dvis_conv1x1_x3_supported(256, 256, 30, 58880, 58880) == 1       # 1.81 GB: below the 2 GiB of 32-bit buffer offsets
     assert lib.dvis_conv1x1_x3_supported(256, 256, 64, 58880, 58880) == 0       # T = 64 in one call: served by the fp32 kernels
+
+
+def test_every_1x1_layer_of_the_r50_at_the_benchmark_shape_is_served_by_the_split_f16_kernel():
+    """conv1x1_bias_act hands a 1x1 layer to csrc/conv1x1_x3.hip first when dvis_conv1x1_x3_supported says so: at 30 frames of
+    736 x 1280 that is every one of the R50's 36 (16 bottlenecks x (conv1, conv3) + 4 shortcuts, detectron2 BottleneckBlock with
+    STRIDE_IN_1X1 False: conv1 reads the block's input map, the stride sits in the 3x3), and the pixel decoder's five projections."""
+    from dvis_plus_amd import native
+    lib = native.lib()
+    layers, cin, hw = [], 64, (184, 320)                      # after the stem + max-pool: 64 channels at stride 4
+    for stage, (blocks, mid, out, stride) in enumerate(((3, 64, 256, 1), (4, 128, 512, 2), (6, 256, 1024, 2), (3, 512, 2048, 2))):
+        for b in range(blocks):
+            s = stride if b == 0 else 1
+            ohw = (hw[0] // s, hw[1] // s)
+            layers.append((cin, mid, hw, hw))                 # conv1 (stride 1, on the input map)
+            layers.append((mid, out, ohw, ohw))               # conv3 (after the strided 3x3)
+            if b == 0:
+                layers.append((cin, out, hw, ohw))            # shortcut (strided for res3 - res5)
+            cin, hw = out, ohw
+    assert len(layers) == 36 and hw == (23, 40)
+    layers += [(2048, 256, (23, 40), (23, 40)), (1024, 256, (46, 80), (46, 80)), (512, 256, (92, 160), (92, 160)),    # input_proj
+               (256, 256, (184, 320), (184, 320)), (256, 256, (184, 320), (184, 320))]                                 # lateral, mask_features
+    for C, K, hin, hout in layers:
+        assert lib.dvis_conv1x1_x3_supported(C, K, 30, hin[0] * hin[1], hout[0] * hout[1]) == 1, (C, K, hin, hout)
