@@ -1,6 +1,16 @@
 """Probe (not product): the pyramid form of the decoder's attention masks with its two small kernels (pool_threshold.hip)
 around the existing contraction, against dvis_attn_mask: bits, allowed counts, time per clip.
-    python tools/exp/attn_mask_pyramid/run.py"""
+    python tools/exp/attn_mask_pyramid/run.py
+
+Measured on MI355X at the end of round 4 (profiles/r04_attn_mask_pyramid_kernels.txt): 1.72 ms per clip against 3.70 ms.
+Wiring it into the product (not done: no GPU budget was left to re-run the parity tests that count attention-mask flips):
+  * the two kernels into csrc/fused_elementwise.hip behind C-ABI entry points (+ include/dvis_hip.h, native.SIGNATURES),
+    better: the threshold + allowed count as an epilogue mode of mask_gemm.hip's MODE 0 (no fp32 logits written);
+  * transformer_decoder._run_layers: pool mask_features once per call (the three maps serve all nine layers), then
+    `Fn.attn_mask(emb, mask_features, size)` -> contraction on the level's pooled map + threshold;
+  * the fall-back for maps whose H or W is not a multiple of 8 stays dvis_attn_mask;
+  * re-run: tests/test_mask_gemm_gpu.py, test_golden_gpu.py (g3), test_model_gpu.py, test_pipeline_720p_gpu.py (the literal
+    1e-3 test: its error is a sum of mask-flip events), test_properties_gpu.py."""
 import ctypes
 import os
 import subprocess
