@@ -135,6 +135,32 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const float *__restri
   }
 }
 
+// any W (rows not a multiple of 4 floats): one output per thread, the generic formula of the kernel above
+__global__ __launch_bounds__(256) void upsample_add_scalar_kernel(const float *__restrict__ lateral, const float *__restrict__ top,
+                                                                  float *__restrict__ out, long long total, int H, int W, int h, int w,
+                                                                  const float *__restrict__ lat_scale,
+                                                                  const float *__restrict__ lat_shift) {
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int x = (int)(idx % W);
+    const long long r = idx / W;
+    const int y = (int)(r % H);
+    const long long pl = r / H;
+    float fy = sy * ((float)y + 0.5f) - 0.5f;
+    fy = fy < 0.f ? 0.f : fy;
+    const int y0 = min((int)fy, h - 1), y1 = y0 + (y0 < h - 1 ? 1 : 0);
+    const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
+    float fx = sx * ((float)x + 0.5f) - 0.5f;
+    fx = fx < 0.f ? 0.f : fx;
+    const int x0 = min((int)fx, w - 1), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+    const float *t0 = top + ((size_t)pl * h + y0) * (size_t)w, *t1 = top + ((size_t)pl * h + y1) * (size_t)w;
+    float lat = lateral[idx];
+    if (lat_scale) lat = lat * lat_scale[pl] + lat_shift[pl];
+    out[idx] = lat + (ly0 * (lx0 * t0[x0] + lx1 * t0[x1]) + ly1 * (lx0 * t1[x0] + lx1 * t1[x1]));
+  }
+}
+
 // out = relu(max_pool2d(x, 3, stride 2, padding 1) + bias[c]) — the ResNet stem after its convolution.  x -> relu(x + b)
 // is monotonic in fp32, so this equals max_pool2d(relu(x + bias)) bit for bit; the stem output (the largest activation
 // of the model) is read once and never written back.  A thread makes 4 outputs of one row from 9 input columns x 3 rows.
@@ -193,6 +219,18 @@ __global__ __launch_bounds__(256) void bias_act_kernel(float *__restrict__ x, co
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     }
     xp[i] = v;
+  }
+}
+
+// the same per element for planes that are not a multiple of 4 floats (odd x odd stride-32 maps, e.g. 15 x 27 from a 480 x 854
+// frame): planes are then not 16-byte aligned, so one float per thread; same operations in the same order -> same bits
+__global__ __launch_bounds__(256) void bias_act_scalar_kernel(float *__restrict__ x, const float *__restrict__ bias,
+                                                              const float *__restrict__ res, int C, long long HW, long long total,
+                                                              int relu) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    float v = x[i] + (bias ? bias[(i / HW) % C] : 0.f);
+    if (res) v += res[i];
+    x[i] = relu ? fmaxf(v, 0.f) : v;
   }
 }
 
@@ -339,8 +377,13 @@ DVIS_EXPORT int dvis_bias_act(float *x, const float *bias, const float *res, int
   DVIS_REQUIRE(planes >= 0 && C > 0 && HW > 0, "bias_act: bad sizes");
   if (planes == 0) return DVIS_OK;
   DVIS_REQUIRE(x, "bias_act: null pointer");
-  DVIS_REQUIRE(HW % 4 == 0 && (((uintptr_t)x | (uintptr_t)res) & 15) == 0,
-               "bias_act: HW must be a multiple of 4 and x / res 16-byte aligned");
+  if (HW % 4 != 0 || (((uintptr_t)x | (uintptr_t)res) & 15) != 0) {       // odd planes: the scalar form
+    const long long total = (long long)planes * HW;
+    const long long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(bias_act_scalar_kernel, dim3((unsigned)(blocks > 65535 * 16 ? 65535 * 16 : blocks)), dim3(256), 0,
+                       (hipStream_t)stream, x, bias, res, C, (long long)HW, total, relu);
+    return dvis_check_launch("bias_act_scalar_kernel");
+  }
   const int HW4 = (int)(HW / 4);
   int chunks = (HW4 + 1023) / 1024;           // ~4 float4 per thread
   if (chunks < 1) chunks = 1;
@@ -392,9 +435,15 @@ static int upsample_add_launch(const float *lateral, const float *top, float *ou
   if (planes == 0) return DVIS_OK;
   DVIS_REQUIRE(lateral && top && out, "upsample_add: null pointer");
   DVIS_REQUIRE((lat_scale == nullptr) == (lat_shift == nullptr), "upsample_add: scale and shift come together");
-  DVIS_REQUIRE(W % 4 == 0 && (((uintptr_t)lateral | (uintptr_t)out) & 15) == 0,
-               "upsample_add: W must be a multiple of 4 and lateral/out 16-byte aligned");
   DVIS_REQUIRE(planes < (1ll << 31), "upsample_add: too many planes");
+  if (W % 4 != 0 || (((uintptr_t)lateral | (uintptr_t)out) & 15) != 0) {
+    const long long tot = (long long)planes * H * W;
+    long long nb = (tot + 255) / 256;
+    if (nb > 256 * 32) nb = 256 * 32;
+    hipLaunchKernelGGL(upsample_add_scalar_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, lateral, top, out, tot, H, W,
+                       h, w, lat_scale, lat_shift);
+    return dvis_check_launch("upsample_add_scalar_kernel");
+  }
   const size_t total = (size_t)planes * H * (W / 4);
   size_t blocks = (total + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;
@@ -445,17 +494,26 @@ namespace {
 __global__ __launch_bounds__(1024) void group_norm_affine_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                                  const float *__restrict__ beta, float *__restrict__ scale,
                                                                  float *__restrict__ shift, int C, int G, long long HW,
-                                                                 float eps) {
+                                                                 float eps, int vec) {
   __shared__ double s_sum[16], s_sq[16];
   const int Cg = C / G;
   const int n = blockIdx.x / G, g = blockIdx.x - n * G;
   const long long count = (long long)Cg * HW, count4 = count / 4;
   const float4 *xp = reinterpret_cast<const float4 *>(x + ((size_t)n * C + (size_t)g * Cg) * HW);
   double sum = 0.0, sq = 0.0;
-  for (long long i = threadIdx.x; i < count4; i += 1024) {
-    const float4 v = xp[i];
-    sum += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
-    sq += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+  if (vec) {
+    for (long long i = threadIdx.x; i < count4; i += 1024) {
+      const float4 v = xp[i];
+      sum += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+      sq += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+    }
+  } else {      // a group that is not a multiple of 4 floats (odd x odd maps): its slab is not 16-byte aligned
+    const float *xs = reinterpret_cast<const float *>(xp);
+    for (long long i = threadIdx.x; i < count; i += 1024) {
+      const double v = (double)xs[i];
+      sum += v;
+      sq += v * v;
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -503,6 +561,16 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(float *__restrict_
   }
 }
 
+__global__ __launch_bounds__(256) void scale_shift_act_scalar_kernel(float *__restrict__ x, const float *__restrict__ scale,
+                                                                     const float *__restrict__ shift, long long HW, long long total,
+                                                                     int relu) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long plane = i / HW;
+    const float v = x[i] * scale[plane] + shift[plane];
+    x[i] = relu ? fmaxf(v, 0.f) : v;
+  }
+}
+
 }  // namespace
 
 DVIS_EXPORT int dvis_group_norm_affine(const float *x, const float *gamma, const float *beta, float *scale, float *shift,
@@ -510,11 +578,11 @@ DVIS_EXPORT int dvis_group_norm_affine(const float *x, const float *gamma, const
   DVIS_REQUIRE(N >= 0 && C > 0 && G > 0 && HW > 0 && C % G == 0, "group_norm_affine: bad sizes (C=%d G=%d)", C, G);
   if (N == 0) return DVIS_OK;
   DVIS_REQUIRE(x && scale && shift, "group_norm_affine: null pointer");
-  DVIS_REQUIRE(C / G <= 1024 && ((int64_t)(C / G) * HW) % 4 == 0 && ((uintptr_t)x & 15) == 0,
-               "group_norm_affine: a group must be a multiple of 4 floats, x 16-byte aligned");
+  DVIS_REQUIRE(C / G <= 1024, "group_norm_affine: at most 1024 channels per group");
+  const int vec = ((int64_t)(C / G) * HW) % 4 == 0 && ((uintptr_t)x & 15) == 0;
   DVIS_REQUIRE(N * G < (1ll << 31), "group_norm_affine: too many groups");
   hipLaunchKernelGGL(group_norm_affine_kernel, dim3((unsigned)(N * G)), dim3(1024), 0, (hipStream_t)stream, x, gamma, beta,
-                     scale, shift, C, G, (long long)HW, eps);
+                     scale, shift, C, G, (long long)HW, eps, vec);
   return dvis_check_launch("group_norm_affine_kernel");
 }
 
@@ -523,7 +591,13 @@ DVIS_EXPORT int dvis_scale_shift_act(float *x, const float *scale, const float *
   DVIS_REQUIRE(planes >= 0 && HW > 0, "scale_shift_act: bad sizes");
   if (planes == 0) return DVIS_OK;
   DVIS_REQUIRE(x && scale && shift, "scale_shift_act: null pointer");
-  DVIS_REQUIRE(HW % 4 == 0 && ((uintptr_t)x & 15) == 0, "scale_shift_act: HW must be a multiple of 4 and x 16-byte aligned");
+  if (HW % 4 != 0 || ((uintptr_t)x & 15) != 0) {
+    const long long total = (long long)planes * HW;
+    const long long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(scale_shift_act_scalar_kernel, dim3((unsigned)(blocks > 65535 * 16 ? 65535 * 16 : blocks)), dim3(256), 0,
+                       (hipStream_t)stream, x, scale, shift, (long long)HW, total, relu);
+    return dvis_check_launch("scale_shift_act_scalar_kernel");
+  }
   const int HW4 = (int)(HW / 4);
   int chunks = (HW4 + 1023) / 1024;
   if (chunks < 1) chunks = 1;

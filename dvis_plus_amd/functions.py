@@ -443,8 +443,8 @@ def group_norm_affine(x, norm):
     (caller falls back to ``norm(x)``)."""
     N, C, H, W = x.shape
     G = norm.num_groups
-    if not (_fused_map_ok(x) and (C // G) * H * W % 4 == 0 and C // G <= 1024 and x.data_ptr() % 16 == 0):
-        _torch_path("group_norm_affine", x, "needs contiguous 16-byte aligned fp32 NCHW, group size % 4 == 0")
+    if not (_fused_map_ok(x) and C // G <= 1024):
+        _torch_path("group_norm_affine", x, "needs contiguous fp32 NCHW, at most 1024 channels per group")
         return None
     scale = torch.empty(N * C, dtype=torch.float32, device=x.device)
     shift = torch.empty(N * C, dtype=torch.float32, device=x.device)
@@ -458,7 +458,7 @@ def group_norm_affine(x, norm):
 
 
 def scale_shift_act_(x, scale, shift, relu=False):
-    """In place: x[n, c] = relu?(x[n, c] * scale[n*C + c] + shift[n*C + c]) on an fp32 NCHW GPU map (HW % 4 == 0)."""
+    """In place: x[n, c] = relu?(x[n, c] * scale[n*C + c] + shift[n*C + c]) on an fp32 NCHW GPU map."""
     N, C, H, W = x.shape
     with torch.cuda.device(x.device):
         rc = native.lib().dvis_scale_shift_act(native.dev_ptr(x, "x"), native.dev_ptr(scale, "scale"),
@@ -473,8 +473,8 @@ def upsample_add(lateral, top, lat_affine=None):
     lat_affine = (scale, shift) from ``group_norm_affine``: the lateral operand is read as lateral * scale + shift (its
     GroupNorm applied on the fly)."""
     N, C, H, W = lateral.shape
-    if not (_fused_map_ok(lateral) and top.dtype == torch.float32 and W % 4 == 0):
-        _torch_path("upsample_add", lateral, "needs contiguous fp32 NCHW with W % 4 == 0")
+    if not (_fused_map_ok(lateral) and top.dtype == torch.float32):
+        _torch_path("upsample_add", lateral, "needs contiguous fp32 NCHW")
         import torch.nn.functional as F
         if lat_affine is not None:
             lateral = lateral * lat_affine[0].view(N, C, 1, 1) + lat_affine[1].view(N, C, 1, 1)
@@ -1255,10 +1255,10 @@ def bias_act_(x, bias=None, res=None, relu=True):
     """In place: x = relu?(x + bias[c] + res) on an NCHW float32 tensor — one pass instead of torch's three kernels
     (conv bias add, residual add, ReLU).  Non-GPU / odd shapes use the torch ops."""
     N, C, H, W = x.shape
-    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and (H * W) % 4 == 0
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
             and (res is None or (res.is_contiguous() and res.shape == x.shape and res.dtype == torch.float32))
             and not torch.is_grad_enabled()):
-        _torch_path("bias_act_", x, "needs contiguous fp32 NCHW with H*W % 4 == 0 (and a matching residual)")
+        _torch_path("bias_act_", x, "needs contiguous fp32 NCHW (and a matching residual)")
         if bias is not None:
             x = x + bias.view(1, -1, 1, 1)
         if res is not None:

@@ -37,7 +37,8 @@ def test_add_layernorm_3d_shapes_like_the_decoder():
     torch.testing.assert_close(out, ref, rtol=1e-5, atol=5e-6)
 
 
-@pytest.mark.parametrize("N,C,h,w,H,W", [(2, 8, 5, 8, 10, 16), (1, 3, 7, 10, 23, 40), (2, 4, 46, 80, 92, 160)])
+@pytest.mark.parametrize("N,C,h,w,H,W", [(2, 8, 5, 8, 10, 16), (1, 3, 7, 10, 23, 40), (2, 4, 46, 80, 92, 160),
+                                           (2, 5, 5, 7, 10, 14), (3, 4, 3, 5, 7, 11)])     # W % 4 != 0: the scalar form
 def test_upsample_add(N, C, h, w, H, W):
     from dvis_plus_amd.functions import upsample_add
     g = torch.Generator().manual_seed(h * w)
@@ -58,7 +59,7 @@ def test_linear_relu_epilogue():
     torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("N,C,H,W", [(2, 64, 8, 12), (3, 256, 23, 40), (1, 7, 5, 4)])
+@pytest.mark.parametrize("N,C,H,W", [(2, 64, 8, 12), (3, 256, 23, 40), (1, 7, 5, 4), (2, 64, 15, 27), (3, 5, 3, 7)])   # last two: HW % 4 != 0
 def test_bias_act_inplace(N, C, H, W):
     from dvis_plus_amd.functions import bias_act_
     g = torch.Generator().manual_seed(C)
@@ -99,7 +100,8 @@ def test_bias_relu_maxpool_is_bit_identical_to_the_three_torch_ops(N, C, H, W):
     assert torch.equal(out_nob, F.max_pool2d(torch.relu(x), kernel_size=3, stride=2, padding=1))
 
 
-@pytest.mark.parametrize("N,C,H,W,relu", [(2, 64, 6, 10, True), (3, 256, 23, 40, False), (1, 32, 92, 160, True)])
+@pytest.mark.parametrize("N,C,H,W,relu", [(2, 64, 6, 10, True), (3, 256, 23, 40, False), (1, 32, 92, 160, True),
+                                              (2, 32, 15, 27, True), (3, 96, 5, 7, False)])      # groups not a multiple of 4 floats
 def test_group_norm_affine_plus_apply_equals_torch_group_norm(N, C, H, W, relu):
     from dvis_plus_amd import functions as Fn
     g = torch.Generator().manual_seed(C + H)

@@ -116,6 +116,28 @@ def test_pipeline_gpu_vs_oracle(mode, task):
         PPar.compare_vss(out, ref, stages, what)
 
 
+@pytest.mark.parametrize("hw", [(150, 200), (224, 350), (90, 290)])
+def test_pipeline_odd_padded_sizes_vs_oracle(hw):
+    """Frames whose padded stride-32 map is odd x odd (160 x 224 -> 5 x 7, 224 x 352 -> 7 x 11, 96 x 320 -> 3 x 10: planes
+    that are not a multiple of 4 floats and not 16-byte aligned) through the whole pipeline in the product's default
+    (strict) mode: every fused glue kernel has a tail for them (csrc/fused_elementwise.hip: the scalar forms), so the
+    reference's "any resolution" holds without a torch formulation running on the GPU; results vs the oracle."""
+    from dvis_plus_amd.meta_architecture import build_dvis_plus_r50
+    H, W = hw
+    cfg = dict(num_classes=20, n_things=10, enc_layers=2, tracker_layers=2, refiner_layers=2)
+    m = build_dvis_plus_r50("offline", task="vps", num_queries=100, dec_layers=4, object_mask_threshold=0.06, **cfg)
+    _perturb_msda(m.sem_seg_head.pixel_decoder)
+    g = torch.Generator().manual_seed(11)
+    frames = [torch.randint(0, 256, (3, H, W), dtype=torch.uint8, generator=g) for _ in range(3)]
+    sd = PPar.cpu_state(m)
+    m = m.to(DEV)
+    out = m([{"image": [f.to(DEV) for f in frames], "height": H, "width": W}])
+    ref, stages = PPar.run_oracle(m, sd, frames, offline=True, task="vps", nheads=8, dec_layers=3,
+                                  object_mask_threshold=0.06, **cfg)
+    assert len(ref[1]) > 0
+    PPar.compare_vps(out, ref, stages, f"offline vps 3x{H}x{W} (odd padded maps)")
+
+
 def test_image_mask2former_gpu_vs_oracle():
     """BASELINE config #1 on the GPU: image Mask2Former semantic output vs the CPU oracle (from backbone outputs on)."""
     from dvis_plus_amd.meta_architecture import build_mask2former_r50
