@@ -736,7 +736,37 @@ X3_CONV_XEXP = int(os.environ.get("DVIS_X3_CONV_XEXP", "2"))
 # ones csrc/conv1x1.hip (weights resident in LDS, exact fp32) was written for: 64 -> 256 + shortcut at 184 x 320 runs at 5.0
 # TB/s there against 4.3, 256 -> 128 in 0.62 ms against 1.13 (tools/x3_time.py conv)
 X3_CONV1X1_MIN_CI = int(os.environ.get("DVIS_X3_CONV1X1_MIN_CI", "64"))
-_X3_PACKED = {}
+
+
+class _PackCache:
+    """Packed forms of weights, made once per (weight, kind of pack, weight version).  Keyed by (id(weight), kind) — the same
+    tensor packed two ways (linear and FFN, 1x1 and 3x3) keeps both — with least-recently-used eviction past `cap` entries
+    (a cleared-at-once dict re-packed every layer of every forward once a process held more than `cap` weights; each pack
+    reads max|w| back to the host)."""
+
+    def __init__(self, cap=4096):
+        from collections import OrderedDict
+        self.cap, self.d = cap, OrderedDict()
+
+    def get(self, key_obj, kind, version_key, make):
+        k = (id(key_obj), kind)
+        ent = self.d.get(k)
+        if ent is None or ent[0] != version_key:
+            self.d[k] = ent = (version_key, make(), key_obj)       # (holds key_obj: id() stays unique)
+            while len(self.d) > self.cap:
+                self.d.popitem(last=False)
+        else:
+            self.d.move_to_end(k)
+        return ent[1]
+
+    def __len__(self):
+        return len(self.d)
+
+    def clear(self):
+        self.d.clear()
+
+
+_X3_PACKED = _PackCache()
 
 
 def _x3_exp(w):
@@ -745,13 +775,8 @@ def _x3_exp(w):
     return 0 if m == 0.0 or m != m else 14 - math.frexp(m)[1]
 
 
-def _x3_cache(key_obj, version_key, make):
-    ent = _X3_PACKED.get(id(key_obj))
-    if ent is None or ent[0] != version_key:
-        if len(_X3_PACKED) > 512:
-            _X3_PACKED.clear()
-        _X3_PACKED[id(key_obj)] = ent = (version_key, make(), key_obj)       # (holds key_obj: id() stays unique)
-    return ent[1]
+def _x3_cache(key_obj, version_key, make, kind="linear"):
+    return _X3_PACKED.get(key_obj, kind, version_key, make)
 
 
 def x3_pack(weight):
@@ -773,9 +798,11 @@ def x3_pack(weight):
     return _x3_cache(weight, (weight._version, weight.data_ptr(), weight.device, tuple(weight.shape)), make)
 
 
-def x3_ok(x, N, K, ln=False):
+def x3_ok(x, N, K, ln=False, add=False):
+    """Does csrc/gemm_x3.hip serve ``x (..., K) @ W (N, K).T``?  ln: the output_proj + residual + LayerNorm form; add: the form
+    with the in-kernel ``x + xadd`` (dvis_x3_linear_add: K = 256 only)."""
     return (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and x.shape[-1] == K
-            and bool(native.lib().dvis_x3_linear_supported(N, K, int(ln))))
+            and (not add or K == 256) and bool(native.lib().dvis_x3_linear_supported(N, K, int(ln))))
 
 
 def _x3_rows(x, name):
@@ -842,7 +869,8 @@ def x3_linear_ln(x, weight, bias, res, norm, pos=None, xexp=None):
 def x3_ffn_ok(x, lin1, lin2):
     K, H, N = lin1.weight.shape[1], lin1.weight.shape[0], lin2.weight.shape[0]
     return (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and x.shape[-1] == K
-            and lin2.weight.shape[1] == H and native.lib().dvis_x3_ffn_packed_bytes(K, H, N) > 0)
+            and lin2.weight.shape[1] == H and lin1.bias is not None and lin2.bias is not None
+            and native.lib().dvis_x3_ffn_packed_bytes(K, H, N) > 0)
 
 
 def x3_ffn_ln(x, lin1, lin2, norm, pos=None, xexp=None, hexp=None):
@@ -861,7 +889,7 @@ def x3_ffn_ln(x, lin1, lin2, norm, pos=None, xexp=None, hexp=None):
                                                        N, e1, e2, ctypes.c_void_p(buf.data_ptr()),
                                                        native.stream_ptr(a.device)), "dvis_x3_ffn_pack")
         return buf, e1, e2
-    buf, e1, e2 = _x3_cache(w1, (w1._version, w2._version, w1.data_ptr(), w2.data_ptr(), w1.device), make)
+    buf, e1, e2 = _x3_cache(w1, (w1._version, w2._version, w1.data_ptr(), w2.data_ptr(), w1.device), make, kind="ffn")
     out = torch.empty((*x.shape[:-1], N), dtype=torch.float32, device=x.device)
     pos, pos_rows, out2 = _x3_pos(pos, x, N)
     with torch.cuda.device(x.device):
@@ -1019,7 +1047,7 @@ def conv1x1_x3(x, weight, bias=None, res=None, relu=False, stride=1, xexp=None):
             native.check(native.lib().dvis_conv1x1_x3_pack(native.dev_ptr(w2, "weight"), Co, Ci, e, ctypes.c_void_p(buf.data_ptr()),
                                                            native.stream_ptr(w2.device)), "dvis_conv1x1_x3_pack")
         return buf, e
-    buf, wexp = _x3_cache(weight, ("c1", weight._version, weight.data_ptr(), weight.device), make)
+    buf, wexp = _x3_cache(weight, (weight._version, weight.data_ptr(), weight.device), make, kind="conv1x1")
     out = torch.empty((N, Co, (H + stride - 1) // stride, (W + stride - 1) // stride), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         native.check(native.lib().dvis_conv1x1_x3(
@@ -1047,7 +1075,7 @@ def conv3x3_x3(x, weight, bias=None, res=None, relu=False, stride=1, xexp=None):
             native.check(native.lib().dvis_conv3x3_x3_pack(native.dev_ptr(w2, "weight"), Co, Ci, e, ctypes.c_void_p(buf.data_ptr()),
                                                            native.stream_ptr(w2.device)), "dvis_conv3x3_x3_pack")
         return buf, e
-    buf, wexp = _x3_cache(weight, ("c3", weight._version, weight.data_ptr(), weight.device), make)
+    buf, wexp = _x3_cache(weight, (weight._version, weight.data_ptr(), weight.device), make, kind="conv3x3")
     out = torch.empty((N, Co, (H + stride - 1) // stride, (W + stride - 1) // stride), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         native.check(native.lib().dvis_conv3x3_x3(

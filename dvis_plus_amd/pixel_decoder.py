@@ -215,7 +215,7 @@ class MSDeformAttn(nn.Module):
             if query_pos is not None and query_pos.shape[0] == 1 and _POS_IN_KERNEL and not lowp:
                 pp = Fn.linear(query_pos[0], w)                                    # (Lq, 3*M*L*P): tiny, once per call
                 po, pl = pp[:, o_off:], pp[:, l_off:]
-            elif query_pos is not None and not (x3 and query_pos.shape[0] == 1 and query.dim() == 3):
+            elif query_pos is not None and not (x3 and query_pos.shape[0] == 1 and query.dim() == 3 and self.d_model == 256):
                 query = query + query_pos
                 query_pos = None
             if x3 and query_pos is not None and po is None:

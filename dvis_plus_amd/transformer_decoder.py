@@ -235,7 +235,7 @@ class _MaskedDecoderBase(nn.Module):
                 # V = (tok + level_embed) Wv^T + bv = tok Wv^T + (bv + Wv level_embed): no pass at all
                 tok = tokens[lvl]                                                               # (N, hw, C)
                 pos_t = self.pe_layer.compute(h, w, tok.device).flatten(2).transpose(1, 2)      # (1, hw, C)
-                if Fn.X3 and Fn.x3_ok(tok, Wk.shape[0], Wk.shape[1]):
+                if Fn.X3 and Fn.x3_ok(tok, Wk.shape[0], Wk.shape[1], add=True):
                     # every pixel's keys / values for all layers of the level: split-f16 matrix-core GEMM (csrc/gemm_x3.hip)
                     tok = tok.contiguous()          # a level's rows of the encoder memory: ONE compaction serves both projections
                     kall = Fn.x3_linear(tok, Wk, bk, xadd=pos_t + le).transpose(0, 1)   # (the (N, hw, C) sum is never written)
