@@ -32,6 +32,8 @@ struct CxArgs {
   long long HW, HW_in, pixels;             // output pixels per image, input pixels per image, output pixels in total
   long long tiles;                         // ceil(pixels / (32 NW))
   float xscale, inv;
+  int *flag;                               // range guard (x3_common.h)
+  int tag;
 };
 
 // the w-th work item of workgroup b: XCD x = b % 8 owns the tiles t = x (mod 8); its workgroups deal (tile, pass) pairs
@@ -170,6 +172,7 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
       }
     }
     // epilogue: lane = pixel; registers = channels co0 + 32 nb + 8 q + 4 g + i
+    float chk = 0.f;                   // range guard: NaN as soon as one value is non-finite BEFORE the ReLU (which would hide a NaN)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       float rv[16];                    // the shortcut's 16 values of the block as one batch of requests
@@ -187,11 +190,13 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
         for (int i = 0; i < 4; ++i) {
           const unsigned o = obase + (unsigned)(co + i) * ochan;
           float v = acc[nb][4 * q + i] * a.inv + b[i] + rv[4 * q + i];
+          chk = __builtin_fmaf(v, 0.f, chk);
           if (a.relu) v = fmaxf(v, 0.f);
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, o, 0, 0);
         }
       }
     }
+    if (a.flag != nullptr && chk != chk && p < a.pixels) atomicCAS(a.flag, 0, a.tag);
     tile = ntile, pass = npass_, gm = ngm;
   }
 }
@@ -267,6 +272,8 @@ static int cx_launch(const float *x, const void *packed, const float *bias, cons
   a.stride = stride, a.W_in = W, a.H_in = H, a.taps = taps, a.OW = OW, a.HW = (long long)OH * OW, a.HW_in = (long long)H * W;
   a.pixels = a.HW * N;
   a.xscale = ldexpf(1.f, xexp), a.inv = ldexpf(1.f, -(xexp + wexp));
+  const X3Guard gd = dvis_x3_guard();
+  a.flag = gd.flag, a.tag = gd.tag;
   const int grid = dvis_x3_persistent_cus();
   hipStream_t st = (hipStream_t)stream;
   static const int nw = getenv("DVIS_X3_CONV_WAVES") ? atoi(getenv("DVIS_X3_CONV_WAVES")) : 8;

@@ -84,6 +84,8 @@ struct EpiArgs {
   int64_t ldo;
   float inv;                         // 2^-(xexp + wexp)
   int relu;
+  int *flag;                         // range guard (x3_common.h): NULL or the device word that receives `tag` on a non-finite row
+  int tag;
 };
 
 // acc (NB blocks x 16) -> out.  LN = false: act(acc * inv + bias).  LN = true: LayerNorm(acc * inv + bias + res) over the
@@ -125,6 +127,8 @@ __device__ __forceinline__ void epilogue(f16v *acc, const EpiArgs &e, const floa
       }
     }
     sum += __shfl_xor(sum, 32);
+    // range guard: a split operand beyond the f16 range leaves a non-finite value in the row, hence in its sum
+    if (e.flag != nullptr && !(fabsf(sum) <= 3.4028235e38f)) atomicCAS(e.flag, 0, e.tag);      // first offender wins: later layers only inherit its NaNs
     mean = sum * (1.f / N);
     float sq = 0.f;
 #pragma unroll
@@ -137,6 +141,7 @@ __device__ __forceinline__ void epilogue(f16v *acc, const EpiArgs &e, const floa
     sq += __shfl_xor(sq, 32);
     rstd = rsqrtf(sq * (1.f / N) + e.eps);
   }
+  float chk = 0.f;                   // range guard of the plain form: NaN as soon as one pre-activation value is inf / NaN
   const float *pr = nullptr;
   f4 pv[2][4];
   auto fetch_pos = [&](int nb, f4 *dst) {
@@ -167,6 +172,7 @@ __device__ __forceinline__ void epilogue(f16v *acc, const EpiArgs &e, const floa
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float t = acc[nb][4 * q + i] * e.inv + b[i];
+          chk = __builtin_fmaf(t, 0.f, chk);
           v[q][i] = e.relu ? fmaxf(t, 0.f) : t;
         }
       }
@@ -179,6 +185,9 @@ __device__ __forceinline__ void epilogue(f16v *acc, const EpiArgs &e, const floa
         store_block(scr, lane, v, e.out2 + tok0 * e.ldo + 32 * nb, e.ldo, rows_valid);
       }
     }
+  }
+  if constexpr (!LN) {
+    if (e.flag != nullptr && chk != chk) atomicCAS(e.flag, 0, e.tag);      // first offender wins: later layers only inherit its NaNs
   }
 }
 
@@ -463,6 +472,32 @@ DVIS_EXPORT int dvis_x3_set_reserve(int cus) {
   return __atomic_exchange_n(&g_x3_reserve, r, __ATOMIC_RELAXED);
 }
 
+// ---- range guard state: one device word per device (registered by the host layer), one tag per thread for the next launch
+static int *g_x3_flag[64] = {};
+static thread_local int t_x3_tag = 1;
+
+X3Guard dvis_x3_guard() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return X3Guard{nullptr, 0};
+  return X3Guard{__atomic_load_n(&g_x3_flag[dev], __ATOMIC_RELAXED), t_x3_tag};
+}
+
+DVIS_EXPORT int dvis_x3_set_range_flag(int32_t *flag) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+    dvis_set_error("dvis_x3_set_range_flag: no current device");
+    return DVIS_E_ARG;
+  }
+  __atomic_store_n(&g_x3_flag[dev], (int *)flag, __ATOMIC_RELAXED);
+  return DVIS_OK;
+}
+
+DVIS_EXPORT int dvis_x3_set_tag(int tag) {
+  const int prev = t_x3_tag;
+  t_x3_tag = tag > 0 ? tag : 1;
+  return prev;
+}
+
 DVIS_EXPORT int dvis_x3_linear_supported(int N, int K, int ln) {
   int nb;
   if (K < 64 || K % 64 != 0 || K > 8192) return 0;
@@ -512,6 +547,8 @@ static int x3_linear_impl(const float *x, int64_t ldx, int64_t M, int K, const v
   if (M == 0) return DVIS_OK;
   EpiArgs e = {};
   e.bias = bias, e.out = out, e.ldo = ldo, e.inv = x3_pow2(-(xexp + wexp)), e.relu = relu;
+  const X3Guard gd = dvis_x3_guard();
+  e.flag = gd.flag, e.tag = gd.tag;
   const float xs = x3_pow2(xexp);
   hipStream_t st = (hipStream_t)stream;
   int NB;
@@ -566,6 +603,8 @@ DVIS_EXPORT int dvis_x3_linear_ln(const float *x, int64_t ldx, int64_t M, int K,
   EpiArgs e = {};
   e.bias = bias, e.res = res, e.ldres = ldres, e.gamma = gamma, e.beta = beta, e.eps = eps, e.pos = pos, e.pos_rows = pos_rows;
   e.out = out, e.out2 = out2, e.ldo = ldo, e.inv = x3_pow2(-(xexp + wexp));
+  const X3Guard gd = dvis_x3_guard();
+  e.flag = gd.flag, e.tag = gd.tag;
   const float xs = x3_pow2(xexp);
   const int npass = 1;
   hipStream_t st = (hipStream_t)stream;
@@ -602,6 +641,8 @@ DVIS_EXPORT int dvis_x3_ffn_ln(const float *x, int64_t ldx, int64_t M, int K, in
   EpiArgs e = {};
   e.bias = b2, e.res = x, e.ldres = ldx, e.gamma = gamma, e.beta = beta, e.eps = eps, e.pos = pos, e.pos_rows = pos_rows;
   e.out = out, e.out2 = out2, e.ldo = ldo, e.inv = x3_pow2(-(hexp + w2exp));
+  const X3Guard gd = dvis_x3_guard();
+  e.flag = gd.flag, e.tag = gd.tag;
   FfnArgs f = {b1, x3_pow2(-(xexp + w1exp)), x3_pow2(hexp), H / 128};
   static DvisLdsOptIn opted;
   return x3_launch(x3_ffn_kernel, &opted, kStages * Ring<8>::kItemBytes + kWaves * kScratch + (size_t)(H + 3 * 256) * 4, M,

@@ -81,6 +81,16 @@ __device__ __forceinline__ void mma_item(const char *stage, int lane, f16v *acc,
 }  // namespace
 // Persistent grids: one workgroup per CU minus the reserve of dvis_x3_set_reserve (defined in csrc/gemm_x3.hip).
 int dvis_x3_persistent_cus();
+// Range guard (defined in csrc/gemm_x3.hip).  An activation beyond the f16 range after its 2^xexp scaling (|x| >= 65520 / 2^xexp)
+// becomes (hi, lo) = (inf, -inf) in split8 and every product with it inf or NaN: the output element is NON-FINITE before its
+// bias / ReLU (a ReLU would turn a NaN into 0 — the silent case).  The kernels' epilogues test exactly that at one fused
+// multiply-add per output value (LayerNorm forms: at the row sum, for free) and store the launch's tag into the device word
+// registered with dvis_x3_set_range_flag; the host reads it once per clip.  x3_guard(): the (flag, tag) of the next launch.
+struct X3Guard {
+  int *flag;      // NULL: no guard registered for the current device
+  int tag;
+};
+X3Guard dvis_x3_guard();
 namespace {
 
 // EXTRA: ordinary loads the kernel keeps in flight, issued between an item's pieces and the next-but-one item's (the

@@ -695,7 +695,7 @@ def linear(x, weight, bias=None, relu=False, own=None):
     OWN_GEMM_DEFAULT decides; otherwise the library GEMM — with a bias the ReLU then runs as the GEMM's epilogue
     (hipBLASLt via torch._addmm_activation) instead of a second pass.  CPU tensors / autograd always take torch ops."""
     forced = own is True
-    if X3 and not forced and x.is_cuda and x.numel() // max(1, x.shape[-1]) >= X3_MIN_ROWS and weight.dim() == 2 \
+    if x3_on() and not forced and x.is_cuda and x.numel() // max(1, x.shape[-1]) >= X3_MIN_ROWS and weight.dim() == 2 \
             and weight._base is None and not torch.is_autocast_enabled() and x3_ok(x, weight.shape[0], weight.shape[1]):
         # tall projections (every pixel / every ViT token of every frame): split-f16 matrix-core kernel (csrc/gemm_x3.hip).
         # Weights that are views (slices made per call) would be re-packed per call: they stay on the paths below.
@@ -727,6 +727,143 @@ def linear_relu(x, lin, own=None):
 # ---- the encoder's tall GEMMs on the F16 matrix cores (csrc/gemm_x3.hip): fp32 operands as two f16 terms, three products
 # per pair, fp32 accumulation -> the error of an fp32 GEMM at 3/16 of its matrix-core time.
 X3 = os.environ.get("DVIS_X3", "1") != "0"
+# Stages of phase A whose layers stay on the exact-fp32 kernels although X3 is on: a comma-separated subset of
+# backbone, pd_proj (the pixel decoder's input projections), mask_path (lateral 1x1 + FPN 3x3 + mask_features 1x1), encoder
+# (MSDeformAttn projections + FFN), decoder_kv (the masked-attention decoder's key / value projections).  The callers mark their stage with `x3_stage(name)`.
+X3_OFF = frozenset(v for v in os.environ.get("DVIS_X3_OFF", "").split(",") if v)
+_x3_tls = threading.local()
+
+
+class x3_stage:
+    """``with x3_stage("encoder"): ...`` — names the stage the enclosed calls belong to (per thread), for X3_OFF."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.prev = getattr(_x3_tls, "stage", None)
+        _x3_tls.stage = self.name
+
+    def __exit__(self, *exc):
+        _x3_tls.stage = self.prev
+
+
+def x3_on():
+    """Split-f16 matrix-core kernels for the calling stage?  (the master switch X3 / DVIS_X3, minus the stages in X3_OFF, and not
+    inside an `x3_disabled()` block)"""
+    return X3 and not getattr(_x3_tls, "disabled", 0) and not (X3_OFF and getattr(_x3_tls, "stage", None) in X3_OFF)
+
+
+class x3_disabled:
+    """``with x3_disabled(): ...`` — the enclosed calls (this thread) take the exact-fp32 kernels: the re-run after an X3RangeError."""
+
+    def __enter__(self):
+        _x3_tls.disabled = getattr(_x3_tls, "disabled", 0) + 1
+
+    def __exit__(self, *exc):
+        _x3_tls.disabled -= 1
+
+
+class X3RangeError(RuntimeError):
+    """An activation left the f16 range of the split-f16 kernels (|x| >= 65520 / 2^xexp: 4095 in the linear / FFN kernels at
+    DVIS_X3_XEXP = 4, 16380 in the convolutions at DVIS_X3_CONV_XEXP = 2): the layer's output rows are non-finite."""
+
+
+# what DVIS_Plus_* do with an X3RangeError on a single GPU: "rerun" the clip on the exact-fp32 kernels with a warning (and keep
+# that model on them from then on), or "raise".  Sharded runs always raise: the other ranks already hold the gathered queries.
+X3_ON_OVERFLOW = os.environ.get("DVIS_X3_ON_OVERFLOW", "rerun")
+
+
+class _X3RangeGuard:
+    """Host side of the kernels' range guard (include/dvis_hip.h: dvis_x3_set_range_flag / dvis_x3_set_tag).  One sticky int32
+    word per device receives the TAG of a launch that produced a non-finite pre-activation value; every packed weight gets a
+    tag, so the word names the layer.  `snapshot()` (after phase A of a clip is enqueued) copies the word to pinned memory
+    behind the clip's kernels — no synchronisation; `verify()` (before the clip's results are used) waits for that copy."""
+
+    def __init__(self):
+        self.words, self.pool, self.tags, self.lock = {}, {}, {}, threading.Lock()
+        self.next_tag = 1
+
+    def word(self, device):
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        w = self.words.get(idx)
+        if w is None:
+            with self.lock:
+                w = self.words.get(idx)
+                if w is None:
+                    w = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", idx))
+                    with torch.cuda.device(idx):
+                        native.check(native.lib().dvis_x3_set_range_flag(ctypes.c_void_p(w.data_ptr())), "dvis_x3_set_range_flag")
+                    self.words[idx] = w
+                    self.pool[idx] = [[torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(16)], 0]
+        return w
+
+    def new_tag(self, weight, kind):
+        import weakref
+        with self.lock:
+            tag = self.next_tag
+            self.next_tag += 1
+            self.tags[tag] = (kind, weakref.ref(weight), tuple(weight.shape))
+        return tag
+
+    def snapshot(self, device):
+        if not (X3 and device.type == "cuda"):
+            return None
+        w = self.word(device)
+        idx = w.device.index
+        bufs = self.pool[idx]
+        host = bufs[0][bufs[1] % len(bufs[0])]
+        bufs[1] += 1
+        host.copy_(w, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(w.device))
+        return (host, ev, w)
+
+    def describe(self, tag, model=None):
+        kind, ref, shape = self.tags.get(tag, ("?", lambda: None, ()))
+        wt, name = ref(), None
+        if wt is not None and model is not None:
+            for n, mod in model.named_modules():
+                for pn, prm in list(mod.named_parameters(recurse=False)) + list(mod.named_buffers(recurse=False)):
+                    if prm is wt:
+                        name = f"{n}.{pn}"
+                if name is None and getattr(mod, "_folded", None) is not None and mod._folded[1] is wt:
+                    name = f"{n} (FrozenBN folded)"
+                if name:
+                    break
+        return f"{name or 'weight'} {shape} [{kind} kernel]"
+
+    def verify(self, snap, model=None):
+        if snap is None:
+            return
+        host, ev, w = snap
+        ev.synchronize()
+        tag = int(host[0])
+        if tag:
+            w.zero_()
+            raise X3RangeError(
+                f"split-f16 range exceeded in {self.describe(tag, model)}: an input activation (or the FFN's hidden activation) "
+                f"reached |x| >= 65520 / 2^xexp (xexp = {X3_XEXP} in the linear / FFN kernels, {X3_CONV_XEXP} in the convolutions) and "
+                "the layer's outputs are non-finite.  Exact-fp32 kernels: DVIS_X3=0 (everything) or DVIS_X3_OFF=<stage,...> "
+                "(backbone, pd_proj, mask_path, encoder, decoder_kv); more range at the cost of small-value precision: "
+                "DVIS_X3_XEXP / DVIS_X3_CONV_XEXP.")
+
+    def check_now(self, device, model=None):
+        """Synchronous form (tests, one-off calls): reads the word after a device synchronisation."""
+        self.verify(self.snapshot(device), model)
+
+
+X3_GUARD = _X3RangeGuard()
+
+
+def x3_range_snapshot(device):
+    return X3_GUARD.snapshot(device)
+
+
+def x3_range_verify(snap, model=None):
+    X3_GUARD.verify(snap, model)
+
+
 X3_MIN_ROWS = 32768        # linear(): below this many rows (128 tiles of 256) the persistent kernel cannot fill the chip
 X3_XEXP = int(os.environ.get("DVIS_X3_XEXP", "4"))      # activations are scaled by 2^4 before the split (|x| < 4094)
 # the convolutions see ReLU'd feature maps without a normalisation in front: more range (|x| < 16376), an absolute floor of
@@ -752,11 +889,15 @@ class _PackCache:
         k = (id(key_obj), kind)
         ent = self.d.get(k)
         if ent is None or ent[0] != version_key:
-            self.d[k] = ent = (version_key, make(), key_obj)       # (holds key_obj: id() stays unique)
+            tag = ent[3] if ent is not None else X3_GUARD.new_tag(key_obj, kind)
+            self.d[k] = ent = (version_key, make(), key_obj, tag)       # (holds key_obj: id() stays unique)
             while len(self.d) > self.cap:
                 self.d.popitem(last=False)
         else:
             self.d.move_to_end(k)
+        # the launch that follows carries this weight's tag (range guard; per host thread) — and the device's guard word exists
+        X3_GUARD.word(key_obj.device)
+        native.lib().dvis_x3_set_tag(ent[3])
         return ent[1]
 
     def __len__(self):
@@ -1023,7 +1164,7 @@ def conv1x1_bias_act(x, weight, bias=None, res=None, relu=False):
 
 def conv1x1_x3_ok(x, weight, stride=1, res=None):
     """Does csrc/conv1x1_x3.hip (split-f16 matrix-core arithmetic, see csrc/gemm_x3.hip) serve this 1x1 convolution?"""
-    if not (X3 and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.is_contiguous()
+    if not (x3_on() and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.is_contiguous()
             and not torch.is_grad_enabled()):
         return False
     N, Ci, H, W = x.shape

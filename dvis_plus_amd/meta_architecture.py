@@ -235,7 +235,9 @@ class _VideoBase(nn.Module):
         chunk = segmenter_frames_per_call(len(images), images.shape[-2], images.shape[-1], self.segmenter_chunk)
         ms, mf = [], []
         for s in range(0, len(images), chunk):
-            f, _, m = self.sem_seg_head.pixel_decoder.forward_features(self.backbone(images[s:s + chunk]))
+            with Fn.x3_stage("backbone"):
+                feats = self.backbone(images[s:s + chunk])
+            f, _, m = self.sem_seg_head.pixel_decoder.forward_features(feats)
             mf.append(f)
             ms.append(m)
         if len(mf) == 1:
@@ -257,6 +259,31 @@ class _VideoBase(nn.Module):
         """Segmenter over this rank's frames.  Returns per-frame queries (t,Q,·) and mask_features (t,Cm,h,w)."""
         ms, mf = self.encode(images)
         return (*self.decode(ms, mf), mf)
+
+    # ---- range guard of the split-f16 kernels (functions._X3RangeGuard): snapshot behind phase A, verify before its results
+    # are used.  The reference's fp32 island (msdeformattn.py:314,320) has no range to leave; here leaving it is an error (or
+    # a re-run on the exact kernels), never silently wrong masks.
+    def _guard_snapshot(self):
+        return Fn.x3_range_snapshot(self.device) if not getattr(self, "_x3_off", False) else None
+
+    def _guard_verify(self, snap):
+        Fn.x3_range_verify(snap, self)
+
+    def _x3_rerun(self, err, run):
+        """X3RangeError policy of a single-GPU call: re-run `run()` on the exact-fp32 kernels (and stay on them), or raise."""
+        sharded = self.clip_shard.world > 1 or self.clip_shard.force
+        if sharded or Fn.X3_ON_OVERFLOW != "rerun":
+            raise err
+        import warnings
+        warnings.warn(f"{err}  Re-running the clip on the exact-fp32 kernels; this model stays on them (DVIS_X3_ON_OVERFLOW=raise "
+                      "turns this into an error).", RuntimeWarning, stacklevel=3)
+        self._x3_off = True
+        return run()
+
+    def _x3_scope(self):
+        """Context for a model call: the exact kernels once a range error was seen (`_x3_off`), else nothing."""
+        import contextlib
+        return Fn.x3_disabled() if getattr(self, "_x3_off", False) else contextlib.nullcontext()
 
     def _task_output(self, cls, aux, mask_fn, img_size, out_hw, padded_size, T_local, video=None):
         """video: the input dict; an optional "object_mask_threshold" entry overrides the model's for this clip (used by
@@ -300,8 +327,13 @@ class MinVIS(_VideoBase):
         video = batched_inputs[0]
         images, img_size = self.preprocess(video["image"])
         pred = self.sem_seg_head.predictor
-        ms, mask_features = self.encode(images)
-        dec, logits, _ = pred._final_heads(pred._run_layers(ms, mask_features), mask_features, False)   # (T,Q,C), (T,Q,K+1)
+        with self._x3_scope():
+            ms, mask_features = self.encode(images)
+            dec, logits, _ = pred._final_heads(pred._run_layers(ms, mask_features), mask_features, False)   # (T,Q,C), (T,Q,K+1)
+        try:
+            self._guard_verify(self._guard_snapshot())
+        except Fn.X3RangeError as e:
+            return self._x3_rerun(e, lambda: self.forward(batched_inputs))
         T, Q, _ = dec.shape
         # ---- alignment chain: frame 0 keeps its order, frame t is matched to the ALIGNED frame t-1
         idx = torch.arange(Q, device=dec.device).unsqueeze(0).repeat(T, 1)
@@ -341,7 +373,12 @@ class DVIS_Plus_online(_VideoBase):
         video = batched_inputs[0]
         self.keep = bool(video.get("keep", False))
         images, img_size = self.preprocess(video["image"])
-        embds, embds_nn, logits, mask_features = self.segment(images)
+        with self._x3_scope():
+            embds, embds_nn, logits, mask_features = self.segment(images)
+        try:
+            self._guard_verify(self._guard_snapshot())     # (the tracker's host-side assignment waits for the segmenter anyway)
+        except Fn.X3RangeError as e:
+            return self._x3_rerun(e, lambda: self.forward(batched_inputs))
         to_bctq = lambda z: z.permute(2, 0, 1).unsqueeze(0)
         track = self.tracker(to_bctq(embds), mask_features.unsqueeze(0), resume=self.keep,
                              frame_embeds_no_norm=to_bctq(embds_nn), need_masks=False)
@@ -415,15 +452,17 @@ class DVIS_Plus_offline(_VideoBase):
                 return self.segment(images)
             mf = images.new_zeros((0, mask_dim, images.shape[-2] // 4, images.shape[-1] // 4))
             return (*self.decode(None, mf), mf)
-        if merged:
-            outs = run(torch.cat(batches, 0))
-            sizes = [len(b) for b in batches]
-            parts = [o.split(sizes, 0) for o in outs]
-            per_clip = [tuple(p[j] for p in parts) for j in range(len(videos))]
-        else:
-            per_clip = [run(b) for b in batches]
+        with self._x3_scope():
+            if merged:
+                outs = run(torch.cat(batches, 0))
+                sizes = [len(b) for b in batches]
+                parts = [o.split(sizes, 0) for o in outs]
+                per_clip = [tuple(p[j] for p in parts) for j in range(len(videos))]
+            else:
+                per_clip = [run(b) for b in batches]
+        guard = self._guard_snapshot()
         for m, (e, e_nn, lg, mf) in zip(metas, per_clip):
-            m.update(embds=e, embds_nn=e_nn, logits=lg, mf=mf)
+            m.update(embds=e, embds_nn=e_nn, logits=lg, mf=mf, guard=guard)
             if self.debug_stages is not None:
                 self.debug_stages.update(mask_features=mf)
         return metas
@@ -477,6 +516,7 @@ class DVIS_Plus_offline(_VideoBase):
         """Phase B on the current stream: ONE all-gather of the per-frame queries, tracker + refiner replicated on every
         rank, masks of this rank's frames, post-processing (VPS: one tiny all-reduce of the segment areas)."""
         self.keep = bool(st["video"].get("keep", False))
+        self._guard_verify(st.get("guard"))
         embds, embds_nn, _ = self.clip_shard.all_gather_frames([st["embds"], st["embds_nn"], st["logits"]], st["T"],
                                                                shift=st["shift"])
         # Replicated tracker + refiner need NO broadcast: every rank holds the same gathered queries, the host assignment
@@ -499,6 +539,8 @@ class DVIS_Plus_offline(_VideoBase):
         then masks and post-processing clip by clip."""
         to_bctq = lambda z: z.permute(2, 0, 1).unsqueeze(0)
         self.keep = False
+        for st in sts:
+            self._guard_verify(st.get("guard"))
         gathered = [self.clip_shard.all_gather_frames([st["embds"], st["embds_nn"], st["logits"]], st["T"], shift=st["shift"])
                     for st in sts]
         embds = torch.cat([to_bctq(g[0]) for g in gathered], 0)                      # (clips, 2C, T, Q)
@@ -535,6 +577,8 @@ class DVIS_Plus_offline(_VideoBase):
                 return self._track_phase_batched(sts)
             return [self._track_phase(st) for st in sts]
         assert m <= shard.world
+        for st in sts:
+            self._guard_verify(st.get("guard"))
         gathered = [shard.all_gather_frames([st["embds"], st["embds_nn"], st["logits"]], st["T"], shift=st["shift"])
                     for st in sts]
         Q, K1 = self.num_queries, sts[0]["logits"].shape[-1]
@@ -596,14 +640,19 @@ class DVIS_Plus_offline(_VideoBase):
             phase A can never find themselves waiting for CUs held by a peer that waits for them (the two-stream stall
             of rounds 1-2).  tests/test_stream_gpu.py asserts that no GEMM / convolution library
             call is issued from here, and soaks T = 64 clips."""
+            def track_round():
+                try:
+                    return self._track_round(sts)
+                except Fn.X3RangeError as e:       # single GPU: the round's clips again, on the exact-fp32 kernels
+                    return self._x3_rerun(e, lambda: [self._track_phase(self._segment_phase(st["video"])) for st in sts])
             if not overlap:
-                return self._track_round(sts)
+                return track_round()
             with torch.cuda.stream(side):
                 for st in sts:
                     side.wait_event(st["done"])
                     for t in (st["embds"], st["embds_nn"], st["logits"], st["mf"]):
                         t.record_stream(side)                                       # allocated on the main stream
-                outs = self._track_round(sts)
+                outs = track_round()
                 ready = torch.cuda.Event(enable_timing=self.stream_timing)
                 ready.record(side)
             for out in outs:
@@ -741,7 +790,10 @@ class DVIS_Plus_offline(_VideoBase):
         assert len(batched_inputs) == 1 and not self.training
         video = batched_inputs[0]
         if self.pipeline_rounds <= 1:
-            out = self._track_phase(self._segment_phase(video))
+            try:
+                out = self._track_phase(self._segment_phase(video))
+            except Fn.X3RangeError as e:
+                out = self._x3_rerun(e, lambda: self._track_phase(self._segment_phase(video)))
             return PP.to_reference_format(out) if self.reference_outputs else out
         self.keep = bool(video.get("keep", False))
         frames = video["image"]
@@ -814,6 +866,7 @@ class DVIS_Plus_offline(_VideoBase):
                 tracks.append(run_tracker(c, segs[c]))
         if overlap:
             main.wait_stream(self._tracker_stream)
+        self._guard_verify(self._guard_snapshot())      # (span pipeline: raises; DVIS_X3=0 is the remedy named in the message)
         cat = lambda xs, d: xs[0] if len(xs) == 1 else torch.cat(xs, d)
         embds_nn = cat([s_["embds_nn"] for s_ in segs], 0)
         track = {"pred_embds": cat([t["pred_embds"] for t in tracks], 2),
@@ -1030,7 +1083,20 @@ class MaskFormer(nn.Module):
         for i, x in enumerate(batched_inputs):
             img = (x["image"].to(self.device, torch.float32) - self.pixel_mean) / self.pixel_std
             batch[i, :, :sizes[i][0], :sizes[i][1]] = img
-        outputs = self.sem_seg_head(self.backbone(batch))
+        if getattr(self, "_x3_off", False):
+            with Fn.x3_disabled():
+                outputs = self.sem_seg_head(self.backbone(batch))
+        else:
+            outputs = self.sem_seg_head(self.backbone(batch))
+            try:        # range guard of the split-f16 kernels (functions._X3RangeGuard); the image path synchronises here
+                Fn.x3_range_verify(Fn.x3_range_snapshot(self.device), self)
+            except Fn.X3RangeError as e:
+                if Fn.X3_ON_OVERFLOW != "rerun":
+                    raise
+                import warnings
+                warnings.warn(f"{e}  Re-running on the exact-fp32 kernels; this model stays on them.", RuntimeWarning)
+                self._x3_off = True
+                return self.forward(batched_inputs)
         mask_cls_results = outputs["pred_logits"]
         mask_pred_results = torch.nn.functional.interpolate(outputs["pred_masks"], size=(Hp, Wp), mode="bilinear",
                                                             align_corners=False)

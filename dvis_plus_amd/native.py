@@ -80,6 +80,8 @@ SIGNATURES = {
     "dvis_gemm_ln_pick_config": (_i, [_i, _i, _i]),
     "dvis_x3_packed_bytes": (_i64, [_i, _i]),
     "dvis_x3_set_reserve": (_i, [_i]),
+    "dvis_x3_set_range_flag": (_i, [_p]),
+    "dvis_x3_set_tag": (_i, [_i]),
     "dvis_x3_pack": (_i, [_p, _i64, _i, _i, _i, _p, _p]),
     "dvis_x3_linear_supported": (_i, [_i, _i, _i]),
     "dvis_x3_linear": (_i, [_p, _i64, _i64, _i, _p, _i, _i, _i, _p, _i, _p, _i64, _p]),

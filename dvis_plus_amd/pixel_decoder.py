@@ -192,7 +192,7 @@ class MSDeformAttn(nn.Module):
         lowp = query.dtype != torch.float32 or torch.is_autocast_enabled()
         hm = fast and _MSDA_HM and input_flatten.is_contiguous() and not lowp
         # the tall projections on the F16 matrix cores with split fp32 operands (csrc/gemm_x3.hip)
-        x3 = fast and Fn.X3 and not lowp and not hm and not _MSDA_SLOTS and Fn.x3_ok(input_flatten, self.d_model, self.d_model) \
+        x3 = fast and Fn.x3_on() and not lowp and not hm and not _MSDA_SLOTS and Fn.x3_ok(input_flatten, self.d_model, self.d_model) \
             and Fn.x3_ok(query, 3 * M * L * P, self.d_model)
         if x3:
             value = Fn.x3_linear(input_flatten, self.value_proj.weight, self.value_proj.bias).view(N, Len_in, M, -1)
@@ -272,7 +272,7 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         """True when `with_pos_embed(src, pos)` is formed inside the offsets | logits projection kernel (dvis_x3_linear_add): no
         layer then needs the (N, S, C) tensor src + pos, neither from the previous layer nor from maps_to_tokens."""
         a = self.self_attn
-        return bool(Fn.X3 and pos is not None and pos.dim() == 3 and pos.shape[0] == 1 and src.dim() == 3 and src.is_cuda
+        return bool(Fn.x3_on() and pos is not None and pos.dim() == 3 and pos.shape[0] == 1 and src.dim() == 3 and src.is_cuda
                     and src.dtype == torch.float32 and not torch.is_grad_enabled() and not torch.is_autocast_enabled()
                     and not _POS_IN_KERNEL and not _MSDA_SLOTS and not _MSDA_HM and a.d_model == 256
                     and 3 * a.n_heads * a.n_levels * a.n_points in (128, 192, 256, 288) and a.d_model // a.n_heads in (32, 64)
@@ -290,7 +290,7 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         else:
             src = self.self_attn(src, reference_points, src, spatial_shapes, level_start_index, padding_mask,
                                  spatial_shapes_py=shapes_py, query_pos=pos, post=(src, self.norm1))
-        if Fn.X3 and Fn.x3_ffn_ok(src, self.linear1, self.linear2) and self.norm2.weight is not None:
+        if Fn.x3_on() and Fn.x3_ffn_ok(src, self.linear1, self.linear2) and self.norm2.weight is not None:
             # linear1 -> ReLU -> linear2 -> + src -> norm2 (-> + pos) in one kernel; the hidden tensor stays on chip
             with_pos = emit_next_query and pos is not None and pos.shape[0] == 1 and src.dim() == 3 and not pos_in_proj
             r = Fn.x3_ffn_ln(src, self.linear1, self.linear2, self.norm2, pos=pos if with_pos else None)
@@ -515,7 +515,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
     def forward_features(self, features):
         """features: dict name -> (N, C, H, W).  fp32 island like the reference (msdeformattn.py:314-320).
         Returns (mask_features, out[0], multi_scale_features[:3])."""
-        with torch.autocast(device_type="cuda", enabled=False):
+        with torch.autocast(device_type="cuda", enabled=False), Fn.x3_stage("pd_proj"):
             srcs, pos, affines = [], [], []
             for idx, f in enumerate(self.transformer_in_features[::-1]):
                 x = features[f].float().contiguous()      # (a backbone may hand over channels-last strided maps)
@@ -527,7 +527,8 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 srcs.append(s_ if affine is not None else gn(s_))
                 affines.append(affine)
                 pos.append(self.pe_layer.compute(x.shape[2], x.shape[3], x.device))
-            y, _, _, shapes_py = self.transformer(srcs, pos, affines)
+            with Fn.x3_stage("encoder"):
+                y, _, _, shapes_py = self.transformer(srcs, pos, affines)
             bs = y.shape[0]
             out, tokens, start = [], [], 0
             for li, (h, w) in enumerate(shapes_py):
@@ -537,13 +538,14 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 else:
                     out.append(tokens[-1].transpose(1, 2).reshape(bs, -1, h, w))  # a strided view, no copy
                 start += h * w
-            for idx, f in enumerate(self.in_features[:self.num_fpn_levels][::-1]):
-                x = features[f].float().contiguous()      # NCHW for the fused FPN path (no-op for the R50's maps)
-                cur_fpn, affine = self.lateral_convs[idx].conv_and_affine(x)    # GroupNorm applied inside upsample_add
-                out.append(self.output_convs[idx](Fn.upsample_add(cur_fpn, out[-1], affine)))
-            multi_scale_features = TokenMaps(out[:self.maskformer_num_feature_levels])
-            multi_scale_features.tokens = tokens[:self.maskformer_num_feature_levels]
-            return self.mask_features(out[-1]), out[0], multi_scale_features
+            with Fn.x3_stage("mask_path"):        # lateral 1x1 -> top-down add -> 3x3 output conv -> mask_features 1x1
+                for idx, f in enumerate(self.in_features[:self.num_fpn_levels][::-1]):
+                    x = features[f].float().contiguous()      # NCHW for the fused FPN path (no-op for the R50's maps)
+                    cur_fpn, affine = self.lateral_convs[idx].conv_and_affine(x)    # GroupNorm applied inside upsample_add
+                    out.append(self.output_convs[idx](Fn.upsample_add(cur_fpn, out[-1], affine)))
+                multi_scale_features = TokenMaps(out[:self.maskformer_num_feature_levels])
+                multi_scale_features.tokens = tokens[:self.maskformer_num_feature_levels]
+                return self.mask_features(out[-1]), out[0], multi_scale_features
 
 
 class TokenMaps(list):

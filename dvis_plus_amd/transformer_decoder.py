@@ -222,34 +222,35 @@ class _MaskedDecoderBase(nn.Module):
         size_list, kproj, vproj = [], {}, {}
         kvw = self._level_kv_weights()
         tokens = getattr(x, "tokens", None)
-        for lvl in range(self.num_feature_levels):
-            h, w = x[lvl].shape[-2:]
-            size_list.append((h, w))
-            if kvw[lvl] is None:
-                continue
-            idx, Wk, bk, Wv, bv = kvw[lvl]
-            le = self.level_embed.weight[lvl]
-            ident = isinstance(self.input_proj[lvl], nn.Sequential) and len(self.input_proj[lvl]) == 0
-            if tokens is not None and ident and not torch.is_grad_enabled():
-                # token-major fast path: K = (tok + level_embed + pos) Wk^T + bk with ONE add pass on the (N, hw, C) tokens;
-                # V = (tok + level_embed) Wv^T + bv = tok Wv^T + (bv + Wv level_embed): no pass at all
-                tok = tokens[lvl]                                                               # (N, hw, C)
-                pos_t = self.pe_layer.compute(h, w, tok.device).flatten(2).transpose(1, 2)      # (1, hw, C)
-                if Fn.X3 and Fn.x3_ok(tok, Wk.shape[0], Wk.shape[1], add=True):
-                    # every pixel's keys / values for all layers of the level: split-f16 matrix-core GEMM (csrc/gemm_x3.hip)
-                    tok = tok.contiguous()          # a level's rows of the encoder memory: ONE compaction serves both projections
-                    kall = Fn.x3_linear(tok, Wk, bk, xadd=pos_t + le).transpose(0, 1)   # (the (N, hw, C) sum is never written)
-                    vall = Fn.x3_linear(tok, Wv, bv + F.linear(le, Wv)).transpose(0, 1)
+        with Fn.x3_stage("decoder_kv"):
+            for lvl in range(self.num_feature_levels):
+                h, w = x[lvl].shape[-2:]
+                size_list.append((h, w))
+                if kvw[lvl] is None:
+                    continue
+                idx, Wk, bk, Wv, bv = kvw[lvl]
+                le = self.level_embed.weight[lvl]
+                ident = isinstance(self.input_proj[lvl], nn.Sequential) and len(self.input_proj[lvl]) == 0
+                if tokens is not None and ident and not torch.is_grad_enabled():
+                    # token-major fast path: K = (tok + level_embed + pos) Wk^T + bk with ONE add pass on the (N, hw, C) tokens;
+                    # V = (tok + level_embed) Wv^T + bv = tok Wv^T + (bv + Wv level_embed): no pass at all
+                    tok = tokens[lvl]                                                               # (N, hw, C)
+                    pos_t = self.pe_layer.compute(h, w, tok.device).flatten(2).transpose(1, 2)      # (1, hw, C)
+                    if Fn.x3_on() and Fn.x3_ok(tok, Wk.shape[0], Wk.shape[1], add=True):
+                        # every pixel's keys / values for all layers of the level: split-f16 matrix-core GEMM (csrc/gemm_x3.hip)
+                        tok = tok.contiguous()          # a level's rows of the encoder memory: ONE compaction serves both projections
+                        kall = Fn.x3_linear(tok, Wk, bk, xadd=pos_t + le).transpose(0, 1)   # (the (N, hw, C) sum is never written)
+                        vall = Fn.x3_linear(tok, Wv, bv + F.linear(le, Wv)).transpose(0, 1)
+                    else:
+                        kall = Fn.linear(tok + (pos_t + le), Wk, bk).transpose(0, 1)                # (hw, N, n_l * C) view
+                        vall = Fn.linear(tok, Wv, bv + F.linear(le, Wv)).transpose(0, 1)
                 else:
-                    kall = Fn.linear(tok + (pos_t + le), Wk, bk).transpose(0, 1)                # (hw, N, n_l * C) view
-                    vall = Fn.linear(tok, Wv, bv + F.linear(le, Wv)).transpose(0, 1)
-            else:
-                src = (self.input_proj[lvl](x[lvl]).flatten(2) + le[None, :, None]).permute(2, 0, 1)
-                pos = self.pe_layer.compute(h, w, x[lvl].device).flatten(2).permute(2, 0, 1)   # (hw, 1, C)
-                kall = Fn.linear(src + pos, Wk, bk)                                             # (hw, N, n_l * C)
-                vall = Fn.linear(src, Wv, bv)
-            for n, i in enumerate(idx):
-                kproj[i], vproj[i] = kall[..., n * C:(n + 1) * C], vall[..., n * C:(n + 1) * C]
+                    src = (self.input_proj[lvl](x[lvl]).flatten(2) + le[None, :, None]).permute(2, 0, 1)
+                    pos = self.pe_layer.compute(h, w, x[lvl].device).flatten(2).permute(2, 0, 1)   # (hw, 1, C)
+                    kall = Fn.linear(src + pos, Wk, bk)                                             # (hw, N, n_l * C)
+                    vall = Fn.linear(src, Wv, bv)
+                for n, i in enumerate(idx):
+                    kproj[i], vproj[i] = kall[..., n * C:(n + 1) * C], vall[..., n * C:(n + 1) * C]
         query_embed = self.query_embed.weight.unsqueeze(1)                                      # (Q, 1, C) broadcasts
         output = self.query_feat.weight.unsqueeze(1).repeat(1, N, 1)
         for i in range(self.num_layers):

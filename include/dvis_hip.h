@@ -469,6 +469,15 @@ int64_t dvis_x3_packed_bytes(int N, int K);
  * second stream of small kernels next to them (DVIS_Plus_offline.stream(): the previous clip's tracker chain) leaves `cus` CUs
  * (a multiple of 8) out of their grids; returns the previous setting.  Default 0 (env DVIS_X3_RESERVE). */
 int dvis_x3_set_reserve(int cus);
+/* Range guard of the split-f16 kernels.  The reference computes this path in fp32 (an explicit fp32 island,
+ * mask2former/modeling/pixel_decoder/msdeformattn.py:314,320): no activation magnitude breaks it.  Here an activation with
+ * |v 2^xexp| >= 65520 becomes (inf, -inf) in the split and its output row non-finite — which a following ReLU would turn into
+ * plain zeros.  Every dvis_x3_* / dvis_conv*_x3 launch therefore tests its PRE-activation outputs and, on a non-finite value,
+ * stores the launch's tag (dvis_x3_set_tag, per host thread, > 0; returns the previous tag) into the int32 device word
+ * registered for the current device (dvis_x3_set_range_flag; NULL = guard off, the default).  The word is sticky: the host
+ * zeroes it, reads it once per clip and maps the tag back to the layer (dvis_plus_amd/functions.py: X3RangeError). */
+int dvis_x3_set_range_flag(int32_t *device_word);
+int dvis_x3_set_tag(int tag);
 int dvis_x3_pack(const float *W, int64_t ldw, int N, int K, int wexp, void *packed, void *stream);
 /* which (N, K) the projection kernels serve (ln != 0: the LayerNorm form) */
 int dvis_x3_linear_supported(int N, int K, int ln);

@@ -103,6 +103,8 @@ def test_f16_range_is_loud():
     x[3, 17] = 9000.0
     out = Fn.x3_linear(x, lin.weight, lin.bias)
     assert not torch.isfinite(out[3]).all() and torch.isfinite(out[:3]).all() and torch.isfinite(out[4:]).all()
+    with pytest.raises(Fn.X3RangeError):          # ... and the kernels' range guard saw it (tests/test_x3_range_guard_gpu.py)
+        Fn.X3_GUARD.check_now(x.device)
     out = Fn.x3_linear(x, lin.weight, lin.bias, xexp=0)
     ref = x.double() @ lin.weight.double().t() + lin.bias.double()
     scale = x.double().abs() @ lin.weight.double().abs().t() + lin.bias.double().abs()
