@@ -45,11 +45,14 @@ struct SplitPlan {
   int nsplit, keys_per_split, qchunks;
 };
 
-SplitPlan plan_split(int BH, int Lq, int Lk) {
+// How the keys of one (batch, head) are split over workgroups — a function of (Lq, Lk) ONLY, never of the batch: the merged
+// result depends on where the splits fall, and a frame of the per-frame segmenter (frames = batch) must get the same bits
+// whether it is computed alone, in a 30-frame clip or in a rank's 4-frame shard (north_star's frame sharding).  (Rounds 1 - 4
+// sized the split from the number of (batch, head) pairs to fill the chip at every batch size: batch-dependent bits.)
+SplitPlan plan_split(int /*BH*/, int Lq, int Lk) {
   SplitPlan p;
   p.qchunks = (Lq + 127) / 128;
-  const long long base = (long long)BH * p.qchunks;
-  int ns = (int)((2048 + base - 1) / base);
+  int ns = (16 + p.qchunks - 1) / p.qchunks;            // >= 16 workgroups per (batch, head) from chunks x splits
   const int max_ns = (Lk + 4 * kKT - 1) / (4 * kKT);   // at least 256 keys per split
   if (ns > max_ns) ns = max_ns;
   if (ns < 1) ns = 1;
@@ -315,16 +318,14 @@ struct KeySplitPlan {
 };
 constexpr int kQT = 7;
 
-KeySplitPlan plan_keysplit(int BH, int Lq, int Lk) {
+// Splits of ~512 keys (32 tiles of 16), whatever the batch (see plan_split): 2 / 8 / 29 splits at the R50 levels of 920 / 3680 /
+// 14 720 keys — at 30 frames x 8 heads 480 / 1920 / 6960 waves for the chip's 2048 wave slots, at one frame 16 / 64 / 232.
+KeySplitPlan plan_keysplit(int /*BH*/, int Lq, int Lk) {
   KeySplitPlan p;
   p.qchunks = ((Lq + 15) / 16 + kQT - 1) / kQT;
-  const long long units = (long long)BH * p.qchunks;
-  long long ns = 2048 / units;                 // 256 CUs x 8 waves in one round
-  const int max_ns = (Lk + 127) / 128;         // at least 8 key tiles per wave
-  if (ns > max_ns) ns = max_ns;
-  if (ns < 1) ns = 1;
   const int tiles = (Lk + 15) / 16;
-  const int kps = (int)((tiles + ns - 1) / ns) * 16;
+  const int ns = (tiles + 31) / 32;
+  const int kps = (tiles + ns - 1) / ns * 16;
   p.nsplit = (Lk + kps - 1) / kps;
   p.keys_per_split = kps;
   return p;
@@ -828,15 +829,20 @@ static int attention_launch(const float *q, const int64_t *q_strides, const floa
   float *ws_o = (float *)ws;
   float *ws_ml = ws_o ? ws_o + (size_t)BH * p.nsplit * Lq * d : nullptr;
   const dim3 grid(p.nsplit, BH, p.qchunks), block(512);
-// few workgroups: one per (batch, head, 16-query tile) with the keys split over 4 waves (8.0 vs 14.8 us for the tracker's
-  // batch-1 call); with many (batch, head) pairs the per-tile K/V restaging costs more than it saves (17 vs 11 us at B=30).
-  // (384: also the tracker's hoisted cross-attention call — 6 layers x 8 heads x 7 query tiles = 336 workgroups, 10.3 us
-  // here against 14.8 us on the one-workgroup-per-(batch, head) kernel, measured inside the tracker's hipGraph)
-  static const long long short_max = []() { const char *e = getenv("DVIS_ATTN_SHORT_MAX"); return e ? atoll(e) : 384ll; }();
-  if (kernel == 1 || (Lk <= 128 && p.nsplit == 1 && (long long)BH * ((Lq + 15) / 16) <= short_max)) {
+// Lk <= 128 (decoder / tracker / refiner self- and cross-attention over queries or frames): one workgroup per (batch, head,
+  // 16-query tile) with the keys split over 4 waves (8.0 vs 14.8 us for the tracker's batch-1 call) — for EVERY batch size: the
+  // kernels differ in their summation order, and choosing between them by the number of (batch, head) pairs (rounds 1 - 4: <= 384
+  // workgroups; at B = 30 the other kernel is 6 us faster per call) made a frame's bits depend on its batch mates.
+  // DVIS_ATTN_SHORT_MAX (development): the old rule.
+  static const long long short_max = []() { const char *e = getenv("DVIS_ATTN_SHORT_MAX"); return e ? atoll(e) : -1ll; }();
+  if (kernel == 1 || (Lk <= 128 && p.nsplit == 1 && (short_max < 0 || (long long)BH * ((Lq + 15) / 16) <= short_max))) {
     const dim3 sgrid((Lq + 15) / 16, BH);
     const int nrows = (Lk + 15) / 16 * 16, ls = d + 4;
     const size_t lds = sizeof(float) * ((size_t)std::max(nrows * ls, 64 * d) + (size_t)nrows * ls + 128);
+    static DvisLdsOptIn opted32, opted64;       // (d = 64 with 113 .. 128 keys needs 70 KB)
+    if (const int rc = d == 32 ? dvis_lds_opt_in((const void *)attn_short_kernel<32>, lds, &opted32, "attn_short_kernel")
+                               : dvis_lds_opt_in((const void *)attn_short_kernel<64>, lds, &opted64, "attn_short_kernel"))
+      return rc;
     if (d == 32)
       hipLaunchKernelGGL((attn_short_kernel<32>), sgrid, dim3(256), lds, st, q, qs, k, ks, v, vs, out, os, mask, allowed_count,
                          heads, Lq, Lk, scale);

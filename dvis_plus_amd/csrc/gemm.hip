@@ -418,9 +418,41 @@ int pick_config(int M, int N, int K, int batch) {
   return K >= 256 ? 1 : 0;
 }
 
+// Tile configuration inside ONE K-split family: `nw` waves split K, so every configuration this returns sums an output
+// element's products in the same order — the result of a row depends on (N, K, nw) only, NOT on how many rows share the call.
+// Phase A (the per-frame segmenter: frames are the batch, video_mask2former_transformer_decoder.py:327-335) takes its small
+// GEMMs from here, so a frame gets the same bits alone, in a 30-frame clip or in a rank's 4-frame shard.
+//   nw = 1: one-wave tiles, K unsplit (tall projections over every pixel: 64 x 64 / 128 x 64)
+//   nw = 4: 16 x 16 / 32 x 32 / 64 x 32 / 64 x 64      nw = 8: 16 x 16 / 32 x 16 / 32 x 32 / 64 x 32
+int pick_config_nw(int M, int N, int K, int batch, int nw) {
+  auto wgs = [&](int c) {
+    const long long rb = (M + 16 * kConfigs[c].rt - 1) / (16 * kConfigs[c].rt);
+    const long long cb = (N + 16 * kConfigs[c].ct - 1) / (16 * kConfigs[c].ct);
+    return rb * cb * batch;
+  };
+  if (nw == 1) return ((long long)M * K * 4 > (64ll << 20) && N >= 64) || wgs(14) >= 1024 ? 14 : 12;
+  if (nw == 4) {
+    if (wgs(8) >= 256 || (K >= 1024 && wgs(8) >= 128)) return 8;
+    if (wgs(6) >= 256) return 6;
+    if (wgs(3) >= 192) return 3;
+    return 0;
+  }
+  if (wgs(7) >= 256) return 7;
+  if (wgs(4) >= 192) return 4;
+  if (wgs(2) >= 96) return 2;
+  return 1;
+}
+
 }  // namespace
 
 DVIS_EXPORT int dvis_gemm_num_configs(void) { return kNumConfigs; }
+
+DVIS_EXPORT int dvis_gemm_pick_config_nw(int M, int N, int K, int batch, int nw) {
+  if (nw != 1 && nw != 4 && nw != 8) return -1;
+  return pick_config_nw(M, N, K, batch > 0 ? batch : 1, nw);
+}
+
+DVIS_EXPORT int dvis_gemm_config_waves(int config) { return config >= 0 && config < kNumConfigs ? kConfigs[config].nw : -1; }
 
 DVIS_EXPORT int dvis_gemm_pick_config(int M, int N, int K, int batch) { return pick_config(M, N, K, batch > 0 ? batch : 1); }
 

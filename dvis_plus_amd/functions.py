@@ -499,7 +499,7 @@ def upsample_add(lateral, top, lat_affine=None):
 # (own=True at their call sites: their stream must never carry a library stream-K kernel, csrc/gemm.hip); everything
 # else follows this switch.  DVIS_DETERMINISTIC=1: every GEMM of the pipeline that goes through this module is the own
 # kernel -> two runs of a clip give bit-identical tensors (the library's split / stream-K kernels do not promise that).
-OWN_GEMM_DEFAULT = os.environ.get("DVIS_DETERMINISTIC", "0") == "1"
+OWN_GEMM_DEFAULT = os.environ.get("DVIS_DETERMINISTIC", "1") != "0"
 
 
 class gemm_sizes_as:
@@ -690,27 +690,41 @@ def _own_gemm_ok(x, weight):
             and weight.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
 
 
-def linear(x, weight, bias=None, relu=False, own=None):
-    """``F.linear`` (+ optional ReLU).  own=True: the deterministic own kernel (tracker / refiner call sites); own=None:
-    OWN_GEMM_DEFAULT decides; otherwise the library GEMM — with a bias the ReLU then runs as the GEMM's epilogue
-    (hipBLASLt via torch._addmm_activation) instead of a second pass.  CPU tensors / autograd always take torch ops."""
+def linear(x, weight, bias=None, relu=False, own=None, tall=False):
+    """``F.linear`` (+ optional ReLU) on fp32 GPU inference tensors WITHOUT a library GEMM, in a form whose result for a row does
+    not depend on how many rows share the call (the segmenter folds frames into the batch; a frame must get the same bits alone,
+    in a 30-frame clip or in a rank's shard of it):
+      tall=True   a projection over every pixel / token of every frame: the split-f16 matrix-core kernel (csrc/gemm_x3.hip)
+                  where it is on and serves the shape, else the own exact GEMM from its ONE-WAVE family (K unsplit);
+      default     the decoder's small GEMMs (rows = frames x queries): the own exact GEMM from the K-split family of its K
+                  (4 waves, 8 from K = 1024 on) — dvis_gemm_pick_config_nw: every tile size of a family sums in the same order;
+      own=True    the tracker / refiner call sites: the own GEMM with the size-driven configuration (their batch is pinned
+                  with gemm_sizes_as), raising on operands it cannot serve.
+    DVIS_DETERMINISTIC=0 hands the non-forced calls back to the library (hipBLASLt: faster on some tall exact shapes, bits that
+    change with the row count).  CPU tensors, autograd, autocast / half precision always take torch ops."""
     forced = own is True
-    if x3_on() and not forced and x.is_cuda and x.numel() // max(1, x.shape[-1]) >= X3_MIN_ROWS and weight.dim() == 2 \
-            and weight._base is None and not torch.is_autocast_enabled() and x3_ok(x, weight.shape[0], weight.shape[1]):
-        # tall projections (every pixel / every ViT token of every frame): split-f16 matrix-core kernel (csrc/gemm_x3.hip).
-        # Weights that are views (slices made per call) would be re-packed per call: they stay on the paths below.
+    gpu_inf = x.is_cuda and not torch.is_grad_enabled() and not torch.is_autocast_enabled()
+    if tall and not forced and gpu_inf and x3_on() and weight.dim() == 2 and weight._base is None \
+            and x3_ok(x, weight.shape[0], weight.shape[1]):
+        # Weights that are views (slices made per call) would be re-packed per call: they stay on the exact kernels below.
         return x3_linear(x, weight, bias, relu=relu)
     own = OWN_GEMM_DEFAULT if own is None else own
     if own and x.is_cuda and not torch.is_grad_enabled():
         if _own_gemm_ok(x, weight):
-            return gemm_nt(x, weight.detach(), None if bias is None else bias.detach(), relu=relu)
+            cfg = -1
+            if not forced:
+                K = x.shape[-1]
+                cfg = native.lib().dvis_gemm_pick_config_nw(max(1, x.numel() // K), weight.shape[0], K, 1,
+                                                            1 if tall else (8 if K >= 1024 else 4))
+            return gemm_nt(x, weight.detach(), None if bias is None else bias.detach(), relu=relu, config=cfg)
         if forced:
             # tracker / refiner call sites: their stream must NEVER carry a library (stream-K) GEMM and every rank must
             # compute the same bits — a refused operand is an error whatever DVIS_STRICT says (as in gemm_nt itself)
             raise RuntimeError(f"linear(own=True): the own GEMM cannot serve these operands (needs fp32, K % 4 == 0, 16-byte "
                                f"aligned operands, weight row stride % 4 == 0; x {tuple(x.shape)} {x.dtype}, weight "
                                f"{tuple(weight.shape)} {weight.dtype} stride {tuple(weight.stride())})")
-        _torch_path("linear(own GEMM)", x, "needs fp32, K % 4 == 0 and 16-byte aligned operands")
+        if x.dtype == torch.float32 and not torch.is_autocast_enabled():
+            _torch_path("linear(own GEMM)", x, "needs fp32, K % 4 == 0 and 16-byte aligned operands")
     if relu and bias is not None and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled():
         K = x.shape[-1]
         y = torch._addmm_activation(bias, x.reshape(-1, K), weight.t(), use_gelu=False)
@@ -719,9 +733,9 @@ def linear(x, weight, bias=None, relu=False, own=None):
     return torch.relu(y) if relu else y
 
 
-def linear_relu(x, lin, own=None):
+def linear_relu(x, lin, own=None, tall=False):
     """relu(lin(x)) for an ``nn.Linear``."""
-    return linear(x, lin.weight, lin.bias, relu=True, own=own)
+    return linear(x, lin.weight, lin.bias, relu=True, own=own, tall=tall)
 
 
 # ---- the encoder's tall GEMMs on the F16 matrix cores (csrc/gemm_x3.hip): fp32 operands as two f16 terms, three products
@@ -864,7 +878,6 @@ def x3_range_verify(snap, model=None):
     X3_GUARD.verify(snap, model)
 
 
-X3_MIN_ROWS = 32768        # linear(): below this many rows (128 tiles of 256) the persistent kernel cannot fill the chip
 X3_XEXP = int(os.environ.get("DVIS_X3_XEXP", "4"))      # activations are scaled by 2^4 before the split (|x| < 4094)
 # the convolutions see ReLU'd feature maps without a normalisation in front: more range (|x| < 16376), an absolute floor of
 # 2^-27 = 7.5e-9 per element below |x| = 0.03
@@ -1172,7 +1185,15 @@ def conv1x1_x3_ok(x, weight, stride=1, res=None):
     OH, OW = (H + stride - 1) // stride, (W + stride - 1) // stride
     if res is not None and not (res.is_contiguous() and res.dtype == torch.float32 and tuple(res.shape) == (N, Co, OH, OW)):
         return False
-    return bool(native.lib().dvis_conv1x1_x3_supported(Ci, Co, N, H * W, OH * OW))
+    # (per IMAGE: a batch whose tensors exceed the kernel's 2 GiB of 32-bit offsets is launched in chunks of images by
+    # _conv_x3_chunks — the dispatch, and with it a frame's bits, must not depend on how many frames share the call)
+    return N == 0 or bool(native.lib().dvis_conv1x1_x3_supported(Ci, Co, 1, H * W, OH * OW))
+
+
+def _conv_x3_chunks(N, Ci, Co, HW_in, HW_out):
+    """Images per launch of the split-f16 convolution kernels: both tensors of a launch stay below 2 GiB."""
+    per = max(Ci * HW_in, Co * HW_out) * 4
+    return max(1, min(N, (2 ** 31 - 1) // per))
 
 
 def conv1x1_x3(x, weight, bias=None, res=None, relu=False, stride=1, xexp=None):
@@ -1189,12 +1210,18 @@ def conv1x1_x3(x, weight, bias=None, res=None, relu=False, stride=1, xexp=None):
                                                            native.stream_ptr(w2.device)), "dvis_conv1x1_x3_pack")
         return buf, e
     buf, wexp = _x3_cache(weight, (weight._version, weight.data_ptr(), weight.device), make, kind="conv1x1")
-    out = torch.empty((N, Co, (H + stride - 1) // stride, (W + stride - 1) // stride), dtype=torch.float32, device=x.device)
+    OH, OW = (H + stride - 1) // stride, (W + stride - 1) // stride
+    out = torch.empty((N, Co, OH, OW), dtype=torch.float32, device=x.device)
+    step = _conv_x3_chunks(N, Ci, Co, H * W, OH * OW)
     with torch.cuda.device(x.device):
-        native.check(native.lib().dvis_conv1x1_x3(
-            native.dev_ptr(x, "x"), ctypes.c_void_p(buf.data_ptr()), None if bias is None else native.dev_ptr(bias.detach(), "bias"),
-            None if res is None else native.dev_ptr(res, "res"), native.dev_ptr(out, "out"), N, Ci, Co, H, W, stride,
-            X3_CONV_XEXP if xexp is None else xexp, wexp, 1 if relu else 0, native.stream_ptr(x.device)), "dvis_conv1x1_x3")
+        for i in range(0, N, step):
+            n = min(step, N - i)
+            native.check(native.lib().dvis_conv1x1_x3(
+                native.dev_ptr(x[i:i + n], "x"), ctypes.c_void_p(buf.data_ptr()),
+                None if bias is None else native.dev_ptr(bias.detach(), "bias"),
+                None if res is None else native.dev_ptr(res[i:i + n], "res"), native.dev_ptr(out[i:i + n], "out"), n, Ci, Co, H, W,
+                stride, X3_CONV_XEXP if xexp is None else xexp, wexp, 1 if relu else 0, native.stream_ptr(x.device)),
+                "dvis_conv1x1_x3")
     return out
 
 
@@ -1217,12 +1244,18 @@ def conv3x3_x3(x, weight, bias=None, res=None, relu=False, stride=1, xexp=None):
                                                            native.stream_ptr(w2.device)), "dvis_conv3x3_x3_pack")
         return buf, e
     buf, wexp = _x3_cache(weight, (weight._version, weight.data_ptr(), weight.device), make, kind="conv3x3")
-    out = torch.empty((N, Co, (H + stride - 1) // stride, (W + stride - 1) // stride), dtype=torch.float32, device=x.device)
+    OH, OW = (H + stride - 1) // stride, (W + stride - 1) // stride
+    out = torch.empty((N, Co, OH, OW), dtype=torch.float32, device=x.device)
+    step = _conv_x3_chunks(N, Ci, Co, H * W, OH * OW)
     with torch.cuda.device(x.device):
-        native.check(native.lib().dvis_conv3x3_x3(
-            native.dev_ptr(x, "x"), ctypes.c_void_p(buf.data_ptr()), None if bias is None else native.dev_ptr(bias.detach(), "bias"),
-            None if res is None else native.dev_ptr(res, "res"), native.dev_ptr(out, "out"), N, Ci, Co, H, W, stride,
-            X3_CONV_XEXP if xexp is None else xexp, wexp, 1 if relu else 0, native.stream_ptr(x.device)), "dvis_conv3x3_x3")
+        for i in range(0, N, step):
+            n = min(step, N - i)
+            native.check(native.lib().dvis_conv3x3_x3(
+                native.dev_ptr(x[i:i + n], "x"), ctypes.c_void_p(buf.data_ptr()),
+                None if bias is None else native.dev_ptr(bias.detach(), "bias"),
+                None if res is None else native.dev_ptr(res[i:i + n], "res"), native.dev_ptr(out[i:i + n], "out"), n, Ci, Co, H, W,
+                stride, X3_CONV_XEXP if xexp is None else xexp, wexp, 1 if relu else 0, native.stream_ptr(x.device)),
+                "dvis_conv3x3_x3")
     return out
 
 

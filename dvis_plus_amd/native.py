@@ -99,6 +99,8 @@ SIGNATURES = {
     "dvis_conv3x3_x3": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dvis_gemm_num_configs": (_i, []),
     "dvis_gemm_pick_config": (_i, [_i, _i, _i, _i]),
+    "dvis_gemm_pick_config_nw": (_i, [_i, _i, _i, _i, _i]),
+    "dvis_gemm_config_waves": (_i, [_i]),
 }
 
 _lib = None

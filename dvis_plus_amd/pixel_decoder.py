@@ -201,7 +201,7 @@ class MSDeformAttn(nn.Module):
             value = Fn.gemm_nt(input_flatten.view(N * Len_in, self.d_model), self.value_proj.weight.detach(),
                                self.value_proj.bias.detach(), head_major=self.d_model // M).view(M, N, Len_in, -1)
         else:
-            value = Fn.linear(input_flatten, self.value_proj.weight, self.value_proj.bias)  # library, or own (DVIS_DETERMINISTIC)
+            value = Fn.linear(input_flatten, self.value_proj.weight, self.value_proj.bias, tall=True)   # exact own GEMM (one-wave family)
             if input_padding_mask is not None:
                 value = value.masked_fill(input_padding_mask[..., None], float(0))
             value = value.view(N, Len_in, M, self.d_model // M)
@@ -224,7 +224,7 @@ class MSDeformAttn(nn.Module):
             elif x3:
                 proj = Fn.x3_linear(query.reshape(N * Len_q, self.d_model), self._fused[4], self._fused[5])
             else:
-                proj = Fn.linear(query.reshape(N * Len_q, self.d_model), w, b)     # offsets | logits in one GEMM
+                proj = Fn.linear(query.reshape(N * Len_q, self.d_model), w, b, tall=True)     # offsets | logits in one GEMM
             ref = reference_points if reference_points.is_contiguous() else reference_points.contiguous()
             output = Fn.msda_fused_forward(value, input_spatial_shapes, input_level_start_index, ref,
                                            proj[:, o_off:], proj[:, l_off:], L, P, shapes_host=spatial_shapes_py,
@@ -234,7 +234,7 @@ class MSDeformAttn(nn.Module):
                 return (Fn.x3_linear_ln(output, self.output_proj.weight, self.output_proj.bias, post[0], post[1]),)
             if x3:
                 return Fn.x3_linear(output, self.output_proj.weight, self.output_proj.bias)
-            return Fn.linear(output, self.output_proj.weight, self.output_proj.bias)
+            return Fn.linear(output, self.output_proj.weight, self.output_proj.bias, tall=True)
         if query_pos is not None:
             query = query + query_pos
         sampling_offsets = self.sampling_offsets(query).view(N, Len_q, M, L, P, 2)
@@ -295,7 +295,7 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
             with_pos = emit_next_query and pos is not None and pos.shape[0] == 1 and src.dim() == 3 and not pos_in_proj
             r = Fn.x3_ffn_ln(src, self.linear1, self.linear2, self.norm2, pos=pos if with_pos else None)
             return r if with_pos or not emit_next_query else (r, None)
-        src2 = Fn.linear(Fn.linear_relu(src, self.linear1), self.linear2.weight, self.linear2.bias)
+        src2 = Fn.linear(Fn.linear_relu(src, self.linear1, tall=True), self.linear2.weight, self.linear2.bias, tall=True)
         if emit_next_query and pos is not None and pos.shape[0] == 1:
             return Fn.add_layer_norm(src2, src, self.norm2, pos=pos)
         out = Fn.add_layer_norm(src2, src, self.norm2)

@@ -35,7 +35,7 @@ def _xavier_(module):
 
 
 class SelfAttentionLayer(nn.Module):
-    own_gemm = None      # None: Fn.OWN_GEMM_DEFAULT decides; the tracker / refiner set True on their layers
+    own_gemm = None      # None: the frame-invariant own GEMM of Fn.linear (segmenter); the tracker / refiner set True on their layers
 
     def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False):
         super().__init__()
@@ -209,8 +209,11 @@ class _MaskedDecoderBase(nn.Module):
                 if not ws:
                     per_level.append(None)
                     continue
+                Wv, bv = torch.cat([w[2] for w in ws], 0).detach(), torch.cat([w[3] for w in ws], 0).detach()
+                # V = (tok + level_embed) Wv^T + bv = tok Wv^T + (bv + Wv level_embed): the folded bias, made once per weights
+                bv_le = (bv.double() + Wv.double() @ self.level_embed.weight[lvl].detach().double()).float()
                 per_level.append((idx, torch.cat([w[0] for w in ws], 0).detach(), torch.cat([w[1] for w in ws], 0).detach(),
-                                  torch.cat([w[2] for w in ws], 0).detach(), torch.cat([w[3] for w in ws], 0).detach()))
+                                  Wv, bv, bv_le))
             self._kv_cache = ((ver, dev), per_level)
         return self._kv_cache[1]
 
@@ -228,7 +231,7 @@ class _MaskedDecoderBase(nn.Module):
                 size_list.append((h, w))
                 if kvw[lvl] is None:
                     continue
-                idx, Wk, bk, Wv, bv = kvw[lvl]
+                idx, Wk, bk, Wv, bv, bv_le = kvw[lvl]
                 le = self.level_embed.weight[lvl]
                 ident = isinstance(self.input_proj[lvl], nn.Sequential) and len(self.input_proj[lvl]) == 0
                 if tokens is not None and ident and not torch.is_grad_enabled():
@@ -240,15 +243,15 @@ class _MaskedDecoderBase(nn.Module):
                         # every pixel's keys / values for all layers of the level: split-f16 matrix-core GEMM (csrc/gemm_x3.hip)
                         tok = tok.contiguous()          # a level's rows of the encoder memory: ONE compaction serves both projections
                         kall = Fn.x3_linear(tok, Wk, bk, xadd=pos_t + le).transpose(0, 1)   # (the (N, hw, C) sum is never written)
-                        vall = Fn.x3_linear(tok, Wv, bv + F.linear(le, Wv)).transpose(0, 1)
+                        vall = Fn.x3_linear(tok, Wv, bv_le).transpose(0, 1)
                     else:
-                        kall = Fn.linear(tok + (pos_t + le), Wk, bk).transpose(0, 1)                # (hw, N, n_l * C) view
-                        vall = Fn.linear(tok, Wv, bv + F.linear(le, Wv)).transpose(0, 1)
+                        kall = Fn.linear(tok + (pos_t + le), Wk, bk, tall=True).transpose(0, 1)                # (hw, N, n_l * C) view
+                        vall = Fn.linear(tok, Wv, bv_le, tall=True).transpose(0, 1)
                 else:
                     src = (self.input_proj[lvl](x[lvl]).flatten(2) + le[None, :, None]).permute(2, 0, 1)
                     pos = self.pe_layer.compute(h, w, x[lvl].device).flatten(2).permute(2, 0, 1)   # (hw, 1, C)
-                    kall = Fn.linear(src + pos, Wk, bk)                                             # (hw, N, n_l * C)
-                    vall = Fn.linear(src, Wv, bv)
+                    kall = Fn.linear(src + pos, Wk, bk, tall=True)                                          # (hw, N, n_l * C)
+                    vall = Fn.linear(src, Wv, bv, tall=True)
                 for n, i in enumerate(idx):
                     kproj[i], vproj[i] = kall[..., n * C:(n + 1) * C], vall[..., n * C:(n + 1) * C]
         query_embed = self.query_embed.weight.unsqueeze(1)                                      # (Q, 1, C) broadcasts
@@ -267,7 +270,7 @@ class _MaskedDecoderBase(nn.Module):
 
     def _final_heads(self, output, mask_features, need_masks):
         dec = self.decoder_norm(output).transpose(0, 1)                                         # (N, Q, C)
-        logits = self.class_embed(dec)
+        logits = Fn.linear(dec, self.class_embed.weight, self.class_embed.bias)
         masks = Fn.mask_logits(self.mask_embed(dec).contiguous(), mask_features) if need_masks else None
         return dec, logits, masks
 

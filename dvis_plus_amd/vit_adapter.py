@@ -83,14 +83,14 @@ class Attention(nn.Module):
     def core(self, x):
         """(B, N, C) -> attention output before the out-projection, (B, N, C)."""
         B, N, C = x.shape
-        qkv = Fn.linear(x, self.qkv.weight, self.qkv.bias)                       # (B, N, 3C)
+        qkv = Fn.linear(x, self.qkv.weight, self.qkv.bias, tall=True)                       # (B, N, 3C)
         v = qkv.transpose(0, 1)                                                    # (N, B, 3C) view: rows strided
         out = torch.empty((B, N, C), dtype=x.dtype, device=x.device)
         Fn.attention(v[..., :C], v[..., C:2 * C], v[..., 2 * C:], self.num_heads, out=out.transpose(0, 1))
         return out
 
     def forward(self, x):
-        return Fn.linear(self.core(x), self.proj.weight, self.proj.bias)
+        return Fn.linear(self.core(x), self.proj.weight, self.proj.bias, tall=True)
 
 
 class Mlp(nn.Module):
@@ -100,10 +100,10 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features, bias=bias)
 
     def hidden(self, x):
-        return F.gelu(Fn.linear(x, self.fc1.weight, self.fc1.bias))               # exact (erf) GELU as nn.GELU()
+        return F.gelu(Fn.linear(x, self.fc1.weight, self.fc1.bias, tall=True))               # exact (erf) GELU as nn.GELU()
 
     def forward(self, x):
-        return Fn.linear(self.hidden(x), self.fc2.weight, self.fc2.bias)
+        return Fn.linear(self.hidden(x), self.fc2.weight, self.fc2.bias, tall=True)
 
 
 class Block(nn.Module):
@@ -121,9 +121,9 @@ class Block(nn.Module):
 
     def forward(self, x):
         w, b = self._f1.get(self.attn.proj, self.ls1)
-        x = x + Fn.linear(self.attn.core(Fn.add_layer_norm(x, None, self.norm1)), w, b)
+        x = x + Fn.linear(self.attn.core(Fn.add_layer_norm(x, None, self.norm1)), w, b, tall=True)
         w, b = self._f2.get(self.mlp.fc2, self.ls2)
-        return x + Fn.linear(self.mlp.hidden(Fn.add_layer_norm(x, None, self.norm2)), w, b)
+        return x + Fn.linear(self.mlp.hidden(Fn.add_layer_norm(x, None, self.norm2)), w, b, tall=True)
 
 
 class DinoVisionTransformer(nn.Module):
@@ -228,9 +228,9 @@ class ConvFFN(nn.Module):
         self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
 
     def forward(self, x, H, W):
-        x = Fn.linear(x, self.fc1.weight, self.fc1.bias)
+        x = Fn.linear(x, self.fc1.weight, self.fc1.bias, tall=True)
         x = F.gelu(self.dwconv(x, H, W))
-        return Fn.linear(x, self.fc2.weight, self.fc2.bias)
+        return Fn.linear(x, self.fc2.weight, self.fc2.bias, tall=True)
 
 
 class Extractor(nn.Module):

@@ -429,6 +429,13 @@ int dvis_gemm_num_configs(void);
  * so a caller that wants the SAME bits for a row whether it is computed alone or stacked with other rows (the tracker run
  * for one clip or for two clips at once) pins the configuration of the smaller problem. */
 int dvis_gemm_pick_config(int M, int N, int K, int batch);
+/* Configuration for these sizes INSIDE the K-split family of `nw` waves (1, 4 or 8; -1 otherwise): all configurations of a
+ * family sum an output element's products in the same order, so a row's bits depend on (N, K, nw) only — not on M.  The
+ * per-frame segmenter folds the frames of a clip into the batch (dvis_Plus/video_mask2former_transformer_decoder.py:327-335);
+ * taking its GEMMs from one family makes a frame's result independent of how many frames share the call (a rank's shard of a
+ * clip vs the whole clip: north_star's frame sharding).  dvis_gemm_config_waves: the family of a configuration. */
+int dvis_gemm_pick_config_nw(int M, int N, int K, int batch, int nw);
+int dvis_gemm_config_waves(int config);
 
 /*
  * GEMM with the LayerNorm(s) of the post-norm transformer blocks folded into its A-operand prologue:

@@ -21,7 +21,10 @@ def test_sharded_stream_on_one_gpu(world, frames, port, tmp_path):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tools", "stream_shard_check.py"),
            "--clips", "3", "--frames", str(frames), "--out", str(tmp_path)]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-    tail = "\n".join((r.stdout + r.stderr).splitlines()[-25:])
+    # on failure: the CHECKER's lines (rank … / clip … / SHARD_CHECK / [intcmp]), not torch-elastic's traceback
+    own = [l for l in r.stdout.splitlines() if l.lstrip().startswith(("rank", "clip", "SHARD_CHECK", "[intcmp]", "product", "oracle"))]
+    err = [l for l in r.stderr.splitlines() if "Error" in l or "error" in l or "Traceback" in l or "assert" in l][-10:]
+    tail = "\n".join(own[-40:] + ["--- stderr (filtered) ---"] + err)
     assert r.returncode == 0 and f"SHARD_CHECK OK world={world}" in r.stdout, tail
 
 
