@@ -244,11 +244,11 @@ def cpu_baseline_msda(budget_s=8.0):
                       f"{dt * 1e3:.1f} ms each"}
 
 
-def cpu_baseline(model, clip, frames=3, thr=0.8):
+def cpu_baseline(model, clip, frames=3, thr=0.8, windows=3):
     """The metric's own unit on the host cores: the oracle's restatement of the reference pipeline (windowed,
     frame-by-frame tracker, torch ops; oracle/dvis_torch.py) on a bounded sample = the first `frames` frames of the same
     synthetic clip = one window of the reference's loop (TEST.WINDOW_SIZE = 3), same weights, backbone = the same torch
-    modules on the CPU.  One warm-up window, one timed window."""
+    modules on the CPU.  One warm-up window, `windows` timed windows (median reported, p10 / p50 / p90 beside it)."""
     import copy
     from oracle import dvis_torch as O
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
@@ -265,11 +265,15 @@ def cpu_baseline(model, clip, frames=3, thr=0.8):
                                 task="vps", object_mask_threshold=thr, overlap_threshold=0.8, out_hw=(720, 1280))
         return time.time() - t0
     warm = run()                               # thread pools, oneDNN primitives, allocator
-    dt = run()
-    return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+    dts = sorted(run() for _ in range(windows))      # 1 warm-up + 3 timed, median and p10 / p90
+    pick = lambda q: dts[min(len(dts) - 1, int(q * len(dts)))]
+    med = dts[len(dts) // 2]
+    return {"value": round(frames / med, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "p10_p50_p90": [round(frames / pick(0.9), 4), round(frames / med, 4), round(frames / pick(0.1), 4)],
+            "window_seconds": [round(d, 2) for d in dts],
             "sample": f"first {frames} frames (one reference window, TEST.WINDOW_SIZE=3) of the same 720p synthetic clip "
                       f"through oracle/dvis_torch.py (fp32 torch CPU ops, {threads} threads): 1 warm-up window "
-                      f"({warm:.1f} s) + 1 timed window ({dt:.1f} s)",
+                      f"({warm:.1f} s) + {windows} timed windows (median {med:.1f} s); value = frames / median window time",
             "msda_op": cpu_baseline_msda()}
 
 
@@ -603,12 +607,32 @@ def main():
         exact = {"value": round(T * n3 / dt3, 3), "unit": "frames/s", "steps": n3, "ms_per_step": round(dt3 / n3 * 1e3, 2),
                  "note": "DVIS_X3=0: every GEMM / convolution on v_mfma_f32_*_f32 or the fp32 library GEMM"}
 
+    # fourth, short timed pass: the same clips one forward() at a time, back to back (no overlap of clip i's tracker / refiner /
+    # post-processing with clip i + 1's segmenter): BASELINE.md section 3's "frames/s = T / clip latency" reading of the metric
+    cbc = None
+    if world == 1 and not dist_on and not args.no_extra and streamed:
+        n4 = min(6, args.steps)
+        streamed = False
+        try:
+            run_pass(videos[:1])
+            torch.cuda.synchronize()
+            lt4 = []
+            t1 = time.perf_counter()
+            run_pass(videos[:n4], lt4)
+            torch.cuda.synchronize()
+            dt4 = time.perf_counter() - t1
+        finally:
+            streamed = True
+        l4 = sorted(e0.elapsed_time(e1) for e0, e1 in lt4)
+        cbc = {"value": round(T * n4 / dt4, 3), "unit": "frames/s", "steps": n4, "ms_per_step": round(dt4 / n4 * 1e3, 2),
+               "latency_ms_p50": round(l4[len(l4) // 2], 2), "note": "--clip-stream 0: one forward() per clip, nothing overlapped"}
+
     if rank == 0:
         fps = T * args.steps / dt
         sec, nfr, nlaunch = timer.summary()
         achieved = MSDA_BYTES_PER_FRAME_LAYER * nfr / sec / 1e9
         traffic, traffic_src = None, None     # HBM bytes per launch from the committed rocprofv3 PMC passes (bench.py cannot read PMCs itself)
-        for name in ("r03_msda_traffic.json", "r02_msda_traffic.json", "r01_msda_traffic.json"):
+        for name in ("r05_msda_traffic.json", "r03_msda_traffic.json", "r02_msda_traffic.json", "r01_msda_traffic.json"):
             tj = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tj):
                 t = json.load(open(tj))
@@ -677,6 +701,7 @@ def main():
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                        "clip_stream": streamed, "warmup_clips_run": warm_clips,
                        "tracker_owner_rounds": False if world > 1 else None},
+            "latency_fps": round(T / (pct(0.5) * 1e-3), 1) if ms else None,     # T / p50 clip latency (BASELINE.md section 3's definition)
             "latency_ms": {"p10": pct(0.1), "p50": pct(0.5), "p90": pct(0.9), "n": len(ms),
                            "note": "clip handed to the model -> its outputs complete (HIP events); under clip streaming a "
                                    "clip waits one segmenter pass of the previous clip"},
@@ -698,6 +723,8 @@ def main():
             res["roofline_ffn"] = ffn_roof
         if exact is not None:
             res["exact_f32"] = exact
+        if cbc is not None:
+            res["clip_by_clip"] = cbc
         if owner_line is not None:
             res["owner_rounds"] = owner_line
         if cand100 is not None:

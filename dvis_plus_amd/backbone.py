@@ -60,10 +60,11 @@ class ConvBN(nn.Conv2d):
         if plain and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0):
             return Fn.conv1x1_bias_act(x, w, b, res, relu)
         if plain and self.kernel_size == (1, 1) and self.stride == (2, 2) and self.padding == (0, 0) and not key_is_channels_last(w) \
-                and Fn.conv1x1s2_supported(x, w) and _res_ok(res, x, w.shape[0], 2):
-            if Fn.conv1x1_x3_ok(x, w, 2, res):
+                and _res_ok(res, x, w.shape[0], 2):
+            if Fn.conv1x1_x3_ok(x, w, 2, res):       # (any map size: small test maps included — no library convolution in phase A)
                 return Fn.conv1x1_x3(x, w, b, res, relu, stride=2)
-            return Fn.conv1x1_mfma(x, w, b, res, relu, stride=2)     # the down-sampling shortcut, read in place
+            if Fn.conv1x1s2_supported(x, w):
+                return Fn.conv1x1_mfma(x, w, b, res, relu, stride=2)     # the down-sampling shortcut, read in place
         if plain and self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) and res is None and x.is_cuda \
                 and not key_is_channels_last(w):
             return Fn.conv3x3_bias_act(x, w, b, relu)            # own Winograd kernel where the shape is served
