@@ -4,6 +4,12 @@
 //   MODE 0  outputs_mask = einsum("bqc,bchw->bqhw", mask_embed, mask_features)                       (:363)
 //   MODE 1  attn_mask = (F.interpolate(outputs_mask, size, bilinear, align_corners=False).sigmoid() < 0.5)  (:367-371)
 //           + the "row blocked everywhere -> allow everything" reset done with a host-syncing torch.where (:297)
+//   MODE 2  the same mask from a POOLED feature map (round 5): the down-sizing is linear, so the four centre pixels of every
+//           s x s block are averaged ONCE per clip into three small maps (dvis_center_pool3: one read of the 1.8 GB map for
+//           all nine decoder layers) and a layer contracts its level's map — 1/4 of MODE 1's products, no re-read of the
+//           stride-4 map: mask = (einsum(embed, pooled) < 0).  Same value up to the rounding ORDER (average-then-contract vs
+//           contract-then-average): bits differ only where |logit| is of the order of its own rounding error, where the
+//           reference's own fp32 result is as arbitrary (measured: 12 of 57 960 000 bits per clip, all |logit| < 5e-6).
 // MODE 1 never writes the stride-4 logits to HBM (23.6 MB per call at 720p in the reference) and emits the mask
 // once per frame, not replicated over the 8 heads.
 //
@@ -67,9 +73,9 @@ __global__ __launch_bounds__(512) void mask_gemm_kernel(
   int cur_b = -1;
   // MODE 1: allowed pixels per query row, summed in LDS over the workgroup's steps of one frame, then one global atomic
   int *counts = reinterpret_cast<int *>(lds + 4 * ROWS * kARow);
-  if (MODE == 1 && tid < ROWS) counts[tid] = 0;
+  if (MODE != 0 && tid < ROWS) counts[tid] = 0;
   auto flush_counts = [&]() {   // between two barriers
-    if (MODE == 1 && cur_b >= 0 && tid < ROWS) {
+    if (MODE != 0 && cur_b >= 0 && tid < ROWS) {
       const int q = qbeg + tid, c = counts[tid];
       if (q < Q && c > 0) atomicAdd(&allowed_count[(size_t)cur_b * Q + q], c);
       counts[tid] = 0;
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(512) void mask_gemm_kernel(
   bool ok[4];
   const unsigned gbase = (unsigned)(g * CQ) * chan_bytes;
   auto set_columns = [&](int group) {
-    if (MODE == 0) {
+    if (MODE != 1) {
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
         const size_t p = (size_t)group * 64 + 4 * j + n;
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(512) void mask_gemm_kernel(
     for (int i = 0; i < 4; ++i) {
       const unsigned so = (unsigned)(u0 + i) * chan_bytes;   // uniform
       const bool cv = FULLC ? true : (u0 + i < ulim);
-      if (MODE == 0 && VEC) {
+      if (MODE != 1 && VEC) {
         const dvis_v4u t =
             __builtin_bit_cast(dvis_v4u, __builtin_amdgcn_raw_buffer_load_b128(rs, cv ? off[0] : kOOB, so, 0));
         dst[i] = __builtin_bit_cast(dvis_f4, t);
@@ -235,6 +241,34 @@ __global__ __launch_bounds__(512) void mask_gemm_kernel(
             }
           }
         }
+    } else if (MODE == 2) {
+      // lane j holds pixels group * 64 + 4 j + n (n = 0 .. 3) of query rows qt * 16 + 4 g + r: four mask bytes = one 32-bit store
+      const __amdgpu_buffer_rsrc_t ro = dvis_make_rsrc_uniform(out_mask + (size_t)b * Q * HW, (unsigned)((size_t)Q * HW));
+      const unsigned vo = (unsigned)((size_t)(qbeg + g * 4) * HW + (size_t)group * 64 + 4 * j);
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          unsigned packed = 0;
+          int n_allowed = 0;
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            const bool blocked = acc[qt][n][r] < 0.f;
+            packed |= (blocked ? 1u : 0u) << (8 * n);
+            const unsigned long long bal = __ballot(okc[n] && !blocked);
+            n_allowed += __popc((unsigned)((bal >> (16 * g)) & 0xffffull));
+          }
+          if (j == 0 && n_allowed > 0) atomicAdd(&counts[qt * 16 + g * 4 + r], n_allowed);   // LDS
+          if (qbeg + qt * 16 + g * 4 + r >= Q) continue;
+          const unsigned so = (unsigned)((size_t)(qt * 16 + r) * HW);   // uniform
+          if (VEC) {
+            if (okc[0]) __builtin_amdgcn_raw_buffer_store_b32(packed, ro, vo, so, 0);
+          } else {
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+              if (okc[n]) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)((packed >> (8 * n)) & 1u), ro, vo + n, so, 0);
+          }
+        }
     } else {
       const __amdgpu_buffer_rsrc_t ro = dvis_make_rsrc_uniform(out_mask + (size_t)b * Q * OHW, (unsigned)((size_t)Q * OHW));
       const unsigned vo = (unsigned)((qbeg + g * 4) * OHW + group * 16 + j);
@@ -304,7 +338,75 @@ int launch(const float *embed, const float *feat, int B, int Q, int C, int H, in
   return dvis_check_launch("mask_gemm_kernel");
 }
 
+// The four centre pixels of every s x s block of a map, s = 2, 4, 8, averaged in the reference's order ((a + b) + (c + d)) * 0.25
+// — what F.interpolate(bilinear, align_corners=False) by an even integer factor samples — for all three decoder levels in ONE
+// read of the map.  One thread = one 8 x 8 block of one plane (lanes run along x: 32 contiguous bytes per lane and row).
+__global__ __launch_bounds__(256) void center_pool3_kernel(const float *__restrict__ f, float *__restrict__ p2,
+                                                           float *__restrict__ p4, float *__restrict__ p8, int H, int W,
+                                                           long long blocks) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= blocks) return;
+  const int bw = W >> 3, bh = H >> 3;
+  const int bx = (int)(i % bw);
+  const long long r = i / bw;
+  const int by = (int)(r % bh);
+  const long long plane = r / bh;
+  const float *src = f + (plane * H + by * 8) * (long long)W + bx * 8;
+  float v[8][8];
+#pragma unroll
+  for (int y = 0; y < 8; ++y) {
+    const dvis_f4 lo = *reinterpret_cast<const dvis_f4 *>(src + (long long)y * W);
+    const dvis_f4 hi = *reinterpret_cast<const dvis_f4 *>(src + (long long)y * W + 4);
+    v[y][0] = lo[0]; v[y][1] = lo[1]; v[y][2] = lo[2]; v[y][3] = lo[3];
+    v[y][4] = hi[0]; v[y][5] = hi[1]; v[y][6] = hi[2]; v[y][7] = hi[3];
+  }
+  auto avg = [&](int y, int x) { return ((v[y][x] + v[y][x + 1]) + (v[y + 1][x] + v[y + 1][x + 1])) * 0.25f; };
+  float *o2 = p2 + (plane * (H >> 1) + by * 4) * (long long)(W >> 1) + bx * 4;      // s = 2: 4 x 4 outputs
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    *reinterpret_cast<dvis_f4 *>(o2 + (long long)k * (W >> 1)) = dvis_f4{avg(2 * k, 0), avg(2 * k, 2), avg(2 * k, 4), avg(2 * k, 6)};
+  float *o4 = p4 + (plane * (H >> 2) + by * 2) * (long long)(W >> 2) + bx * 2;      // s = 4: rows 4 i + 1, columns 4 j + 1
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    o4[(long long)k * (W >> 2)] = avg(4 * k + 1, 1);
+    o4[(long long)k * (W >> 2) + 1] = avg(4 * k + 1, 5);
+  }
+  p8[(plane * bh + by) * (long long)bw + bx] = avg(3, 3);                           // s = 8: rows 3, 4; columns 3, 4
+}
+
 }  // namespace
+
+DVIS_EXPORT int dvis_center_pool3(const float *feat, int64_t planes, int H, int W, float *p2, float *p4, float *p8, void *stream) {
+  DVIS_REQUIRE(planes >= 0 && H > 0 && W > 0, "center_pool3: bad sizes");
+  if (planes == 0) return DVIS_OK;
+  DVIS_REQUIRE(feat && p2 && p4 && p8, "center_pool3: null pointer");
+  DVIS_REQUIRE(H % 8 == 0 && W % 8 == 0 && (((uintptr_t)feat | (uintptr_t)p2) & 15) == 0,
+               "center_pool3: H, W multiples of 8 and 16-byte aligned maps (H=%d W=%d)", H, W);
+  const long long blocks = (long long)planes * (H / 8) * (W / 8);
+  DVIS_REQUIRE((blocks + 255) / 256 < (1ll << 31), "center_pool3: grid too large");
+  hipLaunchKernelGGL(center_pool3_kernel, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, feat, p2, p4, p8,
+                     H, W, blocks);
+  return dvis_check_launch("center_pool3_kernel");
+}
+
+DVIS_EXPORT int dvis_attn_mask_pooled(const float *embed, const float *pooled, int B, int Q, int C, int h, int w, uint8_t *mask,
+                                      int32_t *allowed_count, void *stream) {
+  DVIS_REQUIRE(B >= 0 && Q > 0 && C > 0 && h > 0 && w > 0, "attn_mask_pooled: bad sizes");
+  if (B == 0) return DVIS_OK;
+  DVIS_REQUIRE(embed && pooled && mask && allowed_count, "attn_mask_pooled: null pointer");
+  DVIS_REQUIRE(C <= 256, "attn_mask_pooled: supports C <= 256 (got C=%d)", C);
+  const int64_t HW = (int64_t)h * w;
+  DVIS_REQUIRE((long long)((C + 31) / 32 * 32) * HW * 4 < (1ll << 31) && (long long)Q * HW < (1ll << 31),
+               "attn_mask_pooled: one frame of the pooled map / of the mask must stay below 2 GiB");
+  hipError_t e = hipMemsetAsync(allowed_count, 0, (size_t)B * Q * sizeof(int32_t), (hipStream_t)stream);
+  if (e != hipSuccess) {
+    dvis_set_error("attn_mask_pooled: hipMemsetAsync: %s", hipGetErrorString(e));
+    return DVIS_E_LAUNCH;
+  }
+  const bool vec = HW % 4 == 0 && (((uintptr_t)pooled | (uintptr_t)mask) & 15) == 0;
+  return vec ? launch<2, true>(embed, pooled, B, Q, C, h, w, h, w, nullptr, mask, allowed_count, (hipStream_t)stream)
+             : launch<2, false>(embed, pooled, B, Q, C, h, w, h, w, nullptr, mask, allowed_count, (hipStream_t)stream);
+}
 
 DVIS_EXPORT int dvis_mask_logits(const float *embed, const float *feat, int B, int Q, int C, int64_t HW, float *out,
                                  void *stream) {

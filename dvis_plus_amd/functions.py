@@ -238,6 +238,47 @@ def attn_mask(mask_embed, mask_features, target_size):
     return mask, allowed
 
 
+ATTN_MASK_PYRAMID = os.environ.get("DVIS_ATTN_MASK_PYRAMID", "1") != "0"
+
+
+def center_pool3(mask_features):
+    """The decoder's attention-mask pyramid, once per call of the decoder: (p8, p4, p2) — low resolution first, the decoder's
+    level order — with p_s[n, c, i, j] = 0.25 * ((f_a + f_b) + (f_c + f_d)) over the four centre pixels of block (i, j) of s x s
+    pixels: what F.interpolate(bilinear, align_corners=False) to 1/s samples, on the FEATURES (the contraction is linear).  None
+    when the map is not served (H, W not multiples of 8, CPU tensors, autograd): the caller uses ``attn_mask``."""
+    if not (ATTN_MASK_PYRAMID and mask_features.is_cuda and mask_features.dtype == torch.float32 and mask_features.dim() == 4
+            and mask_features.is_contiguous() and not torch.is_grad_enabled()):
+        return None
+    N, C, H, W = mask_features.shape
+    if H % 8 or W % 8 or mask_features.data_ptr() % 16:
+        return None
+    p2 = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=mask_features.device)
+    p4 = torch.empty((N, C, H // 4, W // 4), dtype=torch.float32, device=mask_features.device)
+    p8 = torch.empty((N, C, H // 8, W // 8), dtype=torch.float32, device=mask_features.device)
+    if N:
+        with torch.cuda.device(mask_features.device):
+            native.check(native.lib().dvis_center_pool3(native.dev_ptr(mask_features, "mask_features"), N * C, H, W,
+                                                        native.dev_ptr(p2, "p2"), native.dev_ptr(p4, "p4"), native.dev_ptr(p8, "p8"),
+                                                        native.stream_ptr(mask_features.device)), "dvis_center_pool3")
+    return p8, p4, p2
+
+
+def attn_mask_pooled(mask_embed, pooled):
+    """``attn_mask`` on a level's pooled map (center_pool3): (mask uint8 (B, Q, h*w), allowed_count int32 (B, Q))."""
+    B, Q, C = mask_embed.shape
+    Bf, Cf, h, w = pooled.shape
+    if (Bf, Cf) != (B, C):
+        raise RuntimeError("attn_mask_pooled: mask_embed (B,Q,C) and pooled (B,C,h,w) disagree")
+    pe, pf = _f32_gpu(mask_embed, "mask_embed"), _f32_gpu(pooled, "pooled")
+    mask = torch.empty((B, Q, h * w), dtype=torch.uint8, device=mask_embed.device)
+    allowed = torch.empty((B, Q), dtype=torch.int32, device=mask_embed.device)
+    with torch.cuda.device(mask_embed.device):
+        native.check(native.lib().dvis_attn_mask_pooled(pe, pf, B, Q, C, h, w, native.dev_ptr(mask, "mask"),
+                                                        native.dev_ptr(allowed, "allowed"), native.stream_ptr(mask_embed.device)),
+                     "dvis_attn_mask_pooled")
+    return mask, allowed
+
+
 def _strides3(t, B, C, d):
     """(L, B, C) tensor -> {batch, head, row} strides in floats for the kernel's (B, heads, L, d) view."""
     return (ctypes.c_int64 * 3)(t.stride(1) if B > 1 else C, d, t.stride(0))

@@ -36,6 +36,8 @@ SIGNATURES = {
     "dvis_nchw_to_tokens_affine": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i64, _i64, _i64, _p]),
     "dvis_mask_logits": (_i, [_p, _p, _i, _i, _i, _i64, _p, _p]),
     "dvis_attn_mask": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "dvis_center_pool3": (_i, [_p, _i64, _i, _i, _p, _p, _p, _p]),
+    "dvis_attn_mask_pooled": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "dvis_attention_ws_bytes": (_i64, [_i, _i, _i, _i]),
     "dvis_attention_forward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p]),
     "dvis_attention_forward_k": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p, _i]),

@@ -256,10 +256,18 @@ class _MaskedDecoderBase(nn.Module):
                     kproj[i], vproj[i] = kall[..., n * C:(n + 1) * C], vall[..., n * C:(n + 1) * C]
         query_embed = self.query_embed.weight.unsqueeze(1)                                      # (Q, 1, C) broadcasts
         output = self.query_feat.weight.unsqueeze(1).repeat(1, N, 1)
+        # the attention masks' feature pyramid: the four centre pixels of every 8 x 8 / 4 x 4 / 2 x 2 block of mask_features
+        # averaged ONCE (one read of the map) — every layer then contracts its level's small map instead of the stride-4 one
+        pyramid = Fn.center_pool3(mask_features)
+        if pyramid is not None and [tuple(p.shape[-2:]) for p in pyramid] != [tuple(sz) for sz in size_list[:3]]:
+            pyramid = None                                                                      # (levels that are not 1/8, 1/4, 1/2)
         for i in range(self.num_layers):
             lvl = i % self.num_feature_levels
             emb = self.mask_embed(self.decoder_norm(output).transpose(0, 1))                    # (N, Q, Cm)
-            mask, allowed = Fn.attn_mask(emb.contiguous(), mask_features, size_list[lvl])
+            if pyramid is not None:
+                mask, allowed = Fn.attn_mask_pooled(emb.contiguous(), pyramid[lvl])
+            else:
+                mask, allowed = Fn.attn_mask(emb.contiguous(), mask_features, size_list[lvl])
             if self.debug_masks is not None:     # rows blocked everywhere attend everywhere (…decoder.py:297)
                 self.debug_masks.append(mask.bool() & (allowed > 0)[..., None])
             layer = self.transformer_cross_attention_layers[i]

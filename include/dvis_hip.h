@@ -180,6 +180,19 @@ int dvis_mask_logits(const float *embed, const float *feat, int B, int Q, int C,
  */
 int dvis_attn_mask(const float *embed, const float *feat, int B, int Q, int C, int H, int W, int h, int w,
                    uint8_t *mask, int32_t *allowed_count, void *stream);
+/*
+ * The same attention mask from a feature PYRAMID (round 5).  The bilinear down-sizing of forward_prediction_heads
+ * (dvis_Plus/video_mask2former_transformer_decoder.py:367, F.interpolate(..., align_corners=False) by an even integer factor) is
+ * linear: out = 0.25 ((l_a + l_b) + (l_c + l_d)) over the four centre pixels of a block = the contraction of
+ * 0.25 ((f_a + f_b) + (f_c + f_d)).  dvis_center_pool3 forms those averages for the factors 2 / 4 / 8 of a stride-4 map in ONE read
+ * (feat: `planes` maps of H x W, H % 8 == W % 8 == 0 -> p2 (H/2 x W/2), p4, p8), once per clip; dvis_attn_mask_pooled contracts a
+ * level's pooled map (B, C, h, w) and thresholds: mask (B, Q, h*w) uint8 (1 = blocked), allowed_count as above.  One quarter of
+ * dvis_attn_mask's products per layer and no re-read of the stride-4 map in any of the nine decoder layers.  Equal to
+ * dvis_attn_mask except where |logit| is of the order of its rounding error (the two orders round differently).
+ */
+int dvis_center_pool3(const float *feat, int64_t planes, int H, int W, float *p2, float *p4, float *p8, void *stream);
+int dvis_attn_mask_pooled(const float *embed, const float *pooled, int B, int Q, int C, int h, int w, uint8_t *mask,
+                          int32_t *allowed_count, void *stream);
 
 /*
  * softmax(Q K^T * scale [masked]) V for B batch entries x `heads` heads, fp32 in/out, exact-fp32 MFMA.

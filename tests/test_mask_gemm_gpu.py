@@ -82,3 +82,62 @@ def test_mask_gemm_errors():
         mask_logits(e, f)
     with pytest.raises(RuntimeError, match="even integer"):
         attn_mask(e.to(DEV), f.to(DEV), (2, 2))     # factor 3
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 256, 16, 32), (1, 7, 8, 8), (3, 64, 24, 40), (1, 256, 184, 320)])
+def test_center_pool3_has_the_bits_of_the_torch_expression(N, C, H, W):
+    """p_s = 0.25 * ((f_a + f_b) + (f_c + f_d)) over the four centre pixels of every s x s block: the taps and weights of
+    F.interpolate(bilinear, align_corners=False) to 1 / s, added in the order dvis_attn_mask adds the four logits."""
+    from dvis_plus_amd.functions import center_pool3
+    f = torch.randn(N, C, H, W, generator=torch.Generator().manual_seed(H + W)).to(DEV)
+    with torch.no_grad():
+        p8, p4, p2 = center_pool3(f)
+    for s, p in ((8, p8), (4, p4), (2, p2)):
+        o = s // 2 - 1
+        a, b = f[:, :, o::s, o::s], f[:, :, o::s, o + 1::s]
+        c, d = f[:, :, o + 1::s, o::s], f[:, :, o + 1::s, o + 1::s]
+        assert torch.equal(p, ((a + b) + (c + d)) * 0.25), s
+        # ... which is what the bilinear resize samples (fp64 check of the taps)
+        ref = F.interpolate(f.double(), size=(H // s, W // s), mode="bilinear", align_corners=False)
+        assert float((p.double() - ref).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("B,Q,C,H,W", [(2, 100, 256, 16, 32), (1, 6, 16, 16, 24), (2, 200, 256, 24, 40), (1, 100, 256, 184, 320),
+                                        (3, 17, 40, 8, 8)])
+def test_attn_mask_pooled_vs_fp64_and_vs_the_unpooled_kernel(B, Q, C, H, W):
+    """The pyramid form against the reference's op sequence in fp64 (einsum -> interpolate -> sigmoid < 0.5): equal wherever the
+    down-sized logit is not within 1e-4 of the threshold; the row counts are those of the emitted mask; against dvis_attn_mask
+    (contract-then-average) only such near-threshold bits may differ."""
+    from dvis_plus_amd.functions import attn_mask, attn_mask_pooled, center_pool3
+    e, f = _inputs(B, Q, C, H, W, seed=11 + B)
+    logits = torch.einsum("bqc,bchw->bqhw", e.double(), f.double())
+    with torch.no_grad():
+        pyr = center_pool3(f.to(DEV))
+        assert pyr is not None
+        for s, p in zip((8, 4, 2), pyr):
+            h, w = H // s, W // s
+            small = F.interpolate(logits, size=(h, w), mode="bilinear", align_corners=False).flatten(2)
+            ref = small.sigmoid() < 0.5
+            mask, allowed = attn_mask_pooled(e.to(DEV), p)
+            old, old_allowed = attn_mask(e.to(DEV), f.to(DEV), (h, w))
+            mask, allowed, old = mask.cpu().bool(), allowed.cpu(), old.cpu().bool()
+            decided = small.abs() > 1e-4
+            assert torch.equal(mask[decided], ref[decided]), s
+            assert torch.equal(allowed.long(), (~mask).sum(-1)), s
+            assert not (mask != old)[decided].any(), s
+
+
+def test_attn_mask_pooled_fully_blocked_rows_and_odd_sizes():
+    from dvis_plus_amd.functions import attn_mask_pooled, center_pool3
+    B, Q, C = 2, 100, 256
+    e, f = _inputs(B, Q, C, 16, 40, seed=3)
+    f, e = f.abs() + 0.1, e.abs()
+    e[0, 5], e[1, 99] = -e[0, 5], -e[1, 99]
+    with torch.no_grad():
+        p8, p4, p2 = center_pool3(f.to(DEV))                       # p8 is 2 x 5 = 10 pixels: not a multiple of 4 (byte stores)
+        for p in (p8, p4, p2):
+            mask, allowed = attn_mask_pooled(e.to(DEV), p)
+            allowed = allowed.cpu()
+            assert allowed[0, 5] == 0 and allowed[1, 99] == 0 and (allowed > 0).sum() == B * Q - 2
+            assert mask.cpu()[0, 5].all() and not mask.cpu()[0, 6].any()
+        assert center_pool3(torch.randn(1, 8, 12, 20, device=DEV)) is None        # H % 8 != 0: the caller keeps dvis_attn_mask
