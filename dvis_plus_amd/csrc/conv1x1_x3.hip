@@ -34,6 +34,11 @@ struct CxArgs {
   float xscale, inv;
   int *flag;                               // range guard (x3_common.h)
   int tag;
+  // second source of a 1x1 launch (C2 > 0): the contraction runs over [C channels of x | C2 channels of x2], x2 sampled with its
+  // own stride — conv3(a) + shortcut(x) of a down-sampling bottleneck as ONE accumulation, the shortcut map never written
+  const float *x2;
+  int C2, stride2, W2_in;
+  long long HW2_in;
 };
 
 // the w-th work item of workgroup b: XCD x = b % 8 owns the tiles t = x (mod 8); its workgroups deal (tile, pass) pairs
@@ -70,6 +75,15 @@ __device__ __forceinline__ unsigned cx_tap_offset(const CxArgs &a, const CxGeom 
   return ok ? gm.base + (unsigned)((iy * a.W_in + ix) * 4) : kOOB;
 }
 
+// byte offset of channel 0 of source 2's input pixel for output pixel p (stride2 sampling, no padding); kOOB past the end
+__device__ __forceinline__ unsigned cx_geom2(const CxArgs &a, long long p) {
+  if (a.C2 == 0 || p >= a.pixels) return kOOB;
+  const long long n = p / a.HW;
+  const int pix = (int)(p - n * a.HW);
+  const int oy = pix / a.OW, ox = pix - oy * a.OW;
+  return (unsigned)(n * a.C2 * a.HW2_in * 4) + (unsigned)((oy * a.stride2 * a.W2_in + ox * a.stride2) * 4);
+}
+
 // NW waves x 32 pixels per tile; 8 waves = two per SIMD (<= 256 registers each) cover each other's stalls.
 // IK k-steps per ring item: 2 (three stages) or 4 (= one activation chunk; two stages of up to 64 KB: half the barriers).
 template <int NB, int NW, int IK>
@@ -78,7 +92,7 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
   static_assert(2 * IK * NB % NW == 0, "the item's pieces must divide among the waves");
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
-  const int NCC = a.C / 64, NC = a.taps * NCC, NI = IPC * NC;   // chunks per tap, chunks and ring items per work item
+  const int NCC = a.C / 64, NC1 = a.taps * NCC, NC = NC1 + a.C2 / 64, NI = IPC * NC;   // chunks per tap, of source 1, in all; ring items per work item
   long long wcount = 0;
   {
     long long t;
@@ -90,6 +104,8 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
   const __amdgpu_buffer_rsrc_t ry = dvis_make_rsrc_uniform(a.y, (unsigned)((long long)a.N * a.K * a.HW * 4));
   const __amdgpu_buffer_rsrc_t rr = dvis_make_rsrc_uniform(a.res ? a.res : a.y, (unsigned)((long long)a.N * a.K * a.HW * 4));
   const unsigned chan = (unsigned)(a.HW_in * 4);              // bytes between two input channels of a pixel
+  const __amdgpu_buffer_rsrc_t rx2 = dvis_make_rsrc_uniform(a.C2 ? a.x2 : a.x, a.C2 ? (unsigned)((long long)a.N * a.C2 * a.HW2_in * 4) : 0u);
+  const unsigned chan2 = (unsigned)(a.HW2_in * 4);
 
   typedef Ring<PW, 32, NW, STAGES> RingT;
   RingT ring;
@@ -118,19 +134,22 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
   float raw[32];
   // (an out-of-range pixel has offset kOOB = 2^31; the served tensors are below 2^31 bytes, so kOOB + anything stays out of
   // range without a select — a per-load select makes hipcc branch around every load)
-  auto load_raw = [&](unsigned pixoff, int cc) {
-    const unsigned vo = pixoff + (unsigned)(8 * g) * chan;
-    const unsigned so = (unsigned)(64 * cc) * chan;
+  auto load_raw = [&](unsigned pixoff, int cc, bool second = false) {     // `second` is wave-uniform
+    const __amdgpu_buffer_rsrc_t r = second ? rx2 : rx;
+    const unsigned ch = second ? chan2 : chan;
+    const unsigned vo = pixoff + (unsigned)(8 * g) * ch;
+    const unsigned so = (unsigned)(64 * cc) * ch;
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int e = 0; e < 8; ++e)
-        raw[8 * s + e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo, so + (unsigned)(16 * s + e) * chan, 0));
+        raw[8 * s + e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, so + (unsigned)(16 * s + e) * ch, 0));
   };
   long long tile;
   int pass;
   cx_item(a, 0, &tile, &pass);
   CxGeom gm = cx_geom(a, tile * kTile + wave * 32 + j);
+  unsigned gm2 = cx_geom2(a, tile * kTile + wave * 32 + j);
   load_raw(cx_tap_offset(a, gm, 0), 0);
   for (long long w = 0; w < wcount; ++w) {
     const long long p = tile * kTile + wave * 32 + j;
@@ -139,6 +158,7 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
     int npass_ = pass;
     const bool more = cx_item(a, w + 1, &ntile, &npass_);
     const CxGeom ngm = more ? cx_geom(a, ntile * kTile + wave * 32 + j) : CxGeom{kOOB, 0, 0};
+    const unsigned ngm2 = more ? cx_geom2(a, ntile * kTile + wave * 32 + j) : kOOB;
     int tap = 0, cc = 0;                   // of the chunk that is requested next
     f16v acc[NB];
 #pragma unroll
@@ -163,7 +183,11 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
       }
       // ALWAYS 32 loads here (the ring's counted wait relies on it): the next chunk, the next item's first, or nothing (OOB)
       if (++cc == NCC) cc = 0, ++tap;
-      load_raw(kc + 1 < NC ? cx_tap_offset(a, gm, tap) : cx_tap_offset(a, ngm, 0), kc + 1 < NC ? cc : 0);
+      {
+        const bool first = kc + 1 < NC1, sec = !first && kc + 1 < NC;      // wave-uniform; the second source's chunks follow the first's
+        const unsigned po = first ? cx_tap_offset(a, gm, tap) : (sec ? gm2 : cx_tap_offset(a, ngm, 0));
+        load_raw(po, first ? cc : (sec ? kc + 1 - NC1 : 0), sec);
+      }
 #pragma unroll
       for (int part = 0; part < IPC; ++part) {
         const char *stage = ring.wait(false);
@@ -197,7 +221,7 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
       }
     }
     if (a.flag != nullptr && chk != chk && p < a.pixels) atomicCAS(a.flag, 0, a.tag);
-    tile = ntile, pass = npass_, gm = ngm;
+    tile = ntile, pass = npass_, gm = ngm, gm2 = ngm2;
   }
 }
 
@@ -229,7 +253,18 @@ DVIS_EXPORT int dvis_conv1x1_x3_pack(const float *w, int K, int C, int wexp, voi
 }
 
 static int cx_launch(const float *x, const void *packed, const float *bias, const float *res, float *y, int N, int C, int K, int H, int W,
-                     int stride, int taps, int xexp, int wexp, int relu, void *stream);
+                     int stride, int taps, int xexp, int wexp, int relu, void *stream, const float *x2 = nullptr, int C2 = 0, int H2 = 0,
+                     int W2 = 0, int stride2 = 1);
+
+DVIS_EXPORT int dvis_conv1x1_x3_dual(const float *x, const float *x2, const void *packed, const float *bias, const float *res, float *y,
+                                     int N, int C, int C2, int K, int H, int W, int H2, int W2, int stride2, int xexp, int wexp, int relu,
+                                     void *stream) {
+  DVIS_REQUIRE(x2 != nullptr && C2 >= 64 && C2 % 64 == 0 && C2 <= 4096, "dvis_conv1x1_x3_dual: C2 %% 64 == 0 (got %d)", C2);
+  DVIS_REQUIRE((stride2 == 1 || stride2 == 2) && (H2 + stride2 - 1) / stride2 == H && (W2 + stride2 - 1) / stride2 == W,
+               "dvis_conv1x1_x3_dual: x2 (%d x %d, stride %d) must down-sample onto x's %d x %d map", H2, W2, stride2, H, W);
+  DVIS_REQUIRE((long long)N * C2 * H2 * W2 * 4 < ((long long)1 << 31) && (uintptr_t)x2 % 16 == 0, "dvis_conv1x1_x3_dual: x2 below 2 GiB, 16-byte aligned");
+  return cx_launch(x, packed, bias, res, y, N, C, K, H, W, 1, 1, xexp, wexp, relu, stream, x2, C2, H2, W2, stride2);
+}
 
 DVIS_EXPORT int dvis_conv1x1_x3(const float *x, const void *packed, const float *bias, const float *res, float *y, int N, int C, int K,
                                 int H, int W, int stride, int xexp, int wexp, int relu, void *stream) {
@@ -259,7 +294,7 @@ DVIS_EXPORT int dvis_conv3x3_x3(const float *x, const void *packed, const float 
 }
 
 static int cx_launch(const float *x, const void *packed, const float *bias, const float *res, float *y, int N, int C, int K, int H, int W,
-                     int stride, int taps, int xexp, int wexp, int relu, void *stream) {
+                     int stride, int taps, int xexp, int wexp, int relu, void *stream, const float *x2, int C2, int H2, int W2, int stride2) {
   DVIS_REQUIRE(x && packed && y, "dvis_conv1x1_x3: null operand");
   DVIS_REQUIRE(stride == 1 || stride == 2, "dvis_conv1x1_x3: stride %d", stride);
   const int OH = (H + stride - 1) / stride, OW = (W + stride - 1) / stride;
@@ -274,6 +309,7 @@ static int cx_launch(const float *x, const void *packed, const float *bias, cons
   a.xscale = ldexpf(1.f, xexp), a.inv = ldexpf(1.f, -(xexp + wexp));
   const X3Guard gd = dvis_x3_guard();
   a.flag = gd.flag, a.tag = gd.tag;
+  a.x2 = x2, a.C2 = x2 ? C2 : 0, a.stride2 = stride2, a.W2_in = W2, a.HW2_in = (long long)H2 * W2;
   const int grid = dvis_x3_persistent_cus();
   hipStream_t st = (hipStream_t)stream;
   static const int nw = getenv("DVIS_X3_CONV_WAVES") ? atoi(getenv("DVIS_X3_CONV_WAVES")) : 8;

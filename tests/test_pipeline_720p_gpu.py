@@ -133,7 +133,12 @@ def test_T30_natural_logit_scale_literal_1e3_and_error_budget():
     decisive, which multiplies the absolute error by the same factor).  Also records the per-stage error budget
     (encoder -> decoder -> 30-frame tracker recurrence -> refiner -> mask embeddings -> logits)."""
     import bench
-    gain = 2.0       # max |logit| ~ 5; (x3: ~7.3, measured error 5.7e-4 / 9.0e-4 on two boxes — it is a sum of discrete events)
+    # max |logit| ~ 4.6.  The error is a sum of discrete events (attention-mask bits that differ where a down-sized logit sits
+    # within rounding distance of 0).  Round 5 swept it: 5 clips x 8 arithmetic configurations (profiles/r05_x3_error_sweep.txt) —
+    # 1.1e-4 ... 2.0e-4 with the split-f16 kernels everywhere, 1.0e-4 ... 2.2e-4 with the exact-fp32 kernels in all four stages
+    # after the backbone: the split arithmetic does not spend the budget, the summation-order difference to the CPU oracle does,
+    # equally for both.  Asserted at 5e-4 = 2.5x the worst of the sweep, half of BASELINE's literal 1e-3.
+    gain = 2.0
     m, sd = _model("offline", "vps", gain=gain)
     m = m.to(DEV)
     clip = bench.synthetic_clip(30, torch.device(DEV), seed=1234)
@@ -152,7 +157,7 @@ def test_T30_natural_logit_scale_literal_1e3_and_error_budget():
     rows = PPar.error_budget(m.debug_stages, stages, all_logits, what)
     err, scale = rows["mask_logits"]
     assert 2.0 <= scale <= 16.0, f"the test's premise: natural logit scale (got max |logit| {scale:.1f})"
-    assert err <= 1e-3, f"mask logits: max |product - oracle| {err:.3e} exceeds BASELINE's literal 1e-3 at max |logit| {scale:.1f}"
+    assert err <= 5e-4, f"mask logits: max |product - oracle| {err:.3e} exceeds 5e-4 (BASELINE's literal bar: 1e-3) at max |logit| {scale:.1f}"
     # Where the budget's largest entry (the decoder's per-frame queries) comes from: not rounding, but BOOLEAN attention-mask
     # bits that differ where a down-sized mask logit sits within rounding distance of 0 — that query then attends to a
     # different key set in that layer.  Frames without a single differing bit must agree to rounding level.

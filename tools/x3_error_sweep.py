@@ -30,6 +30,8 @@ CONFIGS = [
     ("exact: mask_path + decoder_kv", "mask_path,decoder_kv"),
     ("exact: mask_path + encoder", "mask_path,encoder"),
     ("exact: all four (x3 only in the backbone)", "pd_proj,mask_path,encoder,decoder_kv"),
+    ("x3 everywhere, attention masks WITHOUT the feature pyramid (dvis_attn_mask)", "nopyramid"),
+    ("exact: all four, attention masks WITHOUT the feature pyramid", "pd_proj,mask_path,encoder,decoder_kv,nopyramid"),
 ]
 
 
@@ -70,7 +72,8 @@ def main():
         video = {"image": clip, "height": 720, "width": 1280}
         m.object_mask_threshold = bench.calibrate_threshold(m, [video], 20)
         for name, off in configs:
-            Fn.X3_OFF = frozenset(v for v in off.split(",") if v)
+            Fn.X3_OFF = frozenset(v for v in off.split(",") if v and v != "nopyramid")
+            Fn.ATTN_MASK_PYRAMID = "nopyramid" not in off
             for o in m.stream([video] * 2):
                 pass
             torch.cuda.synchronize()
@@ -83,14 +86,15 @@ def main():
     for seed in [int(v) for v in args.seeds.split(",")]:
         clip = bench.synthetic_clip(args.frames, dev, seed=seed)
         video = {"image": clip, "height": 720, "width": 1280}
-        Fn.X3_OFF = frozenset()
+        Fn.X3_OFF, Fn.ATTN_MASK_PYRAMID = frozenset(), True
         m.object_mask_threshold = bench.calibrate_threshold(m, [video], 20)
         t0 = time.perf_counter()
         ref, stages = PPar.run_oracle(m, sd, [f for f in clip.cpu()], offline=True, task="vps", attn_masks=True,
                                       object_mask_threshold=m.object_mask_threshold, overlap_threshold=0.0, out_hw=(720, 1280))
         say(f"seed {seed}: oracle {time.perf_counter() - t0:.0f} s; max |oracle logit| {float(stages['masks'].abs().max()):.2f}")
         for name, off in configs:
-            Fn.X3_OFF = frozenset(v for v in off.split(",") if v)
+            Fn.X3_OFF = frozenset(v for v in off.split(",") if v and v != "nopyramid")
+            Fn.ATTN_MASK_PYRAMID = "nopyramid" not in off
             m.debug_stages = {}
             m.sem_seg_head.predictor.debug_masks = []
             m([video])
@@ -108,7 +112,7 @@ def main():
             say(f"seed {seed} | {name}: mask-logit error {err:.3e}; attention-mask bits differing {int(flips.sum())} "
                 f"(frames touched {int((flips.sum((0, 2)) > 0).sum())}/{args.frames}); decoder query error max {float(fe.max()):.2e}, "
                 f"median frame {float(fe.median()):.2e}; mask_features error {mf:.2e}")
-    Fn.X3_OFF = frozenset()
+    Fn.X3_OFF, Fn.ATTN_MASK_PYRAMID = frozenset(), True
     say("# worst over seeds")
     for name, _ in configs:
         say(f"worst | {name}: {worst[name]:.3e}")
