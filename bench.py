@@ -166,11 +166,23 @@ class ConvTimer:
             self.events1.append((e0, e1, 2.0 * N * C * K * ((H + stride - 1) // stride) * ((W + stride - 1) // stride)))
             return rc
         lib.dvis_conv1x1_x3 = timed_1
+        self.orig2 = lib.dvis_conv1x1_x3_dual
+
+        def timed_2(x, x2, packed, bias, res, y, N, C, C2, K, H, W, *rest):        # conv3 + shortcut as one launch of the same kernel
+            st = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            rc = self.orig2(x, x2, packed, bias, res, y, N, C, C2, K, H, W, *rest)
+            e1.record(st)
+            self.events1.append((e0, e1, 2.0 * N * (C + C2) * K * H * W))
+            return rc
+        lib.dvis_conv1x1_x3_dual = timed_2
         return self
 
     def __exit__(self, *exc):
         setattr(self.lib, self.name, self.orig)
         self.lib.dvis_conv1x1_x3 = self.orig1
+        self.lib.dvis_conv1x1_x3_dual = self.orig2
 
     def summary(self):
         torch.cuda.synchronize()

@@ -112,8 +112,17 @@ class BottleneckBlock(nn.Module):
     def forward(self, x):
         out = self.conv1(x, relu=True)
         out = self.conv2(out, relu=True)
-        shortcut = x if self.shortcut is None else self.shortcut(x)
-        return self.conv3(out, res=shortcut, relu=True)
+        sc, c3 = self.shortcut, self.conv3
+        if sc is not None and sc.kernel_size == (1, 1) and sc.padding == (0, 0) and sc.stride[0] == sc.stride[1] \
+                and sc.dilation == (1, 1) and sc.groups == 1 and c3.kernel_size == (1, 1) and c3.stride == (1, 1) \
+                and c3.dilation == (1, 1) and c3.groups == 1 and x.is_cuda:
+            (w3, b3), (ws, bs) = c3.folded(), sc.folded()
+            if not key_is_channels_last(w3) and not key_is_channels_last(ws) and Fn.conv1x1_x3_dual_ok(out, w3, x, ws, sc.stride[0]):
+                # conv3 and the projection shortcut as ONE accumulation over [conv2's channels | the block input's channels]: the
+                # shortcut's map (256 channels at the stage's resolution) is neither written nor read back
+                return Fn.conv1x1_x3_dual(out, w3, b3, x, ws, bs, relu=True, stride2=sc.stride[0])
+        shortcut = x if sc is None else sc(x)
+        return c3(out, res=shortcut, relu=True)
 
 
 class ResNet(nn.Module):

@@ -1266,6 +1266,55 @@ def conv1x1_x3(x, weight, bias=None, res=None, relu=False, stride=1, xexp=None):
     return out
 
 
+X3_DUAL = os.environ.get("DVIS_X3_DUAL", "1") != "0"
+
+
+def conv1x1_x3_dual_ok(a, w3, x, ws, stride2):
+    """conv3(a) + shortcut(x) of a bottleneck with a projection shortcut as ONE launch of the split-f16 kernel?"""
+    if not (X3_DUAL and conv1x1_x3_ok(a, w3) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous()
+            and ws.dtype == torch.float32 and ws.shape[0] == w3.shape[0] and stride2 in (1, 2)):
+        return False
+    N, C, H, W = a.shape
+    N2, C2, H2, W2 = x.shape
+    Co = w3.shape[0]
+    return (N2 == N and C2 % 64 == 0 and 64 <= C2 <= 4096 and (H2 + stride2 - 1) // stride2 == H and (W2 + stride2 - 1) // stride2 == W
+            and (C + C2) <= 4096 and bool(native.lib().dvis_conv1x1_x3_supported(C + C2, Co, 1, H * W, H * W))
+            and C2 * H2 * W2 * 4 < 2 ** 31)
+
+
+def conv1x1_x3_dual(a, w3, b3, x, ws, bs, relu=True, stride2=1, xexp=None):
+    """relu?(conv1x1(a, w3) + b3 + conv1x1(x, ws)[:, :, ::stride2, ::stride2] + bs) through dvis_conv1x1_x3_dual."""
+    N, C, H, W = a.shape
+    _, C2, H2, W2 = x.shape
+    Co = w3.shape[0]
+
+    def make():
+        wcat = torch.cat([w3.detach().reshape(Co, C), ws.detach().reshape(Co, C2)], 1).contiguous()
+        e = _x3_exp(wcat)
+        buf = torch.empty(native.lib().dvis_conv1x1_x3_packed_bytes(C + C2, Co), dtype=torch.uint8, device=wcat.device)
+        with torch.cuda.device(wcat.device):
+            native.check(native.lib().dvis_conv1x1_x3_pack(native.dev_ptr(wcat, "weight"), Co, C + C2, e, ctypes.c_void_p(buf.data_ptr()),
+                                                           native.stream_ptr(wcat.device)), "dvis_conv1x1_x3_pack")
+        bias = None
+        if b3 is not None or bs is not None:
+            bias = (0 if b3 is None else b3.detach()) + (0 if bs is None else bs.detach())
+        return buf, e, bias
+    buf, wexp, bias = _x3_cache(w3, (w3._version, w3.data_ptr(), ws._version, ws.data_ptr(), w3.device,
+                                     None if b3 is None else b3._version, None if bs is None else bs._version), make,
+                                kind="conv1x1 + shortcut")
+    out = torch.empty((N, Co, H, W), dtype=torch.float32, device=a.device)
+    step = min(_conv_x3_chunks(N, C, Co, H * W, H * W), _conv_x3_chunks(N, C2, Co, H2 * W2, H * W))
+    with torch.cuda.device(a.device):
+        for i in range(0, N, step):
+            n = min(step, N - i)
+            native.check(native.lib().dvis_conv1x1_x3_dual(
+                native.dev_ptr(a[i:i + n], "a"), native.dev_ptr(x[i:i + n], "x"), ctypes.c_void_p(buf.data_ptr()),
+                None if bias is None else native.dev_ptr(bias, "bias"), None, native.dev_ptr(out[i:i + n], "out"), n, C, C2, Co, H, W,
+                H2, W2, stride2, X3_CONV_XEXP if xexp is None else xexp, wexp, 1 if relu else 0, native.stream_ptr(a.device)),
+                "dvis_conv1x1_x3_dual")
+    return out
+
+
 def conv3x3_x3_ok(x, weight, stride=1, res=None):
     """Does the 3x3 / padding 1 form of csrc/conv1x1_x3.hip serve this convolution?"""
     return weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3) and conv1x1_x3_ok(x, weight, stride, res)

@@ -96,6 +96,7 @@ SIGNATURES = {
     "dvis_conv1x1_x3_packed_bytes": (_i64, [_i, _i]),
     "dvis_conv1x1_x3_pack": (_i, [_p, _i, _i, _i, _p, _p]),
     "dvis_conv1x1_x3": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "dvis_conv1x1_x3_dual": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dvis_conv3x3_x3_packed_bytes": (_i64, [_i, _i]),
     "dvis_conv3x3_x3_pack": (_i, [_p, _i, _i, _i, _p, _p]),
     "dvis_conv3x3_x3": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),

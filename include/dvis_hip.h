@@ -539,6 +539,12 @@ int64_t dvis_conv1x1_x3_packed_bytes(int C, int K);
 int dvis_conv1x1_x3_pack(const float *w, int K, int C, int wexp, void *packed, void *stream);
 int dvis_conv1x1_x3(const float *x, const void *packed, const float *bias, const float *res, float *y, int N, int C, int K, int H,
                     int W, int stride, int xexp, int wexp, int relu, void *stream);
+/* The last 1x1 convolution of a down-sampling bottleneck TOGETHER with its shortcut (detectron2 BottleneckBlock with a
+ * projection shortcut, SURVEY.md App. B: out = relu(conv3(a) + shortcut(x))): one accumulation over the concatenated channels
+ * [a (N, C, H, W) | x2 (N, C2, H2, W2) sampled with stride2], `packed` = dvis_conv1x1_x3_pack of the (K, C + C2) matrix
+ * [W3 | Ws], bias = b3 + bs.  The shortcut's (N, K, H, W) map is neither written nor read back. */
+int dvis_conv1x1_x3_dual(const float *x, const float *x2, const void *packed, const float *bias, const float *res, float *y, int N,
+                         int C, int C2, int K, int H, int W, int H2, int W2, int stride2, int xexp, int wexp, int relu, void *stream);
 /* The 3x3 / padding 1 / stride 1 or 2 convolution through the same kernel: nine taps = nine times the input channels, each
  * chunk of 64 channels read at the tap's pixel (outside the image: an out-of-range buffer offset, i.e. exact zero padding).
  * w (K, C, 3, 3).  Serves the stride-2 conv2 of the first res3 / res4 / res5 bottleneck (detectron2 BottleneckBlock). */

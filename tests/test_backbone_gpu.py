@@ -99,7 +99,7 @@ def test_resnet50_production_size_strict_own_kernels_vs_unfused_fp64():
     sd = {k: v.double() for k, v in m.state_dict().items()}
     lib = native.lib()
     names = ("dvis_conv3x3_winograd", "dvis_conv1x1_mfma", "dvis_conv1x1s2_mfma", "dvis_conv3x3s2", "dvis_conv7x7s2",
-             "dvis_conv1x1_bias_act", "dvis_bias_relu_maxpool", "dvis_conv1x1_x3", "dvis_conv3x3_x3")
+             "dvis_conv1x1_bias_act", "dvis_bias_relu_maxpool", "dvis_conv1x1_x3", "dvis_conv3x3_x3", "dvis_conv1x1_x3_dual")
     calls = {n: 0 for n in names}
     orig = {n: getattr(lib, n) for n in names}
     lib_convs = []
@@ -135,9 +135,12 @@ def test_resnet50_production_size_strict_own_kernels_vs_unfused_fp64():
     # channels) runs on csrc/conv1x1_x3.hip; DVIS_X3=0: the compute-bound ones and the stride-2 shortcuts on
     # csrc/conv1x1_mfma.hip, the rest on the LDS-weights kernel csrc/conv1x1.hip
     from dvis_plus_amd import functions as Fn
-    mm = calls["dvis_conv1x1_x3"] if Fn.X3 else calls["dvis_conv1x1_mfma"] + calls["dvis_conv1x1s2_mfma"]
+    # (round 5: the four blocks with a projection shortcut run conv3 + shortcut as ONE launch, dvis_conv1x1_x3_dual = 2 layers each)
+    dual = calls["dvis_conv1x1_x3_dual"]
+    assert dual == (4 if Fn.X3 and Fn.X3_DUAL else 0), calls
+    mm = calls["dvis_conv1x1_x3"] + 2 * dual if Fn.X3 else calls["dvis_conv1x1_mfma"] + calls["dvis_conv1x1s2_mfma"]
     assert mm >= 20 and mm + calls["dvis_conv1x1_bias_act"] == 36, calls
-    assert calls["dvis_conv1x1_x3"] + calls["dvis_conv1x1_mfma"] + calls["dvis_conv1x1s2_mfma"] == mm, calls
+    assert calls["dvis_conv1x1_x3"] + 2 * dual + calls["dvis_conv1x1_mfma"] + calls["dvis_conv1x1s2_mfma"] == mm, calls
     want = _resnet50_fp64(sd, x.double())
     for k, c, s in (("res2", 256, 4), ("res3", 512, 8), ("res4", 1024, 16), ("res5", 2048, 32)):
         assert got[k].shape == want[k].shape == (2, c, 736 // s, 1280 // s)

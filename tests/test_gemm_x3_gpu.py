@@ -247,6 +247,46 @@ def test_conv1x1_x3(Ci, Co, H, W, stride, N, res, relu):
     assert torch.equal(got, Fn.conv1x1_x3(x, w, b, r, relu, stride))
 
 
+@pytest.mark.parametrize("C,C2,Co,H,W,s2,N", [
+    (64, 64, 256, 46, 80, 1, 2),          # res2.0: conv3 64 -> 256 + shortcut 64 -> 256, same resolution
+    (128, 256, 512, 23, 40, 2, 3),        # res3.0: shortcut reads the stride-4 map with stride 2
+    (256, 512, 1024, 12, 20, 2, 2),       # res4.0
+    (512, 1024, 2048, 6, 10, 2, 1),       # res5.0
+    (128, 256, 512, 23, 39, 2, 2),        # odd input sizes: (45 x 77) -> (23 x 39)
+])
+def test_conv1x1_x3_dual_is_conv3_plus_shortcut(C, C2, Co, H, W, s2, N):
+    """dvis_conv1x1_x3_dual: relu(conv3(a) + b3 + shortcut(x)[::s] + bs) as one accumulation, against fp64 next to the fp32
+    library's error; integer operands: exact (the concatenated k order and the second source's stride-2 geometry)."""
+    from dvis_plus_amd import functions as Fn
+    torch.manual_seed(C + C2 + H)
+    H2, W2 = (2 * H - (1 if W % 2 else 0), 2 * W - (1 if W % 2 else 0)) if s2 == 2 else (H, W)
+    a = torch.randn(N, C, H, W, device=DEV).relu()
+    x = torch.randn(N, C2, H2, W2, device=DEV).relu()
+    w3 = torch.randn(Co, C, 1, 1, device=DEV) * (2.0 / C) ** 0.5
+    ws = torch.randn(Co, C2, 1, 1, device=DEV) * (2.0 / C2) ** 0.5
+    b3, bs = torch.randn(Co, device=DEV), torch.randn(Co, device=DEV)
+    assert Fn.conv1x1_x3_dual_ok(a, w3, x, ws, s2)
+    xs = x[:, :, ::s2, ::s2]
+    ref = (F.conv2d(a.double(), w3.double(), b3.double()) + F.conv2d(xs.double(), ws.double(), bs.double())).clamp_min(0)
+    scale = F.conv2d(a.double().abs(), w3.double().abs(), b3.double().abs()) + F.conv2d(xs.double().abs(), ws.double().abs(), bs.double().abs())
+    lib = (F.conv2d(a, w3, b3) + F.conv2d(xs.contiguous(), ws, bs)).clamp_min(0)
+    got = Fn.conv1x1_x3_dual(a, w3, b3, x, ws, bs, relu=True, stride2=s2)
+    assert got.shape == ref.shape
+    e, e_lib = _rel(got, ref, scale), _rel(lib, ref, scale)
+    assert e <= max(1.25 * e_lib, 3e-7), (e, e_lib)
+    assert torch.equal(got, Fn.conv1x1_x3_dual(a, w3, b3, x, ws, bs, relu=True, stride2=s2))
+    # ... and a frame's result does not depend on its batch mates
+    assert torch.equal(got[:1], Fn.conv1x1_x3_dual(a[:1].contiguous(), w3, b3, x[:1].contiguous(), ws, bs, relu=True, stride2=s2))
+    g = torch.Generator().manual_seed(3)
+    ai = torch.randint(-20, 21, (N, C, H, W), generator=g).float().to(DEV)
+    xi = torch.randint(-20, 21, (N, C2, H2, W2), generator=g).float().to(DEV)
+    w3i = torch.randint(-3, 4, (Co, C, 1, 1), generator=g).float().to(DEV)
+    wsi = torch.randint(-3, 4, (Co, C2, 1, 1), generator=g).float().to(DEV)
+    bi = torch.randint(-50, 50, (Co,), generator=g).float().to(DEV)
+    want = (F.conv2d(ai.double(), w3i.double(), bi.double()) + F.conv2d(xi[:, :, ::s2, ::s2].double(), wsi.double())).float()
+    assert torch.equal(Fn.conv1x1_x3_dual(ai, w3i, bi, xi, wsi, None, relu=False, stride2=s2), want)
+
+
 def test_conv1x1_x3_layout_is_exact_on_integer_operands():
     from dvis_plus_amd import functions as Fn
     g = torch.Generator().manual_seed(9)
