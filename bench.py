@@ -42,6 +42,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MSDA_BYTES_PER_FRAME_LAYER = 4 * (19320 * 8 * 32 + 19320 * 8 * 3 * 4 * 2 + 19320 * 8 * 3 * 4 + 19320 * 8 * 32)  # 61 824 000
+# what the sampling actually moves ON CHIP: every (query, head, level, point) gathers 4 corner lines of 128 B through the vector
+# L1 / texture-address path into VGPRs — 949.6 MB per frame-layer, 15x the compulsory HBM bytes; that path delivers 64 B per clock
+# and CU (x 256 CUs x 2.1 GHz under load = 34.4 TB/s): the roof this kernel is actually under
+MSDA_GATHERED_BYTES_PER_FRAME_LAYER = 19320 * 8 * 3 * 4 * 4 * 128
+L1_PATH_PEAK_GBS = 64 * 256 * 2.1
 HBM_PEAK_GBS = 8000.0
 MFMA_F32_PEAK_TF = 157.3      # dense fp32 matrix peak (MI355X_MICROARCH.md)
 MFMA_F16_PEAK_TF = 2500.0     # dense f16 / bf16 matrix peak (MI355X_MICROARCH.md)
@@ -723,7 +728,13 @@ def main():
                          "traffic_source": traffic_src,
                          "alg_bytes_per_launch": int(MSDA_BYTES_PER_FRAME_LAYER * nfr),
                          "us_per_launch": round(sec * 1e6, 1), "frames_per_launch": nfr, "launches_timed": nlaunch,
-                         "alg_bytes_per_frame_layer": MSDA_BYTES_PER_FRAME_LAYER},
+                         "alg_bytes_per_frame_layer": MSDA_BYTES_PER_FRAME_LAYER,
+                         # the same launches against the roof the kernel is actually under: the vector-L1 return path
+                         "l1_path": {"bound": "vector L1 -> VGPR return path (64 B / clk / CU)",
+                                     "gathered_bytes_per_frame_layer": MSDA_GATHERED_BYTES_PER_FRAME_LAYER,
+                                     "achieved": round(MSDA_GATHERED_BYTES_PER_FRAME_LAYER * nfr / sec / 1e9, 1),
+                                     "peak": round(L1_PATH_PEAK_GBS, 1), "unit": "GB/s",
+                                     "frac": round(MSDA_GATHERED_BYTES_PER_FRAME_LAYER * nfr / sec / 1e9 / L1_PATH_PEAK_GBS, 4)}},
         }
         if dist_info is not None:
             res["dist"] = dist_info

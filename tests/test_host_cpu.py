@@ -146,3 +146,74 @@ def test_every_1x1_layer_of_the_r50_at_the_benchmark_shape_is_served_by_the_spli
                (256, 256, (184, 320), (184, 320)), (256, 256, (184, 320), (184, 320))]                                 # lateral, mask_features
     for C, K, hin, hout in layers:
         assert lib.dvis_conv1x1_x3_supported(C, K, 30, hin[0] * hin[1], hout[0] * hout[1]) == 1, (C, K, hin, hout)
+
+
+def test_gemm_config_families_share_their_k_split():
+    """dvis_gemm_pick_config_nw: whatever the row count, the configuration comes from the family of `nw` waves (its K split) —
+    the property that makes a frame's GEMM results independent of how many frames share the call (Fn.linear)."""
+    from dvis_plus_amd import native
+    lib = native.lib()
+    for nw in (1, 4, 8):
+        seen = set()
+        for M in (1, 100, 300, 700, 3000, 6400, 20000, 579600):
+            for N, K in ((256, 256), (2048, 256), (256, 2048), (125, 256), (1536, 512), (512, 512)):
+                c = lib.dvis_gemm_pick_config_nw(M, N, K, 1, nw)
+                assert 0 <= c < lib.dvis_gemm_num_configs() and lib.dvis_gemm_config_waves(c) == nw, (nw, M, N, K, c)
+                seen.add(c)
+        assert len(seen) >= 2, "a family should offer more than one tile size"
+    assert lib.dvis_gemm_pick_config_nw(100, 256, 256, 1, 3) == -1 and lib.dvis_gemm_config_waves(99) == -1
+
+
+def test_x3_stage_switches_and_pack_cache():
+    from dvis_plus_amd import functions as Fn
+    old_x3, old_off = Fn.X3, Fn.X3_OFF
+    try:
+        Fn.X3, Fn.X3_OFF = True, frozenset({"mask_path"})
+        assert Fn.x3_on()
+        with Fn.x3_stage("mask_path"):
+            assert not Fn.x3_on()
+            with Fn.x3_stage("encoder"):
+                assert Fn.x3_on()
+            assert not Fn.x3_on()
+        with Fn.x3_disabled():
+            assert not Fn.x3_on()
+            with Fn.x3_disabled():
+                assert not Fn.x3_on()
+            assert not Fn.x3_on()
+        assert Fn.x3_on()
+        Fn.X3 = False
+        assert not Fn.x3_on()
+    finally:
+        Fn.X3, Fn.X3_OFF = old_x3, old_off
+    # least-recently-used eviction, one entry per (weight, kind), re-made when the version key changes
+    cache = Fn._PackCache(cap=3)
+    made = []
+    import unittest.mock as mock
+    ws = [torch.zeros(2, 2) for _ in range(5)]
+    with mock.patch.object(Fn.X3_GUARD, "word", lambda dev: None), mock.patch.object(Fn.native, "lib") as lib:
+        lib.return_value.dvis_x3_set_tag = lambda t: 1
+        get = lambda w, kind, ver: cache.get(w, kind, ver, lambda: made.append((id(w), kind, ver)) or (id(w), kind))
+        get(ws[0], "linear", 0), get(ws[0], "ffn", 0), get(ws[1], "linear", 0)
+        assert len(cache) == 3 and len(made) == 3
+        get(ws[0], "linear", 0)                       # hit: refreshed, nothing made
+        assert len(made) == 3
+        get(ws[2], "linear", 0)                       # evicts the least recently used: (ws[0], "ffn")
+        assert len(cache) == 3 and len(made) == 4
+        get(ws[0], "linear", 0)
+        assert len(made) == 4                         # ... not the one just used
+        get(ws[0], "ffn", 0)
+        assert len(made) == 5                         # the evicted one is re-made
+        get(ws[0], "ffn", 1)
+        assert len(made) == 6                         # a new weight version re-packs in place
+        tags = {e[3] for e in cache.d.values()}
+        assert len(tags) == len(cache.d)              # every packed weight has its own range-guard tag
+
+
+def test_range_guard_names_the_layer():
+    from dvis_plus_amd import functions as Fn
+    net = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Sequential(torch.nn.Linear(4, 8)))
+    g = Fn._X3RangeGuard()
+    tag = g.new_tag(net[1][0].weight, "linear")
+    assert g.describe(tag, net) == "1.0.weight (8, 4) [linear kernel]"
+    assert "weight" in g.describe(tag, None) and "?" in g.describe(12345, net)
+    assert g.snapshot(torch.device("cpu")) is None and g.verify(None) is None
