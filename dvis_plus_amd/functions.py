@@ -750,7 +750,9 @@ def linear(x, weight, bias=None, relu=False, own=None, tall=False):
         # Weights that are views (slices made per call) would be re-packed per call: they stay on the exact kernels below.
         return x3_linear(x, weight, bias, relu=relu)
     own = OWN_GEMM_DEFAULT if own is None else own
-    if own and x.is_cuda and not torch.is_grad_enabled():
+    if own and x.is_cuda and not torch.is_grad_enabled() and (forced or not torch.is_autocast_enabled()):
+        # (under torch.autocast — how the reference evaluates, train_net_video.py:259 — the projections are torch's half-precision
+        # GEMMs: their fp16 / bf16 outputs feed the half-precision fused MSDeformAttn kernel)
         if _own_gemm_ok(x, weight):
             cfg = -1
             if not forced:

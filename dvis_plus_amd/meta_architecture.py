@@ -690,13 +690,21 @@ class DVIS_Plus_offline(_VideoBase):
 
         # the split-f16 kernels of phase A are persistent (one workgroup per CU for the whole launch): leave 32 CUs (4 per XCD)
         # to phase B's small kernels on the side stream — measured 356 -> 365 - 370 frames/s (8 / 16 / 24 CUs lose, 40 - 64 gain less)
-        reserve = int(os.environ.get("DVIS_X3_RESERVE", "32")) if overlap else 0
-        prev_reserve = native.lib().dvis_x3_set_reserve(reserve) if overlap else 0
+        # (set only WHILE a round's phase A is enqueued — the grid size is fixed at launch — and restored before this generator
+        # yields: the caller's own kernels between two clips see the process-wide setting)
+        self._stream_reserve = int(os.environ.get("DVIS_X3_RESERVE", "32")) if overlap else 0
+        yield from self._stream_rounds(videos, per_round, sharded_owner, overlap, main, side, phase_b, hand_over)
+
+    def _segment_round_reserved(self, chunk, shift, rotate):
+        """_segment_round with the persistent split-f16 grids leaving `_stream_reserve` CUs to the side stream."""
+        r = getattr(self, "_stream_reserve", 0)
+        if not r:
+            return self._segment_round(chunk, shift=shift, rotate=rotate)
+        prev = native.lib().dvis_x3_set_reserve(r)
         try:
-            yield from self._stream_rounds(videos, per_round, sharded_owner, overlap, main, side, phase_b, hand_over)
+            return self._segment_round(chunk, shift=shift, rotate=rotate)
         finally:
-            if overlap:
-                native.lib().dvis_x3_set_reserve(prev_reserve)
+            native.lib().dvis_x3_set_reserve(prev)
 
     def _stream_rounds(self, videos, per_round, sharded_owner, overlap, main, side, phase_b, hand_over):
         import itertools
@@ -712,7 +720,7 @@ class DVIS_Plus_offline(_VideoBase):
             # clips): no rotation — a clip takes ceil(T / world) frames of segmenter time whoever holds the short block,
             # and a fixed split means every rank keeps ONE batch shape (a new convolution shape costs a MIOpen solver
             # search, seconds).
-            sts = self._segment_round(chunk, shift=n if sharded_owner else 0, rotate=sharded_owner) if chunk else []
+            sts = self._segment_round_reserved(chunk, n if sharded_owner else 0, sharded_owner) if chunk else []
             n += len(chunk)
             if overlap and sts:
                 done = torch.cuda.Event()
@@ -773,7 +781,7 @@ class DVIS_Plus_offline(_VideoBase):
                 chunk = list(itertools.islice(it, per_round))
                 if not chunk:
                     break
-                sts = self._segment_round(chunk, shift=n if sharded_owner else 0, rotate=sharded_owner)
+                sts = self._segment_round_reserved(chunk, n if sharded_owner else 0, sharded_owner)
                 n += len(chunk)
                 done = torch.cuda.Event()
                 done.record(main)
