@@ -186,26 +186,3 @@ def test_tracker_batch_is_bit_identical_on_the_gpu():
         assert torch.equal(g["pred_masks"], w["pred_masks"]), f"clip {i}: panoptic map differs from the unbatched run"
     assert any(w["segments_infos"] for w in want), "degenerate test: no segment anywhere"
 
-
-def test_online_segmenter_graph_replay_equals_eager(monkeypatch):
-    """DVIS_Plus_online replays the segmenter of a small window from a hipGraph (config #2: ~450 launches per 5-frame window,
-    17 % of the wall was the device waiting for the host).  Same bits as the eager launches, window after window (`keep`
-    continues the video: meta_architecture.py:629-632, 793)."""
-    from dvis_plus_amd.meta_architecture import build_dvis_plus_r50
-    m = build_dvis_plus_r50("online", task="vps", object_mask_threshold=0.008).to(DEV)
-    windows = [_clip(5, 11), _clip(5, 12), _clip(3, 13)]
-
-    def run():
-        outs = []
-        for i, w in enumerate(windows):
-            o = m([dict(w, keep=i > 0)])
-            outs.append((o["pred_masks"].clone(), o["segments_infos"], o["pred_ids"]))
-        return outs
-    monkeypatch.setenv("DVIS_SEGMENTER_GRAPH", "0")
-    eager = run()
-    assert m._seg_graph is None or not m._seg_graph._cache
-    monkeypatch.setenv("DVIS_SEGMENTER_GRAPH", "8")
-    first, replay = run(), run()                 # capture, then pure replays
-    assert len(m._seg_graph._cache) == 2          # two window shapes (5 and 3 frames)
-    for a, b, c in zip(eager, first, replay):
-        assert torch.equal(a[0], b[0]) and torch.equal(a[0], c[0]) and a[1] == b[1] == c[1] and a[2] == b[2] == c[2]

@@ -12,7 +12,6 @@ if [ "$S" = "0" ] || [ "$S" = "1" ]; then
   PMC=0 bash tools/prof.sh r05_bench python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra > /dev/null 2>&1
   bash tools/exp/steady.sh r05 > /dev/null 2>&1
   python bench.py --mode online --frames 5 --steps 20 --warmup 4 --no-cpu-baseline --no-extra > gpurun_out/r05/r05_bench_line_online_T5.json 2>/dev/null
-  DVIS_SEGMENTER_GRAPH=0 python bench.py --mode online --frames 5 --steps 20 --warmup 4 --no-cpu-baseline --no-extra > gpurun_out/r05/r05_bench_line_online_T5_eager.json 2>/dev/null
   python bench.py --frames 64 --steps 6 --warmup 2 --no-cpu-baseline --no-extra > gpurun_out/r05/r05_bench_line_T64.json 2>/dev/null
   python bench.py --backbone vitl --queries 200 --steps 4 --warmup 2 --no-cpu-baseline --no-extra > gpurun_out/r05/r05_bench_line_vitl_200q.json 2>/dev/null
   python bench.py --task vis --no-cpu-baseline --no-extra > gpurun_out/r05/r05_bench_line_vis.json 2>/dev/null
