@@ -324,7 +324,8 @@ KeySplitPlan plan_keysplit(int /*BH*/, int Lq, int Lk) {
   KeySplitPlan p;
   p.qchunks = ((Lq + 15) / 16 + kQT - 1) / kQT;
   const int tiles = (Lk + 15) / 16;
-  const int ns = (tiles + 31) / 32;
+  static const int per = []() { const char *e = getenv("DVIS_ATTN_KPS_TILES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 32; }();   // (development: A/B of the split size)
+  const int ns = (tiles + per - 1) / per;
   const int kps = (tiles + ns - 1) / ns * 16;
   p.nsplit = (Lk + kps - 1) / kps;
   p.keys_per_split = kps;
