@@ -318,14 +318,19 @@ struct KeySplitPlan {
 };
 constexpr int kQT = 7;
 
-// Splits of ~512 keys (32 tiles of 16), whatever the batch (see plan_split): 2 / 8 / 29 splits at the R50 levels of 920 / 3680 /
-// 14 720 keys — at 30 frames x 8 heads 480 / 1920 / 6960 waves for the chip's 2048 wave slots, at one frame 16 / 64 / 232.
+// EIGHT splits of the keys (at least 8 tiles of 16 keys each), whatever the batch (see plan_split): 7 / 8 / 8 splits at the R50
+// levels of 920 / 3680 / 14 720 keys — what the batch-sized rule of rounds 1 - 4 chose at the benchmark's 30 frames x 8 heads
+// (1680 - 1920 waves for the chip's 2048 wave slots); a single frame runs 56 - 64 waves.  Measured at 30 frames
+// (profiles/r05_attn_key_splits.txt): splits of 32 tiles (29 at the finest level) 691 / 156 / 139 us per level, of 128 tiles
+// 585 / 496 / 254 us: the finest level wants few long splits (partials: 13 KB written and re-read per split), the coarse ones
+// want their 7 - 8.  DVIS_ATTN_KEY_SPLITS (development): another split count.
 KeySplitPlan plan_keysplit(int /*BH*/, int Lq, int Lk) {
   KeySplitPlan p;
   p.qchunks = ((Lq + 15) / 16 + kQT - 1) / kQT;
   const int tiles = (Lk + 15) / 16;
-  static const int per = []() { const char *e = getenv("DVIS_ATTN_KPS_TILES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 32; }();   // (development: A/B of the split size)
-  const int ns = (tiles + per - 1) / per;
+  static const int want = []() { const char *e = getenv("DVIS_ATTN_KEY_SPLITS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 8; }();
+  int ns = tiles / 8 < want ? tiles / 8 : want;
+  if (ns < 1) ns = 1;
   const int kps = (tiles + ns - 1) / ns * 16;
   p.nsplit = (Lk + kps - 1) / kps;
   p.keys_per_split = kps;
