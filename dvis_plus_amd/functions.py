@@ -753,21 +753,28 @@ def linear(x, weight, bias=None, relu=False, own=None, tall=False):
     if own and x.is_cuda and not torch.is_grad_enabled() and (forced or not torch.is_autocast_enabled()):
         # (under torch.autocast — how the reference evaluates, train_net_video.py:259 — the projections are torch's half-precision
         # GEMMs: their fp16 / bf16 outputs feed the half-precision fused MSDeformAttn kernel)
+        if not forced and not _own_gemm_ok(x, weight) and x.dtype == torch.float32 and weight.dtype == torch.float32 \
+                and x.shape[-1] % 4 == 0:
+            # a view whose rows are not 16-byte aligned / unit-strided (a slice of the last dim, a transposed weight): one copy
+            # makes it servable — cheaper than letting the call fall to the library with other bits per batch size
+            if x.stride(-1) != 1 or x.data_ptr() % 16:
+                x = x.contiguous()
+            if weight.stride(-1) != 1 or weight.stride(0) % 4 or weight.data_ptr() % 16:
+                weight = weight.contiguous()
         if _own_gemm_ok(x, weight):
             cfg = -1
             if not forced:
                 K = x.shape[-1]
                 cfg = native.lib().dvis_gemm_pick_config_nw(max(1, x.numel() // K), weight.shape[0], K, 1,
                                                             1 if tall else (8 if K >= 1024 else 4))
-            return gemm_nt(x, weight.detach(), None if bias is None else bias.detach(), relu=relu, config=cfg)
+            return gemm_nt(x, weight.detach(), None if bias is None else bias.detach().contiguous(), relu=relu, config=cfg)
         if forced:
             # tracker / refiner call sites: their stream must NEVER carry a library (stream-K) GEMM and every rank must
             # compute the same bits — a refused operand is an error whatever DVIS_STRICT says (as in gemm_nt itself)
             raise RuntimeError(f"linear(own=True): the own GEMM cannot serve these operands (needs fp32, K % 4 == 0, 16-byte "
                                f"aligned operands, weight row stride % 4 == 0; x {tuple(x.shape)} {x.dtype}, weight "
                                f"{tuple(weight.shape)} {weight.dtype} stride {tuple(weight.stride())})")
-        if x.dtype == torch.float32 and not torch.is_autocast_enabled():
-            _torch_path("linear(own GEMM)", x, "needs fp32, K % 4 == 0 and 16-byte aligned operands")
+        # (K % 4 != 0 or mixed dtypes: no layer of the reference's configurations; the library GEMM below serves them)
     if relu and bias is not None and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled():
         K = x.shape[-1]
         y = torch._addmm_activation(bias, x.reshape(-1, K), weight.t(), use_gelu=False)
