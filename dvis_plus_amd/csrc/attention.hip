@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "dvis_common.h"
+#include "x3_common.h"
 
 namespace {
 
@@ -761,6 +762,180 @@ __global__ __launch_bounds__(256) void attn_short_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Long self-attention at head dim 64 on the F16 matrix cores with split fp32 operands (round 5): the DINOv2 / ViT-Adapter blocks
+// of BASELINE config #5 (3681 tokens x 16 heads x 24 blocks: 40 TFLOP per 30-frame clip, 38 % of that clip on the fp32 kernel
+// above at 0.71 of the fp32 matrix peak).  Same partition as attn_fwd_kernel — 8 waves x 16 queries per workgroup, K / V staged
+// through LDS for all of them, online softmax in base 2 with the score tile of key tile kt + 1 issued before the softmax of tile
+// kt — with the arithmetic of csrc/gemm_x3.hip: every fp32 operand v is carried as hi = rn16(v 2^e), lo = rn16(v 2^e - hi) and
+// every product as lo*hi + hi*lo + hi*hi on v_mfma_f32_16x16x16_f16 (fp32 accumulation): 12 matrix instructions of 8 cycles per
+// 16-key tile and product where the fp32 form issues 16 of 32 cycles.
+//   S^T tile (16 keys x 16 queries):  A = K[key j][16 c + 4 g ..+3], B = Q[query j][16 c + 4 g ..+3], c = 0..3
+//     -> lane (j, g) holds S[query j][key0 + 4 g + r] = the A layout of the next product: P[query j][keys 4 g ..+3]
+//   O tile (16 queries x 16 dims):    A = P (from registers), B = V[key0 + 4 g ..+3][16 n + j]: four CONSECUTIVE KEYS of one
+//     dim per lane, so V is staged TRANSPOSED ([dim][key], split once per stage by the threads that load it).
+// Scales: Q (already times scale log2 e), K, V by 2^4 (|v| < 4094; elements down to 2^-7 keep 22 bits), P (in [0, 1]) by 2^10;
+// the score tile is scaled back by 2^-8, the output by 2^-14 inside its 1 / l.  No mask, no key split (callers: nsplit == 1).
+typedef _Float16 ah4 __attribute__((ext_vector_type(4)));
+constexpr int kX3KT = 64;             // keys per stage
+constexpr int kX3Row = 72;            // halves per LDS row (64 + 8: the 8-byte fragment reads of 32 lanes cover all 64 banks)
+
+__device__ __forceinline__ void x3_split4(float a, float b, float c, float d, ah4 &hi, ah4 &lo) {
+  const _Float16 h0 = (_Float16)a, h1 = (_Float16)b, h2 = (_Float16)c, h3 = (_Float16)d;
+  hi = ah4{h0, h1, h2, h3};
+  lo = ah4{(_Float16)(a - (float)h0), (_Float16)(b - (float)h1), (_Float16)(c - (float)h2), (_Float16)(d - (float)h3)};
+}
+
+__global__ __launch_bounds__(512) void attn_x3_kernel(const float *__restrict__ q, dvis_strides qs, const float *__restrict__ k,
+                                                      dvis_strides ks_, const float *__restrict__ v, dvis_strides vs,
+                                                      float *__restrict__ out, dvis_strides os, int heads, int Lq, int Lk,
+                                                      float scale, int *__restrict__ guard_flag, int guard_tag) {
+  constexpr int DH = 64, KT = kX3KT, RS = kX3Row;
+  __shared__ _Float16 kh_lds[KT * RS], kl_lds[KT * RS];      // [key][dim]
+  __shared__ _Float16 vh_lds[DH * RS], vl_lds[DH * RS];      // [dim][key]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, bi = bh / heads, hi_ = bh - bi * heads;
+  const int q0 = blockIdx.z * 128 + wv * 16;
+  const bool wave_on = q0 < Lq;
+  const int myq = q0 + j;
+  const bool q_ok = myq < Lq;
+  constexpr float kOp = 16.f, kP = 1024.f;
+
+  // ---- B operand of S^T: Q[myq][16 c + 4 g ..+3] * scale * log2(e) * 2^4, split
+  ah4 qh[4], ql[4];
+  {
+    const float *qrow = q + (size_t)bi * qs.b + (size_t)hi_ * qs.h + (size_t)(q_ok ? myq : 0) * qs.r + 4 * g;
+    const float f = q_ok ? scale * kLog2e * kOp : 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float4 t = *reinterpret_cast<const float4 *>(qrow + 16 * c);
+      x3_split4(t.x * f, t.y * f, t.z * f, t.w * f, qh[c], ql[c]);
+    }
+  }
+  dvis_f4 o[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) o[n] = dvis_f4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_part = 0.f;
+
+  const float *kb = k + (size_t)bi * ks_.b + (size_t)hi_ * ks_.h;
+  const float *vb = v + (size_t)bi * vs.b + (size_t)hi_ * vs.h;
+  // stage = 64 keys x 64 dims = 1024 float4 per matrix: two per thread, prefetched one stage ahead
+  float4 pk0, pv0, pk1, pv1;
+  auto prefetch = [&](int ks) {          // rows past the last key re-read it: their scores are set to -inf below
+    int row = tid >> 4, c4 = tid & 15;
+    int key = min(ks + row, Lk - 1);
+    pk0 = *reinterpret_cast<const float4 *>(kb + (size_t)key * ks_.r + 4 * c4);
+    pv0 = *reinterpret_cast<const float4 *>(vb + (size_t)key * vs.r + 4 * c4);
+    row += 32;
+    key = min(ks + row, Lk - 1);
+    pk1 = *reinterpret_cast<const float4 *>(kb + (size_t)key * ks_.r + 4 * c4);
+    pv1 = *reinterpret_cast<const float4 *>(vb + (size_t)key * vs.r + 4 * c4);
+  };
+  auto store_stage = [&](const float4 &pk, const float4 &pv, int row) {
+    const int c4 = tid & 15;
+    ah4 h, l;
+    x3_split4(pk.x * kOp, pk.y * kOp, pk.z * kOp, pk.w * kOp, h, l);
+    *reinterpret_cast<ah4 *>(&kh_lds[row * RS + 4 * c4]) = h;
+    *reinterpret_cast<ah4 *>(&kl_lds[row * RS + 4 * c4]) = l;
+    x3_split4(pv.x * kOp, pv.y * kOp, pv.z * kOp, pv.w * kOp, h, l);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      vh_lds[(4 * c4 + e) * RS + row] = h[e];
+      vl_lds[(4 * c4 + e) * RS + row] = l[e];
+    }
+  };
+  prefetch(0);
+  for (int ks = 0; ks < Lk; ks += KT) {
+    __syncthreads();
+    store_stage(pk0, pv0, tid >> 4);
+    store_stage(pk1, pv1, (tid >> 4) + 32);
+    __syncthreads();
+    if (ks + KT < Lk) prefetch(ks + KT);
+    if (!wave_on) continue;
+    auto score_tile = [&](int kt) -> dvis_f4 {      // S^T tile: rows = 16 keys, cols = 16 queries (scaled by 2^8)
+      dvis_f4 sc = dvis_f4{0.f, 0.f, 0.f, 0.f};
+      const _Float16 *kh = &kh_lds[(kt * 16 + j) * RS + 4 * g], *kl = &kl_lds[(kt * 16 + j) * RS + 4 * g];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const ah4 a_h = *reinterpret_cast<const ah4 *>(kh + 16 * c), a_l = *reinterpret_cast<const ah4 *>(kl + 16 * c);
+        sc = __builtin_amdgcn_mfma_f32_16x16x16f16(a_l, qh[c], sc, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_16x16x16f16(a_h, ql[c], sc, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_16x16x16f16(a_h, qh[c], sc, 0, 0, 0);
+      }
+      return sc;
+    };
+    dvis_f4 s_next = score_tile(0);
+#pragma unroll 1
+    for (int kt = 0; kt < KT / 16; ++kt) {
+      const int key0 = ks + kt * 16;
+      if (key0 >= Lk) break;                        // uniform
+      const dvis_f4 s = s_next;
+      if (kt + 1 < KT / 16 && key0 + 16 < Lk) s_next = score_tile(kt + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const int kbase = key0 + 4 * g;
+      float sv[4] = {s[0] * (1.f / 256.f), s[1] * (1.f / 256.f), s[2] * (1.f / 256.f), s[3] * (1.f / 256.f)};
+      if (key0 + 16 > Lk) {                         // the ragged last tile (uniform)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sv[r] = kbase + r >= Lk ? -INFINITY : sv[r];
+      }
+      float tmax = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float m_new = fmaxf(m_run, tmax);
+      float alpha = 1.f;
+      if (!__all(m_new == m_run)) alpha = (m_new == -INFINITY) ? 1.f : ex2(m_run - m_new);
+      const float m_sub = (m_new == -INFINITY) ? 0.f : m_new;
+      float p[4], psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p[r] = ex2(sv[r] - m_sub);
+        psum += p[r];
+      }
+      l_part = l_part * alpha + psum;
+      m_run = m_new;
+      if (!__all(alpha == 1.f)) {
+        const dvis_f4 av = dvis_f4{__shfl(alpha, 4 * g), __shfl(alpha, 4 * g + 1), __shfl(alpha, 4 * g + 2),
+                                   __shfl(alpha, 4 * g + 3)};
+#pragma unroll
+        for (int n = 0; n < 4; ++n) o[n] = o[n] * av;
+      }
+      // ---- O += P V: A = P[query j][keys 4 g ..+3] (this lane's four probabilities), B = V^T rows 16 n + j, keys kt 16 + 4 g ..+3
+      ah4 ph, pl;
+      x3_split4(p[0] * kP, p[1] * kP, p[2] * kP, p[3] * kP, ph, pl);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const ah4 b_h = *reinterpret_cast<const ah4 *>(&vh_lds[(16 * n + j) * RS + kt * 16 + 4 * g]);
+        const ah4 b_l = *reinterpret_cast<const ah4 *>(&vl_lds[(16 * n + j) * RS + kt * 16 + 4 * g]);
+        o[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(pl, b_h, o[n], 0, 0, 0);
+        o[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(ph, b_l, o[n], 0, 0, 0);
+        o[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(ph, b_h, o[n], 0, 0, 0);
+      }
+    }
+  }
+  if (!wave_on) return;
+  float l_tot = l_part + __shfl_xor(l_part, 16);
+  l_tot += __shfl_xor(l_tot, 32);
+  float chk = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float lr = __shfl(l_tot, 4 * g + r);
+    const int qq = q0 + 4 * g + r;
+    const float inv = lr > 0.f ? (1.f / (kOp * kP)) / lr : 0.f;
+    if (qq < Lq) {
+      float *orow = out + (size_t)bi * os.b + (size_t)hi_ * os.h + (size_t)qq * os.r;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const float val = o[n][r] * inv;
+        chk = __builtin_fmaf(val, 0.f, chk);
+        orow[16 * n + j] = val;
+      }
+    }
+  }
+  // range guard (x3_common.h): an operand beyond the f16 range (|v| >= 4094) leaves non-finite outputs
+  if (guard_flag != nullptr && chk != chk) atomicCAS(guard_flag, 0, guard_tag);
+}
+
 // Merge the per-split partials: O = sum_s O_s e^{m_s - M} / sum_s l_s e^{m_s - M}.
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restrict__ ws_o, const float *__restrict__ ws_ml,
                                                            int nsplit, int Lq, int DH, int heads, size_t total,
@@ -813,7 +988,15 @@ static int attention_launch(const float *q, const int64_t *q_strides, const floa
                "attention: q/k/v must be 16-byte aligned with strides that are multiples of 4 floats");
   DVIS_REQUIRE(mask == nullptr || ((uintptr_t)mask & 3) == 0, "attention: mask must be 4-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  DVIS_REQUIRE(kernel == 0 || (kernel == 1 && Lk <= 128), "attention: kernel 1 (short keys) needs Lk <= 128 (Lk=%d)", Lk);
+  DVIS_REQUIRE(kernel == 0 || kernel == 2 || (kernel == 1 && Lk <= 128), "attention: kernel 1 (short keys) needs Lk <= 128 (Lk=%d)", Lk);
+  if (kernel == 2) {      // split-f16 long self-attention (ViT blocks): d = 64, no mask, enough query chunks that keys need no split
+    DVIS_REQUIRE(d == 64 && mask == nullptr && Lk >= 128, "attention: kernel 2 (split-f16) serves d = 64 without a mask, Lk >= 128");
+    const X3Guard gd = dvis_x3_guard();
+    hipLaunchKernelGGL(attn_x3_kernel, dim3(1, BH, (Lq + 127) / 128), dim3(512), 0, st, q, qs, k, ks, v, vs, out, os, heads, Lq, Lk, scale,
+                       gd.flag, gd.tag);
+    return dvis_check_launch("attn_x3_kernel");
+  }
+  kernel = kernel == 1 ? 1 : 0;
   if (kernel == 0 && keysplit_applies(Lq, Lk, d, mask != nullptr, ks.r, vs.r)) {
     const KeySplitPlan kp = plan_keysplit(BH, Lq, Lk);
     DVIS_REQUIRE(kp.nsplit == 1 || ws, "attention: workspace required (dvis_attention_ws_bytes)");

@@ -318,6 +318,11 @@ def attention(q, k, v, nheads, mask=None, allowed_count=None, out=None, short=Fa
                 raise RuntimeError("attention: allowed_count must be int32 (B, Lq)")
             aptr = native.dev_ptr(allowed_count, "allowed_count")
     lib = native.lib()
+    kern = 1 if short else 0
+    if not short and mask is None and d == 64 and Lq >= 1024 and Lk >= 1024 and x3_on():
+        # long self-attention at head dim 64 (the DINOv2 / ViT-Adapter blocks: 3681 tokens x 16 heads): split-f16 matrix-core kernel
+        kern = 2
+        X3_GUARD.word(q.device)          # (its range guard reports under the tag of the last packed weight: the block's qkv)
     nbytes = lib.dvis_attention_ws_bytes(B * nheads, Lq, Lk, d)
     ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=q.device) if nbytes else None
     with torch.cuda.device(q.device):
@@ -325,7 +330,7 @@ def attention(q, k, v, nheads, mask=None, allowed_count=None, out=None, short=Fa
             ctypes.c_void_p(q.data_ptr()), _strides3(q, B, C, d), ctypes.c_void_p(k.data_ptr()), _strides3(k, B, C, d),
             ctypes.c_void_p(v.data_ptr()), _strides3(v, B, C, d), ctypes.c_void_p(out.data_ptr()),
             _strides3(out, B, C, d), mptr, aptr, B, nheads, Lq, Lk, d, 1.0 / (d ** 0.5),
-            ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, native.stream_ptr(q.device), 1 if short else 0)
+            ctypes.c_void_p(ws.data_ptr()) if ws is not None else None, native.stream_ptr(q.device), kern)
     native.check(rc, "dvis_attention_forward")
     return out
 

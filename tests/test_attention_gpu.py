@@ -156,3 +156,42 @@ def test_lazy_row_maximum_between_raises():
     ref = ref_attention(q, k, v, H)
     out = attention(q.to(DEV), k.to(DEV), v.to(DEV), H).cpu()
     torch.testing.assert_close(out.double(), ref, rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("L,B,H", [(3681, 1, 16), (1100, 2, 4), (1024, 1, 2)])
+def test_long_self_attention_on_split_f16_products_vs_fp64(L, B, H, monkeypatch):
+    """attn_x3_kernel (head dim 64, no mask, >= 1024 tokens: the ViT blocks of config #5): against fp64 at the fp32 kernel's
+    tolerance, next to the fp32 kernel's own error on the same operands; ragged last key tile / query chunk (3681, 1100);
+    operands of mixed magnitude; a batch entry's bits do not depend on its batch mates; same bits run to run."""
+    from dvis_plus_amd import functions as Fn
+    if not Fn.X3:
+        pytest.skip("DVIS_X3=0")
+    g = torch.Generator().manual_seed(L + B)
+    C = H * 64
+    q, k, v = (torch.randn(L, B, C, generator=g) for _ in range(3))
+    q = q * 2.0
+    k[:, :, ::7] *= 8.0                       # a few large channels, as LayerNorm'd ViT activations have
+    v[:, :, 3::11] *= 0.01
+    ref = ref_attention(q, k, v, H)
+    dq, dk, dv = q.to(DEV), k.to(DEV), v.to(DEV)
+    seen = []
+    lib = Fn.native.lib()
+    orig = lib.dvis_attention_forward_k
+    monkeypatch.setattr(lib, "dvis_attention_forward_k", lambda *a: (seen.append(a[-1]), orig(*a))[1])
+    out = Fn.attention(dq, dk, dv, H)
+    assert seen == [2], "the long d = 64 self-attention must take the split-f16 kernel"
+    with Fn.x3_disabled():
+        exact = Fn.attention(dq, dk, dv, H)
+    assert seen[-1] == 0
+    e_x3 = float((out.cpu().double() - ref).abs().max())
+    e_f32 = float((exact.cpu().double() - ref).abs().max())
+    assert e_x3 <= max(2.0 * e_f32, 2e-5), (e_x3, e_f32)
+    assert torch.equal(out, Fn.attention(dq, dk, dv, H))
+    if B > 1:
+        one = Fn.attention(dq[:, :1].contiguous(), dk[:, :1].contiguous(), dv[:, :1].contiguous(), H)
+        assert torch.equal(one, out[:, :1])
+    Fn.X3_GUARD.check_now(dq.device)
+    dk[5, 0, 3] = 1e4                         # beyond the split's range: the guard names it instead of NaN output going on
+    Fn.attention(dq, dk, dv, H)
+    with pytest.raises(Fn.X3RangeError):
+        Fn.X3_GUARD.check_now(dq.device)
