@@ -778,157 +778,219 @@ __global__ __launch_bounds__(256) void attn_short_kernel(
 // the score tile is scaled back by 2^-8, the output by 2^-14 inside its 1 / l.  No mask, no key split (callers: nsplit == 1).
 typedef _Float16 ah4 __attribute__((ext_vector_type(4)));
 constexpr int kX3KT = 64;             // keys per stage
-constexpr int kX3Row = 72;            // halves per LDS row (64 + 8: the 8-byte fragment reads of 32 lanes cover all 64 banks)
+constexpr int kX3Row = 144;           // halves per LDS row of K ([hi 64 | lo 64] + 16: ds_read_b128 is served in the 16-lane groups {0-3, 12-15,
+                                      // 20-27}, ... — rows 72 dwords apart put each group's 16 fragments (8 of lane group g, 8 of g + 1)
+                                      // on 16 different 4-bank slots; at 68 dwords one pair collides)
+constexpr int kX3RowV = 144;          // ... of V, read through ds_read_b64_tr_b16: eight key rows x 32 B tile the 64 banks at 72 dwords per row
+typedef __fp16 dvis_fp4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+// The LDS transpose read of gfx950: within a group of 16 lanes, lane i names 8 bytes (row i / 4, 16-bit columns 4 (i % 4) ..+3 of a
+// [4][16] block) and receives column i of the block's four rows.  V stays [key][dim] in LDS — the layout it is staged in with
+// 8-byte writes — and still arrives as the k-contiguous B operand of P V (four keys of one dim per lane).
+__device__ __forceinline__ ah4 lds_read_tr16(const _Float16 *p) {
+  return __builtin_bit_cast(ah4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) dvis_fp4 *)(p)));
+}
 
+typedef _Float16 ah8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ ah8 x3_cat(ah4 a, ah4 b) { return ah8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
 __device__ __forceinline__ void x3_split4(float a, float b, float c, float d, ah4 &hi, ah4 &lo) {
   const _Float16 h0 = (_Float16)a, h1 = (_Float16)b, h2 = (_Float16)c, h3 = (_Float16)d;
   hi = ah4{h0, h1, h2, h3};
   lo = ah4{(_Float16)(a - (float)h0), (_Float16)(b - (float)h1), (_Float16)(c - (float)h2), (_Float16)(d - (float)h3)};
 }
 
-__global__ __launch_bounds__(512) void attn_x3_kernel(const float *__restrict__ q, dvis_strides qs, const float *__restrict__ k,
-                                                      dvis_strides ks_, const float *__restrict__ v, dvis_strides vs,
-                                                      float *__restrict__ out, dvis_strides os, int heads, int Lq, int Lk,
-                                                      float scale, int *__restrict__ guard_flag, int guard_tag) {
-  constexpr int DH = 64, KT = kX3KT, RS = kX3Row;
-  __shared__ _Float16 kh_lds[KT * RS], kl_lds[KT * RS];      // [key][dim]
-  __shared__ _Float16 vh_lds[DH * RS], vl_lds[DH * RS];      // [dim][key]
+// Pass 1: Q, K, V -> two-term f16 images in the workspace, [matrix][batch-head][token][hi 64 | lo 64] (256 B per token and matrix:
+// what one fp32 row takes).  Q carries scale * log2(e) * 2^4, K and V 2^4.  The split then costs one pass over the operands
+// instead of one per workgroup that stages them (29 query blocks stream the same K / V at 3681 tokens) — in the main kernel the
+// splitting arithmetic was half of all vector instructions.
+__global__ __launch_bounds__(256) void attn_x3_pack_kernel(const float *__restrict__ q, dvis_strides qs, const float *__restrict__ k,
+                                                           dvis_strides ks_, const float *__restrict__ v, dvis_strides vs,
+                                                           _Float16 *__restrict__ ws, int heads, int Lq, int Lk, float qscale) {
+  const int which = blockIdx.z, bh = blockIdx.y, bi = bh / heads, hi_ = bh - bi * heads;
+  const int L = which == 0 ? Lq : Lk;
+  const int row = blockIdx.x * 32 + (threadIdx.x >> 3), c8 = threadIdx.x & 7;
+  if (row >= L) return;
+  const float *src = which == 0 ? q : which == 1 ? k : v;
+  const dvis_strides st = which == 0 ? qs : which == 1 ? ks_ : vs;
+  const float f = which == 0 ? qscale : 16.f;
+  const float *p = src + (size_t)bi * st.b + (size_t)hi_ * st.h + (size_t)row * st.r + 8 * c8;
+  const float4 x = *reinterpret_cast<const float4 *>(p), y = *reinterpret_cast<const float4 *>(p + 4);
+  ah4 h0, l0, h1, l1;
+  x3_split4(x.x * f, x.y * f, x.z * f, x.w * f, h0, l0);
+  x3_split4(y.x * f, y.y * f, y.z * f, y.w * f, h1, l1);
+  const size_t BH = gridDim.y;
+  _Float16 *dst = ws + (which == 0 ? (size_t)0 : which == 1 ? BH * Lq * 128 : BH * ((size_t)Lq + Lk) * 128) + ((size_t)bh * L + row) * 128 +
+                  8 * c8;
+  *reinterpret_cast<ah8 *>(dst) = x3_cat(h0, h1);
+  *reinterpret_cast<ah8 *>(dst + 64) = x3_cat(l0, l1);
+}
+
+// Pass 2.  QT query tiles of 16 per wave (a workgroup covers 128 QT queries): every K / V fragment read from LDS serves QT matrix
+// instructions, and a staged K / V tile QT times the queries.
+template <int QT>
+__global__ __launch_bounds__(512) void attn_x3_kernel(const _Float16 *__restrict__ ws, float *__restrict__ out, dvis_strides os, int BH,
+                                                      int heads, int Lq, int Lk, int *__restrict__ guard_flag, int guard_tag) {
+  constexpr int KT = kX3KT, NT = KT / 16, RS = kX3Row, RV = kX3RowV;
+  __shared__ __attribute__((aligned(16))) _Float16 k_lds[KT * RS], v_lds[KT * RV];      // [key][hi 64 | lo 64 | pad]; V is read transposed
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
-  const int bh = blockIdx.y, bi = bh / heads, hi_ = bh - bi * heads;
-  const int q0 = blockIdx.z * 128 + wv * 16;
+  // Workgroup -> (batch-head, query block), XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs, each with its own
+  // L2; all query blocks of one (batch, head) stream the same K / V (1.9 MB at 3681 keys), so they are given to ONE XCD and to
+  // consecutive slots there — K / V then come from HBM once and from that L2 for the other blocks.  (With the plain (bh, block)
+  // grid every resident workgroup streamed a different head's K / V: 8.7 GB of L2 misses per ViT-L block at 10 frames.)
+  constexpr int QB = 128 * QT;
+  const int nqb = (Lq + QB - 1) / QB;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int bh = (slot / nqb) * 8 + xcd, qb = slot - (slot / nqb) * nqb;
+  if (bh >= BH) return;
+  const int bi = bh / heads, hi_ = bh - bi * heads;
+  const int q0 = qb * QB + wv * (16 * QT);
   const bool wave_on = q0 < Lq;
-  const int myq = q0 + j;
-  const bool q_ok = myq < Lq;
-  constexpr float kOp = 16.f, kP = 1024.f;
+  constexpr float kOp = 16.f, kLogP = 10.f;        // operands x 2^4; probabilities x 2^10 (folded into the exponent)
+  const _Float16 *wq = ws + (size_t)bh * Lq * 128;
+  const _Float16 *wk = ws + (size_t)BH * Lq * 128 + (size_t)bh * Lk * 128;
+  const _Float16 *wvv = ws + (size_t)BH * ((size_t)Lq + Lk) * 128 + (size_t)bh * Lk * 128;
 
-  // ---- B operand of S^T: Q[myq][16 c + 4 g ..+3] * scale * log2(e) * 2^4, split
-  ah4 qh[4], ql[4];
-  {
-    const float *qrow = q + (size_t)bi * qs.b + (size_t)hi_ * qs.h + (size_t)(q_ok ? myq : 0) * qs.r + 4 * g;
-    const float f = q_ok ? scale * kLog2e * kOp : 0.f;
+  // ---- B operands of S^T (v_mfma_f32_16x16x32_f16: lane (j, g) holds k = 8 g ..+7): Q[q0 + 16 t + j][32 c + 8 g ..+7]
+  ah8 qh[QT][2], ql[QT][2];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float4 t = *reinterpret_cast<const float4 *>(qrow + 16 * c);
-      x3_split4(t.x * f, t.y * f, t.z * f, t.w * f, qh[c], ql[c]);
+  for (int t = 0; t < QT; ++t) {
+    const int myq = min(q0 + 16 * t + j, Lq - 1);          // (rows past Lq repeat the last query: computed, never stored)
+    const _Float16 *qrow = wq + (size_t)myq * 128 + 8 * g;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      qh[t][c] = *reinterpret_cast<const ah8 *>(qrow + 32 * c);
+      ql[t][c] = *reinterpret_cast<const ah8 *>(qrow + 64 + 32 * c);
     }
   }
-  dvis_f4 o[4];
+  dvis_f4 o[QT][4];
+  float m_run[QT], l_part[QT];
 #pragma unroll
-  for (int n = 0; n < 4; ++n) o[n] = dvis_f4{0.f, 0.f, 0.f, 0.f};
-  float m_run = -INFINITY, l_part = 0.f;
+  for (int t = 0; t < QT; ++t) {
+    m_run[t] = -INFINITY, l_part[t] = 0.f;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) o[t][n] = dvis_f4{0.f, 0.f, 0.f, 0.f};
+  }
 
-  const float *kb = k + (size_t)bi * ks_.b + (size_t)hi_ * ks_.h;
-  const float *vb = v + (size_t)bi * vs.b + (size_t)hi_ * vs.h;
-  // stage = 64 keys x 64 dims = 1024 float4 per matrix: two per thread, prefetched one stage ahead
-  float4 pk0, pv0, pk1, pv1;
+  // stage = 64 keys x 256 B per matrix = 1024 16-byte pieces: two per thread and matrix, prefetched one stage ahead
+  ah8 pk[2], pv[2];
   auto prefetch = [&](int ks) {          // rows past the last key re-read it: their scores are set to -inf below
-    int row = tid >> 4, c4 = tid & 15;
-    int key = min(ks + row, Lk - 1);
-    pk0 = *reinterpret_cast<const float4 *>(kb + (size_t)key * ks_.r + 4 * c4);
-    pv0 = *reinterpret_cast<const float4 *>(vb + (size_t)key * vs.r + 4 * c4);
-    row += 32;
-    key = min(ks + row, Lk - 1);
-    pk1 = *reinterpret_cast<const float4 *>(kb + (size_t)key * ks_.r + 4 * c4);
-    pv1 = *reinterpret_cast<const float4 *>(vb + (size_t)key * vs.r + 4 * c4);
-  };
-  auto store_stage = [&](const float4 &pk, const float4 &pv, int row) {
-    const int c4 = tid & 15;
-    ah4 h, l;
-    x3_split4(pk.x * kOp, pk.y * kOp, pk.z * kOp, pk.w * kOp, h, l);
-    *reinterpret_cast<ah4 *>(&kh_lds[row * RS + 4 * c4]) = h;
-    *reinterpret_cast<ah4 *>(&kl_lds[row * RS + 4 * c4]) = l;
-    x3_split4(pv.x * kOp, pv.y * kOp, pv.z * kOp, pv.w * kOp, h, l);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      vh_lds[(4 * c4 + e) * RS + row] = h[e];
-      vl_lds[(4 * c4 + e) * RS + row] = l[e];
+    for (int i = 0; i < 2; ++i) {
+      const int id = tid + 512 * i, key = min(ks + (id >> 4), Lk - 1);
+      pk[i] = *reinterpret_cast<const ah8 *>(wk + (size_t)key * 128 + 8 * (id & 15));
+      pv[i] = *reinterpret_cast<const ah8 *>(wvv + (size_t)key * 128 + 8 * (id & 15));
     }
   };
   prefetch(0);
   for (int ks = 0; ks < Lk; ks += KT) {
     __syncthreads();
-    store_stage(pk0, pv0, tid >> 4);
-    store_stage(pk1, pv1, (tid >> 4) + 32);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int id = tid + 512 * i;
+      *reinterpret_cast<ah8 *>(&k_lds[(id >> 4) * RS + 8 * (id & 15)]) = pk[i];
+      *reinterpret_cast<ah8 *>(&v_lds[(id >> 4) * RV + 8 * (id & 15)]) = pv[i];
+    }
     __syncthreads();
     if (ks + KT < Lk) prefetch(ks + KT);
     if (!wave_on) continue;
-    auto score_tile = [&](int kt) -> dvis_f4 {      // S^T tile: rows = 16 keys, cols = 16 queries (scaled by 2^8)
-      dvis_f4 sc = dvis_f4{0.f, 0.f, 0.f, 0.f};
-      const _Float16 *kh = &kh_lds[(kt * 16 + j) * RS + 4 * g], *kl = &kl_lds[(kt * 16 + j) * RS + 4 * g];
+    // ---- the stage's four S^T tiles per query tile (rows = 16 keys, cols = 16 queries; scaled by 2^8), ONE running-max update per
+    //      64 keys: the cross-lane reduction and the exp chain are paid once per stage, not per tile
+    dvis_f4 s[QT][NT];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const ah4 a_h = *reinterpret_cast<const ah4 *>(kh + 16 * c), a_l = *reinterpret_cast<const ah4 *>(kl + 16 * c);
-        sc = __builtin_amdgcn_mfma_f32_16x16x16f16(a_l, qh[c], sc, 0, 0, 0);
-        sc = __builtin_amdgcn_mfma_f32_16x16x16f16(a_h, ql[c], sc, 0, 0, 0);
-        sc = __builtin_amdgcn_mfma_f32_16x16x16f16(a_h, qh[c], sc, 0, 0, 0);
-      }
-      return sc;
-    };
-    dvis_f4 s_next = score_tile(0);
-#pragma unroll 1
-    for (int kt = 0; kt < KT / 16; ++kt) {
-      const int key0 = ks + kt * 16;
-      if (key0 >= Lk) break;                        // uniform
-      const dvis_f4 s = s_next;
-      if (kt + 1 < KT / 16 && key0 + 16 < Lk) s_next = score_tile(kt + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      const int kbase = key0 + 4 * g;
-      float sv[4] = {s[0] * (1.f / 256.f), s[1] * (1.f / 256.f), s[2] * (1.f / 256.f), s[3] * (1.f / 256.f)};
-      if (key0 + 16 > Lk) {                         // the ragged last tile (uniform)
+    for (int kt = 0; kt < NT; ++kt) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sv[r] = kbase + r >= Lk ? -INFINITY : sv[r];
+      for (int t = 0; t < QT; ++t) s[t][kt] = dvis_f4{0.f, 0.f, 0.f, 0.f};
+      const _Float16 *kr = &k_lds[(kt * 16 + j) * RS + 8 * g];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const ah8 a_h = *reinterpret_cast<const ah8 *>(kr + 32 * c), a_l = *reinterpret_cast<const ah8 *>(kr + 64 + 32 * c);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l, qh[t][c], s[t][kt], 0, 0, 0);
+          s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h, ql[t][c], s[t][kt], 0, 0, 0);
+          s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h, qh[t][c], s[t][kt], 0, 0, 0);
+        }
       }
-      float tmax = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+    }
+    ah8 a_h[QT][NT / 2], a_l[QT][NT / 2];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      if (ks + KT > Lk) {                             // the ragged last stage (uniform)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[t][kt][r] = ks + kt * 16 + 4 * g + r >= Lk ? -INFINITY : s[t][kt][r];
+      }
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) tmax = fmaxf(tmax, fmaxf(fmaxf(s[t][kt][0], s[t][kt][1]), fmaxf(s[t][kt][2], s[t][kt][3])));
       tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-      const float m_new = fmaxf(m_run, tmax);
+      const float m_new = fmaxf(m_run[t], tmax * (1.f / 256.f));      // every stage holds at least one key: finite
+      const bool grew = !__all(m_new == m_run[t]);
       float alpha = 1.f;
-      if (!__all(m_new == m_run)) alpha = (m_new == -INFINITY) ? 1.f : ex2(m_run - m_new);
-      const float m_sub = (m_new == -INFINITY) ? 0.f : m_new;
-      float p[4], psum = 0.f;
+      if (grew) alpha = ex2(m_run[t] - m_new);        // first stage: ex2(-inf) = 0 on zero accumulators
+      const float shift = kLogP - m_new;
+      ah4 ph[NT], pl[NT];
+      float psum = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        p[r] = ex2(sv[r] - m_sub);
-        psum += p[r];
-      }
-      l_part = l_part * alpha + psum;
-      m_run = m_new;
-      if (!__all(alpha == 1.f)) {
-        const dvis_f4 av = dvis_f4{__shfl(alpha, 4 * g), __shfl(alpha, 4 * g + 1), __shfl(alpha, 4 * g + 2),
-                                   __shfl(alpha, 4 * g + 3)};
+      for (int kt = 0; kt < NT; ++kt) {
+        float p[4];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) o[n] = o[n] * av;
+        for (int r = 0; r < 4; ++r) {
+          p[r] = ex2(__builtin_fmaf(s[t][kt][r], 1.f / 256.f, shift));
+          psum += p[r];
+        }
+        x3_split4(p[0], p[1], p[2], p[3], ph[kt], pl[kt]);
       }
-      // ---- O += P V: A = P[query j][keys 4 g ..+3] (this lane's four probabilities), B = V^T rows 16 n + j, keys kt 16 + 4 g ..+3
-      ah4 ph, pl;
-      x3_split4(p[0] * kP, p[1] * kP, p[2] * kP, p[3] * kP, ph, pl);
+      l_part[t] = l_part[t] * alpha + psum;
+      m_run[t] = m_new;
+      if (grew) {
+        const dvis_f4 av = dvis_f4{__shfl(alpha, 4 * g), __shfl(alpha, 4 * g + 1), __shfl(alpha, 4 * g + 2), __shfl(alpha, 4 * g + 3)};
+#pragma unroll
+        for (int n = 0; n < 4; ++n) o[t][n] = o[t][n] * av;
+      }
+#pragma unroll
+      for (int pb = 0; pb < NT / 2; ++pb) a_h[t][pb] = x3_cat(ph[2 * pb], ph[2 * pb + 1]), a_l[t][pb] = x3_cat(pl[2 * pb], pl[2 * pb + 1]);
+    }
+    // ---- O += P V, 32 keys per matrix instruction.  The k index of the instruction is a free permutation as long as both operands
+    //      use it: slot 8 g + e is key 4 g + e of tile 2 pb (e < 4) or of tile 2 pb + 1 (e >= 4) — exactly the probabilities this
+    //      lane holds (A = P[query j][slot]); B = V[key(slot)][dim 16 n + j]: two transpose reads, one per tile.
+#pragma unroll
+    for (int pb = 0; pb < NT / 2; ++pb) {
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
-        const ah4 b_h = *reinterpret_cast<const ah4 *>(&vh_lds[(16 * n + j) * RS + kt * 16 + 4 * g]);
-        const ah4 b_l = *reinterpret_cast<const ah4 *>(&vl_lds[(16 * n + j) * RS + kt * 16 + 4 * g]);
-        o[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(pl, b_h, o[n], 0, 0, 0);
-        o[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(ph, b_l, o[n], 0, 0, 0);
-        o[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(ph, b_h, o[n], 0, 0, 0);
+        const int voff = (pb * 32 + 4 * g + (j >> 2)) * RV + 16 * n + 4 * (j & 3);      // this lane's 8 bytes of the group's block
+        const ah8 b_h = x3_cat(lds_read_tr16(&v_lds[voff]), lds_read_tr16(&v_lds[voff + 16 * RV]));
+        const ah8 b_l = x3_cat(lds_read_tr16(&v_lds[voff + 64]), lds_read_tr16(&v_lds[voff + 64 + 16 * RV]));
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          o[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l[t][pb], b_h, o[t][n], 0, 0, 0);
+          o[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[t][pb], b_l, o[t][n], 0, 0, 0);
+          o[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[t][pb], b_h, o[t][n], 0, 0, 0);
+        }
       }
     }
   }
   if (!wave_on) return;
-  float l_tot = l_part + __shfl_xor(l_part, 16);
-  l_tot += __shfl_xor(l_tot, 32);
   float chk = 0.f;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const float lr = __shfl(l_tot, 4 * g + r);
-    const int qq = q0 + 4 * g + r;
-    const float inv = lr > 0.f ? (1.f / (kOp * kP)) / lr : 0.f;
-    if (qq < Lq) {
-      float *orow = out + (size_t)bi * os.b + (size_t)hi_ * os.h + (size_t)qq * os.r;
+  for (int t = 0; t < QT; ++t) {
+    float l_tot = l_part[t] + __shfl_xor(l_part[t], 16);
+    l_tot += __shfl_xor(l_tot, 32);
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        const float val = o[n][r] * inv;
-        chk = __builtin_fmaf(val, 0.f, chk);
-        orow[16 * n + j] = val;
+    for (int r = 0; r < 4; ++r) {
+      const float lr = __shfl(l_tot, 4 * g + r);
+      const int qq = q0 + 16 * t + 4 * g + r;
+      const float inv = lr > 0.f ? (1.f / kOp) / lr : 0.f;        // l carries the probabilities' 2^10
+      if (qq < Lq) {
+        float *orow = out + (size_t)bi * os.b + (size_t)hi_ * os.h + (size_t)qq * os.r;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          const float val = o[t][n][r] * inv;
+          chk = __builtin_fmaf(val, 0.f, chk);
+          orow[16 * n + j] = val;
+        }
       }
     }
   }
@@ -962,6 +1024,12 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restri
 
 }  // namespace
 
+DVIS_EXPORT int64_t dvis_attention_ws_bytes_k(int BH, int Lq, int Lk, int d, int kernel) {
+  if (kernel != 2) return dvis_attention_ws_bytes(BH, Lq, Lk, d);
+  if (BH <= 0 || Lq <= 0 || Lk <= 0 || d != 64) return 0;
+  return (int64_t)BH * ((int64_t)Lq + 2 * (int64_t)Lk) * 128 * (int64_t)sizeof(_Float16);       // the two-term f16 images of Q, K, V
+}
+
 DVIS_EXPORT int64_t dvis_attention_ws_bytes(int BH, int Lq, int Lk, int d) {
   if (BH <= 0 || Lq <= 0 || Lk <= 0 || d <= 0) return 0;
   const SplitPlan p = plan_split(BH, Lq, Lk);
@@ -991,9 +1059,19 @@ static int attention_launch(const float *q, const int64_t *q_strides, const floa
   DVIS_REQUIRE(kernel == 0 || kernel == 2 || (kernel == 1 && Lk <= 128), "attention: kernel 1 (short keys) needs Lk <= 128 (Lk=%d)", Lk);
   if (kernel == 2) {      // split-f16 long self-attention (ViT blocks): d = 64, no mask, enough query chunks that keys need no split
     DVIS_REQUIRE(d == 64 && mask == nullptr && Lk >= 128, "attention: kernel 2 (split-f16) serves d = 64 without a mask, Lk >= 128");
+    DVIS_REQUIRE(ws != nullptr, "attention: kernel 2 needs its workspace (dvis_attention_ws_bytes_k)");
     const X3Guard gd = dvis_x3_guard();
-    hipLaunchKernelGGL(attn_x3_kernel, dim3(1, BH, (Lq + 127) / 128), dim3(512), 0, st, q, qs, k, ks, v, vs, out, os, heads, Lq, Lk, scale,
-                       gd.flag, gd.tag);
+    _Float16 *wsh = (_Float16 *)ws;
+    hipLaunchKernelGGL(attn_x3_pack_kernel, dim3((std::max(Lq, Lk) + 31) / 32, BH, 3), dim3(256), 0, st, q, qs, k, ks, v, vs, wsh, heads, Lq,
+                       Lk, scale * kLog2e * 16.f);
+    if (const int rc = dvis_check_launch("attn_x3_pack_kernel")) return rc;
+    static const int qt = []() { const char *e = getenv("DVIS_ATTN_X3_QT"); return e ? atoi(e) : 1; }();     // (development)
+    if (qt == 2)
+      hipLaunchKernelGGL(attn_x3_kernel<2>, dim3(((BH + 7) / 8) * 8 * ((Lq + 255) / 256)), dim3(512), 0, st, wsh, out, os, BH, heads, Lq, Lk,
+                         gd.flag, gd.tag);
+    else
+      hipLaunchKernelGGL(attn_x3_kernel<1>, dim3(((BH + 7) / 8) * 8 * ((Lq + 127) / 128)), dim3(512), 0, st, wsh, out, os, BH, heads, Lq, Lk,
+                         gd.flag, gd.tag);
     return dvis_check_launch("attn_x3_kernel");
   }
   kernel = kernel == 1 ? 1 : 0;

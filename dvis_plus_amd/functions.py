@@ -323,7 +323,7 @@ def attention(q, k, v, nheads, mask=None, allowed_count=None, out=None, short=Fa
         # long self-attention at head dim 64 (the DINOv2 / ViT-Adapter blocks: 3681 tokens x 16 heads): split-f16 matrix-core kernel
         kern = 2
         X3_GUARD.word(q.device)          # (its range guard reports under the tag of the last packed weight: the block's qkv)
-    nbytes = lib.dvis_attention_ws_bytes(B * nheads, Lq, Lk, d)
+    nbytes = lib.dvis_attention_ws_bytes_k(B * nheads, Lq, Lk, d, kern)
     ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=q.device) if nbytes else None
     with torch.cuda.device(q.device):
         rc = lib.dvis_attention_forward_k(

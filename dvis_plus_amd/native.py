@@ -39,6 +39,7 @@ SIGNATURES = {
     "dvis_center_pool3": (_i, [_p, _i64, _i, _i, _p, _p, _p, _p]),
     "dvis_attn_mask_pooled": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "dvis_attention_ws_bytes": (_i64, [_i, _i, _i, _i]),
+    "dvis_attention_ws_bytes_k": (_i64, [_i, _i, _i, _i, _i]),
     "dvis_attention_forward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p]),
     "dvis_attention_forward_k": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p, _i]),
     "dvis_add_layernorm": (_i, [_p, _p, _i64, _p, _p, _p, _i64, _i, _f, _p]),

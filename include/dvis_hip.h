@@ -216,6 +216,13 @@ int dvis_attention_forward_k(const float *q, const int64_t *q_strides, const flo
                            const float *v, const int64_t *v_strides, float *out, const int64_t *o_strides,
                            const uint8_t *mask, const int32_t *allowed_count, int B, int heads, int Lq, int Lk,
                            int d, float scale, void *ws, void *stream, int kernel);
+/* kernel 2: long self-attention at d = 64 without a mask (the ViT blocks of the DINOv2 / ViT-Adapter backbones,
+ * dvis_Plus/../vit_adapter: 3681 tokens x 16 heads at 720p) on split-f16 matrix-core products — Q, K, V as two f16 terms each
+ * (x3_common.h: three products per fp32 product, fp32 accumulation), softmax in fp32, the probabilities split the same way.
+ * Two launches: the operands' two-term images are written once into `ws` (dvis_attention_ws_bytes_k(.., 2) bytes: what Q, K, V
+ * take in fp32), then one workgroup per (batch-head, 128 queries) streams K / V from there.  Operands must stay below 4094 in
+ * magnitude (the range guard of dvis_x3_set_range_flag reports a violation). */
+int64_t dvis_attention_ws_bytes_k(int BH, int Lq, int Lk, int d, int kernel);
 
 /*
  * out[r, :] = LayerNorm(x[r, :] + res[r, :]) * gamma + beta, rows x C fp32 (C % 4 == 0, C <= 1024); `res` may be NULL
