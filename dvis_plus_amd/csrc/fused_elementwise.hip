@@ -320,6 +320,71 @@ __global__ __launch_bounds__(256) void normalize_pad_kernel(const T *__restrict_
   }
 }
 
+// ---- ViT-Adapter stride-4 output (adapter.py:341-356: c1 = up(c2) + c1; c1 += interpolate(x1, 4); f1 = norm1(c1)) --------------
+// `up` is a 2 x 2 / stride-2 transposed convolution = a GEMM over the stride-8 tokens with 4 C output features (dy, dx, co); its
+// result g arrives TOKEN-major.  This kernel is the pixel shuffle back to NCHW with everything that follows folded in:
+//     out[b, co, 2y+dy, 2x+dx] = g[(b, y, x), (dy, dx, co)] + scale[co] * (c1[b, co, 2y+dy, 2x+dx] + up4(x1)[...]) + shift[co]
+// (eval BatchNorm scale folded into the GEMM's weights by the caller; shift = scale * up.bias + BN shift).  One pass over the
+// 7.2 GB (30 frames, 1024 channels, 184 x 320) instead of transposed-conv output + two adds + upsample + BN + a layout copy.
+// Tile: 32 tokens of one stride-8 row x 64 channels: g through LDS (read along co, written along x), the two x1 source rows the
+// tile's two output rows interpolate between (18 columns x 64 channels) staged the same way.
+__global__ __launch_bounds__(256) void adapter_res2_kernel(const float *__restrict__ g, const float *__restrict__ c1,
+                                                           const float *__restrict__ x1, const float *__restrict__ scale,
+                                                           const float *__restrict__ shift, float *__restrict__ out, int C, int h8,
+                                                           int w8) {
+  constexpr int TS = 65;                               // token stride in LDS (floats)
+  __shared__ float gs[4 * 32 * TS];                    // [sub][token][co]
+  __shared__ float xs[2 * 18 * TS];                    // [row][col][co]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tx = blockIdx.x * 32, co0 = blockIdx.y * 64;
+  const int b = blockIdx.z / h8, y = blockIdx.z - b * h8;
+  const int H4 = 2 * h8, W4 = 2 * w8, h16 = h8 / 2, w16 = w8 / 2;
+  const int ntok = min(32, w8 - tx);
+  // g: rows of 4 C floats per token; 64 lanes read one (token, sub)'s 64 channels
+  for (int r = wv; r < 128; r += 4) {
+    const int tok = r >> 2, sub = r & 3;
+    if (tok < ntok) gs[(sub * 32 + tok) * TS + lane] = g[(((size_t)b * h8 + y) * w8 + tx + tok) * (size_t)(4 * C) + (size_t)sub * C + co0 + lane];
+  }
+  // x1 source rows / columns of this tile (align_corners = False, factor 4: src = (dst + 0.5) / 4 - 0.5, clamped at 0)
+  const int ys0 = max((y >> 1) - ((y & 1) ? 0 : 1), 0), ys1 = min(((y >> 1) - ((y & 1) ? 0 : 1)) + 1, h16 - 1);
+  const int xc0 = (tx >> 1) - 1;                       // first staged column (may be -1: clamped on load)
+  if (x1 != nullptr) {
+    for (int r = wv; r < 36; r += 4) {
+      const int row = r / 18, col = r - row * 18;
+      const int ysrc = row ? ys1 : ys0, xsrc = min(max(xc0 + col, 0), w16 - 1);
+      xs[(row * 18 + col) * TS + lane] = x1[(((size_t)b * h16 + ysrc) * w16 + xsrc) * (size_t)C + co0 + lane];
+    }
+  }
+  __syncthreads();
+  const int X = 2 * tx + lane;                         // this lane's output column
+  const bool x_ok = lane < 2 * ntok;
+  float fx = ((float)X + 0.5f) * 0.25f - 0.5f;
+  fx = fx < 0.f ? 0.f : fx;
+  const int xi0 = min((int)fx, w16 - 1), xi1 = min(xi0 + 1, w16 - 1);
+  const float lx1 = fx - (float)xi0, lx0 = 1.f - lx1;
+  const int cA = xi0 - xc0, cB = xi1 - xc0;            // staged columns (0 .. 17)
+  for (int r = wv; r < 128; r += 4) {
+    const int c = r >> 1, dy = r & 1, co = co0 + c;
+    const int Y = 2 * y + dy;
+    float up = 0.f;
+    if (x1 != nullptr) {
+      float fy = ((float)Y + 0.5f) * 0.25f - 0.5f;
+      fy = fy < 0.f ? 0.f : fy;
+      const int yi0 = min((int)fy, h16 - 1);
+      const float ly1 = fy - (float)yi0, ly0 = 1.f - ly1;
+      const int rA = yi0 == ys0 ? 0 : 1, rB = (min(yi0 + 1, h16 - 1)) == ys0 ? 0 : 1;
+      // the order of F.interpolate's bilinear kernel: w00 * v00 + w01 * v01 + w10 * v10 + w11 * v11 with wij = ly_i * lx_j
+      up = ly0 * (lx0 * xs[(rA * 18 + cA) * TS + c] + lx1 * xs[(rA * 18 + cB) * TS + c]) +
+           ly1 * (lx0 * xs[(rB * 18 + cA) * TS + c] + lx1 * xs[(rB * 18 + cB) * TS + c]);
+    }
+    if (x_ok) {
+      const size_t o = (((size_t)b * C + co) * H4 + Y) * (size_t)W4 + X;
+      const float gv = gs[((dy * 2 + (lane & 1)) * 32 + (lane >> 1)) * TS + c];
+      out[o] = gv + scale[co] * (c1[o] + up) + shift[co];
+    }
+  }
+}
+
 }  // namespace
 
 DVIS_EXPORT int dvis_normalize_pad(const void *in, int is_u8, float *out, int64_t planes, int C, int H, int W, int Hp, int Wp,
@@ -456,6 +521,18 @@ static int upsample_add_launch(const float *lateral, const float *top, float *ou
     hipLaunchKernelGGL(upsample_add_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, lateral, top,
                        out, (int)planes, H, W, h, w, lat_scale, lat_shift);
   return dvis_check_launch("upsample_add_kernel");
+}
+
+DVIS_EXPORT int dvis_adapter_res2(const float *g, const float *c1, const float *x1, const float *scale, const float *shift, float *out,
+                                  int B, int C, int h8, int w8, void *stream) {
+  DVIS_REQUIRE(g && c1 && scale && shift && out, "adapter_res2: null pointer");
+  DVIS_REQUIRE(B >= 0 && C > 0 && C % 64 == 0 && h8 > 0 && w8 > 0 && h8 % 2 == 0 && w8 % 2 == 0,
+               "adapter_res2: C %% 64 == 0 and an even stride-8 grid are required (C %d, grid %d x %d)", C, h8, w8);
+  DVIS_REQUIRE((int64_t)B * h8 <= 65535 && C / 64 <= 65535, "adapter_res2: grid too large (B * rows %lld)", (long long)B * h8);
+  if (B == 0) return DVIS_OK;
+  hipLaunchKernelGGL(adapter_res2_kernel, dim3((w8 + 31) / 32, C / 64, B * h8), dim3(256), 0, (hipStream_t)stream, g, c1, x1, scale, shift,
+                     out, C, h8, w8);
+  return dvis_check_launch("adapter_res2_kernel");
 }
 
 DVIS_EXPORT int dvis_upsample_add(const float *lateral, const float *top, float *out, int64_t planes, int H, int W, int h,

@@ -541,6 +541,29 @@ def upsample_add(lateral, top, lat_affine=None):
     return out
 
 
+def adapter_res2(g, c1, x1_tokens, scale, shift, h8, w8):
+    """The ViT-Adapter's stride-4 output in one pass (dvis_adapter_res2, include/dvis_hip.h):
+    out[b, co, 2y+dy, 2x+dx] = g[(b, y, x), (dy, dx, co)] + scale[co] * (c1 + up4(x1))[b, co, 2y+dy, 2x+dx] + shift[co].
+    g (B*h8*w8, 4C) token-major result of the transposed convolution run as a GEMM, c1 (B, C, 2 h8, 2 w8) contiguous NCHW,
+    x1_tokens (B, h8/2 * w8/2, C) or None.  fp32 GPU tensors only (the caller keeps the torch composition for the rest)."""
+    B, C = c1.shape[0], c1.shape[1]
+    for t, name in ((g, "g"), (c1, "c1"), (scale, "scale"), (shift, "shift")) + (((x1_tokens, "x1"),) if x1_tokens is not None else ()):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError(f"adapter_res2: {name} must be a contiguous float32 GPU tensor")
+    if g.shape != (B * h8 * w8, 4 * C) or c1.shape != (B, C, 2 * h8, 2 * w8) or \
+            (x1_tokens is not None and x1_tokens.shape != (B, (h8 // 2) * (w8 // 2), C)):
+        raise RuntimeError(f"adapter_res2: shapes g {tuple(g.shape)}, c1 {tuple(c1.shape)}, x1 "
+                           f"{None if x1_tokens is None else tuple(x1_tokens.shape)} do not match a {h8} x {w8} stride-8 grid")
+    out = torch.empty_like(c1)
+    with torch.cuda.device(c1.device):
+        rc = native.lib().dvis_adapter_res2(native.dev_ptr(g, "g"), native.dev_ptr(c1, "c1"),
+                                            None if x1_tokens is None else native.dev_ptr(x1_tokens, "x1"),
+                                            native.dev_ptr(scale, "scale"), native.dev_ptr(shift, "shift"), native.dev_ptr(out, "out"),
+                                            B, C, h8, w8, native.stream_ptr(c1.device))
+    native.check(rc, "dvis_adapter_res2")
+    return out
+
+
 # Library GEMMs or the own deterministic kernel (dvis_gemm_nt)?  The tracker / refiner ALWAYS take the own kernel
 # (own=True at their call sites: their stream must never carry a library stream-K kernel, csrc/gemm.hip); everything
 # else follows this switch.  DVIS_DETERMINISTIC=1: every GEMM of the pipeline that goes through this module is the own

@@ -65,6 +65,7 @@ SIGNATURES = {
     "dvis_scale_shift_act": (_i, [_p, _p, _p, _i64, _i64, _i, _p]),
     "dvis_upsample_add_affine": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _p]),
     "dvis_upsample_add": (_i, [_p, _p, _p, _i64, _i, _i, _i, _i, _p]),
+    "dvis_adapter_res2": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "dvis_vps_argmax": (_i, [_p, _i64, _i64, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "dvis_vss_argmax": (_i, [_p, _i64, _i64, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "dvis_resize2_gt0": (_i, [_p, _i64, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),

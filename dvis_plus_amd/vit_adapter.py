@@ -15,6 +15,7 @@ projection that precedes it once per weight version (like FrozenBN in backbone.p
 identity, SyncBatchNorm is batch-norm with running statistics.
 """
 import math
+import os
 from functools import partial
 
 import torch
@@ -363,23 +364,56 @@ class DinoV2ViTAdapter(nn.Module):
         t, H, W = self.vit_module.prepare_tokens_with_masks(x, masks=None, return_HW=True)
         dim = t.shape[-1]
         cls, t = t[:, :1], t[:, 1:]
-        outs = []
+        outs, x1_tok = [], None
         for i, layer in enumerate(self.interactions):
             lo, hi = self.interaction_indexes[i]
             t, c, cls = layer(t, c, cls, self.vit_module.blocks[lo:hi + 1], d2, H, W)
-            outs.append(t.transpose(1, 2).reshape(bs, dim, H, W))
-        c2, c3, c4 = c[:, :n2], c[:, n2:n2 + n3], c[:, n2 + n3:]
-        c2 = c2.transpose(1, 2).reshape(bs, dim, H * 2, W * 2)
+            if i == 0:
+                x1_tok = t
+            outs.append(t.transpose(1, 2).reshape(bs, dim, H, W) if i > 0 or not self._res2_fused_ok(c1, t) else None)
+        c2_tok, c3, c4 = c[:, :n2], c[:, n2:n2 + n3], c[:, n2 + n3:]
+        c2 = c2_tok.transpose(1, 2).reshape(bs, dim, H * 2, W * 2)
         c3 = c3.transpose(1, 2).reshape(bs, dim, H, W)
         c4 = c4.transpose(1, 2).reshape(bs, dim, H // 2, W // 2)
-        c1 = self.up(c2) + c1
+        f1 = None
+        if outs[0] is None:
+            # stride-4 output in two launches: `up` as a GEMM over the stride-8 tokens (BatchNorm scale folded into its weights),
+            # then pixel shuffle + SPM feature + 4x-upsampled ViT feature + BatchNorm shift in one pass (Fn.adapter_res2)
+            w_l, scale, shift = self._res2_folded()
+            g = Fn.linear(c2_tok.reshape(bs * n2, dim), w_l, None, tall=True)
+            f1 = Fn.adapter_res2(g, c1, x1_tok if self.add_vit_feature else None, scale, shift, 2 * H, 2 * W)
+        else:
+            c1 = self.up(c2) + c1
         if self.add_vit_feature:
             x1, x2, x3, x4 = outs
-            c1 = c1 + F.interpolate(x1, scale_factor=4, mode="bilinear", align_corners=False)
+            if f1 is None:
+                c1 = c1 + F.interpolate(x1, scale_factor=4, mode="bilinear", align_corners=False)
             c2 = c2 + F.interpolate(x2, scale_factor=2, mode="bilinear", align_corners=False)
             c3 = c3 + x3
             c4 = c4 + F.interpolate(x4, scale_factor=0.5, mode="bilinear", align_corners=False)
-        return [self.norm1(c1), self.norm2(c2), self.norm3(c3), self.norm4(c4)]
+        return [self.norm1(c1) if f1 is None else f1, self.norm2(c2), self.norm3(c3), self.norm4(c4)]
+
+    def _res2_fused_ok(self, c1, t):
+        bn = self.norm1
+        return (c1.is_cuda and not torch.is_grad_enabled() and not torch.is_autocast_enabled() and c1.dtype == torch.float32
+                and t.dtype == torch.float32 and c1.is_contiguous() and c1.shape[1] % 64 == 0 and c1.shape[2] % 4 == 0
+                and c1.shape[3] % 4 == 0 and c1.shape[0] * (c1.shape[2] // 2) <= 65535 and isinstance(bn, nn.BatchNorm2d)
+                and bn.track_running_stats and bn.running_mean is not None and os.environ.get("DVIS_ADAPTER_RES2", "1") != "0")
+
+    def _res2_folded(self):
+        """(W_l, scale, shift): ConvTranspose2d(C, C, 2, 2) as a linear layer over the stride-8 tokens, rows ordered (dy, dx, co),
+        with norm1's eval affine folded in: W_l[(dy, dx, co), ci] = s[co] * up.weight[ci, co, dy, dx]; shift = s * up.bias + beta -
+        mean * s.  Cached per parameter version."""
+        up, bn = self.up, self.norm1
+        key = tuple(p._version for p in (up.weight, up.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)) + (up.weight.device,)
+        if getattr(self, "_res2_cache", None) is None or self._res2_cache[0] != key:
+            with torch.no_grad():
+                s = (bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps))
+                sh = s * up.bias.double() + bn.bias.double() - bn.running_mean.double() * s
+                C = up.weight.shape[1]
+                w_l = (up.weight.double() * s.view(1, C, 1, 1)).permute(2, 3, 1, 0).reshape(4 * C, up.weight.shape[0])
+                self._res2_cache = (key, w_l.float().contiguous(), s.float().contiguous(), sh.float().contiguous())
+        return self._res2_cache[1:]
 
 
 def get_adapter_args(name="vitl"):

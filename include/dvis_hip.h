@@ -361,6 +361,19 @@ int dvis_upsample_add_affine(const float *lateral, const float *lat_scale, const
                              float *out, int64_t planes, int H, int W, int h, int w, void *stream);
 
 /*
+ * The stride-4 output of the ViT-Adapter backbone (mask2former/modeling/backbones_vitAdapter/adapter.py, forward:
+ * `c1 = self.up(c2) + c1; c1 = c1 + F.interpolate(x1, scale_factor=4, mode="bilinear", align_corners=False); f1 = self.norm1(c1)`).
+ * `up` = ConvTranspose2d(C, C, 2, 2) is a GEMM over the stride-8 tokens with 4 C output features ordered (dy, dx, co); the caller
+ * runs it with the eval-BatchNorm scale folded into the weights and hands the TOKEN-major result in:
+ *   out[b, co, 2y+dy, 2x+dx] = g[(b, y, x), (dy, dx, co)] + scale[co] * (c1[b, co, 2y+dy, 2x+dx] + up4(x1)[b, co, 2y+dy, 2x+dx]) + shift[co]
+ *   g (B * h8 * w8, 4 C); c1 / out (B, C, 2 h8, 2 w8) NCHW; x1 (B, (h8 / 2) * (w8 / 2), C) tokens of the stride-16 ViT grid or NULL;
+ *   shift = scale * up.bias + (BN beta - mean * scale).  C % 64 == 0, h8 and w8 even, B * h8 <= 65535.
+ * One pass over the output (7.2 GB at 30 frames x 1024 channels x 184 x 320) instead of six.
+ */
+int dvis_adapter_res2(const float *g, const float *c1, const float *x1, const float *scale, const float *shift, float *out, int B, int C,
+                      int h8, int w8, void *stream);
+
+/*
  * Panoptic arg-max of a clip in one pass (inference_video_vps, dvis_Plus/meta_architecture.py:890-925):
  *   prob_k = resize2(sigmoid(resize1(logits_k)[:img_h, :img_w])), both resizes bilinear align_corners=False
  *   (stride-4 map (h,w) -> padded input (first_h, first_w) -> crop (img_h, img_w) -> output (out_h, out_w));

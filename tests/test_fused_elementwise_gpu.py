@@ -227,3 +227,39 @@ def test_preprocess_of_the_meta_architecture_takes_the_fused_pass(monkeypatch):
         x, size = m.preprocess(frames)
     ref = F.pad((torch.stack(frames).to(DEV).float() - m.pixel_mean) / m.pixel_std, (0, 96 - 70, 0, 64 - 50))
     assert calls and size == (50, 70) and torch.equal(x, ref)
+
+
+@pytest.mark.parametrize("B,C,h8,w8,with_x1", [(2, 64, 6, 10, True), (1, 128, 4, 34, True), (3, 64, 2, 2, True), (2, 64, 8, 66, False)])
+def test_adapter_res2_equals_transposed_conv_add_upsample_batchnorm(B, C, h8, w8, with_x1):
+    """dvis_adapter_res2 + the transposed convolution as a GEMM (vit_adapter._res2_folded) against the reference's composition
+    (adapter.py forward: c1 = up(c2) + c1; c1 += interpolate(x1, 4); norm1(c1)) in fp64."""
+    import torch.nn.functional as F
+    from dvis_plus_amd import functions as Fn
+    g = torch.Generator().manual_seed(B * 1000 + C + h8 + w8)
+    up = torch.nn.ConvTranspose2d(C, C, 2, 2)
+    bn = torch.nn.BatchNorm2d(C).eval()
+    with torch.no_grad():
+        up.weight.copy_(torch.randn(C, C, 2, 2, generator=g) * 0.1)
+        up.bias.copy_(torch.randn(C, generator=g))
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g))
+        bn.running_mean.copy_(torch.randn(C, generator=g))
+        bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    c2_tok = torch.randn(B, h8 * w8, C, generator=g)
+    c1 = torch.randn(B, C, 2 * h8, 2 * w8, generator=g)
+    x1_tok = torch.randn(B, (h8 // 2) * (w8 // 2), C, generator=g)
+    with torch.no_grad():
+        upd, bnd = up.double(), bn.double()
+        ref = upd(c2_tok.double().transpose(1, 2).reshape(B, C, h8, w8)) + c1.double()
+        if with_x1:
+            ref = ref + F.interpolate(x1_tok.double().transpose(1, 2).reshape(B, C, h8 // 2, w8 // 2), scale_factor=4, mode="bilinear",
+                                      align_corners=False)
+        ref = bnd(ref)
+        up, bn = up.float(), bn.float()
+        s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        shift = s * up.bias + bn.bias - bn.running_mean * s
+        w_l = (up.weight * s.view(1, C, 1, 1)).permute(2, 3, 1, 0).reshape(4 * C, C).contiguous()
+        gm = (c2_tok.reshape(-1, C).double() @ w_l.double().t()).float()
+        out = Fn.adapter_res2(gm.to(DEV), c1.to(DEV), x1_tok.to(DEV) if with_x1 else None, s.to(DEV), shift.to(DEV), h8, w8)
+    err = float((out.double().cpu() - ref).abs().max())
+    assert err <= 2e-5 * max(1.0, float(ref.abs().max())), err
