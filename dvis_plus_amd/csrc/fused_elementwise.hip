@@ -385,6 +385,61 @@ __global__ __launch_bounds__(256) void adapter_res2_kernel(const float *__restri
   }
 }
 
+// ---- depthwise 3 x 3 convolution (+ bias, + GELU) on TOKEN-major maps: the ConvFFN of the ViT-Adapter extractors
+// (adapter_modules.py DWConv: three pyramid levels stored one after the other in a (B, N, C) token tensor; the reference
+// transposes each level to NCHW, runs a grouped Conv2d, transposes back and concatenates).  Channels are the contiguous axis here,
+// so a lane keeps 4 channels' 9 taps in registers and walks 4 neighbouring tokens of a row: 18 loads of 16 bytes per 4 outputs.
+__global__ __launch_bounds__(256) void dwconv3x3_tokens_kernel(const float *__restrict__ x, float *__restrict__ out, int64_t batch_stride,
+                                                               int B, int h, int w, int C, const float *__restrict__ wt,
+                                                               const float *__restrict__ bias, int gelu) {
+  const int c4 = (blockIdx.y * 64 + (threadIdx.x & 63)) * 4;
+  if (c4 >= C) return;
+  const int wq = (w + 3) / 4;
+  const int64_t strip = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);       // (b, y, x-quad)
+  const int xq = (int)(strip % wq);
+  const int64_t r = strip / wq;
+  const int y = (int)(r % h);
+  const int64_t b = r / h;
+  if (b >= B) return;
+  float4 k[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) k[t] = float4{wt[(c4 + 0) * 9 + t], wt[(c4 + 1) * 9 + t], wt[(c4 + 2) * 9 + t], wt[(c4 + 3) * 9 + t]};
+  const float4 bv = bias ? *reinterpret_cast<const float4 *>(bias + c4) : float4{0.f, 0.f, 0.f, 0.f};
+  const float *xb = x + b * batch_stride + c4;
+  float4 acc[4] = {bv, bv, bv, bv};
+  const int x0 = 4 * xq;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int yy = y + dy - 1;
+    if (yy < 0 || yy >= h) continue;
+    float4 col[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int xx = x0 + i - 1;
+      col[i] = xx >= 0 && xx < w ? *reinterpret_cast<const float4 *>(xb + ((int64_t)yy * w + xx) * C) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const float4 kk = k[dy * 3 + dx], v = col[o + dx];
+        acc[o].x = __builtin_fmaf(kk.x, v.x, acc[o].x), acc[o].y = __builtin_fmaf(kk.y, v.y, acc[o].y);
+        acc[o].z = __builtin_fmaf(kk.z, v.z, acc[o].z), acc[o].w = __builtin_fmaf(kk.w, v.w, acc[o].w);
+      }
+  }
+  float *ob = out + b * batch_stride + c4;
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    if (x0 + o >= w) break;
+    float4 v = acc[o];
+    if (gelu) {
+      v.x = 0.5f * v.x * (1.f + erff(v.x * 0.70710678118654752440f)), v.y = 0.5f * v.y * (1.f + erff(v.y * 0.70710678118654752440f));
+      v.z = 0.5f * v.z * (1.f + erff(v.z * 0.70710678118654752440f)), v.w = 0.5f * v.w * (1.f + erff(v.w * 0.70710678118654752440f));
+    }
+    *reinterpret_cast<float4 *>(ob + ((int64_t)y * w + x0 + o) * C) = v;
+  }
+}
+
 }  // namespace
 
 DVIS_EXPORT int dvis_normalize_pad(const void *in, int is_u8, float *out, int64_t planes, int C, int H, int W, int Hp, int Wp,
@@ -521,6 +576,21 @@ static int upsample_add_launch(const float *lateral, const float *top, float *ou
     hipLaunchKernelGGL(upsample_add_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, lateral, top,
                        out, (int)planes, H, W, h, w, lat_scale, lat_shift);
   return dvis_check_launch("upsample_add_kernel");
+}
+
+DVIS_EXPORT int dvis_dwconv3x3_tokens(const float *x, float *out, int64_t batch_stride, int B, int h, int w, int C, const float *weight,
+                                      const float *bias, int gelu, void *stream) {
+  DVIS_REQUIRE(x && out && weight, "dwconv3x3_tokens: null pointer");
+  DVIS_REQUIRE(B >= 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0 && batch_stride % 4 == 0 && batch_stride >= (int64_t)h * w * C,
+               "dwconv3x3_tokens: C %% 4 == 0 and a batch stride that is a multiple of 4 floats >= h * w * C are required");
+  DVIS_REQUIRE(((uintptr_t)x | (uintptr_t)out | (uintptr_t)(bias ? bias : weight)) % 16 == 0, "dwconv3x3_tokens: 16-byte alignment");
+  DVIS_REQUIRE(x != out, "dwconv3x3_tokens: in place is not possible (neighbouring tokens are read)");
+  if (B == 0) return DVIS_OK;
+  const int64_t strips = (int64_t)h * ((w + 3) / 4);
+  DVIS_REQUIRE(strips * B < ((int64_t)1 << 32), "dwconv3x3_tokens: too many tokens");
+  hipLaunchKernelGGL(dwconv3x3_tokens_kernel, dim3((unsigned)((strips * B + 3) / 4), (C / 4 + 63) / 64), dim3(256), 0, (hipStream_t)stream, x,
+                     out, batch_stride, B, h, w, C, weight, bias, gelu);
+  return dvis_check_launch("dwconv3x3_tokens_kernel");
 }
 
 DVIS_EXPORT int dvis_adapter_res2(const float *g, const float *c1, const float *x1, const float *scale, const float *shift, float *out,

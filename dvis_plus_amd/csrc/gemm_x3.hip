@@ -58,7 +58,9 @@ __device__ __forceinline__ void load_x(const float *x, int64_t ldx, int64_t row,
 // Row-contiguous stores of one 32-feature block: the lane-per-token accumulator quads go through the wave's 4 KB of LDS
 // (rows of 128 B, 16-byte slots XOR-swizzled with (row >> 1) & 7: conflict-free both ways) and leave as 8 lanes x 16 B per
 // token row — 8 lines per store instruction instead of 32.
-__device__ __forceinline__ void store_block(char *scr, int lane, const f4 *v, float *dst, int64_t ld, int rows_valid) {
+// `radd` (NULL or the same block of a residual tensor, row stride ldr) is added on the way out, in the row-contiguous shape.
+__device__ __forceinline__ void store_block(char *scr, int lane, const f4 *v, float *dst, int64_t ld, int rows_valid,
+                                            const float *radd = nullptr, int64_t ldr = 0) {
   const int j = lane & 31, g = lane >> 5, sw = (j >> 1) & 7;
 #pragma unroll
   for (int q = 0; q < 4; ++q) *(f4 *)(scr + j * 128 + (((2 * q + g) ^ sw) << 4)) = v[q];
@@ -66,7 +68,8 @@ __device__ __forceinline__ void store_block(char *scr, int lane, const f4 *v, fl
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int jr = 8 * t + (lane >> 3), pp = lane & 7;
-    const f4 o = *(const f4 *)(scr + jr * 128 + ((pp ^ ((jr >> 1) & 7)) << 4));
+    f4 o = *(const f4 *)(scr + jr * 128 + ((pp ^ ((jr >> 1) & 7)) << 4));
+    if (radd != nullptr && jr < rows_valid) o += *(const f4 *)(radd + jr * ldr + 4 * pp);
     if (jr < rows_valid) *(f4 *)(dst + jr * ld + 4 * pp) = o;
   }
   __builtin_amdgcn_wave_barrier();
@@ -83,7 +86,8 @@ struct EpiArgs {
   float *out, *out2;
   int64_t ldo;
   float inv;                         // 2^-(xexp + wexp)
-  int relu;
+  int relu;                          // plain form: 0 none, 1 ReLU, 2 GELU (exact: 0.5 t (1 + erf(t / sqrt 2)), nn.GELU())
+  const float *radd;                 // plain form: NULL or M x N residual (row stride ldres) added AFTER the activation
   int *flag;                         // range guard (x3_common.h): NULL or the device word that receives `tag` on a non-finite row
   int tag;
 };
@@ -93,7 +97,9 @@ struct EpiArgs {
 // cb / cg / cbeta: bias (of this pass) / gamma / beta in LDS (staged once per workgroup): at 512 registers per lane hipcc
 // serialises global loads in an epilogue (one in flight, 32 round trips in a row); the residual rows and the position rows
 // are requested as ONE batch each, into the registers the activation fragments no longer need.
-template <int NB, bool LN>
+// EX: the plain form with the GELU / residual options (e.relu == 2, e.radd) — its own instantiation: the erf polynomial next to
+// 128 live accumulator values costs the ReLU kernels registers (23 spilled at NB = 8).
+template <int NB, bool LN, bool EX = false>
 __device__ __forceinline__ void epilogue(f16v *acc, const EpiArgs &e, const float *cb, const float *cg, const float *cbeta, char *scr,
                                          int lane, int64_t tok0, int64_t M, int col0 = 0) {
   const int j = lane & 31, g = lane >> 5;
@@ -173,11 +179,18 @@ __device__ __forceinline__ void epilogue(f16v *acc, const EpiArgs &e, const floa
         for (int i = 0; i < 4; ++i) {
           const float t = acc[nb][4 * q + i] * e.inv + b[i];
           chk = __builtin_fmaf(t, 0.f, chk);
-          v[q][i] = e.relu ? fmaxf(t, 0.f) : t;
+          if constexpr (EX)
+            v[q][i] = e.relu == 1 ? fmaxf(t, 0.f) : e.relu == 2 ? 0.5f * t * (1.f + erff(t * 0.70710678118654752440f)) : t;
+          else
+            v[q][i] = e.relu ? fmaxf(t, 0.f) : t;
         }
       }
     }
-    store_block(scr, lane, v, e.out + tok0 * e.ldo + col0 + 32 * nb, e.ldo, rows_valid);
+    if constexpr (!EX)
+      store_block(scr, lane, v, e.out + tok0 * e.ldo + col0 + 32 * nb, e.ldo, rows_valid);
+    else
+      store_block(scr, lane, v, e.out + tok0 * e.ldo + col0 + 32 * nb, e.ldo, rows_valid,
+                  e.radd ? e.radd + tok0 * e.ldres + col0 + 32 * nb : nullptr, e.ldres);
     if constexpr (LN) {
       if (e.pos != nullptr) {
 #pragma unroll
@@ -240,7 +253,7 @@ __global__ __launch_bounds__(kThreads) void x3_linear_kernel(const float *__rest
 // LDS-DMA issue and epilogue are covered by its partner's products) x 32 tokens; the 64 k-values of the chunk after the one
 // being multiplied are in flight (8 x 16 bytes per lane; the ring's counted wait leaves them out), so neither operand waits
 // behind the other and K is any multiple of 64.  Passes of 32 NB output features re-read the tile's rows from L2.
-template <int NB, bool LN>
+template <int NB, bool LN, bool EX = false>
 __global__ __launch_bounds__(512) void x3_linear_stream_kernel(const float *__restrict__ x, int64_t ldx, int64_t M, int K,
                                                                const void *__restrict__ wp, float xscale, int npass, EpiArgs e) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -300,7 +313,7 @@ __global__ __launch_bounds__(512) void x3_linear_stream_kernel(const float *__re
           mma_item<2, NB, PW>(stage, lane, acc, xh + 2 * half, xl + 2 * half, [&](int i) { ring.piece(i); });
         }
       }
-      if (tok0 < M) epilogue<NB, LN>(acc, e, cst + pass * 32 * NB, cst + ntot, cst + ntot + 32 * NB, scr, lane, tok0, M, pass * 32 * NB);
+      if (tok0 < M) epilogue<NB, LN, EX>(acc, e, cst + pass * 32 * NB, cst + ntot, cst + ntot + 32 * NB, scr, lane, tok0, M, pass * 32 * NB);
     }
     rowp = nrowp;
   }
@@ -524,7 +537,8 @@ DVIS_EXPORT int dvis_x3_pack(const float *w, int64_t ldw, int N, int K, int wexp
 }
 
 static int x3_linear_impl(const float *x, int64_t ldx, int64_t M, int K, const void *wp, int N, int xexp, int wexp, const float *xadd,
-                          int64_t xadd_rows, const float *bias, int relu, float *out, int64_t ldo, void *stream);
+                          int64_t xadd_rows, const float *bias, int relu, float *out, int64_t ldo, void *stream,
+                          const float *radd = nullptr, int64_t ldr = 0);
 
 DVIS_EXPORT int dvis_x3_linear(const float *x, int64_t ldx, int64_t M, int K, const void *wp, int N, int xexp, int wexp,
                                const float *bias, int relu, float *out, int64_t ldo, void *stream) {
@@ -539,37 +553,52 @@ DVIS_EXPORT int dvis_x3_linear_add(const float *x, int64_t ldx, int64_t M, int K
   return x3_linear_impl(x, ldx, M, K, wp, N, xexp, wexp, xadd, xadd_rows, bias, relu, out, ldo, stream);
 }
 
+DVIS_EXPORT int dvis_x3_linear_res(const float *x, int64_t ldx, int64_t M, int K, const void *wp, int N, int xexp, int wexp,
+                                   const float *bias, int act, const float *res, int64_t ldres, float *out, int64_t ldo, void *stream) {
+  DVIS_REQUIRE(act >= 0 && act <= 2, "dvis_x3_linear_res: act must be 0 (none), 1 (ReLU) or 2 (GELU)");
+  DVIS_REQUIRE(res == nullptr || ((uintptr_t)res % 16 == 0 && ldres % 4 == 0 && ldres >= N),
+               "dvis_x3_linear_res: res must be 16-byte aligned with a row stride that is a multiple of 4 floats and >= N");
+  return x3_linear_impl(x, ldx, M, K, wp, N, xexp, wexp, nullptr, 0, bias, act, out, ldo, stream, res, ldres);
+}
+
 static int x3_linear_impl(const float *x, int64_t ldx, int64_t M, int K, const void *wp, int N, int xexp, int wexp, const float *xadd,
-                          int64_t xadd_rows, const float *bias, int relu, float *out, int64_t ldo, void *stream) {
+                          int64_t xadd_rows, const float *bias, int relu, float *out, int64_t ldo, void *stream, const float *radd,
+                          int64_t ldr) {
   DVIS_REQUIRE(dvis_x3_linear_supported(N, K, 0), "dvis_x3_linear: (N, K) = (%d, %d) is not served (K %% 64 == 0; N in 128 / 192 / 256 or N %% 256 == 0; N = 288 at K = 256)", N, K);
   const int rc = x3_check_common(x, ldx, M, wp, out, ldo);
   if (rc != DVIS_OK) return rc;
   if (M == 0) return DVIS_OK;
   EpiArgs e = {};
   e.bias = bias, e.out = out, e.ldo = ldo, e.inv = x3_pow2(-(xexp + wexp)), e.relu = relu;
+  e.radd = radd, e.ldres = ldr;
   const X3Guard gd = dvis_x3_guard();
   e.flag = gd.flag, e.tag = gd.tag;
   const float xs = x3_pow2(xexp);
   hipStream_t st = (hipStream_t)stream;
   int NB;
   const int npass = x3_passes(N, &NB);
-#define DVIS_X3_STREAM(NBV, LNV, WHAT, LDS_EXTRA)                                                                   \
+#define DVIS_X3_STREAM_EX(NBV, LNV, EXV, WHAT, LDS_EXTRA)                                                            \
   {                                                                                                                  \
     static DvisLdsOptIn opted;                                                                                       \
     typedef Ring<4 * NBV / 8, 8, 8> R;                                                                               \
     const size_t lds_bytes = kStages * R::kItemBytes + 8 * kScratch + (LDS_EXTRA);                                   \
-    const int rc2 = dvis_lds_opt_in((const void *)x3_linear_stream_kernel<NBV, LNV>, lds_bytes, &opted, WHAT);       \
+    const int rc2 = dvis_lds_opt_in((const void *)x3_linear_stream_kernel<NBV, LNV, EXV>, lds_bytes, &opted, WHAT);  \
     if (rc2 != DVIS_OK) return rc2;                                                                                  \
     const int64_t ntiles = (M + 255) / 256;                                                                          \
-    hipLaunchKernelGGL((x3_linear_stream_kernel<NBV, LNV>), dim3(x3_grid(ntiles)), dim3(512), lds_bytes, st, x, ldx, M, K, wp, xs, \
-                       npass, e);                                                                                    \
+    hipLaunchKernelGGL((x3_linear_stream_kernel<NBV, LNV, EXV>), dim3(x3_grid(ntiles)), dim3(512), lds_bytes, st, x, ldx, M, K, wp, \
+                       xs, npass, e);                                                                                \
     return dvis_check_launch(WHAT);                                                                                  \
   }
+#define DVIS_X3_STREAM(NBV, LNV, WHAT, LDS_EXTRA) DVIS_X3_STREAM_EX(NBV, LNV, false, WHAT, LDS_EXTRA)
 #define DVIS_X3_RESIDENT(NBV)                                                                                        \
   {                                                                                                                  \
     static DvisLdsOptIn opted;                                                                                       \
     return x3_launch(x3_linear_kernel<256, NBV, false>, &opted, kStages * Ring<NBV>::kItemBytes + kWaves * kScratch + (size_t)N * 4, \
                      M, st, "dvis_x3_linear", x, ldx, M, wp, xs, npass, xadd, xadd_rows, e);                         \
+  }
+  if (relu == 2 || radd) {      // GELU / residual epilogue: the ViT blocks' shapes (N a multiple of 256)
+    DVIS_REQUIRE(NB == 8 && !xadd, "dvis_x3_linear_res: the GELU / residual epilogue is served for N %% 256 == 0 (N = %d)", N);
+    DVIS_X3_STREAM_EX(8, false, true, "dvis_x3_linear_res", (size_t)N * 4)
   }
   if (xadd) {      // the resident-fragment kernel adds the embedding while it builds the row's fragments (K = 256)
     switch (NB) {
@@ -610,6 +639,7 @@ DVIS_EXPORT int dvis_x3_linear_ln(const float *x, int64_t ldx, int64_t M, int K,
   hipStream_t st = (hipStream_t)stream;
   DVIS_X3_STREAM(8, true, "dvis_x3_linear_ln", (size_t)3 * 256 * 4)
 #undef DVIS_X3_STREAM
+#undef DVIS_X3_STREAM_EX
 }
 
 DVIS_EXPORT int64_t dvis_x3_ffn_packed_bytes(int K, int H, int N) {

@@ -541,6 +541,29 @@ def upsample_add(lateral, top, lat_affine=None):
     return out
 
 
+def dwconv3x3_tokens(x, level_shapes, weight, bias, gelu=False):
+    """Depthwise 3x3 convolution (+ bias, + exact GELU) of every pyramid level of a token tensor x (B, N, C) whose levels
+    `level_shapes` = [(h, w), ...] are stored one after the other along N (dvis_dwconv3x3_tokens, one launch per level).
+    weight (C, 1, 3, 3).  fp32 contiguous GPU tensors."""
+    B, N, C = x.shape
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and weight.dtype == torch.float32 and C % 4 == 0
+            and sum(h * w for h, w in level_shapes) == N and weight.shape == (C, 1, 3, 3)):
+        raise RuntimeError(f"dwconv3x3_tokens: needs a contiguous float32 GPU (B, N, C) tensor, C % 4 == 0, levels summing to N "
+                           f"(x {tuple(x.shape)}, levels {list(level_shapes)})")
+    out = torch.empty_like(x)
+    wt = weight.detach().reshape(C, 9).contiguous()
+    bptr = None if bias is None else native.dev_ptr(bias.detach().contiguous(), "bias")
+    off = 0
+    with torch.cuda.device(x.device):
+        for h, w in level_shapes:
+            rc = native.lib().dvis_dwconv3x3_tokens(ctypes.c_void_p(x.data_ptr() + 4 * off * C), ctypes.c_void_p(out.data_ptr() + 4 * off * C),
+                                                    N * C, B, h, w, C, native.dev_ptr(wt, "weight"), bptr, int(gelu),
+                                                    native.stream_ptr(x.device))
+            native.check(rc, "dvis_dwconv3x3_tokens")
+            off += h * w
+    return out
+
+
 def adapter_res2(g, c1, x1_tokens, scale, shift, h8, w8):
     """The ViT-Adapter's stride-4 output in one pass (dvis_adapter_res2, include/dvis_hip.h):
     out[b, co, 2y+dy, 2x+dx] = g[(b, y, x), (dy, dx, co)] + scale[co] * (c1 + up4(x1))[b, co, 2y+dy, 2x+dx] + shift[co].
@@ -759,7 +782,7 @@ def _own_gemm_ok(x, weight):
             and weight.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
 
 
-def linear(x, weight, bias=None, relu=False, own=None, tall=False):
+def linear(x, weight, bias=None, relu=False, own=None, tall=False, act=None, residual=None):
     """``F.linear`` (+ optional ReLU) on fp32 GPU inference tensors WITHOUT a library GEMM, in a form whose result for a row does
     not depend on how many rows share the call (the segmenter folds frames into the batch; a frame must get the same bits alone,
     in a 30-frame clip or in a rank's shard of it):
@@ -776,7 +799,17 @@ def linear(x, weight, bias=None, relu=False, own=None, tall=False):
     if tall and not forced and gpu_inf and x3_on() and weight.dim() == 2 and weight._base is None \
             and x3_ok(x, weight.shape[0], weight.shape[1]):
         # Weights that are views (slices made per call) would be re-packed per call: they stay on the exact kernels below.
-        return x3_linear(x, weight, bias, relu=relu)
+        if (act is not None or residual is not None) and weight.shape[0] % 256 == 0:
+            return x3_linear(x, weight, bias, relu=relu, act=act, residual=residual)
+        if act is None and residual is None:
+            return x3_linear(x, weight, bias, relu=relu)
+    if act is not None or residual is not None:
+        # act ("gelu": the exact erf form of nn.GELU()) / residual (added after it): fused into the split-f16 kernel's epilogue
+        # above; everywhere else the same composition in separate passes
+        y = linear(x, weight, bias, relu=relu or act == "relu", own=own, tall=tall)
+        if act == "gelu":
+            y = torch.nn.functional.gelu(y)
+        return y if residual is None else y.add_(residual) if not torch.is_grad_enabled() else y + residual
     own = OWN_GEMM_DEFAULT if own is None else own
     if own and x.is_cuda and not torch.is_grad_enabled() and (forced or not torch.is_autocast_enabled()):
         # (under torch.autocast — how the reference evaluates, train_net_video.py:259 — the projections are torch's half-precision
@@ -1045,14 +1078,31 @@ def _x3_rows(x, name):
     return x2, ld
 
 
-def x3_linear(x, weight, bias, relu=False, xexp=None, xadd=None):
-    """``relu?((x + xadd) @ weight.T + bias)`` through dvis_x3_linear[_add].  x (..., K) float32 GPU; weight (N, K); xadd: None or
+def x3_linear(x, weight, bias, relu=False, xexp=None, xadd=None, act=None, residual=None):
+    """``relu?((x + xadd) @ weight.T + bias)`` through dvis_x3_linear[_add]; with act ("gelu" | "relu" | None) / residual:
+    ``act(x @ weight.T + bias) + residual`` through dvis_x3_linear_res (GELU and the residual add inside the GEMM's epilogue).  x (..., K) float32 GPU; weight (N, K); xadd: None or
     a (1, S, 256) / (S, 256) embedding for x of shape (B, S, 256), broadcast over B — added inside the kernel while it builds the
     row's fragments, the sum is never written (K = 256, any N the kernels serve: all passes over N run from one read of the row)."""
     N, K = weight.shape
     x2, ldx = _x3_rows(x, "x")
     buf, wexp = x3_pack(weight)
     out = torch.empty((*x.shape[:-1], N), dtype=torch.float32, device=x.device)
+    if act is not None or residual is not None:
+        if xadd is not None:
+            raise RuntimeError("x3_linear: xadd and act / residual are served by different entry points")
+        code = {None: int(bool(relu)), "relu": 1, "gelu": 2}[act]
+        rptr, ldr = None, 0
+        if residual is not None:
+            if residual.shape != out.shape or residual.dtype != torch.float32 or not residual.is_cuda:
+                raise RuntimeError("x3_linear: residual must be a float32 GPU tensor of the output's shape")
+            r2, ldr = _x3_rows(residual, "residual")
+            rptr = ctypes.c_void_p(r2.data_ptr())
+        with torch.cuda.device(x.device):
+            native.check(native.lib().dvis_x3_linear_res(
+                ctypes.c_void_p(x2.data_ptr()), ldx, x2.shape[0], K, ctypes.c_void_p(buf.data_ptr()), N,
+                X3_XEXP if xexp is None else xexp, wexp, None if bias is None else native.dev_ptr(bias.detach(), "bias"), code,
+                rptr, ldr, ctypes.c_void_p(out.data_ptr()), N, native.stream_ptr(x.device)), "dvis_x3_linear_res")
+        return out
     if xadd is not None:
         if x.dim() != 3 or xadd.numel() != x.shape[1] * K or xadd.dtype != torch.float32 or not xadd.is_cuda:
             raise RuntimeError("x3_linear: xadd must be a float32 GPU (S, K) embedding for x of shape (B, S, K)")

@@ -65,6 +65,7 @@ SIGNATURES = {
     "dvis_scale_shift_act": (_i, [_p, _p, _p, _i64, _i64, _i, _p]),
     "dvis_upsample_add_affine": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _p]),
     "dvis_upsample_add": (_i, [_p, _p, _p, _i64, _i, _i, _i, _i, _p]),
+    "dvis_dwconv3x3_tokens": (_i, [_p, _p, _i64, _i, _i, _i, _i, _p, _p, _i, _p]),
     "dvis_adapter_res2": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "dvis_vps_argmax": (_i, [_p, _i64, _i64, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "dvis_vss_argmax": (_i, [_p, _i64, _i64, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
@@ -89,6 +90,7 @@ SIGNATURES = {
     "dvis_x3_pack": (_i, [_p, _i64, _i, _i, _i, _p, _p]),
     "dvis_x3_linear_supported": (_i, [_i, _i, _i]),
     "dvis_x3_linear": (_i, [_p, _i64, _i64, _i, _p, _i, _i, _i, _p, _i, _p, _i64, _p]),
+    "dvis_x3_linear_res": (_i, [_p, _i64, _i64, _i, _p, _i, _i, _i, _p, _i, _p, _i64, _p, _i64, _p]),
     "dvis_x3_linear_add": (_i, [_p, _i64, _i64, _i, _p, _i, _i, _i, _p, _i64, _p, _i, _p, _i64, _p]),
     "dvis_x3_linear_ln": (_i, [_p, _i64, _i64, _i, _p, _i, _i, _i, _p, _p, _i64, _p, _p, _f, _p, _i64, _p, _p, _i64, _p]),
     "dvis_x3_ffn_packed_bytes": (_i64, [_i, _i, _i]),

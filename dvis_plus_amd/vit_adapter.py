@@ -101,7 +101,7 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features, bias=bias)
 
     def hidden(self, x):
-        return F.gelu(Fn.linear(x, self.fc1.weight, self.fc1.bias, tall=True))               # exact (erf) GELU as nn.GELU()
+        return Fn.linear(x, self.fc1.weight, self.fc1.bias, tall=True, act="gelu")            # exact (erf) GELU as nn.GELU()
 
     def forward(self, x):
         return Fn.linear(self.hidden(x), self.fc2.weight, self.fc2.bias, tall=True)
@@ -122,9 +122,9 @@ class Block(nn.Module):
 
     def forward(self, x):
         w, b = self._f1.get(self.attn.proj, self.ls1)
-        x = x + Fn.linear(self.attn.core(Fn.add_layer_norm(x, None, self.norm1)), w, b, tall=True)
+        x = Fn.linear(self.attn.core(Fn.add_layer_norm(x, None, self.norm1)), w, b, tall=True, residual=x)
         w, b = self._f2.get(self.mlp.fc2, self.ls2)
-        return x + Fn.linear(self.mlp.hidden(Fn.add_layer_norm(x, None, self.norm2)), w, b, tall=True)
+        return Fn.linear(self.mlp.hidden(Fn.add_layer_norm(x, None, self.norm2)), w, b, tall=True, residual=x)
 
 
 class DinoVisionTransformer(nn.Module):
@@ -211,6 +211,14 @@ class DWConv(nn.Module):
         super().__init__()
         self.dwconv = nn.Conv2d(dim, dim, 3, 1, 1, bias=True, groups=dim)
 
+    def levels(self, N, H, W):
+        return [(H * 2, W * 2), (H, W), (H // 2, W // 2)]
+
+    def fused_ok(self, x, H, W):
+        return (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and not torch.is_autocast_enabled()
+                and x.is_contiguous() and x.shape[2] % 4 == 0 and H % 2 == 0 and W % 2 == 0 and x.shape[1] == 21 * (H // 2) * (W // 2)
+                and os.environ.get("DVIS_DWCONV_TOKENS", "1") != "0")
+
     def forward(self, x, H, W):
         B, N, C = x.shape
         n = N // 21
@@ -228,10 +236,14 @@ class ConvFFN(nn.Module):
         self.dwconv = DWConv(hidden_features or in_features)
         self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
 
-    def forward(self, x, H, W):
+    def forward(self, x, H, W, residual=None):
         x = Fn.linear(x, self.fc1.weight, self.fc1.bias, tall=True)
-        x = F.gelu(self.dwconv(x, H, W))
-        return Fn.linear(x, self.fc2.weight, self.fc2.bias, tall=True)
+        if self.dwconv.fused_ok(x, H, W):
+            # depthwise 3x3 + bias + GELU on the token tensor itself, level by level (no NCHW round trip, no concatenation)
+            x = Fn.dwconv3x3_tokens(x, self.dwconv.levels(x.shape[1], H, W), self.dwconv.dwconv.weight, self.dwconv.dwconv.bias, gelu=True)
+        else:
+            x = F.gelu(self.dwconv(x, H, W))
+        return Fn.linear(x, self.fc2.weight, self.fc2.bias, tall=True, residual=residual)
 
 
 class Extractor(nn.Module):
@@ -249,7 +261,7 @@ class Extractor(nn.Module):
                          Fn.add_layer_norm(feat, None, self.feat_norm), spatial_shapes, level_start_index, None)
         query = query + attn
         if self.with_cffn:
-            query = query + self.ffn(Fn.add_layer_norm(query, None, self.ffn_norm), H, W)
+            query = self.ffn(Fn.add_layer_norm(query, None, self.ffn_norm), H, W, residual=query)
         return query
 
 

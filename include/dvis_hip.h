@@ -361,6 +361,17 @@ int dvis_upsample_add_affine(const float *lateral, const float *lat_scale, const
                              float *out, int64_t planes, int H, int W, int h, int w, void *stream);
 
 /*
+ * Depthwise 3 x 3 convolution (padding 1) + bias (+ exact GELU) on a TOKEN-major map: the ConvFFN of the ViT-Adapter extractors
+ * (mask2former/modeling/backbones_vitAdapter/adapter_modules.py, DWConv + the GELU that follows it in ConvFFN.forward).  The
+ * reference transposes each of the three pyramid levels of its (B, N, C) token tensor to NCHW, runs a grouped Conv2d, transposes
+ * back and concatenates; here one call per level reads and writes the token tensor in place of all that:
+ *   x / out: level base pointers, token (b, y, x) at base + b * batch_stride + (y * w + x) * C; weight (C, 1, 3, 3) = C x 9; bias C or
+ *   NULL; C % 4 == 0; out must not alias x.
+ */
+int dvis_dwconv3x3_tokens(const float *x, float *out, int64_t batch_stride, int B, int h, int w, int C, const float *weight,
+                          const float *bias, int gelu, void *stream);
+
+/*
  * The stride-4 output of the ViT-Adapter backbone (mask2former/modeling/backbones_vitAdapter/adapter.py, forward:
  * `c1 = self.up(c2) + c1; c1 = c1 + F.interpolate(x1, scale_factor=4, mode="bilinear", align_corners=False); f1 = self.norm1(c1)`).
  * `up` = ConvTranspose2d(C, C, 2, 2) is a GEMM over the stride-8 tokens with 4 C output features ordered (dy, dx, co); the caller
@@ -536,6 +547,13 @@ int dvis_x3_linear(const float *x, int64_t ldx, int64_t M, int K, const void *pa
  * video_mask2former_transformer_decoder.py:81-88.  K = 256 (the row's fragments stay in registers for every pass over N). */
 int dvis_x3_linear_add(const float *x, int64_t ldx, int64_t M, int K, const void *packed, int N, int xexp, int wexp,
                        const float *xadd, int64_t xadd_rows, const float *bias, int relu, float *out, int64_t ldo, void *stream);
+/* dvis_x3_linear with the activation chosen by `act` (0 none, 1 ReLU, 2 the exact GELU of nn.GELU(): 0.5 t (1 + erf(t / sqrt 2)))
+ * and an optional residual added AFTER it: out = act(x W^T + bias) + res (res: M x N, row stride ldres floats, 16-byte aligned; may
+ * alias nothing the kernel writes).  The ViT blocks of the DINOv2 / ViT-Adapter backbones (mask2former/modeling/
+ * backbones_vitAdapter: `x = x + ls1(attn(norm1(x)))`, `Mlp: fc2(act(fc1(x)))`) take their GELU and their residual adds here
+ * instead of in two more passes over the 452 MB token tensor of a 30-frame clip. */
+int dvis_x3_linear_res(const float *x, int64_t ldx, int64_t M, int K, const void *wp, int N, int xexp, int wexp, const float *bias, int act,
+                       const float *res, int64_t ldres, float *out, int64_t ldo, void *stream);
 /* out = LayerNorm( x W^T + bias + res ) over the N = 256 features (gamma, beta, eps; two-pass statistics as torch);
  * pos (pos_rows x N, optional): out2[t] = out[t] + pos[t mod pos_rows] (the next layer's `with_pos_embed(src, pos)`,
  * msdeformattn.py:99-101,122).  Replaces output_proj + `src = norm1(src + dropout1(src2))`, msdeformattn.py:124-125. */

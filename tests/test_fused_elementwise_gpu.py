@@ -263,3 +263,31 @@ def test_adapter_res2_equals_transposed_conv_add_upsample_batchnorm(B, C, h8, w8
         out = Fn.adapter_res2(gm.to(DEV), c1.to(DEV), x1_tok.to(DEV) if with_x1 else None, s.to(DEV), shift.to(DEV), h8, w8)
     err = float((out.double().cpu() - ref).abs().max())
     assert err <= 2e-5 * max(1.0, float(ref.abs().max())), err
+
+
+@pytest.mark.parametrize("B,C,H,W,gelu", [(2, 64, 4, 6, True), (1, 256, 6, 10, True), (3, 8, 2, 2, False), (2, 260, 4, 14, True)])
+def test_dwconv3x3_tokens_equals_the_transposed_grouped_convolution(B, C, H, W, gelu):
+    """dvis_dwconv3x3_tokens on the three-level token tensor against adapter_modules.py's DWConv (+ ConvFFN's GELU): per level
+    transpose to NCHW, grouped Conv2d, transpose back, concatenate."""
+    from dvis_plus_amd import functions as Fn
+    g = torch.Generator().manual_seed(B + C + H + W)
+    conv = torch.nn.Conv2d(C, C, 3, 1, 1, bias=True, groups=C)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(C, 1, 3, 3, generator=g) * 0.3)
+        conv.bias.copy_(torch.randn(C, generator=g))
+    levels = [(2 * H, 2 * W), (H, W), (H // 2, W // 2)]
+    N = sum(h * w for h, w in levels)
+    x = torch.randn(B, N, C, generator=g)
+    outs, off = [], 0
+    with torch.no_grad():
+        cd = conv.double()
+        for h, w in levels:
+            m = x[:, off:off + h * w].double().transpose(1, 2).reshape(B, C, h, w)
+            outs.append(cd(m).flatten(2).transpose(1, 2))
+            off += h * w
+        ref = torch.cat(outs, 1)
+        if gelu:
+            ref = F.gelu(ref)
+        conv = conv.float()
+        out = Fn.dwconv3x3_tokens(x.to(DEV), levels, conv.weight.to(DEV), conv.bias.to(DEV), gelu=gelu)
+    assert float((out.double().cpu() - ref).abs().max()) <= 1e-5

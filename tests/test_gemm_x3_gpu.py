@@ -375,3 +375,34 @@ def test_linear_with_the_position_added_in_the_kernel(N, B, S):
     ref = xs @ lin.weight.double().t() + lin.bias.double()
     scale = xs.abs() @ lin.weight.double().abs().t() + lin.bias.double().abs()
     assert _rel(got, ref, scale) <= 4e-7
+
+
+@pytest.mark.parametrize("K,N,M,act,with_res", [(1024, 1024, 3000, None, True), (1024, 4096, 777, "gelu", False),
+                                                (4096, 1024, 1500, None, True), (256, 256, 301, "gelu", True),
+                                                (1024, 3072, 513, "relu", True)])
+def test_linear_with_gelu_and_residual_in_the_epilogue(K, N, M, act, with_res):
+    """dvis_x3_linear_res — the ViT blocks' `x + proj(...)`, `fc2(gelu(fc1(x)))` (backbones_vitAdapter) without separate GELU /
+    add passes: against fp64, not worse than the fp32 composition; and through Fn.linear(tall=True, act=, residual=)."""
+    from dvis_plus_amd import functions as Fn
+    lin = _lin(K, N, K + N)
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, K, generator=g).to(DEV)
+    res = torch.randn(M, N, generator=g).to(DEV) if with_res else None
+    ref = x.double() @ lin.weight.double().t() + lin.bias.double()
+    f32 = F.linear(x, lin.weight, lin.bias)
+    if act == "gelu":
+        ref, f32 = F.gelu(ref), F.gelu(f32)
+    elif act == "relu":
+        ref, f32 = torch.relu(ref), torch.relu(f32)
+    if with_res:
+        ref, f32 = ref + res.double(), f32 + res
+    out = Fn.x3_linear(x, lin.weight, lin.bias, act=act, residual=res)
+    scale = (x.double().abs() @ lin.weight.double().abs().t() + 1.0)
+    e_x3, e_f32 = _rel(out, ref, scale), _rel(f32, ref, scale)
+    assert e_x3 <= max(1.5 * e_f32, 2e-7), (e_x3, e_f32)
+    via = Fn.linear(x, lin.weight, lin.bias, tall=True, act=act, residual=res)
+    assert torch.equal(via, out)
+    # a 3-D input with a residual view
+    if with_res and M % 3 == 0:
+        o3 = Fn.linear(x.view(3, M // 3, K), lin.weight, lin.bias, tall=True, act=act, residual=res.view(3, M // 3, N))
+        assert torch.equal(o3.view(M, N), out)
