@@ -797,6 +797,9 @@ def linear(x, weight, bias=None, relu=False, own=None, tall=False, act=None, res
     forced = own is True
     gpu_inf = x.is_cuda and not torch.is_grad_enabled() and not torch.is_autocast_enabled()
     if tall and not forced and gpu_inf and x3_on() and weight.dim() == 2 and weight._base is None \
+            and x3_tile_ok(x, weight.shape[0], weight.shape[1]):
+        return x3_tile_linear(x, weight, bias, act="relu" if relu and act is None else act, residual=residual)
+    if tall and not forced and gpu_inf and x3_on() and weight.dim() == 2 and weight._base is None \
             and x3_ok(x, weight.shape[0], weight.shape[1]):
         # Weights that are views (slices made per call) would be re-packed per call: they stay on the exact kernels below.
         if (act is not None or residual is not None) and weight.shape[0] % 256 == 0:
@@ -1061,6 +1064,57 @@ def x3_pack(weight):
                                                    ctypes.c_void_p(buf.data_ptr()), native.stream_ptr(w.device)), "dvis_x3_pack")
         return buf, e
     return _x3_cache(weight, (weight._version, weight.data_ptr(), weight.device, tuple(weight.shape)), make)
+
+
+# The large-K tall GEMMs (ViT blocks: K = 1024 .. 4096, N a multiple of 256) take the TILED split-f16 kernel (csrc/gemm_x3_tile.hip:
+# both operands through LDS, one split of the rows per 256 output features); the encoder's K = 256 layers keep the streaming
+# kernels with their fused LayerNorm / position forms.  DVIS_X3_TILE_MIN_K (development): K from which the tiled kernel is used.
+X3_TILE_MIN_K = int(os.environ.get("DVIS_X3_TILE_MIN_K", "512"))
+
+
+def x3_tile_ok(x, N, K):
+    return (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and x.shape[-1] == K and K >= X3_TILE_MIN_K
+            and bool(native.lib().dvis_x3_tile_supported(N, K)))
+
+
+def x3_tile_pack(weight):
+    """(packed buffer, wexp) of an (N, K) float32 GPU weight in the tiled kernel's LDS image, made once per weight version."""
+    def make():
+        w = weight.detach()
+        if w.stride(1) != 1:
+            w = w.contiguous()
+        N, K = w.shape
+        nbytes = native.lib().dvis_x3_tile_packed_bytes(N, K)
+        if nbytes <= 0:
+            raise RuntimeError(f"x3_tile_pack: weight {tuple(w.shape)} is not served (N % 256 == 0, K % 32 == 0)")
+        e = _x3_exp(w)
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        with torch.cuda.device(w.device):
+            native.check(native.lib().dvis_x3_tile_pack(ctypes.c_void_p(w.data_ptr()), w.stride(0), N, K, e,
+                                                        ctypes.c_void_p(buf.data_ptr()), native.stream_ptr(w.device)), "dvis_x3_tile_pack")
+        return buf, e
+    return _x3_cache(weight, (weight._version, weight.data_ptr(), weight.device, tuple(weight.shape)), make, kind="tile")
+
+
+def x3_tile_linear(x, weight, bias, act=None, residual=None, xexp=None):
+    """``act(x @ weight.T + bias) + residual`` through dvis_x3_tile_linear (act: None | "relu" | "gelu")."""
+    N, K = weight.shape
+    x2, ldx = _x3_rows(x, "x")
+    buf, wexp = x3_tile_pack(weight)
+    out = torch.empty((*x.shape[:-1], N), dtype=torch.float32, device=x.device)
+    rptr, ldr = None, 0
+    if residual is not None:
+        if residual.shape != out.shape or residual.dtype != torch.float32 or not residual.is_cuda:
+            raise RuntimeError("x3_tile_linear: residual must be a float32 GPU tensor of the output's shape")
+        r2, ldr = _rows2d(residual, N)
+        rptr = ctypes.c_void_p(r2.data_ptr())
+    with torch.cuda.device(x.device):
+        native.check(native.lib().dvis_x3_tile_linear(
+            ctypes.c_void_p(x2.data_ptr()), ldx, x2.shape[0], K, ctypes.c_void_p(buf.data_ptr()), N,
+            X3_XEXP if xexp is None else xexp, wexp, None if bias is None else native.dev_ptr(bias.detach(), "bias"),
+            {None: 0, "relu": 1, "gelu": 2}[act], rptr, ldr, ctypes.c_void_p(out.data_ptr()), N, native.stream_ptr(x.device)),
+            "dvis_x3_tile_linear")
+    return out
 
 
 def x3_ok(x, N, K, ln=False, add=False):

@@ -90,6 +90,10 @@ SIGNATURES = {
     "dvis_x3_pack": (_i, [_p, _i64, _i, _i, _i, _p, _p]),
     "dvis_x3_linear_supported": (_i, [_i, _i, _i]),
     "dvis_x3_linear": (_i, [_p, _i64, _i64, _i, _p, _i, _i, _i, _p, _i, _p, _i64, _p]),
+    "dvis_x3_tile_supported": (_i, [_i, _i]),
+    "dvis_x3_tile_packed_bytes": (_i64, [_i, _i]),
+    "dvis_x3_tile_pack": (_i, [_p, _i64, _i, _i, _i, _p, _p]),
+    "dvis_x3_tile_linear": (_i, [_p, _i64, _i64, _i, _p, _i, _i, _i, _p, _i, _p, _i64, _p, _i64, _p]),
     "dvis_x3_linear_res": (_i, [_p, _i64, _i64, _i, _p, _i, _i, _i, _p, _i, _p, _i64, _p, _i64, _p]),
     "dvis_x3_linear_add": (_i, [_p, _i64, _i64, _i, _p, _i, _i, _i, _p, _i64, _p, _i, _p, _i64, _p]),
     "dvis_x3_linear_ln": (_i, [_p, _i64, _i64, _i, _p, _i, _i, _i, _p, _p, _i64, _p, _p, _f, _p, _i64, _p, _p, _i64, _p]),

@@ -400,9 +400,34 @@ def test_linear_with_gelu_and_residual_in_the_epilogue(K, N, M, act, with_res):
     scale = (x.double().abs() @ lin.weight.double().abs().t() + 1.0)
     e_x3, e_f32 = _rel(out, ref, scale), _rel(f32, ref, scale)
     assert e_x3 <= max(1.5 * e_f32, 2e-7), (e_x3, e_f32)
+    # Fn.linear(tall=True): the tiled kernel from K = 512 on (csrc/gemm_x3_tile.hip), the streaming kernel below
     via = Fn.linear(x, lin.weight, lin.bias, tall=True, act=act, residual=res)
-    assert torch.equal(via, out)
-    # a 3-D input with a residual view
+    e_via = _rel(via, ref, scale)
+    assert e_via <= max(1.5 * e_f32, 2e-7), (e_via, e_f32)
+    if K < Fn.X3_TILE_MIN_K:
+        assert torch.equal(via, out)
+    # a 3-D input with a residual view; a row's bits do not depend on the rows around it
     if with_res and M % 3 == 0:
         o3 = Fn.linear(x.view(3, M // 3, K), lin.weight, lin.bias, tall=True, act=act, residual=res.view(3, M // 3, N))
-        assert torch.equal(o3.view(M, N), out)
+        assert torch.equal(o3.view(M, N), via)
+    part = Fn.linear(x[:100], lin.weight, lin.bias, tall=True, act=act, residual=None if res is None else res[:100])
+    assert torch.equal(part, via[:100])
+
+
+@pytest.mark.parametrize("K,N,M", [(1024, 256, 1), (512, 512, 255), (1024, 1024, 257), (2048, 256, 1000)])
+def test_tiled_kernel_layout_is_exact_on_integer_operands_and_strided_rows(K, N, M):
+    """csrc/gemm_x3_tile.hip: integer-valued operands come out bit for bit (every fragment / chunk / tile index is right), rows
+    with a stride (a slice of a wider tensor), ragged M."""
+    from dvis_plus_amd import functions as Fn
+    g = torch.Generator().manual_seed(K + N + M)
+    w = torch.randint(-8, 9, (N, K), generator=g).float().to(DEV)
+    b = torch.randint(-8, 9, (N,), generator=g).float().to(DEV)
+    wide = torch.randint(-8, 9, (M, K + 64), generator=g).float().to(DEV)
+    x = wide[:, 32:32 + K]
+    assert Fn.x3_tile_ok(x, N, K)
+    out = Fn.x3_tile_linear(x, w, b)
+    ref = (x.double() @ w.double().t() + b.double()).float()
+    assert torch.equal(out, ref)
+    res = torch.randint(-8, 9, (M, N), generator=g).float().to(DEV)
+    out = Fn.x3_tile_linear(x, w, b, act="relu", residual=res)
+    assert torch.equal(out, torch.relu(ref) + res)
