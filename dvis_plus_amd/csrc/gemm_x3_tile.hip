@@ -5,34 +5,37 @@
 // csrc/gemm_x3.hip was shaped for the deformable encoder (K = 256: a wave keeps its 32 tokens' fragments in registers and streams
 // the weights; every pass over 256 output features re-reads and re-splits the tile's rows, every wave reads every weight fragment
 // from LDS).  At K = 1024 .. 4096 that costs 12 - 16 passes over a 1 - 4 MB row tile that no cache holds (7 GB of HBM reads for
-// the qkv projection of one block) and leaves the matrix pipe 0.43 busy.  Here both operands are TILED:
-//   workgroup = 256 tokens x 256 features, 8 waves as 2 (tokens) x 4 (features), a wave owns 128 x 64 = 8 accumulator blocks of
-//   32 x 32; K advances in steps of 32 through a double-buffered LDS stage (A: the tokens' rows, split into hi / lo f16 ONCE per
-//   tile by the threads that stage them; B: the packed weights, already split); per k-step of 16 a wave reads 8 + 4 fragments
-//   of 1 KB and issues 24 products — half the LDS bytes per product of the streaming kernel, and no activation re-read: the
-//   tile's rows come from memory once per 256 output features, from an L2 that holds them (workgroups that share a row tile are
-//   neighbours on the same XCD).
-// LDS image of one operand part (hi or lo), 256 rows x 32 k: four 16-byte k-chunks, chunk c = k / 8, rows contiguous inside a
-// chunk (a fragment read = 32 lanes x 16 contiguous bytes per lane half: conflict-free for ds_read_b128's lane groups), chunks
-// 4096 + 32 bytes apart (the staging writes of four lanes holding one row's four chunks land on different banks).
+// the qkv projection of one block).  Here both operands are TILED:
+//   workgroup = 128 tokens x 256 features, 4 waves (one per SIMD, 204 registers) as 2 (tokens) x 2 (features), a wave owns
+//   64 x 128 = 8 accumulator blocks of 32 x 32; K advances in steps of 16 through a double-buffered LDS stage of 24 KB (A: the
+//   tokens' rows, fetched two steps ahead into registers and split into hi / lo f16 ONCE per tile by the threads that stage them;
+//   B: the packed weights, global -> LDS directly, no registers); per step a wave reads 4 + 8 fragments of 1 KB for 24 products
+//   — half the LDS bytes per product of the streaming kernel — and a row tile is read once per 256 output features from the L2
+//   of the XCD that owns it (workgroups that share a row tile are neighbours there).  48.5 KB of LDS per workgroup: TWO
+//   workgroups share a CU, drift apart, and one's epilogue (a 128 KB tile store) runs under the other's products.
+// Measured (profiles/r05_x3_tile.txt): 9.95 ms per ViT-L block of 30 frames (qkv + proj + fc1 + fc2) against 11.09 on the
+// streaming kernel = 0.35 of the nominal f16 matrix peak — which is 0.55 of what the matrix pipes SUSTAIN on this part with
+// random operands (tools/exp/ubench/mfma_peak.hip: 2.34 PFLOP/s with constant operands, 1.6 - 1.67 with random ones: the clock
+// gives way under the toggling; GRBM_GUI_ACTIVE / time = 1.84 GHz inside these kernels).  An 8-wave 256 x 256 variant (one
+// workgroup per CU, 132 KB) measured the same 9.95 ms and was dropped.
+// LDS image of one operand part (hi or lo): 16-byte k-chunks (chunk c = k / 8), rows contiguous inside a chunk (a fragment read =
+// 32 lanes x 16 contiguous bytes per lane half: conflict-free for ds_read_b128's lane groups); A's two chunks 2048 + 64 bytes apart
+// (the staging writes of two lanes holding one row's chunks land 16 banks apart), B's 4096 + 32.
 #include "dvis_common.h"
 #include "x3_common.h"
 
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
-constexpr int kTM = 256, kTN = 256, kTK = 32;
-constexpr int kChunk = 4096 + 32;                  // bytes between the k-chunks of a part
-constexpr int kPart = 4 * kChunk;                  // one operand part (hi or lo): 16 512 bytes
-constexpr int kStage = 4 * kPart;                  // A hi | A lo | B hi | B lo: 66 048 bytes
-constexpr int kTileLds = 2 * kStage;               // double buffered: 132 096 bytes
+constexpr int kTN = 256;
 
 struct TileArgs {
   const float *x;
   int64_t ldx, M;
   int K, N;
-  const char *wp;                    // packed weights: [n-tile][k-tile][hi, lo][chunk][256 rows][8 halves] = 32 KB per (n-tile, k-tile)
+  const char *wp;                    // packed weights
   float xscale, inv;
   const float *bias, *radd;
   int64_t ldres;
@@ -42,168 +45,164 @@ struct TileArgs {
   int *flag;
   int tag;
   int tm, tn;                        // tiles along M / N
-  int dbg;                           // development: 1 = no global fetch in the loop, 2 = no LDS staging in the loop
 };
 
+// Packed weights: [n-tile][k-tile of 16][hi, lo][chunk 0, 1][256 rows][8 halves] = 16 KB per (n-tile, k-tile).
+constexpr int k2TM = 128, k2TK = 16;
+constexpr int k2ChunkA = 2048 + 64;                 // 128 rows x 16 B (+ 64: the two chunks of a row land 16 banks apart when written)
+constexpr int k2ChunkB = 4096 + 32;
+constexpr int k2PartA = 2 * k2ChunkA, k2PartB = 2 * k2ChunkB;
+constexpr int k2Stage = 2 * k2PartA + 2 * k2PartB;  // A hi | A lo | B hi | B lo = 24 896 bytes
+constexpr int k2Lds = 2 * k2Stage;
+
 __global__ void x3_tile_pack_kernel(const float *__restrict__ w, int64_t ldw, int N, int K, float scale, _Float16 *__restrict__ out,
-                                    int64_t pieces) {
+                                     int64_t pieces) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one thread per 16-byte piece (8 k of one row), hi and lo
   if (idx >= pieces) return;
-  const int row = idx & 255, c = (idx >> 8) & 3;
-  const int64_t t = idx >> 10;
-  const int KT = K / kTK;
+  const int row = idx & 255, c = (idx >> 8) & 1;
+  const int64_t t = idx >> 9;
+  const int KT = K / k2TK;
   const int kt = (int)(t % KT), nt = (int)(t / KT);
-  const int n = nt * kTN + row, k0 = kt * kTK + 8 * c;
-  _Float16 *o = out + t * (2 * 4 * 256 * 8) + (size_t)c * 256 * 8 + row * 8;
+  const int n = nt * kTN + row, k0 = kt * k2TK + 8 * c;
+  _Float16 *o = out + t * (2 * 2 * 256 * 8) + (size_t)c * 256 * 8 + row * 8;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const float v = n < N ? w[(int64_t)n * ldw + k0 + e] * scale : 0.f;
     const _Float16 h = (_Float16)v;
     o[e] = h;
-    o[4 * 256 * 8 + e] = (_Float16)(v - (float)h);
+    o[2 * 256 * 8 + e] = (_Float16)(v - (float)h);
   }
 }
 
 template <bool GELU>
-__global__ __launch_bounds__(512) void x3_tile_kernel(TileArgs a) {
+__global__ __launch_bounds__(256, 2) void x3_tile_kernel(TileArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, g = lane >> 5;
-  const int wm = wave >> 2, wn = wave & 3;
-  // tile of this workgroup, XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs; a row tile (and its tn feature
-  // tiles) belongs to ONE XCD, whose L2 then serves the row tile's re-reads
+  const int wm = wave >> 1, wn = wave & 1;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int mt = (slot / a.tn) * 8 + xcd, nt = slot - (slot / a.tn) * a.tn;
   if (mt >= a.tm) return;
-  const int64_t m0 = (int64_t)mt * kTM;
-  const int KT = a.K / kTK;
+  const int64_t m0 = (int64_t)mt * k2TM;
+  const int KT = a.K / k2TK;
 
-  // ---- staging: A rows (tid >> 2) and + 128, k-chunk tid & 3 (8 floats = two 16-byte loads per row); B: four 16-byte pieces
-  const int aq = tid & 3;
-  const float *arow[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int64_t m = m0 + (tid >> 2) + 128 * i;
-    arow[i] = a.x + (m < a.M ? m : a.M - 1) * a.ldx + 8 * aq;
+  // staging: A row tid >> 1, k-chunk tid & 1 (8 floats), two k-tiles ahead in registers; B by LDS-DMA (16 pieces of 1 KB, 4 per wave)
+  const int aq = tid & 1;
+  const float *arow;
+  {
+    const int64_t m = m0 + (tid >> 1);
+    arow = a.x + (m < a.M ? m : a.M - 1) * a.ldx + 8 * aq;
   }
-  const char *bsrc = a.wp + (size_t)nt * KT * 32768 + tid * 16;
+  const char *bsrc = a.wp + (size_t)nt * KT * 16384 + lane * 16;
   f4 ra[2][2];
-  h8 rb[4];
-  auto fetch = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) ra[i][0] = *(const f4 *)(arow[i] + kt * kTK), ra[i][1] = *(const f4 *)(arow[i] + kt * kTK + 4);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) rb[i] = *(const h8 *)(bsrc + (size_t)kt * 32768 + i * 8192);
-  };
-  auto stash = [&](int st) {
-    char *s = lds + st * kStage;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      h8 hi, lo;
-      split8(ra[i][0], ra[i][1], a.xscale, hi, lo);
-      char *p = s + aq * kChunk + ((tid >> 2) + 128 * i) * 16;
-      *(h8 *)p = hi;
-      *(h8 *)(p + kPart) = lo;
-    }
+  auto fetch_a = [&](int kt, int set) { ra[set][0] = *(const f4 *)(arow + kt * k2TK), ra[set][1] = *(const f4 *)(arow + kt * k2TK + 4); };
+  auto dma_b = [&](int kt) {
+    char *s = lds + (kt & 1) * k2Stage + 2 * k2PartA;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int e = tid + 512 * i;               // 16-byte piece of the packed 32 KB: part = e >> 10, chunk = (e >> 8) & 3, row = e & 255
-      *(h8 *)(s + 2 * kPart + (e >> 10) * kPart + ((e >> 8) & 3) * kChunk + (e & 255) * 16) = rb[i];
+      const int p = wave + 4 * i;                   // piece: part = p >> 3, chunk = (p >> 2) & 1, quarter = p & 3
+      glds16(bsrc + (size_t)kt * 16384 + p * 1024, s + (p >> 3) * k2PartB + ((p >> 2) & 1) * k2ChunkB + (p & 3) * 1024);
     }
   };
+  auto stash_a = [&](int st, int set) {
+    h8 hi, lo;
+    split8(ra[set][0], ra[set][1], a.xscale, hi, lo);
+    char *p = lds + st * k2Stage + aq * k2ChunkA + (tid >> 1) * 16;
+    *(h8 *)p = hi;
+    *(h8 *)(p + k2PartA) = lo;
+  };
 
-  f16v acc[4][2];
+  f16v acc[2][4];
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb)
+  for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
 
-  fetch(0);
-  stash(0);
+  dma_b(0);
+  fetch_a(0, 0);
+  if (KT > 1) fetch_a(1, 1);
+  stash_a(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  const int aoff = (wm * 128 + r) * 16 + g * kChunk, boff = 2 * kPart + (wn * 64 + r) * 16 + g * kChunk;
-  // Fragments just in time: all eight waves leave the barrier together, so a k-step that first reads its 12 fragments and then
-  // issues its 24 products leaves the matrix pipes idle while the LDS serves 96 KB (768 cycles) and the LDS idle afterwards.  The
-  // A fragments of block mb + 1 (and, behind the last block, the next k-step's B fragments and first A block) are requested
-  // before block mb's six products are issued; a product group then waits only for what was requested one group earlier.
-  h8 ah[2], al[2], bh[2][2], bl[2][2];
-  auto load_b = [&](const char *s, int ks, int buf) {
+  const int aoff = (wm * 64 + r) * 16 + g * k2ChunkA, boff = 2 * k2PartA + (wn * 128 + r) * 16 + g * k2ChunkB;
+  // fragments: B blocks one after the other (each serves the two A blocks), the next block's pair requested before the
+  // current block's six products
+  h8 ah[2], al[2], bh[2], bl[2];
+  auto load_a = [&](const char *s) {
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      const char *p = s + boff + 2 * ks * kChunk + nb * 512;
-      bh[buf][nb] = *(const h8 *)p, bl[buf][nb] = *(const h8 *)(p + kPart);
+    for (int mb = 0; mb < 2; ++mb) {
+      const char *p = s + aoff + mb * 512;
+      ah[mb] = *(const h8 *)p, al[mb] = *(const h8 *)(p + k2PartA);
     }
   };
-  auto load_a = [&](const char *s, int ks, int mb, int buf) {
-    const char *p = s + aoff + 2 * ks * kChunk + mb * 512;
-    ah[buf] = *(const h8 *)p, al[buf] = *(const h8 *)(p + kPart);
+  auto load_b = [&](const char *s, int nb, int buf) {
+    const char *p = s + boff + nb * 512;
+    bh[buf] = *(const h8 *)p, bl[buf] = *(const h8 *)(p + k2PartB);
   };
+  load_a(lds);
   load_b(lds, 0, 0);
-  load_a(lds, 0, 0, 0);
-  for (int kt = 0; kt < KT; ++kt) {
-    if (kt + 1 < KT && !(a.dbg & 1)) fetch(kt + 1);
-    const char *s = lds + (kt & 1) * kStage;
+  auto tile = [&](int kt, auto set_c) {
+    constexpr int SET = decltype(set_c)::value;      // tile kt + 1 is in set SET; tile kt + 2 goes to set SET ^ 1
+    if (kt + 1 < KT) dma_b(kt + 1);
+    if (kt + 2 < KT) fetch_a(kt + 2, SET ^ 1);
+    const char *s = lds + (kt & 1) * k2Stage;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int mb = 0; mb < 4; ++mb) {
-        const int t = ks * 4 + mb;                 // A buffers alternate per block, B buffers per k-step
-        if (!(a.dbg & 8)) {
-          if (mb + 1 < 4)
-            load_a(s, ks, mb + 1, (t + 1) & 1);
-          else if (ks == 0)
-            load_b(s, 1, 1), load_a(s, 1, 0, (t + 1) & 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // the three products of a block alternate between its two accumulators: a product never issues right behind the one
-        // it accumulates onto
-        acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t & 1], bh[ks][0], acc[mb][0], 0, 0, 0);
-        acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t & 1], bh[ks][1], acc[mb][1], 0, 0, 0);
-        acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t & 1], bl[ks][0], acc[mb][0], 0, 0, 0);
-        acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t & 1], bl[ks][1], acc[mb][1], 0, 0, 0);
-        acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t & 1], bh[ks][0], acc[mb][0], 0, 0, 0);
-        acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t & 1], bh[ks][1], acc[mb][1], 0, 0, 0);
-        if (ks == 0 && mb == 1 && kt + 1 < KT && !(a.dbg & 2)) stash((kt + 1) & 1);      // the other stage: free since the last barrier
-        __builtin_amdgcn_sched_barrier(0);
-      }
+    for (int nb = 0; nb < 4; ++nb) {
+      if (nb + 1 < 4) load_b(s, nb + 1, (nb + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0], bh[nb & 1], acc[0][nb], 0, 0, 0);
+      acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[1], bh[nb & 1], acc[1][nb], 0, 0, 0);
+      acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0], bl[nb & 1], acc[0][nb], 0, 0, 0);
+      acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1], bl[nb & 1], acc[1][nb], 0, 0, 0);
+      acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0], bh[nb & 1], acc[0][nb], 0, 0, 0);
+      acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1], bh[nb & 1], acc[1][nb], 0, 0, 0);
+      if (nb == 1 && kt + 1 < KT) stash_a((kt + 1) & 1, SET);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (!(a.dbg & 4)) __syncthreads();
-    if (kt + 1 < KT && !(a.dbg & 8)) {
-      const char *sn = lds + ((kt + 1) & 1) * kStage;
+    if (kt + 2 < KT)
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // tile kt + 1's B pieces landed; tile kt + 2's two row loads stay in flight
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < KT) {
+      const char *sn = lds + ((kt + 1) & 1) * k2Stage;
+      load_a(sn);
       load_b(sn, 0, 0);
-      load_a(sn, 0, 0, 0);
     }
+  };
+  for (int kt = 0; kt < KT; kt += 2) {
+    tile(kt, std::integral_constant<int, 1>());
+    if (kt + 1 < KT) tile(kt + 1, std::integral_constant<int, 0>());
   }
 
-  // ---- epilogue: accumulator i of block (mb, nb) is row 8 (i / 4) + 4 g + i % 4, column r: 32 lanes store 128 contiguous bytes
   float chk = 0.f;
+  const bool full = m0 + k2TM <= a.M;
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    const int n = nt * kTN + wn * 64 + nb * 32 + r;
+  for (int nb = 0; nb < 4; ++nb) {
+    const int n = nt * kTN + wn * 128 + nb * 32 + r;
     const float bv = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
+    for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int64_t m = m0 + wm * 128 + mb * 32 + 8 * (i >> 2) + 4 * g + (i & 3);
+        const int64_t m = m0 + wm * 64 + mb * 32 + 8 * (i >> 2) + 4 * g + (i & 3);
         const float t = acc[mb][nb][i] * a.inv + bv;
         chk = __builtin_fmaf(t, 0.f, chk);
         float v = GELU ? 0.5f * t * (1.f + erff(t * 0.70710678118654752440f)) : a.act == 1 ? fmaxf(t, 0.f) : t;
-        if (m < a.M) {
+        if (full || m < a.M) {
           if (a.radd) v += a.radd[m * a.ldres + n];
           a.out[m * a.ldo + n] = v;
         }
       }
   }
-  // range guard (x3_common.h): a split operand beyond the f16 range leaves a non-finite pre-activation value
   if (a.flag != nullptr && chk != chk) atomicCAS(a.flag, 0, a.tag);
 }
 
 }  // namespace
 
-DVIS_EXPORT int dvis_x3_tile_supported(int N, int K) { return N > 0 && K > 0 && N % kTN == 0 && K % kTK == 0; }
+DVIS_EXPORT int dvis_x3_tile_supported(int N, int K) { return N > 0 && K > 0 && N % kTN == 0 && K % 32 == 0; }
 
 DVIS_EXPORT int64_t dvis_x3_tile_packed_bytes(int N, int K) {
   if (!dvis_x3_tile_supported(N, K)) return -1;
@@ -234,20 +233,17 @@ DVIS_EXPORT int dvis_x3_tile_linear(const float *x, int64_t ldx, int64_t M, int 
   a.bias = bias, a.radd = res, a.ldres = ldres, a.out = out, a.ldo = ldo, a.act = act;
   const X3Guard gd = dvis_x3_guard();
   a.flag = gd.flag, a.tag = gd.tag;
-  const int64_t tm = (M + kTM - 1) / kTM;
+  const int64_t tm = (M + k2TM - 1) / k2TM;
   a.tm = (int)tm, a.tn = N / kTN;
-  static const int dbg = []() { const char *e = getenv("DVIS_X3_TILE_DBG"); return e ? atoi(e) : 0; }();
-  a.dbg = dbg;
-  if (dbg) a.flag = nullptr;
   const int64_t grid = (tm + 7) / 8 * 8 * a.tn;
   DVIS_REQUIRE(grid < ((int64_t)1 << 31), "dvis_x3_tile_linear: too many tiles");
-  static DvisLdsOptIn opted, opted_gelu;
+  static DvisLdsOptIn o2, o2g;
   if (act == 2) {
-    if (const int rc = dvis_lds_opt_in((const void *)x3_tile_kernel<true>, kTileLds, &opted_gelu, "x3_tile_kernel")) return rc;
-    hipLaunchKernelGGL(x3_tile_kernel<true>, dim3((unsigned)grid), dim3(512), kTileLds, (hipStream_t)stream, a);
+    if (const int rc = dvis_lds_opt_in((const void *)x3_tile_kernel<true>, k2Lds, &o2g, "x3_tile_kernel")) return rc;
+    hipLaunchKernelGGL(x3_tile_kernel<true>, dim3((unsigned)grid), dim3(256), k2Lds, (hipStream_t)stream, a);
   } else {
-    if (const int rc = dvis_lds_opt_in((const void *)x3_tile_kernel<false>, kTileLds, &opted, "x3_tile_kernel")) return rc;
-    hipLaunchKernelGGL(x3_tile_kernel<false>, dim3((unsigned)grid), dim3(512), kTileLds, (hipStream_t)stream, a);
+    if (const int rc = dvis_lds_opt_in((const void *)x3_tile_kernel<false>, k2Lds, &o2, "x3_tile_kernel")) return rc;
+    hipLaunchKernelGGL(x3_tile_kernel<false>, dim3((unsigned)grid), dim3(256), k2Lds, (hipStream_t)stream, a);
   }
   return dvis_check_launch("x3_tile_kernel");
 }

@@ -558,10 +558,10 @@ int dvis_x3_linear_res(const float *x, int64_t ldx, int64_t M, int K, const void
 /*
  * The same `out = act(x W^T + bias) + res` for the LARGE tall GEMMs of the ViT blocks (K = 1024 .. 4096; qkv / proj / fc1 / fc2 of
  * mask2former/modeling/backbones_vitAdapter at 110 430 tokens per 30-frame clip), csrc/gemm_x3_tile.hip: workgroup tiles of
- * 256 tokens x 256 features with BOTH operands staged through LDS (the rows split into their two f16 terms once per tile), so a
+ * 128 tokens x 256 features with BOTH operands staged through LDS (the rows split into their two f16 terms once per tile), so a
  * row tile is read once per 256 output features from the L2 of the XCD that owns it — the streaming kernels above re-read and
  * re-split it per pass from HBM.  N % 256 == 0, K % 32 == 0 (dvis_x3_tile_supported); weights packed once with dvis_x3_tile_pack
- * into dvis_x3_tile_packed_bytes(N, K) bytes (the LDS image per (feature tile, k-step of 32), scaled by 2^wexp).
+ * into dvis_x3_tile_packed_bytes(N, K) bytes (the LDS image per (feature tile, k-step of 16), scaled by 2^wexp).
  * A row's result does not depend on M.  Same range guard as the other split-f16 kernels.
  */
 int dvis_x3_tile_supported(int N, int K);
