@@ -16,9 +16,12 @@ if [ "$S" = "0" ] || [ "$S" = "1" ]; then
   python bench.py --backbone vitl --queries 200 --steps 4 --warmup 2 --no-cpu-baseline --no-extra > gpurun_out/r05/r05_bench_line_vitl_200q.json 2>/dev/null
   python bench.py --task vis --no-cpu-baseline --no-extra > gpurun_out/r05/r05_bench_line_vis.json 2>/dev/null
   bash tools/exp/steady.sh r05_online_T5 --mode online --frames 5 > /dev/null 2>&1
+  bash tools/exp/steady.sh r05_vitl_200q --backbone vitl --queries 200 > /dev/null 2>&1
+  python tools/attn_time.py 2>&1 | grep -v "Warn\|amdgpu.ids" > gpurun_out/r05/r05_attn_time.txt
+  python bench.py --clip-stream 0 --no-cpu-baseline --no-extra > gpurun_out/r05/r05_bench_line_clip_by_clip.json 2>/dev/null
   cp gpurun_out/prof/r05_bench_kernel_stats.csv gpurun_out/r05/r05_bench_kernel_stats.csv 2>/dev/null
   grep "^{" gpurun_out/prof/r05_bench_run.log | cut -c1-2000 > gpurun_out/r05/r05_bench_line_under_rocprof.json 2>/dev/null
-  cp gpurun_out/r05_steady_state_kernels.txt gpurun_out/r05_online_T5_steady_state_kernels.txt gpurun_out/r05/ 2>/dev/null
+  cp gpurun_out/r05_steady_state_kernels.txt gpurun_out/r05_online_T5_steady_state_kernels.txt gpurun_out/r05_vitl_200q_steady_state_kernels.txt gpurun_out/r05/ 2>/dev/null
 fi
 if [ "$S" = "0" ] || [ "$S" = "2" ]; then
   PMC_LIGHT=1 timeout 600 bash tools/prof.sh r05_pd python tools/pd_only.py pixel_decoder 5 > /dev/null 2>&1
