@@ -20,6 +20,8 @@
 // per query tile before one atomic per line — not wider lanes.
 #include "dvis_common.h"
 
+#include <algorithm>
+
 namespace {
 
 template <typename A, int GS>
@@ -29,12 +31,32 @@ __device__ __forceinline__ A group_sum(A v) {
   return v;
 }
 
-template <typename T, int GS>
+// DET (fp32 only): grad_value is accumulated in 64-bit FIXED POINT — every contribution is rounded to a multiple of 2^-e on its own
+// (e from the launch's max |grad_out| x max |weight|: 42 bits below the largest possible contribution, 20 bits of headroom above it for
+// colliding contributions; the resolution is ABSOLUTE — 2^-42 of that bound — not relative to a cell's own sum)
+// and integer addition is associative, so the sum does not depend on the order the atomics land in: two runs give the same bits,
+// which float atomics do not (the reference's backward is not reproducible either: ms_deform_im2col_cuda.cuh atomicAdd).
+struct DetArgs {
+  unsigned long long *acc;           // N * S * M * D accumulators (zeroed by the host function)
+  const unsigned *absmax;            // bit patterns of max |grad_out|, max |attn weight|
+};
+
+__device__ __forceinline__ float det_scale(const unsigned *absmax) {
+  const float bound = __uint_as_float(absmax[0]) * __uint_as_float(absmax[1]);
+  int ex = 0;
+  frexpf(bound > 0.f && bound < 3.0e38f ? bound : 1.f, &ex);      // bound < 2^ex
+  return ldexpf(1.f, 42 - ex);
+}
+
+template <typename T, int GS, bool DET = false>
 __global__ __launch_bounds__(256) void msda_bwd_kernel(
     const T *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ level_start,
     const T *__restrict__ loc, const T *__restrict__ w, const T *__restrict__ grad_out, size_t npairs, int S, int M,
-    int D, int L, int Lq, int P, T *__restrict__ grad_value, T *__restrict__ grad_loc, T *__restrict__ grad_w) {
+    int D, int L, int Lq, int P, T *__restrict__ grad_value, T *__restrict__ grad_loc, T *__restrict__ grad_w,
+    DetArgs det = {}) {
   constexpr int GPB = 256 / GS;
+  float dscale = 0.f;
+  if constexpr (DET) dscale = det_scale(det.absmax);
   const int gl = threadIdx.x % GS;
   const size_t pix = (size_t)M * D;
   for (size_t pair = (size_t)blockIdx.x * GPB + threadIdx.x / GS; pair < npairs; pair += (size_t)gridDim.x * GPB) {
@@ -65,10 +87,20 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(
             gx += g * (hh * (b - a) + lh * (f - e));
             gy += g * (hw * (e - a) + lw * (f - b));
             const T ga = g * aw;
-            if (ok1) atomicAdd(grad_value + i1 + c, ga * hh * hw);
-            if (ok2) atomicAdd(grad_value + i2 + c, ga * hh * lw);
-            if (ok3) atomicAdd(grad_value + i3 + c, ga * lh * hw);
-            if (ok4) atomicAdd(grad_value + i4 + c, ga * lh * lw);
+            if constexpr (DET) {
+              auto add = [&](long long idx, float v) {
+                atomicAdd(det.acc + idx, (unsigned long long)__float2ll_rn(v * dscale));      // two's complement: signed sums wrap correctly
+              };
+              if (ok1) add(i1 + c, (float)(ga * hh * hw));
+              if (ok2) add(i2 + c, (float)(ga * hh * lw));
+              if (ok3) add(i3 + c, (float)(ga * lh * hw));
+              if (ok4) add(i4 + c, (float)(ga * lh * lw));
+            } else {
+              if (ok1) atomicAdd(grad_value + i1 + c, ga * hh * hw);
+              if (ok2) atomicAdd(grad_value + i2 + c, ga * hh * lw);
+              if (ok3) atomicAdd(grad_value + i3 + c, ga * lh * hw);
+              if (ok4) atomicAdd(grad_value + i4 + c, ga * lh * lw);
+            }
           }
         }
         gw = group_sum<T, GS>(gw);
@@ -103,7 +135,65 @@ int launch_bwd(const void *value, const int64_t *shapes, const int64_t *ls, cons
   return dvis_check_launch("msda_bwd_kernel");
 }
 
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, size_t n, unsigned *__restrict__ out) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bit patterns; NaN -> 0x7fc..: the largest
+}
+
+__global__ __launch_bounds__(256) void det_finish_kernel(const unsigned long long *__restrict__ acc, const unsigned *__restrict__ absmax,
+                                                         float *__restrict__ grad_value, size_t n) {
+  const float inv = 1.f / det_scale(absmax);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    grad_value[i] = (float)((double)(long long)acc[i] * (double)inv);
+}
+
 }  // namespace
+
+DVIS_EXPORT int64_t dvis_msda_backward_det_ws_bytes(int N, int S, int M, int D) {
+  if (N < 0 || S <= 0 || M <= 0 || D <= 0) return -1;
+  return (int64_t)N * S * M * D * 8 + 16;
+}
+
+// fp32 backward with a run-to-run REPRODUCIBLE grad_value (see DetArgs); grad_loc / grad_w are per-sample reductions in a fixed
+// order in both forms.  ws: dvis_msda_backward_det_ws_bytes bytes, 16-byte aligned.
+DVIS_EXPORT int dvis_msda_backward_det(const float *value, const int64_t *shapes, const int64_t *level_start, const float *loc,
+                                       const float *w, const float *grad_out, int N, int S, int M, int D, int L, int Lq, int P,
+                                       float *grad_value, float *grad_loc, float *grad_w, void *ws, void *stream) {
+  DVIS_REQUIRE(N >= 0 && S > 0 && M > 0 && D > 0 && L > 0 && Lq >= 0 && P > 0, "msda_backward_det: bad sizes");
+  DVIS_REQUIRE(value && shapes && level_start && loc && w && grad_out && grad_value && grad_loc && grad_w && ws &&
+                   (uintptr_t)ws % 16 == 0, "msda_backward_det: null / misaligned pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t nval = (size_t)N * S * M * D;
+  if (N == 0) return DVIS_OK;
+  if (Lq == 0) return hipMemsetAsync(grad_value, 0, nval * 4, st) == hipSuccess ? DVIS_OK : DVIS_E_LAUNCH;
+  unsigned *absmax = (unsigned *)ws;
+  unsigned long long *acc = (unsigned long long *)((char *)ws + 16);
+  if (hipMemsetAsync(ws, 0, 16 + nval * 8, st) != hipSuccess) {
+    dvis_set_error("msda_backward_det: hipMemsetAsync failed");
+    return DVIS_E_LAUNCH;
+  }
+  const size_t ngo = (size_t)N * Lq * M * D, nw = (size_t)N * Lq * M * L * P;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<size_t>((ngo + 255) / 256, 2048)), dim3(256), 0, st, grad_out, ngo, absmax);
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<size_t>((nw + 255) / 256, 2048)), dim3(256), 0, st, w, nw, absmax + 1);
+  const size_t npairs = (size_t)N * Lq * M;
+  const DetArgs det = {acc, absmax};
+  if (D <= 32) {
+    const size_t blocks = (npairs + 7) / 8;
+    hipLaunchKernelGGL((msda_bwd_kernel<float, 32, true>), dim3((unsigned)(blocks > 262144 ? 262144 : blocks)), dim3(256), 0, st, value,
+                       shapes, level_start, loc, w, grad_out, npairs, S, M, D, L, Lq, P, grad_value, grad_loc, grad_w, det);
+  } else {
+    const size_t blocks = (npairs + 3) / 4;
+    hipLaunchKernelGGL((msda_bwd_kernel<float, 64, true>), dim3((unsigned)(blocks > 262144 ? 262144 : blocks)), dim3(256), 0, st, value,
+                       shapes, level_start, loc, w, grad_out, npairs, S, M, D, L, Lq, P, grad_value, grad_loc, grad_w, det);
+  }
+  if (const int rc = dvis_check_launch("msda_bwd_kernel (deterministic)")) return rc;
+  hipLaunchKernelGGL(det_finish_kernel, dim3((unsigned)std::min<size_t>((nval + 255) / 256, 65536)), dim3(256), 0, st, acc, absmax, grad_value,
+                     nval);
+  return dvis_check_launch("det_finish_kernel");
+}
 
 DVIS_EXPORT int dvis_msda_backward(int dtype, const void *value, const int64_t *shapes, const int64_t *level_start,
                                    const void *loc, const void *w, const void *grad_out, int N, int S, int M, int D,

@@ -67,18 +67,40 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     return out
 
 
+# Reproducible MSDeformAttn backward (fp32): 1 = always, 0 = never, default = when torch.use_deterministic_algorithms(True) is set.
+MSDA_BWD_DETERMINISTIC = os.environ.get("DVIS_MSDA_BWD_DETERMINISTIC")
+
+
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
-                            im2col_step=128):
-    """-> [grad_value, grad_sampling_loc, grad_attn_weight] (ops/src/ms_deform_attn.h:47-66)."""
+                            im2col_step=128, deterministic=None):
+    """-> [grad_value, grad_sampling_loc, grad_attn_weight] (ops/src/ms_deform_attn.h:47-66).
+    deterministic (fp32): grad_value through 64-bit fixed-point integer atomics (dvis_msda_backward_det) — the same bits every run;
+    default: DVIS_MSDA_BWD_DETERMINISTIC, else torch.are_deterministic_algorithms_enabled()."""
     N, S, M, D, L, Lq, P = _check_msda_inputs(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
     if not grad_output.is_cuda:
         raise RuntimeError("grad_output must be a GPU tensor")
     grad_output = grad_output.contiguous()
     if grad_output.dtype != value.dtype or grad_output.numel() != N * Lq * M * D:
         raise RuntimeError("grad_output must be (N, Lq, M*D) with value's dtype")
-    grad_value = torch.zeros_like(value)
+    if deterministic is None:
+        deterministic = (MSDA_BWD_DETERMINISTIC == "1") if MSDA_BWD_DETERMINISTIC in ("0", "1") \
+            else torch.are_deterministic_algorithms_enabled()
     grad_loc = torch.empty_like(sampling_loc)
     grad_w = torch.empty_like(attn_weight)
+    if deterministic and value.dtype == torch.float32:
+        grad_value = torch.empty_like(value)
+        nbytes = native.lib().dvis_msda_backward_det_ws_bytes(N, S, M, D)
+        ws = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=value.device)
+        with torch.cuda.device(value.device):
+            rc = native.lib().dvis_msda_backward_det(
+                native.dev_ptr(value, "value"), native.dev_ptr(spatial_shapes, "spatial_shapes"),
+                native.dev_ptr(level_start_index, "level_start_index"), native.dev_ptr(sampling_loc, "sampling_loc"),
+                native.dev_ptr(attn_weight, "attn_weight"), native.dev_ptr(grad_output, "grad_output"),
+                N, S, M, D, L, Lq, P, native.dev_ptr(grad_value, "grad_value"), native.dev_ptr(grad_loc, "grad_loc"),
+                native.dev_ptr(grad_w, "grad_w"), ctypes.c_void_p(ws.data_ptr()), native.stream_ptr(value.device))
+        native.check(rc, "dvis_msda_backward_det")
+        return [grad_value, grad_loc, grad_w]
+    grad_value = torch.zeros_like(value)
     with torch.cuda.device(value.device):
         rc = native.lib().dvis_msda_backward(
             native.dtype_code(value), native.dev_ptr(value, "value"), native.dev_ptr(spatial_shapes, "spatial_shapes"),

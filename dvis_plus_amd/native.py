@@ -24,6 +24,8 @@ SIGNATURES = {
     "dvis_version": (_i, []),
     "dvis_msda_forward": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "dvis_msda_backward": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "dvis_msda_backward_det_ws_bytes": (_i64, [_i, _i, _i, _i]),
+    "dvis_msda_backward_det": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "dvis_msda_fused_forward": (_i, [_p, _p, _p, _p, _i, _p, _i64, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "dvis_msda_fused_forward_pos": (_i, [_p, _p, _p, _p, _i, _p, _i64, _p, _i64, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _i,
                                          _p, _p, _p]),

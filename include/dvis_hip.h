@@ -104,6 +104,21 @@ int dvis_msda_backward(int dtype, const void *value, const int64_t *shapes, cons
                        void *grad_value, void *grad_loc, void *grad_w, void *stream);
 
 /*
+ * The fp32 backward with a run-to-run REPRODUCIBLE grad_value.  The reference accumulates grad_value with float
+ * atomics (ops/src/cuda/ms_deform_im2col_cuda.cuh: atomicAdd in every col2im kernel), so two runs of its backward differ in their
+ * last bits; dvis_msda_backward does the same.  Here every contribution is rounded on its own to a multiple of 2^-e (e from the
+ * launch's max |grad_out| x max |attention weight|: 42 bits below the largest possible contribution) and added as a 64-bit INTEGER
+ * atomic — integer addition is associative, the order the atomics land in does not matter — then converted back.  grad_loc / grad_w
+ * are per-sample reductions in a fixed order in both entry points.  ws: dvis_msda_backward_det_ws_bytes(N, S, M, D) bytes
+ * (8 per value element + 16), 16-byte aligned, zeroed inside.  ABSOLUTE resolution 2^-42 of max |grad_out| x max |weight| (fp32 carries
+ * 2^-24 relative to each sum): cells whose whole sum is below 2^-18 of that bound are less precise than with float atomics.
+ */
+int64_t dvis_msda_backward_det_ws_bytes(int N, int S, int M, int D);
+int dvis_msda_backward_det(const float *value, const int64_t *shapes, const int64_t *level_start, const float *loc, const float *w,
+                           const float *grad_out, int N, int S, int M, int D, int L, int Lq, int P, float *grad_value, float *grad_loc,
+                           float *grad_w, void *ws, void *stream);
+
+/*
  * Fused forward (fp32): takes the RAW outputs of the sampling_offsets / attention_weights linears.
  *   offsets  rows of (M, L, P, 2) floats, row stride `off_stride` floats, one row per (n, q)
  *   logits   rows of (M, L*P)     floats, row stride `logit_stride` floats

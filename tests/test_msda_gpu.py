@@ -390,3 +390,46 @@ def test_encoder_geometry_kernel_is_bit_identical_to_tile_kernel(shapes, spread,
     loc = ref.cpu()[:, :, None, :, None, :] + off.view(N, Lq, M, L, P, 2) / norm[None, None, None, :, None, :]
     want = torch.from_numpy(omsda.msda_forward(value.cpu(), s, lsi, loc.contiguous(), w.contiguous()))
     torch.testing.assert_close(outs[0].cpu(), want, rtol=1e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("case", [SHAPES[0], SHAPES[2], SHAPES[6]], ids=["r50", "vitl", "odd_d"])
+def test_deterministic_backward_repeats_bit_for_bit_and_matches_the_oracle(case):
+    """dvis_msda_backward_det: grad_value through 64-bit fixed-point integer atomics — two runs give the same
+    bits (the float-atomic form, like the reference's col2im kernels, does not at these sizes), the values are the oracle's to fp32
+    accuracy, grad_loc / grad_w equal the default entry point's bit for bit; heavy collisions (every query samples the same cell)
+    and a large dynamic range included."""
+    from dvis_plus_amd import functions as Fn
+    N, M, D, shapes, Lq, P, dt = case
+    s0, _ = level_tensors(shapes)
+    Lq = int(s0.prod(1).sum()) if Lq is None else Lq
+    value, s, lsi, loc, w = make_msda_inputs(N, M, D, shapes, Lq, P, dt, seed=N * 11 + D)
+    loc[:, : Lq // 2] = 0.37                                        # half of the queries hit one cell per level: thousands of colliding atomics
+    go = torch.randn(N, Lq, M * D, generator=torch.Generator().manual_seed(2), dtype=torch.float64).to(dt)
+    go[0, 0] *= 1e4                                                 # dynamic range: the fixed-point scale follows max |grad_out|
+    args = [t.to(DEV) for t in (value, s, lsi, loc, w, go)]
+    a = Fn.ms_deform_attn_backward(*args, deterministic=True)
+    b = Fn.ms_deform_attn_backward(*args, deterministic=True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    d = Fn.ms_deform_attn_backward(*args, deterministic=False)
+    assert torch.equal(a[1], d[1]) and torch.equal(a[2], d[2])
+    # fp64 reference from the same (fp32-valued) inputs; error bound of fp32 contributions (three roundings each) summed exactly:
+    # a few eps32 of the cell's sum of |contributions|
+    v64, l64, w64, g64 = value.double(), loc.double(), w.double(), go.double()
+    ref = torch.from_numpy(omsda.msda_backward(v64, s, lsi, l64, w64, g64)[0])
+    bound = torch.from_numpy(omsda.msda_backward(v64, s, lsi, l64, w64.abs(), g64.abs())[0])
+    err = (a[0].cpu().double() - ref.double()).abs()
+    # + the fixed point's ABSOLUTE resolution: 2^-42 of max |grad_out| x max |w| per contribution
+    floor = 1e-9 * float(go.abs().max()) * float(w.abs().max())
+    assert bool((err <= 4e-7 * bound.double() + floor).all()), float((err - 4e-7 * bound.double()).max())
+    assert float(err.max()) <= 2.0 * float((d[0].cpu().double() - ref.double()).abs().max()) + 1e-12
+    # through autograd with torch's switch
+    prev = torch.are_deterministic_algorithms_enabled()
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    try:
+        v, l_, w_ = (t.to(DEV).requires_grad_(True) for t in (value, loc, w))
+        out = _fn().apply(v, s.to(DEV), lsi.to(DEV), l_, w_, 128)
+        out.backward(go.to(DEV).view_as(out))
+        assert torch.equal(v.grad, a[0])
+    finally:
+        torch.use_deterministic_algorithms(prev)

@@ -36,10 +36,11 @@ def case(name, N, shapes, M, D, Lq, P=4):
     loc = (ref[None, :, None, None, None, :] + off_px / wh[None, None, None, :, None, :]).to(DEV).contiguous()
     w = torch.softmax(torch.randn(N, Lq, M, L * P, generator=g), -1).view(N, Lq, M, L, P).to(DEV).contiguous()
     go = torch.randn(N, Lq, M * D, generator=g).to(DEV)
-    run = lambda: Fn.ms_deform_attn_backward(value, ss, lsi, loc, w, go)
+    run = lambda: Fn.ms_deform_attn_backward(value, ss, lsi, loc, w, go, deterministic=False)
+    det = lambda: Fn.ms_deform_attn_backward(value, ss, lsi, loc, w, go, deterministic=True)
     fwd = lambda: Fn.ms_deform_attn_forward(value, ss, lsi, loc, w)
     out = {}
-    for tag, fn in (("backward", run), ("forward", fwd)):
+    for tag, fn in (("backward", run), ("deterministic", det), ("forward", fwd)):
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
@@ -56,7 +57,8 @@ def case(name, N, shapes, M, D, Lq, P=4):
     print(f"{name}: backward {out['backward']:.1f} us per launch ({N} frames; includes the zero-fill of grad_value) = "
           f"{out['backward'] / N:.1f} us/frame, algorithmic {bwd_bytes / N / 1e6:.1f} MB/frame -> "
           f"{bwd_bytes / (us * 1e-6) / 1e9:.0f} GB/s = {bwd_bytes / (us * 1e-6) / 8e12:.3f} of 8 TB/s;  forward (unfused op) "
-          f"{out['forward'] / N:.1f} us/frame", flush=True)
+          f"{out['forward'] / N:.1f} us/frame;  deterministic backward (64-bit fixed-point atomics + max / convert passes) "
+          f"{out['deterministic'] / N:.1f} us/frame", flush=True)
 
 
 def main():
