@@ -340,10 +340,17 @@ __global__ __launch_bounds__(256) void adapter_res2_kernel(const float *__restri
   const int b = blockIdx.z / h8, y = blockIdx.z - b * h8;
   const int H4 = 2 * h8, W4 = 2 * w8, h16 = h8 / 2, w16 = w8 / 2;
   const int ntok = min(32, w8 - tx);
-  // g: rows of 4 C floats per token; 64 lanes read one (token, sub)'s 64 channels
-  for (int r = wv; r < 128; r += 4) {
-    const int tok = r >> 2, sub = r & 3;
-    if (tok < ntok) gs[(sub * 32 + tok) * TS + lane] = g[(((size_t)b * h8 + y) * w8 + tx + tok) * (size_t)(4 * C) + (size_t)sub * C + co0 + lane];
+  // g: rows of 4 C floats per token; 16 lanes read one (token, sub)'s 64 channels as float4, a wave four such rows per instruction
+  {
+    const int cl = lane & 15, rr = lane >> 4;
+    for (int r = wv * 4 + rr; r < 128; r += 16) {
+      const int tok = r >> 2, sub = r & 3;
+      if (tok < ntok) {
+        const float4 v = *reinterpret_cast<const float4 *>(g + (((size_t)b * h8 + y) * w8 + tx + tok) * (size_t)(4 * C) + (size_t)sub * C + co0 + 4 * cl);
+        float *d = &gs[(sub * 32 + tok) * TS + 4 * cl];
+        d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+      }
+    }
   }
   // x1 source rows / columns of this tile (align_corners = False, factor 4: src = (dst + 0.5) / 4 - 0.5, clamped at 0)
   const int ys0 = max((y >> 1) - ((y & 1) ? 0 : 1), 0), ys1 = min(((y >> 1) - ((y & 1) ? 0 : 1)) + 1, h16 - 1);
@@ -356,31 +363,46 @@ __global__ __launch_bounds__(256) void adapter_res2_kernel(const float *__restri
     }
   }
   __syncthreads();
-  const int X = 2 * tx + lane;                         // this lane's output column
-  const bool x_ok = lane < 2 * ntok;
-  float fx = ((float)X + 0.5f) * 0.25f - 0.5f;
-  fx = fx < 0.f ? 0.f : fx;
-  const int xi0 = min((int)fx, w16 - 1), xi1 = min(xi0 + 1, w16 - 1);
-  const float lx1 = fx - (float)xi0, lx0 = 1.f - lx1;
-  const int cA = xi0 - xc0, cB = xi1 - xc0;            // staged columns (0 .. 17)
-  for (int r = wv; r < 128; r += 4) {
-    const int c = r >> 1, dy = r & 1, co = co0 + c;
+  // output: a lane writes 4 consecutive columns (16 bytes) of one (channel, dy) row, a wave four rows per instruction
+  const int xl = lane & 15, rr = lane >> 4;
+  const bool x_ok = 4 * xl < 2 * ntok;                 // (w8 even -> ntok even: whole float4s)
+  int cA[4], cB[4];
+  float lx0[4], lx1[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float fx = ((float)(2 * tx + 4 * xl + e) + 0.5f) * 0.25f - 0.5f;
+    fx = fx < 0.f ? 0.f : fx;
+    const int xi0 = min((int)fx, w16 - 1), xi1 = min(xi0 + 1, w16 - 1);
+    lx1[e] = fx - (float)xi0, lx0[e] = 1.f - lx1[e];
+    cA[e] = min(max(xi0 - xc0, 0), 17), cB[e] = min(max(xi1 - xc0, 0), 17);      // staged columns (lanes past the row's end: clamped, unused)
+  }
+  for (int R = wv * 4 + rr; R < 128; R += 16) {
+    const int c = R >> 1, dy = R & 1, co = co0 + c;
     const int Y = 2 * y + dy;
-    float up = 0.f;
+    float up[4] = {0.f, 0.f, 0.f, 0.f};
     if (x1 != nullptr) {
       float fy = ((float)Y + 0.5f) * 0.25f - 0.5f;
       fy = fy < 0.f ? 0.f : fy;
       const int yi0 = min((int)fy, h16 - 1);
       const float ly1 = fy - (float)yi0, ly0 = 1.f - ly1;
       const int rA = yi0 == ys0 ? 0 : 1, rB = (min(yi0 + 1, h16 - 1)) == ys0 ? 0 : 1;
-      // the order of F.interpolate's bilinear kernel: w00 * v00 + w01 * v01 + w10 * v10 + w11 * v11 with wij = ly_i * lx_j
-      up = ly0 * (lx0 * xs[(rA * 18 + cA) * TS + c] + lx1 * xs[(rA * 18 + cB) * TS + c]) +
-           ly1 * (lx0 * xs[(rB * 18 + cA) * TS + c] + lx1 * xs[(rB * 18 + cB) * TS + c]);
+      // the order of F.interpolate's bilinear kernel: ly0 (lx0 v00 + lx1 v01) + ly1 (lx0 v10 + lx1 v11)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        up[e] = ly0 * (lx0[e] * xs[(rA * 18 + cA[e]) * TS + c] + lx1[e] * xs[(rA * 18 + cB[e]) * TS + c]) +
+                ly1 * (lx0[e] * xs[(rB * 18 + cA[e]) * TS + c] + lx1[e] * xs[(rB * 18 + cB[e]) * TS + c]);
     }
     if (x_ok) {
-      const size_t o = (((size_t)b * C + co) * H4 + Y) * (size_t)W4 + X;
-      const float gv = gs[((dy * 2 + (lane & 1)) * 32 + (lane >> 1)) * TS + c];
-      out[o] = gv + scale[co] * (c1[o] + up) + shift[co];
+      const size_t o = (((size_t)b * C + co) * H4 + Y) * (size_t)W4 + 2 * tx + 4 * xl;
+      const float4 cv = *reinterpret_cast<const float4 *>(c1 + o);
+      const float sc = scale[co], sh = shift[co];
+      const float *gq = &gs[(dy * 2 * 32 + 2 * xl) * TS + c];          // (sub = 2 dy + dx, token 2 xl + t): columns 4 xl + 2 t + dx
+      float4 v;
+      v.x = gq[0] + sc * (cv.x + up[0]) + sh;
+      v.y = gq[32 * TS] + sc * (cv.y + up[1]) + sh;
+      v.z = gq[TS] + sc * (cv.z + up[2]) + sh;
+      v.w = gq[33 * TS] + sc * (cv.w + up[3]) + sh;
+      *reinterpret_cast<float4 *>(out + o) = v;
     }
   }
 }
@@ -596,6 +618,7 @@ DVIS_EXPORT int dvis_dwconv3x3_tokens(const float *x, float *out, int64_t batch_
 DVIS_EXPORT int dvis_adapter_res2(const float *g, const float *c1, const float *x1, const float *scale, const float *shift, float *out,
                                   int B, int C, int h8, int w8, void *stream) {
   DVIS_REQUIRE(g && c1 && scale && shift && out, "adapter_res2: null pointer");
+  DVIS_REQUIRE(((uintptr_t)g | (uintptr_t)c1 | (uintptr_t)out) % 16 == 0, "adapter_res2: g / c1 / out must be 16-byte aligned");
   DVIS_REQUIRE(B >= 0 && C > 0 && C % 64 == 0 && h8 > 0 && w8 > 0 && h8 % 2 == 0 && w8 % 2 == 0,
                "adapter_res2: C %% 64 == 0 and an even stride-8 grid are required (C %d, grid %d x %d)", C, h8, w8);
   DVIS_REQUIRE((int64_t)B * h8 <= 65535 && C / 64 <= 65535, "adapter_res2: grid too large (B * rows %lld)", (long long)B * h8);
