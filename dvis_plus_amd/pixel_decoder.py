@@ -165,7 +165,9 @@ class MSDeformAttn(nn.Module):
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
                 input_padding_mask=None, spatial_shapes_py=None, query_pos=None, post=None):
         """Reference signature + optional extras.  post: (residual, LayerNorm) — return ``norm(residual + forward(...))``,
-        the encoder layer's next step (msdeformattn.py:124-125), fused into the output projection where that is served.
+        the encoder layer's next step (msdeformattn.py:124-125), fused into the output projection where that is served;
+        (residual, None) — return ``residual + forward(...)`` (the ViT-Adapter extractor's ``query + attn``), the add in the
+        projection's epilogue.
         `spatial_shapes_py`: a python copy of the shapes.  When the
         queries are the pixels themselves (encoder self-attention) it lets the kernel give each block an 8x8 pixel
         tile (cache locality); results do not depend on it.
@@ -175,7 +177,9 @@ class MSDeformAttn(nn.Module):
         if post is not None:
             out = self._forward(query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
                                 input_padding_mask, spatial_shapes_py, query_pos, post)
-            return out[0] if isinstance(out, tuple) else Fn.add_layer_norm(out, post[0], post[1])
+            if isinstance(out, tuple):
+                return out[0]
+            return out + post[0] if post[1] is None else Fn.add_layer_norm(out, post[0], post[1])
         return self._forward(query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
                              input_padding_mask, spatial_shapes_py, query_pos, None)
 
@@ -195,7 +199,8 @@ class MSDeformAttn(nn.Module):
         x3 = fast and Fn.x3_on() and not lowp and not hm and not _MSDA_SLOTS and Fn.x3_ok(input_flatten, self.d_model, self.d_model) \
             and Fn.x3_ok(query, 3 * M * L * P, self.d_model)
         if x3:
-            value = Fn.x3_linear(input_flatten, self.value_proj.weight, self.value_proj.bias).view(N, Len_in, M, -1)
+            # (Fn.linear: the tiled split-f16 kernel from K = 512 on — the ViT-Adapter extractors' d_model = 1024 — else the streaming one)
+            value = Fn.linear(input_flatten, self.value_proj.weight, self.value_proj.bias, tall=True).view(N, Len_in, M, -1)
         elif hm:
             # own GEMM with a head-major epilogue: value[m, n, s, :] — neighbouring pixels of a head are adjacent lines
             value = Fn.gemm_nt(input_flatten.view(N * Len_in, self.d_model), self.value_proj.weight.detach(),
@@ -229,11 +234,13 @@ class MSDeformAttn(nn.Module):
             output = Fn.msda_fused_forward(value, input_spatial_shapes, input_level_start_index, ref,
                                            proj[:, o_off:], proj[:, l_off:], L, P, shapes_host=spatial_shapes_py,
                                            pos_offsets=po, pos_logits=pl, head_stride=slot, value_head_major=hm)
-            if x3 and post is not None and Fn.x3_ok(output, self.d_model, self.d_model, ln=True) \
+            if x3 and post is not None and post[1] is None and post[0].shape[:-1] == output.shape[:-1] and post[0].dtype == torch.float32:
+                return (Fn.linear(output, self.output_proj.weight, self.output_proj.bias, tall=True, residual=post[0]),)
+            if x3 and post is not None and post[1] is not None and Fn.x3_ok(output, self.d_model, self.d_model, ln=True) \
                     and post[0].shape == output.shape and post[0].dtype == torch.float32 and post[1].weight is not None:
                 return (Fn.x3_linear_ln(output, self.output_proj.weight, self.output_proj.bias, post[0], post[1]),)
             if x3:
-                return Fn.x3_linear(output, self.output_proj.weight, self.output_proj.bias)
+                return Fn.linear(output, self.output_proj.weight, self.output_proj.bias, tall=True)
             return Fn.linear(output, self.output_proj.weight, self.output_proj.bias, tall=True)
         if query_pos is not None:
             query = query + query_pos

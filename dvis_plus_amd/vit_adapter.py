@@ -257,9 +257,9 @@ class Extractor(nn.Module):
             self.ffn_norm = LayerNorm(dim)
 
     def forward(self, query, reference_points, feat, spatial_shapes, level_start_index, H, W, shapes_py=None):
-        attn = self.attn(Fn.add_layer_norm(query, None, self.query_norm), reference_points,
-                         Fn.add_layer_norm(feat, None, self.feat_norm), spatial_shapes, level_start_index, None)
-        query = query + attn
+        query = self.attn(Fn.add_layer_norm(query, None, self.query_norm), reference_points,
+                          Fn.add_layer_norm(feat, None, self.feat_norm), spatial_shapes, level_start_index, None,
+                          post=(query, None))                      # query + attn: the add in the output projection's epilogue
         if self.with_cffn:
             query = self.ffn(Fn.add_layer_norm(query, None, self.ffn_norm), H, W, residual=query)
         return query
