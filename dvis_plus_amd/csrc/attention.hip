@@ -1143,6 +1143,20 @@ DVIS_EXPORT int dvis_attention_forward(const float *q, const int64_t *q_strides,
                           scale, ws, stream, 0);
 }
 
+// Kernel 2's second launch alone: Q, K, V are already in `ws` as two-term f16 images (written by dvis_x3_tile_linear_qkv, the qkv
+// projection's epilogue) — self-attention of B x heads (batch, head) pairs over L tokens at d = 64, no mask.
+DVIS_EXPORT int dvis_attention_x3_packed(const void *ws, float *out, const int64_t *o_strides, int B, int heads, int L, void *stream) {
+  DVIS_REQUIRE(ws && out && o_strides && B >= 0 && heads > 0 && L >= 128, "attention_x3_packed: bad arguments (L >= 128)");
+  DVIS_REQUIRE((uintptr_t)ws % 16 == 0, "attention_x3_packed: workspace must be 16-byte aligned");
+  if (B == 0) return DVIS_OK;
+  const int BH = B * heads;
+  const dvis_strides os{o_strides[0], o_strides[1], o_strides[2]};
+  const X3Guard gd = dvis_x3_guard();
+  hipLaunchKernelGGL(attn_x3_kernel<1>, dim3(((BH + 7) / 8) * 8 * ((L + 127) / 128)), dim3(512), 0, (hipStream_t)stream, (const _Float16 *)ws, out,
+                     os, BH, heads, L, L, gd.flag, gd.tag);
+  return dvis_check_launch("attn_x3_kernel");
+}
+
 DVIS_EXPORT int dvis_attention_forward_k(const float *q, const int64_t *q_strides, const float *k, const int64_t *k_strides,
                                          const float *v, const int64_t *v_strides, float *out, const int64_t *o_strides,
                                          const uint8_t *mask, const int32_t *allowed_count, int B, int heads, int Lq,

@@ -45,6 +45,11 @@ struct TileArgs {
   int *flag;
   int tag;
   int tm, tn;                        // tiles along M / N
+  // PACK form (the ViT blocks' qkv projection): instead of `out`, the two-term f16 images the split-f16 attention kernel reads
+  // (csrc/attention.hip: [matrix q, k, v][batch-head][token][hi 64 | lo 64]); rows are (batch entry, token) with pack_L tokens per entry
+  _Float16 *pack_ws;
+  int pack_heads, pack_L;
+  float pack_qscale;                 // Q's factor (softmax scale x log2(e) x 2^4); K and V carry 2^4
 };
 
 // Packed weights: [n-tile][k-tile of 16][hi, lo][chunk 0, 1][256 rows][8 halves] = 16 KB per (n-tile, k-tile).
@@ -74,7 +79,7 @@ __global__ void x3_tile_pack_kernel(const float *__restrict__ w, int64_t ldw, in
   }
 }
 
-template <bool GELU>
+template <bool GELU, bool PACK = false>
 __global__ __launch_bounds__(256, 2) void x3_tile_kernel(TileArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -179,6 +184,45 @@ __global__ __launch_bounds__(256, 2) void x3_tile_kernel(TileArgs a) {
 
   float chk = 0.f;
   const bool full = m0 + k2TM <= a.M;
+  if constexpr (PACK) {
+    // qkv -> the attention kernel's operand images: column n = (matrix, head, dim), row m = (batch entry, token); 32 lanes hold 32
+    // consecutive dims of one head: 64 contiguous bytes per store for the hi terms, 64 for the lo terms
+    const int Cq = a.pack_heads * 64;
+    const size_t BH = (size_t)((a.M + a.pack_L - 1) / a.pack_L) * a.pack_heads;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      const int n = nt * kTN + wn * 128 + nb * 32 + r;
+      const float bv = a.bias ? a.bias[n] : 0.f;
+      const int which = n / Cq, hd = (n - which * Cq) >> 6, dim = n & 63;
+      const float f = which == 0 ? a.pack_qscale : 16.f;
+      _Float16 *base = a.pack_ws + ((size_t)which * BH * a.pack_L) * 128 + dim;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const int64_t mrow = m0 + wm * 64 + mb * 32 + 4 * g;
+        const int64_t b0 = mrow / a.pack_L;
+        const int t0 = (int)(mrow - b0 * a.pack_L);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int d = 8 * (i >> 2) + (i & 3);
+          const int64_t m = mrow + d;
+          int tok = t0 + d;
+          int64_t be = b0;
+          if (tok >= a.pack_L) tok -= a.pack_L, be += 1;       // (d < 32 <= pack_L: one wrap at most)
+          const float t = acc[mb][nb][i] * a.inv + bv;
+          chk = __builtin_fmaf(t, 0.f, chk);
+          const float sv = t * f;
+          const _Float16 h = (_Float16)sv;
+          if (full || m < a.M) {
+            _Float16 *dst = base + ((size_t)(be * a.pack_heads + hd) * a.pack_L + tok) * 128;
+            dst[0] = h;
+            dst[64] = (_Float16)(sv - (float)h);
+          }
+        }
+      }
+    }
+    if (a.flag != nullptr && chk != chk) atomicCAS(a.flag, 0, a.tag);
+    return;
+  }
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb) {
     const int n = nt * kTN + wn * 128 + nb * 32 + r;
@@ -226,6 +270,32 @@ DVIS_EXPORT int dvis_x3_tile_pack(const float *w, int64_t ldw, int N, int K, int
   hipLaunchKernelGGL(x3_tile_pack_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, ldw, N, K,
                      ldexpf(1.f, wexp), (_Float16 *)packed, pieces);
   return dvis_check_launch("dvis_x3_tile_pack");
+}
+
+// The ViT blocks' qkv projection writing the split-f16 attention kernel's operand images directly (no fp32 qkv tensor, no pack
+// pass): x (B * L rows) W^T + bias with N = 3 * heads * 64 columns ordered (q | k | v, head, dim) -> ws as attn_x3_pack_kernel
+// leaves it.  qscale = softmax scale x log2(e) x 2^4.
+DVIS_EXPORT int dvis_x3_tile_linear_qkv(const float *x, int64_t ldx, int64_t M, int K, const void *wp, int N, int xexp, int wexp,
+                                        const float *bias, int heads, int L, float qscale, void *ws, void *stream) {
+  DVIS_REQUIRE(dvis_x3_tile_supported(N, K) && heads > 0 && N == 3 * heads * 64, "dvis_x3_tile_linear_qkv: N must be 3 * heads * 64 (N %d, heads %d), K %% 32 == 0", N, heads);
+  DVIS_REQUIRE(x && wp && ws && M >= 0 && L >= 32 && M % L == 0, "dvis_x3_tile_linear_qkv: rows must be whole batch entries of L >= 32 tokens (M %lld, L %d)", (long long)M, L);
+  DVIS_REQUIRE(((uintptr_t)x | (uintptr_t)wp | (uintptr_t)ws) % 16 == 0 && ldx % 4 == 0 && ldx >= K, "dvis_x3_tile_linear_qkv: 16-byte alignment, ldx %% 4 == 0");
+  if (M == 0) return DVIS_OK;
+  TileArgs a = {};
+  a.x = x, a.ldx = ldx, a.M = M, a.K = K, a.N = N, a.wp = (const char *)wp;
+  a.xscale = ldexpf(1.f, xexp), a.inv = ldexpf(1.f, -(xexp + wexp));
+  a.bias = bias;
+  a.pack_ws = (_Float16 *)ws, a.pack_heads = heads, a.pack_L = L, a.pack_qscale = qscale;
+  const X3Guard gd = dvis_x3_guard();
+  a.flag = gd.flag, a.tag = gd.tag;
+  const int64_t tm = (M + k2TM - 1) / k2TM;
+  a.tm = (int)tm, a.tn = N / kTN;
+  const int64_t grid = (tm + 7) / 8 * 8 * a.tn;
+  DVIS_REQUIRE(grid < ((int64_t)1 << 31), "dvis_x3_tile_linear_qkv: too many tiles");
+  static DvisLdsOptIn op;
+  if (const int rc = dvis_lds_opt_in((const void *)x3_tile_kernel<false, true>, k2Lds, &op, "x3_tile_kernel")) return rc;
+  hipLaunchKernelGGL((x3_tile_kernel<false, true>), dim3((unsigned)grid), dim3(256), k2Lds, (hipStream_t)stream, a);
+  return dvis_check_launch("x3_tile_kernel (qkv pack)");
 }
 
 DVIS_EXPORT int dvis_x3_tile_linear(const float *x, int64_t ldx, int64_t M, int K, const void *wp, int N, int xexp, int wexp,

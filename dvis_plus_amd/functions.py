@@ -1139,6 +1139,42 @@ def x3_tile_linear(x, weight, bias, act=None, residual=None, xexp=None):
     return out
 
 
+X3_QKV_FUSED = os.environ.get("DVIS_X3_QKV_FUSED", "1") != "0"
+
+
+def x3_qkv_attention_ok(x, weight, heads):
+    """Can ``self_attention(x @ weight.T + bias)`` take the fused form (dvis_x3_tile_linear_qkv + dvis_attention_x3_packed)?
+    x (B, L, C) float32 GPU inference tensor, weight (3C, C), head dim 64, L >= 1024 (the ViT blocks)."""
+    if not (X3_QKV_FUSED and x.dim() == 3 and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+            and not torch.is_autocast_enabled() and x3_on() and weight.dim() == 2 and weight._base is None):
+        return False
+    B, L, C = x.shape
+    return (C == heads * 64 and weight.shape == (3 * C, C) and L >= 1024 and x.is_contiguous() and x.data_ptr() % 16 == 0
+            and x3_tile_ok(x, 3 * C, C))
+
+
+def x3_qkv_attention(x, weight, bias, heads):
+    """softmax(q k^T / 8) v per head for qkv = x @ weight.T + bias (columns ordered q | k | v, head, dim), x (B, L, C), head dim 64:
+    the projection's epilogue writes the split-f16 attention kernel's operand images, the attention kernel reads them — the fp32
+    qkv tensor and the pack pass do not exist.  -> (B, L, C)."""
+    B, L, C = x.shape
+    buf, wexp = x3_tile_pack(weight)
+    lib = native.lib()
+    nbytes = lib.dvis_attention_ws_bytes_k(B * heads, L, L, 64, 2)
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+    out = torch.empty((B, L, C), dtype=torch.float32, device=x.device)
+    qscale = (1.0 / 8.0) * 1.4426950408889634 * 16.0
+    with torch.cuda.device(x.device):
+        native.check(lib.dvis_x3_tile_linear_qkv(
+            ctypes.c_void_p(x.data_ptr()), C, B * L, C, ctypes.c_void_p(buf.data_ptr()), 3 * C, X3_XEXP, wexp,
+            None if bias is None else native.dev_ptr(bias.detach(), "bias"), heads, L, qscale, ctypes.c_void_p(ws.data_ptr()),
+            native.stream_ptr(x.device)), "dvis_x3_tile_linear_qkv")
+        strides = (ctypes.c_int64 * 3)(L * C, 64, C)
+        native.check(lib.dvis_attention_x3_packed(ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(out.data_ptr()), strides, B, heads, L,
+                                                  native.stream_ptr(x.device)), "dvis_attention_x3_packed")
+    return out
+
+
 def x3_ok(x, N, K, ln=False, add=False):
     """Does csrc/gemm_x3.hip serve ``x (..., K) @ W (N, K).T``?  ln: the output_proj + residual + LayerNorm form; add: the form
     with the in-kernel ``x + xadd`` (dvis_x3_linear_add: K = 256 only)."""

@@ -84,6 +84,9 @@ class Attention(nn.Module):
     def core(self, x):
         """(B, N, C) -> attention output before the out-projection, (B, N, C)."""
         B, N, C = x.shape
+        if Fn.x3_qkv_attention_ok(x, self.qkv.weight, self.num_heads):
+            # the projection's epilogue writes the attention kernel's split-f16 operands: no fp32 qkv tensor, no pack pass
+            return Fn.x3_qkv_attention(x, self.qkv.weight, self.qkv.bias, self.num_heads)
         qkv = Fn.linear(x, self.qkv.weight, self.qkv.bias, tall=True)                       # (B, N, 3C)
         v = qkv.transpose(0, 1)                                                    # (N, B, 3C) view: rows strided
         out = torch.empty((B, N, C), dtype=x.dtype, device=x.device)

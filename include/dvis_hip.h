@@ -584,6 +584,15 @@ int64_t dvis_x3_tile_packed_bytes(int N, int K);
 int dvis_x3_tile_pack(const float *w, int64_t ldw, int N, int K, int wexp, void *packed, void *stream);
 int dvis_x3_tile_linear(const float *x, int64_t ldx, int64_t M, int K, const void *wp, int N, int xexp, int wexp, const float *bias, int act,
                         const float *res, int64_t ldres, float *out, int64_t ldo, void *stream);
+/* The ViT blocks' fused qkv projection + attention operands (backbones_vitAdapter attention: `qkv = self.qkv(x)`, then softmax(q k^T
+ * / sqrt(d)) v per head): dvis_x3_tile_linear_qkv computes x W^T + bias for N = 3 * heads * 64 columns ordered (q | k | v, head, dim)
+ * and writes, instead of the fp32 qkv tensor, the two-term f16 operand images of the split-f16 attention kernel into `ws`
+ * (dvis_attention_ws_bytes_k(B * heads, L, L, 64, 2) bytes; rows of x = B batch entries of L tokens; qscale = softmax scale x log2(e)
+ * x 2^4); dvis_attention_x3_packed then runs that kernel's main launch on `ws` (out: (B, heads, L, 64) view, strides in floats as in
+ * dvis_attention_forward).  Saves the 1.36 GB qkv tensor's write + re-read and the pack launch per block. */
+int dvis_x3_tile_linear_qkv(const float *x, int64_t ldx, int64_t M, int K, const void *wp, int N, int xexp, int wexp, const float *bias,
+                            int heads, int L, float qscale, void *ws, void *stream);
+int dvis_attention_x3_packed(const void *ws, float *out, const int64_t *o_strides, int B, int heads, int L, void *stream);
 /* out = LayerNorm( x W^T + bias + res ) over the N = 256 features (gamma, beta, eps; two-pass statistics as torch);
  * pos (pos_rows x N, optional): out2[t] = out[t] + pos[t mod pos_rows] (the next layer's `with_pos_embed(src, pos)`,
  * msdeformattn.py:99-101,122).  Replaces output_proj + `src = norm1(src + dropout1(src2))`, msdeformattn.py:124-125. */

@@ -195,3 +195,28 @@ def test_long_self_attention_on_split_f16_products_vs_fp64(L, B, H, monkeypatch)
     Fn.attention(dq, dk, dv, H)
     with pytest.raises(Fn.X3RangeError):
         Fn.X3_GUARD.check_now(dq.device)
+
+
+@pytest.mark.parametrize("B,L,heads", [(2, 1100, 8), (3, 1024, 8), (1, 1283, 16)])
+def test_qkv_projection_writing_the_attention_operands_equals_projection_then_attention(B, L, heads):
+    """dvis_x3_tile_linear_qkv + dvis_attention_x3_packed (the ViT blocks' `attn(qkv(x))`, backbones_vitAdapter) against fp64, and
+    against the unfused product path (Fn.linear -> Fn.attention): batch entries that straddle the GEMM's row tiles, ragged L."""
+    from dvis_plus_amd import functions as Fn
+    if not Fn.X3:
+        pytest.skip("DVIS_X3=0")
+    C = heads * 64
+    g = torch.Generator().manual_seed(B * L + heads)
+    x = torch.randn(B, L, C, generator=g).to(DEV)
+    w = (torch.randn(3 * C, C, generator=g) * (C ** -0.5)).to(DEV)
+    b = (torch.randn(3 * C, generator=g) * 0.1).to(DEV)
+    with torch.no_grad():
+        assert Fn.x3_qkv_attention_ok(x, w, heads)
+        out = Fn.x3_qkv_attention(x, w, b, heads)
+        qkv = (x.double() @ w.double().t() + b.double()).view(B, L, 3, heads, 64).permute(2, 0, 3, 1, 4)      # (3, B, h, L, 64)
+        p = torch.softmax(qkv[0] @ qkv[1].transpose(-1, -2) / 8.0, -1)
+        ref = (p @ qkv[2]).permute(0, 2, 1, 3).reshape(B, L, C)
+        q32 = Fn.linear(x, w, b, tall=True).transpose(0, 1)
+        unfused = torch.empty_like(out)
+        Fn.attention(q32[..., :C], q32[..., C:2 * C], q32[..., 2 * C:], heads, out=unfused.transpose(0, 1))
+    err, err_u = float((out.double() - ref).abs().max()), float((unfused.double() - ref).abs().max())
+    assert err <= 2e-5 and err <= 3 * err_u + 1e-6, (err, err_u)
