@@ -146,9 +146,10 @@ class ResNet(nn.Module):
         return {k: ShapeSpec(channels=self._out_channels[k], stride=2 ** int(k[3:]))
                 for k in self._out_features}
 
+    @Fn.fp32_island
     def forward(self, x):
         out = {}
-        x = self.stem(x)
+        x = self.stem(Fn.f32(x))
         for name in self.stage_names:
             x = getattr(self, name)(x)
             if name in self._out_features:

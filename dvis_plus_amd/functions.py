@@ -32,6 +32,43 @@ def _torch_path(op, x, why):
                            f"{tuple(x.shape)}, dtype {x.dtype}, contiguous {x.is_contiguous()})")
 
 
+class no_autocast:
+    """``with no_autocast(): ...`` — torch.autocast switched off (CUDA and CPU) for the enclosed calls: the fp32 island around the
+    hand-written fp32 / split-f16 path.  The reference's launcher evaluates under ``with autocast():`` (train_net_video.py:259)
+    and only its pixel decoder opts out (msdeformattn.py:314,320); here the WHOLE model does: under the launcher's context the
+    results are the ones of the plain call, bit for bit (fp32 storage, within BASELINE's 1e-3 of the fp32 CPU reference — the
+    reference's own GPU run is the half-precision one and is further from it)."""
+
+    def __enter__(self):
+        import contextlib
+        self._stack = contextlib.ExitStack()
+        self._stack.enter_context(torch.autocast(device_type="cuda", enabled=False))
+        self._stack.enter_context(torch.autocast(device_type="cpu", enabled=False))
+        return self
+
+    def __exit__(self, *exc):
+        return self._stack.__exit__(*exc)
+
+
+def fp32_island(fn):
+    """Decorator form of ``no_autocast`` for a module's ``forward`` (not for generators: a context must not stay entered
+    across a ``yield`` — the consumer's code would run with autocast off)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        if not (torch.is_autocast_enabled() or torch.is_autocast_enabled("cpu")):
+            return fn(*args, **kwargs)
+        with no_autocast():
+            return fn(*args, **kwargs)
+    return wrapper
+
+
+def f32(t):
+    """A half / double tensor handed over by an autocast region outside the island -> float32 (None and fp32 tensors pass)."""
+    return t if t is None or not torch.is_tensor(t) or not t.is_floating_point() or t.dtype == torch.float32 else t.float()
+
+
 def _check_msda_inputs(value, spatial_shapes, level_start_index, sampling_loc, attn_weight):
     for name, t in (("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
                     ("sampling_loc", sampling_loc), ("attn_weight", attn_weight)):
@@ -834,7 +871,14 @@ def linear(x, weight, bias=None, relu=False, own=None, tall=False, act=None, res
         y = linear(x, weight, bias, relu=relu or act == "relu", own=own, tall=tall)
         if act == "gelu":
             y = torch.nn.functional.gelu(y)
-        return y if residual is None else y.add_(residual) if not torch.is_grad_enabled() else y + residual
+        if residual is None:
+            return y
+        # in place only where that cannot change the result's dtype: under torch.autocast y is fp16 / bf16 and the reference's
+        # `x = x + ls(attn(norm(x)))` promotes to the residual stream's fp32
+        if not torch.is_grad_enabled() and y.dtype == residual.dtype and not torch.is_autocast_enabled() \
+                and not torch.is_autocast_enabled("cpu"):
+            return y.add_(residual)
+        return residual + y
     own = OWN_GEMM_DEFAULT if own is None else own
     if own and x.is_cuda and not torch.is_grad_enabled() and (forced or not torch.is_autocast_enabled()):
         # (under torch.autocast — how the reference evaluates, train_net_video.py:259 — the projections are torch's half-precision

@@ -76,6 +76,7 @@ class MaskFormerHead(nn.Module):
             "transformer_predictor": d2.build_transformer_decoder(cfg, in_channels, mask_classification=True),
         }
 
+    @Fn.fp32_island
     def forward(self, features, mask=None):
         mask_features, _, multi_scale_features = self.pixel_decoder.forward_features(features)
         return self.predictor(multi_scale_features, mask_features, mask)
@@ -320,6 +321,7 @@ class MinVIS(_VideoBase):
         return ret
 
     @torch.no_grad()
+    @Fn.fp32_island
     def forward(self, batched_inputs):
         assert len(batched_inputs) == 1 and not self.training
         from . import functions as Fn
@@ -368,6 +370,7 @@ class DVIS_Plus_online(_VideoBase):
         return ret
 
     @torch.no_grad()
+    @Fn.fp32_island
     def forward(self, batched_inputs):
         assert len(batched_inputs) == 1 and not self.training
         video = batched_inputs[0]
@@ -702,7 +705,9 @@ class DVIS_Plus_offline(_VideoBase):
             # clips): no rotation — a clip takes ceil(T / world) frames of segmenter time whoever holds the short block,
             # and a fixed split means every rank keeps ONE batch shape (a new convolution shape costs a MIOpen solver
             # search, seconds).
-            sts = self._segment_round_reserved(chunk, n if sharded_owner else 0, sharded_owner) if chunk else []
+            # (the fp32 island of forward(), entered per step: a context must not stay open across a `yield`)
+            with Fn.no_autocast():
+                sts = self._segment_round_reserved(chunk, n if sharded_owner else 0, sharded_owner) if chunk else []
             n += len(chunk)
             if overlap and sts:
                 done = torch.cuda.Event()
@@ -710,7 +715,9 @@ class DVIS_Plus_offline(_VideoBase):
                 for st in sts:
                     st["done"] = done
             if prev is not None:
-                yield from hand_over(phase_b(prev))
+                with Fn.no_autocast():
+                    outs = hand_over(phase_b(prev))
+                yield from outs
             prev = sts or None
             if not sts:
                 break
@@ -763,7 +770,8 @@ class DVIS_Plus_offline(_VideoBase):
                 chunk = list(itertools.islice(it, per_round))
                 if not chunk:
                     break
-                sts = self._segment_round_reserved(chunk, n if sharded_owner else 0, sharded_owner)
+                with Fn.no_autocast():
+                    sts = self._segment_round_reserved(chunk, n if sharded_owner else 0, sharded_owner)
                 n += len(chunk)
                 done = torch.cuda.Event()
                 done.record(main)
@@ -794,6 +802,7 @@ class DVIS_Plus_offline(_VideoBase):
             main.wait_stream(self._tracker_stream)
 
     @torch.no_grad()
+    @Fn.fp32_island
     def forward(self, batched_inputs):
         assert len(batched_inputs) == 1 and not self.training
         video = batched_inputs[0]
@@ -1081,6 +1090,7 @@ class MaskFormer(nn.Module):
         return {"pred_masks": pred_masks, "scores": scores_per_image * mask_scores, "pred_classes": labels_per_image}
 
     @torch.no_grad()
+    @Fn.fp32_island
     def forward(self, batched_inputs):
         assert not self.training, "dvis_plus_amd implements the inference path"
         sizes = [tuple(x["image"].shape[-2:]) for x in batched_inputs]

@@ -129,12 +129,14 @@ class TemporalRefiner(nn.Module):
         class_output = (decoder_output * activation).sum(dim=2, keepdim=True).repeat(1, 1, T, 1, 1)
         return Fn.linear(class_output, ce.weight, ce.bias, own=True).transpose(2, 3)
 
+    @Fn.fp32_island
     def forward(self, instance_embeds, frame_embeds, mask_features, need_masks=True, query_index=None):
         """instance_embeds / frame_embeds (b, c, t, q), mask_features (b, t, c, h, w) device-resident.
         Returns pred_logits (b,t,q,K+1), pred_masks (b,q',t,h,w) [q' = len(query_index) if given] or None,
         pred_embds (b,c,t,q), mask_embed (b,t,q,Cm)."""
         if self.training:
             raise NotImplementedError("dvis_plus_amd implements the refiner's inference path")
+        instance_embeds, frame_embeds, mask_features = Fn.f32(instance_embeds), Fn.f32(frame_embeds), Fn.f32(mask_features)
         self._kv_weights()
         for seq in self.conv_short_aggregate_layers:                               # cached GEMM weights, outside capture
             self._conv_weights.get(seq[0]), self._conv_weights.get(seq[2])

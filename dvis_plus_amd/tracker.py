@@ -255,6 +255,7 @@ class ReferringTracker_noiser(nn.Module):
                 last_outputs = outputs[T - 1]
         return outputs, refs, last_outputs
 
+    @Fn.fp32_island
     def forward(self, frame_embeds, mask_features, resume=False, return_indices=False, frame_classes=None,
                 frame_embeds_no_norm=None, need_masks=True):
         """frame_embeds (b, c, t, q); mask_features (b, t, c, h, w) [may be None when need_masks=False].
@@ -262,6 +263,7 @@ class ReferringTracker_noiser(nn.Module):
         pred_embds (b,c,t,q), pred_references (b,c,t,q), aux_outputs []."""
         if self.training:
             raise NotImplementedError("dvis_plus_amd implements the tracker's inference path")
+        frame_embeds, frame_embeds_no_norm, mask_features = Fn.f32(frame_embeds), Fn.f32(frame_embeds_no_norm), Fn.f32(mask_features)
         fe = frame_embeds.permute(2, 3, 0, 1)                                  # (t, q, b, c)
         fe_nn = fe if frame_embeds_no_norm is None else frame_embeds_no_norm.permute(2, 3, 0, 1)
         T, Q, B, C = fe.shape

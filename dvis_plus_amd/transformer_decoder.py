@@ -217,6 +217,16 @@ class _MaskedDecoderBase(nn.Module):
             self._kv_cache = ((ver, dev), per_level)
         return self._kv_cache[1]
 
+    @staticmethod
+    def _f32_inputs(x, mask_features):
+        """Maps handed over by a half-precision region outside the island (a foreign backbone / pixel decoder under autocast)."""
+        if any(m.dtype != torch.float32 for m in x):
+            tokens = getattr(x, "tokens", None)
+            x = type(x)(Fn.f32(m) for m in x)
+            if tokens is not None:
+                x.tokens = [Fn.f32(t) for t in tokens]
+        return x, Fn.f32(mask_features)
+
     def _run_layers(self, x, mask_features):
         """x: 3 feature maps (N, C, h_l, w_l), low-res first; mask_features (N, Cm, H, W).
         Returns the un-normed residual stream (Q, N, C) after the last layer."""
@@ -291,8 +301,10 @@ class MultiScaleMaskedTransformerDecoder(_MaskedDecoderBase):
     def from_config(cls, cfg, in_channels, mask_classification):
         return cls._base_from_config(cfg, in_channels, mask_classification)
 
+    @Fn.fp32_island
     def forward(self, x, mask_features, mask=None):
         assert len(x) == self.num_feature_levels
+        x, mask_features = self._f32_inputs(x, mask_features)
         output = self._run_layers(x, mask_features)
         _, logits, masks = self._final_heads(output, mask_features, True)
         return {"pred_logits": logits, "pred_masks": masks, "aux_outputs": []}
@@ -324,6 +336,7 @@ class VideoMultiScaleMaskedTransformerDecoder_dvisPlus(_MaskedDecoderBase):
                    num_reid_head_layers=cfg.MODEL.MASK_FORMER.NUM_REID_HEAD_LAYERS)
         return ret
 
+    @Fn.fp32_island
     def forward(self, x, mask_features, mask=None):
         """Eval semantics of the reference (bs = 1: all frames form one clip).  Shapes as in the reference:
         pred_logits (1,T,Q,K+1), pred_masks (1,Q,T,H,W) or None, pred_embds / pred_embds_without_norm (1,2C,T,Q),
@@ -331,6 +344,7 @@ class VideoMultiScaleMaskedTransformerDecoder_dvisPlus(_MaskedDecoderBase):
         assert len(x) == self.num_feature_levels
         if self.training:
             raise NotImplementedError("dvis_plus_amd decoders implement the inference path")
+        x, mask_features = self._f32_inputs(x, mask_features)
         output = self._run_layers(x, mask_features)
         dec, logits, masks = self._final_heads(output, mask_features, self.compute_pred_masks)
         reid = self.reid_embed(dec)                                                              # (T, Q, C)
@@ -366,9 +380,11 @@ class VideoMultiScaleMaskedTransformerDecoder_dvis(_MaskedDecoderBase):
         ret.update(num_frames=cfg.INPUT.SAMPLING_FRAME_NUM)
         return ret
 
+    @Fn.fp32_island
     def forward(self, x, mask_features, mask=None):
         if self.training:
             raise NotImplementedError("dvis_plus_amd decoders implement the inference path")
+        x, mask_features = self._f32_inputs(x, mask_features)
         output = self._run_layers(x, mask_features)
         dec, logits, masks = self._final_heads(output, mask_features, True)
         return {"pred_logits": logits.unsqueeze(0), "pred_masks": masks.permute(1, 0, 2, 3).unsqueeze(0),

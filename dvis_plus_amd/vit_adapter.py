@@ -368,9 +368,11 @@ class DinoV2ViTAdapter(nn.Module):
             self._deform_cache = {key: (ref, shapes, lsi)}
         return self._deform_cache[key]
 
+    @Fn.fp32_island
     def forward(self, x):
         if self.training:
             raise NotImplementedError("dvis_plus_amd implements the backbone's inference path")
+        x = Fn.f32(x)
         bs, _, h, w = x.shape
         d2 = self._deform_inputs(h, w, x.device)
         c1, c2, c3, c4 = self.spm(x)

@@ -28,6 +28,36 @@ def test_sharded_stream_on_one_gpu(world, frames, port, tmp_path):
     assert r.returncode == 0 and f"SHARD_CHECK OK world={world}" in r.stdout, tail
 
 
+def test_rccl_collectives_on_a_single_rank():
+    """The RCCL path itself, in the driver's suite: backend "nccl" (= RCCL), world size 1, DVIS_FORCE_COLLECTIVES=1 — the packed
+    query all-gather (sync and async + wait on the tracker stream), the owner rounds' result all-gather and the VPS all-reduce are
+    really issued, around the tracker / refiner hipGraphs; stream() with owner rounds on and off, forward(), the span-pipelined
+    forward: torch.equal to the run without a process group (tools/rccl_single_rank_check.py)."""
+    env = dict(os.environ, DVIS_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_single_rank_check.py"), "--port", "29543"], cwd=ROOT,
+                       env=env, capture_output=True, text=True, timeout=600)
+    own = [l for l in r.stdout.splitlines() if l.startswith(("rank", "RCCL_CHECK"))]
+    err = [l for l in r.stderr.splitlines() if "Error" in l or "error" in l or "Traceback" in l or "assert" in l][-10:]
+    assert r.returncode == 0 and "RCCL_CHECK OK backend=nccl world=1" in r.stdout, "\n".join(own[-30:] + ["--- stderr ---"] + err)
+
+
+def test_bench_forced_collectives_runs_on_rccl():
+    """`bench.py --gpus 1` with DVIS_FORCE_COLLECTIVES=1: the process group the driver's N > 1 runs will use (backend nccl,
+    device_id set, barrier + max-over-ranks all-reduce around the timed region, all_gather_object of the rank table) on one rank."""
+    import json
+    env = dict(os.environ, DVIS_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT="29544")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--frames", "6",
+                        "--no-extra", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    tail = "\n".join((r.stdout + r.stderr).splitlines()[-25:])
+    assert r.returncode == 0, tail
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["dist"]["backend"] == "nccl" and d["dist"]["world_size"] == 1 and d["value"] > 0, tail
+
+
 def test_bench_self_launches_two_ranks_on_one_gpu(tmp_path):
     """`python bench.py --gpus 2` without a launcher around it starts its two ranks itself (bench.launch_command; the
     reference's analogue is detectron2's launch(main, args.num_gpus), train_net_video.py:322-329).  On a one-GPU box the ranks
