@@ -43,6 +43,21 @@ static inline int dvis_lds_opt_in(const void *kernel, size_t bytes, DvisLdsOptIn
   return DVIS_OK;
 }
 
+// Zero `nwords` 32-bit words as a KERNEL on the stream — not hipMemsetAsync.  Captured into a hipGraph (ROCm 7.2) the memset of
+// the attention masks' `allowed_count` took effect while the stream was being captured and not on the replays: the first replay
+// found zeros, every later one accumulated on what the graph's pool held at that address (counts of 4e8, rows of the decoder
+// "allowed nowhere" -> un-masked) — the round-5 "segmenter graph goes wrong after a tracker call" (DESIGN.md section 9,
+// tools/exp/seg_graph_bisect.py).  A kernel node replays like every other launch.
+static __global__ void dvis_zero_words_kernel(uint32_t *__restrict__ p, size_t nwords) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < nwords) p[i] = 0u;
+}
+static inline int dvis_zero_words(void *p, size_t nwords, hipStream_t st, const char *what) {
+  if (nwords == 0) return DVIS_OK;
+  hipLaunchKernelGGL(dvis_zero_words_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, st, (uint32_t *)p, nwords);
+  return dvis_check_launch(what);
+}
+
 #define DVIS_REQUIRE(cond, ...)      \
   do {                               \
     if (!(cond)) {                   \

@@ -398,11 +398,7 @@ DVIS_EXPORT int dvis_attn_mask_pooled(const float *embed, const float *pooled, i
   const int64_t HW = (int64_t)h * w;
   DVIS_REQUIRE((long long)((C + 31) / 32 * 32) * HW * 4 < (1ll << 31) && (long long)Q * HW < (1ll << 31),
                "attn_mask_pooled: one frame of the pooled map / of the mask must stay below 2 GiB");
-  hipError_t e = hipMemsetAsync(allowed_count, 0, (size_t)B * Q * sizeof(int32_t), (hipStream_t)stream);
-  if (e != hipSuccess) {
-    dvis_set_error("attn_mask_pooled: hipMemsetAsync: %s", hipGetErrorString(e));
-    return DVIS_E_LAUNCH;
-  }
+  if (const int rc = dvis_zero_words(allowed_count, (size_t)B * Q, (hipStream_t)stream, "attn_mask_pooled: zero counts")) return rc;
   const bool vec = HW % 4 == 0 && (((uintptr_t)pooled | (uintptr_t)mask) & 15) == 0;
   return vec ? launch<2, true>(embed, pooled, B, Q, C, h, w, h, w, nullptr, mask, allowed_count, (hipStream_t)stream)
              : launch<2, false>(embed, pooled, B, Q, C, h, w, h, w, nullptr, mask, allowed_count, (hipStream_t)stream);
@@ -432,10 +428,6 @@ DVIS_EXPORT int dvis_attn_mask(const float *embed, const float *feat, int B, int
                "attn_mask: needs an even integer down-sizing factor (H=%d W=%d -> h=%d w=%d)", H, W, h, w);
   DVIS_REQUIRE((long long)((C + 31) / 32 * 32) * H * W * 4 < (1ll << 31),
                "attn_mask: one frame of mask_features must stay below 2 GiB");
-  hipError_t e = hipMemsetAsync(allowed_count, 0, (size_t)B * Q * sizeof(int32_t), (hipStream_t)stream);
-  if (e != hipSuccess) {
-    dvis_set_error("attn_mask: hipMemsetAsync: %s", hipGetErrorString(e));
-    return DVIS_E_LAUNCH;
-  }
+  if (const int rc = dvis_zero_words(allowed_count, (size_t)B * Q, (hipStream_t)stream, "attn_mask: zero counts")) return rc;
   return launch<1, false>(embed, feat, B, Q, C, H, W, h, w, nullptr, mask, allowed_count, (hipStream_t)stream);
 }

@@ -168,13 +168,11 @@ DVIS_EXPORT int dvis_msda_backward_det(const float *value, const int64_t *shapes
   hipStream_t st = (hipStream_t)stream;
   const size_t nval = (size_t)N * S * M * D;
   if (N == 0) return DVIS_OK;
-  if (Lq == 0) return hipMemsetAsync(grad_value, 0, nval * 4, st) == hipSuccess ? DVIS_OK : DVIS_E_LAUNCH;
+  if (Lq == 0) return dvis_zero_words(grad_value, nval, st, "msda_backward_det: zero grad_value");
   unsigned *absmax = (unsigned *)ws;
   unsigned long long *acc = (unsigned long long *)((char *)ws + 16);
-  if (hipMemsetAsync(ws, 0, 16 + nval * 8, st) != hipSuccess) {
-    dvis_set_error("msda_backward_det: hipMemsetAsync failed");
-    return DVIS_E_LAUNCH;
-  }
+  // (a kernel, not hipMemsetAsync: a memset captured into a hipGraph does not replay on this ROCm, dvis_common.h)
+  if (const int rc = dvis_zero_words(ws, 4 + nval * 2, st, "msda_backward_det: zero workspace")) return rc;
   const size_t ngo = (size_t)N * Lq * M * D, nw = (size_t)N * Lq * M * L * P;
   hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<size_t>((ngo + 255) / 256, 2048)), dim3(256), 0, st, grad_out, ngo, absmax);
   hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<size_t>((nw + 255) / 256, 2048)), dim3(256), 0, st, w, nw, absmax + 1);

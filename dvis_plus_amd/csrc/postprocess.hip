@@ -316,11 +316,7 @@ DVIS_EXPORT int dvis_vps_argmax(const float *logits, int64_t stride_k, int64_t s
   DVIS_REQUIRE((size_t)T * out_h * out_w < 0x7fffffffu, "vps_argmax: more than 2^31 output pixels");
   DVIS_REQUIRE(logits && scores && ids && conf && areas, "vps_argmax: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(areas, 0, (size_t)3 * K * sizeof(int32_t), st);
-  if (e != hipSuccess) {
-    dvis_set_error("vps_argmax: hipMemsetAsync: %s", hipGetErrorString(e));
-    return DVIS_E_LAUNCH;
-  }
+  if (const int rc = dvis_zero_words(areas, (size_t)3 * K, st, "vps_argmax: zero areas")) return rc;      // (a kernel, not a memset node)
   if (T == 0) return DVIS_OK;
   const size_t npix = (size_t)T * out_h * out_w;
   size_t blocks = (npix + 255) / 256;

@@ -18,7 +18,8 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from . import native
+from . import cpu_ops, native
+from .cpu_ops import ms_deform_attn_core_pytorch    # noqa: F401  (the reference's name for the CPU-tensor formulation, ms_deform_attn_func.py:52)
 
 
 def _torch_path(op, x, why):
@@ -255,6 +256,13 @@ def msda_fused_forward(value, spatial_shapes, level_start_index, reference_point
     return out
 
 
+def _on_cpu(*tensors):
+    """Every tensor lives on the CPU: the call takes the torch formulation of cpu_ops.py (BASELINE config #1, "PyTorch CPU
+    MSDeformAttn fallback (plumbing, no GPU)").  Decided by DEVICE alone: a GPU tensor never ends up there — the HIP kernel runs
+    or the call raises."""
+    return all(t.device.type == "cpu" for t in tensors)
+
+
 def _f32_gpu(t, name):
     if t.dtype != torch.float32:
         raise RuntimeError(f"{name} must be float32 (got {t.dtype})")
@@ -268,6 +276,8 @@ def mask_logits(mask_embed, mask_features):
     Bf, Cf, H, W = mask_features.shape
     if (Bf, Cf) != (B, C):
         raise RuntimeError("mask_logits: mask_embed (B,Q,C) and mask_features (B,C,H,W) disagree")
+    if _on_cpu(mask_embed, mask_features):
+        return cpu_ops.mask_logits(mask_embed, mask_features)
     pe, pf = _f32_gpu(mask_embed, "mask_embed"), _f32_gpu(mask_features, "mask_features")
     out = torch.empty((B, Q, H, W), dtype=torch.float32, device=mask_embed.device)
     with torch.cuda.device(mask_embed.device):
@@ -287,6 +297,8 @@ def attn_mask(mask_embed, mask_features, target_size):
     h, w = int(target_size[0]), int(target_size[1])
     if (Bf, Cf) != (B, C):
         raise RuntimeError("attn_mask: mask_embed (B,Q,C) and mask_features (B,C,H,W) disagree")
+    if _on_cpu(mask_embed, mask_features):
+        return cpu_ops.attn_mask(mask_embed, mask_features, (h, w))
     pe, pf = _f32_gpu(mask_embed, "mask_embed"), _f32_gpu(mask_features, "mask_features")
     mask = torch.empty((B, Q, h * w), dtype=torch.uint8, device=mask_embed.device)
     allowed = torch.empty((B, Q), dtype=torch.int32, device=mask_embed.device)
@@ -358,6 +370,8 @@ def attention(q, k, v, nheads, mask=None, allowed_count=None, out=None, short=Fa
     Lq, B, C = q.shape
     Lk = k.shape[0]
     d = C // nheads
+    if _on_cpu(q, k, v):
+        return cpu_ops.attention(q, k, v, nheads, mask, allowed_count, out)
     for name, t in (("q", q), ("k", k), ("v", v)):
         if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 3 or t.stride(2) != 1:
             raise RuntimeError(f"attention: {name} must be a float32 GPU (L, B, C) tensor with a contiguous last dim")

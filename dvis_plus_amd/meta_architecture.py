@@ -148,6 +148,7 @@ class _VideoBase(nn.Module):
         # scores are near-uniform).  Off by default: the reference's input dicts have no such key.
         self.allow_input_threshold = False
         self.debug_stages = None              # tests: a dict here receives the floats behind the last clip's decisions
+        self._seg_graph = None                # online mode: hipGraph of the segmenter per window shape (_segmenter_graph_ok)
         if hasattr(self.sem_seg_head.predictor, "compute_pred_masks"):
             self.sem_seg_head.predictor.compute_pred_masks = False
 
@@ -260,6 +261,21 @@ class _VideoBase(nn.Module):
         """Segmenter over this rank's frames.  Returns per-frame queries (t,Q,·) and mask_features (t,Cm,h,w)."""
         ms, mf = self.encode(images)
         return (*self.decode(ms, mf), mf)
+
+    def _segmenter_graph_ok(self, images):
+        """hipGraph replay of the segmenter for small windows (online mode: a 5-frame window is ~450 launches for ~20 ms of
+        kernels — the device waits for the host).  DVIS_SEGMENTER_GRAPH=0 switches it off, =N sets the largest window (frames)
+        that is captured (default 8: a graph keeps its private memory pool alive).
+        (Round 5 withdrew this: replays "went wrong after a tracker call".  Cause, round 6: the attention masks' allowed_count
+        was zeroed with hipMemsetAsync, which a captured graph does not replay on this ROCm — csrc/dvis_common.h
+        dvis_zero_words; every replay after the first accumulated on stale counts.)"""
+        limit = int(os.environ.get("DVIS_SEGMENTER_GRAPH", "8"))
+        ok = bool(images.is_cuda and 0 < len(images) <= limit and not torch.is_grad_enabled() and self.debug_stages is None
+                  and getattr(self.sem_seg_head.predictor, "debug_masks", None) is None)
+        if ok and self._seg_graph is None:
+            from .graphs import GraphRunner
+            self._seg_graph = GraphRunner(lambda im: tuple(self.segment(im)), max_entries=4)
+        return ok
 
     # ---- range guard of the split-f16 kernels (functions._X3RangeGuard): snapshot behind phase A, verify before its results
     # are used.  The reference's fp32 island (msdeformattn.py:314,320) has no range to leave; here leaving it is an error (or
@@ -377,7 +393,13 @@ class DVIS_Plus_online(_VideoBase):
         self.keep = bool(video.get("keep", False))
         images, img_size = self.preprocess(video["image"])
         with self._x3_scope():
-            embds, embds_nn, logits, mask_features = self.segment(images)
+            # small windows replay the segmenter from a hipGraph captured per (frames, size, kernel switches); its outputs are
+            # static buffers, consumed before this call returns
+            if self._segmenter_graph_ok(images):
+                embds, embds_nn, logits, mask_features = self._seg_graph(
+                    (tuple(images.shape), getattr(self, "_x3_off", False), Fn.X3, Fn.X3_OFF), images)
+            else:
+                embds, embds_nn, logits, mask_features = self.segment(images)
         try:
             self._guard_verify(self._guard_snapshot())     # (the tracker's host-side assignment waits for the segmenter anyway)
         except Fn.X3RangeError as e:

@@ -257,9 +257,15 @@ class MSDeformAttn(nn.Module):
         else:
             raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
                 reference_points.shape[-1]))
-        output = Fn.MSDeformAttnFunction.apply(value.contiguous(), input_spatial_shapes, input_level_start_index,
-                                               sampling_locations.contiguous(), attention_weights.contiguous(),
-                                               self.im2col_step)
+        if value.device.type == "cpu":
+            # CPU tensors: the reference's torch formulation under its own name (ms_deform_attn_func.py:52-72; BASELINE config #1).
+            # Chosen by device — the reference gets there through a bare `except` around the CUDA op (ms_deform_attn.py:116-121),
+            # for GPU tensors too; here a GPU tensor takes the HIP op below or raises.
+            output = Fn.ms_deform_attn_core_pytorch(value, input_spatial_shapes, sampling_locations, attention_weights)
+        else:
+            output = Fn.MSDeformAttnFunction.apply(value.contiguous(), input_spatial_shapes, input_level_start_index,
+                                                   sampling_locations.contiguous(), attention_weights.contiguous(),
+                                                   self.im2col_step)
         return self.output_proj(output)
 
 

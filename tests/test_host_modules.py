@@ -37,15 +37,19 @@ def test_pixel_decoder_loads_reference_state_dict_and_matches(oracle_ops):
     torch.testing.assert_close(a, g.outs["attn_out"], **TOL)
 
 
-def test_msdeformattn_module_has_no_silent_fallback():
-    """Without the fixture the module must raise on CPU tensors (the reference silently runs grid_sample)."""
-    from dvis_plus_amd.pixel_decoder import MSDeformAttn
-    m = MSDeformAttn(32, 3, 2, 4).eval()
+def test_msdeformattn_op_has_no_silent_fallback():
+    """The CUDA-op surface (MSDeformAttnFunction / ms_deform_attn_forward) raises on CPU tensors — the reference's module hides
+    that behind a bare `except` (ms_deform_attn.py:116-121).  The MODULE serves CPU tensors through the reference's torch
+    formulation by device (test_config1_cpu.py); a GPU tensor never takes it."""
+    from dvis_plus_amd import functions as Fn
     shapes = torch.tensor([(2, 3), (4, 6), (8, 12)])
     lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
     S = int(shapes.prod(1).sum())
-    with pytest.raises(RuntimeError, match="GPU tensor"), torch.no_grad():
-        m(torch.randn(1, S, 32), torch.rand(1, S, 3, 2), torch.randn(1, S, 32), shapes, lsi)
+    value, loc, w = torch.randn(1, S, 2, 16), torch.rand(1, S, 2, 3, 4, 2), torch.rand(1, S, 2, 3, 4)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        Fn.MSDeformAttnFunction.apply(value, shapes, lsi, loc, w, 128)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        Fn.ms_deform_attn_forward(value, shapes, lsi, loc, w)
 
 
 def test_decoders_match_goldens(oracle_ops):

@@ -186,3 +186,49 @@ def test_tracker_batch_is_bit_identical_on_the_gpu():
         assert torch.equal(g["pred_masks"], w["pred_masks"]), f"clip {i}: panoptic map differs from the unbatched run"
     assert any(w["segments_infos"] for w in want), "degenerate test: no segment anywhere"
 
+
+
+def test_online_segmenter_graph_replay_equals_eager(monkeypatch):
+    """DVIS_Plus_online replays the segmenter of a small window from a hipGraph (config #2: ~450 launches per 5-frame window,
+    17 % of the wall was the device waiting for the host).  Same bits as the eager launches, window after window (`keep`
+    continues the video: meta_architecture.py:629-632, 793), through tracker calls in between and replay after replay — the
+    regression test of round 5's withdrawn graph (a hipMemsetAsync node that did not replay, csrc/dvis_common.h)."""
+    from dvis_plus_amd.meta_architecture import build_dvis_plus_r50
+    m = build_dvis_plus_r50("online", task="vps", object_mask_threshold=0.008).to(DEV)
+    windows = [_clip(5, 11), _clip(5, 12), _clip(3, 13)]
+
+    def run():
+        outs = []
+        for i, w in enumerate(windows):
+            o = m([dict(w, keep=i > 0)])
+            outs.append((o["pred_masks"].clone(), o["segments_infos"], o["pred_ids"]))
+        return outs
+    monkeypatch.setenv("DVIS_SEGMENTER_GRAPH", "0")
+    eager = run()
+    assert m._seg_graph is None or not m._seg_graph._cache
+    monkeypatch.setenv("DVIS_SEGMENTER_GRAPH", "8")
+    first, replay, replay2 = run(), run(), run()                 # capture, then pure replays (tracker calls in between)
+    assert len(m._seg_graph._cache) == 2          # two window shapes (5 and 3 frames)
+    assert any(e[1] for e in eager), "degenerate test: no segment"
+    for a, b, c, d in zip(eager, first, replay, replay2):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[0], c[0]) and torch.equal(a[0], d[0])
+        assert a[1] == b[1] == c[1] == d[1] and a[2] == b[2] == c[2] == d[2]
+
+
+def test_captured_attention_mask_counts_replay(monkeypatch):
+    """The op-level form of the same regression: attn_mask / attn_mask_pooled inside a hipGraph give the eager call's mask AND
+    counts on every replay (the counts are accumulated with atomics onto a buffer the launch itself zeroes — with a kernel)."""
+    from dvis_plus_amd import functions as Fn
+    from dvis_plus_amd.graphs import GraphRunner
+    torch.manual_seed(0)
+    emb = torch.randn(3, 100, 256, device=DEV)
+    feat = torch.randn(3, 256, 48, 80, device=DEV)
+    pooled = Fn.center_pool3(feat)
+    want_a, want_p = Fn.attn_mask(emb, feat, (12, 20)), Fn.attn_mask_pooled(emb, pooled[1])
+    g = GraphRunner(lambda e, f, p: (*Fn.attn_mask(e, f, (12, 20)), *Fn.attn_mask_pooled(e, p)))
+    for i in range(4):
+        got = [t.clone() for t in g("k", emb, feat, pooled[1])]
+        torch.empty(1 << 20, device=DEV).normal_()              # (other work between the replays)
+        assert torch.equal(got[0], want_a[0]) and torch.equal(got[1], want_a[1]), f"attn_mask, replay {i}"
+        assert torch.equal(got[2], want_p[0]) and torch.equal(got[3], want_p[1]), f"attn_mask_pooled, replay {i}"
+    assert int(want_a[1].min()) >= 0 and int(want_p[1].max()) <= 12 * 20
