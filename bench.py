@@ -240,6 +240,67 @@ class FfnTimer:
         return secs, sum(f for _, _, f in self.events), len(self.events)
 
 
+class LibTimer:
+    """Times every launch of one C-ABI entry point in the timed region with HIP events on the launch stream (as MsdaTimer).
+    `account(*args)` -> dict of additive per-launch quantities (flops, bytes, ...) or None to leave the launch untimed."""
+
+    def __init__(self, name, account):
+        from dvis_plus_amd import native
+        self.native, self.name, self.account, self.events = native, name, account, []
+
+    def __enter__(self):
+        self.lib = self.native.lib()
+        self.orig = getattr(self.lib, self.name)
+
+        def timed(*a):
+            acc = self.account(*a)
+            if acc is None:
+                return self.orig(*a)
+            st = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            rc = self.orig(*a)
+            e1.record(st)
+            self.events.append((e0, e1, acc))
+            return rc
+        setattr(self.lib, self.name, timed)
+        return self
+
+    def __exit__(self, *exc):
+        setattr(self.lib, self.name, self.orig)
+
+    def summary(self, pred=lambda acc: True):
+        """-> (seconds, summed quantities, launches) over the launches whose accounting dict satisfies `pred`."""
+        torch.cuda.synchronize()
+        tot, secs, n = {}, 0.0, 0
+        for e0, e1, acc in self.events:
+            if pred(acc):
+                secs += e0.elapsed_time(e1) / 1e3
+                n += 1
+                for k, v in acc.items():
+                    if isinstance(v, (int, float)):
+                        tot[k] = tot.get(k, 0.0) + v
+        return secs, tot, n
+
+
+def _acct_mask_logits(pe, pf, B, Q, C, HW, out, stream):
+    # SURVEY.md section 8(d): flops 2 Q C HW, bytes 4 (Q C + C HW + Q HW) per frame
+    return {"flops": 2.0 * B * Q * C * HW, "bytes": 4.0 * B * (Q * C + C * HW + Q * HW), "frames": B, "queries": Q, "form": 0}
+
+
+def _acct_mask_pooled(pe, pf, B, Q, C, h, w, mask, allowed, stream):
+    # the decoder's attention masks on the level's pooled map: fp32 operands in, ONE byte per (query, pixel) + a count per query out
+    return {"flops": 2.0 * B * Q * C * h * w, "bytes": 4.0 * B * (Q * C + C * h * w) + 1.0 * B * Q * h * w + 4.0 * B * Q, "frames": B,
+            "queries": Q, "form": 2}
+
+
+def _acct_attention(q, qs, k, ks, v, vs, out, os_, mask, allowed, B, heads, Lq, Lk, d, scale, ws, stream, kernel):
+    # QK^T + PV: 4 Lq Lk d per (batch, head); bytes: q, out (Lq rows), k, v (Lk rows) of heads * d floats + the byte mask
+    masked = bool(mask)
+    return {"flops": 4.0 * B * heads * Lq * Lk * d, "bytes": 4.0 * B * heads * d * (2 * Lq + 2 * Lk) + (1.0 * B * Lq * Lk if masked else 0.0),
+            "masked": masked, "Lk": Lk, "kernel": int(kernel), "long": Lk > 128}
+
+
 def cpu_baseline_msda(budget_s=8.0):
     """Oracle (C port, OpenMP) of the MSDA forward on a bounded sample: one 720p frame-layer per call."""
     from oracle import msda as omsda
@@ -292,6 +353,20 @@ def cpu_baseline(model, clip, frames=3, thr=0.8, windows=3):
                       f"through oracle/dvis_torch.py (fp32 torch CPU ops, {threads} threads): 1 warm-up window "
                       f"({warm:.1f} s) + {windows} timed windows (median {med:.1f} s); value = frames / median window time",
             "msda_op": cpu_baseline_msda()}
+
+
+def load_x3_traffic():
+    """HBM bytes per launch of the split-f16 kernels from the committed rocprofv3 PMC passes (bench.py cannot read PMCs itself):
+    profiles/rNN_x3_traffic.json, written by tools/x3_traffic_json.py from the raw counter summaries (separate --pmc passes for
+    FETCH_SIZE and WRITE_SIZE, the guide's gfx950 corrections).  {kernel family: {"hbm_bytes_per_launch", "source", ...}}"""
+    for name in ("r06_x3_traffic.json", "r05_x3_traffic.json"):
+        tj = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(tj):
+            try:
+                return json.load(open(tj))
+            except ValueError:
+                pass
+    return {}
 
 
 def round_sizes(n_clips, per_round):
@@ -377,6 +452,64 @@ def stage_breakdown(model, video, task):
     return acc
 
 
+def other_configurations(model, clips, device, args):
+    """BASELINE.json's other single-GPU-runnable configurations as short passes AFTER the headline's timed region (same protocol:
+    inputs resident in HBM, warm-up, K clips between synchronisations): #2 online T=5, #4's clip length T=64 (on one GPU, unsharded),
+    #5 ViT-Adapter-L with 200 queries.  -> {name: {"value", "unit", "steps", "ms_per_step", "workload"}}"""
+    from dvis_plus_amd.meta_architecture import build_dvis_plus_r50
+    out = {}
+
+    def timed(m, vids, warm, streamed):
+        def run(vs):
+            if streamed:
+                for _ in m.stream(vs):
+                    pass
+            else:
+                for v in vs:
+                    m([v])
+        run(vids[:warm])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(vids)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    def videos_of(m, frames_list):
+        vids = [{"image": f, "height": 720, "width": 1280} for f in frames_list]
+        m.allow_input_threshold = True
+        if args.task == "vps":
+            for v in vids:
+                v["object_mask_threshold"] = calibrate_threshold(m, [v], args.candidates * m.num_queries // 100)
+        return vids
+
+    # ---- config #2: DVIS++ online R50, T = 5 windows (the segmenter of a window replays from a hipGraph)
+    m2 = build_dvis_plus_r50("online", task=args.task, object_mask_threshold=0.0, num_queries=100).to(device)
+    wins = [clips[i % len(clips)][5 * (i // len(clips)):5 * (i // len(clips)) + 5] for i in range(8)]
+    vids = videos_of(m2, wins)
+    dt = timed(m2, vids, 2, False)
+    out["online_T5"] = {"value": round(5 * len(vids) / dt, 3), "unit": "frames/s", "steps": len(vids), "ms_per_step": round(dt / len(vids) * 1e3, 2),
+                        "workload": "BASELINE config #2: DVIS++ online R50, T=5 720p windows, 100 queries, one forward() per window"}
+    del m2, vids, wins
+    # ---- config #4's clip length on one GPU: T = 64 through the headline model
+    long_clips = [synthetic_clip(64, device, seed=4321 + i) for i in range(2)]
+    vids = videos_of(model, long_clips) * 2
+    dt = timed(model, vids[:3], 1, True)
+    out["offline_T64"] = {"value": round(64 * 3 / dt, 3), "unit": "frames/s", "steps": 3, "ms_per_step": round(dt / 3 * 1e3, 2),
+                          "workload": "BASELINE config #4's clip (DVIS++ offline R50, T=64 720p, refiner on) unsharded on one GPU, stream()"}
+    del vids, long_clips
+    torch.cuda.empty_cache()
+    # ---- config #5: ViT-Adapter-L backbone, 200 queries, T = 30
+    m5 = build_dvis_plus_r50("offline", task=args.task, object_mask_threshold=0.0, backbone="vitl", num_queries=200).to(device)
+    vids = videos_of(m5, clips[:3])
+    dt = timed(m5, vids, 1, True)
+    out["vitl_200q_T30"] = {"value": round(30 * len(vids) / dt, 3), "unit": "frames/s", "steps": len(vids),
+                            "ms_per_step": round(dt / len(vids) * 1e3, 2),
+                            "workload": "BASELINE config #5: DVIS++ offline DINOv2 ViT-L / ViT-Adapter, T=30 720p, 200 queries, on one GPU, stream()"}
+    del m5, vids
+    torch.cuda.empty_cache()
+    return out
+
+
 BB_NAME = {"r50": "R50", "vitl": "ViT-Adapter-L", "vitb": "ViT-Adapter-B"}
 
 
@@ -417,6 +550,7 @@ def main():
     ap.add_argument("--candidates", type=int, default=20, help="queries sent to the panoptic stage (see main)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed stage breakdown and the 100-candidate pass")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short passes of BASELINE configs #2 / #4-length / #5")
     ap.add_argument("--backbone", default="r50", choices=["r50", "vitl", "vitb"],
                     help="r50 = the headline config; vitl = BASELINE config #5 (ViT-Adapter-L, use --queries 200)")
     ap.add_argument("--queries", type=int, default=100)
@@ -532,8 +666,10 @@ def main():
         model.stream_timing = True
         tm, lt = MsdaTimer(), []
         tm.conv, tm.ffn = ConvTimer(), FfnTimer()
+        tm.mask0, tm.mask2 = LibTimer("dvis_mask_logits", _acct_mask_logits), LibTimer("dvis_attn_mask_pooled", _acct_mask_pooled)
+        tm.attn = LibTimer("dvis_attention_forward_k", _acct_attention)
         t0 = time.perf_counter()
-        with tm, tm.conv, tm.ffn:
+        with tm, tm.conv, tm.ffn, tm.mask0, tm.mask2, tm.attn:
             res_ = run_pass(videos[:args.steps], lt)
         torch.cuda.synchronize()
         if dist_on:
@@ -644,6 +780,18 @@ def main():
         cbc = {"value": round(T * n4 / dt4, 3), "unit": "frames/s", "steps": n4, "ms_per_step": round(dt4 / n4 * 1e3, 2),
                "latency_ms_p50": round(l4[len(l4) // 2], 2), "note": "--clip-stream 0: one forward() per clip, nothing overlapped"}
 
+    timed_clips = args.steps               # clips the kernel timers saw
+    if rank == 0 and not timer.events:
+        timed_clips = 2
+        # online mode replays the window's segmenter from a hipGraph: its launches do not pass the Python front-ends the timers
+        # wrap.  One more (untimed) window launched eagerly, under the same timers, prices the kernels.
+        prev = os.environ.get("DVIS_SEGMENTER_GRAPH")
+        os.environ["DVIS_SEGMENTER_GRAPH"] = "0"
+        try:
+            with timer, timer.conv, timer.ffn, timer.mask0, timer.mask2, timer.attn:
+                run_pass(videos[:2])
+        finally:
+            os.environ.pop("DVIS_SEGMENTER_GRAPH") if prev is None else os.environ.__setitem__("DVIS_SEGMENTER_GRAPH", prev)
     if rank == 0:
         fps = T * args.steps / dt
         sec, nfr, nlaunch = timer.summary()
@@ -665,7 +813,7 @@ def main():
                                                     "split-f16 kernel)",
                          "achieved": round(tf16, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf16 / MFMA_F16_PEAK_TF, 4),
                          "fp32_equivalent_tflops": round(cflops / csec / 1e12, 1), "launches_timed": claunch,
-                         "ms_per_clip": round(csec / args.steps * 1e3, 2), "traffic": None,
+                         "ms_per_clip": round(csec / timed_clips * 1e3, 2), "traffic": None,
                          "note": "f16 matrix-core flops issued = 3 x 2*9*N*C*K*OH*OW per launch, summed over the timed launches / their "
                                  "summed HIP-event durations (the exact-fp32 Winograd kernel it replaces ran these layers at 216 - 264 "
                                  "TF direct-equivalent)"}
@@ -675,7 +823,7 @@ def main():
             conv_roof = {"bound": "mfma", "kernel": "winograd_f2x3 (3x3 convolutions: FPN output conv + R50 conv2)",
                          "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
                          "direct_equivalent_tflops": round(cflops / csec / 1e12, 1), "launches_timed": claunch,
-                         "ms_per_clip": round(csec / args.steps * 1e3, 2), "traffic": None,
+                         "ms_per_clip": round(csec / timed_clips * 1e3, 2), "traffic": None,
                          "note": "flops = 2 * 4 * N*C*K*H*W per launch (Winograd multiplies), summed over the timed launches / "
                                  "their summed HIP-event durations"}
         ksec, kflops, klaunch = timer.conv.summary_kernel()
@@ -686,7 +834,7 @@ def main():
                                                      "projections, FPN output conv) - the kernel with the largest share of a clip's time",
                           "achieved": round(tf16, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf16 / MFMA_F16_PEAK_TF, 4),
                           "fp32_equivalent_tflops": round(kflops / ksec / 1e12, 1), "launches_timed": klaunch,
-                          "ms_per_clip": round(ksec / args.steps * 1e3, 2), "traffic": None,
+                          "ms_per_clip": round(ksec / timed_clips * 1e3, 2), "traffic": None,
                           "note": "f16 matrix-core flops issued = 3 x 2*taps*N*C*K*OH*OW per launch, summed over the timed launches / their "
                                   "summed HIP-event durations; includes the HBM-bound layers (64 / 128 input channels at the large maps)"}
         fsec, fflops, flaunch = timer.ffn.summary()
@@ -697,10 +845,58 @@ def main():
             ffn_roof = {"bound": "mfma", "kernel": "x3_ffn (encoder FFN: linear1 + ReLU + linear2 + residual + LayerNorm, one kernel)",
                         "achieved": round(tf16, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf16 / MFMA_F16_PEAK_TF, 4),
                         "fp32_equivalent_tflops": round(fflops / fsec / 1e12, 1), "launches_timed": flaunch,
-                        "ms_per_clip": round(fsec / args.steps * 1e3, 2), "traffic": None,
+                        "ms_per_clip": round(fsec / timed_clips * 1e3, 2), "traffic": None,
                         "note": "f16 matrix-core flops issued = 3 x the fp32 GEMM flops 2*M*H*(K+N) per launch, summed over the "
                                 "timed launches / their summed HIP-event durations; fp32_equivalent = the fp32 GEMM flops / time "
                                 "(the fp32 matrix peak is 157.3)"}
+        x3_traffic = load_x3_traffic()
+        for roof, key in ((convk_roof, "conv1x1_x3_kernel"), (conv_roof, "conv1x1_x3_kernel"), (ffn_roof, "x3_ffn_kernel")):
+            if roof is not None:
+                # the split-f16 kernels issue 3 matrix-core products per algorithmic one: alg_frac prices the ALGORITHMIC flops
+                #  against the same dense f16 peak
+                roof["alg_frac"] = round(roof["fp32_equivalent_tflops"] / MFMA_F16_PEAK_TF, 4) if "fp32_equivalent_tflops" in roof else None
+                t = x3_traffic.get(key)
+                if t is not None:
+                    roof["traffic"] = t["hbm_bytes_per_launch"]
+                    roof["traffic_source"] = t["source"]
+        mask_roof = attn_roof = None
+        m0s, m0, m0n = timer.mask0.summary()
+        m2s, m2, m2n = timer.mask2.summary()
+        if m0n or m2n:
+            def entry(secs, tot, n, what):
+                gbs, tf = tot["bytes"] / secs / 1e9, tot["flops"] / secs / 1e12
+                return {"form": what, "achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "tflops_f32": round(tf, 1),
+                        "mfma_f32_frac": round(tf / MFMA_F32_PEAK_TF, 4), "launches_timed": n, "us_per_launch": round(secs / n * 1e6, 1),
+                        "alg_bytes_per_launch": int(tot["bytes"] / n), "flops_per_launch": int(tot["flops"] / n),
+                        "ms_per_clip": round(secs / timed_clips * 1e3, 3)}
+            forms = {}
+            if m0n:
+                forms["mask_logits"] = entry(m0s, m0, m0n, "einsum(bqc,bchw->bqhw) at stride 4 for the queries post-processing keeps (a8 / a11: 2 Q' C HW "
+                                                           "flops, 4 (Q' C + C HW + Q' HW) B per frame)")
+            if m2n:
+                forms["attn_mask_pooled"] = entry(m2s, m2, m2n, "the decoder's per-layer attention masks: contraction on the level's pooled map + threshold "
+                                                                "(2 Q C hw flops; fp32 operands in, one byte per (query, pixel) out)")
+            lead = forms.get("mask_logits") or forms["attn_mask_pooled"]
+            # the contraction is HBM-bound at fp32 (AI = 36 flop / B at Q = 100; exact-fp32 MFMA is the arithmetic)
+            mask_roof = {"bound": "hbm", "kernel": "mask_gemm_kernel (exact-fp32 MFMA mask-logit contraction, csrc/mask_gemm.hip)",
+                         "achieved": lead["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lead["frac"], "traffic": None,
+                         "mfma_f32_frac": lead["mfma_f32_frac"], "mfma_f32_peak_tflops": MFMA_F32_PEAK_TF, "forms": forms,
+                         "note": "algorithmic bytes / summed HIP-event durations of the timed launches; mfma_f32_frac = the same launches' "
+                                 "2 Q C HW flops against the dense fp32 matrix peak (both roofs shown: at Q' = 20 kept queries the "
+                                 "stride-4 feature map read dominates, at Q = 100 the fp32 matrix pipe does)"}
+        a_s, a_t, a_n = timer.attn.summary(lambda a: a["masked"] and a["long"])
+        if a_n:
+            tf = a_t["flops"] / a_s / 1e12
+            s_s, s_t, s_n = timer.attn.summary(lambda a: not a["long"])
+            attn_roof = {"bound": "mfma", "kernel": "attn_keysplit_kernel (masked cross-attention of the decoder, exact fp32 MFMA, keys split over "
+                                                    "workgroups) + attn_combine_kernel", "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TF,
+                         "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": None, "launches_timed": a_n,
+                         "us_per_launch": round(a_s / a_n * 1e6, 1), "ms_per_clip": round(a_s / timed_clips * 1e3, 3),
+                         "alg_bytes_per_launch": int(a_t["bytes"] / a_n), "hbm_frac_of_alg_bytes": round(a_t["bytes"] / a_s / 1e9 / HBM_PEAK_GBS, 4),
+                         "short_key_calls": {"launches_timed": s_n, "us_per_launch": round(s_s / max(1, s_n) * 1e6, 1),
+                                             "note": "self-attention over the queries / tracker / refiner (Lk <= 128): latency-bound, not priced"},
+                         "note": "flops = 4 Q HW_l C per frame and layer (QK^T + PV, SURVEY.md section 8d), summed over the timed masked "
+                                 "launches (levels 920 / 3680 / 14720 keys) / their summed HIP-event durations (both launches of a call)"}
         ms = sorted(e0.elapsed_time(e1) for e0, e1 in lat)
         pct = lambda q: round(ms[min(len(ms) - 1, int(q * len(ms)))], 2) if ms else None
         res = {
@@ -744,6 +940,10 @@ def main():
             res["roofline_conv_x3"] = convk_roof
         if ffn_roof is not None:
             res["roofline_ffn"] = ffn_roof
+        if mask_roof is not None:
+            res["roofline_mask_gemm"] = mask_roof
+        if attn_roof is not None:
+            res["roofline_attn"] = attn_roof
         if exact is not None:
             res["exact_f32"] = exact
         if cbc is not None:
@@ -760,6 +960,9 @@ def main():
             res["stages_ms"] = stage_breakdown(model, videos[0], args.task)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(model, clips[0], thr=videos[0].get("object_mask_threshold", 0.8))
+        if world == 1 and not dist_on and not args.no_extra and not args.no_configs and args.mode == "offline" \
+                and args.backbone == "r50" and T == 30 and len(clips) >= 2:
+            res["configs"] = other_configurations(model, clips, device, args)
         print(json.dumps(res))
     if dist_on:
         torch.distributed.destroy_process_group()

@@ -223,12 +223,13 @@ def test_captured_attention_mask_counts_replay(monkeypatch):
     torch.manual_seed(0)
     emb = torch.randn(3, 100, 256, device=DEV)
     feat = torch.randn(3, 256, 48, 80, device=DEV)
-    pooled = Fn.center_pool3(feat)
-    want_a, want_p = Fn.attn_mask(emb, feat, (12, 20)), Fn.attn_mask_pooled(emb, pooled[1])
-    g = GraphRunner(lambda e, f, p: (*Fn.attn_mask(e, f, (12, 20)), *Fn.attn_mask_pooled(e, p)))
-    for i in range(4):
-        got = [t.clone() for t in g("k", emb, feat, pooled[1])]
-        torch.empty(1 << 20, device=DEV).normal_()              # (other work between the replays)
-        assert torch.equal(got[0], want_a[0]) and torch.equal(got[1], want_a[1]), f"attn_mask, replay {i}"
-        assert torch.equal(got[2], want_p[0]) and torch.equal(got[3], want_p[1]), f"attn_mask_pooled, replay {i}"
+    with torch.no_grad():
+        pooled = Fn.center_pool3(feat)
+        want_a, want_p = Fn.attn_mask(emb, feat, (12, 20)), Fn.attn_mask_pooled(emb, pooled[1])
+        g = GraphRunner(lambda e, f, p: (*Fn.attn_mask(e, f, (12, 20)), *Fn.attn_mask_pooled(e, p)))
+        for i in range(4):
+            got = [t.clone() for t in g("k", emb, feat, pooled[1])]
+            torch.empty(1 << 20, device=DEV).normal_()              # (other work between the replays)
+            assert torch.equal(got[0], want_a[0]) and torch.equal(got[1], want_a[1]), f"attn_mask, replay {i}"
+            assert torch.equal(got[2], want_p[0]) and torch.equal(got[3], want_p[1]), f"attn_mask_pooled, replay {i}"
     assert int(want_a[1].min()) >= 0 and int(want_p[1].max()) <= 12 * 20
