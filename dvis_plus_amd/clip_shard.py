@@ -48,27 +48,36 @@ class ClipShard:
             plan.append((start, end, lo, min(end, lo + k)))
         return plan, k
 
-    def all_gather_frames(self, parts, T, per=None, async_op=False, shift=0):
+    def all_gather_frames(self, parts, T, per=None, async_op=False, shift=0, guard=None):
         """parts: list of (t_local, Q, c_i) tensors for this rank's frames.  Returns the same list with all T frames,
         identical on every rank.  One collective on one packed buffer.  `per` = slot size per rank (default
         ceil(T / world)); with async_op the result is (tensors, work) and the caller waits on `work` in the stream that
-        consumes the tensors."""
+        consumes the tensors.
+        guard: this rank's range-guard word (int32 device tensor, functions._X3RangeGuard) or None.  It rides in the SAME
+        collective — four more floats per query row, the tag in the first — and `self.last_guard_tags` then holds every rank's
+        tag (a (world,) view of the gathered buffer, valid once the collective is complete): the decision to raise / re-run is
+        taken from the same data on every rank (a rank that raised alone would leave the others in the next collective)."""
         if self.world == 1 and not self.force:
+            self.last_guard_tags = None
             return (parts, None) if async_op else parts
         per = per or self.frames_per_rank(T)
         widths = [p.shape[-1] for p in parts]
         Q = parts[0].shape[1]
-        packed = torch.zeros((per, Q, sum(widths)), dtype=parts[0].dtype, device=parts[0].device)
+        W = sum(widths) + (4 if guard is not None else 0)
+        packed = torch.zeros((per, Q, W), dtype=parts[0].dtype, device=parts[0].device)
         t_local = parts[0].shape[0]
         if t_local:
-            packed[:t_local] = torch.cat(parts, dim=-1)
-        gathered = torch.empty((self.world * per, Q, sum(widths)), dtype=packed.dtype, device=packed.device)
+            packed[:t_local, :, :sum(widths)] = torch.cat(parts, dim=-1)
+        if guard is not None:
+            packed[0, 0, W - 4] = guard.reshape(-1)[0].to(packed.dtype)          # (tags are small integers: exact in fp32)
+        gathered = torch.empty((self.world * per, Q, W), dtype=packed.dtype, device=packed.device)
         work = dist.all_gather_into_tensor(gathered, packed, group=self.group, async_op=async_op)
+        self.last_guard_tags = gathered.view(self.world, per, Q, W)[:, 0, 0, W - 4] if guard is not None else None
         if shift % self.world:                       # block b came from rank (b + shift) mod world: back to frame order
             assert not async_op, "the rotation reads the gathered buffer"
             gathered = gathered.view(self.world, per, Q, -1).roll(-(shift % self.world), 0).reshape(self.world * per, Q, -1)
         gathered = gathered[:T]                      # blocks are frame-contiguous: padding only sits at the very end
-        out = list(gathered.split(widths, dim=-1))
+        out = list(gathered.split(widths + ([4] if guard is not None else []), dim=-1))[:len(widths)]
         return (out, work) if async_op else out
 
     def all_gather_rows(self, row):
@@ -82,6 +91,11 @@ class ClipShard:
     def all_reduce_sum(self, x):
         if self.world > 1 or self.force:
             dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
+        return x
+
+    def all_reduce_max(self, x):
+        if self.world > 1 or self.force:
+            dist.all_reduce(x, op=dist.ReduceOp.MAX, group=self.group)
         return x
 
     def check_replicas(self, tensors, what):
@@ -120,7 +134,8 @@ class EmulatedShard(ClipShard):
     def __init__(self, world, rank=0):
         self.group, self.world, self.rank, self.force = None, int(world), int(rank), False
 
-    def all_gather_frames(self, parts, T, per=None, async_op=False, shift=0):
+    def all_gather_frames(self, parts, T, per=None, async_op=False, shift=0, guard=None):
+        self.last_guard_tags = None if guard is None else guard.reshape(-1)[:1].to(torch.float32)
         per = per or self.frames_per_rank(T)
         widths = [p.shape[-1] for p in parts]
         Q = parts[0].shape[1]
@@ -137,6 +152,9 @@ class EmulatedShard(ClipShard):
         return row.unsqueeze(0).expand(self.world, -1).contiguous()
 
     def all_reduce_sum(self, x):
+        return x
+
+    def all_reduce_max(self, x):
         return x
 
     def check_replicas(self, tensors, what):

@@ -146,8 +146,15 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x
 __global__ __launch_bounds__(256) void det_finish_kernel(const unsigned long long *__restrict__ acc, const unsigned *__restrict__ absmax,
                                                          float *__restrict__ grad_value, size_t n) {
   const float inv = 1.f / det_scale(absmax);
+  // A NaN / Inf in grad_output or the weights (absmax keeps the largest BIT PATTERN: NaN > Inf > finite) has no fixed-point image:
+  // the float-atomic form and the reference would hand back non-finite gradients, so does this one — a diverged training run must
+  // not be hidden by torch.use_deterministic_algorithms(True).  Headroom: a cell's sum may reach 2^20 x the bound
+  // (max |grad_out| x max |weight|) before the 64-bit accumulator wraps — 19 320 x 8 x 12 x 4 = 7.4 M < 2^23 colliding corner
+  // contributions of weight <= 1 each would need every sample of a frame-layer to hit ONE pixel with full weight to get there.
+  const float bound = __uint_as_float(absmax[0]) * __uint_as_float(absmax[1]);
+  const bool finite = bound < 3.0e38f;      // false for Inf and NaN
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-    grad_value[i] = (float)((double)(long long)acc[i] * (double)inv);
+    grad_value[i] = finite ? (float)((double)(long long)acc[i] * (double)inv) : __builtin_nanf("");
 }
 
 }  // namespace

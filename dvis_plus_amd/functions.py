@@ -1002,8 +1002,9 @@ class _X3RangeGuard:
                     w = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", idx))
                     with torch.cuda.device(idx):
                         native.check(native.lib().dvis_x3_set_range_flag(ctypes.c_void_p(w.data_ptr())), "dvis_x3_set_range_flag")
-                    self.words[idx] = w
+                    # (pool before words: a lock-free reader that finds the word must find its pinned buffers too)
                     self.pool[idx] = [[torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(16)], 0]
+                    self.words[idx] = w
         return w
 
     def new_tag(self, weight, kind):
@@ -1025,7 +1026,9 @@ class _X3RangeGuard:
         host.copy_(w, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(w.device))
-        return (host, ev, w)
+        # (4th entry: the word's value at this point of the stream as a DEVICE tensor — what a sharded run sends through the
+        # clip's all-gather so that every rank takes the same decision, clip_shard.all_gather_frames)
+        return (host, ev, w, w.clone())
 
     def describe(self, tag, model=None):
         kind, ref, shape = self.tags.get(tag, ("?", lambda: None, ()))
@@ -1044,9 +1047,18 @@ class _X3RangeGuard:
     def verify(self, snap, model=None):
         if snap is None:
             return
-        host, ev, w = snap
+        host, ev, w = snap[:3]
         ev.synchronize()
-        tag = int(host[0])
+        self.raise_if(int(host[0]), w, model)
+
+    def verify_gathered(self, tags, device, model=None):
+        """The collective form: `tags` = every rank's guard word as gathered with the clip's queries (float tensor).  Same
+        data on every rank -> every rank raises (or none does)."""
+        if tags is None:
+            return
+        self.raise_if(int(tags.max().item()), self.word(device), model)
+
+    def raise_if(self, tag, w, model=None):
         if tag:
             w.zero_()
             raise X3RangeError(
@@ -1090,18 +1102,19 @@ class _PackCache:
 
     def __init__(self, cap=4096):
         from collections import OrderedDict
-        self.cap, self.d = cap, OrderedDict()
+        self.cap, self.d, self.lock = cap, OrderedDict(), threading.Lock()
 
     def get(self, key_obj, kind, version_key, make):
         k = (id(key_obj), kind)
-        ent = self.d.get(k)
-        if ent is None or ent[0] != version_key:
-            tag = ent[3] if ent is not None else X3_GUARD.new_tag(key_obj, kind)
-            self.d[k] = ent = (version_key, make(), key_obj, tag)       # (holds key_obj: id() stays unique)
-            while len(self.d) > self.cap:
-                self.d.popitem(last=False)
-        else:
-            self.d.move_to_end(k)
+        with self.lock:                # (stream()'s phase-B thread and the main thread both pack: the LRU order is shared state)
+            ent = self.d.get(k)
+            if ent is None or ent[0] != version_key:
+                tag = ent[3] if ent is not None else X3_GUARD.new_tag(key_obj, kind)
+                self.d[k] = ent = (version_key, make(), key_obj, tag)       # (holds key_obj: id() stays unique)
+                while len(self.d) > self.cap:
+                    self.d.popitem(last=False)
+            else:
+                self.d.move_to_end(k)
         # the launch that follows carries this weight's tag (range guard; per host thread) — and the device's guard word exists
         X3_GUARD.word(key_obj.device)
         native.lib().dvis_x3_set_tag(ent[3])

@@ -286,6 +286,21 @@ class _VideoBase(nn.Module):
     def _guard_verify(self, snap):
         Fn.x3_range_verify(snap, self)
 
+    def _gather_guarded(self, st):
+        """The clip's ONE all-gather of the per-frame queries.  Unsharded: the local range-guard check, then nothing to gather.
+        Sharded: the rank's guard word travels IN the gather and the check runs on the gathered tags — every rank raises (or
+        none): a rank that raised alone would leave the others waiting in the next collective."""
+        shard = self.clip_shard
+        sharded = shard.world > 1 or shard.force
+        snap = st.get("guard")
+        if not sharded:
+            self._guard_verify(snap)
+        out = shard.all_gather_frames([st["embds"], st["embds_nn"], st["logits"]], st["T"], shift=st["shift"],
+                                      guard=snap[3] if sharded and snap is not None else None)
+        if sharded:
+            Fn.X3_GUARD.verify_gathered(shard.last_guard_tags, self.device, self)
+        return out
+
     def _x3_rerun(self, err, run):
         """X3RangeError policy of a single-GPU call: re-run `run()` on the exact-fp32 kernels (and stay on them), or raise."""
         sharded = self.clip_shard.world > 1 or self.clip_shard.force
@@ -541,9 +556,7 @@ class DVIS_Plus_offline(_VideoBase):
         """Phase B on the current stream: ONE all-gather of the per-frame queries, tracker + refiner replicated on every
         rank, masks of this rank's frames, post-processing (VPS: one tiny all-reduce of the segment areas)."""
         self.keep = bool(st["video"].get("keep", False))
-        self._guard_verify(st.get("guard"))
-        embds, embds_nn, _ = self.clip_shard.all_gather_frames([st["embds"], st["embds_nn"], st["logits"]], st["T"],
-                                                               shift=st["shift"])
+        embds, embds_nn, _ = self._gather_guarded(st)
         # Replicated tracker + refiner need NO broadcast: every rank holds the same gathered queries, the host assignment
         # is deterministic, and since round 3 phase B runs no library kernel (own deterministic GEMM, attention, add+LN)
         # — same bits on every rank, so the post-processing decisions agree.  north_star's "single all-gather" is
@@ -564,10 +577,7 @@ class DVIS_Plus_offline(_VideoBase):
         then masks and post-processing clip by clip."""
         to_bctq = lambda z: z.permute(2, 0, 1).unsqueeze(0)
         self.keep = False
-        for st in sts:
-            self._guard_verify(st.get("guard"))
-        gathered = [self.clip_shard.all_gather_frames([st["embds"], st["embds_nn"], st["logits"]], st["T"], shift=st["shift"])
-                    for st in sts]
+        gathered = [self._gather_guarded(st) for st in sts]
         embds = torch.cat([to_bctq(g[0]) for g in gathered], 0)                      # (clips, 2C, T, Q)
         embds_nn = torch.cat([to_bctq(g[1]) for g in gathered], 0)
         track = self.tracker(embds, None, resume=False, frame_embeds_no_norm=embds_nn, need_masks=False)
@@ -602,10 +612,7 @@ class DVIS_Plus_offline(_VideoBase):
                 return self._track_phase_batched(sts)
             return [self._track_phase(st) for st in sts]
         assert m <= shard.world
-        for st in sts:
-            self._guard_verify(st.get("guard"))
-        gathered = [shard.all_gather_frames([st["embds"], st["embds_nn"], st["logits"]], st["T"], shift=st["shift"])
-                    for st in sts]
+        gathered = [self._gather_guarded(st) for st in sts]
         Q, K1 = self.num_queries, sts[0]["logits"].shape[-1]
         Cm = self.refiner.mask_embed.layers[-1].out_features
         C2 = self.tracker.decoder_norm.weight.shape[0]
@@ -905,7 +912,12 @@ class DVIS_Plus_offline(_VideoBase):
                 tracks.append(run_tracker(c, segs[c]))
         if overlap:
             main.wait_stream(self._tracker_stream)
-        self._guard_verify(self._guard_snapshot())      # (span pipeline: raises; DVIS_X3=0 is the remedy named in the message)
+        snap = self._guard_snapshot()                   # (span pipeline: raises; DVIS_X3=0 is the remedy named in the message)
+        if snap is not None and (shard.world > 1 or shard.force):
+            tag = shard.all_reduce_max(snap[3].to(torch.float32))      # same decision on every rank
+            Fn.X3_GUARD.verify_gathered(tag, self.device, self)
+        else:
+            self._guard_verify(snap)
         cat = lambda xs, d: xs[0] if len(xs) == 1 else torch.cat(xs, d)
         embds_nn = cat([s_["embds_nn"] for s_ in segs], 0)
         track = {"pred_embds": cat([t["pred_embds"] for t in tracks], 2),

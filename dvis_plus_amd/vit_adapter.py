@@ -37,9 +37,27 @@ class PatchEmbed(nn.Module):
         self.num_patches = (img_size // patch_size) ** 2
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
 
+    def _flat_weight(self):
+        """The stride-p p x p convolution as a linear layer over flattened patches: (D, 3 p p), an own tensor (not a view: the
+        packed split-f16 image is cached per weight tensor), refreshed when the parameter changes."""
+        w = self.proj.weight
+        key = (w._version, w.data_ptr(), w.device)
+        if getattr(self, "_flat", None) is None or self._flat[0] != key:
+            self._flat = (key, w.detach().reshape(w.shape[0], -1).clone())
+        return self._flat[1]
+
     def forward(self, x, return_HW=False):
-        _, _, H, W = x.shape
-        assert H % self.patch_size[0] == 0 and W % self.patch_size[1] == 0, "image size must be a multiple of the patch"
+        B, Cin, H, W = x.shape
+        ph, pw = self.patch_size
+        assert H % ph == 0 and W % pw == 0, "image size must be a multiple of the patch"
+        if x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and not torch.is_autocast_enabled() \
+                and self.proj.stride == self.proj.kernel_size and self.proj.padding == (0, 0) and (Cin * ph * pw) % 4 == 0:
+            # non-overlapping patches: ONE gather into (B h w, 3 p p) rows and a tall GEMM (split-f16 tiled kernel from K = 512 on)
+            # whose output already is the token matrix — no library convolution, no flatten / transpose copy
+            h, w = H // ph, W // pw
+            rows = x.view(B, Cin, h, ph, w, pw).permute(0, 2, 4, 1, 3, 5).reshape(B * h * w, Cin * ph * pw)
+            t = Fn.linear(rows, self._flat_weight(), self.proj.bias, tall=True).view(B, h * w, -1)
+            return (t, h, w) if return_HW else t
         x = self.proj(x)
         H, W = x.shape[-2:]
         x = x.flatten(2).transpose(1, 2)
@@ -315,6 +333,55 @@ class SpatialPriorModule(nn.Module):
         tok = lambda t: t.flatten(2).transpose(1, 2)
         return self.fc1(c1), tok(self.fc2(c2)), tok(self.fc3(c3)), tok(self.fc4(c4))
 
+    # ---- the same module on the repo's own convolution kernels (round 6: no MIOpen / hipBLASLt call left in the stem)
+    def _folded(self, conv, bn, embed7=False):
+        """(weight, bias) of `conv` with the eval-mode BatchNorm that follows folded in (y = s (W x) + (beta - mean s), s = gamma /
+        sqrt(var + eps)), cached per parameter version.  embed7: the 3 x 3 / stride 2 / padding 1 kernel laid into the centre of a
+        7 x 7 / padding 3 one (the same convolution) — the shape the direct stem kernel serves (csrc/conv7x7s2.hip)."""
+        key = (conv.weight._version, bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+               conv.weight.device, embed7)
+        cache = self.__dict__.setdefault("_fold_cache", {})
+        ent = cache.get(id(conv))
+        if ent is None or ent[0] != key:
+            with torch.no_grad():
+                s = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+                w = (conv.weight.double() * s.view(-1, 1, 1, 1)).float()
+                b = (bn.bias.double() - bn.running_mean.double() * s).float().contiguous()
+                if embed7:
+                    w7 = w.new_zeros(w.shape[0], w.shape[1], 7, 7)
+                    w7[:, :, 2:5, 2:5] = w
+                    w = w7
+                cache[id(conv)] = ent = (key, w.contiguous(), b)
+        return ent[1], ent[2]
+
+    def own_ok(self, x):
+        bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+        return bool(x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not torch.is_grad_enabled() and not self.training
+                    and not torch.is_autocast_enabled() and x.shape[2] % 32 == 0 and x.shape[3] % 32 == 0
+                    and all(b.track_running_stats and b.running_mean is not None and b.weight is not None for b in bns)
+                    and os.environ.get("DVIS_SPM_OWN", "1") != "0")
+
+    def forward_own(self, x, level_embed):
+        """-> (c1 (B, D, H/4, W/4), c (B, n2 + n3 + n4, D) = cat(tok(c2) + le[0], tok(c3) + le[1], tok(c4) + le[2]), n2, n3): the
+        module's four outputs as the adapter consumes them (adapter.py:558-565), every convolution on an own kernel with the
+        BatchNorm folded, ReLU (and the max-pool) in the epilogues, the level embeddings in the projections' biases and the three
+        token blocks written straight into one buffer (no torch.cat)."""
+        st = self.stem
+        w, b = self._folded(st[0], st[1], embed7=True)
+        y = Fn.conv7x7s2_stem(x, w, b, relu=True)                                   # 3 -> 64, stride 2
+        w, b = self._folded(st[3], st[4])
+        y = Fn.conv3x3_bias_act(y, w, b, relu=True)
+        w, b = self._folded(st[6], st[7])
+        c1 = Fn.bias_relu_maxpool(Fn.conv3x3_bias_act(y, w, None, relu=False), b)   # + shift, ReLU, 3 x 3 / 2 max-pool in one pass
+        c2 = Fn.conv3x3s2_bias_act(c1, *self._folded(self.conv2[0], self.conv2[1]), relu=True)
+        c3 = Fn.conv3x3s2_bias_act(c2, *self._folded(self.conv3[0], self.conv3[1]), relu=True)
+        c4 = Fn.conv3x3s2_bias_act(c3, *self._folded(self.conv4[0], self.conv4[1]), relu=True)
+        f1 = Fn.conv1x1_bias_act(c1, self.fc1.weight, self.fc1.bias)
+        le = level_embed.detach()
+        maps = [Fn.conv1x1_bias_act(c, fc.weight, fc.bias.detach() + le[i]) for i, (c, fc) in
+                enumerate(((c2, self.fc2), (c3, self.fc3), (c4, self.fc4)))]
+        return f1, Fn.maps_to_tokens(maps), maps[0].shape[2] * maps[0].shape[3], maps[1].shape[2] * maps[1].shape[3]
+
 
 class DinoV2ViTAdapter(nn.Module):
     def __init__(self, vit_module=None, pretrain_size=224, conv_inplane=64, n_points=4, deform_num_heads=6,
@@ -375,9 +442,12 @@ class DinoV2ViTAdapter(nn.Module):
         x = Fn.f32(x)
         bs, _, h, w = x.shape
         d2 = self._deform_inputs(h, w, x.device)
-        c1, c2, c3, c4 = self.spm(x)
-        n2, n3 = c2.shape[1], c3.shape[1]
-        c = torch.cat([c2 + self.level_embed[0], c3 + self.level_embed[1], c4 + self.level_embed[2]], dim=1)
+        if self.spm.own_ok(x):
+            c1, c, n2, n3 = self.spm.forward_own(x, self.level_embed)
+        else:
+            c1, c2, c3, c4 = self.spm(x)
+            n2, n3 = c2.shape[1], c3.shape[1]
+            c = torch.cat([c2 + self.level_embed[0], c3 + self.level_embed[1], c4 + self.level_embed[2]], dim=1)
         t, H, W = self.vit_module.prepare_tokens_with_masks(x, masks=None, return_HW=True)
         dim = t.shape[-1]
         cls, t = t[:, :1], t[:, 1:]

@@ -79,7 +79,11 @@ def test_mask_gemm_errors():
     from dvis_plus_amd.functions import attn_mask, mask_logits
     e, f = _inputs(1, 4, 8, 6, 6, 0)
     with pytest.raises(RuntimeError, match="GPU tensor"):
-        mask_logits(e, f)
+        mask_logits(e.to(DEV), f)                   # mixed devices: never a silent copy or a torch formulation
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        mask_logits(e, f.to(DEV))
+    # all-CPU tensors take the torch formulation of cpu_ops.py (BASELINE config #1), chosen by device alone
+    torch.testing.assert_close(mask_logits(e, f), torch.einsum("bqc,bchw->bqhw", e, f))
     with pytest.raises(RuntimeError, match="even integer"):
         attn_mask(e.to(DEV), f.to(DEV), (2, 2))     # factor 3
 

@@ -433,3 +433,18 @@ def test_deterministic_backward_repeats_bit_for_bit_and_matches_the_oracle(case)
         assert torch.equal(v.grad, a[0])
     finally:
         torch.use_deterministic_algorithms(prev)
+
+
+def test_deterministic_backward_propagates_non_finite_gradients():
+    """A NaN / Inf in grad_output must come back as non-finite grad_value from the fixed-point form too (a diverged
+    training run may not be hidden by torch.use_deterministic_algorithms(True)); finite inputs stay finite."""
+    from dvis_plus_amd import functions as Fn
+    value, s, lsi, loc, w = make_msda_inputs(1, 8, 32, [(6, 10), (12, 20)], 300, 4, torch.float32, seed=3)
+    go = torch.randn(1, 300, 8 * 32)
+    args = [t.to(DEV) for t in (value, s, lsi, loc, w)]
+    assert bool(torch.isfinite(Fn.ms_deform_attn_backward(*args, go.to(DEV), deterministic=True)[0]).all())
+    for bad in (float("nan"), float("inf")):
+        g = go.clone()
+        g[0, 7, 3] = bad
+        gv = Fn.ms_deform_attn_backward(*args, g.to(DEV), deterministic=True)[0]
+        assert not bool(torch.isfinite(gv).any()), f"grad_output with {bad}: finite grad_value came back"

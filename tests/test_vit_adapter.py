@@ -125,3 +125,40 @@ def test_vitl_720p_full_configuration_vs_oracle():
     assert out["pred_masks"].shape == (10, 2, 720, 1280)
     tol = PPar.logit_tolerance(float(stages["masks"].abs().max()))
     PPar.compare_vis(out, ref, stages, "config #5 ViT-Adapter-L, 200 queries, 2 x 720p, full layer counts", tol=tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw", [(736, 1280), (128, 192)])
+def test_spatial_prior_module_on_own_kernels_vs_fp64(hw, monkeypatch):
+    """The ViT-Adapter's SpatialPriorModule (adapter.py:304-360) on the repo's own convolution kernels (BatchNorm folded, ReLU and
+    the max-pool in the epilogues, level embeddings in the projections' biases, tokens written into one buffer) against the
+    module's own torch composition evaluated in fp64 — at BASELINE's frame size and at a small one."""
+    from dvis_plus_amd.vit_adapter import SpatialPriorModule
+    torch.manual_seed(0)
+    spm = SpatialPriorModule(inplanes=64, embed_dim=1024).eval()
+    with torch.no_grad():
+        for m in spm.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):          # trained-looking statistics (a fresh BatchNorm is the identity)
+                m.running_mean.normal_(0, 0.3)
+                m.running_var.uniform_(0.5, 2.0)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+    le = torch.randn(3, 1024)
+    x = torch.randn(2, 3, *hw, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        ref = spm.double()(x.double())
+        want_c = torch.cat([ref[1] + le[0].double(), ref[2] + le[1].double(), ref[3] + le[2].double()], 1)
+        spm = spm.float().to("cuda:0")
+        assert spm.own_ok(x.to("cuda:0"))
+        calls = []
+        import torch.nn.functional as F
+        orig = F.conv2d
+        monkeypatch.setattr(F, "conv2d", lambda *a, **k: (calls.append(a[1].shape), orig(*a, **k))[1])
+        c1, c, n2, n3 = spm.forward_own(x.to("cuda:0"), le.to("cuda:0"))
+    if hw == (736, 1280):
+        assert not calls, f"a library convolution ran: {calls}"
+    assert (n2, n3) == (ref[1].shape[1], ref[2].shape[1]) and c.shape == want_c.shape
+    for got, want, name in ((c1, ref[0], "c1"), (c, want_c, "tokens")):
+        scale = float(want.abs().max())
+        err = float((got.double().cpu() - want).abs().max())
+        assert err <= 5e-5 * scale + 1e-5, f"{name}: max |own - fp64| {err:.3e} at scale {scale:.2f}"
