@@ -136,10 +136,12 @@ int launch_bwd(const void *value, const int64_t *shapes, const int64_t *ls, cons
 }
 
 __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, size_t n, unsigned *__restrict__ out) {
+  // fmaxf DROPS a NaN operand; the fixed-point form must see it (det_finish_kernel hands back NaN then): a NaN-keeping maximum
+  auto nanmax = [](float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : fmaxf(a, b); };
   float m = 0.f;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = nanmax(m, fabsf(x[i]));
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  for (int o = 32; o > 0; o >>= 1) m = nanmax(m, __shfl_xor(m, o));
   if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bit patterns; NaN -> 0x7fc..: the largest
 }
 

@@ -435,7 +435,7 @@ def preprocess(frames, pixel_mean, pixel_std, size_divisibility=32):
 def dvis_plus_forward(sd, backbone, frames, *, offline=True, nheads=8, enc_layers=6, dec_layers=9, tracker_layers=6,
                       refiner_layers=6, window_size=3, num_classes=124, n_things=58, task="vps", max_num=20,
                       object_mask_threshold=0.8, overlap_threshold=0.8, out_hw=None, stages=None, keep=False,
-                      tracker=None):
+                      tracker=None, seg_workers=1):
     """DVIS_Plus_offline.forward (eval) = run_window_inference (meta_architecture.py:1446-1500) + post_processing
     (:758-772) + inference_video_{vis,vps,vss}; offline=False: DVIS_Plus_online (:774-816).  `sd` uses the product's /
     reference's checkpoint names (sem_seg_head.pixel_decoder.*, sem_seg_head.predictor.*, tracker.*, refiner.*);
@@ -444,17 +444,34 @@ def dvis_plus_forward(sd, backbone, frames, *, offline=True, nheads=8, enc_layer
     keep / tracker: the `keep` entry of the input dict (:629-632, :1301-1304) and the Tracker object of the previous
     call (its cross-call state).  ONLINE: the first window resumes when keep is set (`i != 0 or self.keep`, :793).
     OFFLINE: the window loop resumes only for i != 0 (:1479-1486) — `keep` is read but has no effect there.
-    nheads: an int, or (segmenter heads, tracker / refiner heads)."""
+    nheads: an int, or (segmenter heads, tracker / refiner heads).
+    seg_workers > 1 (the tests' time budget, not a change of the algorithm): the windows' SEGMENTER passes — independent of each
+    other and of the tracker — are evaluated by that many host threads at once, window by window as before; the tracker then walks
+    the windows in order.  Same calls, same window batches, another schedule (the torch CPU ops of a 3-frame window stop scaling at
+    ~8 threads: tools/exp/oracle_threads.py)."""
     images, img_size = preprocess(frames, sd["pixel_mean"].flatten(), sd["pixel_std"].flatten())
     pd, pr = _sub(sd, "sem_seg_head.pixel_decoder."), _sub(sd, "sem_seg_head.predictor.")
     nheads, nheads_t = (nheads, nheads) if isinstance(nheads, int) else nheads
     trk = tracker if tracker is not None else Tracker(_sub(sd, "tracker."), nheads_t, tracker_layers)
     T = len(images)
     all_mf, all_fe_nn, all_inst, online_logits, online_masks, all_fe, all_ms0 = [], [], [], [], [], [], []
-    for s in range(0, T, window_size):                                      # the reference's window loop
-        feats = backbone(images[s:s + window_size])
+    def segment_window(feats):
         mf, _, ms = pixel_decoder_forward(pd, feats, nheads, enc_layers)
-        out = decoder_forward(pr, ms, mf, nheads, dec_layers)
+        return mf, ms, decoder_forward(pr, ms, mf, nheads, dec_layers)
+    starts = list(range(0, T, window_size))
+    ahead = None
+    if seg_workers > 1 and len(starts) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        feats_all = [backbone(images[s:s + window_size]) for s in starts]   # (the backbone callable may drive a GPU: this thread only)
+        with ThreadPoolExecutor(max_workers=int(seg_workers)) as ex:
+            ahead = list(ex.map(lambda f: torch.no_grad()(segment_window)(f), feats_all))
+        del feats_all
+    for wi, s in enumerate(starts):                                         # the reference's window loop
+        if ahead is not None:
+            mf, ms, out = ahead[wi]
+            ahead[wi] = None
+        else:
+            mf, ms, out = segment_window(backbone(images[s:s + window_size]))
         t_out = trk.forward(out["pred_embds"], mf.unsqueeze(0), resume=(s != 0) or (bool(keep) and not offline),
                             frame_embeds_no_norm=out["pred_embds_without_norm"], with_masks=not offline)
         all_mf.append(mf)

@@ -77,8 +77,20 @@ def run_oracle(m, sd, frames_cpu, *, offline, task, attn_masks=False, **cfg):
     """-> (task outputs of oracle.dvis_plus_forward, stages dict with the floats behind the integer decisions)."""
     from oracle import dvis_torch as O
     stages = {"want_attn_masks": True} if attn_masks else {}
-    with torch.no_grad():
-        ref = O.dvis_plus_forward(sd, gpu_backbone(m), frames_cpu, offline=offline, task=task, stages=stages, **cfg)
+    # Host threads: torch's default on the GPU box (128 of 256 logical CPUs) makes the oracle's 3-frame windows 2.3x SLOWER than 32
+    # threads and no faster than 8 (tools/exp/oracle_threads.py, profiles/r06_oracle_threads.txt) — so 8 threads per op, and the
+    # windows' independent segmenter passes on up to 8 host threads at once (oracle.dvis_plus_forward: seg_workers).
+    import os
+    prev = torch.get_num_threads()
+    ncpu = os.cpu_count() or 8
+    workers = max(1, min(8, ncpu // 16, (len(frames_cpu) + 2) // 3))
+    torch.set_num_threads(max(4, min(8 if workers > 1 else 32, ncpu)))
+    try:
+        with torch.no_grad():
+            ref = O.dvis_plus_forward(sd, gpu_backbone(m), frames_cpu, offline=offline, task=task, stages=stages,
+                                      seg_workers=workers, **cfg)
+    finally:
+        torch.set_num_threads(prev)
     return ref, stages
 
 

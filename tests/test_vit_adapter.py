@@ -97,9 +97,15 @@ def _vit_pipeline(device, size="vitb", hw=(128, 192), T=4, full=False):
     m = m.to(device)
     out = m([{"image": [f.to(device) for f in frames], "height": hw[0], "width": hw[1]}])
     stages = {}
-    with torch.no_grad():
-        ref = O.dvis_plus_forward(sd, oracle_backbone, frames, offline=True, task="vis", nheads=8,
-                                  dec_layers=9 if full else 3, max_num=10, stages=stages, **cfg)
+    import os
+    prev = torch.get_num_threads()            # (the GPU box's default of 128 host threads slows the oracle's CPU ops down 2.3x against 32)
+    torch.set_num_threads(max(4, min(32, os.cpu_count() or 8)))
+    try:
+        with torch.no_grad():
+            ref = O.dvis_plus_forward(sd, oracle_backbone, frames, offline=True, task="vis", nheads=8,
+                                      dec_layers=9 if full else 3, max_num=10, stages=stages, **cfg)
+    finally:
+        torch.set_num_threads(prev)
     return out, ref, stages, PPar
 
 
