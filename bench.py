@@ -333,6 +333,13 @@ def cpu_baseline(model, clip, frames=3, thr=0.8, windows=3):
     sd["pixel_mean"], sd["pixel_std"] = model.pixel_mean.cpu(), model.pixel_std.cpu()
     backbone = copy.deepcopy(model.backbone).cpu().eval()
     sample = [f for f in clip[:frames].cpu()]
+    # host threads: torch's default on the GPU box (128 of its 256 logical CPUs) runs the oracle's 3-frame window 2.3x SLOWER than 32
+    # threads (profiles/r06_oracle_threads.txt: 14.4 s vs 5.8 s for pixel decoder + decoder); the baseline uses the faster setting
+    prev_threads = torch.get_num_threads()
+    if (os.cpu_count() or 0) >= 64 and "DVIS_CPU_BASELINE_THREADS" not in os.environ:
+        torch.set_num_threads(32)
+    elif "DVIS_CPU_BASELINE_THREADS" in os.environ:
+        torch.set_num_threads(int(os.environ["DVIS_CPU_BASELINE_THREADS"]))
     threads = torch.get_num_threads()
 
     def run():
@@ -346,13 +353,16 @@ def cpu_baseline(model, clip, frames=3, thr=0.8, windows=3):
     dts = sorted(run() for _ in range(windows))      # 1 warm-up + 3 timed, median and p10 / p90
     pick = lambda q: dts[min(len(dts) - 1, int(q * len(dts)))]
     med = dts[len(dts) // 2]
+    msda_op = cpu_baseline_msda()
+    torch.set_num_threads(prev_threads)
     return {"value": round(frames / med, 4), "unit": "frames/s", "cores": threads, "kind": "port",
             "p10_p50_p90": [round(frames / pick(0.9), 4), round(frames / med, 4), round(frames / pick(0.1), 4)],
             "window_seconds": [round(d, 2) for d in dts],
             "sample": f"first {frames} frames (one reference window, TEST.WINDOW_SIZE=3) of the same 720p synthetic clip "
                       f"through oracle/dvis_torch.py (fp32 torch CPU ops, {threads} threads): 1 warm-up window "
-                      f"({warm:.1f} s) + {windows} timed windows (median {med:.1f} s); value = frames / median window time",
-            "msda_op": cpu_baseline_msda()}
+                      f"({warm:.1f} s) + {windows} timed windows (median {med:.1f} s); value = frames / median window time"
+                      f"; {threads} threads is the fastest setting on this host (torch's default of {prev_threads} is slower)",
+            "msda_op": msda_op}
 
 
 def load_x3_traffic():

@@ -61,12 +61,11 @@ def test_online_T5_720p_vs_oracle(task):
 
 
 def test_bench_workload_vps_stream_vs_oracle():
-    """The benchmark's workload (bench.py clips, calibrated candidate count, stream()) against the oracle.  T = 12 here (four
-    reference windows): the 30-frame configuration itself is compared to the oracle by
-    test_T30_natural_logit_scale_literal_1e3_and_error_budget below — two 30-frame oracle runs (3 - 6 minutes of CPU each on a
-    shared host) put the suite at the driver's time limit."""
+    """The benchmark's workload (bench.py clips, calibrated candidate count, stream(), T = 30) against the oracle.  (Round 5 ran it
+    at T = 12 for the suite's time limit; round 6 got the time back: the oracle's windows run on several host threads at the thread
+    count the CPU ops actually scale to — profiles/r06_oracle_threads.txt.  DVIS_TEST_STREAM_T overrides.)"""
     import bench
-    T = 12
+    T = int(os.environ.get("DVIS_TEST_STREAM_T", "30"))
     m, sd = _model("offline", "vps")
     m = m.to(DEV)
     dev = torch.device(DEV)
