@@ -232,12 +232,33 @@ class _VideoBase(nn.Module):
             x = torch.nn.functional.pad(x, (0, Wp - W, 0, Hp - H))
         return x, (H, W)
 
+    def _reserve_scope(self, stage):
+        """Inside stream(): the persistent split-f16 grids of `stage` leave `_stream_reserve` CUs to the side stream when the
+        reserve is scoped to that stage (DVIS_X3_RESERVE_SCOPE, default "backbone": phase B of the previous round starts on the
+        device when this round's phase A does and is over — 20 ms of few-workgroup kernels — before the 22 ms backbone is; the
+        pixel decoder and decoder then run on every CU.  "phase_a" = rounds 4 - 5: the whole of phase A leaves the CUs free)."""
+        import contextlib
+        r = getattr(self, "_stream_reserve_now", 0)
+        if not r or self._reserve_scope_name != stage:
+            return contextlib.nullcontext()
+
+        @contextlib.contextmanager
+        def scope():
+            prev = native.lib().dvis_x3_set_reserve(r)
+            try:
+                yield
+            finally:
+                native.lib().dvis_x3_set_reserve(prev)
+        return scope()
+
+    _reserve_scope_name = os.environ.get("DVIS_X3_RESERVE_SCOPE", "backbone")
+
     def encode(self, images):
         """Backbone + pixel decoder over this rank's frames: (multi_scale_features, mask_features (t,Cm,h,w))."""
         chunk = segmenter_frames_per_call(len(images), images.shape[-2], images.shape[-1], self.segmenter_chunk)
         ms, mf = [], []
         for s in range(0, len(images), chunk):
-            with Fn.x3_stage("backbone"):
+            with Fn.x3_stage("backbone"), self._reserve_scope("backbone"):
                 feats = self.backbone(images[s:s + chunk])
             f, _, m = self.sem_seg_head.pixel_decoder.forward_features(feats)
             mf.append(f)
@@ -710,10 +731,17 @@ class DVIS_Plus_offline(_VideoBase):
         yield from self._stream_rounds(videos, per_round, sharded_owner, overlap, main, side, phase_b, hand_over)
 
     def _segment_round_reserved(self, chunk, shift, rotate):
-        """_segment_round with the persistent split-f16 grids leaving `_stream_reserve` CUs to the side stream."""
+        """_segment_round with the persistent split-f16 grids leaving `_stream_reserve` CUs to the side stream — for the stage
+        `_reserve_scope` names, or for all of phase A."""
         r = getattr(self, "_stream_reserve", 0)
         if not r:
             return self._segment_round(chunk, shift=shift, rotate=rotate)
+        if self._reserve_scope_name != "phase_a":
+            self._stream_reserve_now = r
+            try:
+                return self._segment_round(chunk, shift=shift, rotate=rotate)
+            finally:
+                self._stream_reserve_now = 0
         prev = native.lib().dvis_x3_set_reserve(r)
         try:
             return self._segment_round(chunk, shift=shift, rotate=rotate)
