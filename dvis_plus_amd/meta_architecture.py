@@ -234,9 +234,11 @@ class _VideoBase(nn.Module):
 
     def _reserve_scope(self, stage):
         """Inside stream(): the persistent split-f16 grids of `stage` leave `_stream_reserve` CUs to the side stream when the
-        reserve is scoped to that stage (DVIS_X3_RESERVE_SCOPE, default "backbone": phase B of the previous round starts on the
-        device when this round's phase A does and is over — 20 ms of few-workgroup kernels — before the 22 ms backbone is; the
-        pixel decoder and decoder then run on every CU.  "phase_a" = rounds 4 - 5: the whole of phase A leaves the CUs free)."""
+        reserve is scoped to that stage (DVIS_X3_RESERVE_SCOPE=backbone; development).  Default "phase_a": the whole of phase A
+        leaves the CUs free.  Measured in round 6 (profiles/r06_reserve_scope.txt): phase B of the previous round starts on the
+        device when this round's phase A does, so scoping the reserve to the 22 ms backbone looked free — it is not: 380 against
+        388 frames/s (phase B's host-paced chain outlasts the backbone, and its few-workgroup kernels then queue behind
+        full-device grids)."""
         import contextlib
         r = getattr(self, "_stream_reserve_now", 0)
         if not r or self._reserve_scope_name != stage:
@@ -251,7 +253,7 @@ class _VideoBase(nn.Module):
                 native.lib().dvis_x3_set_reserve(prev)
         return scope()
 
-    _reserve_scope_name = os.environ.get("DVIS_X3_RESERVE_SCOPE", "backbone")
+    _reserve_scope_name = os.environ.get("DVIS_X3_RESERVE_SCOPE", "phase_a")
 
     def encode(self, images):
         """Backbone + pixel decoder over this rank's frames: (multi_scale_features, mask_features (t,Cm,h,w))."""
