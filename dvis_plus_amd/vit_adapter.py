@@ -451,10 +451,11 @@ class DinoV2ViTAdapter(nn.Module):
         t, H, W = self.vit_module.prepare_tokens_with_masks(x, masks=None, return_HW=True)
         dim = t.shape[-1]
         cls, t = t[:, :1], t[:, 1:]
-        outs, x1_tok = [], None
+        outs, x1_tok, outs_tok = [], None, []
         for i, layer in enumerate(self.interactions):
             lo, hi = self.interaction_indexes[i]
             t, c, cls = layer(t, c, cls, self.vit_module.blocks[lo:hi + 1], d2, H, W)
+            outs_tok.append(t)
             if i == 0:
                 x1_tok = t
             outs.append(t.transpose(1, 2).reshape(bs, dim, H, W) if i > 0 or not self._res2_fused_ok(c1, t) else None)
@@ -471,6 +472,21 @@ class DinoV2ViTAdapter(nn.Module):
             f1 = Fn.adapter_res2(g, c1, x1_tok if self.add_vit_feature else None, scale, shift, 2 * H, 2 * W)
         else:
             c1 = self.up(c2) + c1
+        if f1 is not None and self.add_vit_feature and self._tail_fused_ok(c, H, W):
+            # stride 8 / 16 / 32 outputs without a library kernel (round 6): eval BatchNorm is a per-channel affine, so
+            #   norm2(c2 + up2(x2)) = (s c2 + t) + up2(s x2)            -> Fn.upsample_add with the lateral's affine applied on the fly
+            #   norm3(c3 + x3)      = s (c3 + x3) + t                   (token-major, then one tiled transpose)
+            #   norm4(c4 + down2(x4)) with down2 = the mean of every 2 x 2 block (what bilinear, align_corners=False samples at 1/2)
+            t2, t3, t4 = (tok.contiguous() for tok in (outs_tok[1], outs_tok[2], outs_tok[3]))
+            (s2, b2), (s3, b3), (s4, b4) = (self._bn_affine(bn) for bn in (self.norm2, self.norm3, self.norm4))
+            c_all = c.contiguous()
+            lat2 = Fn.tokens_to_map(c_all, 0, 2 * H, 2 * W)
+            top2 = Fn.tokens_to_map(t2 * s2, 0, H, W)
+            f2 = Fn.upsample_add(lat2, top2, (s2.repeat(bs).contiguous(), b2.repeat(bs).contiguous()))
+            f3 = Fn.tokens_to_map(((c_all[:, n2:n2 + n3] + t3) * s3 + b3).contiguous(), 0, H, W)
+            x4d = t4.view(bs, H // 2, 2, W // 2, 2, dim).mean(dim=(2, 4)).reshape(bs, -1, dim)
+            f4 = Fn.tokens_to_map(((c_all[:, n2 + n3:] + x4d) * s4 + b4).contiguous(), 0, H // 2, W // 2)
+            return [f1, f2, f3, f4]
         if self.add_vit_feature:
             x1, x2, x3, x4 = outs
             if f1 is None:
@@ -479,6 +495,23 @@ class DinoV2ViTAdapter(nn.Module):
             c3 = c3 + x3
             c4 = c4 + F.interpolate(x4, scale_factor=0.5, mode="bilinear", align_corners=False)
         return [self.norm1(c1) if f1 is None else f1, self.norm2(c2), self.norm3(c3), self.norm4(c4)]
+
+    def _tail_fused_ok(self, c, H, W):
+        bns = (self.norm2, self.norm3, self.norm4)
+        return (c.is_cuda and c.dtype == torch.float32 and not torch.is_grad_enabled() and H % 2 == 0 and W % 2 == 0
+                and all(isinstance(b, nn.BatchNorm2d) and b.track_running_stats and b.running_mean is not None and b.weight is not None
+                        for b in bns) and os.environ.get("DVIS_ADAPTER_TAIL", "1") != "0")
+
+    def _bn_affine(self, bn):
+        """Eval-mode BatchNorm as (scale, shift) per channel, fp64 arithmetic rounded once, cached per parameter version."""
+        key = tuple(p._version for p in (bn.weight, bn.bias, bn.running_mean, bn.running_var)) + (bn.weight.device,)
+        cache = self.__dict__.setdefault("_bn_cache", {})
+        ent = cache.get(id(bn))
+        if ent is None or ent[0] != key:
+            with torch.no_grad():
+                s = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+                cache[id(bn)] = ent = (key, s.float().contiguous(), (bn.bias.double() - bn.running_mean.double() * s).float().contiguous())
+        return ent[1], ent[2]
 
     def _res2_fused_ok(self, c1, t):
         bn = self.norm1
