@@ -1085,9 +1085,11 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restri
 
 }  // namespace
 
-// DVIS_ATTN_X3_PIPE=0: the unpipelined form of the split-f16 self-attention kernel (round 5)
+// DVIS_ATTN_X3_PIPE=1: the pipelined form of the split-f16 self-attention kernel (round 6).  Measured and NOT the default: 1994.5 vs
+// 1939.7 us per ViT-L block of 10 frames (profiles/r06_attn_x3_pipe.txt) — with two waves per SIMD the other wave's products already
+// fill the softmax phases; issuing the next stage's score tiles early only lengthens the dependency on the LDS stage.
 static bool attn_x3_pipe() {
-  static const bool on = []() { const char *e = getenv("DVIS_ATTN_X3_PIPE"); return !(e && e[0] == '0'); }();
+  static const bool on = []() { const char *e = getenv("DVIS_ATTN_X3_PIPE"); return e && e[0] == '1'; }();
   return on;
 }
 
