@@ -826,11 +826,7 @@ __global__ __launch_bounds__(256) void attn_x3_pack_kernel(const float *__restri
 
 // Pass 2.  QT query tiles of 16 per wave (a workgroup covers 128 QT queries): every K / V fragment read from LDS serves QT matrix
 // instructions, and a staged K / V tile QT times the queries.
-// PIPE (round 6): the score tiles of stage i + 1 are ISSUED before the softmax of stage i and the P V products of stage i after it,
-// so a wave's exp / split arithmetic runs under its own matrix instructions instead of between them (all eight waves of a workgroup
-// march in step behind the two barriers of a stage: without this the matrix pipe idles through every softmax phase and the VALU
-// through every product phase).  K is staged one stage AHEAD of V: k_lds holds stage i + 1 while v_lds holds stage i.
-template <int QT, bool PIPE = false>
+template <int QT>
 __global__ __launch_bounds__(512) void attn_x3_kernel(const _Float16 *__restrict__ ws, float *__restrict__ out, dvis_strides os, int BH,
                                                       int heads, int Lq, int Lk, int *__restrict__ guard_flag, int guard_tag) {
   constexpr int KT = kX3KT, NT = KT / 16, RS = kX3Row, RV = kX3RowV;
@@ -885,9 +881,21 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const _Float16 *__restrict
       pv[i] = *reinterpret_cast<const ah8 *>(wvv + (size_t)key * 128 + 8 * (id & 15));
     }
   };
-  // ---- the stage's four S^T tiles per query tile (rows = 16 keys, cols = 16 queries; scaled by 2^8), ONE running-max update per
-  //      64 keys: the cross-lane reduction and the exp chain are paid once per stage, not per tile
-  auto score_tiles = [&](dvis_f4 (&s)[QT][NT]) {
+  prefetch(0);
+  for (int ks = 0; ks < Lk; ks += KT) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int id = tid + 512 * i;
+      *reinterpret_cast<ah8 *>(&k_lds[(id >> 4) * RS + 8 * (id & 15)]) = pk[i];
+      *reinterpret_cast<ah8 *>(&v_lds[(id >> 4) * RV + 8 * (id & 15)]) = pv[i];
+    }
+    __syncthreads();
+    if (ks + KT < Lk) prefetch(ks + KT);
+    if (!wave_on) continue;
+    // ---- the stage's four S^T tiles per query tile (rows = 16 keys, cols = 16 queries; scaled by 2^8), ONE running-max update per
+    //      64 keys: the cross-lane reduction and the exp chain are paid once per stage, not per tile
+    dvis_f4 s[QT][NT];
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
 #pragma unroll
@@ -903,69 +911,6 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const _Float16 *__restrict
           s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h, qh[t][c], s[t][kt], 0, 0, 0);
         }
       }
-    }
-  };
-  auto stage_k = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int id = tid + 512 * i;
-      *reinterpret_cast<ah8 *>(&k_lds[(id >> 4) * RS + 8 * (id & 15)]) = pk[i];
-    }
-  };
-  auto stage_v = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int id = tid + 512 * i;
-      *reinterpret_cast<ah8 *>(&v_lds[(id >> 4) * RV + 8 * (id & 15)]) = pv[i];
-    }
-  };
-  auto prefetch_k = [&](int ks) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int id = tid + 512 * i, key = min(ks + (id >> 4), Lk - 1);
-      pk[i] = *reinterpret_cast<const ah8 *>(wk + (size_t)key * 128 + 8 * (id & 15));
-    }
-  };
-  auto prefetch_v = [&](int ks) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int id = tid + 512 * i, key = min(ks + (id >> 4), Lk - 1);
-      pv[i] = *reinterpret_cast<const ah8 *>(wvv + (size_t)key * 128 + 8 * (id & 15));
-    }
-  };
-  dvis_f4 s[QT][NT], s_next[QT][NT];
-  if constexpr (PIPE) {           // prologue: K of stage 0 staged and multiplied, K of stage 1 and V of stage 0 in flight
-    prefetch_k(0);
-    prefetch_v(0);
-    stage_k();
-    __syncthreads();
-    if (KT < Lk) prefetch_k(KT);
-    if (wave_on) score_tiles(s);
-  } else {
-    prefetch(0);
-  }
-  for (int ks = 0; ks < Lk; ks += KT) {
-    __syncthreads();
-    if constexpr (PIPE) {
-      if (ks + KT < Lk) stage_k();         // K of stage i + 1 (k_lds was last read by the score tiles of stage i: behind the barrier)
-      stage_v();                           // V of stage i     (v_lds was last read by P V of stage i - 1)
-    } else {
-      stage_k();
-      stage_v();
-    }
-    __syncthreads();
-    if constexpr (PIPE) {
-      if (ks + 2 * KT < Lk) prefetch_k(ks + 2 * KT);
-      if (ks + KT < Lk) prefetch_v(ks + KT);
-    } else {
-      if (ks + KT < Lk) prefetch(ks + KT);
-    }
-    if (!wave_on) continue;
-    if constexpr (PIPE) {
-      if (ks + KT < Lk) score_tiles(s_next);          // issued first: they run on the matrix pipe under the softmax below
-      __builtin_amdgcn_sched_barrier(0);
-    } else {
-      score_tiles(s);
     }
     ah8 a_h[QT][NT / 2], a_l[QT][NT / 2];
 #pragma unroll
@@ -1026,12 +971,6 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const _Float16 *__restrict
         }
       }
     }
-    if constexpr (PIPE) {
-#pragma unroll
-      for (int t = 0; t < QT; ++t)
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt) s[t][kt] = s_next[t][kt];
-    }
   }
   if (!wave_on) return;
   float chk = 0.f;
@@ -1085,14 +1024,6 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restri
 
 }  // namespace
 
-// DVIS_ATTN_X3_PIPE=1: the pipelined form of the split-f16 self-attention kernel (round 6).  Measured and NOT the default: 1994.5 vs
-// 1939.7 us per ViT-L block of 10 frames (profiles/r06_attn_x3_pipe.txt) — with two waves per SIMD the other wave's products already
-// fill the softmax phases; issuing the next stage's score tiles early only lengthens the dependency on the LDS stage.
-static bool attn_x3_pipe() {
-  static const bool on = []() { const char *e = getenv("DVIS_ATTN_X3_PIPE"); return e && e[0] == '1'; }();
-  return on;
-}
-
 DVIS_EXPORT int64_t dvis_attention_ws_bytes_k(int BH, int Lq, int Lk, int d, int kernel) {
   if (kernel != 2) return dvis_attention_ws_bytes(BH, Lq, Lk, d);
   if (BH <= 0 || Lq <= 0 || Lk <= 0 || d != 64) return 0;
@@ -1135,11 +1066,6 @@ static int attention_launch(const float *q, const int64_t *q_strides, const floa
                        Lk, scale * kLog2e * 16.f);
     if (const int rc = dvis_check_launch("attn_x3_pack_kernel")) return rc;
     static const int qt = []() { const char *e = getenv("DVIS_ATTN_X3_QT"); return e ? atoi(e) : 1; }();     // (development)
-    if (attn_x3_pipe() && qt != 2) {
-      hipLaunchKernelGGL((attn_x3_kernel<1, true>), dim3(((BH + 7) / 8) * 8 * ((Lq + 127) / 128)), dim3(512), 0, st, wsh, out, os, BH, heads, Lq,
-                         Lk, gd.flag, gd.tag);
-      return dvis_check_launch("attn_x3_kernel");
-    }
     if (qt == 2)
       hipLaunchKernelGGL(attn_x3_kernel<2>, dim3(((BH + 7) / 8) * 8 * ((Lq + 255) / 256)), dim3(512), 0, st, wsh, out, os, BH, heads, Lq, Lk,
                          gd.flag, gd.tag);
@@ -1226,12 +1152,8 @@ DVIS_EXPORT int dvis_attention_x3_packed(const void *ws, float *out, const int64
   const int BH = B * heads;
   const dvis_strides os{o_strides[0], o_strides[1], o_strides[2]};
   const X3Guard gd = dvis_x3_guard();
-  if (attn_x3_pipe())
-    hipLaunchKernelGGL((attn_x3_kernel<1, true>), dim3(((BH + 7) / 8) * 8 * ((L + 127) / 128)), dim3(512), 0, (hipStream_t)stream,
-                       (const _Float16 *)ws, out, os, BH, heads, L, L, gd.flag, gd.tag);
-  else
-    hipLaunchKernelGGL(attn_x3_kernel<1>, dim3(((BH + 7) / 8) * 8 * ((L + 127) / 128)), dim3(512), 0, (hipStream_t)stream, (const _Float16 *)ws, out,
-                       os, BH, heads, L, L, gd.flag, gd.tag);
+  hipLaunchKernelGGL(attn_x3_kernel<1>, dim3(((BH + 7) / 8) * 8 * ((L + 127) / 128)), dim3(512), 0, (hipStream_t)stream, (const _Float16 *)ws, out,
+                     os, BH, heads, L, L, gd.flag, gd.tag);
   return dvis_check_launch("attn_x3_kernel");
 }
 

@@ -86,12 +86,9 @@ __device__ __forceinline__ unsigned cx_geom2(const CxArgs &a, long long p) {
 
 // NW waves x 32 pixels per tile; 8 waves = two per SIMD (<= 256 registers each) cover each other's stalls.
 // IK k-steps per ring item: 2 (three stages) or 4 (= one activation chunk; two stages of up to 64 KB: half the barriers).
-// STG: ring stages (default: 2 for 64 KB items, else 3).  MINW: waves per SIMD the register allocation must allow — 2 for the form
-// with TWO 4-wave workgroups per CU (NW = 4, IK = 2, STG = 2: 64 KB of LDS each): one workgroup's epilogue (128 dword stores per
-// lane, no products) then overlaps the other's products instead of idling the matrix pipe (round 6).
-template <int NB, int NW, int IK, int STG = (IK == 4 ? 2 : 3), int MINW = 1>
-__global__ __launch_bounds__(NW * 64, MINW) void conv1x1_x3_kernel(const CxArgs a) {
-  constexpr int kTile = NW * 32, PW = 2 * IK * NB / NW, STAGES = STG, IPC = 4 / IK;
+template <int NB, int NW, int IK>
+__global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
+  constexpr int kTile = NW * 32, PW = 2 * IK * NB / NW, STAGES = IK == 4 ? 2 : 3, IPC = 4 / IK;
   static_assert(2 * IK * NB % NW == 0, "the item's pieces must divide among the waves");
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
@@ -328,19 +325,6 @@ static int cx_launch(const float *x, const void *packed, const float *bias, cons
     hipLaunchKernelGGL((conv1x1_x3_kernel<NBV, NWV, IKV>), dim3(grid), dim3(NWV * 64), lds, st, a);                \
   }
   static const int ik = getenv("DVIS_X3_CONV_ITEM") ? atoi(getenv("DVIS_X3_CONV_ITEM")) : 4;   // (2: three stages of 32 KB, 2 - 5 % slower)
-  // DVIS_X3_CONV_TWO_WG: 256-channel passes as TWO 4-wave workgroups per CU (128-pixel tiles, two ring stages of 32 KB each) for
-  // launches with fewer than this many input channels x taps (0 = off): short contractions pay their epilogue un-overlapped
-  static const int two_wg = getenv("DVIS_X3_CONV_TWO_WG") ? atoi(getenv("DVIS_X3_CONV_TWO_WG")) : 0;
-  if (K >= 256 && two_wg > 0 && (C + (x2 ? C2 : 0)) * taps <= two_wg) {
-    static DvisLdsOptIn opted;
-    typedef Ring<8, 32, 4, 2> R;                 // PW = 2 IK NB / NW = 8 pieces per wave: 32 KB items
-    a.tiles = (a.pixels + 127) / 128;
-    const size_t lds = 2 * R::kItemBytes;
-    const int rc = dvis_lds_opt_in((const void *)conv1x1_x3_kernel<8, 4, 2, 2, 2>, lds, &opted, "dvis_conv1x1_x3");
-    if (rc != DVIS_OK) return rc;
-    hipLaunchKernelGGL((conv1x1_x3_kernel<8, 4, 2, 2, 2>), dim3(2 * grid), dim3(256), lds, st, a);
-    return dvis_check_launch("dvis_conv1x1_x3");
-  }
   if (K == 64) {
     if (nw == 8) DVIS_CX_LAUNCH(2, 8, 2) else DVIS_CX_LAUNCH(2, 4, 2)
   } else if (K == 128) {

@@ -141,10 +141,6 @@ struct TileMap {
   // still one 128-byte line, but neighbouring pixels of the head are ADJACENT lines (two x-neighbouring corners = 256
   // contiguous bytes) instead of M * D * 4 = 1 KB apart — what the value projection writes through dvis_gemm_nt_hm.
   int value_hm;
-  // fp32 output stores write-through (`sc1`): the stored lines are DROPPED from the XCD's L2 instead of kept (MI355X_MICROARCH.md,
-  // stores of each flavour) — the output is never read by this kernel, and 2.5 MB per (frame, head) of it otherwise competes
-  // with the head's 2.5 MB `value` slice for the XCD's 4 MB.  DVIS_MSDA_OUT_SC1 (round 6 experiment, profiles/r06_msda_*).
-  int out_sc1;
 };
 
 bool make_tile_map(const int64_t *shapes_host, int L, int Lq, TileMap *tm) {
@@ -327,7 +323,6 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile(
   const int g = lane / G, j = lane - g * G;
   const unsigned lane_bytes = (unsigned)j * 16u;   // kOOB + lane_bytes is still out of range
   T *const out_frame = out + ((size_t)n * Lq * M + m) * D;   // uniform
-  const __amdgpu_buffer_rsrc_t rout = dvis_make_rsrc_uniform(out_frame, (unsigned)((((size_t)Lq - 1) * MD + D) * sizeof(T)));
 
   // Latency is hidden by WAVES, not by a deep per-wave pipeline: each wave keeps one batch of B samples
   // (4*B corner loads) in flight, reads that batch's taps from LDS just in time, and stays within the
@@ -378,18 +373,7 @@ __global__ __launch_bounds__(256, WPS) void msda_fwd_tile(
         }
       }
     }
-    if (q >= 0) {
-      if constexpr (CPL == 4) {
-        if (tm.out_sc1) {
-          const dvis_v4u pk = {__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]), __float_as_uint(acc[3])};
-          __builtin_amdgcn_raw_buffer_store_b128(pk, rout, (unsigned)(((size_t)q * MD + CPL * j) * sizeof(T)), 0, /*aux = sc1*/ 16);
-        } else {
-          Chan<T>::store(out_frame + (size_t)q * MD + CPL * j, acc);
-        }
-      } else {
-        Chan<T>::store(out_frame + (size_t)q * MD + CPL * j, acc);
-      }
-    }
+    if (q >= 0) Chan<T>::store(out_frame + (size_t)q * MD + CPL * j, acc);
   }
 }
 
@@ -587,8 +571,6 @@ DVIS_EXPORT int dvis_msda_fused_forward_slots(const float *value, const int64_t 
   if (!has_pos) make_tile_map(shapes_host, L, Lq, &tm);
   tm.off_hs = off_head_stride, tm.logit_hs = logit_head_stride;
   tm.value_hm = value_head_major ? 1 : 0;
-  static const int out_sc1 = []() { const char *e = getenv("DVIS_MSDA_OUT_SC1"); return e ? atoi(e) : 0; }();
-  tm.out_sc1 = out_sc1;
   if (has_pos) {
     DVIS_REQUIRE(pos_offsets && pos_logits && pos_stride >= (int64_t)(M - 1) * off_hs + L * P * 2 && pos_stride % 4 == 0 &&
                      aligned16(pos_offsets) && aligned16(pos_logits),
