@@ -907,6 +907,11 @@ def main():
                                              "note": "self-attention over the queries / tracker / refiner (Lk <= 128): latency-bound, not priced"},
                          "note": "flops = 4 Q HW_l C per frame and layer (QK^T + PV, SURVEY.md section 8d), summed over the timed masked "
                                  "launches (levels 920 / 3680 / 14720 keys) / their summed HIP-event durations (both launches of a call)"}
+        for roof, key in ((mask_roof, "mask_gemm_kernel"), (attn_roof, "attn_keysplit_kernel")):
+            t = x3_traffic.get(key)
+            if roof is not None and t is not None:
+                roof["traffic"] = t["hbm_bytes_per_launch"]      # (mean over every launch of the kernel family in the profiled bench run)
+                roof["traffic_source"] = t["source"]
         ms = sorted(e0.elapsed_time(e1) for e0, e1 in lat)
         pct = lambda q: round(ms[min(len(ms) - 1, int(q * len(ms)))], 2) if ms else None
         res = {

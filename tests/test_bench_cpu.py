@@ -64,3 +64,26 @@ def test_under_a_launcher_world_size_must_match_gpus(monkeypatch):
                 bench.main()
         finally:
             faulthandler.cancel_dump_traceback_later()      # main() arms a watchdog first; not in the test process
+
+
+def test_roofline_accounting_follows_the_survey_formulas():
+    """mask contraction 2 Q C HW flops and 4 (Q C + C HW + Q HW) bytes per frame (3.015 GFLOP / 83.9 MB at
+    Q = 100, C = 256, 184 x 320); masked cross-attention 4 Q HW_l C flops per frame and layer."""
+    import bench
+    a = bench._acct_mask_logits(None, None, 1, 100, 256, 58880, None, None)
+    assert a["flops"] == 2 * 100 * 256 * 58880 == 3_014_656_000 and a["bytes"] == 4 * (100 * 256 + 256 * 58880 + 100 * 58880) == 83_947_520
+    p = bench._acct_mask_pooled(None, None, 30, 100, 256, 23, 40, None, None, None)
+    assert p["flops"] == 2.0 * 30 * 100 * 256 * 920 and p["form"] == 2
+    import ctypes
+    m = bench._acct_attention(None, None, None, None, None, None, None, None, ctypes.c_void_p(16), None, 30, 8, 100, 14720, 32, 0.1, None, None, 0)
+    assert m["flops"] == 4.0 * 30 * 100 * 14720 * 256 and m["masked"] and m["long"]
+    s = bench._acct_attention(None, None, None, None, None, None, None, None, None, None, 30, 8, 100, 100, 32, 0.1, None, None, 0)
+    assert not s["masked"] and not s["long"]
+
+
+def test_committed_pmc_traffic_files_are_readable():
+    """bench.py fills `traffic` of the roofline entries from profiles/ (it cannot read PMCs itself)."""
+    import bench
+    t = bench.load_x3_traffic()
+    for fam in ("conv1x1_x3_kernel", "x3_ffn_kernel"):
+        assert fam in t and t[fam]["hbm_bytes_per_launch"] > 0 and "FETCH_SIZE" in t[fam]["source"]
