@@ -105,6 +105,27 @@ def main():
         for t in (torch.ones(3, device=dev),):
             dist.all_reduce(t)
             assert torch.equal(t, torch.ones(3, device=dev))
+        # the range-guard decision is COLLECTIVE in a sharded run: the rank's guard word rides in the clip's all-gather and every
+        # rank raises from the gathered tags (a rank raising alone would leave the others in the next collective)
+        from dvis_plus_amd import functions as Fn
+        snap_fn = m._guard_snapshot
+
+        def flagged():
+            snap = snap_fn()
+            return None if snap is None else (*snap[:3], torch.full_like(snap[3], 1))      # tag 1 = the first packed weight
+        m._guard_snapshot = flagged
+        before = calls["all_gather"]
+        try:
+            m([clips[0]])
+            print("rank 0: a flagged guard word did NOT raise in the sharded run", flush=True)
+            bad += 1
+        except Fn.X3RangeError as e:
+            ok = calls["all_gather"] - before == 1            # ... raised AFTER the gather, from the gathered tags
+            print(f"rank 0: flagged guard word -> X3RangeError after the clip's all-gather = {ok} ({str(e)[:60]}...)", flush=True)
+            bad += not ok
+        finally:
+            m._guard_snapshot = snap_fn
+        check("forward() after the guard error (state intact)", [grab(m([c])) for c in clips])
     finally:
         dist.all_gather_into_tensor, dist.all_reduce = ag, ar
     dist.barrier()
