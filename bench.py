@@ -807,7 +807,7 @@ def main():
         sec, nfr, nlaunch = timer.summary()
         achieved = MSDA_BYTES_PER_FRAME_LAYER * nfr / sec / 1e9
         traffic, traffic_src = None, None     # HBM bytes per launch from the committed rocprofv3 PMC passes (bench.py cannot read PMCs itself)
-        for name in ("r05_msda_traffic.json", "r03_msda_traffic.json", "r02_msda_traffic.json", "r01_msda_traffic.json"):
+        for name in ("r06_msda_traffic.json", "r05_msda_traffic.json", "r03_msda_traffic.json", "r02_msda_traffic.json", "r01_msda_traffic.json"):
             tj = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tj):
                 t = json.load(open(tj))

@@ -43,11 +43,12 @@ static inline int dvis_lds_opt_in(const void *kernel, size_t bytes, DvisLdsOptIn
   return DVIS_OK;
 }
 
-// Zero `nwords` 32-bit words as a KERNEL on the stream — not hipMemsetAsync.  Captured into a hipGraph (ROCm 7.2) the memset of
-// the attention masks' `allowed_count` took effect while the stream was being captured and not on the replays: the first replay
-// found zeros, every later one accumulated on what the graph's pool held at that address (counts of 4e8, rows of the decoder
-// "allowed nowhere" -> un-masked) — the round-5 "segmenter graph goes wrong after a tracker call" (DESIGN.md section 9,
-// tools/exp/seg_graph_bisect.py).  A kernel node replays like every other launch.
+// Zero `nwords` 32-bit words as a KERNEL on the stream — not hipMemsetAsync.  A hipMemsetAsync captured into a hipGraph (ROCm 7.2,
+// HIP 7.0.51831) replays correctly ONCE: from the second replay on the node fills the buffer with a garbage word instead of the
+// value (minimal reproduction tools/exp/memset_graph_repro.py: 0 -> 0x0A40xxxx for 2000 B, 4 KB and 1 MB alike,
+// profiles/r06_memset_graph_repro.txt).  The attention masks' `allowed_count` was zeroed that way: the first replay of a captured
+// segmenter was right, every later one added its atomics onto ~4e8 — the round-5 "segmenter graph goes wrong after a tracker
+// call" (tools/exp/seg_graph_bisect.py).  A kernel node replays like every other launch.
 static __global__ void dvis_zero_words_kernel(uint32_t *__restrict__ p, size_t nwords) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i < nwords) p[i] = 0u;

@@ -180,7 +180,7 @@ DVIS_EXPORT int dvis_msda_backward_det(const float *value, const int64_t *shapes
   if (Lq == 0) return dvis_zero_words(grad_value, nval, st, "msda_backward_det: zero grad_value");
   unsigned *absmax = (unsigned *)ws;
   unsigned long long *acc = (unsigned long long *)((char *)ws + 16);
-  // (a kernel, not hipMemsetAsync: a memset captured into a hipGraph does not replay on this ROCm, dvis_common.h)
+  // (a kernel, not hipMemsetAsync: a memset node of a hipGraph fills with garbage from its second replay on, dvis_common.h)
   if (const int rc = dvis_zero_words(ws, 4 + nval * 2, st, "msda_backward_det: zero workspace")) return rc;
   const size_t ngo = (size_t)N * Lq * M * D, nw = (size_t)N * Lq * M * L * P;
   hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<size_t>((ngo + 255) / 256, 2048)), dim3(256), 0, st, grad_out, ngo, absmax);

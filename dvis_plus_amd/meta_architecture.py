@@ -290,7 +290,7 @@ class _VideoBase(nn.Module):
         kernels — the device waits for the host).  DVIS_SEGMENTER_GRAPH=0 switches it off, =N sets the largest window (frames)
         that is captured (default 8: a graph keeps its private memory pool alive).
         (Round 5 withdrew this: replays "went wrong after a tracker call".  Cause, round 6: the attention masks' allowed_count
-        was zeroed with hipMemsetAsync, which a captured graph does not replay on this ROCm — csrc/dvis_common.h
+        was zeroed with hipMemsetAsync, and a memset node replays correctly only ONCE on this ROCm (garbage fill afterwards) — csrc/dvis_common.h
         dvis_zero_words; every replay after the first accumulated on stale counts.)"""
         limit = int(os.environ.get("DVIS_SEGMENTER_GRAPH", "8"))
         ok = bool(images.is_cuda and 0 < len(images) <= limit and not torch.is_grad_enabled() and self.debug_stages is None

@@ -192,7 +192,7 @@ def test_online_segmenter_graph_replay_equals_eager(monkeypatch):
     """DVIS_Plus_online replays the segmenter of a small window from a hipGraph (config #2: ~450 launches per 5-frame window,
     17 % of the wall was the device waiting for the host).  Same bits as the eager launches, window after window (`keep`
     continues the video: meta_architecture.py:629-632, 793), through tracker calls in between and replay after replay — the
-    regression test of round 5's withdrawn graph (a hipMemsetAsync node that did not replay, csrc/dvis_common.h)."""
+    regression test of round 5's withdrawn graph (a hipMemsetAsync node that fills with garbage from its second replay on, csrc/dvis_common.h)."""
     from dvis_plus_amd.meta_architecture import build_dvis_plus_r50
     m = build_dvis_plus_r50("online", task="vps", object_mask_threshold=0.008).to(DEV)
     windows = [_clip(5, 11), _clip(5, 12), _clip(3, 13)]
