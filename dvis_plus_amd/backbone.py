@@ -146,12 +146,36 @@ class ResNet(nn.Module):
         return {k: ShapeSpec(channels=self._out_channels[k], stride=2 ** int(k[3:]))
                 for k in self._out_features}
 
+    @staticmethod
+    def _chain_blocks(stage):
+        """The stage's bottlenecks as folded (weight, shift) dicts for Fn.bneck_stage_x3, or None when a block is not the plain
+        stride-1 1x1 / 3x3 / 1x1 form."""
+        blocks = []
+        for b in stage:
+            convs = [b.conv1, b.conv2, b.conv3] + ([b.shortcut] if b.shortcut is not None else [])
+            if any(c.stride != (1, 1) or c.dilation != (1, 1) or c.groups != 1 for c in convs) or b.conv2.padding != (1, 1) \
+                    or any(c.padding != (0, 0) for c in (b.conv1, b.conv3)):
+                return None
+            (w1, b1), (w2, b2), (w3, b3) = b.conv1.folded(), b.conv2.folded(), b.conv3.folded()
+            ws, bs = b.shortcut.folded() if b.shortcut is not None else (None, None)
+            if any(key_is_channels_last(w) for w in (w1, w2, w3) + ((ws,) if ws is not None else ())):
+                return None
+            blocks.append(dict(w1=w1, b1=b1, w2=w2, b2=b2, w3=w3, b3=b3, ws=ws, bs=bs))
+        return blocks
+
     @Fn.fp32_island
     def forward(self, x):
         out = {}
         x = self.stem(Fn.f32(x))
         for name in self.stage_names:
-            x = getattr(self, name)(x)
+            stage = getattr(self, name)
+            blocks = self._chain_blocks(stage) if name == "res2" and x.is_cuda and not torch.is_grad_enabled() else None
+            if blocks is not None and Fn.bneck_stage_x3_ok(x, blocks):
+                # res2 as a chain: one launch per bottleneck (conv2 -> conv3 + shortcut -> the next block's conv1), the 64-channel
+                # maps between them as operand images (csrc/bneck_x3.hip)
+                x = Fn.bneck_stage_x3(x, blocks)
+            else:
+                x = stage(x)
             if name in self._out_features:
                 out[name] = x
         return out

@@ -39,6 +39,11 @@ struct CxArgs {
   const float *x2;
   int C2, stride2, W2_in;
   long long HW2_in;
+  // K = 64, stride 1: the output as an OPERAND IMAGE of csrc/bneck_x3.hip instead of an fp32 map (y == NULL): per 32-pixel group
+  // (n, oy, ox / 32) 8 KB = [k-step][hi, lo][32 g + ox % 32][8 halves], the output channels in accumulator order, split with oscale
+  void *img;
+  int XG;
+  float oscale;
 };
 
 // the w-th work item of workgroup b: XCD x = b % 8 owns the tiles t = x (mod 8); its workgroups deal (tile, pass) pairs
@@ -197,6 +202,41 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
     }
     // epilogue: lane = pixel; registers = channels co0 + 32 nb + 8 q + 4 g + i
     float chk = 0.f;                   // range guard: NaN as soon as one value is non-finite BEFORE the ReLU (which would hide a NaN)
+    if constexpr (NB == 2) {
+      if (a.img != nullptr) {
+        const __amdgpu_buffer_rsrc_t ri = dvis_make_rsrc_uniform(a.img, (unsigned)((long long)a.N * a.H_in * a.XG * 8192));
+        unsigned ibase = kOOB;
+        if (p < a.pixels) {
+          const int pix = (int)(p - n * a.HW), oy = pix / a.OW, ox = pix - oy * a.OW;
+          ibase = (unsigned)(((n * a.H_in + oy) * a.XG + (ox >> 5)) * 8192 + g * 512 + (ox & 31) * 16);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          float v[16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f4 b = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias) b = *(const f4 *)(a.bias + 32 * nb + 8 * q + 4 * g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float t = acc[nb][4 * q + i] * a.inv + b[i];
+              chk = __builtin_fmaf(t, 0.f, chk);
+              v[4 * q + i] = a.relu ? fmaxf(t, 0.f) : t;
+            }
+          }
+          h8 hi[2], lo[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const f4 p0 = {v[8 * u], v[8 * u + 1], v[8 * u + 2], v[8 * u + 3]}, p1 = {v[8 * u + 4], v[8 * u + 5], v[8 * u + 6], v[8 * u + 7]};
+            split8(p0, p1, a.oscale, hi[u], lo[u]);
+          }
+          store_fragments4(ri, ibase, hi[0], 4096 * nb, lo[0], 4096 * nb + 1024, hi[1], 4096 * nb + 2048, lo[1], 4096 * nb + 3072);
+        }
+        if (a.flag != nullptr && chk != chk && p < a.pixels) atomicCAS(a.flag, 0, a.tag);
+        tile = ntile, pass = npass_, gm = ngm, gm2 = ngm2;
+        continue;
+      }
+    }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       float rv[16];                    // the shortcut's 16 values of the block as one batch of requests
@@ -254,7 +294,7 @@ DVIS_EXPORT int dvis_conv1x1_x3_pack(const float *w, int K, int C, int wexp, voi
 
 static int cx_launch(const float *x, const void *packed, const float *bias, const float *res, float *y, int N, int C, int K, int H, int W,
                      int stride, int taps, int xexp, int wexp, int relu, void *stream, const float *x2 = nullptr, int C2 = 0, int H2 = 0,
-                     int W2 = 0, int stride2 = 1);
+                     int W2 = 0, int stride2 = 1, void *image = nullptr, int oexp = 0);
 
 DVIS_EXPORT int dvis_conv1x1_x3_dual(const float *x, const float *x2, const void *packed, const float *bias, const float *res, float *y,
                                      int N, int C, int C2, int K, int H, int W, int H2, int W2, int stride2, int xexp, int wexp, int relu,
@@ -269,6 +309,15 @@ DVIS_EXPORT int dvis_conv1x1_x3_dual(const float *x, const float *x2, const void
 DVIS_EXPORT int dvis_conv1x1_x3(const float *x, const void *packed, const float *bias, const float *res, float *y, int N, int C, int K,
                                 int H, int W, int stride, int xexp, int wexp, int relu, void *stream) {
   return cx_launch(x, packed, bias, res, y, N, C, K, H, W, stride, 1, xexp, wexp, relu, stream);
+}
+
+/* relu?(conv1x1(x, w) + bias) for K = 64 output channels, written as the operand image csrc/bneck_x3.hip reads (dvis_bneck_x3_image_bytes(N, H, W)
+ * bytes; the values split with 2^oexp): the first conv1 of the res2 stage */
+DVIS_EXPORT int dvis_conv1x1_x3_image(const float *x, const void *packed, const float *bias, void *image, int N, int C, int H, int W, int xexp,
+                                      int wexp, int oexp, int relu, void *stream) {
+  DVIS_REQUIRE(image != nullptr && (uintptr_t)image % 16 == 0, "dvis_conv1x1_x3_image: null / unaligned image");
+  DVIS_REQUIRE((long long)N * H * ((W + 31) / 32) * 8192 < ((long long)1 << 31), "dvis_conv1x1_x3_image: the image must stay below 2 GiB");
+  return cx_launch(x, packed, bias, nullptr, nullptr, N, C, 64, H, W, 1, 1, xexp, wexp, relu, stream, nullptr, 0, 0, 0, 1, image, oexp);
 }
 
 DVIS_EXPORT int64_t dvis_conv3x3_x3_packed_bytes(int C, int K) {
@@ -294,8 +343,9 @@ DVIS_EXPORT int dvis_conv3x3_x3(const float *x, const void *packed, const float 
 }
 
 static int cx_launch(const float *x, const void *packed, const float *bias, const float *res, float *y, int N, int C, int K, int H, int W,
-                     int stride, int taps, int xexp, int wexp, int relu, void *stream, const float *x2, int C2, int H2, int W2, int stride2) {
-  DVIS_REQUIRE(x && packed && y, "dvis_conv1x1_x3: null operand");
+                     int stride, int taps, int xexp, int wexp, int relu, void *stream, const float *x2, int C2, int H2, int W2, int stride2,
+                     void *image, int oexp) {
+  DVIS_REQUIRE(x && packed && (y || image), "dvis_conv1x1_x3: null operand");
   DVIS_REQUIRE(stride == 1 || stride == 2, "dvis_conv1x1_x3: stride %d", stride);
   const int OH = (H + stride - 1) / stride, OW = (W + stride - 1) / stride;
   DVIS_REQUIRE(dvis_conv1x1_x3_supported(C, K, N, (int64_t)H * W, (int64_t)OH * OW), "dvis_conv1x1_x3: shape (N %d, C %d, K %d, %d x %d, "
@@ -310,6 +360,7 @@ static int cx_launch(const float *x, const void *packed, const float *bias, cons
   const X3Guard gd = dvis_x3_guard();
   a.flag = gd.flag, a.tag = gd.tag;
   a.x2 = x2, a.C2 = x2 ? C2 : 0, a.stride2 = stride2, a.W2_in = W2, a.HW2_in = (long long)H2 * W2;
+  a.img = image, a.XG = (OW + 31) / 32, a.oscale = ldexpf(1.f, oexp);
   const int grid = dvis_x3_persistent_cus();
   hipStream_t st = (hipStream_t)stream;
   static const int nw = getenv("DVIS_X3_CONV_WAVES") ? atoi(getenv("DVIS_X3_CONV_WAVES")) : 8;

@@ -39,6 +39,26 @@ __device__ __forceinline__ void split8(f4 a, f4 b, float s, h8 &hi, h8 &lo) {
   }
 }
 
+// Four 16-byte stores of operand-image fragments, then a pause before anything may touch their data registers.
+// gfx950 / ROCm 7.2 hipcc: a buffer_store_dwordx4 reads its 4 data registers over ~16 cycles AFTER it has issued (a quad of
+// lanes per row and cycle, dword by dword); a VALU instruction that overwrites one of them in the next few cycles — hipcc
+// recycles the split's registers at once, e.g.  buffer_store_dwordx4 v[32:35], v67, s[56:59], s4 offen ; v_mul_f32 v32, s61, v40
+// — reaches memory instead of the stored value in lanes 12 - 15 of every 16 (the last quads read), run-to-run different with two
+// waves per SIMD.  hipcc's hazard recogniser allows that re-use after ONE wait state, and after none when the store carries a
+// scalar offset register — measured here to be too little (tools/exp/bneck_debug3.py: stored low terms read 2.25, 7.5, 8.75 = the
+// upper halves of the fp32 values 4.0, 65536.0, 229376.0 written by the NEXT instruction).  So: nothing is scheduled into the
+// group, and 32 wait states follow it.  (8-byte stores showed the same, 4-byte stores — every other epilogue — never did.)
+__device__ __forceinline__ void store_fragments4(__amdgpu_buffer_rsrc_t r, unsigned voff, h8 a, unsigned sa, h8 b, unsigned sb, h8 c,
+                                                 unsigned sc, h8 d, unsigned sd) {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dvis_v4u, a), r, voff, sa, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dvis_v4u, b), r, voff, sb, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dvis_v4u, c), r, voff, sc, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dvis_v4u, d), r, voff, sd, 0);
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // One item of the weight stream: STEPS k-steps x NBL blocks of 32 output features, image [s][nb][hi, lo][lane][8 halves].
 //   * The fragment pair of block t + 1 is requested before block t's three products are issued (hipcc on its own reads each
 //     fragment into one register quad and waits for it right away: an LDS round trip per product pair with the matrix pipe idle

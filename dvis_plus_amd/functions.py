@@ -1619,6 +1619,102 @@ def conv3x3_x3(x, weight, bias=None, res=None, relu=False, stride=1, xexp=None):
     return out
 
 
+X3_BNECK = os.environ.get("DVIS_X3_BNECK", "1") != "0"
+
+
+def bneck_stage_x3_ok(x, blocks):
+    """Does csrc/bneck_x3.hip serve this stage?  `blocks`: per bottleneck a dict of FOLDED weights / shifts
+    {w1, b1, w2, b2, w3, b3, ws, bs} (ws / bs None for an identity shortcut) — the res2 stage of the R50: 64 -> (64, 3x3 64, 256),
+    stride 1, a projection shortcut in the first block only."""
+    if not (X3_BNECK and x3_on() and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous()
+            and not torch.is_grad_enabled() and len(blocks) >= 2 and x.shape[1] == 64 and x.shape[0] > 0):
+        return False
+    for i, b in enumerate(blocks):
+        cin = 64 if i == 0 else 256
+        if tuple(b["w1"].shape) != (64, cin, 1, 1) or tuple(b["w2"].shape) != (64, 64, 3, 3) or tuple(b["w3"].shape) != (256, 64, 1, 1):
+            return False
+        if (b["ws"] is not None) != (i == 0) or (i == 0 and tuple(b["ws"].shape) != (256, 64, 1, 1)):
+            return False
+        if any(b[k] is not None and (b[k].dtype != torch.float32 or b[k].device != x.device) for k in b):
+            return False
+    return bool(native.lib().dvis_bneck_x3_supported(1, x.shape[2], x.shape[3]))
+
+
+def bneck_stage_x3(x, blocks, xexp=None):
+    """The whole stage through dvis_conv1x1_x3_image (first conv1) + one dvis_bneck_x3 per block (conv2 -> conv3 + shortcut ->
+    the next block's conv1); the 64-channel maps between the launches are operand images.  Returns the stage's output."""
+    N, _, H, W = x.shape
+    lib = native.lib()
+    xe = X3_CONV_XEXP if xexp is None else xexp
+    dev = x.device
+
+    def packed_conv1():
+        w = blocks[0]["w1"]
+
+        def make():
+            w2d = w.detach().reshape(64, 64).contiguous()
+            e = _x3_exp(w2d)
+            buf = torch.empty(lib.dvis_conv1x1_x3_packed_bytes(64, 64), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                native.check(lib.dvis_conv1x1_x3_pack(native.dev_ptr(w2d, "weight"), 64, 64, e, ctypes.c_void_p(buf.data_ptr()),
+                                                      native.stream_ptr(dev)), "dvis_conv1x1_x3_pack")
+            return buf, e
+        return _x3_cache(w, (w._version, w.data_ptr(), w.device), make, kind="conv1x1")
+
+    def packed_block(i):
+        b, nxt = blocks[i], (blocks[i + 1] if i + 1 < len(blocks) else None)
+        ws, w1n = b["ws"], (None if nxt is None else nxt["w1"])
+
+        def make():
+            w2 = b["w2"].detach().contiguous()
+            w3 = b["w3"].detach().reshape(256, 64).contiguous()
+            wsd = None if ws is None else ws.detach().reshape(256, 64).contiguous()
+            w1d = None if w1n is None else w1n.detach().reshape(64, 256).contiguous()
+            e2, e1 = _x3_exp(w2), (0 if w1d is None else _x3_exp(w1d))
+            e3 = _x3_exp(w3 if wsd is None else torch.cat([w3, wsd], 1))
+            buf = torch.empty(lib.dvis_bneck_x3_packed_bytes(0 if w1d is None else 1, 0 if wsd is None else 1), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                native.check(lib.dvis_bneck_x3_pack(native.dev_ptr(w2, "w2"), native.dev_ptr(w3, "w3"),
+                                                    None if wsd is None else native.dev_ptr(wsd, "ws"),
+                                                    None if w1d is None else native.dev_ptr(w1d, "w1"), e2, e3, e1,
+                                                    ctypes.c_void_p(buf.data_ptr()), native.stream_ptr(dev)), "dvis_bneck_x3_pack")
+            b3 = b["b3"]
+            if b["bs"] is not None:
+                b3 = b["bs"].detach() if b3 is None else b3.detach() + b["bs"].detach()
+            return buf, e2, e3, e1, (None if b3 is None else b3.detach().contiguous())
+        key = tuple((t._version, t.data_ptr()) if t is not None else None for t in (b["w2"], b["w3"], ws, w1n, b["b3"], b["bs"])) + (dev,)
+        return _x3_cache(b["w2"], key, make, kind="bottleneck chain")
+
+    img_bytes = lib.dvis_bneck_x3_image_bytes(N, H, W)
+    imgs = [torch.empty(img_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+    ys = [torch.empty((N, 256, H, W), dtype=torch.float32, device=dev) for _ in range(min(2, len(blocks)))]
+    step = max(1, min(N, (2 ** 31 - 1) // (256 * H * W * 4)))       # images per launch: every tensor below 2 GiB
+    per_img = img_bytes // N
+
+    def ptr(t):
+        return None if t is None else native.dev_ptr(t.detach(), "shift")
+
+    with torch.cuda.device(dev):
+        for i0 in range(0, N, step):
+            n = min(step, N - i0)
+            isl = slice(i0 * per_img, (i0 + n) * per_img)
+            buf1, e1 = packed_conv1()
+            native.check(lib.dvis_conv1x1_x3_image(native.dev_ptr(x[i0:i0 + n], "x"), ctypes.c_void_p(buf1.data_ptr()), ptr(blocks[0]["b1"]),
+                                                   ctypes.c_void_p(imgs[0][isl].data_ptr()), n, 64, H, W, xe, e1, xe, 1, native.stream_ptr(dev)),
+                         "dvis_conv1x1_x3_image")
+            for i, b in enumerate(blocks):
+                buf, e2, e3, e1n, b3 = packed_block(i)
+                last = i + 1 == len(blocks)
+                y, yprev = ys[i % 2], ys[(i + 1) % 2]
+                native.check(lib.dvis_bneck_x3(
+                    ctypes.c_void_p(imgs[i % 2][isl].data_ptr()), None if i == 0 else native.dev_ptr(yprev[i0:i0 + n], "res"),
+                    native.dev_ptr(x[i0:i0 + n], "x") if i == 0 else None, ctypes.c_void_p(buf.data_ptr()), ptr(b["b2"]), ptr(b3),
+                    None if last else ptr(blocks[i + 1]["b1"]), native.dev_ptr(y[i0:i0 + n], "y"),
+                    None if last else ctypes.c_void_p(imgs[(i + 1) % 2][isl].data_ptr()), n, H, W, xe, e2, e3, e1n, native.stream_ptr(dev)),
+                    "dvis_bneck_x3")
+    return ys[(len(blocks) - 1) % 2]
+
+
 CONV1X1_MFMA = os.environ.get("DVIS_CONV1X1_MFMA", "1") != "0"
 _C1_PACKED = {}
 

@@ -55,6 +55,8 @@
  *                               (ops/modules/ms_deform_attn.py:96-117), `norm1(src + src2)`, forward_ffn =
  *                               `norm2(src + linear2(relu(linear1(src))))` (mask2former/modeling/pixel_decoder/msdeformattn.py:103-131)
  *   dvis_conv1x1_x3          <- the compute-bound 1x1 convolutions of the R50 bottlenecks (as dvis_conv1x1_mfma) in that arithmetic
+ *   dvis_bneck_x3            <- the res2 bottlenecks (detectron2 BottleneckBlock.forward: conv2 -> conv3 + shortcut -> the next block's
+ *                               conv1) as one kernel per block, 64-channel maps as pre-split operand images
  */
 #ifndef DVIS_HIP_H
 #define DVIS_HIP_H
@@ -629,6 +631,25 @@ int64_t dvis_conv3x3_x3_packed_bytes(int C, int K);
 int dvis_conv3x3_x3_pack(const float *w, int K, int C, int wexp, void *packed, void *stream);
 int dvis_conv3x3_x3(const float *x, const void *packed, const float *bias, const float *res, float *y, int N, int C, int K, int H,
                     int W, int stride, int xexp, int wexp, int relu, void *stream);
+/*
+ * The res2 bottlenecks as a chain (csrc/bneck_x3.hip; detectron2 BottleneckBlock, 64 middle / 256 output channels):
+ * one launch = conv2 (3x3) + ReLU -> conv3 + shortcut + ReLU -> the NEXT block's conv1 + ReLU, per 32-pixel group, without
+ * conv2's map or a second read of the block output touching memory.  The 64-channel maps between blocks are OPERAND IMAGES:
+ * per group (n, y, x / 32) 8 KB = [k-step][hi, lo f16 term][32 g + x % 32][8 halves] in accumulator channel order
+ * (dvis_bneck_x3_image_bytes(N, H, W) bytes), written by dvis_conv1x1_x3_image (the stage's first conv1) or by the previous
+ * dvis_bneck_x3.  res: the identity shortcut (N, 256, H, W); or NULL with x2 = the block input (N, 64, H, W) and a stream packed
+ * with the projection shortcut ws (first block).  out: NULL (last block: no chained conv1, packed without w1) or the next image.
+ * y (N, 256, H, W); b2 / b3 (+ bs) / b1: folded-BN shifts (64 / 256 / 64).  e2 / e3 / e1: the weights' scaling exponents.
+ */
+int dvis_bneck_x3_supported(int64_t N, int H, int W);
+int64_t dvis_bneck_x3_image_bytes(int64_t N, int H, int W);
+int64_t dvis_bneck_x3_packed_bytes(int tail, int dual);
+int dvis_bneck_x3_pack(const float *w2, const float *w3, const float *ws, const float *w1, int e2, int e3, int e1, void *packed,
+                       void *stream);
+int dvis_bneck_x3(const void *a1, const float *res, const float *x2, const void *packed, const float *b2, const float *b3,
+                  const float *b1, float *y, void *out, int N, int H, int W, int xexp, int e2, int e3, int e1, void *stream);
+int dvis_conv1x1_x3_image(const float *x, const void *packed, const float *bias, void *image, int N, int C, int H, int W, int xexp,
+                          int wexp, int oexp, int relu, void *stream);
 int dvis_x3_ffn_pack(const float *W1, int64_t ldw1, const float *W2, int64_t ldw2, int K, int H, int N, int w1exp, int w2exp,
                      void *packed, void *stream);
 int dvis_x3_ffn_ln(const float *x, int64_t ldx, int64_t M, int K, int H, int N, const void *packed, int xexp, int w1exp,
