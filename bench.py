@@ -294,6 +294,16 @@ def _acct_mask_pooled(pe, pf, B, Q, C, h, w, mask, allowed, stream):
             "queries": Q, "form": 2}
 
 
+def _acct_bneck(a1, res, x2, packed, b2, b3, b1, y, out, N, H, W, *rest):
+    # csrc/bneck_x3.hip, one res2 bottleneck from conv1's map on (+ the next block's conv1): algorithmic HBM bytes per pixel =
+    # the 64-channel operand image in (256 B) + the shortcut in (1024 B identity, 256 B projection input) + the block output
+    # (1024 B) + the next operand image (256 B); flops = 2 (9 64 64 + 64 256 [+ 64 256] + [256 64]) per pixel
+    px = float(N) * H * W
+    proj, tail = bool(x2), bool(out)
+    return {"bytes": px * (256 + (256 if proj else 1024) + 1024 + (256 if tail else 0)),
+            "flops": 2.0 * px * (9 * 64 * 64 + 64 * 256 + (64 * 256 if proj else 0) + (256 * 64 if tail else 0)), "frames": N}
+
+
 def _acct_attention(q, qs, k, ks, v, vs, out, os_, mask, allowed, B, heads, Lq, Lk, d, scale, ws, stream, kernel):
     # QK^T + PV: 4 Lq Lk d per (batch, head); bytes: q, out (Lq rows), k, v (Lk rows) of heads * d floats + the byte mask
     masked = bool(mask)
@@ -678,6 +688,7 @@ def main():
         tm.conv, tm.ffn = ConvTimer(), FfnTimer()
         tm.mask0, tm.mask2 = LibTimer("dvis_mask_logits", _acct_mask_logits), LibTimer("dvis_attn_mask_pooled", _acct_mask_pooled)
         tm.attn = LibTimer("dvis_attention_forward_k", _acct_attention)
+        tm.bneck = LibTimer("dvis_bneck_x3", _acct_bneck)
         t0 = time.perf_counter()
         with tm, tm.conv, tm.ffn, tm.mask0, tm.mask2, tm.attn:
             res_ = run_pass(videos[:args.steps], lt)
@@ -798,7 +809,7 @@ def main():
         prev = os.environ.get("DVIS_SEGMENTER_GRAPH")
         os.environ["DVIS_SEGMENTER_GRAPH"] = "0"
         try:
-            with timer, timer.conv, timer.ffn, timer.mask0, timer.mask2, timer.attn:
+            with timer, timer.conv, timer.ffn, timer.mask0, timer.mask2, timer.attn, timer.bneck:
                 run_pass(videos[:2])
         finally:
             os.environ.pop("DVIS_SEGMENTER_GRAPH") if prev is None else os.environ.__setitem__("DVIS_SEGMENTER_GRAPH", prev)
@@ -907,7 +918,20 @@ def main():
                                              "note": "self-attention over the queries / tracker / refiner (Lk <= 128): latency-bound, not priced"},
                          "note": "flops = 4 Q HW_l C per frame and layer (QK^T + PV, SURVEY.md section 8d), summed over the timed masked "
                                  "launches (levels 920 / 3680 / 14720 keys) / their summed HIP-event durations (both launches of a call)"}
-        for roof, key in ((mask_roof, "mask_gemm_kernel"), (attn_roof, "attn_keysplit_kernel")):
+        bneck_roof = None
+        b_s, b_t, b_n = timer.bneck.summary()
+        if b_n:
+            gbs, tf16 = b_t["bytes"] / b_s / 1e9, 3.0 * b_t["flops"] / b_s / 1e12
+            bneck_roof = {"bound": "hbm", "kernel": "bneck_chain_kernel (csrc/bneck_x3.hip: a res2 bottleneck per launch - conv2 3x3 -> conv3 + "
+                                                    "shortcut -> the next block's conv1, 64-channel maps as pre-split operand images)",
+                          "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                          "launches_timed": b_n, "us_per_launch": round(b_s / b_n * 1e6, 1), "ms_per_clip": round(b_s / timed_clips * 1e3, 3),
+                          "alg_bytes_per_launch": int(b_t["bytes"] / b_n), "mfma_f16_issued_tflops": round(tf16, 1),
+                          "mfma_f16_frac": round(tf16 / MFMA_F16_PEAK_TF, 4),
+                          "note": "algorithmic bytes (operand image in, shortcut in, block output out, next operand image out) / summed "
+                                  "HIP-event durations of the timed launches; the three layers it replaces moved 7.2 GB per 30-frame block "
+                                  "as separate launches, the chain 4.6 GB"}
+        for roof, key in ((mask_roof, "mask_gemm_kernel"), (attn_roof, "attn_keysplit_kernel"), (bneck_roof, "bneck_chain_kernel")):
             t = x3_traffic.get(key)
             if roof is not None and t is not None:
                 roof["traffic"] = t["hbm_bytes_per_launch"]      # (mean over every launch of the kernel family in the profiled bench run)
@@ -955,6 +979,8 @@ def main():
             res["roofline_conv_x3"] = convk_roof
         if ffn_roof is not None:
             res["roofline_ffn"] = ffn_roof
+        if bneck_roof is not None:
+            res["roofline_bneck"] = bneck_roof
         if mask_roof is not None:
             res["roofline_mask_gemm"] = mask_roof
         if attn_roof is not None:

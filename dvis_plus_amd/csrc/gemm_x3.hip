@@ -30,6 +30,10 @@
 //                            resident (K = 256: 128 registers per lane);
 //   x3_ffn_kernel            linear1 + ReLU + linear2 + residual + LayerNorm: 4 waves at 512 registers (fragments of the row
 //                            128, accumulators 128 + 64, hidden fragments 64).
+// The ring's LDS-DMA requests in the MUBUF encoding (x3_common.h: dma16): hipcc's own waits stay counted instead of full drains
+// (linear 256 -> 256 0.364 -> 0.350 ms, FFN 1.895 -> 1.802 ms per 30-frame layer; the convolution kernels measured +- 1 % and
+// keep the FLAT form).
+#define DVIS_X3_DMA_MUBUF 1
 #include "dvis_common.h"
 #include "x3_common.h"
 

@@ -1,6 +1,7 @@
 // Shared device code of the split-f16 matrix-core kernels (csrc/gemm_x3.hip, csrc/conv1x1_x3.hip): operand split, fragment
 // MFMA loop over one item of the packed weight stream, the LDS ring that streams it.  See gemm_x3.hip for the design.
 #pragma once
+#pragma clang diagnostic ignored "-Winline-asm"      // (m0 on a clobber list: the LDS-DMA statement sets it)
 #include "dvis_common.h"
 #include <stdlib.h>
 
@@ -25,6 +26,24 @@ constexpr int kScratch = 4096;        // per wave: 32 tokens x 32 floats, the ep
 __device__ __forceinline__ void glds16(const void *g, void *l) {
   __builtin_amdgcn_global_load_lds((const DVIS_GLB void *)g, (DVIS_LDS void *)l, 16, 0, 0);
 }
+
+// The same request in the MUBUF encoding, as an assembler statement: 1 KB of the stream (descriptor `rs`, scalar byte offset `so`,
+// the lane's 16 bytes in `voff`) to LDS address `dst` + 16 lane.  hipcc's wait-count insertion treats the FLAT-encoded
+// global_load_lds as "may touch LDS AND memory" and from then on turns every vmcnt / lgkmcnt wait it inserts into a full drain
+// (s_waitcnt vmcnt(0) / lgkmcnt(0)) until both counters have been zero once; the assembler statement is not counted at all, so
+// the compiler's waits for ITS loads stay counted (they only over-wait by the requests in flight, which complete in order),
+// and the requests themselves are waited for explicitly (Ring::wait).
+typedef unsigned x3_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ x3_u4 x3_stream_rsrc(const void *base) {
+  const uintptr_t b = (uintptr_t)base;
+  const x3_u4 r = {(unsigned)__builtin_amdgcn_readfirstlane((unsigned)b), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) & 0xffffu,
+                   0xffffffffu, 0x00020000u};
+  return r;
+}
+__device__ __forceinline__ void dma16(x3_u4 rs, unsigned voff, unsigned so, unsigned dst) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(voff), "s"(rs), "s"(so) : "memory", "m0");
+}
+__device__ __forceinline__ unsigned lds_address(const void *p) { return (unsigned)(uintptr_t)(DVIS_LDS const char *)p; }
 
 // v * s -> (hi, lo) for 8 values (round to nearest twice; s is a power of two, so v * s and the residual are exact)
 __device__ __forceinline__ void split8(f4 a, f4 b, float s, h8 &hi, h8 &lo) {
@@ -124,16 +143,29 @@ struct Ring {
   static constexpr int kAhead = STAGES - 1;                 // items requested ahead of the one being multiplied
   static constexpr int kLeave = (STAGES - 2) * PW + EXTRA;  // loads newer than the item waited for that may stay in flight
 
+#ifdef DVIS_X3_DMA_MUBUF
+  x3_u4 rs;
+  unsigned lds0, voff;
+#endif
   __device__ __forceinline__ void issue_at(size_t byte_offset) {
+#ifdef DVIS_X3_DMA_MUBUF
+#pragma unroll
+    for (int p = 0; p < PW; ++p) dma16(rs, voff, (unsigned)byte_offset + (NW * p) * kPiece, lds0 + st_iss * kItemBytes + (NW * p) * kPiece);
+#else
     const char *g = src + byte_offset + lane * 16;
     char *l = lds + st_iss * kItemBytes;
 #pragma unroll
     for (int p = 0; p < PW; ++p) glds16(g + (wave + NW * p) * kPiece, l + (wave + NW * p) * kPiece);
+#endif
     st_iss = st_iss + 1 == STAGES ? 0 : st_iss + 1;
   }
   __device__ __forceinline__ void init(const void *stream, char *ring, int period_, int total_, int wave_, int lane_) {
     src = (const char *)stream, lds = ring, period = period_, total = total_, it = 0, st_cmp = 0, st_iss = 0;
     wave = wave_, lane = lane_;
+#ifdef DVIS_X3_DMA_MUBUF
+    wave = __builtin_amdgcn_readfirstlane(wave_);
+    rs = x3_stream_rsrc(stream), lds0 = lds_address(ring) + wave * kPiece, voff = lane * 16 + wave * kPiece;
+#endif
   }
   __device__ __forceinline__ void start(const void *stream, char *ring, int period_, int total_, int wave_, int lane_) {
     init(stream, ring, period_, total_, wave_, lane_);
@@ -159,17 +191,26 @@ struct Ring {
   }
   const char *dma_src;
   char *dma_dst;
+  unsigned dma_so, dma_ld;
   bool dma_on;
   __device__ __forceinline__ bool more() const { return it + kAhead - 1 < total; }      // after wait(): is there an item to request?
   __device__ __forceinline__ void begin(size_t byte_offset) {       // after wait(): `it` already counts the waited item
     dma_on = more();
+#ifdef DVIS_X3_DMA_MUBUF
+    dma_so = (unsigned)byte_offset, dma_ld = lds0 + st_iss * kItemBytes;
+#else
     dma_src = src + byte_offset + lane * 16 + wave * kPiece;
     dma_dst = lds + st_iss * kItemBytes + wave * kPiece;
+#endif
     if (dma_on) st_iss = st_iss + 1 == STAGES ? 0 : st_iss + 1;
   }
   __device__ __forceinline__ void begin_periodic() { begin((size_t)((it + kAhead - 1) % period) * kItemBytes); }
   __device__ __forceinline__ void piece(int i) {
+#ifdef DVIS_X3_DMA_MUBUF
+    if (dma_on) dma16(rs, voff, dma_so + i * (NW * kPiece), dma_ld + i * (NW * kPiece));
+#else
     if (dma_on) glds16(dma_src + i * (NW * kPiece), dma_dst + i * (NW * kPiece));
+#endif
   }
 };
 

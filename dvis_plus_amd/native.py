@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdvis_hip.so")
+LIB_PATH = os.environ.get("DVIS_HIP_LIB") or os.path.join(_HERE, "lib", "libdvis_hip.so")      # (DVIS_HIP_LIB: development — A / B of two builds)
 
 F32, F64, F16, BF16 = 0, 1, 2, 3
 _DTYPE = {torch.float32: F32, torch.float64: F64, torch.float16: F16, torch.bfloat16: BF16}

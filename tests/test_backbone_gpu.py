@@ -99,7 +99,8 @@ def test_resnet50_production_size_strict_own_kernels_vs_unfused_fp64():
     sd = {k: v.double() for k, v in m.state_dict().items()}
     lib = native.lib()
     names = ("dvis_conv3x3_winograd", "dvis_conv1x1_mfma", "dvis_conv1x1s2_mfma", "dvis_conv3x3s2", "dvis_conv7x7s2",
-             "dvis_conv1x1_bias_act", "dvis_bias_relu_maxpool", "dvis_conv1x1_x3", "dvis_conv3x3_x3", "dvis_conv1x1_x3_dual")
+             "dvis_conv1x1_bias_act", "dvis_bias_relu_maxpool", "dvis_conv1x1_x3", "dvis_conv3x3_x3", "dvis_conv1x1_x3_dual",
+             "dvis_bneck_x3", "dvis_conv1x1_x3_image")
     calls = {n: 0 for n in names}
     orig = {n: getattr(lib, n) for n in names}
     lib_convs = []
@@ -126,21 +127,25 @@ def test_resnet50_production_size_strict_own_kernels_vs_unfused_fp64():
     # 16 bottlenecks: 13 stride-1 3x3 (Winograd) + 3 stride-2 3x3; 4 shortcuts (1 stride-1, 3 stride-2); the stem
     from dvis_plus_amd import functions as Fn
     assert calls["dvis_conv7x7s2"] == 1
-    if Fn.X3:     # from 128 channels on (and every stride-2 layer) the nine-tap split-f16 kernel, the three 64-channel ones Winograd
-        assert calls["dvis_conv3x3_winograd"] == 3 and calls["dvis_conv3x3s2"] == 0 and calls["dvis_conv3x3_x3"] == 13, calls
+    chain = Fn.X3 and Fn.X3_BNECK     # round 6: res2 = one launch per bottleneck (csrc/bneck_x3.hip) behind the first conv1
+    if Fn.X3:     # from 128 channels on (and every stride-2 layer) the nine-tap split-f16 kernel; the three 64-channel ones inside
+        # the chain, or (DVIS_X3_BNECK=0) Winograd
+        assert calls["dvis_conv3x3_winograd"] == (0 if chain else 3) and calls["dvis_conv3x3s2"] == 0 and calls["dvis_conv3x3_x3"] == 13, calls
     else:
         assert calls["dvis_conv3x3_winograd"] == 13 and calls["dvis_conv3x3s2"] == 3 and calls["dvis_conv3x3_x3"] == 0, calls
+    assert calls["dvis_bneck_x3"] == (3 if chain else 0) and calls["dvis_conv1x1_x3_image"] == (1 if chain else 0), calls
     assert calls["dvis_bias_relu_maxpool"] == 1
     # the 1x1 layers: 16 x (conv1, conv3) + 4 shortcuts = 36: with the split-f16 kernels on, every one of them (>= 64 input
     # channels) runs on csrc/conv1x1_x3.hip; DVIS_X3=0: the compute-bound ones and the stride-2 shortcuts on
     # csrc/conv1x1_mfma.hip, the rest on the LDS-weights kernel csrc/conv1x1.hip
-    from dvis_plus_amd import functions as Fn
-    # (round 5: the four blocks with a projection shortcut run conv3 + shortcut as ONE launch, dvis_conv1x1_x3_dual = 2 layers each)
+    # (round 5: the blocks with a projection shortcut run conv3 + shortcut as ONE launch, dvis_conv1x1_x3_dual = 2 layers each;
+    # round 6: the 7 layers of res2 are inside the chain's 4 launches)
     dual = calls["dvis_conv1x1_x3_dual"]
-    assert dual == (4 if Fn.X3 and Fn.X3_DUAL else 0), calls
-    mm = calls["dvis_conv1x1_x3"] + 2 * dual if Fn.X3 else calls["dvis_conv1x1_mfma"] + calls["dvis_conv1x1s2_mfma"]
+    assert dual == ((3 if chain else 4) if Fn.X3 and Fn.X3_DUAL else 0), calls
+    in_chain = 7 if chain else 0
+    mm = calls["dvis_conv1x1_x3"] + 2 * dual + in_chain if Fn.X3 else calls["dvis_conv1x1_mfma"] + calls["dvis_conv1x1s2_mfma"]
     assert mm >= 20 and mm + calls["dvis_conv1x1_bias_act"] == 36, calls
-    assert calls["dvis_conv1x1_x3"] + 2 * dual + calls["dvis_conv1x1_mfma"] + calls["dvis_conv1x1s2_mfma"] == mm, calls
+    assert calls["dvis_conv1x1_x3"] + 2 * dual + in_chain + calls["dvis_conv1x1_mfma"] + calls["dvis_conv1x1s2_mfma"] == mm, calls
     want = _resnet50_fp64(sd, x.double())
     for k, c, s in (("res2", 256, 4), ("res3", 512, 8), ("res4", 1024, 16), ("res5", 2048, 32)):
         assert got[k].shape == want[k].shape == (2, c, 736 // s, 1280 // s)
