@@ -182,12 +182,25 @@ class ConvTimer:
             self.events1.append((e0, e1, 2.0 * N * (C + C2) * K * H * W))
             return rc
         lib.dvis_conv1x1_x3_dual = timed_2
+        self.orig3 = lib.dvis_conv_x3_image
+
+        def timed_3(ximg, x, packed, bias, res, y, image, N, C, K, H, W, stride, taps, *rest):      # the same kernel with operand images on either side
+            st = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            rc = self.orig3(ximg, x, packed, bias, res, y, image, N, C, K, H, W, stride, taps, *rest)
+            e1.record(st)
+            (self.events if taps == 9 and self.x3 else self.events1).append(
+                (e0, e1, 2.0 * taps * N * C * K * ((H + stride - 1) // stride) * ((W + stride - 1) // stride)))
+            return rc
+        lib.dvis_conv_x3_image = timed_3
         return self
 
     def __exit__(self, *exc):
         setattr(self.lib, self.name, self.orig)
         self.lib.dvis_conv1x1_x3 = self.orig1
         self.lib.dvis_conv1x1_x3_dual = self.orig2
+        self.lib.dvis_conv_x3_image = self.orig3
 
     def summary(self):
         torch.cuda.synchronize()
@@ -690,7 +703,7 @@ def main():
         tm.attn = LibTimer("dvis_attention_forward_k", _acct_attention)
         tm.bneck = LibTimer("dvis_bneck_x3", _acct_bneck)
         t0 = time.perf_counter()
-        with tm, tm.conv, tm.ffn, tm.mask0, tm.mask2, tm.attn:
+        with tm, tm.conv, tm.ffn, tm.mask0, tm.mask2, tm.attn, tm.bneck:
             res_ = run_pass(videos[:args.steps], lt)
         torch.cuda.synchronize()
         if dist_on:

@@ -109,7 +109,48 @@ class BottleneckBlock(nn.Module):
         self.conv2 = ConvBN(bottleneck, bottleneck, 3, stride=stride, padding=1)  # stride on the 3x3
         self.conv3 = ConvBN(bottleneck, cout, 1)
 
+    def _plain(self):
+        c1, c2, c3 = self.conv1, self.conv2, self.conv3
+        return all(c.dilation == (1, 1) and c.groups == 1 for c in (c1, c2, c3)) and c1.kernel_size == (1, 1) and c1.stride == (1, 1) \
+            and c1.padding == (0, 0) and c2.kernel_size == (3, 3) and c2.padding == (1, 1) and c2.stride[0] == c2.stride[1] \
+            and c2.stride[0] in (1, 2) and c3.kernel_size == (1, 1) and c3.stride == (1, 1) and c3.padding == (0, 0)
+
+    def _forward_images(self, x):
+        """The maps INSIDE the bottleneck as operand images (csrc/conv1x1_x3.hip, IMGIN / IMGOUT): conv1's epilogue splits its
+        output once, the nine taps of conv2 and conv3's 1x1 read fragments.  None when the block / shapes are not served."""
+        if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and not torch.is_grad_enabled() and self._plain()):
+            return None
+        N, C, H, W = x.shape
+        (w1, b1), (w2, b2), (w3, b3) = self.conv1.folded(), self.conv2.folded(), self.conv3.folded()
+        if any(key_is_channels_last(w) for w in (w1, w2, w3)):
+            return None
+        M, s = w1.shape[0], self.conv2.stride[0]
+        OH, OW = (H + s - 1) // s, (W + s - 1) // s
+        if M < 128 or not (Fn.x3_images_ok(N, C, M, H, W, x.device) and Fn.x3_images_ok(N, M, M, H, W, x.device, 9, s)):
+            return None
+        sc = self.shortcut
+        if sc is None:
+            if s != 1 or not Fn.x3_images_ok(N, M, w3.shape[0], OH, OW, x.device):
+                return None
+            a1 = Fn.conv_x3_image(x, w1, b1, None, relu=True, out_image=True)
+            a2 = Fn.conv_x3_image(a1, w2, b2, None, relu=True, out_image=True)
+            return Fn.conv_x3_image(a2, w3, b3, x, relu=True)
+        # projection shortcut: conv1 -> image -> conv2 (fp32 map out) -> conv3 + shortcut as one accumulation (the fp32-map kernel)
+        if not (sc.kernel_size == (1, 1) and sc.padding == (0, 0) and sc.stride[0] == sc.stride[1] == s and sc.dilation == (1, 1) and sc.groups == 1):
+            return None
+        ws, bs = sc.folded()
+        if key_is_channels_last(ws):
+            return None
+        a1 = Fn.conv_x3_image(x, w1, b1, None, relu=True, out_image=True)
+        a2 = Fn.conv_x3_image(a1, w2, b2, None, relu=True, stride=s)
+        if not Fn.conv1x1_x3_dual_ok(a2, w3, x, ws, s):
+            return None
+        return Fn.conv1x1_x3_dual(a2, w3, b3, x, ws, bs, relu=True, stride2=s)
+
     def forward(self, x):
+        y = self._forward_images(x)
+        if y is not None:
+            return y
         out = self.conv1(x, relu=True)
         out = self.conv2(out, relu=True)
         sc, c3 = self.shortcut, self.conv3

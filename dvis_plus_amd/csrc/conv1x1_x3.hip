@@ -18,6 +18,8 @@
 #include "dvis_common.h"
 #include "x3_common.h"
 
+DVIS_EXPORT int64_t dvis_conv_x3_image_bytes(int64_t N, int C, int H, int W);
+
 namespace {
 
 constexpr unsigned kOOB = 0x80000000u;     // beyond any served tensor (< 2 GiB): buffer loads return 0, stores are dropped
@@ -44,6 +46,12 @@ struct CxArgs {
   void *img;
   int XG;
   float oscale;
+  int OH;                                  // output rows
+  // IMGIN: the input as an operand image (written by an IMGOUT launch, dvis_upsample_add_image or csrc/bneck_x3.hip) instead of
+  // x: per 32-pixel group (n, iy, ix / 32) C / 64 chunks of 8 KB, the channels of a chunk in accumulator order — the weights
+  // are packed to match (dvis_conv_x3_pack_image).  Nothing is split: a chunk is 8 loads of 16 bytes per lane.
+  const void *ximg;
+  int XG_in;
 };
 
 // the w-th work item of workgroup b: XCD x = b % 8 owns the tiles t = x (mod 8); its workgroups deal (tile, pass) pairs
@@ -61,15 +69,17 @@ __device__ __forceinline__ bool cx_item(const CxArgs &a, long long w, long long 
 struct CxGeom {
   unsigned base;      // byte offset of channel 0 of image n; kOOB for a pixel past the end
   int iy, ix;         // oy * stride - pad, ox * stride - pad
+  int row0;           // n * H_in: the image's first row in an operand image
 };
 __device__ __forceinline__ CxGeom cx_geom(const CxArgs &a, long long p) {
-  CxGeom gm = {kOOB, 0, 0};
+  CxGeom gm = {kOOB, 0, 0, 0};
   if (p >= a.pixels) return gm;
   const long long n = p / a.HW;
   const int pix = (int)(p - n * a.HW);
   const int oy = pix / a.OW, ox = pix - oy * a.OW, pad = a.taps == 9 ? 1 : 0;
   gm.base = (unsigned)(n * a.C * a.HW_in * 4);
   gm.iy = oy * a.stride - pad, gm.ix = ox * a.stride - pad;
+  gm.row0 = (int)(n * a.H_in);
   return gm;
 }
 // byte offset of channel 0 of the input pixel tap (dy, dx) of the geometry; kOOB outside the image (zero padding)
@@ -78,6 +88,14 @@ __device__ __forceinline__ unsigned cx_tap_offset(const CxArgs &a, const CxGeom 
   const int iy = gm.iy + dy, ix = gm.ix + dx;
   const bool ok = gm.base != kOOB && iy >= 0 && iy < a.H_in && ix >= 0 && ix < a.W_in;
   return ok ? gm.base + (unsigned)((iy * a.W_in + ix) * 4) : kOOB;
+}
+
+// IMGIN: byte offset of the lane's 16 bytes (k-step 0, high term) in chunk 0 of the group that holds input pixel tap (dy, dx)
+__device__ __forceinline__ unsigned cx_tap_offset_img(const CxArgs &a, const CxGeom &gm, int tap, int g) {
+  const int dy = a.taps == 9 ? tap / 3 : 0, dx = a.taps == 9 ? tap - 3 * dy : 0;
+  const int iy = gm.iy + dy, ix = gm.ix + dx;
+  const bool ok = gm.base != kOOB && iy >= 0 && iy < a.H_in && ix >= 0 && ix < a.W_in;
+  return ok ? (unsigned)(((gm.row0 + iy) * a.XG_in + (ix >> 5)) * ((a.C / 64) * 8192) + g * 512 + (ix & 31) * 16) : kOOB;
 }
 
 // byte offset of channel 0 of source 2's input pixel for output pixel p (stride2 sampling, no padding); kOOB past the end
@@ -91,7 +109,10 @@ __device__ __forceinline__ unsigned cx_geom2(const CxArgs &a, long long p) {
 
 // NW waves x 32 pixels per tile; 8 waves = two per SIMD (<= 256 registers each) cover each other's stalls.
 // IK k-steps per ring item: 2 (three stages) or 4 (= one activation chunk; two stages of up to 64 KB: half the barriers).
-template <int NB, int NW, int IK>
+// IMGIN / IMGOUT: the input / output as operand images (CxArgs::ximg / img) — the 64 .. 512-channel maps INSIDE a bottleneck and the
+// FPN output convolution's input travel that way: the producer's epilogue splits once, the nine taps of a 3x3 consumer re-read the
+// image (8 loads of 16 bytes per chunk and lane instead of 32 of 4 bytes, no split arithmetic in the loop).
+template <int NB, int NW, int IK, bool IMGIN = false, bool IMGOUT = false>
 __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
   constexpr int kTile = NW * 32, PW = 2 * IK * NB / NW, STAGES = IK == 4 ? 2 : 3, IPC = 4 / IK;
   static_assert(2 * IK * NB % NW == 0, "the item's pieces must divide among the waves");
@@ -112,7 +133,7 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
   const __amdgpu_buffer_rsrc_t rx2 = dvis_make_rsrc_uniform(a.C2 ? a.x2 : a.x, a.C2 ? (unsigned)((long long)a.N * a.C2 * a.HW2_in * 4) : 0u);
   const unsigned chan2 = (unsigned)(a.HW2_in * 4);
 
-  typedef Ring<PW, 32, NW, STAGES> RingT;
+  typedef Ring<PW, IMGIN ? 8 : 32, NW, STAGES> RingT;
   RingT ring;
   // issue cursor: where the next item to request lives
   long long iw = 0;
@@ -150,19 +171,33 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
       for (int e = 0; e < 8; ++e)
         raw[8 * s + e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vo, so + (unsigned)(16 * s + e) * ch, 0));
   };
+  // IMGIN: the next chunk's operand pair, requested as it will be multiplied
+  const __amdgpu_buffer_rsrc_t rxi = dvis_make_rsrc_uniform(IMGIN ? a.ximg : (const void *)a.x,
+                                                            IMGIN ? (unsigned)((long long)a.N * a.H_in * a.XG_in * (a.C / 64) * 8192) : 0u);
+  h8 nh[4], nl[4];
+  auto load_img = [&](unsigned off, int cc) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      nh[s] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rxi, off, (unsigned)(8192 * cc + 2048 * s), 0));
+      nl[s] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rxi, off, (unsigned)(8192 * cc + 2048 * s + 1024), 0));
+    }
+  };
   long long tile;
   int pass;
   cx_item(a, 0, &tile, &pass);
   CxGeom gm = cx_geom(a, tile * kTile + wave * 32 + j);
   unsigned gm2 = cx_geom2(a, tile * kTile + wave * 32 + j);
-  load_raw(cx_tap_offset(a, gm, 0), 0);
+  if constexpr (IMGIN)
+    load_img(cx_tap_offset_img(a, gm, 0, g), 0);
+  else
+    load_raw(cx_tap_offset(a, gm, 0), 0);
   for (long long w = 0; w < wcount; ++w) {
     const long long p = tile * kTile + wave * 32 + j;
     // the next work item (its first chunk is requested while this one's last chunk is multiplied)
     long long ntile = tile;
     int npass_ = pass;
     const bool more = cx_item(a, w + 1, &ntile, &npass_);
-    const CxGeom ngm = more ? cx_geom(a, ntile * kTile + wave * 32 + j) : CxGeom{kOOB, 0, 0};
+    const CxGeom ngm = more ? cx_geom(a, ntile * kTile + wave * 32 + j) : CxGeom{kOOB, 0, 0, 0};
     const unsigned ngm2 = more ? cx_geom2(a, ntile * kTile + wave * 32 + j) : kOOB;
     int tap = 0, cc = 0;                   // of the chunk that is requested next
     f16v acc[NB];
@@ -177,18 +212,28 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
     for (int kc = 0; kc < NC; ++kc) {
       // the chunk's values are taken HERE (an opaque use: hipcc otherwise sinks the split below the requests that follow and,
       // with LDS-DMA in flight, waits for everything it finds outstanding there — the next chunk included)
-#pragma unroll
-      for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(raw[i]));
       h8 xh[4], xl[4];
+      if constexpr (IMGIN) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const f4 lo4 = {raw[8 * s], raw[8 * s + 1], raw[8 * s + 2], raw[8 * s + 3]};
-        const f4 hi4 = {raw[8 * s + 4], raw[8 * s + 5], raw[8 * s + 6], raw[8 * s + 7]};
-        split8(lo4, hi4, a.xscale, xh[s], xl[s]);
-      }
-      // ALWAYS 32 loads here (the ring's counted wait relies on it): the next chunk, the next item's first, or nothing (OOB)
-      if (++cc == NCC) cc = 0, ++tap;
-      {
+        for (int s = 0; s < 4; ++s) {
+          asm volatile("" : "+v"(nh[s]), "+v"(nl[s]));
+          xh[s] = nh[s], xl[s] = nl[s];
+        }
+        // ALWAYS 8 loads here (the ring's counted wait relies on it): the next chunk, the next item's first, or nothing (OOB)
+        if (++cc == NCC) cc = 0, ++tap;
+        const bool first = kc + 1 < NC1;
+        load_img(first ? cx_tap_offset_img(a, gm, tap, g) : cx_tap_offset_img(a, ngm, 0, g), first ? cc : 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(raw[i]));
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const f4 lo4 = {raw[8 * s], raw[8 * s + 1], raw[8 * s + 2], raw[8 * s + 3]};
+          const f4 hi4 = {raw[8 * s + 4], raw[8 * s + 5], raw[8 * s + 6], raw[8 * s + 7]};
+          split8(lo4, hi4, a.xscale, xh[s], xl[s]);
+        }
+        // ALWAYS 32 loads here (the ring's counted wait relies on it): the next chunk, the next item's first, or nothing (OOB)
+        if (++cc == NCC) cc = 0, ++tap;
         const bool first = kc + 1 < NC1, sec = !first && kc + 1 < NC;      // wave-uniform; the second source's chunks follow the first's
         const unsigned po = first ? cx_tap_offset(a, gm, tap) : (sec ? gm2 : cx_tap_offset(a, ngm, 0));
         load_raw(po, first ? cc : (sec ? kc + 1 - NC1 : 0), sec);
@@ -202,13 +247,15 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
     }
     // epilogue: lane = pixel; registers = channels co0 + 32 nb + 8 q + 4 g + i
     float chk = 0.f;                   // range guard: NaN as soon as one value is non-finite BEFORE the ReLU (which would hide a NaN)
-    if constexpr (NB == 2) {
+    if constexpr (NB == 2 || IMGOUT) {
       if (a.img != nullptr) {
-        const __amdgpu_buffer_rsrc_t ri = dvis_make_rsrc_uniform(a.img, (unsigned)((long long)a.N * a.H_in * a.XG * 8192));
+        // K / 64 chunks per group; this pass holds chunks co0 / 64 .. : block nb = k-steps 2 (nb & 1), 2 (nb & 1) + 1 of chunk nb / 2
+        const unsigned gs = (unsigned)(a.K / 64) * 8192u;
+        const __amdgpu_buffer_rsrc_t ri = dvis_make_rsrc_uniform(a.img, (unsigned)((long long)a.N * a.OH * a.XG * gs));
         unsigned ibase = kOOB;
         if (p < a.pixels) {
           const int pix = (int)(p - n * a.HW), oy = pix / a.OW, ox = pix - oy * a.OW;
-          ibase = (unsigned)(((n * a.H_in + oy) * a.XG + (ox >> 5)) * 8192 + g * 512 + (ox & 31) * 16);
+          ibase = (unsigned)(((n * a.OH + oy) * a.XG + (ox >> 5)) * gs + (co0 / 64) * 8192 + g * 512 + (ox & 31) * 16);
         }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -216,7 +263,7 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             f4 b = {0.f, 0.f, 0.f, 0.f};
-            if (a.bias) b = *(const f4 *)(a.bias + 32 * nb + 8 * q + 4 * g);
+            if (a.bias) b = *(const f4 *)(a.bias + co0 + 32 * nb + 8 * q + 4 * g);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const float t = acc[nb][4 * q + i] * a.inv + b[i];
@@ -230,7 +277,7 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
             const f4 p0 = {v[8 * u], v[8 * u + 1], v[8 * u + 2], v[8 * u + 3]}, p1 = {v[8 * u + 4], v[8 * u + 5], v[8 * u + 6], v[8 * u + 7]};
             split8(p0, p1, a.oscale, hi[u], lo[u]);
           }
-          store_fragments4(ri, ibase, hi[0], 4096 * nb, lo[0], 4096 * nb + 1024, hi[1], 4096 * nb + 2048, lo[1], 4096 * nb + 3072);
+          store_fragments4(ri, ibase, hi[0], 4096 * nb, lo[0], 4096 * nb + 1024, hi[1], 4096 * nb + 2048, lo[1], 4096 * nb + 3072);      // (8192 (nb / 2) + 2048 (2 (nb & 1) + u) + 1024 hl)
         }
         if (a.flag != nullptr && chk != chk && p < a.pixels) atomicCAS(a.flag, 0, a.tag);
         tile = ntile, pass = npass_, gm = ngm, gm2 = ngm2;
@@ -265,7 +312,75 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
   }
 }
 
+// lateral * scale + shift + bilinear(top) (the FPN's top-down sum, csrc/fused_elementwise.hip: upsample_add_kernel — the same
+// formula and operation order) written as an OPERAND IMAGE of C channels: the 3x3 output convolution behind it (IMGIN) reads
+// fragments instead of splitting the fp32 map nine times.  One workgroup = one (32-pixel group, 64-channel chunk): thread
+// (k-step S, half g, pixel x) makes the 8 channels of its fragment; a wave's store is 1 KB of consecutive image bytes.
+__global__ __launch_bounds__(256) void upsample_add_image_kernel(const float *__restrict__ lateral, const float *__restrict__ top,
+                                                                 void *__restrict__ img, int N, int C, int H, int W, int h, int w,
+                                                                 const float *__restrict__ lat_scale, const float *__restrict__ lat_shift,
+                                                                 float oscale) {
+  // grid (chunk, group of the row, block of 16 image rows): no per-thread division beyond row -> (image, y)
+  const int NCC = C / 64, XG = (W + 31) / 32;
+  const int cc = blockIdx.x, xg = blockIdx.y;
+  const int x = threadIdx.x & 31, g = (threadIdx.x >> 5) & 1, S = threadIdx.x >> 6;
+  const int px = 32 * xg + x;
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  const int pxc = px < W ? px : W - 1;               // (lanes past the row's end compute a value nobody reads)
+  float fx = sx * ((float)pxc + 0.5f) - 0.5f;
+  fx = fx < 0.f ? 0.f : fx;
+  const int x0 = min((int)fx, w - 1), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+  const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+  const __amdgpu_buffer_rsrc_t ri = dvis_make_rsrc_uniform(img, (unsigned)((long long)N * H * XG * NCC * 8192));
+  const unsigned rows = (unsigned)N * (unsigned)H;
+  for (unsigned row = blockIdx.z * 16u; row < blockIdx.z * 16u + 16u && row < rows; ++row) {
+    const unsigned n = row / (unsigned)H;
+    const int y = (int)(row - n * (unsigned)H);
+    float fy = sy * ((float)y + 0.5f) - 0.5f;
+    fy = fy < 0.f ? 0.f : fy;
+    const int y0 = min((int)fy, h - 1), y1 = y0 + (y0 < h - 1 ? 1 : 0);
+    const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = 64 * cc + 32 * (S >> 1) + 16 * (S & 1) + 8 * (e >> 2) + 4 * g + (e & 3);
+      const unsigned pl = n * (unsigned)C + (unsigned)c;
+      const float *t0 = top + ((size_t)pl * h + y0) * (size_t)w, *t1 = top + ((size_t)pl * h + y1) * (size_t)w;
+      float lat = lateral[((size_t)pl * H + y) * (size_t)W + pxc];
+      if (lat_scale) lat = lat * lat_scale[pl] + lat_shift[pl];
+      v[e] = lat + (ly0 * (lx0 * t0[x0] + lx1 * t0[x1]) + ly1 * (lx0 * t1[x0] + lx1 * t1[x1]));
+    }
+    const f4 p0 = {v[0], v[1], v[2], v[3]}, p1 = {v[4], v[5], v[6], v[7]};
+    h8 hi, lo;
+    split8(p0, p1, oscale, hi, lo);
+    const unsigned G = row * (unsigned)XG + (unsigned)xg;
+    const unsigned off = (G * (unsigned)NCC + (unsigned)cc) * 8192u + (unsigned)(S * 2048 + g * 512 + x * 16);
+    store_fragments2(ri, off, hi, 0, lo, 1024);
+  }
+}
+
 }  // namespace
+
+/* image (C channels, dvis_conv_x3_image_bytes(N, C, H, W)) = split(lateral * scale + shift + bilinear(top)): dvis_upsample_add[_affine]
+ * with the result as an operand image for an image-input convolution; lat_scale / lat_shift per plane or NULL */
+DVIS_EXPORT int dvis_upsample_add_image(const float *lateral, const float *lat_scale, const float *lat_shift, const float *top, void *image,
+                                        int N, int C, int H, int W, int h, int w, int oexp, void *stream) {
+  DVIS_REQUIRE(lateral && top && image, "dvis_upsample_add_image: null pointer");
+  DVIS_REQUIRE((lat_scale == nullptr) == (lat_shift == nullptr), "dvis_upsample_add_image: scale and shift together");
+  DVIS_REQUIRE(N > 0 && C > 0 && C % 64 == 0 && H > 0 && W > 0 && h > 0 && w > 0, "dvis_upsample_add_image: bad sizes");
+  DVIS_REQUIRE((uintptr_t)image % 16 == 0 && dvis_conv_x3_image_bytes(N, C, H, W) < ((int64_t)1 << 31), "dvis_upsample_add_image: a 16-byte "
+               "aligned image below 2 GiB");
+  const int per = 16 * 65535 / H;    // images per launch: the grid's z extent is the image rows / 16
+  DVIS_REQUIRE(per >= 1 && (W + 31) / 32 <= 65535, "dvis_upsample_add_image: map too large (%d x %d)", H, W);
+  for (int i = 0; i < N; i += per) {
+    const int n = N - i < per ? N - i : per;
+    hipLaunchKernelGGL(upsample_add_image_kernel, dim3(C / 64, (W + 31) / 32, (n * H + 15) / 16), dim3(256), 0, (hipStream_t)stream,
+                       lateral + (size_t)i * C * H * W, top + (size_t)i * C * h * w,
+                       (char *)image + (size_t)i * H * ((W + 31) / 32) * (C / 64) * 8192, n, C, H, W, h, w,
+                       lat_scale ? lat_scale + (size_t)i * C : nullptr, lat_shift ? lat_shift + (size_t)i * C : nullptr, ldexpf(1.f, oexp));
+  }
+  return dvis_check_launch("dvis_upsample_add_image");
+}
 
 DVIS_EXPORT int dvis_conv1x1_x3_supported(int C, int K, int64_t N, int64_t HW_in, int64_t HW_out) {
   if (C < 64 || C % 64 != 0 || C > 4096) return 0;
@@ -294,7 +409,7 @@ DVIS_EXPORT int dvis_conv1x1_x3_pack(const float *w, int K, int C, int wexp, voi
 
 static int cx_launch(const float *x, const void *packed, const float *bias, const float *res, float *y, int N, int C, int K, int H, int W,
                      int stride, int taps, int xexp, int wexp, int relu, void *stream, const float *x2 = nullptr, int C2 = 0, int H2 = 0,
-                     int W2 = 0, int stride2 = 1, void *image = nullptr, int oexp = 0);
+                     int W2 = 0, int stride2 = 1, void *image = nullptr, int oexp = 0, const void *ximg = nullptr);
 
 DVIS_EXPORT int dvis_conv1x1_x3_dual(const float *x, const float *x2, const void *packed, const float *bias, const float *res, float *y,
                                      int N, int C, int C2, int K, int H, int W, int H2, int W2, int stride2, int xexp, int wexp, int relu,
@@ -318,6 +433,47 @@ DVIS_EXPORT int dvis_conv1x1_x3_image(const float *x, const void *packed, const 
   DVIS_REQUIRE(image != nullptr && (uintptr_t)image % 16 == 0, "dvis_conv1x1_x3_image: null / unaligned image");
   DVIS_REQUIRE((long long)N * H * ((W + 31) / 32) * 8192 < ((long long)1 << 31), "dvis_conv1x1_x3_image: the image must stay below 2 GiB");
   return cx_launch(x, packed, bias, nullptr, nullptr, N, C, 64, H, W, 1, 1, xexp, wexp, relu, stream, nullptr, 0, 0, 0, 1, image, oexp);
+}
+
+/* Operand images with C channels: per 32-pixel group (n, y, x / 32) C / 64 chunks of 8 KB (dvis_conv_x3_image_bytes). */
+DVIS_EXPORT int64_t dvis_conv_x3_image_bytes(int64_t N, int C, int H, int W) {
+  if (N < 0 || C <= 0 || C % 64 != 0 || H <= 0 || W <= 0) return -1;
+  return N * H * ((W + 31) / 32) * (int64_t)(C / 64) * 8192;
+}
+
+/* weights (K, C, taps: 1 or 9) for an image-input launch: the channels of every 64-chunk in ACCUMULATOR order (the order in which the
+ * producer's lanes hold them), otherwise the layout of dvis_conv1x1_x3_pack / dvis_conv3x3_x3_pack (same packed size) */
+DVIS_EXPORT int dvis_conv_x3_pack_image(const float *w, int K, int C, int taps, int wexp, void *packed, void *stream) {
+  DVIS_REQUIRE(w && packed, "dvis_conv_x3_pack_image: null operand");
+  DVIS_REQUIRE(taps == 1 || taps == 9, "dvis_conv_x3_pack_image: taps = %d", taps);
+  DVIS_REQUIRE(dvis_conv1x1_x3_supported(C, K, 1, 1, 1) && K >= 128, "dvis_conv_x3_pack_image: (C, K) = (%d, %d) is not served", C, K);
+  DVIS_REQUIRE(wexp >= -60 && wexp <= 60, "dvis_conv_x3_pack_image: wexp = %d", wexp);
+  const int NB = K == 128 ? 4 : 8;
+  const int64_t fragments = (int64_t)(taps * C / 16) * (K / 32) * 64;
+  hipLaunchKernelGGL(x3_pack_kernel, dim3((unsigned)((fragments + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (int64_t)taps * C, K,
+                     taps * C, NB, 1, ldexpf(1.f, wexp), (_Float16 *)packed, fragments, taps);
+  return dvis_check_launch("dvis_conv_x3_pack_image");
+}
+
+/* relu?(conv(x) + bias + res) with the INPUT and / or the OUTPUT as operand images (csrc/conv1x1_x3.hip, IMGIN / IMGOUT):
+ *   ximg != NULL: input image of C channels on the H x W map (x ignored), weights from dvis_conv_x3_pack_image; else x (N, C, H, W) and
+ *                 weights from dvis_conv1x1_x3_pack / dvis_conv3x3_x3_pack;
+ *   image != NULL: output image of K channels (y, res ignored), the values split with 2^oexp; else y (N, K, OH, OW).
+ * xexp: the exponent the INPUT was / is split with.  K = 128 or K %% 256 == 0; taps 1 (1x1) or 9 (3x3, padding 1); stride 1 or 2. */
+DVIS_EXPORT int dvis_conv_x3_image(const void *ximg, const float *x, const void *packed, const float *bias, const float *res, float *y,
+                                   void *image, int N, int C, int K, int H, int W, int stride, int taps, int xexp, int wexp, int oexp, int relu,
+                                   void *stream) {
+  DVIS_REQUIRE(ximg != nullptr || image != nullptr, "dvis_conv_x3_image: neither side is an operand image (use dvis_conv1x1_x3 / dvis_conv3x3_x3)");
+  DVIS_REQUIRE((ximg != nullptr) != (x != nullptr), "dvis_conv_x3_image: exactly one of ximg and x");
+  DVIS_REQUIRE((image != nullptr) != (y != nullptr), "dvis_conv_x3_image: exactly one of image and y");
+  DVIS_REQUIRE(K == 128 || K % 256 == 0, "dvis_conv_x3_image: K = %d (128 or a multiple of 256)", K);
+  DVIS_REQUIRE(taps == 1 || taps == 9, "dvis_conv_x3_image: taps = %d", taps);
+  DVIS_REQUIRE(image == nullptr || res == nullptr, "dvis_conv_x3_image: an image output takes no residual");
+  DVIS_REQUIRE(((uintptr_t)ximg | (uintptr_t)image) % 16 == 0, "dvis_conv_x3_image: images must be 16-byte aligned");
+  const int OH = (H + stride - 1) / stride, OW = (W + stride - 1) / stride;
+  DVIS_REQUIRE(dvis_conv_x3_image_bytes(N, C, H, W) < ((int64_t)1 << 31) && dvis_conv_x3_image_bytes(N, K, OH, OW) < ((int64_t)1 << 31),
+               "dvis_conv_x3_image: images must stay below 2 GiB");
+  return cx_launch(x, packed, bias, res, y, N, C, K, H, W, stride, taps, xexp, wexp, relu, stream, nullptr, 0, 0, 0, 1, image, oexp, ximg);
 }
 
 DVIS_EXPORT int64_t dvis_conv3x3_x3_packed_bytes(int C, int K) {
@@ -344,8 +500,8 @@ DVIS_EXPORT int dvis_conv3x3_x3(const float *x, const void *packed, const float 
 
 static int cx_launch(const float *x, const void *packed, const float *bias, const float *res, float *y, int N, int C, int K, int H, int W,
                      int stride, int taps, int xexp, int wexp, int relu, void *stream, const float *x2, int C2, int H2, int W2, int stride2,
-                     void *image, int oexp) {
-  DVIS_REQUIRE(x && packed && (y || image), "dvis_conv1x1_x3: null operand");
+                     void *image, int oexp, const void *ximg) {
+  DVIS_REQUIRE((x || ximg) && packed && (y || image), "dvis_conv1x1_x3: null operand");
   DVIS_REQUIRE(stride == 1 || stride == 2, "dvis_conv1x1_x3: stride %d", stride);
   const int OH = (H + stride - 1) / stride, OW = (W + stride - 1) / stride;
   DVIS_REQUIRE(dvis_conv1x1_x3_supported(C, K, N, (int64_t)H * W, (int64_t)OH * OW), "dvis_conv1x1_x3: shape (N %d, C %d, K %d, %d x %d, "
@@ -360,7 +516,8 @@ static int cx_launch(const float *x, const void *packed, const float *bias, cons
   const X3Guard gd = dvis_x3_guard();
   a.flag = gd.flag, a.tag = gd.tag;
   a.x2 = x2, a.C2 = x2 ? C2 : 0, a.stride2 = stride2, a.W2_in = W2, a.HW2_in = (long long)H2 * W2;
-  a.img = image, a.XG = (OW + 31) / 32, a.oscale = ldexpf(1.f, oexp);
+  a.img = image, a.XG = (OW + 31) / 32, a.oscale = ldexpf(1.f, oexp), a.OH = OH;
+  a.ximg = ximg, a.XG_in = (W + 31) / 32;
   const int grid = dvis_x3_persistent_cus();
   hipStream_t st = (hipStream_t)stream;
   static const int nw = getenv("DVIS_X3_CONV_WAVES") ? atoi(getenv("DVIS_X3_CONV_WAVES")) : 8;
@@ -375,6 +532,29 @@ static int cx_launch(const float *x, const void *packed, const float *bias, cons
     if (rc != DVIS_OK) return rc;                                                                                  \
     hipLaunchKernelGGL((conv1x1_x3_kernel<NBV, NWV, IKV>), dim3(grid), dim3(NWV * 64), lds, st, a);                \
   }
+#define DVIS_CX_LAUNCH_IMG(NBV, IKV, INV, OUTV)                                                                                    \
+  {                                                                                                                                \
+    static DvisLdsOptIn opted;                                                                                                     \
+    typedef Ring<2 * IKV * NBV / 8, 8, 8, (IKV == 4 ? 2 : 3)> R;                                                                   \
+    a.tiles = (a.pixels + 255) / 256;                                                                                              \
+    const size_t lds = (IKV == 4 ? 2 : 3) * R::kItemBytes;                                                                         \
+    const int rc = dvis_lds_opt_in((const void *)conv1x1_x3_kernel<NBV, 8, IKV, INV, OUTV>, lds, &opted, "dvis_conv_x3_image");    \
+    if (rc != DVIS_OK) return rc;                                                                                                  \
+    hipLaunchKernelGGL((conv1x1_x3_kernel<NBV, 8, IKV, INV, OUTV>), dim3(grid), dim3(512), lds, st, a);                            \
+    return dvis_check_launch("dvis_conv_x3_image");                                                                                \
+  }
+  if (ximg != nullptr || (image != nullptr && K != 64)) {      // operand images on either side (K = 64 out: the runtime branch of the plain kernels)
+    DVIS_REQUIRE(x2 == nullptr, "dvis_conv_x3_image: no second source");
+    if (K == 128) {
+      if (ximg && image) DVIS_CX_LAUNCH_IMG(4, 2, true, true)
+      if (ximg) DVIS_CX_LAUNCH_IMG(4, 2, true, false)
+      DVIS_CX_LAUNCH_IMG(4, 2, false, true)
+    }
+    if (ximg && image) DVIS_CX_LAUNCH_IMG(8, 4, true, true)
+    if (ximg) DVIS_CX_LAUNCH_IMG(8, 4, true, false)
+    DVIS_CX_LAUNCH_IMG(8, 4, false, true)
+  }
+#undef DVIS_CX_LAUNCH_IMG
   static const int ik = getenv("DVIS_X3_CONV_ITEM") ? atoi(getenv("DVIS_X3_CONV_ITEM")) : 4;   // (2: three stages of 32 KB, 2 - 5 % slower)
   if (K == 64) {
     if (nw == 8) DVIS_CX_LAUNCH(2, 8, 2) else DVIS_CX_LAUNCH(2, 4, 2)

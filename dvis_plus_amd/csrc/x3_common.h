@@ -78,6 +78,14 @@ __device__ __forceinline__ void store_fragments4(__amdgpu_buffer_rsrc_t r, unsig
   __builtin_amdgcn_sched_barrier(0);
 }
 
+__device__ __forceinline__ void store_fragments2(__amdgpu_buffer_rsrc_t r, unsigned voff, h8 a, unsigned sa, h8 b, unsigned sb) {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dvis_v4u, a), r, voff, sa, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dvis_v4u, b), r, voff, sb, 0);
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // One item of the weight stream: STEPS k-steps x NBL blocks of 32 output features, image [s][nb][hi, lo][lane][8 halves].
 //   * The fragment pair of block t + 1 is requested before block t's three products are issued (hipcc on its own reads each
 //     fragment into one register quad and waits for it right away: an LDS round trip per product pair with the matrix pipe idle

@@ -1619,6 +1619,110 @@ def conv3x3_x3(x, weight, bias=None, res=None, relu=False, stride=1, xexp=None):
     return out
 
 
+X3_IMAGES = os.environ.get("DVIS_X3_IMAGES", "1") != "0"
+
+
+class OperandImage:
+    """A C-channel map as csrc/conv1x1_x3.hip's operand image (include/dvis_hip.h: dvis_conv_x3_image): per 32-pixel group C / 64
+    chunks of 8 KB of pre-split f16 terms.  `exp`: the power of two the values were scaled with before the split."""
+
+    def __init__(self, data, N, C, H, W, exp):
+        self.data, self.N, self.C, self.H, self.W, self.exp = data, N, C, H, W, exp
+
+    @property
+    def device(self):
+        return self.data.device
+
+    def images(self, i, n):
+        per = self.data.numel() // self.N
+        return self.data[i * per:(i + n) * per]
+
+
+def x3_images_ok(N, C, K, H, W, device, taps=1, stride=1):
+    """Operand images between two launches of csrc/conv1x1_x3.hip: split-f16 kernels on, a GPU, channel counts the image forms serve."""
+    if not (X3_IMAGES and x3_on() and device.type == "cuda" and not torch.is_grad_enabled()):
+        return False
+    if C % 64 != 0 or not (K == 128 or K % 256 == 0) or N <= 0:
+        return False
+    OH, OW = (H + stride - 1) // stride, (W + stride - 1) // stride
+    return bool(native.lib().dvis_conv1x1_x3_supported(C, K, 1, H * W, OH * OW))
+
+
+def _image_chunks(N, C, K, H, W, OH, OW):
+    per = max(C * H * W, K * OH * OW) * 4
+    return max(1, min(N, (2 ** 31 - 1) // per))
+
+
+def upsample_add_image(lateral, top, lat_affine=None, oexp=None):
+    """`upsample_add` with the sum written as an operand image (the 3x3 output convolution behind it reads fragments)."""
+    N, C, H, W = lateral.shape
+    lib = native.lib()
+    oe = X3_CONV_XEXP if oexp is None else oexp
+    top = top.contiguous()
+    data = torch.empty(lib.dvis_conv_x3_image_bytes(N, C, H, W), dtype=torch.uint8, device=lateral.device)
+    img = OperandImage(data, N, C, H, W, oe)
+    step = _image_chunks(N, C, C, H, W, H, W)
+    with torch.cuda.device(lateral.device):
+        for i in range(0, N, step):
+            n = min(step, N - i)
+            sc = None if lat_affine is None else native.dev_ptr(lat_affine[0].reshape(N, C)[i:i + n], "scale")
+            sh = None if lat_affine is None else native.dev_ptr(lat_affine[1].reshape(N, C)[i:i + n], "shift")
+            native.check(lib.dvis_upsample_add_image(native.dev_ptr(lateral[i:i + n], "lateral"), sc, sh, native.dev_ptr(top[i:i + n], "top"),
+                                                     ctypes.c_void_p(img.images(i, n).data_ptr()), n, C, H, W, top.shape[-2], top.shape[-1], oe,
+                                                     native.stream_ptr(lateral.device)), "dvis_upsample_add_image")
+    return img
+
+
+def conv_x3_image(src, weight, bias=None, res=None, relu=False, stride=1, out_image=False, oexp=None, xexp=None):
+    """relu?(conv2d(src, weight, stride, padding = k // 2) + bias + res) through dvis_conv_x3_image: `src` an OperandImage or an
+    (N, C, H, W) fp32 map (then out_image must be set), weight (K, C, 1, 1) or (K, C, 3, 3); returns an OperandImage (out_image) or
+    the (N, K, OH, OW) fp32 map."""
+    lib = native.lib()
+    from_img = isinstance(src, OperandImage)
+    if not (from_img or out_image):
+        raise ValueError("conv_x3_image: neither side is an operand image")
+    N, C, H, W = (src.N, src.C, src.H, src.W) if from_img else src.shape
+    K, taps = weight.shape[0], weight.shape[2] * weight.shape[3]
+    dev = weight.device
+
+    def make():
+        w2 = weight.detach().contiguous()
+        e = _x3_exp(w2)
+        nbytes = lib.dvis_conv1x1_x3_packed_bytes(C, K) * taps
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            if from_img:
+                native.check(lib.dvis_conv_x3_pack_image(native.dev_ptr(w2, "weight"), K, C, taps, e, ctypes.c_void_p(buf.data_ptr()),
+                                                         native.stream_ptr(dev)), "dvis_conv_x3_pack_image")
+            elif taps == 1:
+                native.check(lib.dvis_conv1x1_x3_pack(native.dev_ptr(w2.reshape(K, C), "weight"), K, C, e, ctypes.c_void_p(buf.data_ptr()),
+                                                      native.stream_ptr(dev)), "dvis_conv1x1_x3_pack")
+            else:
+                native.check(lib.dvis_conv3x3_x3_pack(native.dev_ptr(w2, "weight"), K, C, e, ctypes.c_void_p(buf.data_ptr()),
+                                                      native.stream_ptr(dev)), "dvis_conv3x3_x3_pack")
+        return buf, e
+    kind = ("conv%dx%d" % ((1, 1) if taps == 1 else (3, 3))) + (" image-in" if from_img else "")
+    buf, wexp = _x3_cache(weight, (weight._version, weight.data_ptr(), weight.device), make, kind=kind)
+    OH, OW = (H + stride - 1) // stride, (W + stride - 1) // stride
+    xe = src.exp if from_img else (X3_CONV_XEXP if xexp is None else xexp)
+    oe = X3_CONV_XEXP if oexp is None else oexp
+    if out_image:
+        out = OperandImage(torch.empty(lib.dvis_conv_x3_image_bytes(N, K, OH, OW), dtype=torch.uint8, device=dev), N, K, OH, OW, oe)
+    else:
+        out = torch.empty((N, K, OH, OW), dtype=torch.float32, device=dev)
+    step = _image_chunks(N, C, K, H, W, OH, OW)
+    with torch.cuda.device(dev):
+        for i in range(0, N, step):
+            n = min(step, N - i)
+            native.check(lib.dvis_conv_x3_image(
+                ctypes.c_void_p(src.images(i, n).data_ptr()) if from_img else None, None if from_img else native.dev_ptr(src[i:i + n], "x"),
+                ctypes.c_void_p(buf.data_ptr()), None if bias is None else native.dev_ptr(bias.detach(), "bias"),
+                None if res is None else native.dev_ptr(res[i:i + n], "res"), None if out_image else native.dev_ptr(out[i:i + n], "out"),
+                ctypes.c_void_p(out.images(i, n).data_ptr()) if out_image else None, n, C, K, H, W, stride, taps, xe, wexp, oe, 1 if relu else 0,
+                native.stream_ptr(dev)), "dvis_conv_x3_image")
+    return out
+
+
 X3_BNECK = os.environ.get("DVIS_X3_BNECK", "1") != "0"
 
 

@@ -118,6 +118,10 @@ SIGNATURES = {
     "dvis_bneck_x3_pack": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "dvis_bneck_x3": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dvis_conv1x1_x3_image": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "dvis_conv_x3_image_bytes": (_i64, [_i64, _i, _i, _i]),
+    "dvis_conv_x3_pack_image": (_i, [_p, _i, _i, _i, _i, _p, _p]),
+    "dvis_conv_x3_image": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "dvis_upsample_add_image": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dvis_gemm_num_configs": (_i, []),
     "dvis_gemm_pick_config": (_i, [_i, _i, _i, _i]),
     "dvis_gemm_pick_config_nw": (_i, [_i, _i, _i, _i, _i]),

@@ -437,8 +437,17 @@ class ConvNorm(nn.Conv2d):
             return self.norm(y), None
         return self.forward(x), None
 
+    def image_input_ok(self, N, C, H, W, device):
+        """May the input arrive as an operand image (Fn.upsample_add_image -> Fn.conv_x3_image)?  The plain 3x3 / 1x1 forms only."""
+        return self.stride == (1, 1) and self.dilation == (1, 1) and self.groups == 1 and self.weight.dtype == torch.float32 \
+            and ((self.kernel_size == (3, 3) and self.padding == (1, 1)) or (self.kernel_size == (1, 1) and self.padding == (0, 0))) \
+            and C == self.in_channels and Fn.x3_images_ok(N, C, self.out_channels, H, W, device, taps=self.kernel_size[0] ** 2)
+
     def forward(self, x):
-        x = self.conv(x)
+        if isinstance(x, Fn.OperandImage):
+            x = Fn.conv_x3_image(x, self.weight, self.bias)
+        else:
+            x = self.conv(x)
         if isinstance(self.norm, nn.GroupNorm) and self.activation in (None, F.relu):
             # statistics in one read, normalisation (+ReLU) in one in-place pass (torch: moments, apply, clamp)
             aff = Fn.group_norm_affine(x, self.norm)
@@ -555,7 +564,13 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 for idx, f in enumerate(self.in_features[:self.num_fpn_levels][::-1]):
                     x = features[f].float().contiguous()      # NCHW for the fused FPN path (no-op for the R50's maps)
                     cur_fpn, affine = self.lateral_convs[idx].conv_and_affine(x)    # GroupNorm applied inside upsample_add
-                    out.append(self.output_convs[idx](Fn.upsample_add(cur_fpn, out[-1], affine)))
+                    oc = self.output_convs[idx]
+                    if cur_fpn.is_cuda and cur_fpn.dtype == torch.float32 and cur_fpn.is_contiguous() and out[-1].dtype == torch.float32 \
+                            and oc.image_input_ok(*cur_fpn.shape, cur_fpn.device):
+                        # the top-down sum as an operand image: the 3x3 output convolution reads pre-split fragments (csrc/conv1x1_x3.hip)
+                        out.append(oc(Fn.upsample_add_image(cur_fpn, out[-1], affine)))
+                    else:
+                        out.append(oc(Fn.upsample_add(cur_fpn, out[-1], affine)))
                 multi_scale_features = TokenMaps(out[:self.maskformer_num_feature_levels])
                 multi_scale_features.tokens = tokens[:self.maskformer_num_feature_levels]
                 return self.mask_features(out[-1]), out[0], multi_scale_features

@@ -650,6 +650,21 @@ int dvis_bneck_x3(const void *a1, const float *res, const float *x2, const void 
                   const float *b1, float *y, void *out, int N, int H, int W, int xexp, int e2, int e3, int e1, void *stream);
 int dvis_conv1x1_x3_image(const float *x, const void *packed, const float *bias, void *image, int N, int C, int H, int W, int xexp,
                           int wexp, int oexp, int relu, void *stream);
+/*
+ * Operand images on either side of csrc/conv1x1_x3.hip (the maps INSIDE the res3 - res5 bottlenecks and the FPN output convolution's
+ * input): C channels = C / 64 chunks of 8 KB per 32-pixel group (n, y, x / 32), each [k-step][hi, lo f16 term][32 g + x % 32][8 halves]
+ * in accumulator channel order.  The producer's epilogue splits once; a 3x3 consumer's nine taps re-read the image: 8 loads of 16 bytes
+ * per 64-channel chunk and lane instead of 32 of 4 bytes, no split arithmetic in the loop.
+ *   dvis_conv_x3_pack_image  weights (K, C, taps 1 | 9) for an image-INPUT launch (channels of a chunk in accumulator order)
+ *   dvis_conv_x3_image       relu?(conv + bias + res): ximg | x in, image | y out (at least one image); K = 128 or K % 256 == 0
+ *   dvis_upsample_add_image  dvis_upsample_add[_affine] with the sum written as an operand image (the FPN's top-down path)
+ */
+int64_t dvis_conv_x3_image_bytes(int64_t N, int C, int H, int W);
+int dvis_conv_x3_pack_image(const float *w, int K, int C, int taps, int wexp, void *packed, void *stream);
+int dvis_conv_x3_image(const void *ximg, const float *x, const void *packed, const float *bias, const float *res, float *y, void *image,
+                       int N, int C, int K, int H, int W, int stride, int taps, int xexp, int wexp, int oexp, int relu, void *stream);
+int dvis_upsample_add_image(const float *lateral, const float *lat_scale, const float *lat_shift, const float *top, void *image, int N,
+                            int C, int H, int W, int h, int w, int oexp, void *stream);
 int dvis_x3_ffn_pack(const float *W1, int64_t ldw1, const float *W2, int64_t ldw2, int K, int H, int N, int w1exp, int w2exp,
                      void *packed, void *stream);
 int dvis_x3_ffn_ln(const float *x, int64_t ldx, int64_t M, int K, int H, int N, const void *packed, int xexp, int w1exp,

@@ -100,7 +100,7 @@ def test_resnet50_production_size_strict_own_kernels_vs_unfused_fp64():
     lib = native.lib()
     names = ("dvis_conv3x3_winograd", "dvis_conv1x1_mfma", "dvis_conv1x1s2_mfma", "dvis_conv3x3s2", "dvis_conv7x7s2",
              "dvis_conv1x1_bias_act", "dvis_bias_relu_maxpool", "dvis_conv1x1_x3", "dvis_conv3x3_x3", "dvis_conv1x1_x3_dual",
-             "dvis_bneck_x3", "dvis_conv1x1_x3_image")
+             "dvis_bneck_x3", "dvis_conv1x1_x3_image", "dvis_conv_x3_image")
     calls = {n: 0 for n in names}
     orig = {n: getattr(lib, n) for n in names}
     lib_convs = []
@@ -128,24 +128,29 @@ def test_resnet50_production_size_strict_own_kernels_vs_unfused_fp64():
     from dvis_plus_amd import functions as Fn
     assert calls["dvis_conv7x7s2"] == 1
     chain = Fn.X3 and Fn.X3_BNECK     # round 6: res2 = one launch per bottleneck (csrc/bneck_x3.hip) behind the first conv1
-    if Fn.X3:     # from 128 channels on (and every stride-2 layer) the nine-tap split-f16 kernel; the three 64-channel ones inside
-        # the chain, or (DVIS_X3_BNECK=0) Winograd
-        assert calls["dvis_conv3x3_winograd"] == (0 if chain else 3) and calls["dvis_conv3x3s2"] == 0 and calls["dvis_conv3x3_x3"] == 13, calls
+    images = Fn.X3 and Fn.X3_IMAGES   # round 6: the maps inside the res3 - res5 bottlenecks as operand images (dvis_conv_x3_image)
+    # 52 convolution layers behind the stem: 16 x (conv1, conv2, conv3) + 4 projection shortcuts
+    n3x3_res2, n3x3_rest = 3, 13
+    if Fn.X3:
+        assert calls["dvis_conv3x3s2"] == 0, calls
+        assert calls["dvis_conv3x3_winograd"] == (0 if chain else n3x3_res2), calls
+        assert calls["dvis_conv3x3_x3"] == (0 if images else n3x3_rest), calls
     else:
         assert calls["dvis_conv3x3_winograd"] == 13 and calls["dvis_conv3x3s2"] == 3 and calls["dvis_conv3x3_x3"] == 0, calls
     assert calls["dvis_bneck_x3"] == (3 if chain else 0) and calls["dvis_conv1x1_x3_image"] == (1 if chain else 0), calls
+    # 10 identity blocks x 3 launches + 3 projection blocks x 2 (conv1 -> image, conv2 from the image; conv3 + shortcut stay one fp32-map launch)
+    assert calls["dvis_conv_x3_image"] == (36 if images else 0), calls
     assert calls["dvis_bias_relu_maxpool"] == 1
-    # the 1x1 layers: 16 x (conv1, conv3) + 4 shortcuts = 36: with the split-f16 kernels on, every one of them (>= 64 input
-    # channels) runs on csrc/conv1x1_x3.hip; DVIS_X3=0: the compute-bound ones and the stride-2 shortcuts on
-    # csrc/conv1x1_mfma.hip, the rest on the LDS-weights kernel csrc/conv1x1.hip
-    # (round 5: the blocks with a projection shortcut run conv3 + shortcut as ONE launch, dvis_conv1x1_x3_dual = 2 layers each;
-    # round 6: the 7 layers of res2 are inside the chain's 4 launches)
+    # (round 5: the blocks with a projection shortcut run conv3 + shortcut as ONE launch, dvis_conv1x1_x3_dual = 2 layers each)
     dual = calls["dvis_conv1x1_x3_dual"]
     assert dual == ((3 if chain else 4) if Fn.X3 and Fn.X3_DUAL else 0), calls
-    in_chain = 7 if chain else 0
-    mm = calls["dvis_conv1x1_x3"] + 2 * dual + in_chain if Fn.X3 else calls["dvis_conv1x1_mfma"] + calls["dvis_conv1x1s2_mfma"]
-    assert mm >= 20 and mm + calls["dvis_conv1x1_bias_act"] == 36, calls
-    assert calls["dvis_conv1x1_x3"] + 2 * dual + in_chain + calls["dvis_conv1x1_mfma"] + calls["dvis_conv1x1s2_mfma"] == mm, calls
+    if Fn.X3:
+        layers = (10 if chain else n3x3_res2 * (calls["dvis_conv3x3_winograd"] > 0)) + calls["dvis_conv_x3_image"] + 2 * dual \
+            + calls["dvis_conv1x1_x3"] + calls["dvis_conv3x3_x3"] + calls["dvis_conv1x1_bias_act"]
+        assert layers == 52, (layers, calls)
+    else:
+        mm = calls["dvis_conv1x1_mfma"] + calls["dvis_conv1x1s2_mfma"]
+        assert mm >= 20 and mm + calls["dvis_conv1x1_bias_act"] == 36, calls
     want = _resnet50_fp64(sd, x.double())
     for k, c, s in (("res2", 256, 4), ("res3", 512, 8), ("res4", 1024, 16), ("res5", 2048, 32)):
         assert got[k].shape == want[k].shape == (2, c, 736 // s, 1280 // s)
