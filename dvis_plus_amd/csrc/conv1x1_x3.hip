@@ -252,6 +252,7 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
         // K / 64 chunks per group; this pass holds chunks co0 / 64 .. : block nb = k-steps 2 (nb & 1), 2 (nb & 1) + 1 of chunk nb / 2
         const unsigned gs = (unsigned)(a.K / 64) * 8192u;
         const __amdgpu_buffer_rsrc_t ri = dvis_make_rsrc_uniform(a.img, (unsigned)((long long)a.N * a.OH * a.XG * gs));
+        const __amdgpu_buffer_rsrc_t rb = dvis_make_rsrc_uniform(a.bias ? (const void *)a.bias : (const void *)a.img, a.bias ? (unsigned)a.K * 4u : 0u);
         unsigned ibase = kOOB;
         if (p < a.pixels) {
           const int pix = (int)(p - n * a.HW), oy = pix / a.OW, ox = pix - oy * a.OW;
@@ -260,10 +261,11 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_x3_kernel(const CxArgs a) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           float v[16];
+          // (the shifts through a descriptor that is empty without a bias: no branch per load — with 32 conditional loads at NB = 8
+          // hipcc hoisted them all to the epilogue's head and spilled 60 - 100 registers around them)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            f4 b = {0.f, 0.f, 0.f, 0.f};
-            if (a.bias) b = *(const f4 *)(a.bias + co0 + 32 * nb + 8 * q + 4 * g);
+            const f4 b = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)(co0 + 32 * nb + 8 * q + 4 * g) * 4u, 0, 0));
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const float t = acc[nb][4 * q + i] * a.inv + b[i];
