@@ -392,7 +392,7 @@ def load_x3_traffic():
     """HBM bytes per launch of the split-f16 kernels from the committed rocprofv3 PMC passes (bench.py cannot read PMCs itself):
     profiles/rNN_x3_traffic.json, written by tools/x3_traffic_json.py from the raw counter summaries (separate --pmc passes for
     FETCH_SIZE and WRITE_SIZE, the guide's gfx950 corrections).  {kernel family: {"hbm_bytes_per_launch", "source", ...}}"""
-    for name in ("r06_x3_traffic.json", "r05_x3_traffic.json"):
+    for name in ("r06b_x3_traffic.json", "r06_x3_traffic.json", "r05_x3_traffic.json"):
         tj = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tj):
             try:
@@ -831,7 +831,7 @@ def main():
         sec, nfr, nlaunch = timer.summary()
         achieved = MSDA_BYTES_PER_FRAME_LAYER * nfr / sec / 1e9
         traffic, traffic_src = None, None     # HBM bytes per launch from the committed rocprofv3 PMC passes (bench.py cannot read PMCs itself)
-        for name in ("r06_msda_traffic.json", "r05_msda_traffic.json", "r03_msda_traffic.json", "r02_msda_traffic.json", "r01_msda_traffic.json"):
+        for name in ("r06b_msda_traffic.json", "r06_msda_traffic.json", "r05_msda_traffic.json", "r03_msda_traffic.json", "r02_msda_traffic.json", "r01_msda_traffic.json"):
             tj = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tj):
                 t = json.load(open(tj))

@@ -11,7 +11,7 @@ import sys
 src, dst = sys.argv[1], sys.argv[2]
 FAMILIES = {"conv1x1_x3_kernel": r"conv1x1_x3_kernel<", "x3_ffn_kernel": r"x3_ffn_kernel", "x3_linear": r"x3_linear(_stream)?_kernel<",
             "x3_tile_kernel": r"x3_tile_kernel<", "msda_fwd": r"msda_fwd_tile", "mask_gemm_kernel": r"mask_gemm_kernel<",
-            "attn_keysplit_kernel": r"attn_keysplit_kernel"}
+            "attn_keysplit_kernel": r"attn_keysplit_kernel", "bneck_chain_kernel": r"bneck_chain_kernel<"}
 blocks, cur = [], None
 for line in open(src).read().split("\n"):
     m = re.match(r"(\S.*?)\s+dispatches=(\d+)", line)
