@@ -98,15 +98,19 @@ __global__ __launch_bounds__(256, 2) void x3_tile_kernel(TileArgs a) {
     const int64_t m = m0 + (tid >> 1);
     arow = a.x + (m < a.M ? m : a.M - 1) * a.ldx + 8 * aq;
   }
-  const char *bsrc = a.wp + (size_t)nt * KT * 16384 + lane * 16;
+  // (the B pieces as MUBUF LDS-DMA statements, x3_common.h: dma16 — hipcc's own waits for the row loads stay counted)
+  const x3_u4 rsb = x3_stream_rsrc(a.wp);
+  const unsigned bsrc = (unsigned)nt * (unsigned)KT * 16384u, lane16 = lane * 16;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned lds_b = lds_address(lds);
   f4 ra[2][2];
   auto fetch_a = [&](int kt, int set) { ra[set][0] = *(const f4 *)(arow + kt * k2TK), ra[set][1] = *(const f4 *)(arow + kt * k2TK + 4); };
   auto dma_b = [&](int kt) {
-    char *s = lds + (kt & 1) * k2Stage + 2 * k2PartA;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int p = wave + 4 * i;                   // piece: part = p >> 3, chunk = (p >> 2) & 1, quarter = p & 3
-      glds16(bsrc + (size_t)kt * 16384 + p * 1024, s + (p >> 3) * k2PartB + ((p >> 2) & 1) * k2ChunkB + (p & 3) * 1024);
+      const int p = wave_u + 4 * i;                 // piece: part = p >> 3, chunk = (p >> 2) & 1, quarter = p & 3
+      dma16(rsb, lane16, bsrc + (unsigned)kt * 16384u + (unsigned)p * 1024u,
+            lds_b + (unsigned)((kt & 1) * k2Stage + 2 * k2PartA + (p >> 3) * k2PartB + ((p >> 2) & 1) * k2ChunkB + (p & 3) * 1024));
     }
   };
   auto stash_a = [&](int st, int set) {
