@@ -1649,7 +1649,8 @@ def x3_images_ok(N, C, K, H, W, device, taps=1, stride=1):
 
 
 def _image_chunks(N, C, K, H, W, OH, OW):
-    per = max(C * H * W, K * OH * OW) * 4
+    """Images per launch: every tensor of the launch below 2 GiB — fp32 maps, and operand images (rows padded to 32 pixels)."""
+    per = max(C * H * ((W + 31) // 32 * 32), K * OH * ((OW + 31) // 32 * 32)) * 4
     return max(1, min(N, (2 ** 31 - 1) // per))
 
 
