@@ -826,9 +826,13 @@ __global__ __launch_bounds__(256) void attn_x3_pack_kernel(const float *__restri
 
 // Pass 2.  QT query tiles of 16 per wave (a workgroup covers 128 QT queries): every K / V fragment read from LDS serves QT matrix
 // instructions, and a staged K / V tile QT times the queries.
-template <int QT>
+// IMG: the output as the ROW IMAGE of the GEMM that consumes it (csrc/gemm_x3_tile.hip: [row tile of 128][k-tile of 16][hi, lo][chunk]
+// [128 rows][8 halves], rows = (batch entry, token), k = (head, dim)) x img_scale: a lane holds four dims of a query, two neighbouring
+// lanes one 16-byte fragment (k order 2 of x3_tile_k) — no fp32 attention output, no split in the projection.
+template <int QT, bool IMG = false>
 __global__ __launch_bounds__(512) void attn_x3_kernel(const _Float16 *__restrict__ ws, float *__restrict__ out, dvis_strides os, int BH,
-                                                      int heads, int Lq, int Lk, int *__restrict__ guard_flag, int guard_tag) {
+                                                      int heads, int Lq, int Lk, int *__restrict__ guard_flag, int guard_tag,
+                                                      char *__restrict__ img = nullptr, float img_scale = 1.f) {
   constexpr int KT = kX3KT, NT = KT / 16, RS = kX3Row, RV = kX3RowV;
   __shared__ __attribute__((aligned(16))) _Float16 k_lds[KT * RS], v_lds[KT * RV];      // [key][hi 64 | lo 64 | pad]; V is read transposed
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -974,6 +978,46 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const _Float16 *__restrict
   }
   if (!wave_on) return;
   float chk = 0.f;
+  if constexpr (IMG) {
+    const int KT = heads * 4, jp = j >> 1;
+    char *base = img + (size_t)(4 * hi_ + (jp >> 1)) * 8192 + (jp & 1) * 2048 + (j & 1) * 8;
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      float l_tot = l_part[t] + __shfl_xor(l_part[t], 16);
+      l_tot += __shfl_xor(l_tot, 32);
+      ah4 vh[4], vl[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float lr = __shfl(l_tot, 4 * g + r);
+        const float inv = lr > 0.f ? (1.f / kOp) / lr : 0.f;
+        float v[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          v[n] = o[t][n][r] * inv;
+          chk = __builtin_fmaf(v[n], 0.f, chk);
+          v[n] *= img_scale;
+        }
+        x3_split4(v[0], v[1], v[2], v[3], vh[r], vl[r]);
+      }
+      // (nothing may be scheduled into the stores and a pause follows them: a vector store reads its data registers after it has
+      // issued — x3_common.h, store_fragments4)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qq = q0 + 16 * t + 4 * g + r;
+        if (qq < Lq) {
+          const size_t m = (size_t)bi * Lq + qq;
+          char *dst = base + (m >> 7) * KT * 8192 + (m & 127) * 16;
+          *reinterpret_cast<ah4 *>(dst) = vh[r];
+          *reinterpret_cast<ah4 *>(dst + 4096) = vl[r];
+        }
+      }
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (guard_flag != nullptr && chk != chk) atomicCAS(guard_flag, 0, guard_tag);
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     float l_tot = l_part[t] + __shfl_xor(l_part[t], 16);
@@ -1155,6 +1199,32 @@ DVIS_EXPORT int dvis_attention_x3_packed(const void *ws, float *out, const int64
   hipLaunchKernelGGL(attn_x3_kernel<1>, dim3(((BH + 7) / 8) * 8 * ((L + 127) / 128)), dim3(512), 0, (hipStream_t)stream, (const _Float16 *)ws, out,
                      os, BH, heads, L, L, gd.flag, gd.tag);
   return dvis_check_launch("attn_x3_kernel");
+}
+
+// Rows [M, end of M's row tile) of a row image as zeros (every k-tile): what a producer that only writes whole results leaves open.
+__global__ __launch_bounds__(256) void rows_image_tail_kernel(char *__restrict__ img, size_t M, int KT) {
+  const int kt = blockIdx.x, part = threadIdx.x >> 7, row = threadIdx.x & 127;
+  if (row < (int)(M & 127)) return;
+  char *p = img + ((M >> 7) * KT + kt) * 8192 + row * 16;
+  const dvis_f4 z = {0.f, 0.f, 0.f, 0.f};
+  *reinterpret_cast<dvis_f4 *>(p + part * 2048) = z;
+  *reinterpret_cast<dvis_f4 *>(p + 4096 + part * 2048) = z;
+}
+
+// dvis_attention_x3_packed with the output as the row image of the out-projection (dvis_x3_tile_linear_image, weights packed with
+// dvis_x3_tile_pack_order(order 2)): rows (batch entry, token), K = heads * 64, values x 2^xexp; `image` holds
+// dvis_x3_rows_image_bytes(B * L, heads * 64) bytes.
+DVIS_EXPORT int dvis_attention_x3_packed_image(const void *ws, void *image, int B, int heads, int L, int xexp, void *stream) {
+  DVIS_REQUIRE(ws && image && B >= 0 && heads > 0 && L >= 128, "attention_x3_packed_image: bad arguments (L >= 128)");
+  DVIS_REQUIRE(((uintptr_t)ws | (uintptr_t)image) % 16 == 0, "attention_x3_packed_image: workspace and image must be 16-byte aligned");
+  if (B == 0) return DVIS_OK;
+  const int BH = B * heads;
+  const size_t M = (size_t)B * L;
+  const X3Guard gd = dvis_x3_guard();
+  if (M & 127) hipLaunchKernelGGL(rows_image_tail_kernel, dim3(heads * 4), dim3(256), 0, (hipStream_t)stream, (char *)image, M, heads * 4);
+  hipLaunchKernelGGL((attn_x3_kernel<1, true>), dim3(((BH + 7) / 8) * 8 * ((L + 127) / 128)), dim3(512), 0, (hipStream_t)stream, (const _Float16 *)ws,
+                     (float *)nullptr, dvis_strides{0, 0, 0}, BH, heads, L, L, gd.flag, gd.tag, (char *)image, ldexpf(1.f, xexp));
+  return dvis_check_launch("attn_x3_kernel (row image)");
 }
 
 DVIS_EXPORT int dvis_attention_forward_k(const float *q, const int64_t *q_strides, const float *k, const int64_t *k_strides,

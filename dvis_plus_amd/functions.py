@@ -1170,8 +1170,9 @@ def x3_tile_ok(x, N, K):
             and bool(native.lib().dvis_x3_tile_supported(N, K)))
 
 
-def x3_tile_pack(weight):
-    """(packed buffer, wexp) of an (N, K) float32 GPU weight in the tiled kernel's LDS image, made once per weight version."""
+def x3_tile_pack(weight, order=0):
+    """(packed buffer, wexp) of an (N, K) float32 GPU weight in the tiled kernel's LDS image, made once per weight version.
+    order: the k-slot order of the row image the weight meets (RowImage.order; 0 for fp32 rows)."""
     def make():
         w = weight.detach()
         if w.stride(1) != 1:
@@ -1183,15 +1184,83 @@ def x3_tile_pack(weight):
         e = _x3_exp(w)
         buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
         with torch.cuda.device(w.device):
-            native.check(native.lib().dvis_x3_tile_pack(ctypes.c_void_p(w.data_ptr()), w.stride(0), N, K, e,
-                                                        ctypes.c_void_p(buf.data_ptr()), native.stream_ptr(w.device)), "dvis_x3_tile_pack")
+            native.check(native.lib().dvis_x3_tile_pack_order(ctypes.c_void_p(w.data_ptr()), w.stride(0), N, K, e, order,
+                                                              ctypes.c_void_p(buf.data_ptr()), native.stream_ptr(w.device)),
+                         "dvis_x3_tile_pack_order")
         return buf, e
-    return _x3_cache(weight, (weight._version, weight.data_ptr(), weight.device, tuple(weight.shape)), make, kind="tile")
+    return _x3_cache(weight, (weight._version, weight.data_ptr(), weight.device, tuple(weight.shape)), make,
+                     kind="tile" if order == 0 else f"tile order {order}")
+
+
+# Row images (include/dvis_hip.h, "ROW IMAGES"; csrc/gemm_x3_tile.hip): the tiled GEMM's row operand pre-split by its producer.
+# DVIS_X3_ROW_IMAGES=0 (development): the ViT blocks keep fp32 activations between their layers.
+X3_ROW_IMAGES = os.environ.get("DVIS_X3_ROW_IMAGES", "1") != "0"
+
+
+class RowImage:
+    """fp32 rows (..., K) as the row operand image of dvis_x3_tile_linear_image: `data` (uint8, dvis_x3_rows_image_bytes), `shape` of
+    the tensor it stands for, `exp` (values x 2^exp before the split), `order` (k-slot order: the weights are packed to match)."""
+
+    def __init__(self, data, shape, exp, order):
+        self.data, self.shape, self.exp, self.order = data, tuple(shape), exp, order
+
+    @property
+    def device(self):
+        return self.data.device
+
+    @property
+    def rows(self):
+        n = 1
+        for d in self.shape[:-1]:
+            n *= d
+        return n
+
+
+def _rows_image_buffer(M, K, device):
+    nbytes = native.lib().dvis_x3_rows_image_bytes(M, K)
+    if nbytes < 0:
+        raise RuntimeError(f"row image: K % 32 == 0 is required (K {K})")
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def x3_rows_image(x, xexp=None):
+    """fp32 GPU rows (..., K) -> RowImage (order 0): the stand-alone producer."""
+    K = x.shape[-1]
+    x2, ldx = _x3_rows(x, "x")
+    e = X3_XEXP if xexp is None else xexp
+    buf = _rows_image_buffer(x2.shape[0], K, x.device)
+    with torch.cuda.device(x.device):
+        native.check(native.lib().dvis_x3_rows_image(ctypes.c_void_p(x2.data_ptr()), ldx, x2.shape[0], K, e, ctypes.c_void_p(buf.data_ptr()),
+                                                     native.stream_ptr(x.device)), "dvis_x3_rows_image")
+    return RowImage(buf, x.shape, e, 0)
+
+
+def layer_norm_rows_image_ok(x, norm):
+    C = x.shape[-1]
+    return (X3_ROW_IMAGES and x3_on() and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.data_ptr() % 16 == 0
+            and C % 32 == 0 and C <= 1024 and norm.weight is not None and norm.bias is not None and not torch.is_grad_enabled()
+            and not torch.is_autocast_enabled())
+
+
+def layer_norm_rows_image(x, norm, xexp=None):
+    """``norm(x)`` (nn.LayerNorm over the last dim) written as the RowImage (order 0) of the GEMM that reads it — the value every
+    element holds is add_layer_norm's, split into its two f16 terms."""
+    C = x.shape[-1]
+    M = x.numel() // C
+    e = X3_XEXP if xexp is None else xexp
+    buf = _rows_image_buffer(M, C, x.device)
+    with torch.cuda.device(x.device):
+        native.check(native.lib().dvis_layernorm_rows_image(
+            ctypes.c_void_p(x.data_ptr()), native.dev_ptr(norm.weight, "gamma"), native.dev_ptr(norm.bias, "beta"), M, C, float(norm.eps), e,
+            ctypes.c_void_p(buf.data_ptr()), native.stream_ptr(x.device)), "dvis_layernorm_rows_image")
+    return RowImage(buf, x.shape, e, 0)
 
 
 def x3_tile_linear(x, weight, bias, act=None, residual=None, xexp=None):
     """``act(x @ weight.T + bias) + residual`` through dvis_x3_tile_linear (act: None | "relu" | "gelu")."""
     N, K = weight.shape
+    if isinstance(x, RowImage):
+        return _x3_tile_linear_image(x, weight, bias, act, residual)
     x2, ldx = _x3_rows(x, "x")
     buf, wexp = x3_tile_pack(weight)
     out = torch.empty((*x.shape[:-1], N), dtype=torch.float32, device=x.device)
@@ -1210,12 +1279,49 @@ def x3_tile_linear(x, weight, bias, act=None, residual=None, xexp=None):
     return out
 
 
+def _x3_tile_linear_image(img, weight, bias, act, residual):
+    """x3_tile_linear on a RowImage.  act None / "relu": fp32 rows (+ residual); act "gelu": the result as the next GEMM's RowImage."""
+    N, K = weight.shape
+    if img.shape[-1] != K:
+        raise RuntimeError(f"x3_tile_linear: image of {img.shape} rows against a weight of {tuple(weight.shape)}")
+    M = img.rows
+    buf, wexp = x3_tile_pack(weight, img.order)
+    bptr = None if bias is None else native.dev_ptr(bias.detach(), "bias")
+    lib = native.lib()
+    with torch.cuda.device(img.device):
+        if act == "gelu":
+            if residual is not None:
+                raise RuntimeError("x3_tile_linear: the GELU form of a row image writes a row image (no residual)")
+            out = _rows_image_buffer(M, N, img.device)
+            native.check(lib.dvis_x3_tile_linear_image(ctypes.c_void_p(img.data.data_ptr()), M, K, ctypes.c_void_p(buf.data_ptr()), N, img.exp, wexp,
+                                                       bptr, 2, None, 0, None, 0, ctypes.c_void_p(out.data_ptr()), X3_XEXP,
+                                                       native.stream_ptr(img.device)), "dvis_x3_tile_linear_image")
+            return RowImage(out, (*img.shape[:-1], N), X3_XEXP, 1)
+        out = torch.empty((*img.shape[:-1], N), dtype=torch.float32, device=img.device)
+        rptr, ldr = None, 0
+        if residual is not None:
+            if residual.shape != out.shape or residual.dtype != torch.float32 or not residual.is_cuda:
+                raise RuntimeError("x3_tile_linear: residual must be a float32 GPU tensor of the output's shape")
+            r2, ldr = _rows2d(residual, N)
+            rptr = ctypes.c_void_p(r2.data_ptr())
+        native.check(lib.dvis_x3_tile_linear_image(ctypes.c_void_p(img.data.data_ptr()), M, K, ctypes.c_void_p(buf.data_ptr()), N, img.exp, wexp,
+                                                   bptr, {None: 0, "relu": 1}[act], rptr, ldr, ctypes.c_void_p(out.data_ptr()), N, None, 0,
+                                                   native.stream_ptr(img.device)), "dvis_x3_tile_linear_image")
+    return out
+
+
 X3_QKV_FUSED = os.environ.get("DVIS_X3_QKV_FUSED", "1") != "0"
 
 
 def x3_qkv_attention_ok(x, weight, heads):
     """Can ``self_attention(x @ weight.T + bias)`` take the fused form (dvis_x3_tile_linear_qkv + dvis_attention_x3_packed)?
     x (B, L, C) float32 GPU inference tensor, weight (3C, C), head dim 64, L >= 1024 (the ViT blocks)."""
+    if isinstance(x, RowImage):
+        if len(x.shape) != 3 or not (X3_QKV_FUSED and weight.dim() == 2 and weight._base is None):
+            return False
+        B, L, C = x.shape
+        return (C == heads * 64 and weight.shape == (3 * C, C) and L >= 1024 and C >= X3_TILE_MIN_K
+                and bool(native.lib().dvis_x3_tile_supported(3 * C, C)))
     if not (X3_QKV_FUSED and x.dim() == 3 and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
             and not torch.is_autocast_enabled() and x3_on() and weight.dim() == 2 and weight._base is None):
         return False
@@ -1224,22 +1330,34 @@ def x3_qkv_attention_ok(x, weight, heads):
             and x3_tile_ok(x, 3 * C, C))
 
 
-def x3_qkv_attention(x, weight, bias, heads):
+def x3_qkv_attention(x, weight, bias, heads, out_image=False):
     """softmax(q k^T / 8) v per head for qkv = x @ weight.T + bias (columns ordered q | k | v, head, dim), x (B, L, C), head dim 64:
     the projection's epilogue writes the split-f16 attention kernel's operand images, the attention kernel reads them — the fp32
-    qkv tensor and the pack pass do not exist.  -> (B, L, C)."""
+    qkv tensor and the pack pass do not exist.  x: fp32 tensor or RowImage.  -> (B, L, C) fp32, or with out_image its RowImage
+    (order 2: the out-projection's row operand)."""
     B, L, C = x.shape
-    buf, wexp = x3_tile_pack(weight)
+    image_in = isinstance(x, RowImage)
+    buf, wexp = x3_tile_pack(weight, x.order if image_in else 0)
     lib = native.lib()
     nbytes = lib.dvis_attention_ws_bytes_k(B * heads, L, L, 64, 2)
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
-    out = torch.empty((B, L, C), dtype=torch.float32, device=x.device)
     qscale = (1.0 / 8.0) * 1.4426950408889634 * 16.0
+    bptr = None if bias is None else native.dev_ptr(bias.detach(), "bias")
     with torch.cuda.device(x.device):
-        native.check(lib.dvis_x3_tile_linear_qkv(
-            ctypes.c_void_p(x.data_ptr()), C, B * L, C, ctypes.c_void_p(buf.data_ptr()), 3 * C, X3_XEXP, wexp,
-            None if bias is None else native.dev_ptr(bias.detach(), "bias"), heads, L, qscale, ctypes.c_void_p(ws.data_ptr()),
-            native.stream_ptr(x.device)), "dvis_x3_tile_linear_qkv")
+        if image_in:
+            native.check(lib.dvis_x3_tile_linear_qkv_image(
+                ctypes.c_void_p(x.data.data_ptr()), B * L, C, ctypes.c_void_p(buf.data_ptr()), 3 * C, x.exp, wexp, bptr, heads, L, qscale,
+                ctypes.c_void_p(ws.data_ptr()), native.stream_ptr(x.device)), "dvis_x3_tile_linear_qkv_image")
+        else:
+            native.check(lib.dvis_x3_tile_linear_qkv(
+                ctypes.c_void_p(x.data_ptr()), C, B * L, C, ctypes.c_void_p(buf.data_ptr()), 3 * C, X3_XEXP, wexp, bptr, heads, L, qscale,
+                ctypes.c_void_p(ws.data_ptr()), native.stream_ptr(x.device)), "dvis_x3_tile_linear_qkv")
+        if out_image:
+            out = _rows_image_buffer(B * L, C, x.device)
+            native.check(lib.dvis_attention_x3_packed_image(ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(out.data_ptr()), B, heads, L, X3_XEXP,
+                                                            native.stream_ptr(x.device)), "dvis_attention_x3_packed_image")
+            return RowImage(out, (B, L, C), X3_XEXP, 2)
+        out = torch.empty((B, L, C), dtype=torch.float32, device=x.device)
         strides = (ctypes.c_int64 * 3)(L * C, 64, C)
         native.check(lib.dvis_attention_x3_packed(ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(out.data_ptr()), strides, B, heads, L,
                                                   native.stream_ptr(x.device)), "dvis_attention_x3_packed")

@@ -97,6 +97,13 @@ SIGNATURES = {
     "dvis_x3_tile_pack": (_i, [_p, _i64, _i, _i, _i, _p, _p]),
     "dvis_x3_tile_linear_qkv": (_i, [_p, _i64, _i64, _i, _p, _i, _i, _i, _p, _i, _i, _f, _p, _p]),
     "dvis_attention_x3_packed": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "dvis_x3_rows_image_bytes": (_i64, [_i64, _i]),
+    "dvis_x3_rows_image": (_i, [_p, _i64, _i64, _i, _i, _p, _p]),
+    "dvis_layernorm_rows_image": (_i, [_p, _p, _p, _i64, _i, _f, _i, _p, _p]),
+    "dvis_x3_tile_pack_order": (_i, [_p, _i64, _i, _i, _i, _i, _p, _p]),
+    "dvis_x3_tile_linear_image": (_i, [_p, _i64, _i, _p, _i, _i, _i, _p, _i, _p, _i64, _p, _i64, _p, _i, _p]),
+    "dvis_x3_tile_linear_qkv_image": (_i, [_p, _i64, _i, _p, _i, _i, _i, _p, _i, _i, _f, _p, _p]),
+    "dvis_attention_x3_packed_image": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "dvis_x3_tile_linear": (_i, [_p, _i64, _i64, _i, _p, _i, _i, _i, _p, _i, _p, _i64, _p, _i64, _p]),
     "dvis_x3_linear_res": (_i, [_p, _i64, _i64, _i, _p, _i, _i, _i, _p, _i, _p, _i64, _p, _i64, _p]),
     "dvis_x3_linear_add": (_i, [_p, _i64, _i64, _i, _p, _i, _i, _i, _p, _i64, _p, _i, _p, _i64, _p]),

@@ -141,7 +141,26 @@ class Block(nn.Module):
         self.ls2 = LayerScale(dim, init_values=init_values) if init_values else nn.Identity()
         self._f1, self._f2 = _Folded(), _Folded()
 
+    def row_images_ok(self, x):
+        """norm -> GEMM -> ... with row images between the layers (functions.RowImage): every normalisation / GELU / attention output
+        is written once, pre-split, as the next GEMM's row operand."""
+        if x.dim() != 3 or not (Fn.layer_norm_rows_image_ok(x, self.norm1) and self.norm2.weight is not None and self.norm2.bias is not None):
+            return False
+        B, L, C = x.shape
+        a, m = self.attn, self.mlp
+        H = m.fc1.weight.shape[0]
+        return (C >= Fn.X3_TILE_MIN_K and C % 256 == 0 and H % 256 == 0 and m.fc2.weight.shape == (C, H) and a.proj.weight.shape == (C, C)
+                and m.fc1.bias is not None and Fn.x3_qkv_attention_ok(Fn.RowImage(None, x.shape, 0, 0), a.qkv.weight, a.num_heads))
+
     def forward(self, x):
+        if self.row_images_ok(x):
+            a, m = self.attn, self.mlp
+            h = Fn.x3_qkv_attention(Fn.layer_norm_rows_image(x, self.norm1), a.qkv.weight, a.qkv.bias, a.num_heads, out_image=True)
+            w, b = self._f1.get(a.proj, self.ls1)
+            x = Fn.x3_tile_linear(h, w, b, residual=x)
+            h = Fn.x3_tile_linear(Fn.layer_norm_rows_image(x, self.norm2), m.fc1.weight, m.fc1.bias, act="gelu")
+            w, b = self._f2.get(m.fc2, self.ls2)
+            return Fn.x3_tile_linear(h, w, b, residual=x)
         w, b = self._f1.get(self.attn.proj, self.ls1)
         x = Fn.linear(self.attn.core(Fn.add_layer_norm(x, None, self.norm1)), w, b, tall=True, residual=x)
         w, b = self._f2.get(self.mlp.fc2, self.ls2)

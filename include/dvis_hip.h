@@ -595,6 +595,29 @@ int dvis_x3_tile_linear(const float *x, int64_t ldx, int64_t M, int K, const voi
 int dvis_x3_tile_linear_qkv(const float *x, int64_t ldx, int64_t M, int K, const void *wp, int N, int xexp, int wexp, const float *bias,
                             int heads, int L, float qscale, void *ws, void *stream);
 int dvis_attention_x3_packed(const void *ws, float *out, const int64_t *o_strides, int B, int heads, int L, void *stream);
+/*
+ * ROW IMAGES (round 6): the row operand of the tiled GEMM pre-split by its PRODUCER — [row tile of 128][k-tile of 16][hi, lo][chunk of
+ * 8 k][128 rows][8 halves], values x 2^xexp, dvis_x3_rows_image_bytes(M, K) bytes (the fp32 tensor's size, rows padded to 128) — so
+ * that both operands of the ViT blocks' GEMMs (block.py:36-104: norm1 -> qkv -> attention -> proj, norm2 -> fc1 -> GELU -> fc2) are
+ * LDS-DMA streams and no fp32 activation is written between a normalisation / activation / attention and the GEMM behind it.
+ *   producers: dvis_x3_rows_image (fp32 rows; k order 0), dvis_layernorm_rows_image (LayerNorm of fp32 rows, C <= 1024; order 0),
+ *              dvis_x3_tile_linear_image with act = 2 (GELU; order 1), dvis_attention_x3_packed_image (order 2);
+ *   consumers: dvis_x3_tile_linear_image (act 0 / 1: fp32 rows out, + residual), dvis_x3_tile_linear_qkv_image; their weights
+ *              packed with dvis_x3_tile_pack_order(order of the image's producer): the k slots of a k-tile are a free permutation
+ *              as long as both operands use the same one.
+ * Rows past M of the last row tile are written as zeros by every producer.  Results per row as dvis_x3_tile_linear (the same three
+ * products per k-tile, fp32 accumulate; orders 1 / 2 add the k-tile's terms in another order).
+ */
+int64_t dvis_x3_rows_image_bytes(int64_t M, int K);
+int dvis_x3_rows_image(const float *x, int64_t ldx, int64_t M, int K, int xexp, void *image, void *stream);
+int dvis_layernorm_rows_image(const float *x, const float *gamma, const float *beta, int64_t M, int C, float eps, int xexp, void *image,
+                              void *stream);
+int dvis_x3_tile_pack_order(const float *w, int64_t ldw, int N, int K, int wexp, int order, void *packed, void *stream);
+int dvis_x3_tile_linear_image(const void *ximg, int64_t M, int K, const void *wp, int N, int xexp, int wexp, const float *bias, int act,
+                              const float *res, int64_t ldres, float *out, int64_t ldo, void *oimg, int oexp, void *stream);
+int dvis_x3_tile_linear_qkv_image(const void *ximg, int64_t M, int K, const void *wp, int N, int xexp, int wexp, const float *bias, int heads,
+                                  int L, float qscale, void *ws, void *stream);
+int dvis_attention_x3_packed_image(const void *ws, void *image, int B, int heads, int L, int xexp, void *stream);
 /* out = LayerNorm( x W^T + bias + res ) over the N = 256 features (gamma, beta, eps; two-pass statistics as torch);
  * pos (pos_rows x N, optional): out2[t] = out[t] + pos[t mod pos_rows] (the next layer's `with_pos_embed(src, pos)`,
  * msdeformattn.py:99-101,122).  Replaces output_proj + `src = norm1(src + dropout1(src2))`, msdeformattn.py:124-125. */
