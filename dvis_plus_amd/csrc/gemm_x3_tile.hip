@@ -24,6 +24,10 @@
 #include "dvis_common.h"
 #include "x3_common.h"
 
+#ifndef DVIS_TILE_ABLATION
+#define DVIS_TILE_ABLATION 0      // development (timing only, results garbage): 1 no DMA after the prologue, 2 no fragment reads, 4 no barrier
+#endif
+
 #include <stdlib.h>
 #include <type_traits>
 
@@ -306,7 +310,13 @@ __global__ __launch_bounds__(256, 2) void x3_tile_img_kernel(TileArgs a) {
   if (mt >= a.tm) return;
   const int64_t m0 = (int64_t)mt * k2TM;
   const int KT = a.K / k2TK;
+#if DVIS_TILE_ABLATION & 8
+  const x3_u4 rsa = x3_stream_rsrc(a.ximg), rsb = x3_stream_rsrc(a.wp);        // every workgroup streams the same (cache-resident) bytes
+#elif DVIS_TILE_ABLATION & 16
+  const x3_u4 rsa = x3_stream_rsrc(a.ximg + (size_t)mt * KT * kRowTile), rsb = x3_stream_rsrc(a.wp);      // ... the same weights only
+#else
   const x3_u4 rsa = x3_stream_rsrc(a.ximg + (size_t)mt * KT * kRowTile), rsb = x3_stream_rsrc(a.wp + (size_t)nt * KT * 16384);
+#endif
   const unsigned lane16 = lane * 16, lds0 = lds_address(lds);
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   // a k-tile = 8 row pieces + 16 weight pieces of 1 KB: 2 + 4 per wave
@@ -358,11 +368,15 @@ __global__ __launch_bounds__(256, 2) void x3_tile_img_kernel(TileArgs a) {
   load_b(lds, 0, 0);
   int st = 0;                                       // stage of k-tile kt
   for (int kt = 0; kt < KT; ++kt) {
+#if !(DVIS_TILE_ABLATION & 1)
     if (kt + 2 < KT) dma(kt + 2, st == 0 ? 2 : st - 1);       // (the stage k-tile kt - 1 was read from: released by the last barrier)
+#endif
     const char *s = lds + st * k2Stage;
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
+#if !(DVIS_TILE_ABLATION & 2)
       if (nb + 1 < 4) load_b(s, nb + 1, (nb + 1) & 1);
+#endif
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (MODE == 2) {
         acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nb & 1], al[0], acc[0][nb], 0, 0, 0);
@@ -385,14 +399,21 @@ __global__ __launch_bounds__(256, 2) void x3_tile_img_kernel(TileArgs a) {
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // k-tile kt + 1 landed; k-tile kt + 2's six pieces stay in flight
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if !(DVIS_TILE_ABLATION & 4)
     __syncthreads();
+#endif
     st = st == 2 ? 0 : st + 1;
+#if !(DVIS_TILE_ABLATION & 2)
     if (kt + 1 < KT) {
       const char *sn = lds + st * k2Stage;
       load_a(sn);
       load_b(sn, 0, 0);
     }
+#endif
   }
+#if DVIS_TILE_ABLATION
+  a.flag = nullptr;
+#endif
 
   if constexpr (MODE == 1) {
     tile_store_qkv(a, acc, nt, wm, wn, r, g, m0);
