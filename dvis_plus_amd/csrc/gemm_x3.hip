@@ -26,8 +26,11 @@
 // Three kernels, all persistent (one workgroup per CU, dvis_x3_set_reserve CUs left out):
 //   x3_linear_stream_kernel  projections (+ residual + LayerNorm (+ pos)): 8 waves = two per SIMD at <= 256 registers, the
 //                            activations streamed in chunks of 64 k with the next chunk in flight; any K % 64 == 0;
-//   x3_linear_kernel         the 288-column projection (9 blocks do not divide among 8 waves): 4 waves, the row's fragments
-//                            resident (K = 256: 128 registers per lane);
+//                            the 288-column offsets | logits projection with the position embedding added while the fragments
+//                            are built (9 blocks: the item image carries a tenth, zero, block so that its pieces divide among
+//                            the 8 waves; round 6: 453 -> 383 us per 30-frame layer against the resident-fragment kernel);
+//   x3_linear_kernel         the other `x + embedding` projections (N = 128 / 192 / 256 at K = 256): 4 waves, the row's
+//                            fragments resident (128 registers per lane);
 //   x3_ffn_kernel            linear1 + ReLU + linear2 + residual + LayerNorm: 4 waves at 512 registers (fragments of the row
 //                            128, accumulators 128 + 64, hidden fragments 64).
 // The ring's LDS-DMA requests in the MUBUF encoding (x3_common.h: dma16): hipcc's own waits stay counted instead of full drains
@@ -257,12 +260,19 @@ __global__ __launch_bounds__(kThreads) void x3_linear_kernel(const float *__rest
 // LDS-DMA issue and epilogue are covered by its partner's products) x 32 tokens; the 64 k-values of the chunk after the one
 // being multiplied are in flight (8 x 16 bytes per lane; the ring's counted wait leaves them out), so neither operand waits
 // behind the other and K is any multiple of 64.  Passes of 32 NB output features re-read the tile's rows from L2.
-template <int NB, bool LN, bool EX = false>
+// NB = 9 (the 288-column offsets | logits projection): the item LAYOUT has ten blocks per k-step (40 pieces = 5 per wave; the tenth
+// block is zero weights, never multiplied), the products run over nine.
+// ADD: x + xadd[row mod xadd_rows] is formed while the fragments are built (`with_pos_embed(src, pos)` of the encoder layers); the
+// rows and the embedding's rows are then fetched 32 k at a time (4 + 4 loads in flight: the same eight as the plain form's chunk).
+constexpr int x3_stream_layout_blocks(int nb) { return 4 * nb % 8 == 0 ? nb : nb + 1; }
+
+template <int NB, bool LN, bool EX = false, bool ADD = false>
 __global__ __launch_bounds__(512) void x3_linear_stream_kernel(const float *__restrict__ x, int64_t ldx, int64_t M, int K,
-                                                               const void *__restrict__ wp, float xscale, int npass, EpiArgs e) {
+                                                               const void *__restrict__ wp, float xscale, int npass,
+                                                               const float *__restrict__ xadd, int64_t xadd_rows, EpiArgs e) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
-  constexpr int NW = 8, PW = 4 * NB / NW, kTile = NW * 32;
-  static_assert(4 * NB % NW == 0, "the item's pieces must divide among the waves");
+  constexpr int NBL = x3_stream_layout_blocks(NB);
+  constexpr int NW = 8, PW = 4 * NBL / NW, kTile = NW * 32;
   typedef Ring<PW, 8, NW> RingT;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
   const int NI = K / 32, NC = K / 64;
@@ -278,15 +288,70 @@ __global__ __launch_bounds__(512) void x3_linear_stream_kernel(const float *__re
   if constexpr (LN)
     for (int i = threadIdx.x; i < 32 * NB; i += 512) cst[ntot + i] = e.gamma[i], cst[ntot + 32 * NB + i] = e.beta[i];
   __syncthreads();
+  // one item (2 k-steps) of products
+  auto products = [&](const char *stage, f16v *acc, const h8 *xh, const h8 *xl) {
+    if constexpr (NBL == NB) {
+      mma_item<2, NB, PW>(stage, lane, acc, xh, xl, [&](int i) { ring.piece(i); });
+    } else {
+      mma_item<1, NB, 3>(stage, lane, acc, xh, xl, [&](int i) { ring.piece(i); });
+      mma_item<1, NB, PW - 3>(stage + NBL * 2 * kPiece, lane, acc, xh + 1, xl + 1, [&](int i) { ring.piece(3 + i); });
+    }
+  };
+  auto row_of = [&](int64_t tile) {
+    const int64_t t = tile * kTile + wave * 32 + j;
+    return t < M ? t : M - 1;
+  };
+  if constexpr (ADD) {
+    f4 raw[4], rawp[4];
+    auto load_raw = [&](const float *rowp, const float *posp, int it) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        raw[2 * s] = *(const f4 *)(rowp + 32 * it + 16 * s), raw[2 * s + 1] = *(const f4 *)(rowp + 32 * it + 16 * s + 4);
+        rawp[2 * s] = *(const f4 *)(posp + 32 * it + 16 * s), rawp[2 * s + 1] = *(const f4 *)(posp + 32 * it + 16 * s + 4);
+      }
+    };
+    int64_t r0 = row_of(blockIdx.x);
+    const float *rowp = x + r0 * ldx + 8 * g, *posp = xadd + (r0 % xadd_rows) * K + 8 * g;
+    load_raw(rowp, posp, 0);
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      const int64_t tok0 = tile * kTile + wave * 32;
+      const int64_t rn = row_of(tile + gridDim.x < ntiles ? tile + gridDim.x : tile);
+      const float *nrowp = x + rn * ldx + 8 * g, *nposp = xadd + (rn % xadd_rows) * K + 8 * g;
+      for (int pass = 0; pass < npass; ++pass) {
+        f16v acc[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+        for (int it = 0; it < NI; ++it) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(raw[i]), "+v"(rawp[i]));
+          h8 xh[2], xl[2];
+#pragma unroll
+          for (int s = 0; s < 2; ++s) split8(raw[2 * s] + rawp[2 * s], raw[2 * s + 1] + rawp[2 * s + 1], xscale, xh[s], xl[s]);
+          // ALWAYS 8 loads here: the next item's rows, the next pass's first, the next tile's first
+          if (it + 1 < NI)
+            load_raw(rowp, posp, it + 1);
+          else if (pass + 1 < npass)
+            load_raw(rowp, posp, 0);
+          else
+            load_raw(nrowp, nposp, 0);
+          const char *stage = ring.wait(false);
+          ring.begin_periodic();
+          products(stage, acc, xh, xl);
+        }
+        if (tok0 < M) epilogue<NB, LN, EX>(acc, e, cst + pass * 32 * NB, cst + ntot, cst + ntot + 32 * NB, scr, lane, tok0, M, pass * 32 * NB);
+      }
+      rowp = nrowp, posp = nposp;
+    }
+    return;
+  }
   f4 raw[8];
   auto load_raw = [&](const float *rowp, int kc) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) raw[2 * s] = *(const f4 *)(rowp + 64 * kc + 16 * s), raw[2 * s + 1] = *(const f4 *)(rowp + 64 * kc + 16 * s + 4);
   };
-  auto row_ptr = [&](int64_t tile) {
-    const int64_t t = tile * kTile + wave * 32 + j;
-    return x + (t < M ? t : M - 1) * ldx + 8 * g;
-  };
+  auto row_ptr = [&](int64_t tile) { return x + row_of(tile) * ldx + 8 * g; };
   const float *rowp = row_ptr(blockIdx.x);
   load_raw(rowp, 0);
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -314,7 +379,7 @@ __global__ __launch_bounds__(512) void x3_linear_stream_kernel(const float *__re
         for (int half = 0; half < 2; ++half) {
           const char *stage = ring.wait(false);
           ring.begin_periodic();
-          mma_item<2, NB, PW>(stage, lane, acc, xh + 2 * half, xl + 2 * half, [&](int i) { ring.piece(i); });
+          products(stage, acc, xh + 2 * half, xl + 2 * half);
         }
       }
       if (tok0 < M) epilogue<NB, LN, EX>(acc, e, cst + pass * 32 * NB, cst + ntot, cst + ntot + 32 * NB, scr, lane, tok0, M, pass * 32 * NB);
@@ -519,13 +584,15 @@ DVIS_EXPORT int dvis_x3_linear_supported(int N, int K, int ln) {
   int nb;
   if (K < 64 || K % 64 != 0 || K > 8192) return 0;
   if (ln) return N == 256;
-  if (N == 288) return K == 256;            // (9 blocks of 32 do not divide among the streaming kernel's 8 waves)
+  if (N == 288) return K == 256;            // (the offsets | logits projection of the 3-level encoder)
   return x3_passes(N, &nb) > 0;
 }
 
 DVIS_EXPORT int64_t dvis_x3_packed_bytes(int N, int K) {
   if (!dvis_x3_linear_supported(N, K, 0)) return -1;
-  return (int64_t)(K / 16) * (N / 32) * 2 * kPiece;
+  int NB;
+  const int npass = x3_passes(N, &NB);
+  return (int64_t)(K / 16) * npass * x3_stream_layout_blocks(NB) * 2 * kPiece;
 }
 
 DVIS_EXPORT int dvis_x3_pack(const float *w, int64_t ldw, int N, int K, int wexp, void *packed, void *stream) {
@@ -533,10 +600,11 @@ DVIS_EXPORT int dvis_x3_pack(const float *w, int64_t ldw, int N, int K, int wexp
   DVIS_REQUIRE(dvis_x3_linear_supported(N, K, 0), "dvis_x3_pack: (N, K) = (%d, %d) is not served (K %% 64 == 0; N in 128 / 192 / 256 or N %% 256 == 0; N = 288 at K = 256)", N, K);
   DVIS_REQUIRE(wexp >= -60 && wexp <= 60, "dvis_x3_pack: wexp = %d", wexp);
   int NB;
-  x3_passes(N, &NB);
-  const int64_t fragments = (int64_t)(K / 16) * (N / 32) * 64;
+  const int npass = x3_passes(N, &NB);
+  const int NBL = x3_stream_layout_blocks(NB);       // (N = 288: ten blocks per k-step in the image, the tenth zero)
+  const int64_t fragments = (int64_t)(K / 16) * npass * NBL * 64;
   hipLaunchKernelGGL(x3_pack_kernel, dim3((unsigned)((fragments + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, ldw, N, K,
-                     NB, 0, x3_pow2(wexp), (_Float16 *)packed, fragments);
+                     NBL, 0, x3_pow2(wexp), (_Float16 *)packed, fragments);
   return dvis_check_launch("dvis_x3_pack");
 }
 
@@ -581,18 +649,19 @@ static int x3_linear_impl(const float *x, int64_t ldx, int64_t M, int K, const v
   hipStream_t st = (hipStream_t)stream;
   int NB;
   const int npass = x3_passes(N, &NB);
-#define DVIS_X3_STREAM_EX(NBV, LNV, EXV, WHAT, LDS_EXTRA)                                                            \
+#define DVIS_X3_STREAM_FORM(NBV, LNV, EXV, ADDV, XADD, XROWS, WHAT, LDS_EXTRA)                                        \
   {                                                                                                                  \
     static DvisLdsOptIn opted;                                                                                       \
-    typedef Ring<4 * NBV / 8, 8, 8> R;                                                                               \
+    typedef Ring<4 * x3_stream_layout_blocks(NBV) / 8, 8, 8> R;                                                      \
     const size_t lds_bytes = kStages * R::kItemBytes + 8 * kScratch + (LDS_EXTRA);                                   \
-    const int rc2 = dvis_lds_opt_in((const void *)x3_linear_stream_kernel<NBV, LNV, EXV>, lds_bytes, &opted, WHAT);  \
+    const int rc2 = dvis_lds_opt_in((const void *)x3_linear_stream_kernel<NBV, LNV, EXV, ADDV>, lds_bytes, &opted, WHAT);  \
     if (rc2 != DVIS_OK) return rc2;                                                                                  \
     const int64_t ntiles = (M + 255) / 256;                                                                          \
-    hipLaunchKernelGGL((x3_linear_stream_kernel<NBV, LNV, EXV>), dim3(x3_grid(ntiles)), dim3(512), lds_bytes, st, x, ldx, M, K, wp, \
-                       xs, npass, e);                                                                                \
+    hipLaunchKernelGGL((x3_linear_stream_kernel<NBV, LNV, EXV, ADDV>), dim3(x3_grid(ntiles)), dim3(512), lds_bytes, st, x, ldx, M, K, wp, \
+                       xs, npass, XADD, XROWS, e);                                                                   \
     return dvis_check_launch(WHAT);                                                                                  \
   }
+#define DVIS_X3_STREAM_EX(NBV, LNV, EXV, WHAT, LDS_EXTRA) DVIS_X3_STREAM_FORM(NBV, LNV, EXV, false, (const float *)nullptr, (int64_t)0, WHAT, LDS_EXTRA)
 #define DVIS_X3_STREAM(NBV, LNV, WHAT, LDS_EXTRA) DVIS_X3_STREAM_EX(NBV, LNV, false, WHAT, LDS_EXTRA)
 #define DVIS_X3_RESIDENT(NBV)                                                                                        \
   {                                                                                                                  \
@@ -604,19 +673,19 @@ static int x3_linear_impl(const float *x, int64_t ldx, int64_t M, int K, const v
     DVIS_REQUIRE(NB == 8 && !xadd, "dvis_x3_linear_res: the GELU / residual epilogue is served for N %% 256 == 0 (N = %d)", N);
     DVIS_X3_STREAM_EX(8, false, true, "dvis_x3_linear_res", (size_t)N * 4)
   }
-  if (xadd) {      // the resident-fragment kernel adds the embedding while it builds the row's fragments (K = 256)
+  if (xadd) {      // the embedding is added while the row's fragments are built (K = 256)
     switch (NB) {
       case 4: DVIS_X3_RESIDENT(4)
       case 6: DVIS_X3_RESIDENT(6)
       case 8: DVIS_X3_RESIDENT(8)
-      default: DVIS_X3_RESIDENT(9)
+      default: DVIS_X3_STREAM_FORM(9, false, false, true, xadd, xadd_rows, "dvis_x3_linear_add", (size_t)N * 4)
     }
   }
   switch (NB) {
     case 4: DVIS_X3_STREAM(4, false, "dvis_x3_linear", (size_t)N * 4)
     case 6: DVIS_X3_STREAM(6, false, "dvis_x3_linear", (size_t)N * 4)
     case 8: DVIS_X3_STREAM(8, false, "dvis_x3_linear", (size_t)N * 4)
-    default: DVIS_X3_RESIDENT(9)
+    default: DVIS_X3_STREAM(9, false, "dvis_x3_linear", (size_t)N * 4)
   }
 #undef DVIS_X3_RESIDENT
 }
@@ -644,6 +713,7 @@ DVIS_EXPORT int dvis_x3_linear_ln(const float *x, int64_t ldx, int64_t M, int K,
   DVIS_X3_STREAM(8, true, "dvis_x3_linear_ln", (size_t)3 * 256 * 4)
 #undef DVIS_X3_STREAM
 #undef DVIS_X3_STREAM_EX
+#undef DVIS_X3_STREAM_FORM
 }
 
 DVIS_EXPORT int64_t dvis_x3_ffn_packed_bytes(int K, int H, int N) {
