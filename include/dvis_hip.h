@@ -530,7 +530,8 @@ int dvis_gemm_ln_pick_config(int M, int N, int K);
  * split; |v 2^e| must stay below 65504 (f16 range; values beyond saturate to +-inf in the hi term).
  *
  * dvis_x3_pack: W (N x K, row stride ldw) -> `packed` (dvis_x3_packed_bytes(N, K) bytes), the kernels' LDS image (1 KB
- * fragments [pass][k-step][row block][hi, lo][lane][8 halves]).  Once per weight.
+ * fragments [pass][k-step][row block][hi, lo][lane][8 halves]; N = 288: ten row blocks per k-step, the tenth zero, so that an item's
+ * pieces divide among the streaming kernel's 8 waves — dvis_x3_packed_bytes(288, K) = 320 K 4).  Once per weight.
  */
 int64_t dvis_x3_packed_bytes(int N, int K);
 /* The dvis_x3_* / dvis_conv*_x3 kernels are persistent (one workgroup per CU for the length of the launch).  A host that runs a

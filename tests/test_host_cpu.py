@@ -115,7 +115,8 @@ def test_x3_shape_tables():
     for N, K, ok in ((256, 256, 1), (288, 256, 1), (288, 512, 0), (768, 256, 1), (128, 64, 1), (192, 1024, 1), (3072, 1024, 1),
                      (100, 256, 0), (256, 100, 0), (320, 256, 0)):
         assert lib.dvis_x3_linear_supported(N, K, 0) == ok, (N, K)
-        assert (lib.dvis_x3_packed_bytes(N, K) == N * K * 4) == bool(ok)          # hi + lo halves: 4 bytes per weight
+        # hi + lo halves: 4 bytes per weight (N = 288: the item image carries a tenth, zero, block of 32 — csrc/gemm_x3.hip)
+        assert (lib.dvis_x3_packed_bytes(N, K) == (320 if N == 288 else N) * K * 4) == bool(ok)
     assert lib.dvis_x3_linear_supported(256, 256, 1) == 1 and lib.dvis_x3_linear_supported(512, 256, 1) == 0
     assert lib.dvis_x3_ffn_packed_bytes(256, 1024, 256) == 2 * 256 * 1024 * 4 and lib.dvis_x3_ffn_packed_bytes(256, 1000, 256) < 0
     for C, K, ok in ((512, 128, 1), (64, 64, 1), (2048, 512, 1), (96, 128, 0), (256, 100, 0)):
@@ -123,6 +124,9 @@ def test_x3_shape_tables():
         assert (lib.dvis_conv3x3_x3_packed_bytes(C, K) == 9 * C * K * 4) == bool(ok)
     assert lib.dvis_conv1x1_x3_supported(256, 256, 30, 58880, 58880) == 1       # 1.81 GB: below the 2 GiB of 32-bit buffer offsets
     assert lib.dvis_conv1x1_x3_supported(256, 256, 64, 58880, 58880) == 0       # T = 64 in one call: served by the fp32 kernels
+    # row images of the tiled GEMM: the fp32 tensor's size with the rows padded to the row tile of 128
+    assert lib.dvis_x3_rows_image_bytes(110430, 1024) == 863 * 128 * 1024 * 4 and lib.dvis_x3_rows_image_bytes(128, 512) == 128 * 512 * 4
+    assert lib.dvis_x3_rows_image_bytes(0, 1024) == 0 and lib.dvis_x3_rows_image_bytes(100, 1000) < 0
 
 
 def test_every_1x1_layer_of_the_r50_at_the_benchmark_shape_is_served_by_the_split_f16_kernel():
