@@ -277,7 +277,10 @@ class ConvFFN(nn.Module):
         self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
 
     def forward(self, x, H, W, residual=None):
-        x = Fn.linear(x, self.fc1.weight, self.fc1.bias, tall=True)
+        if isinstance(x, Fn.RowImage):          # (the normalisation in front wrote fc1's row operand: Extractor.forward)
+            x = Fn.x3_tile_linear(x, self.fc1.weight, self.fc1.bias)
+        else:
+            x = Fn.linear(x, self.fc1.weight, self.fc1.bias, tall=True)
         if self.dwconv.fused_ok(x, H, W):
             # depthwise 3x3 + bias + GELU on the token tensor itself, level by level (no NCHW round trip, no concatenation)
             x = Fn.dwconv3x3_tokens(x, self.dwconv.levels(x.shape[1], H, W), self.dwconv.dwconv.weight, self.dwconv.dwconv.bias, gelu=True)
@@ -301,7 +304,13 @@ class Extractor(nn.Module):
                           Fn.add_layer_norm(feat, None, self.feat_norm), spatial_shapes, level_start_index, None,
                           post=(query, None))                      # query + attn: the add in the output projection's epilogue
         if self.with_cffn:
-            query = self.ffn(Fn.add_layer_norm(query, None, self.ffn_norm), H, W, residual=query)
+            fc1 = self.ffn.fc1
+            if (Fn.layer_norm_rows_image_ok(query, self.ffn_norm) and fc1.weight.shape[1] >= Fn.X3_TILE_MIN_K and fc1.weight._base is None
+                    and bool(Fn.native.lib().dvis_x3_tile_supported(fc1.weight.shape[0], fc1.weight.shape[1]))):
+                normed = Fn.layer_norm_rows_image(query, self.ffn_norm)
+            else:
+                normed = Fn.add_layer_norm(query, None, self.ffn_norm)
+            query = self.ffn(normed, H, W, residual=query)
         return query
 
 
